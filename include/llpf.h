@@ -1,0 +1,220 @@
+/* llpf.h — C ABI of libllpf_hip.so, the MI355X (gfx950) engine behind the particle-filter hot path
+ * of LowLevelParticleFilters.jl (predict! / correct! / update! / resample / logsumexp! /
+ * forward_trajectory / loglik).
+ *
+ * The reference has no FFI: the "plugin interface" of this path is Julia multiple dispatch on
+ * AbstractParticleFilter (reference src/PFtypes.jl:2).  Each entry point below names the
+ * reference method it replaces (file:line under the reference root); INTEGRATION.md shows the
+ * `ccall` a maintainer adds on the Julia side, and lowlevelparticlefilters.jl_amd/_capi.py
+ * is the identical binding in ctypes (the one the tests drive, since Julia is not in this image).
+ *
+ * Conventions
+ *   - every function returns an int status (LLPF_OK == 0); no C++ exception crosses the ABI;
+ *     llpf_last_error() returns a thread-local message for the last non-zero status.
+ *   - all host pointers are borrowed for the duration of the call only.
+ *   - the library owns all device memory behind the opaque handle; one handle = one device +
+ *     one HIP stream; a handle is not re-entrant, distinct handles may be driven from
+ *     distinct host threads.
+ *   - particles cross the boundary in the reference's layout: N contiguous nx-vectors
+ *     (Vector{SVector{nx,Float64}}, reference src/PFtypes.jl:9-10); on the device they live
+ *     structure-of-arrays.
+ *   - ancestor indices are 0-based int64 at this boundary (the Julia wrapper adds 1).
+ *   - user callables (dynamics / measurement / measurement_likelihood, reference
+ *     src/PFtypes.jl:59-63,189-193) cannot run on the GPU; they are replaced by a model
+ *     descriptor: a built-in model id plus its parameters.
+ */
+#ifndef LLPF_H
+#define LLPF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LLPF_VERSION_MAJOR 0
+#define LLPF_VERSION_MINOR 1
+#define LLPF_MAX_DIM 8
+
+/* status codes */
+enum {
+    LLPF_OK             = 0,
+    LLPF_ERR_ARG        = 1,   /* invalid argument / unsupported configuration           */
+    LLPF_ERR_HIP        = 2,   /* HIP runtime error (message has the hipError string)    */
+    LLPF_ERR_NO_DEVICE  = 3,   /* no gfx950 device visible: the engine has NO CPU fallback */
+    LLPF_ERR_DEGENERATE = 4,   /* all weights -Inf or NaN (the reference would return NaN) */
+    LLPF_ERR_ALLOC      = 5
+};
+
+/* covariance storage kinds — mirror PDMats ScalMat / PDiagMat / PDMat, whose quadratic
+ * forms differ in operation order (reference src/utils.jl:110-113) */
+enum { LLPF_COV_SCAL = 0, LLPF_COV_DIAG = 1, LLPF_COV_FULL = 2 };
+
+/* Gaussian density N(mu, Sigma): replaces Distributions.MvNormal / SimpleMvNormal
+ * (reference src/utils.jl:241-270, ext/LowLevelParticleFiltersDistributionsExt.jl:16,80) */
+typedef struct llpf_gaussian {
+    int32_t dim;
+    int32_t kind;                          /* LLPF_COV_*                                        */
+    double  mu[LLPF_MAX_DIM];
+    double  cov[LLPF_MAX_DIM * LLPF_MAX_DIM]; /* SCAL: cov[0]=sigma^2; DIAG: cov[0..dim); FULL: row-major dim x dim */
+} llpf_gaussian;
+
+/* built-in models */
+enum {
+    LLPF_MODEL_LINEAR_GAUSSIAN = 0,  /* f = A x + B u, g = C x  (reference examples/example_lineargaussian.jl:28-29) */
+    LLPF_MODEL_QUADTANK_RK4    = 1   /* quad-tank, RK4          (reference examples/example_quadtank.jl:8-35, src/utils.jl:220-237) */
+};
+
+/* quadtank constant slots in llpf_model.qt[] */
+enum { LLPF_QT_K1 = 0, LLPF_QT_K2, LLPF_QT_G, LLPF_QT_A1, LLPF_QT_A2, LLPF_QT_A3, LLPF_QT_A4,
+       LLPF_QT_a1, LLPF_QT_a2, LLPF_QT_a3, LLPF_QT_a4, LLPF_QT_GAMMA1, LLPF_QT_GAMMA2,
+       LLPF_QT_TSWITCH, LLPF_QT_A1FACTOR, LLPF_QT_EPS, LLPF_QT_COUNT };
+
+/* replaces the callables + densities stored in ParticleFilter / AdvancedParticleFilter
+ * (reference src/PFtypes.jl:21-36, 162-177) */
+typedef struct llpf_model {
+    int32_t model_id;
+    int32_t nx, nu, ny;
+    double  A[LLPF_MAX_DIM * LLPF_MAX_DIM];   /* nx x nx row-major (linear-Gaussian) */
+    double  B[LLPF_MAX_DIM * LLPF_MAX_DIM];   /* nx x nu row-major                   */
+    double  C[LLPF_MAX_DIM * LLPF_MAX_DIM];   /* ny x nx row-major                   */
+    double  qt[LLPF_QT_COUNT];                /* quad-tank constants                 */
+    int32_t supersample;                      /* rk4 supersample (reference src/utils.jl:220) */
+    int32_t reserved;
+    double  Ts;                               /* sample time (reference src/PFtypes.jl:33) */
+    llpf_gaussian dynamics_density;           /* df */
+    llpf_gaussian measurement_density;        /* dg */
+    llpf_gaussian initial_density;            /* d0 */
+} llpf_model;
+
+enum { LLPF_RESAMPLE_SYSTEMATIC = 0, LLPF_RESAMPLE_STRATIFIED = 1 };   /* reference src/LowLevelParticleFilters.jl:43-46 */
+enum { LLPF_PARTICLE_FILTER = 0, LLPF_ADVANCED_PARTICLE_FILTER = 1 };
+
+typedef struct llpf_config {
+    uint32_t struct_size;            /* sizeof(llpf_config), ABI guard                     */
+    int32_t  filter_kind;            /* LLPF_PARTICLE_FILTER / LLPF_ADVANCED_PARTICLE_FILTER */
+    int64_t  n_particles;            /* N                                                   */
+    int32_t  resampling_strategy;    /* LLPF_RESAMPLE_*                                     */
+    int32_t  device;                 /* HIP device ordinal                                  */
+    double   resample_threshold;     /* reference default 0.1 (PF) / 0.5 (APF)              */
+    uint64_t seed;                   /* Philox key                                          */
+    llpf_model model;
+} llpf_config;
+
+typedef struct llpf_filter llpf_filter;   /* opaque: PFstate + filter (reference src/PFtypes.jl:8-36) */
+typedef struct llpf_bank   llpf_bank;     /* opaque: many independent filters on one device   */
+
+/* ---- lifetime --------------------------------------------------------------------------- */
+/* ParticleFilter(N, dynamics, measurement, df, dg, d0; ...) — reference src/PFtypes.jl:65-75,200-210.
+ * Particles are initialised from d0 (as the reference constructor does), w = log(1/N), t = 0. */
+int  llpf_create(const llpf_config* cfg, llpf_filter** out);
+int  llpf_destroy(llpf_filter* f);
+/* reset!(pf) — reference src/filtering.jl:4-14: x ~ d0, w = -log N, we = 1/N, t = 1 */
+int  llpf_reset(llpf_filter* f);
+/* re-key the RNG and zero its step counters (no reference equivalent: the reference never seeds pf.rng) */
+int  llpf_seed(llpf_filter* f, uint64_t seed);
+
+/* ---- the step --------------------------------------------------------------------------- */
+/* correct!(pf,u,y,p,t) -> (ll, 0) — reference src/filtering.jl:164-168 (measurement_equation!
+ * src/PFtypes.jl:107-120,226-239 + logsumexp! src/utils.jl:18-27).  y == NULL means "missing"
+ * (weights untouched, logsumexp! still runs — reference src/PFtypes.jl:109). */
+int  llpf_correct(llpf_filter* f, const double* u, const double* y, double t, double* ll);
+/* predict!(pf,u,p,t) — reference src/filtering.jl:140-153 (shouldresample src/resample.jl:5-10,
+ * resample :12-61, propagate_particles! src/PFtypes.jl:122-139 / DistributionsExt:83-93,
+ * reset_weights! src/utils.jl:73-79) */
+int  llpf_predict(llpf_filter* f, const double* u, double t);
+/* update!(pf,u,y,p,t) = correct! then predict! — reference src/filtering.jl:181-185, functor :238,240 */
+int  llpf_update(llpf_filter* f, const double* u, const double* y, double t, double* ll);
+
+/* history / output selection for llpf_run */
+typedef struct llpf_run_outputs {
+    double* ll_steps;    /* [T] per-step log-likelihood, or NULL                               */
+    double* xmean;       /* [T*nx] weighted_mean after each correct! (reference src/filtering.jl:541-549), or NULL */
+    double* x_hist;      /* [T*N*nx] particles(pf) at each step, time-major (column t of the reference's N x T Matrix), or NULL */
+    double* w_hist;      /* [T*N] weights(pf)    (reference src/filtering.jl:358), or NULL */
+    double* we_hist;     /* [T*N] expweights(pf) (reference src/filtering.jl:359), or NULL */
+} llpf_run_outputs;
+
+/* T iterations of {correct!(u_k,y_k,t_k); predict!(u_k,t_k)} with t_k = (t_index0 + k) * Ts, k = 0..T-1,
+ * enqueued on the device without a host round trip per step.
+ *   forward_trajectory(pf,u,y,p) — reference src/filtering.jl:343-365: llpf_reset, then t_index0 = 0
+ *   loglik(pf,u,y,p)             — reference src/smoothing.jl:227-230: llpf_reset, then t_index0 = 1
+ * U is T x nu row-major, Y is T x ny row-major; a row of Y whose first element is NaN is "missing".
+ * *ll_total receives the sum of the per-step log-likelihoods. */
+int  llpf_run(llpf_filter* f, const double* U, const double* Y, int64_t T, double t_index0,
+              double* ll_total, const llpf_run_outputs* outs);
+
+/* ---- accessors (reference src/PFtypes.jl:296-334) --------------------------------------- */
+int  llpf_num_particles(const llpf_filter* f, int64_t* n);                /* num_particles(pf) */
+int  llpf_index(const llpf_filter* f, int64_t* t);                        /* index(pf) = state.t[] */
+int  llpf_get_particles(llpf_filter* f, double* dst /* N*nx */);          /* particles(pf)     */
+int  llpf_get_weights(llpf_filter* f, double* dst /* N */);               /* weights(pf): log-weights  */
+int  llpf_get_expweights(llpf_filter* f, double* dst /* N */);            /* expweights(pf)    */
+int  llpf_get_ancestors(llpf_filter* f, int64_t* dst /* N, 0-based */);   /* state(pf).j       */
+int  llpf_get_bins(llpf_filter* f, double* dst /* N */);                  /* state(pf).bins (as used by the last resample) */
+int  llpf_set_particles(llpf_filter* f, const double* src /* N*nx */);    /* state(pf).x .= , xprev .=  */
+int  llpf_set_weights(llpf_filter* f, const double* w /* N log-weights */); /* state(pf).w .= w; we .= exp.(w) */
+int  llpf_set_index(llpf_filter* f, int64_t t);
+int  llpf_effective_particles(llpf_filter* f, double* ess);               /* reference src/resample.jl:1-2 */
+int  llpf_shouldresample(llpf_filter* f, int32_t* yes);                   /* reference src/resample.jl:5-10 */
+int  llpf_weighted_mean(llpf_filter* f, double* xh /* nx */);             /* reference src/filtering.jl:541-549,568 */
+int  llpf_last_resampled(llpf_filter* f, int32_t* yes);                   /* did the last predict! resample? */
+int  llpf_maxw(llpf_filter* f, double* maxw);                             /* state(pf).maxw[] */
+
+/* ---- exported array primitives (operate on caller-owned host vectors, computed on the GPU) */
+/* ll = logsumexp!(w, we) — reference src/utils.jl:18-27 */
+int  llpf_logsumexp(int32_t device, double* w, double* we, int64_t n, double* ll);
+/* j = resample(strategy, we, M) — reference src/resample.jl:12-61.  U holds the uniform draws the
+ * reference takes from the global rand(): 1 value (systematic) or m values (stratified).  j is
+ * in/out: entries whose threshold is never met keep their input value, as in the reference. */
+int  llpf_resample(int32_t device, int32_t strategy, const double* we, int64_t n, int64_t m,
+                   const double* U, int64_t* j /* m, 0-based */);
+/* the uniforms the filter path draws for its resample at Philox step `step` (host evaluation of the
+ * shared generator, so a caller / a test can reproduce what predict! used) */
+int  llpf_resample_uniforms(int32_t strategy, int64_t m, uint64_t seed, uint32_t step, double* u /* 1 or m */);
+
+/* ---- banks of independent filters (parameter sweeps) ------------------------------------ */
+/* n_filters filters that share N, model_id, dimensions, strategy and threshold but have their own
+ * model parameters and RNG key (seed + filter index): the `map(svec) do s ... loglik(pfs,u,y)`
+ * sweep of the reference (test/runtests.jl:412-417, src/smoothing.jl:335-347), batched into
+ * single launches over (tile, filter). */
+int  llpf_bank_create(const llpf_config* base, const llpf_model* models, int32_t n_filters, llpf_bank** out);
+int  llpf_bank_destroy(llpf_bank* b);
+int  llpf_bank_reset(llpf_bank* b);
+int  llpf_bank_seed(llpf_bank* b, uint64_t seed);
+/* as llpf_run, shared U / Y, ll_total has n_filters entries; ll_steps (optional) is [T * n_filters] */
+int  llpf_bank_run(llpf_bank* b, const double* U, const double* Y, int64_t T, double t_index0,
+                   double* ll_total, double* ll_steps);
+
+/* ---- measurement ------------------------------------------------------------------------ */
+/* when enabled, every kernel launch of llpf_run / llpf_bank_run is bracketed by hipEvents on the
+ * handle's stream; llpf_get_profile returns accumulated milliseconds and launch counts per kernel
+ * class since the last llpf_set_profiling call.  Classes: 0 propagate+weight, 1 normalise (logsumexp
+ * partials), 2 resample (scan + ancestor expansion), 3 other. */
+enum { LLPF_PROF_PROPAGATE = 0, LLPF_PROF_NORMALISE = 1, LLPF_PROF_RESAMPLE = 2, LLPF_PROF_OTHER = 3, LLPF_PROF_CLASSES = 4 };
+int  llpf_set_profiling(llpf_filter* f, int32_t on);
+int  llpf_get_profile(llpf_filter* f, double* ms /* LLPF_PROF_CLASSES */, int64_t* launches /* LLPF_PROF_CLASSES */);
+int  llpf_bank_set_profiling(llpf_bank* b, int32_t on);
+int  llpf_bank_get_profile(llpf_bank* b, double* ms, int64_t* launches);
+/* number of predict! calls of the last run that resampled (summed over filters for a bank) */
+int  llpf_resample_count(llpf_filter* f, int64_t* n);
+int  llpf_bank_resample_count(llpf_bank* b, int64_t* n);
+/* elapsed device milliseconds of the last llpf_run / llpf_bank_run (hipEvents on the handle's stream) */
+int  llpf_last_run_ms(llpf_filter* f, double* ms);
+int  llpf_bank_last_run_ms(llpf_bank* b, double* ms);
+
+/* ---- misc -------------------------------------------------------------------------------- */
+const char* llpf_last_error(void);
+int  llpf_version(int32_t* major, int32_t* minor);
+int  llpf_device_count(int32_t* n);
+/* device self-test of the shared deterministic math: fills out[] with f(in[]) computed on the GPU.
+ * which: 0 exp, 1 log, 2 log1p, 3 sin2pi, 4 cos2pi, 5 sqrt, 6 reciprocal, 7 u64->f64 of the bit pattern */
+int  llpf_selftest_math(int32_t device, int32_t which, const double* in, double* out, int64_t n);
+/* device self-test of Philox + Box–Muller: out[i*nd + d] = xi_d for particle i at (step, stream) */
+int  llpf_selftest_normals(int32_t device, uint64_t seed, uint32_t step, uint32_t stream, int32_t nd,
+                           double* out, int64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LLPF_H */

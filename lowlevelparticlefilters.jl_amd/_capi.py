@@ -1,0 +1,394 @@
+"""ctypes binding of libllpf_hip.so — one Python function per symbol of include/llpf.h.
+
+This is the same binding a Julia maintainer writes with `ccall` (see INTEGRATION.md and
+julia/LLPFAmd.jl); the tests drive the library through it.  There is no fallback: if the
+shared library is missing or no GPU is visible, loading / constructing raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _structs as S
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libllpf_hip.so")
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int64)
+_vp = C.c_void_p
+
+# every exported symbol of include/llpf.h with its argument types (restype is int unless noted)
+SYMBOLS = {
+    "llpf_create": [C.POINTER(S.Config), C.POINTER(_vp)],
+    "llpf_destroy": [_vp],
+    "llpf_reset": [_vp],
+    "llpf_seed": [_vp, C.c_uint64],
+    "llpf_correct": [_vp, _dp, _dp, C.c_double, _dp],
+    "llpf_predict": [_vp, _dp, C.c_double],
+    "llpf_update": [_vp, _dp, _dp, C.c_double, _dp],
+    "llpf_run": [_vp, _dp, _dp, C.c_int64, C.c_double, _dp, C.POINTER(S.RunOutputs)],
+    "llpf_num_particles": [_vp, _ip],
+    "llpf_index": [_vp, _ip],
+    "llpf_get_particles": [_vp, _dp],
+    "llpf_get_weights": [_vp, _dp],
+    "llpf_get_expweights": [_vp, _dp],
+    "llpf_get_ancestors": [_vp, _ip],
+    "llpf_get_bins": [_vp, _dp],
+    "llpf_set_particles": [_vp, _dp],
+    "llpf_set_weights": [_vp, _dp],
+    "llpf_set_index": [_vp, C.c_int64],
+    "llpf_effective_particles": [_vp, _dp],
+    "llpf_shouldresample": [_vp, C.POINTER(C.c_int32)],
+    "llpf_weighted_mean": [_vp, _dp],
+    "llpf_last_resampled": [_vp, C.POINTER(C.c_int32)],
+    "llpf_maxw": [_vp, _dp],
+    "llpf_logsumexp": [C.c_int32, _dp, _dp, C.c_int64, _dp],
+    "llpf_resample": [C.c_int32, C.c_int32, _dp, C.c_int64, C.c_int64, _dp, _ip],
+    "llpf_resample_uniforms": [C.c_int32, C.c_int64, C.c_uint64, C.c_uint32, _dp],
+    "llpf_bank_create": [C.POINTER(S.Config), C.POINTER(S.Model), C.c_int32, C.POINTER(_vp)],
+    "llpf_bank_destroy": [_vp],
+    "llpf_bank_reset": [_vp],
+    "llpf_bank_seed": [_vp, C.c_uint64],
+    "llpf_bank_run": [_vp, _dp, _dp, C.c_int64, C.c_double, _dp, _dp],
+    "llpf_set_profiling": [_vp, C.c_int32],
+    "llpf_get_profile": [_vp, _dp, _ip],
+    "llpf_bank_set_profiling": [_vp, C.c_int32],
+    "llpf_bank_get_profile": [_vp, _dp, _ip],
+    "llpf_resample_count": [_vp, _ip],
+    "llpf_bank_resample_count": [_vp, _ip],
+    "llpf_last_run_ms": [_vp, _dp],
+    "llpf_bank_last_run_ms": [_vp, _dp],
+    "llpf_last_error": [],
+    "llpf_version": [C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
+    "llpf_device_count": [C.POINTER(C.c_int32)],
+    "llpf_selftest_math": [C.c_int32, C.c_int32, _dp, _dp, C.c_int64],
+    "llpf_selftest_normals": [C.c_int32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int32, _dp, C.c_int64],
+}
+
+OK, ERR_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_DEGENERATE, ERR_ALLOC = 0, 1, 2, 3, 4, 5
+PROF_CLASSES = 4
+
+
+class LLPFError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("llpf status %d: %s" % (code, msg))
+        self.code = code
+
+
+class DegenerateWeights(LLPFError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libllpf_hip.so (fails loudly if it has not been built: run __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libllpf_hip.so not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, args in SYMBOLS.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = C.c_char_p if name == "llpf_last_error" else C.c_int
+        _lib = L
+    return _lib
+
+
+def check(code):
+    if code != OK:
+        msg = lib().llpf_last_error().decode("utf-8", "replace")
+        if code == ERR_DEGENERATE:
+            raise DegenerateWeights(code, msg)
+        raise LLPFError(code, msg)
+
+
+def dptr(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def iptr(a):
+    return a.ctypes.data_as(_ip)
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def device_count():
+    n = C.c_int32(0)
+    lib().llpf_device_count(C.byref(n))
+    return n.value
+
+
+class FilterHandle:
+    """RAII wrapper of an `llpf_filter*` (one filter on one device)."""
+
+    def __init__(self, cfg):
+        self.L = lib()
+        self.cfg = cfg
+        self.h = _vp()
+        check(self.L.llpf_create(C.byref(cfg), C.byref(self.h)))
+        self.N = int(cfg.n_particles)
+        self.nx, self.nu, self.ny = cfg.model.nx, cfg.model.nu, cfg.model.ny
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.llpf_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # --- step ---
+    def reset(self):
+        check(self.L.llpf_reset(self.h))
+
+    def seed(self, s):
+        check(self.L.llpf_seed(self.h, int(s) & 0xFFFFFFFFFFFFFFFF))
+
+    def _u(self, u):
+        if self.nu == 0:
+            return None
+        u = f64(u).reshape(-1)
+        if u.size != self.nu:
+            raise ValueError("u must have %d elements" % self.nu)
+        return u
+
+    def _y(self, y):
+        if y is None:
+            return None
+        y = f64(y).reshape(-1)
+        if y.size != self.ny:
+            raise ValueError("y must have %d elements" % self.ny)
+        return y
+
+    def correct(self, u, y, t):
+        u, y = self._u(u), self._y(y)
+        ll = C.c_double(0)
+        check(self.L.llpf_correct(self.h, dptr(u), dptr(y), float(t), C.byref(ll)))
+        return ll.value
+
+    def predict(self, u, t):
+        u = self._u(u)
+        check(self.L.llpf_predict(self.h, dptr(u), float(t)))
+
+    def update(self, u, y, t):
+        u, y = self._u(u), self._y(y)
+        ll = C.c_double(0)
+        check(self.L.llpf_update(self.h, dptr(u), dptr(y), float(t), C.byref(ll)))
+        return ll.value
+
+    def run(self, U, Y, t_index0=0.0, ll_steps=False, xmean=False, history=False):
+        Y = f64(Y).reshape(-1, self.ny)
+        T = Y.shape[0]
+        U = f64(U).reshape(T, self.nu) if self.nu else None
+        outs = S.RunOutputs()
+        res = {}
+        if ll_steps:
+            res["ll_steps"] = np.zeros(T)
+            outs.ll_steps = dptr(res["ll_steps"])
+        if xmean:
+            res["xmean"] = np.zeros((T, self.nx))
+            outs.xmean = dptr(res["xmean"])
+        if history:
+            res["x"] = np.zeros((T, self.N, self.nx))
+            res["w"] = np.zeros((T, self.N))
+            res["we"] = np.zeros((T, self.N))
+            outs.x_hist, outs.w_hist, outs.we_hist = dptr(res["x"]), dptr(res["w"]), dptr(res["we"])
+        ll = C.c_double(0)
+        check(self.L.llpf_run(self.h, dptr(U), dptr(Y), T, float(t_index0), C.byref(ll), C.byref(outs)))
+        res["ll"] = ll.value
+        return res
+
+    # --- accessors ---
+    def index(self):
+        t = C.c_int64(0)
+        check(self.L.llpf_index(self.h, C.byref(t)))
+        return t.value
+
+    def set_index(self, t):
+        check(self.L.llpf_set_index(self.h, int(t)))
+
+    def particles(self):
+        a = np.empty((self.N, self.nx))
+        check(self.L.llpf_get_particles(self.h, dptr(a)))
+        return a
+
+    def weights(self):
+        a = np.empty(self.N)
+        check(self.L.llpf_get_weights(self.h, dptr(a)))
+        return a
+
+    def expweights(self):
+        a = np.empty(self.N)
+        check(self.L.llpf_get_expweights(self.h, dptr(a)))
+        return a
+
+    def ancestors(self):
+        a = np.empty(self.N, dtype=np.int64)
+        check(self.L.llpf_get_ancestors(self.h, iptr(a)))
+        return a
+
+    def bins(self):
+        a = np.empty(self.N)
+        check(self.L.llpf_get_bins(self.h, dptr(a)))
+        return a
+
+    def set_particles(self, x):
+        x = f64(x).reshape(self.N, self.nx)
+        check(self.L.llpf_set_particles(self.h, dptr(x)))
+
+    def set_weights(self, w):
+        w = f64(w).reshape(self.N)
+        check(self.L.llpf_set_weights(self.h, dptr(w)))
+
+    def ess(self):
+        v = C.c_double(0)
+        check(self.L.llpf_effective_particles(self.h, C.byref(v)))
+        return v.value
+
+    def shouldresample(self):
+        v = C.c_int32(0)
+        check(self.L.llpf_shouldresample(self.h, C.byref(v)))
+        return bool(v.value)
+
+    def last_resampled(self):
+        v = C.c_int32(0)
+        check(self.L.llpf_last_resampled(self.h, C.byref(v)))
+        return bool(v.value)
+
+    def maxw(self):
+        v = C.c_double(0)
+        check(self.L.llpf_maxw(self.h, C.byref(v)))
+        return v.value
+
+    def weighted_mean(self):
+        a = np.empty(self.nx)
+        check(self.L.llpf_weighted_mean(self.h, dptr(a)))
+        return a
+
+    def resample_count(self):
+        v = C.c_int64(0)
+        check(self.L.llpf_resample_count(self.h, C.byref(v)))
+        return v.value
+
+    def last_run_ms(self):
+        v = C.c_double(0)
+        check(self.L.llpf_last_run_ms(self.h, C.byref(v)))
+        return v.value
+
+    def set_profiling(self, on):
+        check(self.L.llpf_set_profiling(self.h, 1 if on else 0))
+
+    def profile(self):
+        ms = np.zeros(PROF_CLASSES)
+        n = np.zeros(PROF_CLASSES, dtype=np.int64)
+        check(self.L.llpf_get_profile(self.h, dptr(ms), iptr(n)))
+        return ms, n
+
+
+class BankHandle:
+    """RAII wrapper of an `llpf_bank*` (many independent filters on one device)."""
+
+    def __init__(self, base_cfg, models):
+        self.L = lib()
+        self.F = len(models)
+        arr = (S.Model * self.F)(*models)
+        self._models = arr
+        self.cfg = base_cfg
+        self.h = _vp()
+        check(self.L.llpf_bank_create(C.byref(base_cfg), arr, self.F, C.byref(self.h)))
+        self.N = int(base_cfg.n_particles)
+        self.nx, self.nu, self.ny = models[0].nx, models[0].nu, models[0].ny
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.llpf_bank_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        check(self.L.llpf_bank_reset(self.h))
+
+    def seed(self, s):
+        check(self.L.llpf_bank_seed(self.h, int(s) & 0xFFFFFFFFFFFFFFFF))
+
+    def run(self, U, Y, t_index0=0.0, ll_steps=False):
+        Y = f64(Y).reshape(-1, self.ny)
+        T = Y.shape[0]
+        U = f64(U).reshape(T, self.nu) if self.nu else None
+        ll = np.zeros(self.F)
+        lls = np.zeros((T, self.F)) if ll_steps else None
+        check(self.L.llpf_bank_run(self.h, dptr(U), dptr(Y), T, float(t_index0), dptr(ll), dptr(lls)))
+        return {"ll": ll, "ll_steps": lls}
+
+    def last_run_ms(self):
+        v = C.c_double(0)
+        check(self.L.llpf_bank_last_run_ms(self.h, C.byref(v)))
+        return v.value
+
+    def resample_count(self):
+        v = C.c_int64(0)
+        check(self.L.llpf_bank_resample_count(self.h, C.byref(v)))
+        return v.value
+
+    def set_profiling(self, on):
+        check(self.L.llpf_bank_set_profiling(self.h, 1 if on else 0))
+
+    def profile(self):
+        ms = np.zeros(PROF_CLASSES)
+        n = np.zeros(PROF_CLASSES, dtype=np.int64)
+        check(self.L.llpf_bank_get_profile(self.h, dptr(ms), iptr(n)))
+        return ms, n
+
+
+# array primitives -----------------------------------------------------------------------------------
+def logsumexp(w, device=0):
+    """ll, w_normalised, we = logsumexp!(w, we)  (reference src/utils.jl:18-27), computed on the GPU."""
+    w = f64(w).copy()
+    we = np.empty_like(w)
+    ll = C.c_double(0)
+    check(lib().llpf_logsumexp(device, dptr(w), dptr(we), w.size, C.byref(ll)))
+    return ll.value, w, we
+
+
+def resample(strategy, we, U, m=None, j0=None, device=0):
+    """j = resample(strategy, we, M) (reference src/resample.jl:12-61), 0-based, computed on the GPU."""
+    we = f64(we)
+    n = we.size
+    m = n if m is None else int(m)
+    j = np.zeros(m, dtype=np.int64) if j0 is None else np.ascontiguousarray(j0, dtype=np.int64).copy()
+    U = f64(np.atleast_1d(U))
+    check(lib().llpf_resample(device, strategy, dptr(we), n, m, dptr(U), iptr(j)))
+    return j
+
+
+def resample_uniforms(strategy, m, seed, step):
+    u = np.zeros(1 if strategy == S.RESAMPLE_SYSTEMATIC else m)
+    check(lib().llpf_resample_uniforms(strategy, m, int(seed) & 0xFFFFFFFFFFFFFFFF, step, dptr(u)))
+    return u
+
+
+def selftest_math(which, x, device=0):
+    x = f64(x)
+    out = np.empty_like(x)
+    check(lib().llpf_selftest_math(device, which, dptr(x), dptr(out), x.size))
+    return out
+
+
+def selftest_normals(seed, step, stream, nd, n, device=0):
+    out = np.empty((n, nd))
+    check(lib().llpf_selftest_normals(device, int(seed), step, stream, nd, dptr(out), n))
+    return out

@@ -1,0 +1,468 @@
+"""Host-side mirror of the reference's particle-filter API for the hot path.
+
+Names follow LowLevelParticleFilters.jl (exports: reference src/LowLevelParticleFilters.jl:3-16) with the
+trailing `!` dropped (`reset!` -> `reset`, `predict!` -> `predict`, `correct!` -> `correct`,
+`update!` -> `update`, `logsumexp!` -> `logsumexp`).  Every verb is a thin call into the C ABI
+(include/llpf.h); nothing here computes particle data on the host, and there is no fallback when
+the GPU library is missing.
+
+User callables cannot run on the GPU, so the `dynamics` / `measurement` /
+`measurement_likelihood` arguments are *model descriptors*:
+
+    LinearDynamics(A, B), LinearMeasurement(C)        x+ = A x + B u,  y = C x
+    QuadTankDynamics(...), QuadTankMeasurement()      reference examples/example_quadtank.jl:8-35
+    GaussianLikelihood(measurement, dg)               logpdf(dg, y - g(x)) for AdvancedParticleFilter
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from . import _structs as S
+
+__all__ = [
+    "MvNormal", "ResampleSystematic", "ResampleStratified",
+    "LinearDynamics", "LinearMeasurement", "QuadTankDynamics", "QuadTankMeasurement", "GaussianLikelihood",
+    "ParticleFilter", "AdvancedParticleFilter", "FilterBank", "ParticleFilteringSolution",
+    "reset", "predict", "correct", "update", "forward_trajectory", "mean_trajectory", "loglik",
+    "particles", "weights", "expweights", "state", "num_particles", "index", "effective_particles",
+    "shouldresample", "resample", "weighted_mean", "logsumexp", "simulate", "parameters",
+    "dynamics", "measurement", "measurement_likelihood", "dynamics_density", "measurement_density",
+    "initial_density", "resample_threshold", "resampling_strategy",
+]
+
+
+# ---------------------------------------------------------------------------------------------------
+# densities and model descriptors
+# ---------------------------------------------------------------------------------------------------
+class MvNormal:
+    """N(mu, Sigma).  `cov`: float -> sigma^2 * I (PDMats.ScalMat), 1-D array -> diagonal (PDiagMat),
+    2-D array -> full (PDMat).  Mirrors Distributions.MvNormal / SimpleMvNormal as used by the
+    reference (src/utils.jl:241-270, ext/LowLevelParticleFiltersDistributionsExt.jl:16,80)."""
+
+    def __init__(self, mu, cov=None, kind=None):
+        if cov is None:            # MvNormal(Sigma): zero mean
+            cov = mu
+            c = np.asarray(cov, dtype=np.float64)
+            if c.ndim == 0:
+                raise ValueError("MvNormal(cov) needs an array covariance to infer the dimension")
+            mu = np.zeros(c.shape[0])
+        self._g = S.make_gaussian(mu, cov, kind)
+
+    def __len__(self):
+        return self._g.dim
+
+    @property
+    def mean(self):
+        return S.gaussian_mean(self._g)
+
+    @property
+    def cov(self):
+        return S.gaussian_cov_matrix(self._g)
+
+    def rand(self, rng):
+        return self.mean + np.linalg.cholesky(self.cov) @ rng.standard_normal(len(self))
+
+    def struct(self):
+        return self._g
+
+
+class ResampleSystematic:      # reference src/LowLevelParticleFilters.jl:44
+    code = S.RESAMPLE_SYSTEMATIC
+
+
+class ResampleStratified:      # reference src/LowLevelParticleFilters.jl:45
+    code = S.RESAMPLE_STRATIFIED
+
+
+class LinearDynamics:
+    def __init__(self, A, B=None):
+        self.A = np.atleast_2d(np.asarray(A, dtype=np.float64))
+        self.B = None if B is None else np.asarray(B, dtype=np.float64).reshape(self.A.shape[0], -1)
+
+    def __call__(self, x, u, p=None, t=0.0):
+        x = np.asarray(x, dtype=np.float64)
+        out = self.A @ x
+        if self.B is not None and self.B.shape[1]:
+            out = out + self.B @ np.asarray(u, dtype=np.float64).reshape(-1)
+        return out
+
+
+class LinearMeasurement:
+    def __init__(self, Cm):
+        self.C = np.atleast_2d(np.asarray(Cm, dtype=np.float64))
+
+    def __call__(self, x, u=None, p=None, t=0.0):
+        return self.C @ np.asarray(x, dtype=np.float64)
+
+
+class QuadTankDynamics:
+    """Quad-tank process discretised with rk4 (reference examples/example_quadtank.jl:8-35,
+    src/utils.jl:220-237)."""
+
+    def __init__(self, supersample=2, **consts):
+        self.supersample = int(supersample)
+        self.consts = dict(S.QUADTANK_DEFAULTS)
+        self.consts.update(consts)
+
+    def rhs(self, h, u, t):
+        c = self.consts
+        a1 = c["a1"] * (c["a1_factor"] if t > c["t_switch"] else 1.0)
+        ss = lambda z: np.sqrt(max(z, 0.0) + c["eps"])
+        g2 = 2.0 * c["g"]
+        return np.array([
+            -a1 / c["A1"] * ss(g2 * h[0]) + c["a3"] / c["A1"] * ss(g2 * h[2]) + c["gamma1"] * c["k1"] / c["A1"] * u[0],
+            -c["a2"] / c["A2"] * ss(g2 * h[1]) + c["a4"] / c["A2"] * ss(g2 * h[3]) + c["gamma2"] * c["k2"] / c["A2"] * u[1],
+            -c["a3"] / c["A3"] * ss(g2 * h[2]) + (1 - c["gamma2"]) * c["k2"] / c["A3"] * u[1],
+            -c["a4"] / c["A4"] * ss(g2 * h[3]) + (1 - c["gamma1"]) * c["k1"] / c["A4"] * u[0]])
+
+    def __call__(self, x, u, p=None, t=0.0, Ts=1.0):
+        x = np.asarray(x, dtype=np.float64).copy()
+        h = Ts / self.supersample
+        for _ in range(self.supersample):
+            f1 = self.rhs(x, u, t)
+            f2 = self.rhs(x + h / 2 * f1, u, t + h / 2)
+            f3 = self.rhs(x + h / 2 * f2, u, t + h / 2)
+            f4 = self.rhs(x + h * f3, u, t + h)
+            x = x + h / 6 * (f1 + 2 * f2 + 2 * f3 + f4)
+            t += h
+        return x
+
+
+class QuadTankMeasurement:
+    def __call__(self, x, u=None, p=None, t=0.0):
+        return np.asarray(x, dtype=np.float64)[:2].copy()
+
+
+class GaussianLikelihood:
+    """measurement_likelihood(x,u,y,p,t) = logpdf(dg, y - measurement(x,u,p,t))."""
+
+    def __init__(self, measurement, measurement_density):
+        self.measurement = measurement
+        self.measurement_density = measurement_density
+
+
+def _build_model(dyn, meas, df, dg, d0, Ts):
+    if isinstance(dyn, LinearDynamics) and isinstance(meas, LinearMeasurement):
+        return S.make_lg_model(dyn.A, dyn.B, meas.C, df.struct(), dg.struct(), d0.struct(), Ts)
+    if isinstance(dyn, QuadTankDynamics) and isinstance(meas, QuadTankMeasurement):
+        return S.make_quadtank_model(df.struct(), dg.struct(), d0.struct(), Ts, dyn.supersample, **dyn.consts)
+    raise TypeError("dynamics/measurement must be built-in model descriptors (LinearDynamics+LinearMeasurement "
+                    "or QuadTankDynamics+QuadTankMeasurement): arbitrary callables cannot run on the GPU")
+
+
+# ---------------------------------------------------------------------------------------------------
+# filters
+# ---------------------------------------------------------------------------------------------------
+class _AbstractParticleFilter:
+    kind = S.PARTICLE_FILTER
+
+    def _setup(self, N, dyn, meas, df, dg, d0, resample_threshold, resampling_strategy, rng, p, threads, Ts, nu, ny, device):
+        self.dynamics = dyn
+        self.measurement = meas
+        self.dynamics_density = df
+        self.measurement_density = dg
+        self.initial_density = d0
+        self.resample_threshold = float(resample_threshold)
+        self.resampling_strategy = resampling_strategy
+        self.rng = 0 if rng is None else int(rng)       # the Philox key (the reference stores an Xoshiro, src/PFtypes.jl:30)
+        self.p = p
+        self.threads = threads                          # accepted for signature parity; the GPU is always parallel
+        self.Ts = float(Ts)
+        self._model = _build_model(dyn, meas, df, dg, d0, Ts)
+        self.nx, self.nu, self.ny = self._model.nx, self._model.nu, self._model.ny
+        if nu not in (-1, self.nu) or ny not in (-1, self.ny):
+            raise ValueError("nu / ny do not match the model descriptor")
+        self._cfg = S.make_config(self._model, N, self.kind, resampling_strategy.code, resample_threshold, self.rng, device)
+        self._h = _capi.FilterHandle(self._cfg)
+        self.N = int(N)
+
+    # pf(u, y, p, t): one update! step (reference src/filtering.jl:238,240)
+    def __call__(self, u, y, p=None, t=None):
+        return update(self, u, y, p, t)
+
+    @property
+    def state(self):
+        return _StateView(self)
+
+
+class ParticleFilter(_AbstractParticleFilter):
+    """ParticleFilter(N, dynamics, measurement, dynamics_density, measurement_density, initial_density; ...)
+    — reference src/PFtypes.jl:21-36,65-75 (defaults: resample_threshold = 0.1, ResampleSystematic, Ts = 1)."""
+    kind = S.PARTICLE_FILTER
+
+    def __init__(self, N, dynamics, measurement, dynamics_density, measurement_density, initial_density, *,
+                 resample_threshold=0.1, resampling_strategy=ResampleSystematic, rng=None, p=None,
+                 threads=False, Ts=1.0, nu=-1, ny=-1, device=0):
+        self._setup(N, dynamics, measurement, dynamics_density, measurement_density, initial_density,
+                    resample_threshold, resampling_strategy, rng, p, threads, Ts, nu, ny, device)
+        self.measurement_likelihood = None
+
+
+class AdvancedParticleFilter(_AbstractParticleFilter):
+    """AdvancedParticleFilter(N, dynamics, measurement, measurement_likelihood, dynamics_density,
+    initial_density; ...) — reference src/PFtypes.jl:162-210 (default resample_threshold = 0.5)."""
+    kind = S.ADVANCED_PARTICLE_FILTER
+
+    def __init__(self, N, dynamics, measurement, measurement_likelihood, dynamics_density, initial_density, *,
+                 resample_threshold=0.5, resampling_strategy=ResampleSystematic, rng=None, p=None,
+                 threads=False, Ts=1.0, nu=-1, ny=-1, device=0):
+        if not isinstance(measurement_likelihood, GaussianLikelihood):
+            raise TypeError("measurement_likelihood must be a GaussianLikelihood descriptor")
+        self._setup(N, dynamics, measurement, dynamics_density, measurement_likelihood.measurement_density,
+                    initial_density, resample_threshold, resampling_strategy, rng, p, threads, Ts, nu, ny, device)
+        self.measurement_likelihood = measurement_likelihood
+
+
+class _StateView:
+    """Read-only view with the reference's PFstate field names (src/PFtypes.jl:8-17)."""
+
+    def __init__(self, pf):
+        self._pf = pf
+
+    x = property(lambda s: s._pf._h.particles())
+    xprev = property(lambda s: s._pf._h.particles())    # xprev == x outside predict! (copyto!, filtering.jl:151)
+    w = property(lambda s: s._pf._h.weights())
+    we = property(lambda s: s._pf._h.expweights())
+    maxw = property(lambda s: s._pf._h.maxw())
+    j = property(lambda s: s._pf._h.ancestors())
+    bins = property(lambda s: s._pf._h.bins())
+    t = property(lambda s: s._pf._h.index())
+
+
+class ParticleFilteringSolution:
+    """Fields f,u,y,x,w,we,ll,t of the reference's struct (src/solutions.jl:334-345).  x is [T, N, nx]
+    (column t of the reference's N x T matrix of SVectors is x[t]); w, we are [T, N]."""
+
+    def __init__(self, f, u, y, x, w, we, ll):
+        self.f, self.u, self.y, self.x, self.w, self.we, self.ll = f, u, y, x, w, we, ll
+        self.t = np.arange(x.shape[0]) * f.Ts
+
+
+# ---------------------------------------------------------------------------------------------------
+# verbs
+# ---------------------------------------------------------------------------------------------------
+def reset(pf):
+    """reset!(pf) — reference src/filtering.jl:4-14."""
+    pf._h.reset()
+
+
+def _t(pf, t):
+    return pf._h.index() * pf.Ts if t is None else float(t)
+
+
+def predict(pf, u, p=None, t=None):
+    """predict!(pf, u, p, t = index(pf)*Ts) — reference src/filtering.jl:140-153."""
+    pf._h.predict(u, _t(pf, t))
+
+
+def correct(pf, u, y, p=None, t=None):
+    """ll, 0 = correct!(pf, u, y, p, t) — reference src/filtering.jl:164-168.  y=None means missing."""
+    return pf._h.correct(u, y, _t(pf, t)), 0
+
+
+def update(pf, u, y, p=None, t=None):
+    """ll, 0 = update!(pf, u, y, p, t) — reference src/filtering.jl:181-185."""
+    return pf._h.update(u, y, _t(pf, t)), 0
+
+
+def forward_trajectory(pf, u, y, p=None):
+    """sol = forward_trajectory(pf, u, y, p) — reference src/filtering.jl:343-365.  The whole T-step loop is
+    enqueued on the device; callbacks of the reference signature are not supported (a fused on-device loop
+    cannot call back into the host) — drive update() step by step if they are needed."""
+    reset(pf)
+    r = pf._h.run(u, y, t_index0=0.0, history=True)
+    return ParticleFilteringSolution(pf, u, y, r["x"], r["w"], r["we"], r["ll"])
+
+
+def loglik(pf, u, y, p=None):
+    """loglik(pf, u, y, p) — reference src/smoothing.jl:227-230 (reset!, then sum of update! with
+    t = index(pf)*Ts, i.e. the first step is at t = 1*Ts)."""
+    reset(pf)
+    return pf._h.run(u, y, t_index0=1.0)["ll"]
+
+
+def mean_trajectory(pf, u=None, y=None, p=None):
+    """x̂, ll = mean_trajectory(pf, u, y) — reference src/filtering.jl:393, 417-432 (including its quirk:
+    correct!(u[1], y[1], t=0) is followed by pf(u[t-1], y[t]) for t = 2..T).
+    mean_trajectory(sol) — reference :405: T x nx matrix of weighted means."""
+    if isinstance(pf, ParticleFilteringSolution):
+        return np.einsum("tnd,tn->td", pf.x, pf.we)
+    reset(pf)
+    Y = np.asarray(y, dtype=np.float64).reshape(-1, pf.ny)
+    Um = np.asarray(u, dtype=np.float64).reshape(Y.shape[0], -1)
+    T = Y.shape[0]
+    xh = np.zeros((T, pf.nx))
+    ll = pf._h.correct(Um[0], Y[0], 0.0)
+    xh[0] = pf._h.weighted_mean()
+    for t in range(1, T):
+        ll += pf._h.update(Um[t - 1], Y[t], t * pf.Ts)
+        xh[t] = pf._h.weighted_mean()
+    return xh, ll
+
+
+# accessors — reference src/PFtypes.jl:296-334
+def particles(pf):
+    return pf._h.particles()
+
+
+def weights(pf):
+    return pf._h.weights()
+
+
+def expweights(pf):
+    return pf._h.expweights()
+
+
+def state(pf):
+    return pf.state
+
+
+def num_particles(pf):
+    return pf.N
+
+
+def index(pf):
+    return pf._h.index()
+
+
+def parameters(pf):
+    return pf.p
+
+
+def dynamics(pf):
+    return pf.dynamics
+
+
+def measurement(pf):
+    return pf.measurement
+
+
+def measurement_likelihood(pf):
+    return pf.measurement_likelihood
+
+
+def dynamics_density(pf):
+    return pf.dynamics_density
+
+
+def measurement_density(pf):
+    return pf.measurement_density
+
+
+def initial_density(pf):
+    return pf.initial_density
+
+
+def resample_threshold(pf):
+    return pf.resample_threshold
+
+
+def resampling_strategy(pf):
+    return pf.resampling_strategy
+
+
+def effective_particles(pf_or_we):
+    """effective_particles(pf | we) — reference src/resample.jl:1-2."""
+    if isinstance(pf_or_we, _AbstractParticleFilter):
+        return pf_or_we._h.ess()
+    we = np.asarray(pf_or_we, dtype=np.float64)
+    # ESS of a plain vector goes through the same normalise kernel: we are exp-weights => log them
+    h = _weights_handle(we)
+    return h.ess()
+
+
+def _weights_handle(we):
+    """A scratch 1-D filter holding log(we) as its weights (weights-only operations on plain vectors)."""
+    g = MvNormal(np.zeros(1), 1.0)
+    m = S.make_lg_model(np.eye(1), None, np.eye(1), g.struct(), g.struct(), g.struct())
+    cfg = S.make_config(m, we.size)
+    h = _capi.FilterHandle(cfg)
+    with np.errstate(divide="ignore"):
+        h.set_weights(np.log(we))
+    return h
+
+
+def shouldresample(pf):
+    """shouldresample(pf) — reference src/resample.jl:5-10."""
+    return pf._h.shouldresample()
+
+
+def resample(a, we=None, M=None, U=None, seed=0, step=0):
+    """resample(pf) / resample(T, we[, M]) / resample(we) — reference src/resample.jl:12-15.  Returns 0-based
+    ancestor indices.  The uniforms the reference draws from the global RNG come from Philox(seed, step)
+    unless given explicitly in U."""
+    if isinstance(a, _AbstractParticleFilter):
+        strategy, wev = a.resampling_strategy, a._h.expweights()
+    elif we is None:
+        strategy, wev = ResampleSystematic, np.asarray(a, dtype=np.float64)
+    else:
+        strategy, wev = a, np.asarray(we, dtype=np.float64)
+    M = wev.size if M is None else int(M)
+    if U is None:
+        U = _capi.resample_uniforms(strategy.code, M, seed, step)
+    return _capi.resample(strategy.code, wev, U, M)
+
+
+def weighted_mean(pf):
+    """weighted_mean(pf) — reference src/filtering.jl:541-549,568."""
+    return pf._h.weighted_mean()
+
+
+def logsumexp(w):
+    """ll, w, we = logsumexp!(w, we) — reference src/utils.jl:18-27 (returns the normalised copies)."""
+    return _capi.logsumexp(w)
+
+
+def simulate(pf, T_or_u, du=None, p=None, dynamics_noise=True, measurement_noise=True, sample_initial=False, rng=None):
+    """x, u, y = simulate(pf, T, du) / simulate(pf, u) — reference src/filtering.jl:457-477.  Host-side data
+    generation (not part of the hot path); rng is a numpy Generator."""
+    rng = np.random.default_rng(0) if rng is None else rng
+    if np.isscalar(T_or_u):
+        T = int(T_or_u)
+        u = np.stack([du.rand(rng) for _ in range(T)]) if pf.nu else np.zeros((T, 0))
+    else:
+        u = np.asarray(T_or_u, dtype=np.float64).reshape(len(T_or_u), -1)
+        T = u.shape[0]
+    d0, df, dg = pf.initial_density, pf.dynamics_density, pf.measurement_density
+    x = np.zeros((T, pf.nx))
+    y = np.zeros((T, pf.ny))
+    x[0] = d0.rand(rng) if sample_initial else d0.mean
+    for t in range(T):
+        ti = t * pf.Ts
+        g = pf.measurement(x[t], u[t], p, ti)
+        y[t] = g + (dg.rand(rng) if measurement_noise else 0.0)
+        if t + 1 < T:
+            if isinstance(pf.dynamics, QuadTankDynamics):
+                fx = pf.dynamics(x[t], u[t], p, ti, pf.Ts)
+            else:
+                fx = pf.dynamics(x[t], u[t], p, ti)
+            x[t + 1] = fx + (df.rand(rng) if dynamics_noise else 0.0)
+    return x, u, y
+
+
+# ---------------------------------------------------------------------------------------------------
+# banks of independent filters (parameter sweeps; reference test/runtests.jl:412-417)
+# ---------------------------------------------------------------------------------------------------
+class FilterBank:
+    """n independent filters sharing N, model family and dimensions, batched into single launches.
+    `filters_spec` is a list of (dynamics, measurement, df, dg, d0) tuples."""
+
+    def __init__(self, N, filters_spec, *, resample_threshold=0.1, resampling_strategy=ResampleSystematic,
+                 rng=None, Ts=1.0, device=0):
+        models = [_build_model(dy, me, df, dg, d0, Ts) for (dy, me, df, dg, d0) in filters_spec]
+        self.Ts = float(Ts)
+        self.N = int(N)
+        self.rng = 0 if rng is None else int(rng)
+        cfg = S.make_config(models[0], N, S.PARTICLE_FILTER, resampling_strategy.code, resample_threshold, self.rng, device)
+        self._h = _capi.BankHandle(cfg, models)
+        self.n_filters = len(models)
+
+    def loglik(self, u, y):
+        """[loglik(pf_k, u, y) for k] — reference src/smoothing.jl:227-230 applied to every filter."""
+        self._h.reset()
+        return self._h.run(u, y, t_index0=1.0)["ll"]
+
+    def forward(self, u, y, ll_steps=False):
+        self._h.reset()
+        return self._h.run(u, y, t_index0=0.0, ll_steps=ll_steps)

@@ -1,0 +1,861 @@
+// capi.hip — host orchestration and the C ABI declared in include/llpf.h.
+//
+// There is deliberately NO CPU implementation behind these entry points: without a gfx950 device every
+// constructor fails with LLPF_ERR_NO_DEVICE.
+#include <math.h>
+#include <string.h>
+
+#include <memory>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "engine.hpp"
+
+using namespace llpf;
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIPC(expr)                                                                                   \
+    do {                                                                                             \
+        hipError_t _e = (expr);                                                                      \
+        if (_e != hipSuccess)                                                                        \
+            return fail(LLPF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));            \
+    } while (0)
+#define CHK(expr)                                                                                    \
+    do {                                                                                             \
+        int _c = (expr);                                                                             \
+        if (_c != LLPF_OK) return _c;                                                                \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// host-side preparation of the densities (same operation order as oracle/llpf_oracle.c:gauss_prepare
+// in device order; transcendental = the shared deterministic log so the constant does not depend on libm)
+// ------------------------------------------------------------------------------------------------
+static int chol_lower(const double* S, int n, double* L) {
+    memset(L, 0, sizeof(double) * MAXD * MAXD);
+    for (int i = 0; i < n; ++i) {
+        for (int j = 0; j <= i; ++j) {
+            double acc = S[i * n + j];
+            for (int k = 0; k < j; ++k) acc = acc - L[i * MAXD + k] * L[j * MAXD + k];
+            if (i == j) {
+                if (!(acc > 0.0)) return -1;
+                L[i * MAXD + i] = llpf_sqrt(acc);
+            } else {
+                L[i * MAXD + j] = acc / L[j * MAXD + j];
+            }
+        }
+    }
+    return 0;
+}
+
+static int gauss_prepare(const llpf_gaussian* g, GaussD* d) {
+    memset(d, 0, sizeof(*d));
+    const int n = g->dim;
+    if (n < 1 || n > MAXD) return -1;
+    d->dim = n;
+    d->kind = g->kind;
+    for (int i = 0; i < n; ++i) d->mu[i] = g->mu[i];
+    double logdet = 0.0;
+    if (g->kind == LLPF_COV_SCAL) {
+        d->scal = g->cov[0];
+        if (!(d->scal > 0.0)) return -1;
+        d->sqrtscal = llpf_sqrt(d->scal);
+        logdet = (double)n * llpf_log(d->scal);
+        for (int i = 0; i < n; ++i) d->L[i * MAXD + i] = d->sqrtscal;
+    } else if (g->kind == LLPF_COV_DIAG) {
+        for (int i = 0; i < n; ++i) {
+            d->diag[i] = g->cov[i];
+            if (!(d->diag[i] > 0.0)) return -1;
+            d->invdiag[i] = 1.0 / d->diag[i];
+            d->sqrtdiag[i] = llpf_sqrt(d->diag[i]);
+            d->L[i * MAXD + i] = d->sqrtdiag[i];
+            logdet = (i == 0) ? llpf_log(d->diag[i]) : logdet + llpf_log(d->diag[i]);
+        }
+    } else if (g->kind == LLPF_COV_FULL) {
+        if (chol_lower(g->cov, n, d->L) != 0) return -1;
+        double dd = 0.0;
+        for (int i = 0; i < n; ++i) dd = (i == 0) ? llpf_log(d->L[i * MAXD + i]) : dd + llpf_log(d->L[i * MAXD + i]);
+        logdet = dd + dd;
+    } else {
+        return -1;
+    }
+    const double log2pi = llpf_log(2.0 * 3.141592653589793);
+    d->c0 = -((double)n * log2pi + logdet) / 2.0;
+    return 0;
+}
+
+static int model_prepare(const llpf_model* m, ModelD* d) {
+    memset(d, 0, sizeof(*d));
+    d->model_id = m->model_id;
+    d->nx = m->nx; d->nu = m->nu; d->ny = m->ny;
+    memcpy(d->A, m->A, sizeof(d->A));
+    memcpy(d->B, m->B, sizeof(d->B));
+    memcpy(d->C, m->C, sizeof(d->C));
+    memcpy(d->qt, m->qt, sizeof(d->qt));
+    d->supersample = m->supersample;
+    d->Ts = m->Ts;
+    if (gauss_prepare(&m->dynamics_density, &d->df)) return -1;
+    if (gauss_prepare(&m->measurement_density, &d->dg)) return -2;
+    if (gauss_prepare(&m->initial_density, &d->d0)) return -3;
+    if (d->df.dim != m->nx || d->d0.dim != m->nx || d->dg.dim != m->ny) return -4;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Bank: F independent filters of N particles on one device / one stream
+// ------------------------------------------------------------------------------------------------
+struct Bank {
+    llpf_config cfg{};
+    int F = 0;
+    int64_t N = 0, Ns = 0;
+    int nx = 0, nu = 0, ny = 0, P1 = 0, P2 = 0;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    ModelD* d_models = nullptr;
+    FilterScal* d_scal = nullptr;
+    double* d_x[2] = {nullptr, nullptr};
+    int cur = 0;
+    double* d_w = nullptr;
+    int32_t* d_anc = nullptr;
+    double* d_pmax = nullptr;
+    NormPartial* d_part = nullptr;
+    double* d_uy = nullptr;          // staging for single-step u / y (2 * MAXD)
+    double* d_U = nullptr;           // resident inputs of a run
+    double* d_Y = nullptr;
+    size_t capU = 0, capY = 0;
+    double* d_ll_steps = nullptr;
+    double* d_xmean = nullptr;
+    size_t cap_ll = 0, cap_xm = 0;
+    double* d_tmp = nullptr;         // F*N*max(nx,1) doubles (also reinterpreted as int64 / double staging)
+    uint64_t seed = 0;
+    uint32_t n_reset = 0, n_predict = 0;
+    int64_t t_index = 0;
+    // measurement
+    bool profiling = false;
+    double prof_ms[LLPF_PROF_CLASSES] = {0, 0, 0, 0};
+    int64_t prof_n[LLPF_PROF_CLASSES] = {0, 0, 0, 0};
+    struct Ev { hipEvent_t a, b; int cls; };
+    std::vector<Ev> pending;
+    std::vector<hipEvent_t> ev_pool;
+    hipEvent_t ev_run0 = nullptr, ev_run1 = nullptr;
+    double last_run_ms = 0.0;
+    int64_t run_resamples = 0;
+
+    BankDev dev() const {
+        BankDev b;
+        b.N = N; b.Ns = Ns; b.F = F; b.nx = nx; b.nu = nu; b.ny = ny;
+        b.strategy = cfg.resampling_strategy;
+        b.model_id = cfg.model.model_id;
+        b.P1 = P1; b.P2 = P2;
+        b.thr = cfg.resample_threshold;
+        b.log1N = llpf_log(1.0 / (double)N);
+        b.mlogN = -llpf_log((double)N);
+        b.models = d_models; b.scal = d_scal;
+        b.xcur = d_x[cur]; b.xnext = d_x[cur ^ 1];
+        b.w = d_w; b.anc = d_anc; b.pmax = d_pmax; b.part = d_part;
+        return b;
+    }
+};
+
+struct llpf_filter { Bank bank; };
+struct llpf_bank { Bank bank; };
+
+static int use_device(const Bank& b) {
+    HIPC(hipSetDevice(b.device));
+    return LLPF_OK;
+}
+
+static void free_bank(Bank& b) {
+    hipSetDevice(b.device);
+    if (b.stream) hipStreamSynchronize(b.stream);
+    hipFree(b.d_models); hipFree(b.d_scal); hipFree(b.d_x[0]); hipFree(b.d_x[1]); hipFree(b.d_w);
+    hipFree(b.d_anc); hipFree(b.d_pmax); hipFree(b.d_part); hipFree(b.d_uy); hipFree(b.d_U); hipFree(b.d_Y);
+    hipFree(b.d_ll_steps); hipFree(b.d_xmean); hipFree(b.d_tmp);
+    for (auto e : b.ev_pool) hipEventDestroy(e);
+    for (auto& e : b.pending) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+    if (b.ev_run0) hipEventDestroy(b.ev_run0);
+    if (b.ev_run1) hipEventDestroy(b.ev_run1);
+    if (b.stream) hipStreamDestroy(b.stream);
+}
+
+static int scal_download(Bank& b, std::vector<FilterScal>& h) {
+    h.resize(b.F);
+    HIPC(hipMemcpyAsync(h.data(), b.d_scal, sizeof(FilterScal) * b.F, hipMemcpyDeviceToHost, b.stream));
+    HIPC(hipStreamSynchronize(b.stream));
+    return LLPF_OK;
+}
+static int scal_upload(Bank& b, const std::vector<FilterScal>& h) {
+    HIPC(hipMemcpyAsync(b.d_scal, h.data(), sizeof(FilterScal) * b.F, hipMemcpyHostToDevice, b.stream));
+    HIPC(hipStreamSynchronize(b.stream));
+    return LLPF_OK;
+}
+
+static void set_keys(Bank& b, std::vector<FilterScal>& h, uint64_t seed) {
+    b.seed = seed;
+    b.n_reset = 0;
+    b.n_predict = 0;
+    for (int f = 0; f < b.F; ++f) {
+        const uint64_t s = seed + (uint64_t)f;
+        h[f].k0 = (uint32_t)s;
+        h[f].k1 = (uint32_t)(s >> 32);
+    }
+}
+
+// profiling helpers ------------------------------------------------------------------------------
+static hipEvent_t get_event(Bank& b) {
+    if (!b.ev_pool.empty()) { hipEvent_t e = b.ev_pool.back(); b.ev_pool.pop_back(); return e; }
+    hipEvent_t e;
+    hipEventCreate(&e);
+    return e;
+}
+struct ProfScope {
+    Bank& b; int cls; hipEvent_t e0 = nullptr;
+    ProfScope(Bank& bb, int c) : b(bb), cls(c) {
+        if (b.profiling) { e0 = get_event(b); hipEventRecord(e0, b.stream); }
+    }
+    ~ProfScope() {
+        if (b.profiling) { hipEvent_t e1 = get_event(b); hipEventRecord(e1, b.stream); b.pending.push_back({e0, e1, cls}); }
+    }
+};
+static void prof_collect(Bank& b) {
+    for (auto& e : b.pending) {
+        float ms = 0.f;
+        hipEventSynchronize(e.b);
+        hipEventElapsedTime(&ms, e.a, e.b);
+        b.prof_ms[e.cls] += ms;
+        b.prof_n[e.cls] += 1;
+        b.ev_pool.push_back(e.a);
+        b.ev_pool.push_back(e.b);
+    }
+    b.pending.clear();
+}
+
+static int bank_init_particles(Bank& b, bool is_reset) {
+    // constructor (src/PFtypes.jl:65-75): x ~ d0, w = log(1/N), j = 1:N, t = 0
+    // reset!      (src/filtering.jl:4-14): x ~ d0, w = -log N, we = 1/N, t = 1   (j untouched)
+    std::vector<FilterScal> h;
+    CHK(scal_download(b, h));
+    BankDev d = b.dev();
+    for (int f = 0; f < b.F; ++f) {
+        FilterScal& s = h[f];
+        s.uniform = 1;
+        s.wconst = is_reset ? d.mlogN : d.log1N;
+        s.norm_pending = 0;
+        s.do_resample = 0;
+        s.status = 0;
+        s.m = 0.0; s.s = 0.0; s.l = 0.0; s.inv = 1.0; s.ll = 0.0; s.e2 = 0.0;
+        s.ess = 0.0;
+        s.K = llpf_qbits(b.N);
+        if (!is_reset) { s.anc_ident = 1; s.last_resampled = 0; s.resample_count = 0; s.ll_total = 0.0; }
+    }
+    CHK(scal_upload(b, h));
+    HIPC(launch_init(d, b.n_reset, is_reset ? 0 : 1, b.stream));
+    b.n_reset++;
+    b.t_index = is_reset ? 1 : 0;
+    HIPC(hipStreamSynchronize(b.stream));
+    return LLPF_OK;
+}
+
+static int bank_create(const llpf_config* cfg, const llpf_model* models, int F, Bank& b) {
+    if (!cfg) return fail(LLPF_ERR_ARG, "null config");
+    if (cfg->struct_size != sizeof(llpf_config)) return fail(LLPF_ERR_ARG, "llpf_config.struct_size mismatch (ABI)");
+    if (F < 1) return fail(LLPF_ERR_ARG, "n_filters must be >= 1");
+    const llpf_model& m0 = models ? models[0] : cfg->model;
+    if (cfg->n_particles < 1 || cfg->n_particles > ((int64_t)1 << 30)) return fail(LLPF_ERR_ARG, "n_particles must be in 1..2^30");
+    if (m0.nx < 1 || m0.nx > MAXD || m0.ny < 1 || m0.ny > MAXD || m0.nu < 0 || m0.nu > MAXD) return fail(LLPF_ERR_ARG, "bad dimensions");
+    if (!step_supported(m0.model_id, m0.nx, m0.ny))
+        return fail(LLPF_ERR_ARG, "no kernel instantiated for this model/dimension (linear-Gaussian nx,ny in 1..4; quad-tank 4/2)");
+    if (cfg->resampling_strategy != LLPF_RESAMPLE_SYSTEMATIC && cfg->resampling_strategy != LLPF_RESAMPLE_STRATIFIED)
+        return fail(LLPF_ERR_ARG, "resampling_strategy must be systematic or stratified");
+    if (!(cfg->resample_threshold >= 0.0 && cfg->resample_threshold <= 1.0)) return fail(LLPF_ERR_ARG, "resample_threshold must be in [0,1]");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(LLPF_ERR_NO_DEVICE, "no HIP device visible; this engine has no CPU fallback");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(LLPF_ERR_ARG, "device ordinal out of range");
+
+    b.cfg = *cfg;
+    b.cfg.model = m0;
+    b.F = F;
+    b.N = cfg->n_particles;
+    b.Ns = (b.N + TILE - 1) / TILE * TILE;
+    b.nx = m0.nx; b.nu = m0.nu; b.ny = m0.ny;
+    b.P1 = (int)(b.Ns / STEP_TILE);
+    b.P2 = (int)(b.Ns / TILE);
+    b.device = cfg->device;
+    std::vector<ModelD> hm(F);
+    for (int f = 0; f < F; ++f) {
+        const llpf_model& mf = models ? models[f] : cfg->model;
+        if (mf.model_id != m0.model_id || mf.nx != m0.nx || mf.nu != m0.nu || mf.ny != m0.ny)
+            return fail(LLPF_ERR_ARG, "all filters of a bank must share model id and dimensions");
+        int rc = model_prepare(&mf, &hm[f]);
+        if (rc) return fail(LLPF_ERR_ARG, "invalid density (covariance not positive definite or dimension mismatch), code " + std::to_string(rc));
+    }
+    HIPC(hipSetDevice(b.device));
+    HIPC(hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking));
+    const size_t FN = (size_t)F * b.Ns;
+    HIPC(hipMalloc(&b.d_models, sizeof(ModelD) * F));
+    HIPC(hipMalloc(&b.d_scal, sizeof(FilterScal) * F));
+    HIPC(hipMalloc(&b.d_x[0], sizeof(double) * FN * b.nx));
+    HIPC(hipMalloc(&b.d_x[1], sizeof(double) * FN * b.nx));
+    HIPC(hipMalloc(&b.d_w, sizeof(double) * FN));
+    HIPC(hipMalloc(&b.d_anc, sizeof(int32_t) * FN));
+    HIPC(hipMalloc(&b.d_pmax, sizeof(double) * (size_t)F * b.P1));
+    HIPC(hipMalloc(&b.d_part, sizeof(NormPartial) * (size_t)F * b.P2));
+    HIPC(hipMalloc(&b.d_uy, sizeof(double) * 4 * MAXD));
+    HIPC(hipMalloc(&b.d_tmp, sizeof(double) * (size_t)F * b.N * (b.nx > 1 ? b.nx : 1) + 64));
+    HIPC(hipMemsetAsync(b.d_x[0], 0, sizeof(double) * FN * b.nx, b.stream));
+    HIPC(hipMemsetAsync(b.d_x[1], 0, sizeof(double) * FN * b.nx, b.stream));
+    HIPC(hipMemsetAsync(b.d_anc, 0, sizeof(int32_t) * FN, b.stream));
+    HIPC(hipMemsetAsync(b.d_scal, 0, sizeof(FilterScal) * F, b.stream));
+    HIPC(hipMemsetAsync(b.d_part, 0, sizeof(NormPartial) * (size_t)F * b.P2, b.stream));
+    HIPC(hipMemcpyAsync(b.d_models, hm.data(), sizeof(ModelD) * F, hipMemcpyHostToDevice, b.stream));
+    HIPC(hipStreamSynchronize(b.stream));
+    HIPC(hipEventCreate(&b.ev_run0));
+    HIPC(hipEventCreate(&b.ev_run1));
+    std::vector<FilterScal> h;
+    CHK(scal_download(b, h));
+    set_keys(b, h, cfg->seed);
+    CHK(scal_upload(b, h));
+    return bank_init_particles(b, false);
+}
+
+static int check_status(Bank& b, std::vector<FilterScal>& h) {
+    for (int f = 0; f < b.F; ++f)
+        if (h[f].status) return fail(h[f].status, "degenerate weights (all -Inf or NaN) in filter " + std::to_string(f));
+    return LLPF_OK;
+}
+
+// ---- single steps -------------------------------------------------------------------------------
+static int bank_correct(Bank& b, const double* u, const double* y, double t, double* ll_out /* [F] */) {
+    CHK(use_device(b));
+    const bool has_y = (y != nullptr) && !(y[0] != y[0]);
+    double hbuf[2 * MAXD] = {0};
+    if (u) for (int i = 0; i < b.nu; ++i) hbuf[i] = u[i];
+    if (has_y) for (int i = 0; i < b.ny; ++i) hbuf[MAXD + i] = y[i];
+    HIPC(hipMemcpyAsync(b.d_uy, hbuf, sizeof(hbuf), hipMemcpyHostToDevice, b.stream));
+    BankDev d = b.dev();
+    StepArgs a{};
+    a.u = b.d_uy; a.y = b.d_uy + MAXD; a.t_prop = t; a.t_meas = t; a.step = 0; a.has_y = has_y ? 1 : 0;
+    HIPC(launch_step(d, MODE_WEIGHT, a, b.stream));
+    HIPC(launch_norm(d, 0, b.stream));
+    FinalizeArgs fa{};
+    fa.ll_steps = nullptr; fa.xmean = nullptr; fa.k = 0; fa.keep_norm = 0; fa.accumulate = 0; fa.after_predict = 0;
+    HIPC(launch_finalize(d, fa, b.stream));
+    std::vector<FilterScal> h;
+    CHK(scal_download(b, h));
+    if (ll_out) for (int f = 0; f < b.F; ++f) ll_out[f] = h[f].ll;
+    return check_status(b, h);
+}
+
+static int bank_predict(Bank& b, const double* u, double t) {
+    CHK(use_device(b));
+    double hbuf[2 * MAXD] = {0};
+    if (u) for (int i = 0; i < b.nu; ++i) hbuf[i] = u[i];
+    HIPC(hipMemcpyAsync(b.d_uy, hbuf, sizeof(hbuf), hipMemcpyHostToDevice, b.stream));
+    BankDev d = b.dev();
+    HIPC(launch_decide(d, b.stream));
+    HIPC(launch_resample(d, b.n_predict, nullptr, b.N, b.d_anc, nullptr, 0, 0, 0, b.stream));
+    StepArgs a{};
+    a.u = b.d_uy; a.y = nullptr; a.t_prop = t; a.t_meas = t; a.step = b.n_predict; a.has_y = 0;
+    HIPC(launch_step(d, MODE_PROP, a, b.stream));
+    HIPC(launch_post_predict(d, b.stream));
+    b.cur ^= 1;
+    b.n_predict++;
+    b.t_index++;
+    HIPC(hipStreamSynchronize(b.stream));
+    return LLPF_OK;
+}
+
+// ---- the trajectory loop ------------------------------------------------------------------------
+static int ensure(double** p, size_t* cap, size_t n) {
+    if (*cap >= n && *p) return LLPF_OK;
+    if (*p) hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    HIPC(hipMalloc(p, sizeof(double) * (n ? n : 1)));
+    *cap = n;
+    return LLPF_OK;
+}
+
+static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double t_index0,
+                    double* ll_total /* [F] */, double* ll_steps /* [T][F] */, double* xmean /* [T][F][nx] */,
+                    double* x_hist, double* w_hist, double* we_hist) {
+    CHK(use_device(b));
+    if (T < 1) return fail(LLPF_ERR_ARG, "T must be >= 1");
+    if (!Y) return fail(LLPF_ERR_ARG, "Y is null");
+    if (b.nu > 0 && !U) return fail(LLPF_ERR_ARG, "U is null");
+    if ((x_hist || w_hist || we_hist) && b.F != 1) return fail(LLPF_ERR_ARG, "history outputs need a single filter");
+    CHK(ensure(&b.d_U, &b.capU, (size_t)T * (b.nu > 0 ? b.nu : 1)));
+    CHK(ensure(&b.d_Y, &b.capY, (size_t)T * b.ny));
+    if (b.nu > 0) HIPC(hipMemcpyAsync(b.d_U, U, sizeof(double) * T * b.nu, hipMemcpyHostToDevice, b.stream));
+    HIPC(hipMemcpyAsync(b.d_Y, Y, sizeof(double) * T * b.ny, hipMemcpyHostToDevice, b.stream));
+    if (ll_steps) CHK(ensure(&b.d_ll_steps, &b.cap_ll, (size_t)T * b.F));
+    if (xmean) CHK(ensure(&b.d_xmean, &b.cap_xm, (size_t)T * b.F * b.nx));
+    {   // zero the running log-likelihood and remember the resample counter
+        std::vector<FilterScal> h;
+        CHK(scal_download(b, h));
+        b.run_resamples = 0;
+        for (int f = 0; f < b.F; ++f) { h[f].ll_total = 0.0; b.run_resamples -= h[f].resample_count; }
+        CHK(scal_upload(b, h));
+    }
+    const double Ts = b.cfg.model.Ts;
+    const int want_xm = xmean ? 1 : 0;
+    auto has_y = [&](int64_t k) { return !(Y[k * b.ny] != Y[k * b.ny]); };
+    auto tk = [&](int64_t k) { return (t_index0 + (double)k) * Ts; };
+
+    HIPC(hipEventRecord(b.ev_run0, b.stream));
+    {   // weighting of the first correct!
+        BankDev d = b.dev();
+        StepArgs a{};
+        a.u = b.nu > 0 ? b.d_U : nullptr; a.y = b.d_Y; a.t_prop = tk(0); a.t_meas = tk(0); a.step = 0; a.has_y = has_y(0) ? 1 : 0;
+        ProfScope ps(b, LLPF_PROF_PROPAGATE);
+        HIPC(launch_step(d, MODE_WEIGHT, a, b.stream));
+    }
+    for (int64_t k = 0; k < T; ++k) {
+        BankDev d = b.dev();
+        {   // logsumexp! of correct!(u_k, y_k)
+            ProfScope ps(b, LLPF_PROF_NORMALISE);
+            HIPC(launch_norm(d, want_xm, b.stream));
+        }
+        {
+            ProfScope ps(b, LLPF_PROF_OTHER);
+            FinalizeArgs fa{};
+            fa.ll_steps = ll_steps ? b.d_ll_steps : nullptr;
+            fa.xmean = xmean ? b.d_xmean : nullptr;
+            fa.k = k; fa.keep_norm = 0; fa.accumulate = 1; fa.after_predict = (k > 0) ? 1 : 0;
+            HIPC(launch_finalize(d, fa, b.stream));
+        }
+        if (x_hist || w_hist || we_hist) {   // forward_trajectory history (reference src/filtering.jl:357-359); not a timed path
+            if (x_hist) {
+                HIPC(launch_soa2aos(d, b.d_x[b.cur], b.d_tmp, b.stream));
+                HIPC(hipMemcpyAsync(x_hist + (size_t)k * b.N * b.nx, b.d_tmp, sizeof(double) * b.N * b.nx, hipMemcpyDeviceToHost, b.stream));
+                HIPC(hipStreamSynchronize(b.stream));
+            }
+            if (w_hist) {
+                HIPC(launch_materialize(d, b.d_tmp, nullptr, b.stream));
+                HIPC(hipMemcpyAsync(w_hist + (size_t)k * b.N, b.d_tmp, sizeof(double) * b.N, hipMemcpyDeviceToHost, b.stream));
+                HIPC(hipStreamSynchronize(b.stream));
+            }
+            if (we_hist) {
+                HIPC(launch_materialize(d, nullptr, b.d_tmp, b.stream));
+                HIPC(hipMemcpyAsync(we_hist + (size_t)k * b.N, b.d_tmp, sizeof(double) * b.N, hipMemcpyDeviceToHost, b.stream));
+                HIPC(hipStreamSynchronize(b.stream));
+            }
+        }
+        {   // predict!(u_k): resample if the device-side decision says so ...
+            ProfScope ps(b, LLPF_PROF_RESAMPLE);
+            HIPC(launch_resample(d, b.n_predict, nullptr, b.N, b.d_anc, nullptr, 0, 0, 0, b.stream));
+        }
+        {   // ... propagate, fused with the weighting of correct!(u_{k+1}, y_{k+1})
+            StepArgs a{};
+            a.u = b.nu > 0 ? b.d_U + k * b.nu : nullptr;
+            a.t_prop = tk(k);
+            a.step = b.n_predict;
+            ProfScope ps(b, LLPF_PROF_PROPAGATE);
+            if (k + 1 < T) {
+                a.y = b.d_Y + (k + 1) * b.ny; a.t_meas = tk(k + 1); a.has_y = has_y(k + 1) ? 1 : 0;
+                HIPC(launch_step(d, MODE_PROP_WEIGHT, a, b.stream));
+            } else {
+                a.y = nullptr; a.t_meas = tk(k); a.has_y = 0;
+                HIPC(launch_step(d, MODE_PROP, a, b.stream));
+            }
+        }
+        b.cur ^= 1;
+        b.n_predict++;
+        b.t_index++;
+    }
+    {
+        BankDev d = b.dev();
+        ProfScope ps(b, LLPF_PROF_OTHER);
+        HIPC(launch_post_predict(d, b.stream));
+    }
+    HIPC(hipEventRecord(b.ev_run1, b.stream));
+    if (ll_steps) HIPC(hipMemcpyAsync(ll_steps, b.d_ll_steps, sizeof(double) * T * b.F, hipMemcpyDeviceToHost, b.stream));
+    if (xmean) HIPC(hipMemcpyAsync(xmean, b.d_xmean, sizeof(double) * T * b.F * b.nx, hipMemcpyDeviceToHost, b.stream));
+    std::vector<FilterScal> h;
+    CHK(scal_download(b, h));
+    float ms = 0.f;
+    HIPC(hipEventElapsedTime(&ms, b.ev_run0, b.ev_run1));
+    b.last_run_ms = ms;
+    if (b.profiling) prof_collect(b);
+    for (int f = 0; f < b.F; ++f) {
+        if (ll_total) ll_total[f] = h[f].ll_total;
+        b.run_resamples += h[f].resample_count;
+    }
+    return check_status(b, h);
+}
+
+// ---- accessors ----------------------------------------------------------------------------------
+static int bank_get_particles(Bank& b, double* dst) {
+    CHK(use_device(b));
+    BankDev d = b.dev();
+    HIPC(launch_soa2aos(d, b.d_x[b.cur], b.d_tmp, b.stream));
+    HIPC(hipMemcpyAsync(dst, b.d_tmp, sizeof(double) * (size_t)b.F * b.N * b.nx, hipMemcpyDeviceToHost, b.stream));
+    HIPC(hipStreamSynchronize(b.stream));
+    return LLPF_OK;
+}
+static int bank_get_w(Bank& b, double* dst, bool expw) {
+    CHK(use_device(b));
+    BankDev d = b.dev();
+    HIPC(launch_materialize(d, expw ? nullptr : b.d_tmp, expw ? b.d_tmp : nullptr, b.stream));
+    HIPC(hipMemcpyAsync(dst, b.d_tmp, sizeof(double) * (size_t)b.F * b.N, hipMemcpyDeviceToHost, b.stream));
+    HIPC(hipStreamSynchronize(b.stream));
+    return LLPF_OK;
+}
+
+static int bank_set_weights(Bank& b, const double* w) {
+    CHK(use_device(b));
+    std::vector<double> stage((size_t)b.F * b.Ns, -INFINITY);
+    for (int f = 0; f < b.F; ++f) memcpy(stage.data() + (size_t)f * b.Ns, w + (size_t)f * b.N, sizeof(double) * b.N);
+    HIPC(hipMemcpyAsync(b.d_w, stage.data(), sizeof(double) * stage.size(), hipMemcpyHostToDevice, b.stream));
+    HIPC(hipStreamSynchronize(b.stream));
+    std::vector<FilterScal> h;
+    CHK(scal_download(b, h));
+    for (auto& s : h) { s.uniform = 0; s.norm_pending = 0; s.status = 0; }
+    CHK(scal_upload(b, h));
+    BankDev d = b.dev();
+    HIPC(launch_max(d, b.stream));
+    HIPC(launch_norm(d, 0, b.stream));
+    FinalizeArgs fa{};
+    fa.keep_norm = 1; fa.accumulate = 0; fa.after_predict = 0;
+    HIPC(launch_finalize(d, fa, b.stream));
+    CHK(scal_download(b, h));
+    return check_status(b, h);
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* llpf_last_error(void) { return g_err.c_str(); }
+
+int llpf_version(int32_t* major, int32_t* minor) {
+    if (major) *major = LLPF_VERSION_MAJOR;
+    if (minor) *minor = LLPF_VERSION_MINOR;
+    return LLPF_OK;
+}
+
+int llpf_device_count(int32_t* n) {
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) c = 0;
+    if (n) *n = c;
+    return LLPF_OK;
+}
+
+int llpf_create(const llpf_config* cfg, llpf_filter** out) {
+    if (!out) return fail(LLPF_ERR_ARG, "null out pointer");
+    *out = nullptr;
+    llpf_filter* f = new (std::nothrow) llpf_filter();
+    if (!f) return fail(LLPF_ERR_ALLOC, "out of host memory");
+    int rc = bank_create(cfg, nullptr, 1, f->bank);
+    if (rc != LLPF_OK) { free_bank(f->bank); delete f; return rc; }
+    *out = f;
+    return LLPF_OK;
+}
+int llpf_destroy(llpf_filter* f) {
+    if (!f) return LLPF_OK;
+    free_bank(f->bank);
+    delete f;
+    return LLPF_OK;
+}
+#define NEEDF(f) if (!(f)) return fail(LLPF_ERR_ARG, "null handle")
+
+int llpf_reset(llpf_filter* f) { NEEDF(f); CHK(use_device(f->bank)); return bank_init_particles(f->bank, true); }
+
+static int bank_seed(Bank& b, uint64_t seed) {
+    CHK(use_device(b));
+    std::vector<FilterScal> h;
+    CHK(scal_download(b, h));
+    set_keys(b, h, seed);
+    return scal_upload(b, h);
+}
+int llpf_seed(llpf_filter* f, uint64_t seed) { NEEDF(f); return bank_seed(f->bank, seed); }
+
+int llpf_correct(llpf_filter* f, const double* u, const double* y, double t, double* ll) {
+    NEEDF(f);
+    double l = 0.0;
+    int rc = bank_correct(f->bank, u, y, t, &l);
+    if (ll) *ll = l;
+    return rc;
+}
+int llpf_predict(llpf_filter* f, const double* u, double t) { NEEDF(f); return bank_predict(f->bank, u, t); }
+int llpf_update(llpf_filter* f, const double* u, const double* y, double t, double* ll) {
+    NEEDF(f);
+    int rc = llpf_correct(f, u, y, t, ll);
+    if (rc != LLPF_OK) return rc;
+    return bank_predict(f->bank, u, t);
+}
+
+int llpf_run(llpf_filter* f, const double* U, const double* Y, int64_t T, double t_index0,
+             double* ll_total, const llpf_run_outputs* o) {
+    NEEDF(f);
+    double lt = 0.0;
+    int rc = bank_run(f->bank, U, Y, T, t_index0, &lt, o ? o->ll_steps : nullptr, o ? o->xmean : nullptr,
+                      o ? o->x_hist : nullptr, o ? o->w_hist : nullptr, o ? o->we_hist : nullptr);
+    if (ll_total) *ll_total = lt;
+    return rc;
+}
+
+int llpf_num_particles(const llpf_filter* f, int64_t* n) { NEEDF(f); if (n) *n = f->bank.N; return LLPF_OK; }
+int llpf_index(const llpf_filter* f, int64_t* t) { NEEDF(f); if (t) *t = f->bank.t_index; return LLPF_OK; }
+int llpf_set_index(llpf_filter* f, int64_t t) { NEEDF(f); f->bank.t_index = t; return LLPF_OK; }
+int llpf_get_particles(llpf_filter* f, double* dst) { NEEDF(f); return bank_get_particles(f->bank, dst); }
+int llpf_get_weights(llpf_filter* f, double* dst) { NEEDF(f); return bank_get_w(f->bank, dst, false); }
+int llpf_get_expweights(llpf_filter* f, double* dst) { NEEDF(f); return bank_get_w(f->bank, dst, true); }
+
+int llpf_get_ancestors(llpf_filter* f, int64_t* dst) {
+    NEEDF(f);
+    Bank& b = f->bank;
+    CHK(use_device(b));
+    HIPC(launch_anc64(b.dev(), reinterpret_cast<int64_t*>(b.d_tmp), b.stream));
+    HIPC(hipMemcpyAsync(dst, b.d_tmp, sizeof(int64_t) * b.N, hipMemcpyDeviceToHost, b.stream));
+    HIPC(hipStreamSynchronize(b.stream));
+    return LLPF_OK;
+}
+int llpf_get_bins(llpf_filter* f, double* dst) {
+    NEEDF(f);
+    Bank& b = f->bank;
+    CHK(use_device(b));
+    BankDev d = b.dev();
+    HIPC(launch_decide(d, b.stream));
+    HIPC(launch_resample(d, b.n_predict, nullptr, b.N, b.d_anc, b.d_tmp, 1, 1, 0, b.stream));
+    HIPC(hipMemcpyAsync(dst, b.d_tmp, sizeof(double) * b.N, hipMemcpyDeviceToHost, b.stream));
+    HIPC(hipStreamSynchronize(b.stream));
+    return LLPF_OK;
+}
+int llpf_set_particles(llpf_filter* f, const double* src) {
+    NEEDF(f);
+    Bank& b = f->bank;
+    CHK(use_device(b));
+    HIPC(hipMemcpyAsync(b.d_tmp, src, sizeof(double) * b.N * b.nx, hipMemcpyHostToDevice, b.stream));
+    HIPC(launch_aos2soa(b.dev(), b.d_tmp, b.d_x[b.cur], b.stream));
+    HIPC(hipStreamSynchronize(b.stream));
+    return LLPF_OK;
+}
+int llpf_set_weights(llpf_filter* f, const double* w) { NEEDF(f); return bank_set_weights(f->bank, w); }
+
+static int scal0(llpf_filter* f, FilterScal* out, bool decide) {
+    Bank& b = f->bank;
+    CHK(use_device(b));
+    if (decide) HIPC(launch_decide(b.dev(), b.stream));
+    std::vector<FilterScal> h;
+    CHK(scal_download(b, h));
+    *out = h[0];
+    return LLPF_OK;
+}
+int llpf_effective_particles(llpf_filter* f, double* ess) {
+    NEEDF(f);
+    FilterScal s;
+    CHK(scal0(f, &s, true));
+    if (ess) *ess = s.ess;
+    return LLPF_OK;
+}
+int llpf_shouldresample(llpf_filter* f, int32_t* yes) {
+    NEEDF(f);
+    FilterScal s;
+    CHK(scal0(f, &s, true));
+    if (yes) *yes = s.do_resample;
+    return LLPF_OK;
+}
+int llpf_last_resampled(llpf_filter* f, int32_t* yes) {
+    NEEDF(f);
+    FilterScal s;
+    CHK(scal0(f, &s, false));
+    if (yes) *yes = s.last_resampled;
+    return LLPF_OK;
+}
+int llpf_maxw(llpf_filter* f, double* maxw) {
+    NEEDF(f);
+    FilterScal s;
+    CHK(scal0(f, &s, false));
+    if (maxw) *maxw = s.m;
+    return LLPF_OK;
+}
+int llpf_weighted_mean(llpf_filter* f, double* xh) {
+    NEEDF(f);
+    Bank& b = f->bank;
+    CHK(use_device(b));
+    HIPC(launch_wmean(b.dev(), b.d_tmp, b.stream));
+    HIPC(hipMemcpyAsync(xh, b.d_tmp, sizeof(double) * b.nx, hipMemcpyDeviceToHost, b.stream));
+    HIPC(hipStreamSynchronize(b.stream));
+    return LLPF_OK;
+}
+int llpf_resample_count(llpf_filter* f, int64_t* n) { NEEDF(f); if (n) *n = f->bank.run_resamples; return LLPF_OK; }
+int llpf_last_run_ms(llpf_filter* f, double* ms) { NEEDF(f); if (ms) *ms = f->bank.last_run_ms; return LLPF_OK; }
+
+static int set_prof(Bank& b, int on) {
+    b.profiling = on != 0;
+    for (int i = 0; i < LLPF_PROF_CLASSES; ++i) { b.prof_ms[i] = 0.0; b.prof_n[i] = 0; }
+    return LLPF_OK;
+}
+static int get_prof(Bank& b, double* ms, int64_t* n) {
+    for (int i = 0; i < LLPF_PROF_CLASSES; ++i) { if (ms) ms[i] = b.prof_ms[i]; if (n) n[i] = b.prof_n[i]; }
+    return LLPF_OK;
+}
+int llpf_set_profiling(llpf_filter* f, int32_t on) { NEEDF(f); return set_prof(f->bank, on); }
+int llpf_get_profile(llpf_filter* f, double* ms, int64_t* n) { NEEDF(f); return get_prof(f->bank, ms, n); }
+
+// ---- banks ---------------------------------------------------------------------------------------
+int llpf_bank_create(const llpf_config* base, const llpf_model* models, int32_t n_filters, llpf_bank** out) {
+    if (!out) return fail(LLPF_ERR_ARG, "null out pointer");
+    *out = nullptr;
+    if (!models) return fail(LLPF_ERR_ARG, "null models");
+    llpf_bank* b = new (std::nothrow) llpf_bank();
+    if (!b) return fail(LLPF_ERR_ALLOC, "out of host memory");
+    int rc = bank_create(base, models, n_filters, b->bank);
+    if (rc != LLPF_OK) { free_bank(b->bank); delete b; return rc; }
+    *out = b;
+    return LLPF_OK;
+}
+int llpf_bank_destroy(llpf_bank* b) {
+    if (!b) return LLPF_OK;
+    free_bank(b->bank);
+    delete b;
+    return LLPF_OK;
+}
+int llpf_bank_reset(llpf_bank* b) { NEEDF(b); CHK(use_device(b->bank)); return bank_init_particles(b->bank, true); }
+int llpf_bank_seed(llpf_bank* b, uint64_t seed) { NEEDF(b); return bank_seed(b->bank, seed); }
+int llpf_bank_run(llpf_bank* b, const double* U, const double* Y, int64_t T, double t_index0,
+                  double* ll_total, double* ll_steps) {
+    NEEDF(b);
+    return bank_run(b->bank, U, Y, T, t_index0, ll_total, ll_steps, nullptr, nullptr, nullptr, nullptr);
+}
+int llpf_bank_set_profiling(llpf_bank* b, int32_t on) { NEEDF(b); return set_prof(b->bank, on); }
+int llpf_bank_get_profile(llpf_bank* b, double* ms, int64_t* n) { NEEDF(b); return get_prof(b->bank, ms, n); }
+int llpf_bank_resample_count(llpf_bank* b, int64_t* n) { NEEDF(b); if (n) *n = b->bank.run_resamples; return LLPF_OK; }
+int llpf_bank_last_run_ms(llpf_bank* b, double* ms) { NEEDF(b); if (ms) *ms = b->bank.last_run_ms; return LLPF_OK; }
+
+// ---- array primitives ------------------------------------------------------------------------------
+// a scratch single-filter context with a dummy 1-D model, used for weights-only operations
+static int scratch_bank(int32_t device, int64_t n, int strategy, std::unique_ptr<llpf_filter>& out) {
+    llpf_config c;
+    memset(&c, 0, sizeof(c));
+    c.struct_size = sizeof(c);
+    c.n_particles = n;
+    c.resampling_strategy = strategy;
+    c.device = device;
+    c.resample_threshold = 0.1;
+    c.seed = 0;
+    llpf_model& m = c.model;
+    m.model_id = LLPF_MODEL_LINEAR_GAUSSIAN;
+    m.nx = 1; m.nu = 0; m.ny = 1;
+    m.A[0] = 1.0; m.C[0] = 1.0; m.Ts = 1.0; m.supersample = 1;
+    llpf_gaussian g;
+    memset(&g, 0, sizeof(g));
+    g.dim = 1; g.kind = LLPF_COV_SCAL; g.cov[0] = 1.0;
+    m.dynamics_density = g; m.measurement_density = g; m.initial_density = g;
+    out.reset(new (std::nothrow) llpf_filter());
+    if (!out) return fail(LLPF_ERR_ALLOC, "out of host memory");
+    int rc = bank_create(&c, nullptr, 1, out->bank);
+    if (rc != LLPF_OK) { free_bank(out->bank); out.reset(); }
+    return rc;
+}
+
+int llpf_logsumexp(int32_t device, double* w, double* we, int64_t n, double* ll) {
+    if (!w || n < 1) return fail(LLPF_ERR_ARG, "bad arguments");
+    std::unique_ptr<llpf_filter> h;
+    CHK(scratch_bank(device, n, LLPF_RESAMPLE_SYSTEMATIC, h));
+    Bank& b = h->bank;
+    int rc = bank_set_weights(b, w);
+    if (rc == LLPF_OK) {
+        std::vector<FilterScal> s;
+        rc = scal_download(b, s);
+        if (rc == LLPF_OK) {
+            if (ll) *ll = s[0].ll;
+            s[0].norm_pending = 1;     // logsumexp! normalises w in place
+            rc = scal_upload(b, s);
+        }
+        if (rc == LLPF_OK) rc = bank_get_w(b, w, false);
+        if (rc == LLPF_OK && we) rc = bank_get_w(b, we, true);
+    }
+    free_bank(b);
+    return rc;
+}
+
+int llpf_resample(int32_t device, int32_t strategy, const double* we, int64_t n, int64_t m, const double* U, int64_t* j) {
+    if (!we || !U || !j || n < 1 || m < 1) return fail(LLPF_ERR_ARG, "bad arguments");
+    if (m > ((int64_t)1 << 30)) return fail(LLPF_ERR_ARG, "m too large");
+    std::unique_ptr<llpf_filter> h;
+    CHK(scratch_bank(device, n, strategy, h));
+    Bank& b = h->bank;
+    int rc = LLPF_OK;
+    int32_t* d_j = nullptr;
+    double* d_U = nullptr;
+    auto body = [&]() -> int {
+        std::vector<double> stage((size_t)b.Ns, 0.0);
+        memcpy(stage.data(), we, sizeof(double) * n);
+        HIPC(hipMemcpyAsync(b.d_w, stage.data(), sizeof(double) * b.Ns, hipMemcpyHostToDevice, b.stream));
+        const int64_t cap = (m > b.Ns ? m : b.Ns);
+        std::vector<int32_t> j32((size_t)cap, 0);
+        for (int64_t i = 0; i < m; ++i) j32[i] = (int32_t)j[i];
+        HIPC(hipMalloc(&d_j, sizeof(int32_t) * cap));
+        HIPC(hipMemcpyAsync(d_j, j32.data(), sizeof(int32_t) * cap, hipMemcpyHostToDevice, b.stream));
+        const int64_t nU = (strategy == LLPF_RESAMPLE_SYSTEMATIC) ? 1 : m;
+        HIPC(hipMalloc(&d_U, sizeof(double) * nU));
+        HIPC(hipMemcpyAsync(d_U, U, sizeof(double) * nU, hipMemcpyHostToDevice, b.stream));
+        std::vector<FilterScal> s;
+        CHK(scal_download(b, s));
+        s[0].uniform = 0; s[0].anc_ident = 0; s[0].status = 0; s[0].do_resample = 1;
+        CHK(scal_upload(b, s));
+        // ancestors are written relative to a row of stride Ns; the scratch bank has one filter, so row 0
+        HIPC(launch_resample(b.dev(), 0, d_U, m, d_j, nullptr, 0, 1, 1, b.stream));
+        HIPC(hipMemcpyAsync(j32.data(), d_j, sizeof(int32_t) * m, hipMemcpyDeviceToHost, b.stream));
+        HIPC(hipStreamSynchronize(b.stream));
+        for (int64_t i = 0; i < m; ++i) j[i] = j32[i];
+        return LLPF_OK;
+    };
+    rc = body();
+    if (d_j) hipFree(d_j);
+    if (d_U) hipFree(d_U);
+    free_bank(b);
+    return rc;
+}
+
+int llpf_resample_uniforms(int32_t strategy, int64_t m, uint64_t seed, uint32_t step, double* u) {
+    if (!u) return fail(LLPF_ERR_ARG, "null output");
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    if (strategy == LLPF_RESAMPLE_SYSTEMATIC) u[0] = llpf_uniform_step(step, LLPF_STREAM_RESAMPLE, k0, k1);
+    else for (int64_t i = 0; i < m; ++i) u[i] = llpf_uniform_idx((uint32_t)i, step, LLPF_STREAM_STRATIFY, k0, k1);
+    return LLPF_OK;
+}
+
+// ---- device self-tests of the shared primitives ---------------------------------------------------
+int llpf_selftest_math(int32_t device, int32_t which, const double* in, double* out, int64_t n) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(LLPF_ERR_NO_DEVICE, "no HIP device visible");
+    HIPC(hipSetDevice(device));
+    double *di = nullptr, *dout = nullptr;
+    HIPC(hipMalloc(&di, sizeof(double) * n));
+    HIPC(hipMalloc(&dout, sizeof(double) * n));
+    HIPC(hipMemcpy(di, in, sizeof(double) * n, hipMemcpyHostToDevice));
+    HIPC(launch_selftest_math(which, di, dout, n, nullptr));
+    HIPC(hipDeviceSynchronize());
+    HIPC(hipMemcpy(out, dout, sizeof(double) * n, hipMemcpyDeviceToHost));
+    hipFree(di);
+    hipFree(dout);
+    return LLPF_OK;
+}
+int llpf_selftest_normals(int32_t device, uint64_t seed, uint32_t step, uint32_t stream, int32_t nd, double* out, int64_t n) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(LLPF_ERR_NO_DEVICE, "no HIP device visible");
+    if (nd < 1 || nd > MAXD) return fail(LLPF_ERR_ARG, "nd out of range");
+    HIPC(hipSetDevice(device));
+    double* dout = nullptr;
+    HIPC(hipMalloc(&dout, sizeof(double) * n * nd));
+    HIPC(launch_selftest_normals((uint32_t)seed, (uint32_t)(seed >> 32), step, stream, nd, dout, n, nullptr));
+    HIPC(hipDeviceSynchronize());
+    HIPC(hipMemcpy(out, dout, sizeof(double) * n * nd, hipMemcpyDeviceToHost));
+    hipFree(dout);
+    return LLPF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,151 @@
+// engine.hpp — device-side data layout and kernel launch interface of the gfx950 particle-filter
+// engine.  Included by kernels.hip (device code) and capi.hip (host orchestration + C ABI).
+//
+// HBM layout (per bank of F independent filters of N particles each; a single filter is F = 1):
+//   x      [2][F][NX][Ns]  fp64  particles, structure-of-arrays, ping-pong (cur / prev) instead of the
+//                                reference's copyto!(xprev, x) (reference src/filtering.jl:151)
+//   w      [F][Ns]         fp64  log-weights as last written by a weighting kernel ("raw"; the
+//                                normalisation (w - m) - l of reference src/utils.jl:20,24 is applied
+//                                lazily by whoever reads them, using the per-filter scalars)
+//   anc    [F][Ns]         i32   ancestor indices j (reference src/PFtypes.jl:14, Int64 there)
+//   pmax   [F][P1]         fp64  per-block maxima of w written by the weighting kernel
+//   part   [F][P2]         NormPartial   per-tile fixed-point sums written by the normalise kernel
+//   scal   [F]             FilterScal    per-filter scalars (maxw, log1p(s), 1/(s+1), ESS, flags, ...)
+// Ns = N rounded up to a multiple of TILE (padding lanes carry zero weight).
+// The exp-weights `we` and the cumulative `bins` of the reference (src/PFtypes.jl:12,15) are never
+// stored: they are recomputed from w in registers where needed.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/llpf.h"
+#include "shared/llpf_detmath.h"
+#include "shared/llpf_fixed.h"
+#include "shared/llpf_philox.h"
+
+namespace llpf {
+
+constexpr int MAXD = LLPF_MAX_DIM;
+constexpr int BLOCK = 256;            // 4 wave64 per workgroup
+constexpr int STEP_PPT = 2;           // particles per thread per iteration in the step kernel (16-B vectors)
+constexpr int STEP_ITERS = 2;         // iterations per block  -> 1024 particles per block
+constexpr int STEP_TILE = BLOCK * STEP_PPT * STEP_ITERS;
+constexpr int NORM_IPT = 8;           // items per thread in normalise / resample kernels
+constexpr int TILE = BLOCK * NORM_IPT;   // 2048 particles per tile: normalise and resample MUST share it
+
+// derived Gaussian (host-prepared): mirrors oracle/llpf_oracle.c:gaussd field for field
+struct GaussD {
+    int32_t dim, kind;
+    double mu[MAXD];
+    double L[MAXD * MAXD];
+    double scal, sqrtscal;
+    double diag[MAXD], invdiag[MAXD], sqrtdiag[MAXD];
+    double c0;
+};
+
+struct ModelD {
+    int32_t model_id, nx, nu, ny;
+    double A[MAXD * MAXD], B[MAXD * MAXD], C[MAXD * MAXD];
+    double qt[LLPF_QT_COUNT];
+    int32_t supersample, pad0;
+    double Ts;
+    GaussD df, dg, d0;
+};
+
+// per-tile partial sums of the normalise kernel (all integer => order independent)
+struct NormPartial {
+    uint64_t S_lo, S_hi;      // sum fix96(e_i)
+    uint64_t E2_lo, E2_hi;    // sum fix96(e_i^2)
+    uint64_t Q;               // sum q64(e_i, K)
+    uint64_t bad;             // number of NaN exp-weights seen
+    double xm[MAXD];          // sum e_i * x_i[d]  (fp64, fixed order; output only, never fed back)
+};
+
+struct FilterScal {
+    double m;            // maxw: offset of the last normalisation (reference state.maxw[])
+    double s;            // sum_{i != argmax} exp(w_i - m)
+    double l;            // log1p(s)
+    double inv;          // 1/(s+1)
+    double ll;           // l + m : log-likelihood increment of the last correct!
+    double ess;          // effective_particles of the current weights
+    double e2;           // sum exp(w_i - m)^2
+    double wconst;       // value of the uniform log-weights (when uniform != 0)
+    double ll_total;     // running sum of ll over a run
+    uint64_t totQ;       // sum_i q64(e_i, K): total of the resampling bins
+    int32_t K;           // fraction bits of the resampling bins
+    int32_t uniform;     // weights are uniform (after reset! / after a resampling predict!)
+    int32_t norm_pending;// w holds raw values; normalised value is (w - m) - l
+    int32_t do_resample; // decision of shouldresample for the next propagate
+    int32_t anc_ident;   // state.j == 1:N (last predict! did not resample)
+    int32_t status;      // 0 ok, LLPF_ERR_DEGENERATE
+    int32_t last_resampled;
+    int32_t pad0;
+    int64_t resample_count;
+    uint32_t k0, k1;     // Philox key of this filter
+};
+
+// arguments common to the step-path kernels
+struct BankDev {
+    int64_t N;           // particles per filter
+    int64_t Ns;          // padded stride
+    int32_t F;           // filters
+    int32_t nx, nu, ny;
+    int32_t strategy;
+    int32_t model_id;
+    int32_t P1;          // step-kernel blocks per filter (pmax entries)
+    int32_t P2;          // tiles per filter (NormPartial entries)
+    double thr;          // resample_threshold
+    double log1N;        // log(1/N)   (reset_weights!, reference src/utils.jl:75)
+    double mlogN;        // -log(N)    (reset!,         reference src/filtering.jl:11)
+    const ModelD* models;
+    FilterScal* scal;
+    double* xcur;        // [F][NX][Ns] current particles (read by propagate, by weight-only)
+    double* xnext;       // [F][NX][Ns] written by propagate
+    double* w;           // [F][Ns]
+    int32_t* anc;        // [F][Ns]
+    double* pmax;        // [F][P1]
+    NormPartial* part;   // [F][P2]
+};
+
+enum StepMode { MODE_WEIGHT = 0, MODE_PROP = 1, MODE_PROP_WEIGHT = 2 };
+
+struct StepArgs {
+    const double* u;       // device pointer to u of the propagate (nu doubles) or nullptr
+    const double* y;       // device pointer to y of the weighting (ny doubles)
+    double t_prop;         // time passed to dynamics
+    double t_meas;         // time passed to measurement
+    uint32_t step;         // Philox step counter of this predict!
+    int32_t has_y;         // 0: measurement missing (weights pass through)
+};
+
+struct FinalizeArgs {
+    double* ll_steps;      // [T][F] or nullptr
+    double* xmean;         // [T][F][nx] or nullptr
+    int64_t k;             // step index into ll_steps / xmean
+    int32_t keep_norm;     // 1: leave norm_pending = 0 (set_weights path: w stays as installed)
+    int32_t accumulate;    // 1: ll_total += ll
+    int32_t after_predict; // 1: a predict! ran since the last finalize: do its bookkeeping (state.j, resample count)
+};
+
+// launchers (kernels.hip)
+hipError_t launch_init(const BankDev& b, uint32_t step, int init_anc, hipStream_t s);
+hipError_t launch_wmean(const BankDev& b, double* out /* [F][nx] */, hipStream_t s);
+hipError_t launch_step(const BankDev& b, int mode, const StepArgs& a, hipStream_t s);
+hipError_t launch_max(const BankDev& b, hipStream_t s);                       // fills pmax from current w state
+hipError_t launch_norm(const BankDev& b, int want_xmean, hipStream_t s);
+hipError_t launch_finalize(const BankDev& b, const FinalizeArgs& a, hipStream_t s);
+hipError_t launch_decide(const BankDev& b, hipStream_t s);
+hipError_t launch_post_predict(const BankDev& b, hipStream_t s);
+hipError_t launch_resample(const BankDev& b, uint32_t step, const double* Uexp, int64_t M,
+                           int32_t* anc_out, double* bins_out, int only_bins, int force, int src_values, hipStream_t s);
+hipError_t launch_materialize(const BankDev& b, double* w_out, double* we_out, hipStream_t s);
+hipError_t launch_soa2aos(const BankDev& b, const double* xsrc, double* dst, hipStream_t s);
+hipError_t launch_aos2soa(const BankDev& b, const double* src, double* xdst, hipStream_t s);
+hipError_t launch_anc64(const BankDev& b, int64_t* dst, hipStream_t s);
+hipError_t launch_selftest_math(int which, const double* in, double* out, int64_t n, hipStream_t s);
+hipError_t launch_selftest_normals(uint32_t k0, uint32_t k1, uint32_t step, uint32_t stream, int nd,
+                                   double* out, int64_t n, hipStream_t s);
+bool step_supported(int model_id, int nx, int ny);
+
+}  // namespace llpf

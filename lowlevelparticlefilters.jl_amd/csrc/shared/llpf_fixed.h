@@ -1,0 +1,100 @@
+/* llpf_fixed.h — order-independent accumulation of exp-weights, shared by host and device.
+ *
+ * The reference normalises weights with fp64 sums whose rounding depends on summation order
+ * (pairwise sum, reference src/utils.jl:66-71; strictly serial cumsum, reference
+ * src/resample.jl:19-22).  A GPU cannot reproduce a serial rounding sequence, and a parallel
+ * fp64 tree would make results depend on launch geometry.  This engine instead converts each
+ * exp-weight e = exp(w - max w) in [0,1] to fixed point and sums integers, which is
+ * associative: any blocking on any machine gives the same bits.
+ *
+ *   fix96(e)  = floor(e * 2^96)  as a 128-bit integer  -> sum_i e_i   (logsumexp, ESS)
+ *   q64(e, K) = floor(e * 2^K)   as a  64-bit integer  -> cumulative bins for resampling,
+ *               K = 62 - ceil(log2 N) so that the total fits 63 bits
+ *
+ * fix96 keeps every bit of any e >= 2^-44 and truncates below 2^-96; the resulting sums are
+ * *more* accurate than any fp64 summation order.
+ */
+#ifndef LLPF_FIXED_H
+#define LLPF_FIXED_H
+
+#include "llpf_detmath.h"
+
+typedef struct { uint64_t lo, hi; } llpf_u128;
+
+LLPF_HD llpf_u128 llpf_u128_add(llpf_u128 a, llpf_u128 b) {
+    llpf_u128 r;
+    r.lo = a.lo + b.lo;
+    r.hi = a.hi + b.hi + (r.lo < a.lo ? 1u : 0u);
+    return r;
+}
+
+/* floor(e * 2^96) for 0 <= e < 2^31 (e is an exp-weight <= 1 or its square) */
+LLPF_HD llpf_u128 llpf_fix96(double e) {
+    llpf_u128 r; r.lo = 0; r.hi = 0;
+    uint64_t u = llpf_d2u(e);
+    int E = (int)(u >> 52) & 0x7ff;
+    if (E == 0 || E == 0x7ff || (u >> 63)) return r; /* zero / subnormal / negative / inf / NaN -> 0 */
+    uint64_t M = (u & 0x000fffffffffffffULL) | 0x0010000000000000ULL;
+    int sh = E - 979;                                /* e*2^96 = M * 2^(E-1075+96) */
+    if (sh >= 0) {
+        if (sh >= 64) { r.hi = M << (sh - 64); }
+        else { r.lo = M << sh; r.hi = sh ? (M >> (64 - sh)) : 0; }
+    } else {
+        int rs = -sh;
+        r.lo = rs >= 53 ? 0 : (M >> rs);
+    }
+    return r;
+}
+
+/* floor(e * 2^K) for 0 <= e <= 1, 0 <= K <= 62 */
+LLPF_HD uint64_t llpf_q64(double e, int K) {
+    uint64_t u = llpf_d2u(e);
+    int E = (int)(u >> 52) & 0x7ff;
+    if (E == 0 || E == 0x7ff || (u >> 63)) return 0;
+    uint64_t M = (u & 0x000fffffffffffffULL) | 0x0010000000000000ULL;
+    int sh = E - 1075 + K;
+    if (sh >= 0) return M << sh;                     /* e <= 1, K <= 62  =>  sh <= 10 */
+    int rs = -sh;
+    return rs >= 53 ? 0 : (M >> rs);
+}
+
+/* number of fraction bits used for the 64-bit resampling bins of an N-particle filter */
+LLPF_HD int llpf_qbits(int64_t n) {
+    int lg = 0;
+    while (((int64_t)1 << lg) < n) ++lg;
+    return 62 - lg;
+}
+
+LLPF_HD int llpf_clz64(uint64_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __clzll((long long)x);
+#else
+    return __builtin_clzll(x);
+#endif
+}
+
+/* round-to-nearest-even conversion of a 128-bit unsigned integer to double */
+LLPF_HD double llpf_u128_to_double(llpf_u128 a) {
+    if (a.hi == 0) return (double)a.lo;
+    int z = llpf_clz64(a.hi);
+    uint64_t top = z ? ((a.hi << z) | (a.lo >> (64 - z))) : a.hi;
+    uint64_t rest = z ? (a.lo << z) : a.lo;
+    if (rest) top |= 1;                              /* sticky bit (11 guard bits below the mantissa) */
+    /* value = top * 2^(64 - z) */
+    return (double)top * llpf_pow2i(64 - z);
+}
+
+/* value of a fix96 accumulator: acc * 2^-96 */
+LLPF_HD double llpf_fix96_to_double(llpf_u128 a) {
+    return llpf_u128_to_double(a) * llpf_pow2i(-96);
+}
+
+/* a - 2^96 (caller guarantees a >= 2^96): removes the maximum's exp(0) = 1 exactly,
+ * the integer analogue of sum_all_but (reference src/utils.jl:66-71) */
+LLPF_HD llpf_u128 llpf_fix96_minus_one(llpf_u128 a) {
+    llpf_u128 r = a;
+    r.hi -= ((uint64_t)1 << 32);
+    return r;
+}
+
+#endif /* LLPF_FIXED_H */

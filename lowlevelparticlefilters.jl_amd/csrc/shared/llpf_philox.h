@@ -1,0 +1,98 @@
+/* llpf_philox.h — Philox4x32-10 counter-based RNG + fp64 uniform / normal transforms,
+ * shared bit-for-bit by the HIP kernels and the device-order oracle.
+ *
+ * The reference draws process noise sequentially from a per-filter Xoshiro via ziggurat
+ * randn (reference src/PFtypes.jl:30,135) and the resampling offset from the *global* RNG
+ * (reference src/resample.jl:23,49); no reference test pins either stream (SURVEY.md §8c:
+ * "parity unpinned"), and a sequential stream cannot be consumed by 10^6 particles in
+ * parallel.  This engine therefore defines its own stream: Philox4x32-10 (Salmon et al.,
+ * SC'11), pinned by the published Random123 known-answer vectors in tests/test_philox.py.
+ *
+ *   key     = (seed_lo, seed_hi)
+ *   counter = (particle index, step counter, sub-block, stream id)
+ */
+#ifndef LLPF_PHILOX_H
+#define LLPF_PHILOX_H
+
+#include "llpf_detmath.h"
+
+enum {
+    LLPF_STREAM_INIT     = 0,   /* reset!: x0 ~ d0                      (filtering.jl:4-14)   */
+    LLPF_STREAM_DYNAMICS = 1,   /* process noise in propagate_particles! (PFtypes.jl:122-139) */
+    LLPF_STREAM_RESAMPLE = 2,   /* systematic offset rand()              (resample.jl:23)     */
+    LLPF_STREAM_STRATIFY = 3,   /* stratified per-stratum rand()         (resample.jl:49)     */
+    LLPF_STREAM_MEASURE  = 4    /* host-side simulate() measurement noise                     */
+};
+
+typedef struct { uint32_t v[4]; } llpf_philox4;
+
+LLPF_HD llpf_philox4 llpf_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                        uint32_t k0, uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)M0 * c0;
+        uint64_t p1 = (uint64_t)M1 * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += W0; k1 += W1;
+    }
+    llpf_philox4 o;
+    o.v[0] = c0; o.v[1] = c1; o.v[2] = c2; o.v[3] = c3;
+    return o;
+}
+
+/* 53-bit uniforms: u_open in (0,1]  (safe for log),  u_half in [0,1) */
+LLPF_HD double llpf_u01_open(uint32_t lo, uint32_t hi) {
+    uint64_t a = ((uint64_t)hi << 32) | lo;
+    return (double)((a >> 11) + 1) * 1.1102230246251565e-16;   /* 2^-53 */
+}
+LLPF_HD double llpf_u01_half(uint32_t lo, uint32_t hi) {
+    uint64_t a = ((uint64_t)hi << 32) | lo;
+    return (double)(a >> 11) * 1.1102230246251565e-16;
+}
+
+/* one Philox block -> two independent N(0,1) draws (Box–Muller on deterministic log/sqrt/sincos) */
+LLPF_HD void llpf_normal_pair(uint32_t idx, uint32_t step, uint32_t sub, uint32_t stream,
+                              uint32_t k0, uint32_t k1, double* z0, double* z1) {
+    llpf_philox4 r = llpf_philox4x32_10(idx, step, sub, stream, k0, k1);
+    double u1 = llpf_u01_open(r.v[0], r.v[1]);
+    double u2 = llpf_u01_half(r.v[2], r.v[3]);
+    double rad = llpf_sqrt(-2.0 * llpf_log(u1));
+    double sn, cs;
+    llpf_sincos2pi(u2, &sn, &cs);
+    *z0 = rad * cs;
+    *z1 = rad * sn;
+}
+
+/* nd standard normals for particle idx at a step: dims (2b, 2b+1) come from sub-block b */
+LLPF_HD void llpf_normals(uint32_t idx, uint32_t step, uint32_t stream, uint32_t k0, uint32_t k1,
+                          int nd, double* xi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int b = 0; 2 * b < nd; ++b) {
+        double z0, z1;
+        llpf_normal_pair(idx, step, (uint32_t)b, stream, k0, k1, &z0, &z1);
+        xi[2 * b] = z0;
+        if (2 * b + 1 < nd) xi[2 * b + 1] = z1;
+    }
+}
+
+/* the single uniform a systematic resample consumes at a step */
+LLPF_HD double llpf_uniform_step(uint32_t step, uint32_t stream, uint32_t k0, uint32_t k1) {
+    llpf_philox4 r = llpf_philox4x32_10(0u, step, 0u, stream, k0, k1);
+    return llpf_u01_half(r.v[0], r.v[1]);
+}
+/* per-stratum uniform for stratified resampling (stratum index i0 is 0-based) */
+LLPF_HD double llpf_uniform_idx(uint32_t i0, uint32_t step, uint32_t stream, uint32_t k0, uint32_t k1) {
+    llpf_philox4 r = llpf_philox4x32_10(i0, step, 0u, stream, k0, k1);
+    return llpf_u01_half(r.v[0], r.v[1]);
+}
+
+#endif /* LLPF_PHILOX_H */

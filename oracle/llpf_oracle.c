@@ -1,0 +1,886 @@
+/* llpf_oracle.c — CPU restatement of the LowLevelParticleFilters.jl particle-filter hot path.
+ * TEST INFRASTRUCTURE ONLY (see llpf_oracle.h for the rules and for how parity is pinned).
+ *
+ * Every function cites the reference lines it follows (paths relative to the reference root,
+ * v3.31.1).  Indices are 0-based here; the reference is 1-based.
+ *
+ * Compile with -ffp-contract=off: no multiply-add may be fused except the explicit llpf_fma()
+ * calls inside llpf_detmath.h.
+ */
+#include "llpf_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../lowlevelparticlefilters.jl_amd/csrc/shared/llpf_detmath.h"
+#include "../lowlevelparticlefilters.jl_amd/csrc/shared/llpf_fixed.h"
+#include "../lowlevelparticlefilters.jl_amd/csrc/shared/llpf_philox.h"
+
+#define MAXD LLPF_MAX_DIM
+
+/* ------------------------------------------------------------------------------------------
+ * Gaussian densities — src/utils.jl:241-270 (SimpleMvNormal), PDMats shims src/utils.jl:110-113,
+ * ext/LowLevelParticleFiltersDistributionsExt.jl:16,80 (Distributions.MvNormal path)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int dim, kind;
+    double mu[MAXD];
+    double L[MAXD * MAXD];      /* lower Cholesky factor (FULL) */
+    double scal, sqrtscal;      /* ScalMat value and its sqrt   */
+    double diag[MAXD], invdiag[MAXD], sqrtdiag[MAXD];
+    double c0;                  /* mvnormal_c0: -(k log2pi + logdet Sigma)/2, src/utils.jl:254-257 */
+} gaussd;
+
+/* cholesky(Sigma).L — Cholesky–Banachiewicz, row by row */
+static int chol_lower(const double* S, int n, double* L) {
+    memset(L, 0, sizeof(double) * MAXD * MAXD);
+    for (int i = 0; i < n; ++i) {
+        for (int j = 0; j <= i; ++j) {
+            double acc = S[i * n + j];
+            for (int k = 0; k < j; ++k) acc = acc - L[i * MAXD + k] * L[j * MAXD + k];
+            if (i == j) {
+                if (!(acc > 0.0)) return -1;
+                L[i * MAXD + i] = sqrt(acc);
+            } else {
+                L[i * MAXD + j] = acc / L[j * MAXD + j];
+            }
+        }
+    }
+    return 0;
+}
+
+static int gauss_prepare(const llpf_gaussian* g, gaussd* d, int order) {
+    memset(d, 0, sizeof(*d));
+    d->dim = g->dim;
+    d->kind = g->kind;
+    int n = g->dim;
+    if (n < 1 || n > MAXD) return -1;
+    for (int i = 0; i < n; ++i) d->mu[i] = g->mu[i];
+    double logdet = 0.0;
+    /* the constant uses libm log in reference order and the shared deterministic log in device
+     * order (so that the engine's host code and this oracle agree to the bit on any libm) */
+#define LOGF(x) (order == ORC_ORDER_DEVICE ? llpf_log(x) : log(x))
+    if (g->kind == LLPF_COV_SCAL) {
+        d->scal = g->cov[0];
+        if (!(d->scal > 0.0)) return -1;
+        d->sqrtscal = sqrt(d->scal);
+        logdet = (double)n * LOGF(d->scal);                 /* PDMats: logdet(ScalMat) = dim*log(value) */
+        for (int i = 0; i < n; ++i) d->L[i * MAXD + i] = d->sqrtscal;
+    } else if (g->kind == LLPF_COV_DIAG) {
+        for (int i = 0; i < n; ++i) {
+            d->diag[i] = g->cov[i];
+            if (!(d->diag[i] > 0.0)) return -1;
+            d->invdiag[i] = 1.0 / d->diag[i];                 /* 1 ./ a.diag, src/utils.jl:113 */
+            d->sqrtdiag[i] = sqrt(d->diag[i]);
+            d->L[i * MAXD + i] = d->sqrtdiag[i];
+            logdet = (i == 0) ? LOGF(d->diag[i]) : logdet + LOGF(d->diag[i]);  /* sum(log, diag) */
+        }
+    } else if (g->kind == LLPF_COV_FULL) {
+        if (chol_lower(g->cov, n, d->L) != 0) return -1;
+        double dd = 0.0;
+        for (int i = 0; i < n; ++i) dd = (i == 0) ? LOGF(d->L[i * MAXD + i]) : dd + LOGF(d->L[i * MAXD + i]);
+        logdet = dd + dd;                                     /* logdet(::Cholesky) */
+    } else {
+        return -1;
+    }
+    const double log2pi = LOGF(2.0 * 3.141592653589793);     /* const log2π = log(2π), src/utils.jl:253 */
+#undef LOGF
+    d->c0 = -((double)n * log2pi + logdet) / 2.0;
+    return 0;
+}
+
+/* extended_logpdf(d, x) = c0 - invquad(Sigma, x - mu)/2 — src/utils.jl:252; invquad per
+ * src/utils.jl:110-113: ScalMat dot(x,x)/value; PDMat dot(x, chol \ x); PDiagMat wsumsq(1 ./ diag, x) */
+static double gauss_logpdf(const gaussd* g, const double* x) {
+    int n = g->dim;
+    double d[MAXD], q;
+    for (int i = 0; i < n; ++i) d[i] = x[i] - g->mu[i];
+    if (g->kind == LLPF_COV_SCAL) {
+        double dot = d[0] * d[0];
+        for (int i = 1; i < n; ++i) dot = dot + d[i] * d[i];
+        q = dot / g->scal;
+    } else if (g->kind == LLPF_COV_DIAG) {
+        double s = (d[0] * d[0]) * g->invdiag[0];
+        for (int i = 1; i < n; ++i) s = s + (d[i] * d[i]) * g->invdiag[i];
+        q = s;
+    } else {
+        double z[MAXD], z2[MAXD];
+        for (int i = 0; i < n; ++i) {                         /* L \ d */
+            double acc = d[i];
+            for (int j = 0; j < i; ++j) acc = acc - g->L[i * MAXD + j] * z[j];
+            z[i] = acc / g->L[i * MAXD + i];
+        }
+        for (int i = n - 1; i >= 0; --i) {                    /* L' \ z */
+            double acc = z[i];
+            for (int j = i + 1; j < n; ++j) acc = acc - g->L[j * MAXD + i] * z2[j];
+            z2[i] = acc / g->L[i * MAXD + i];
+        }
+        double dot = d[0] * z2[0];
+        for (int i = 1; i < n; ++i) dot = dot + d[i] * z2[i];
+        q = dot;
+    }
+    return g->c0 - q / 2.0;
+}
+
+/* rand!(rng, d, out): unwhiten(xi) .+ mu — src/utils.jl:264-268, Distributions _rand!(MvNormal) */
+static void gauss_sample(const gaussd* g, const double* xi, double* out) {
+    int n = g->dim;
+    for (int i = 0; i < n; ++i) {
+        double v;
+        if (g->kind == LLPF_COV_SCAL) v = g->sqrtscal * xi[i];
+        else if (g->kind == LLPF_COV_DIAG) v = g->sqrtdiag[i] * xi[i];
+        else {
+            v = g->L[i * MAXD + 0] * xi[0];
+            for (int j = 1; j <= i; ++j) v = v + g->L[i * MAXD + j] * xi[j];
+        }
+        out[i] = v + g->mu[i];
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Models — SURVEY.md Appendix A.5
+ * ---------------------------------------------------------------------------------------- */
+/* quad-tank right-hand side — examples/example_quadtank.jl:8-27 */
+static void quadtank_rhs(const double* qt, const double* h, const double* u, double t, double* xd) {
+    double k1 = qt[LLPF_QT_K1], k2 = qt[LLPF_QT_K2], g = qt[LLPF_QT_G];
+    double A1 = qt[LLPF_QT_A1], A2 = qt[LLPF_QT_A2], A3 = qt[LLPF_QT_A3], A4 = qt[LLPF_QT_A4];
+    double a1 = qt[LLPF_QT_a1], a2 = qt[LLPF_QT_a2], a3 = qt[LLPF_QT_a3], a4 = qt[LLPF_QT_a4];
+    double g1 = qt[LLPF_QT_GAMMA1], g2 = qt[LLPF_QT_GAMMA2], eps = qt[LLPF_QT_EPS];
+    if (t > qt[LLPF_QT_TSWITCH]) a1 = a1 * qt[LLPF_QT_A1FACTOR];       /* :15-17 */
+    double tg = 2.0 * g;
+    double s[4];
+    for (int i = 0; i < 4; ++i) {                                       /* ssqrt, :19 */
+        double v = tg * h[i];
+        s[i] = sqrt((v > 0.0 ? v : 0.0) + eps);
+    }
+    xd[0] = ((-a1) / A1) * s[0] + (a3 / A1) * s[2] + ((g1 * k1) / A1) * u[0];
+    xd[1] = ((-a2) / A2) * s[1] + (a4 / A2) * s[3] + ((g2 * k2) / A2) * u[1];
+    xd[2] = ((-a3) / A3) * s[2] + (((1.0 - g2) * k2) / A3) * u[1];
+    xd[3] = ((-a4) / A4) * s[3] + (((1.0 - g1) * k1) / A4) * u[0];
+}
+
+/* rk4(f, Ts; supersample) — src/utils.jl:220-237 */
+static void quadtank_rk4(const llpf_model* m, const double* x0, const double* u, double t, double* out) {
+    int ss = m->supersample < 1 ? 1 : m->supersample;
+    double Ts = m->Ts / (double)ss;
+    double x[4], f1[4], f2[4], f3[4], f4[4], xt[4];
+    for (int i = 0; i < 4; ++i) x[i] = x0[i];
+    for (int it = 0; it < ss; ++it) {
+        quadtank_rhs(m->qt, x, u, t, f1);
+        for (int i = 0; i < 4; ++i) xt[i] = x[i] + (Ts / 2.0) * f1[i];
+        quadtank_rhs(m->qt, xt, u, t + Ts / 2.0, f2);
+        for (int i = 0; i < 4; ++i) xt[i] = x[i] + (Ts / 2.0) * f2[i];
+        quadtank_rhs(m->qt, xt, u, t + Ts / 2.0, f3);
+        for (int i = 0; i < 4; ++i) xt[i] = x[i] + Ts * f3[i];
+        quadtank_rhs(m->qt, xt, u, t + Ts, f4);
+        for (int i = 0; i < 4; ++i) x[i] = x[i] + (Ts / 6.0) * (((f1[i] + 2.0 * f2[i]) + 2.0 * f3[i]) + f4[i]);
+        t = t + Ts;
+    }
+    for (int i = 0; i < 4; ++i) out[i] = x[i];
+}
+
+/* the rk4 known-answer case of test/runtests.jl:182-188: xdot = -1 */
+void orc_rk4_scalar_decay(double x0, double Ts0, int supersample, double* out) {
+    double Ts = Ts0 / (double)supersample, x = x0, t = 0.0;
+    for (int it = 0; it < supersample; ++it) {
+        double f1 = -1.0, f2 = -1.0, f3 = -1.0, f4 = -1.0;
+        (void)t;
+        x = x + (Ts / 6.0) * (((f1 + 2.0 * f2) + 2.0 * f3) + f4);
+        t = t + Ts;
+    }
+    *out = x;
+}
+
+/* dynamics(x,u,p,t) without noise */
+void orc_dynamics(const llpf_model* m, const double* x, const double* u, double t, double* out) {
+    if (m->model_id == LLPF_MODEL_LINEAR_GAUSSIAN) {          /* A*x .+ B*u, examples/example_lineargaussian.jl:28 */
+        for (int r = 0; r < m->nx; ++r) {
+            double ax = m->A[r * m->nx + 0] * x[0];
+            for (int c = 1; c < m->nx; ++c) ax = ax + m->A[r * m->nx + c] * x[c];
+            if (m->nu > 0) {
+                double bu = m->B[r * m->nu + 0] * u[0];
+                for (int c = 1; c < m->nu; ++c) bu = bu + m->B[r * m->nu + c] * u[c];
+                ax = ax + bu;
+            }
+            out[r] = ax;
+        }
+    } else {
+        quadtank_rk4(m, x, u, t, out);
+    }
+}
+
+/* measurement(x,u,p,t) */
+void orc_measurement(const llpf_model* m, const double* x, const double* u, double t, double* out) {
+    (void)u; (void)t;
+    if (m->model_id == LLPF_MODEL_LINEAR_GAUSSIAN) {          /* C*x, examples/example_lineargaussian.jl:29 */
+        for (int r = 0; r < m->ny; ++r) {
+            double cx = m->C[r * m->nx + 0] * x[0];
+            for (int c = 1; c < m->nx; ++c) cx = cx + m->C[r * m->nx + c] * x[c];
+            out[r] = cx;
+        }
+    } else {                                                  /* SA[x[1], x[2]], examples/example_quadtank.jl:33 */
+        out[0] = x[0];
+        out[1] = x[1];
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Julia Base semantics used by the path
+ * ---------------------------------------------------------------------------------------- */
+/* Base.isless for Float64: NaN is greatest, -0.0 < 0.0 */
+static int jl_isless(double a, double b) {
+    if (a != a) return 0;
+    if (b != b) return 1;
+    if (a == 0.0 && b == 0.0) return signbit(a) && !signbit(b);
+    return a < b;
+}
+/* findmax(w): first maximal element under isless */
+static double jl_findmax(const double* w, int64_t n, int64_t* idx) {
+    double fm = w[0];
+    int64_t im = 0;
+    for (int64_t i = 1; i < n; ++i)
+        if (jl_isless(fm, w[i])) { fm = w[i]; im = i; }
+    *idx = im;
+    return fm;
+}
+/* Base.mapreduce_impl pairwise summation, block size 1024.  NOTE: Julia's base case is an @simd
+ * loop whose reassociation is CPU-dependent; it is restated here as a serial left-to-right loop. */
+static double pairwise(const double* a, int64_t lo, int64_t hi, int sq) {
+    if (lo == hi) return sq ? a[lo] * a[lo] : a[lo];
+    if (hi - lo < 1024) {
+        double v = sq ? (a[lo] * a[lo] + a[lo + 1] * a[lo + 1]) : (a[lo] + a[lo + 1]);
+        for (int64_t i = lo + 2; i <= hi; ++i) v = sq ? v + a[i] * a[i] : v + a[i];
+        return v;
+    }
+    int64_t mid = lo + ((hi - lo) >> 1);
+    double v1 = pairwise(a, lo, mid, sq);
+    double v2 = pairwise(a, mid + 1, hi, sq);
+    return v1 + v2;
+}
+double orc_pairwise_sum(const double* a, int64_t n) { return n ? pairwise(a, 0, n - 1, 0) : 0.0; }
+
+/* ------------------------------------------------------------------------------------------
+ * logsumexp! / expnormalize! / effective_particles — src/utils.jl:3-79, src/resample.jl:1-2
+ * ---------------------------------------------------------------------------------------- */
+/* sum_all_but(we, i) — src/utils.jl:66-71 */
+static double sum_all_but(double* we, int64_t n, int64_t i) {
+    we[i] -= 1.0;
+    double s = orc_pairwise_sum(we, n);
+    we[i] += 1.0;
+    return s;
+}
+
+/* device-order core: from raw log-weights w (unchanged) produce e_i = exp(w_i - m) and the exact
+ * fixed-point sums; returns s = sum_{i != argmax} e_i rounded once */
+typedef struct { double m, s, l, inv, e2; uint64_t totQ; int K; } devnorm;
+
+static void dev_expsum(const double* w, double* e, int64_t n, devnorm* o) {
+    double m = w[0];
+    for (int64_t i = 1; i < n; ++i) m = llpf_fmax(m, w[i]);
+    llpf_u128 S = {0, 0}, E2 = {0, 0};
+    uint64_t Q = 0;
+    int K = llpf_qbits(n);
+    for (int64_t i = 0; i < n; ++i) {
+        double ei = llpf_exp(w[i] - m);
+        e[i] = ei;
+        S = llpf_u128_add(S, llpf_fix96(ei));
+        E2 = llpf_u128_add(E2, llpf_fix96(ei * ei));
+        Q += llpf_q64(ei, K);
+    }
+    o->m = m;
+    o->K = K;
+    o->totQ = Q;
+    if (S.hi >= ((uint64_t)1 << 32)) o->s = llpf_fix96_to_double(llpf_fix96_minus_one(S));
+    else o->s = llpf_u2d(0x7ff8000000000000ULL);              /* max is -Inf/NaN: degenerate */
+    o->l = llpf_log1p_nonneg(o->s);
+    o->inv = 1.0 / (o->s + 1.0);
+    o->e2 = llpf_fix96_to_double(E2);
+}
+
+/* ll = logsumexp!(w, we [, maxw]) — src/utils.jl:18-27 */
+double orc_logsumexp(double* w, double* we, int64_t n, int order, double* maxw) {
+    if (order == ORC_ORDER_DEVICE) {
+        devnorm d;
+        dev_expsum(w, we, n, &d);
+        for (int64_t i = 0; i < n; ++i) {
+            we[i] = we[i] * d.inv;
+            w[i] = (w[i] - d.m) - d.l;
+        }
+        if (maxw) *maxw = d.m;
+        return d.l + d.m;
+    }
+    int64_t maxind;
+    double offset = jl_findmax(w, n, &maxind);                /* :19 */
+    for (int64_t i = 0; i < n; ++i) w[i] -= offset;           /* :20 */
+    for (int64_t i = 0; i < n; ++i) we[i] = exp(w[i]);        /* :21 exp_map!, :3-7 */
+    double s = sum_all_but(we, n, maxind);                    /* :22 */
+    double sc = 1.0 / (s + 1.0);
+    for (int64_t i = 0; i < n; ++i) we[i] *= sc;              /* :23 */
+    double l = log1p(s);
+    for (int64_t i = 0; i < n; ++i) w[i] -= l;                /* :24 */
+    if (maxw) *maxw = offset;                                 /* :25 */
+    return l + offset;                                        /* :26 */
+}
+
+/* expnormalize!(we, w) — src/utils.jl:48-55 */
+void orc_expnormalize(double* we, double* w, int64_t n) {
+    int64_t maxind;
+    double offset = jl_findmax(w, n, &maxind);
+    for (int64_t i = 0; i < n; ++i) w[i] -= offset;
+    for (int64_t i = 0; i < n; ++i) we[i] = exp(w[i]);
+    for (int64_t i = 0; i < n; ++i) w[i] += offset;
+    double s = sum_all_but(we, n, maxind);
+    double sc = 1.0 / (s + 1.0);
+    for (int64_t i = 0; i < n; ++i) we[i] *= sc;
+}
+/* expnormalize!(w) — src/utils.jl:57-63 */
+void orc_expnormalize_inplace(double* w, int64_t n) {
+    int64_t maxind;
+    double offset = jl_findmax(w, n, &maxind);
+    for (int64_t i = 0; i < n; ++i) w[i] -= offset;
+    for (int64_t i = 0; i < n; ++i) w[i] = exp(w[i]);
+    double s = sum_all_but(w, n, maxind);
+    double sc = 1.0 / (s + 1.0);
+    for (int64_t i = 0; i < n; ++i) w[i] *= sc;
+}
+
+/* effective_particles(we) = 1/sum(abs2, we) — src/resample.jl:1-2 */
+double orc_effective_particles(const double* we, int64_t n) {
+    return 1.0 / pairwise(we, 0, n - 1, 1);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Resampling — src/resample.jl:17-61
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { int strategy; int64_t m; double r, step; const double* U; } thr_ctx;
+
+/* threshold for 0-based output i.
+ * systematic: s = r:(1/M):(bins[N]+r), s[i]  (:23-24); for Float64 arguments that are not all exact
+ *   short rationals Julia builds StepRangeLen{Float64,TwicePrecision,TwicePrecision}(r, 1/M) whose
+ *   getindex evaluates fl(r + fl(i0 * (1/M))) (Base twiceprecision.jl unsafe_getindex; step.lo = 0).
+ * stratified: u = (i - 1 + rand()) / M * bins[N]  (:49), evaluated left to right. */
+static double thr_at(const thr_ctx* c, int64_t i0, double binsN) {
+    if (c->strategy == LLPF_RESAMPLE_SYSTEMATIC) return c->r + (double)i0 * c->step;
+    return ((double)i0 + c->U[i0]) / (double)c->m * binsN;
+}
+
+int orc_resample(int strategy, const double* we, int64_t n, int64_t m, const double* U,
+                 int64_t* j, double* bins, int order) {
+    thr_ctx c;
+    c.strategy = strategy; c.m = m; c.U = U; c.step = 1.0 / (double)m; c.r = 0.0;
+    double* b = bins ? bins : (double*)malloc(sizeof(double) * (size_t)n);
+    if (order == ORC_ORDER_REFERENCE) {
+        b[0] = we[0];                                          /* :19-22 strictly serial cumsum */
+        for (int64_t i = 1; i < n; ++i) b[i] = b[i - 1] + we[i];
+        double binsN = b[n - 1];
+        if (strategy == LLPF_RESAMPLE_SYSTEMATIC) c.r = U[0] * binsN / (double)n;   /* :23 */
+        int64_t bo = 0;                                        /* :25-34 / :52-58 two-pointer search */
+        for (int64_t i = 0; i < m; ++i) {
+            double si = thr_at(&c, i, binsN);
+            for (int64_t k = bo; k < n; ++k) {
+                if (si < b[k]) { j[i] = k; bo = k; break; }
+            }
+        }
+    } else {
+        /* device order: bins[b] = fl( fl(sum_{k<=b} Q_k) / fl(sum_k Q_k) ), Q_k = floor(we_k 2^K): an
+         * integer (associative) cumulative sum, so bins[N-1] == 1.0 exactly and any parallel blocking
+         * gives the same bits.  The search is restated through the count function
+         * c(v) = #{ i : thr_i < v } (thr is non-decreasing in i), which is what the expansion kernel
+         * evaluates; j[i] = first b with thr_i < bins[b] exactly as in the reference. */
+        int K = llpf_qbits(n);
+        uint64_t cum = 0, tot = 0;
+        for (int64_t i = 0; i < n; ++i) tot += llpf_q64(we[i], K);
+        if (tot == 0) { if (!bins) free(b); return -1; }
+        double Td = (double)tot;
+        for (int64_t i = 0; i < n; ++i) {
+            cum += llpf_q64(we[i], K);
+            b[i] = (double)cum / Td;
+        }
+        double binsN = 1.0;
+        if (strategy == LLPF_RESAMPLE_SYSTEMATIC) c.r = U[0] * binsN / (double)n;
+        int64_t bo = 0;
+        for (int64_t i = 0; i < m; ++i) {
+            double si = thr_at(&c, i, binsN);
+            for (int64_t k = bo; k < n; ++k) {
+                if (si < b[k]) { j[i] = k; bo = k; break; }
+            }
+        }
+    }
+    if (!bins) free(b);
+    return 0;
+}
+
+void orc_resample_uniforms(int strategy, int64_t m, uint64_t seed, uint32_t step, double* u) {
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    if (strategy == LLPF_RESAMPLE_SYSTEMATIC) u[0] = llpf_uniform_step(step, LLPF_STREAM_RESAMPLE, k0, k1);
+    else for (int64_t i = 0; i < m; ++i) u[i] = llpf_uniform_idx((uint32_t)i, step, LLPF_STREAM_STRATIFY, k0, k1);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * The filter — PFstate src/PFtypes.jl:8-19; ParticleFilter :21-36,65-75; AdvancedParticleFilter :162-210
+ * ---------------------------------------------------------------------------------------- */
+struct orc_filter {
+    llpf_config cfg;
+    int order;
+    int64_t N;
+    int nx, nu, ny;
+    gaussd df, dg, d0;
+    double *x, *xprev;          /* N*nx, AoS like Vector{SVector} */
+    double *w, *we, *bins, *e;  /* e: exp(w_raw - m) of the last normalisation (device order) */
+    int64_t* j;
+    double maxw;
+    int64_t t;                  /* state.t[] */
+    uint32_t k0, k1, n_reset, n_predict;
+    int last_resampled;
+    int64_t resample_count;
+    int degenerate;
+    /* device-order scalars of the last normalisation */
+    devnorm dn;
+    int dn_valid;
+    double *xi_buf, *U_buf;
+};
+
+static void set_key(orc_filter* f, uint64_t seed) {
+    f->k0 = (uint32_t)seed;
+    f->k1 = (uint32_t)(seed >> 32);
+    f->n_reset = 0;
+    f->n_predict = 0;
+}
+
+static void fill_uniform_weights(orc_filter* f, double wval) {
+    double wev = 1.0 / (double)f->N;
+    for (int64_t i = 0; i < f->N; ++i) { f->w[i] = wval; f->we[i] = wev; }
+    f->dn_valid = 0;
+}
+
+static void init_particles(orc_filter* f, const double* xi) {
+    for (int64_t i = 0; i < f->N; ++i) {
+        gauss_sample(&f->d0, xi + i * f->nx, f->xprev + i * f->nx);
+        for (int d = 0; d < f->nx; ++d) f->x[i * f->nx + d] = f->xprev[i * f->nx + d];
+    }
+}
+
+static void gen_normals(orc_filter* f, uint32_t step, uint32_t stream, double* out) {
+    for (int64_t i = 0; i < f->N; ++i)
+        llpf_normals((uint32_t)i, step, stream, f->k0, f->k1, f->nx, out + i * f->nx);
+}
+
+orc_filter* orc_create(const llpf_config* cfg, int order) {
+    orc_filter* f = (orc_filter*)calloc(1, sizeof(orc_filter));
+    f->cfg = *cfg;
+    f->order = order;
+    f->N = cfg->n_particles;
+    f->nx = cfg->model.nx; f->nu = cfg->model.nu; f->ny = cfg->model.ny;
+    if (gauss_prepare(&cfg->model.dynamics_density, &f->df, order) ||
+        gauss_prepare(&cfg->model.measurement_density, &f->dg, order) ||
+        gauss_prepare(&cfg->model.initial_density, &f->d0, order)) { free(f); return NULL; }
+    size_t N = (size_t)f->N;
+    f->x = (double*)calloc(N * f->nx, 8); f->xprev = (double*)calloc(N * f->nx, 8);
+    f->w = (double*)calloc(N, 8); f->we = (double*)calloc(N, 8);
+    f->bins = (double*)calloc(N, 8); f->e = (double*)calloc(N, 8);
+    f->j = (int64_t*)calloc(N, 8);
+    f->xi_buf = (double*)calloc(N * f->nx, 8); f->U_buf = (double*)calloc(N, 8);
+    set_key(f, cfg->seed);
+    /* constructor: particles ~ d0, w = log(1/N), we = 1/N, j = 1:N, t = 0 — src/PFtypes.jl:65-75 */
+    gen_normals(f, f->n_reset, LLPF_STREAM_INIT, f->xi_buf);
+    f->n_reset++;
+    init_particles(f, f->xi_buf);
+    fill_uniform_weights(f, order == ORC_ORDER_DEVICE ? llpf_log(1.0 / (double)f->N) : log(1.0 / (double)f->N));
+    for (int64_t i = 0; i < f->N; ++i) f->j[i] = i;
+    f->t = 0;
+    return f;
+}
+
+void orc_destroy(orc_filter* f) {
+    if (!f) return;
+    free(f->x); free(f->xprev); free(f->w); free(f->we); free(f->bins); free(f->e); free(f->j);
+    free(f->xi_buf); free(f->U_buf); free(f);
+}
+
+void orc_seed(orc_filter* f, uint64_t seed) { set_key(f, seed); }
+
+/* reset!(pf) — src/filtering.jl:4-14 */
+void orc_reset_explicit(orc_filter* f, const double* xi) {
+    init_particles(f, xi);
+    fill_uniform_weights(f, f->order == ORC_ORDER_DEVICE ? -llpf_log((double)f->N) : -log((double)f->N));
+    f->t = 1;
+}
+void orc_reset(orc_filter* f) {
+    gen_normals(f, f->n_reset, LLPF_STREAM_INIT, f->xi_buf);
+    f->n_reset++;
+    orc_reset_explicit(f, f->xi_buf);
+}
+
+/* normalisation of the current raw log-weights in the filter's order */
+static double filter_logsumexp(orc_filter* f) {
+    if (f->order == ORC_ORDER_DEVICE) {
+        dev_expsum(f->w, f->e, f->N, &f->dn);
+        f->dn_valid = 1;
+        for (int64_t i = 0; i < f->N; ++i) {
+            f->we[i] = f->e[i] * f->dn.inv;
+            f->w[i] = (f->w[i] - f->dn.m) - f->dn.l;
+        }
+        f->maxw = f->dn.m;
+        double ll = f->dn.l + f->dn.m;
+        if (!(ll == ll) || f->dn.m == -LLPF_INF) f->degenerate = 1;
+        return ll;
+    }
+    double ll = orc_logsumexp(f->w, f->we, f->N, ORC_ORDER_REFERENCE, &f->maxw);
+    if (!(ll == ll)) f->degenerate = 1;
+    return ll;
+}
+
+/* correct!(pf,u,y,p,t) — src/filtering.jl:164-168; measurement_equation! src/PFtypes.jl:107-120 (PF),
+ * :226-239 (Advanced: w[i] += measurement_likelihood(x[i],u,y,p,t), which for the built-in models is
+ * logpdf(dg, y - g(x))) */
+double orc_correct(orc_filter* f, const double* u, const double* y, double t) {
+    if (y != NULL && y[0] == y[0]) {                           /* any(ismissing, y) && return w */
+        for (int64_t i = 0; i < f->N; ++i) {
+            double g[MAXD], v[MAXD];
+            orc_measurement(&f->cfg.model, f->x + i * f->nx, u, t, g);
+            for (int k = 0; k < f->ny; ++k) v[k] = y[k] - g[k];
+            f->w[i] += gauss_logpdf(&f->dg, v);
+        }
+    }
+    return filter_logsumexp(f);
+}
+
+static double filter_ess(const orc_filter* f) {
+    if (f->order == ORC_ORDER_DEVICE && f->dn_valid) {
+        /* sum(we^2) = inv^2 * sum(e^2), with sum(e^2) exact in fixed point */
+        return 1.0 / (f->dn.e2 * (f->dn.inv * f->dn.inv));
+    }
+    if (f->order == ORC_ORDER_DEVICE) {
+        /* uniform weights: we = 1/N exactly representable product N * (1/N)^2 */
+        double wev = f->we[0];
+        return 1.0 / ((double)f->N * (wev * wev));
+    }
+    return orc_effective_particles(f->we, f->N);
+}
+double orc_filter_ess(const orc_filter* f) { return filter_ess(f); }
+
+/* shouldresample(pf) — src/resample.jl:5-10 */
+int orc_shouldresample(const orc_filter* f) {
+    if (f->cfg.resample_threshold == 1.0) return 1;
+    double th = (double)f->N * f->cfg.resample_threshold;
+    return filter_ess(f) < th;
+}
+
+/* device-order resample on the filter path: bins from the UNNORMALISED exp-weights e_i = exp(w_i - m)
+ * (scale-invariant: bins = cumQ/totQ), so that the GPU needs no normalised-weight array */
+static void filter_resample_dev(orc_filter* f, const double* U) {
+    int64_t n = f->N;
+    uint64_t cum = 0;
+    double Td = (double)f->dn.totQ;
+    for (int64_t i = 0; i < n; ++i) {
+        cum += llpf_q64(f->e[i], f->dn.K);
+        f->bins[i] = (double)cum / Td;
+    }
+    thr_ctx c;
+    c.strategy = f->cfg.resampling_strategy; c.m = n; c.U = U; c.step = 1.0 / (double)n;
+    c.r = (c.strategy == LLPF_RESAMPLE_SYSTEMATIC) ? U[0] * 1.0 / (double)n : 0.0;
+    int64_t bo = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        double si = thr_at(&c, i, 1.0);
+        for (int64_t k = bo; k < n; ++k) {
+            if (si < f->bins[k]) { f->j[i] = k; bo = k; break; }
+        }
+    }
+}
+
+/* predict!(pf,u,p,t) — src/filtering.jl:140-153 */
+void orc_predict_explicit(orc_filter* f, const double* u, double t, const double* xi, const double* U) {
+    int64_t N = f->N;
+    int nx = f->nx;
+    int res = orc_shouldresample(f);
+    if (res) {
+        /* j = resample(pf) — src/resample.jl:12 */
+        if (f->order == ORC_ORDER_DEVICE && f->dn_valid) filter_resample_dev(f, U);
+        else orc_resample(f->cfg.resampling_strategy, f->we, N, N, U, f->j, f->bins, f->order);
+        /* propagate_particles!(pf,u,j,p,t) — src/PFtypes.jl:122-139 (PF), :242-259 (Advanced) */
+        for (int64_t i = 0; i < N; ++i) {
+            double fx[MAXD], nz[MAXD];
+            orc_dynamics(&f->cfg.model, f->xprev + f->j[i] * nx, u, t, fx);
+            gauss_sample(&f->df, xi + i * nx, nz);
+            for (int d = 0; d < nx; ++d) f->x[i * nx + d] = fx[d] + nz[d];
+        }
+        /* reset_weights!(s) — src/utils.jl:73-79: fill!(w, log(1/N)); fill!(we, 1/N); maxw = 0 */
+        fill_uniform_weights(f, f->order == ORC_ORDER_DEVICE ? llpf_log(1.0 / (double)N) : log(1.0 / (double)N));
+        f->maxw = 0.0;
+        f->resample_count++;
+    } else {
+        for (int64_t i = 0; i < N; ++i) f->j[i] = i;          /* s.j .= 1:N, :148 */
+        /* propagate_particles!(pf,u,p,t) — DistributionsExt:83-93 (PF), src/PFtypes.jl:276-289 (Advanced) */
+        for (int64_t i = 0; i < N; ++i) {
+            double fx[MAXD], nz[MAXD];
+            orc_dynamics(&f->cfg.model, f->xprev + i * nx, u, t, fx);
+            gauss_sample(&f->df, xi + i * nx, nz);
+            for (int d = 0; d < nx; ++d) f->x[i * nx + d] = fx[d] + nz[d];
+        }
+    }
+    memcpy(f->xprev, f->x, sizeof(double) * (size_t)N * nx);   /* copyto!(s.xprev, s.x), :151 */
+    f->t += 1;                                                /* :152 */
+    f->last_resampled = res;
+}
+
+void orc_predict(orc_filter* f, const double* u, double t) {
+    uint32_t step = f->n_predict++;
+    gen_normals(f, step, LLPF_STREAM_DYNAMICS, f->xi_buf);
+    if (f->cfg.resampling_strategy == LLPF_RESAMPLE_SYSTEMATIC)
+        f->U_buf[0] = llpf_uniform_step(step, LLPF_STREAM_RESAMPLE, f->k0, f->k1);
+    else
+        for (int64_t i = 0; i < f->N; ++i)
+            f->U_buf[i] = llpf_uniform_idx((uint32_t)i, step, LLPF_STREAM_STRATIFY, f->k0, f->k1);
+    orc_predict_explicit(f, u, t, f->xi_buf, f->U_buf);
+}
+
+/* update!(pf,u,y,p,t) — src/filtering.jl:181-185 */
+double orc_update(orc_filter* f, const double* u, const double* y, double t) {
+    double ll = orc_correct(f, u, y, t);
+    orc_predict(f, u, t);
+    return ll;
+}
+
+/* weighted_mean(x, we) — src/filtering.jl:541-549 */
+void orc_weighted_mean(const orc_filter* f, double* xh) {
+    for (int d = 0; d < f->nx; ++d) xh[d] = 0.0;
+    for (int64_t i = 0; i < f->N; ++i)
+        for (int d = 0; d < f->nx; ++d) xh[d] += f->x[i * f->nx + d] * f->we[i];
+}
+
+/* the loop of forward_trajectory (src/filtering.jl:351-363, t_index0 = 0 after reset!) and of
+ * loglik (src/smoothing.jl:227-230: t = index(pf)*Ts, index = 1 after reset!, so t_index0 = 1) */
+double orc_run(orc_filter* f, const double* U, const double* Y, int64_t T, double t_index0,
+               double* ll_steps, double* xmean, double* x_hist, double* w_hist, double* we_hist) {
+    double ll = 0.0;
+    size_t N = (size_t)f->N;
+    for (int64_t k = 0; k < T; ++k) {
+        double ti = (t_index0 + (double)k) * f->cfg.model.Ts;
+        const double* u = U + k * f->nu;
+        const double* y = Y + k * f->ny;
+        double lli = orc_correct(f, u, y, ti);
+        ll += lli;
+        if (ll_steps) ll_steps[k] = lli;
+        if (xmean) orc_weighted_mean(f, xmean + k * f->nx);
+        if (x_hist) memcpy(x_hist + (size_t)k * N * f->nx, f->x, 8 * N * f->nx);
+        if (w_hist) memcpy(w_hist + (size_t)k * N, f->w, 8 * N);
+        if (we_hist) memcpy(we_hist + (size_t)k * N, f->we, 8 * N);
+        orc_predict(f, u, ti);
+    }
+    return ll;
+}
+
+int64_t orc_num_particles(const orc_filter* f) { return f->N; }
+int64_t orc_index(const orc_filter* f) { return f->t; }
+void orc_get_particles(const orc_filter* f, double* dst) { memcpy(dst, f->x, 8 * (size_t)f->N * f->nx); }
+void orc_get_weights(const orc_filter* f, double* dst) { memcpy(dst, f->w, 8 * (size_t)f->N); }
+void orc_get_expweights(const orc_filter* f, double* dst) { memcpy(dst, f->we, 8 * (size_t)f->N); }
+void orc_get_ancestors(const orc_filter* f, int64_t* dst) { memcpy(dst, f->j, 8 * (size_t)f->N); }
+void orc_get_bins(const orc_filter* f, double* dst) { memcpy(dst, f->bins, 8 * (size_t)f->N); }
+void orc_set_particles(orc_filter* f, const double* src) {
+    memcpy(f->x, src, 8 * (size_t)f->N * f->nx);
+    memcpy(f->xprev, src, 8 * (size_t)f->N * f->nx);
+}
+/* install log-weights; expweights become softmax(w) in the filter's order, w itself is kept */
+void orc_set_weights(orc_filter* f, const double* w) {
+    int64_t n = f->N;
+    memcpy(f->w, w, 8 * (size_t)n);
+    if (f->order == ORC_ORDER_DEVICE) {
+        dev_expsum(f->w, f->e, n, &f->dn);
+        f->dn_valid = 1;
+        for (int64_t i = 0; i < n; ++i) f->we[i] = f->e[i] * f->dn.inv;
+        f->maxw = f->dn.m;
+    } else {
+        double* tmp = (double*)malloc(8 * (size_t)n);
+        memcpy(tmp, w, 8 * (size_t)n);
+        orc_expnormalize(f->we, tmp, n);
+        free(tmp);
+    }
+}
+void orc_set_index(orc_filter* f, int64_t t) { f->t = t; }
+int orc_last_resampled(const orc_filter* f) { return f->last_resampled; }
+double orc_maxw(const orc_filter* f) { return f->maxw; }
+int64_t orc_resample_count(const orc_filter* f) { return f->resample_count; }
+int orc_degenerate(const orc_filter* f) { return f->degenerate; }
+
+double orc_gauss_logpdf(const llpf_gaussian* g, const double* x) {
+    gaussd d;
+    if (gauss_prepare(g, &d, ORC_ORDER_REFERENCE)) return NAN;
+    return gauss_logpdf(&d, x);
+}
+void orc_gauss_sample(const llpf_gaussian* g, const double* xi, double* out) {
+    gaussd d;
+    if (gauss_prepare(g, &d, ORC_ORDER_REFERENCE)) return;
+    gauss_sample(&d, xi, out);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Closed-form Kalman log-likelihood: independent check for linear-Gaussian inputs.
+ * reset! src/kalman.jl:159-164; predict! src/filtering.jl:52-74; correct! :100-128; loop :293-314
+ * ---------------------------------------------------------------------------------------- */
+static void gauss_cov_full(const llpf_gaussian* g, double* S) {
+    int n = g->dim;
+    for (int i = 0; i < n * n; ++i) S[i] = 0.0;
+    for (int i = 0; i < n; ++i) {
+        if (g->kind == LLPF_COV_SCAL) S[i * n + i] = g->cov[0];
+        else if (g->kind == LLPF_COV_DIAG) S[i * n + i] = g->cov[i];
+    }
+    if (g->kind == LLPF_COV_FULL) for (int i = 0; i < n * n; ++i) S[i] = g->cov[i];
+}
+
+double orc_kalman_loglik(const llpf_model* m, const double* U, const double* Y, int64_t T) {
+    int nx = m->nx, nu = m->nu, ny = m->ny;
+    double R1[64], R2[64], P[64], x[MAXD];
+    gauss_cov_full(&m->dynamics_density, R1);
+    gauss_cov_full(&m->measurement_density, R2);
+    gauss_cov_full(&m->initial_density, P);
+    for (int i = 0; i < nx; ++i) x[i] = m->initial_density.mu[i];
+    double LL = 0.0;
+    for (int64_t k = 0; k < T; ++k) {
+        const double* u = U + k * nu;
+        const double* y = Y + k * ny;
+        if (y[0] == y[0]) {
+            /* e = y - C x ; S = sym(C P C') + R2 */
+            double e[MAXD], CP[64], S[64], Lc[MAXD * MAXD];
+            for (int r = 0; r < ny; ++r) {
+                double cx = 0.0;
+                for (int c = 0; c < nx; ++c) cx += m->C[r * nx + c] * x[c];
+                e[r] = y[r] - cx - m->measurement_density.mu[r];
+            }
+            for (int r = 0; r < ny; ++r)
+                for (int c = 0; c < nx; ++c) {
+                    double a = 0.0;
+                    for (int q = 0; q < nx; ++q) a += m->C[r * nx + q] * P[q * nx + c];
+                    CP[r * nx + c] = a;
+                }
+            for (int r = 0; r < ny; ++r)
+                for (int c = 0; c < ny; ++c) {
+                    double a = 0.0;
+                    for (int q = 0; q < nx; ++q) a += CP[r * nx + q] * m->C[c * nx + q];
+                    S[r * ny + c] = a;
+                }
+            for (int r = 0; r < ny; ++r)
+                for (int c = r + 1; c < ny; ++c) {
+                    double a = 0.5 * (S[r * ny + c] + S[c * ny + r]);
+                    S[r * ny + c] = a; S[c * ny + r] = a;
+                }
+            for (int i = 0; i < ny * ny; ++i) S[i] += R2[i];
+            if (chol_lower(S, ny, Lc)) return NAN;
+            /* Sinv e via the Cholesky factor, logdet S */
+            double z[MAXD], z2[MAXD], logdet = 0.0;
+            for (int i = 0; i < ny; ++i) {
+                double acc = e[i];
+                for (int q = 0; q < i; ++q) acc -= Lc[i * MAXD + q] * z[q];
+                z[i] = acc / Lc[i * MAXD + i];
+                logdet += 2.0 * log(Lc[i * MAXD + i]);
+            }
+            for (int i = ny - 1; i >= 0; --i) {
+                double acc = z[i];
+                for (int q = i + 1; q < ny; ++q) acc -= Lc[q * MAXD + i] * z2[q];
+                z2[i] = acc / Lc[i * MAXD + i];
+            }
+            double quad = 0.0;
+            for (int i = 0; i < ny; ++i) quad += e[i] * z2[i];
+            LL += -((double)ny * log(2.0 * 3.141592653589793) + logdet) / 2.0 - quad / 2.0;
+            /* K = P C' Sinv ; x += K e ; P = sym((I - K C) P) */
+            double K[64], KC[64], Pn[64];
+            for (int r = 0; r < nx; ++r) {
+                /* row r of P C' is CP[:, r]; solve S k' = (P C')[r,:]' */
+                double b[MAXD], t1[MAXD], t2[MAXD];
+                for (int c = 0; c < ny; ++c) b[c] = CP[c * nx + r];
+                for (int i = 0; i < ny; ++i) {
+                    double acc = b[i];
+                    for (int q = 0; q < i; ++q) acc -= Lc[i * MAXD + q] * t1[q];
+                    t1[i] = acc / Lc[i * MAXD + i];
+                }
+                for (int i = ny - 1; i >= 0; --i) {
+                    double acc = t1[i];
+                    for (int q = i + 1; q < ny; ++q) acc -= Lc[q * MAXD + i] * t2[q];
+                    t2[i] = acc / Lc[i * MAXD + i];
+                }
+                for (int c = 0; c < ny; ++c) K[r * ny + c] = t2[c];
+            }
+            for (int r = 0; r < nx; ++r) {
+                double a = 0.0;
+                for (int c = 0; c < ny; ++c) a += K[r * ny + c] * e[c];
+                x[r] += a;
+            }
+            for (int r = 0; r < nx; ++r)
+                for (int c = 0; c < nx; ++c) {
+                    double a = 0.0;
+                    for (int q = 0; q < ny; ++q) a += K[r * ny + q] * m->C[q * nx + c];
+                    KC[r * nx + c] = (r == c ? 1.0 : 0.0) - a;
+                }
+            for (int r = 0; r < nx; ++r)
+                for (int c = 0; c < nx; ++c) {
+                    double a = 0.0;
+                    for (int q = 0; q < nx; ++q) a += KC[r * nx + q] * P[q * nx + c];
+                    Pn[r * nx + c] = a;
+                }
+            for (int r = 0; r < nx; ++r)
+                for (int c = 0; c < nx; ++c) P[r * nx + c] = 0.5 * (Pn[r * nx + c] + Pn[c * nx + r]);
+        }
+        /* x = A x + B u (+ mean of df) ; P = sym(A P A') + R1 */
+        double xn[MAXD], AP[64], Pn[64];
+        for (int r = 0; r < nx; ++r) {
+            double a = 0.0;
+            for (int c = 0; c < nx; ++c) a += m->A[r * nx + c] * x[c];
+            for (int c = 0; c < nu; ++c) a += m->B[r * nu + c] * u[c];
+            xn[r] = a + m->dynamics_density.mu[r];
+        }
+        for (int r = 0; r < nx; ++r) x[r] = xn[r];
+        for (int r = 0; r < nx; ++r)
+            for (int c = 0; c < nx; ++c) {
+                double a = 0.0;
+                for (int q = 0; q < nx; ++q) a += m->A[r * nx + q] * P[q * nx + c];
+                AP[r * nx + c] = a;
+            }
+        for (int r = 0; r < nx; ++r)
+            for (int c = 0; c < nx; ++c) {
+                double a = 0.0;
+                for (int q = 0; q < nx; ++q) a += AP[r * nx + q] * m->A[c * nx + q];
+                Pn[r * nx + c] = a;
+            }
+        for (int r = 0; r < nx; ++r)
+            for (int c = 0; c < nx; ++c) P[r * nx + c] = 0.5 * (Pn[r * nx + c] + Pn[c * nx + r]) + R1[r * nx + c];
+    }
+    return LL;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Probes of the shared primitive headers (host evaluation)
+ * ---------------------------------------------------------------------------------------- */
+void orc_math_vec(int which, const double* in, double* out, int64_t n) {
+    for (int64_t i = 0; i < n; ++i) {
+        double x = in[i], s, c;
+        switch (which) {
+            case 0: out[i] = llpf_exp(x); break;
+            case 1: out[i] = llpf_log(x); break;
+            case 2: out[i] = llpf_log1p_nonneg(x); break;
+            case 3: llpf_sincos2pi(x, &s, &c); out[i] = s; break;
+            case 4: llpf_sincos2pi(x, &s, &c); out[i] = c; break;
+            case 5: out[i] = llpf_sqrt(x); break;
+            case 6: out[i] = 1.0 / x; break;
+            case 7: out[i] = (double)llpf_d2u(x); break;
+            default: out[i] = NAN;
+        }
+    }
+}
+void orc_philox_block(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out4) {
+    llpf_philox4 r = llpf_philox4x32_10(c0, c1, c2, c3, k0, k1);
+    for (int i = 0; i < 4; ++i) out4[i] = r.v[i];
+}
+void orc_normals(uint64_t seed, uint32_t step, uint32_t stream, int nd, double* out, int64_t n) {
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    for (int64_t i = 0; i < n; ++i) llpf_normals((uint32_t)i, step, stream, k0, k1, nd, out + i * nd);
+}
+void orc_fix96(double e, uint64_t* lo_hi) {
+    llpf_u128 r = llpf_fix96(e);
+    lo_hi[0] = r.lo; lo_hi[1] = r.hi;
+}
+uint64_t orc_q64(double e, int K) { return llpf_q64(e, K); }
+double orc_u128_to_double(uint64_t lo, uint64_t hi) {
+    llpf_u128 a; a.lo = lo; a.hi = hi;
+    return llpf_u128_to_double(a);
+}

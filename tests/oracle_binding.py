@@ -1,0 +1,270 @@
+"""ctypes binding of oracle/libllpf_oracle.so — test infrastructure only (see oracle/llpf_oracle.h)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from llpf_amd import _structs as S
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_SO = os.path.join(_ROOT, "oracle", "libllpf_oracle.so")
+
+ORDER_REFERENCE, ORDER_DEVICE = 0, 1
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int64)
+
+
+def _build():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(_ROOT, "oracle")])
+
+
+def load():
+    if not os.path.exists(_SO):
+        _build()
+    lib = C.CDLL(_SO)
+    lib.orc_create.restype = C.c_void_p
+    lib.orc_create.argtypes = [C.POINTER(S.Config), C.c_int]
+    lib.orc_destroy.argtypes = [C.c_void_p]
+    lib.orc_seed.argtypes = [C.c_void_p, C.c_uint64]
+    lib.orc_reset.argtypes = [C.c_void_p]
+    lib.orc_reset_explicit.argtypes = [C.c_void_p, _dp]
+    lib.orc_correct.restype = C.c_double
+    lib.orc_correct.argtypes = [C.c_void_p, _dp, _dp, C.c_double]
+    lib.orc_predict.argtypes = [C.c_void_p, _dp, C.c_double]
+    lib.orc_predict_explicit.argtypes = [C.c_void_p, _dp, C.c_double, _dp, _dp]
+    lib.orc_update.restype = C.c_double
+    lib.orc_update.argtypes = [C.c_void_p, _dp, _dp, C.c_double]
+    lib.orc_run.restype = C.c_double
+    lib.orc_run.argtypes = [C.c_void_p, _dp, _dp, C.c_int64, C.c_double, _dp, _dp, _dp, _dp, _dp]
+    lib.orc_num_particles.restype = C.c_int64
+    lib.orc_num_particles.argtypes = [C.c_void_p]
+    lib.orc_index.restype = C.c_int64
+    lib.orc_index.argtypes = [C.c_void_p]
+    for nm in ("orc_get_particles", "orc_get_weights", "orc_get_expweights", "orc_get_bins",
+               "orc_set_particles", "orc_set_weights", "orc_weighted_mean"):
+        getattr(lib, nm).argtypes = [C.c_void_p, _dp]
+    lib.orc_get_ancestors.argtypes = [C.c_void_p, _ip]
+    lib.orc_set_index.argtypes = [C.c_void_p, C.c_int64]
+    lib.orc_filter_ess.restype = C.c_double
+    lib.orc_filter_ess.argtypes = [C.c_void_p]
+    lib.orc_shouldresample.argtypes = [C.c_void_p]
+    lib.orc_last_resampled.argtypes = [C.c_void_p]
+    lib.orc_maxw.restype = C.c_double
+    lib.orc_maxw.argtypes = [C.c_void_p]
+    lib.orc_resample_count.restype = C.c_int64
+    lib.orc_resample_count.argtypes = [C.c_void_p]
+    lib.orc_degenerate.argtypes = [C.c_void_p]
+    lib.orc_logsumexp.restype = C.c_double
+    lib.orc_logsumexp.argtypes = [_dp, _dp, C.c_int64, C.c_int, _dp]
+    lib.orc_expnormalize.argtypes = [_dp, _dp, C.c_int64]
+    lib.orc_expnormalize_inplace.argtypes = [_dp, C.c_int64]
+    lib.orc_effective_particles.restype = C.c_double
+    lib.orc_effective_particles.argtypes = [_dp, C.c_int64]
+    lib.orc_resample.argtypes = [C.c_int, _dp, C.c_int64, C.c_int64, _dp, _ip, _dp, C.c_int]
+    lib.orc_resample_uniforms.argtypes = [C.c_int, C.c_int64, C.c_uint64, C.c_uint32, _dp]
+    lib.orc_gauss_logpdf.restype = C.c_double
+    lib.orc_gauss_logpdf.argtypes = [C.POINTER(S.Gaussian), _dp]
+    lib.orc_gauss_sample.argtypes = [C.POINTER(S.Gaussian), _dp, _dp]
+    lib.orc_dynamics.argtypes = [C.POINTER(S.Model), _dp, _dp, C.c_double, _dp]
+    lib.orc_measurement.argtypes = [C.POINTER(S.Model), _dp, _dp, C.c_double, _dp]
+    lib.orc_rk4_scalar_decay.argtypes = [C.c_double, C.c_double, C.c_int, _dp]
+    lib.orc_kalman_loglik.restype = C.c_double
+    lib.orc_kalman_loglik.argtypes = [C.POINTER(S.Model), _dp, _dp, C.c_int64]
+    lib.orc_pairwise_sum.restype = C.c_double
+    lib.orc_pairwise_sum.argtypes = [_dp, C.c_int64]
+    lib.orc_math_vec.argtypes = [C.c_int, _dp, _dp, C.c_int64]
+    lib.orc_philox_block.argtypes = [C.c_uint32] * 6 + [C.POINTER(C.c_uint32)]
+    lib.orc_normals.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, _dp, C.c_int64]
+    lib.orc_fix96.argtypes = [C.c_double, C.POINTER(C.c_uint64)]
+    lib.orc_q64.restype = C.c_uint64
+    lib.orc_q64.argtypes = [C.c_double, C.c_int]
+    lib.orc_u128_to_double.restype = C.c_double
+    lib.orc_u128_to_double.argtypes = [C.c_uint64, C.c_uint64]
+    return lib
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = load()
+    return _lib
+
+
+def dptr(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def iptr(a):
+    return a.ctypes.data_as(_ip)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class OracleFilter:
+    """Thin object wrapper over orc_* (same verbs as the product's filter objects)."""
+
+    def __init__(self, cfg, order=ORDER_REFERENCE):
+        self.L = lib()
+        self.cfg = cfg
+        self.order = order
+        self.h = self.L.orc_create(C.byref(cfg), order)
+        if not self.h:
+            raise ValueError("orc_create failed (bad covariance?)")
+        self.N = cfg.n_particles
+        self.nx, self.nu, self.ny = cfg.model.nx, cfg.model.nu, cfg.model.ny
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orc_destroy(self.h)
+            self.h = None
+
+    def seed(self, s):
+        self.L.orc_seed(self.h, s)
+
+    def reset(self, xi=None):
+        if xi is None:
+            self.L.orc_reset(self.h)
+        else:
+            self.L.orc_reset_explicit(self.h, dptr(_f64(xi)))
+
+    def correct(self, u, y, t):
+        u = _f64(u)
+        yy = None if y is None else _f64(y)
+        return self.L.orc_correct(self.h, dptr(u), dptr(yy), float(t))
+
+    def predict(self, u, t, xi=None, U=None):
+        u = _f64(u)
+        if xi is None:
+            self.L.orc_predict(self.h, dptr(u), float(t))
+        else:
+            self.L.orc_predict_explicit(self.h, dptr(u), float(t), dptr(_f64(xi)), dptr(_f64(U)))
+
+    def update(self, u, y, t):
+        u = _f64(u)
+        yy = None if y is None else _f64(y)
+        return self.L.orc_update(self.h, dptr(u), dptr(yy), float(t))
+
+    def run(self, U, Y, t_index0=0.0, ll_steps=False, xmean=False, history=False):
+        U = _f64(U).reshape(-1, max(self.nu, 1)) if self.nu else np.zeros((len(Y), 0))
+        Y = _f64(Y).reshape(-1, self.ny)
+        T = Y.shape[0]
+        out = {}
+        lls = np.zeros(T) if ll_steps else None
+        xm = np.zeros((T, self.nx)) if xmean else None
+        xh = np.zeros((T, self.N, self.nx)) if history else None
+        wh = np.zeros((T, self.N)) if history else None
+        weh = np.zeros((T, self.N)) if history else None
+        ll = self.L.orc_run(self.h, dptr(U), dptr(Y), T, float(t_index0), dptr(lls), dptr(xm),
+                            dptr(xh), dptr(wh), dptr(weh))
+        out.update(ll=ll, ll_steps=lls, xmean=xm, x=xh, w=wh, we=weh)
+        return out
+
+    def particles(self):
+        a = np.empty((self.N, self.nx))
+        self.L.orc_get_particles(self.h, dptr(a))
+        return a
+
+    def weights(self):
+        a = np.empty(self.N)
+        self.L.orc_get_weights(self.h, dptr(a))
+        return a
+
+    def expweights(self):
+        a = np.empty(self.N)
+        self.L.orc_get_expweights(self.h, dptr(a))
+        return a
+
+    def ancestors(self):
+        a = np.empty(self.N, dtype=np.int64)
+        self.L.orc_get_ancestors(self.h, iptr(a))
+        return a
+
+    def bins(self):
+        a = np.empty(self.N)
+        self.L.orc_get_bins(self.h, dptr(a))
+        return a
+
+    def set_particles(self, x):
+        self.L.orc_set_particles(self.h, dptr(_f64(x)))
+
+    def set_weights(self, w):
+        self.L.orc_set_weights(self.h, dptr(_f64(w)))
+
+    def set_index(self, t):
+        self.L.orc_set_index(self.h, int(t))
+
+    def index(self):
+        return self.L.orc_index(self.h)
+
+    def ess(self):
+        return self.L.orc_filter_ess(self.h)
+
+    def shouldresample(self):
+        return bool(self.L.orc_shouldresample(self.h))
+
+    def last_resampled(self):
+        return bool(self.L.orc_last_resampled(self.h))
+
+    def maxw(self):
+        return self.L.orc_maxw(self.h)
+
+    def resample_count(self):
+        return self.L.orc_resample_count(self.h)
+
+    def weighted_mean(self):
+        a = np.empty(self.nx)
+        self.L.orc_weighted_mean(self.h, dptr(a))
+        return a
+
+
+def logsumexp(w, order=ORDER_REFERENCE):
+    w = _f64(w).copy()
+    we = np.empty_like(w)
+    mw = C.c_double(0)
+    ll = lib().orc_logsumexp(dptr(w), dptr(we), w.size, order, C.byref(mw))
+    return ll, w, we, mw.value
+
+
+def resample(strategy, we, U, m=None, order=ORDER_REFERENCE, j0=None):
+    we = _f64(we)
+    n = we.size
+    m = n if m is None else m
+    j = np.zeros(m, dtype=np.int64) if j0 is None else np.ascontiguousarray(j0, dtype=np.int64).copy()
+    bins = np.zeros(n)
+    U = _f64(np.atleast_1d(U))
+    rc = lib().orc_resample(strategy, dptr(we), n, m, dptr(U), iptr(j), dptr(bins), order)
+    if rc != 0:
+        raise ValueError("degenerate weights")
+    return j, bins
+
+
+def resample_uniforms(strategy, m, seed, step):
+    u = np.zeros(1 if strategy == S.RESAMPLE_SYSTEMATIC else m)
+    lib().orc_resample_uniforms(strategy, m, seed, step, dptr(u))
+    return u
+
+
+def math_vec(which, x):
+    x = _f64(x)
+    out = np.empty_like(x)
+    lib().orc_math_vec(which, dptr(x), dptr(out), x.size)
+    return out
+
+
+def normals(seed, step, stream, nd, n):
+    out = np.empty((n, nd))
+    lib().orc_normals(seed, step, stream, nd, dptr(out), n)
+    return out
+
+
+def kalman_loglik(model, U, Y):
+    U = _f64(U)
+    Y = _f64(Y).reshape(-1, model.ny)
+    return lib().orc_kalman_loglik(C.byref(model), dptr(U), dptr(Y), Y.shape[0])

@@ -1,0 +1,353 @@
+"""GPU parity tests: the HIP engine, called through the C ABI, against the CPU oracle.
+
+ * against the DEVICE-ORDER oracle everything that feeds the recursion must be bit-identical
+   (particles, log-weights, log-likelihoods, ancestor indices), over whole trajectories;
+ * against the REFERENCE-ORDER oracle (literal restatement) floating point must agree to the stated
+   tolerances and ancestor indices may differ only at ulp-level ties (counted and bounded).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import llpf_amd
+from llpf_amd import _capi, _structs as S
+import models as M
+import oracle_binding as ob
+
+pytestmark = pytest.mark.gpu
+
+TOL_LL_STEP = 1e-10      # per-step |ll_gpu - ll_ref_order|   
+TOL_LL_SUM = 1e-8        # cumulative
+TOL_WE_REL = 1e-12       # max relative error of exp-weights vs reference order
+
+
+def _cfg(model, N, strategy=S.RESAMPLE_SYSTEMATIC, thr=0.1, seed=7, kind=S.PARTICLE_FILTER):
+    return S.make_config(model, N, kind, strategy, thr, seed, 0)
+
+
+def test_device_math_bit_identical_to_host():
+    rng = np.random.default_rng(0)
+    cases = {
+        0: np.concatenate([rng.uniform(-745, 1, 200000), -10.0 ** rng.uniform(-300, 2, 50000), [0.0, -0.0, -745.1, -746.0]]),
+        1: np.concatenate([rng.uniform(0, 1, 200000), 10.0 ** rng.uniform(-320, 300, 50000), [1.0, 0.5, 2.0]]),
+        2: 10.0 ** rng.uniform(-25, 8, 100000),
+        3: rng.uniform(0, 1, 200000),
+        4: rng.uniform(0, 1, 200000),
+        5: 10.0 ** rng.uniform(-300, 300, 100000),
+        6: 10.0 ** rng.uniform(-300, 300, 100000) * rng.choice([-1.0, 1.0], 100000),
+        7: rng.uniform(0, 1, 100000) * 10.0 ** rng.uniform(-5, 5, 100000),
+    }
+    for which, x in cases.items():
+        host = ob.math_vec(which, x)
+        dev = _capi.selftest_math(which, x)
+        assert np.array_equal(host.view(np.uint64), dev.view(np.uint64)), "primitive %d differs host/device" % which
+
+
+def test_device_normals_bit_identical_to_host():
+    for nd in (1, 2, 3, 4):
+        host = ob.normals(12345, 17, 1, nd, 100000)
+        dev = _capi.selftest_normals(12345, 17, 1, nd, 100000)
+        assert np.array_equal(host.view(np.uint64), dev.view(np.uint64))
+    assert abs(dev.mean()) < 0.01 and abs(dev.var() - 1.0) < 0.01
+
+
+def _compare_state(g, o, exact=True, we_rtol=0.0):
+    xg, xo = g.particles(), o.particles()
+    wg, wo = g.weights(), o.weights()
+    eg, eo = g.expweights(), o.expweights()
+    if exact:
+        assert np.array_equal(xg.view(np.uint64), xo.view(np.uint64)), "particles differ"
+        assert np.array_equal(wg.view(np.uint64), wo.view(np.uint64)), "log-weights differ"
+        assert np.array_equal(eg.view(np.uint64), eo.view(np.uint64)), "exp-weights differ"
+        assert np.array_equal(g.ancestors(), o.ancestors()), "ancestors differ"
+    else:
+        np.testing.assert_allclose(xg, xo, rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(eg, eo, rtol=we_rtol, atol=1e-300)
+
+
+@pytest.mark.parametrize("strategy", [S.RESAMPLE_SYSTEMATIC, S.RESAMPLE_STRATIFIED])
+@pytest.mark.parametrize("thr", [0.1, 1.0])
+def test_c1_trajectory_bit_exact_vs_device_order_oracle(strategy, thr):
+    """BASELINE config C1 (N=500, T=200, nx=nu=ny=2): fused on-device loop == oracle, bit for bit."""
+    model = M.lg_c1_model()
+    _, U, Y = M.simulate_lg(model, 200)
+    cfg = _cfg(model, 500, strategy, thr)
+    g = _capi.FilterHandle(cfg)
+    o = ob.OracleFilter(cfg, ob.ORDER_DEVICE)
+    _compare_state(g, o)                       # constructor draw
+    g.reset(); o.reset()
+    _compare_state(g, o)
+    rg = g.run(U, Y, 0.0, ll_steps=True, xmean=True)
+    ro = o.run(U, Y, 0.0, ll_steps=True, xmean=True)
+    assert np.array_equal(rg["ll_steps"].view(np.uint64), ro["ll_steps"].view(np.uint64))
+    assert rg["ll"] == ro["ll"]
+    np.testing.assert_allclose(rg["xmean"], ro["xmean"], rtol=1e-12, atol=1e-13)
+    _compare_state(g, o)
+    assert g.resample_count() == o.resample_count()
+    assert g.index() == o.index() == 201
+    if thr == 1.0:
+        assert g.resample_count() == 200
+
+
+def test_step_by_step_equals_fused_loop_and_oracle():
+    """correct!/predict! as separate calls (unfused kernels) give the same bits as the fused loop."""
+    model = M.lg_c1_model()
+    _, U, Y = M.simulate_lg(model, 60)
+    cfg = _cfg(model, 3000, thr=0.5)
+    g1, g2 = _capi.FilterHandle(cfg), _capi.FilterHandle(cfg)
+    o = ob.OracleFilter(cfg, ob.ORDER_DEVICE)
+    for h in (g1, g2, o):
+        h.reset()
+    r1 = g1.run(U, Y, 0.0, ll_steps=True)
+    lls = []
+    for k in range(60):
+        ll_g = g2.correct(U[k], Y[k], k * 1.0)
+        ll_o = o.correct(U[k], Y[k], k * 1.0)
+        assert ll_g == ll_o
+        assert g2.ess() == o.ess()
+        assert g2.shouldresample() == o.shouldresample()
+        if k % 20 == 3:
+            _compare_state(g2, o)
+            assert np.array_equal(g2.weighted_mean(), g2.weighted_mean())
+            np.testing.assert_allclose(g2.weighted_mean(), o.weighted_mean(), rtol=1e-12, atol=1e-13)
+        g2.predict(U[k], k * 1.0)
+        o.predict(U[k], k * 1.0)
+        assert g2.last_resampled() == o.last_resampled()
+        lls.append(ll_g)
+    assert np.array_equal(np.array(lls).view(np.uint64), r1["ll_steps"].view(np.uint64))
+    _compare_state(g1, o)
+    _compare_state(g2, o)
+
+
+def test_c1_vs_reference_order_oracle_tolerances():
+    """Against the literal (reference-order) restatement: fp within tolerance, indices equal up to ulp ties."""
+    model = M.lg_c1_model()
+    _, U, Y = M.simulate_lg(model, 200)
+    cfg = _cfg(model, 500, thr=0.1)
+    g = _capi.FilterHandle(cfg)
+    o = ob.OracleFilter(cfg, ob.ORDER_REFERENCE)
+    g.reset(); o.reset()
+    rg = g.run(U, Y, 0.0, ll_steps=True)
+    ro = o.run(U, Y, 0.0, ll_steps=True)
+    assert np.max(np.abs(rg["ll_steps"] - ro["ll_steps"])) <= TOL_LL_STEP
+    assert abs(rg["ll"] - ro["ll"]) <= TOL_LL_SUM
+    assert g.resample_count() == o.resample_count()
+    mism = int(np.sum(g.ancestors() != o.ancestors()))
+    assert mism == 0, "ancestor mismatches vs reference-order oracle: %d" % mism
+    np.testing.assert_allclose(g.expweights(), o.expweights(), rtol=TOL_WE_REL, atol=1e-300)
+
+
+@pytest.mark.parametrize("N", [1, 2, 63, 64, 65, 2047, 2048, 2049, 5000])
+def test_ragged_sizes(N):
+    model = M.lg_test_model()
+    _, U, Y = M.simulate_lg(model, 25)
+    cfg = _cfg(model, N, thr=1.0)
+    g = _capi.FilterHandle(cfg)
+    o = ob.OracleFilter(cfg, ob.ORDER_DEVICE)
+    g.reset(); o.reset()
+    rg = g.run(U, Y, 1.0, ll_steps=True)
+    ro = o.run(U, Y, 1.0, ll_steps=True)
+    assert np.array_equal(rg["ll_steps"].view(np.uint64), ro["ll_steps"].view(np.uint64))
+    _compare_state(g, o)
+
+
+@pytest.mark.parametrize("kind", [S.COV_SCAL, S.COV_DIAG, S.COV_FULL])
+def test_covariance_kinds(kind):
+    rng = np.random.default_rng(5)
+    nx, nu, ny = 3, 2, 2
+    A = 0.8 * np.eye(nx) + 0.05 * rng.standard_normal((nx, nx))
+    B = rng.standard_normal((nx, nu)); Cm = rng.standard_normal((ny, nx))
+
+    def cov(n):
+        if kind == S.COV_SCAL:
+            return 0.3
+        if kind == S.COV_DIAG:
+            return rng.uniform(0.1, 0.5, n)
+        Q = rng.standard_normal((n, n))
+        return Q @ Q.T + 0.2 * np.eye(n)
+    df = S.make_gaussian(0.01 * rng.standard_normal(nx), cov(nx), kind)
+    dg = S.make_gaussian(0.01 * rng.standard_normal(ny), cov(ny), kind)
+    d0 = S.make_gaussian(rng.standard_normal(nx), cov(nx), kind)
+    model = S.make_lg_model(A, B, Cm, df, dg, d0)
+    _, U, Y = M.simulate_lg(model, 40)
+    cfg = _cfg(model, 4096, thr=0.5)
+    g = _capi.FilterHandle(cfg); o = ob.OracleFilter(cfg, ob.ORDER_DEVICE); r = ob.OracleFilter(cfg, ob.ORDER_REFERENCE)
+    for h in (g, o, r):
+        h.reset()
+    rg = g.run(U, Y, 0.0, ll_steps=True); ro = o.run(U, Y, 0.0, ll_steps=True); rr = r.run(U, Y, 0.0, ll_steps=True)
+    assert np.array_equal(rg["ll_steps"].view(np.uint64), ro["ll_steps"].view(np.uint64))
+    _compare_state(g, o)
+    assert np.max(np.abs(rg["ll_steps"] - rr["ll_steps"])) <= TOL_LL_STEP
+
+
+def test_quadtank_bit_exact_and_tolerance():
+    """BASELINE config C3 model (quad-tank, RK4 x2) at oracle-feasible size, crossing the t>500 switch."""
+    model = M.quadtank_model()
+    U, Y = M.quadtank_data(40)
+    cfg = _cfg(model, 6000, thr=0.5, kind=S.ADVANCED_PARTICLE_FILTER)
+    g = _capi.FilterHandle(cfg); o = ob.OracleFilter(cfg, ob.ORDER_DEVICE); r = ob.OracleFilter(cfg, ob.ORDER_REFERENCE)
+    for h in (g, o, r):
+        h.reset()
+    t0 = 485.0      # steps 485..524: the a1 switch at t > 500 is crossed inside rk4 stages
+    rg = g.run(U, Y, t0, ll_steps=True); ro = o.run(U, Y, t0, ll_steps=True); rr = r.run(U, Y, t0, ll_steps=True)
+    assert np.array_equal(rg["ll_steps"].view(np.uint64), ro["ll_steps"].view(np.uint64))
+    _compare_state(g, o)
+    assert np.max(np.abs(rg["ll_steps"] - rr["ll_steps"])) <= 1e-9
+    assert g.resample_count() == o.resample_count() > 0
+
+
+def test_missing_measurement():
+    model = M.lg_c1_model()
+    _, U, Y = M.simulate_lg(model, 30)
+    Y[[3, 4, 17]] = np.nan
+    cfg = _cfg(model, 1000, thr=0.3)
+    g = _capi.FilterHandle(cfg); o = ob.OracleFilter(cfg, ob.ORDER_DEVICE)
+    g.reset(); o.reset()
+    rg = g.run(U, Y, 0.0, ll_steps=True); ro = o.run(U, Y, 0.0, ll_steps=True)
+    assert np.array_equal(rg["ll_steps"].view(np.uint64), ro["ll_steps"].view(np.uint64))
+    _compare_state(g, o)
+    # and through the single-step entry point with y = None
+    assert g.correct(U[0], None, 0.0) == o.correct(U[0], None, 0.0)
+
+
+def test_history_outputs_match_oracle():
+    """forward_trajectory's x / w / we history (reference src/filtering.jl:357-359)."""
+    model = M.lg_c1_model()
+    _, U, Y = M.simulate_lg(model, 20)
+    cfg = _cfg(model, 700, thr=0.5)
+    g = _capi.FilterHandle(cfg); o = ob.OracleFilter(cfg, ob.ORDER_DEVICE)
+    g.reset(); o.reset()
+    rg = g.run(U, Y, 0.0, history=True); ro = o.run(U, Y, 0.0, history=True)
+    for k in ("x", "w", "we"):
+        assert np.array_equal(rg[k].view(np.uint64), ro[k].view(np.uint64)), k
+    assert np.allclose(rg["we"].sum(axis=1), 1.0, atol=1e-12)
+
+
+@pytest.mark.parametrize("strategy", [S.RESAMPLE_SYSTEMATIC, S.RESAMPLE_STRATIFIED])
+@pytest.mark.parametrize("n,m", [(10, 10), (9, 9), (1000, 1000), (5000, 5000), (4097, 300), (300, 4097)])
+def test_standalone_resample_matches_oracle(strategy, n, m):
+    rng = np.random.default_rng(n + m)
+    we = rng.exponential(size=n) ** 3
+    we /= we.sum()
+    U = rng.uniform(size=1 if strategy == S.RESAMPLE_SYSTEMATIC else m)
+    jg = _capi.resample(strategy, we, U, m)
+    jd, _ = ob.resample(strategy, we, U, m, ob.ORDER_DEVICE)
+    jr, _ = ob.resample(strategy, we, U, m, ob.ORDER_REFERENCE)
+    assert np.array_equal(jg, jd)
+    assert np.sum(jg != jr) <= 1          # ulp-level ties only
+    assert jg.min() >= 0 and jg.max() < n
+    if m <= n:      # for M > N the reference's offset r = rand()*bins[end]/N can push the last thresholds past
+        assert np.all(np.diff(jg) >= 0)   # bins[N]; those outputs are never written (stay 0 here)
+
+
+def test_standalone_resample_degenerate_and_stale():
+    # one particle holds all the weight
+    we = np.zeros(3000); we[1234] = 1.0
+    for strategy in (S.RESAMPLE_SYSTEMATIC, S.RESAMPLE_STRATIFIED):
+        U = np.full(1 if strategy == S.RESAMPLE_SYSTEMATIC else 3000, 0.37)
+        assert np.all(_capi.resample(strategy, we, U) == 1234)
+    # thresholds that reach bins[N]: those outputs keep their input value (reference: j[i] not written)
+    we = np.full(8, 0.125)
+    U = np.array([1.0 - 2.0 ** -53])
+    j0 = np.full(8, 77, dtype=np.int64)
+    jg = _capi.resample(S.RESAMPLE_SYSTEMATIC, we, U, 8, j0)
+    jd, _ = ob.resample(S.RESAMPLE_SYSTEMATIC, we, U, 8, ob.ORDER_DEVICE, j0)
+    assert np.array_equal(jg, jd)
+
+
+def test_standalone_logsumexp_matches_oracle():
+    rng = np.random.default_rng(3)
+    for n in (10, 1000, 4096, 100001):
+        w = rng.standard_normal(n) * 30
+        ll_g, w_g, we_g = _capi.logsumexp(w)
+        ll_d, w_d, we_d, _ = ob.logsumexp(w, ob.ORDER_DEVICE)
+        ll_r, w_r, we_r, _ = ob.logsumexp(w, ob.ORDER_REFERENCE)
+        assert ll_g == ll_d
+        assert np.array_equal(w_g.view(np.uint64), w_d.view(np.uint64))
+        assert np.array_equal(we_g.view(np.uint64), we_d.view(np.uint64))
+        assert abs(ll_g - ll_r) <= 1e-12 * max(1.0, abs(ll_r))
+        np.testing.assert_allclose(we_g, we_r, rtol=TOL_WE_REL, atol=1e-300)
+        assert abs(we_g.sum() - 1) < 1e-12
+
+
+def test_degenerate_weights_are_reported():
+    model = M.lg_test_model()
+    cfg = _cfg(model, 100)
+    g = _capi.FilterHandle(cfg)
+    with pytest.raises(_capi.DegenerateWeights):
+        g.set_weights(np.full(100, -np.inf))
+
+
+def test_set_state_roundtrip_and_teacher_forced_step():
+    """Install an arbitrary state on both sides, take one step, compare (also vs reference order)."""
+    model = M.lg_test_model()
+    rng = np.random.default_rng(11)
+    N = 20000
+    cfg = _cfg(model, N, thr=1.0)
+    g = _capi.FilterHandle(cfg); o = ob.OracleFilter(cfg, ob.ORDER_DEVICE); r = ob.OracleFilter(cfg, ob.ORDER_REFERENCE)
+    x = rng.standard_normal((N, 2)) * 3
+    w = rng.standard_normal(N) * 4
+    for h in (g, o, r):
+        h.set_particles(x); h.set_weights(w)
+    assert np.array_equal(g.particles(), x)
+    assert np.array_equal(g.weights(), w)
+    np.testing.assert_allclose(g.expweights(), r.expweights(), rtol=TOL_WE_REL)
+    assert g.ess() == o.ess()
+    assert abs(g.ess() - r.ess()) <= 1e-9 * r.ess()
+    np.testing.assert_array_equal(g.bins(), o_bins_after_predict(o, cfg))
+    u = np.array([0.3])
+    g.predict(u, 0.0); r.predict(u, 0.0)
+    mism = int(np.sum(g.ancestors() != r.ancestors()))
+    assert mism <= 2, mism
+    o2 = ob.OracleFilter(cfg, ob.ORDER_DEVICE)
+    o2.set_particles(x); o2.set_weights(w); o2.predict(u, 0.0)
+    _compare_state(g, o2)
+
+
+def o_bins_after_predict(o, cfg):
+    """The oracle materialises bins during the resampling predict!; the GPU getter returns the bins of the
+    current weights.  Run a throw-away predict on the oracle copy to obtain them."""
+    o.predict(np.array([0.0]), 0.0)
+    return o.bins()
+
+
+def test_bank_equals_individual_filters():
+    """Filter k of a bank with seed s is bit-identical to a single filter with seed s + k."""
+    svec = 10.0 ** np.linspace(-2, 0, 5)
+    models = [M.lg_test_model(s) for s in svec]
+    _, U, Y = M.simulate_lg(models[2], 50)
+    N = 3000
+    base = _cfg(models[0], N, thr=0.1, seed=100)
+    bank = _capi.BankHandle(base, models)
+    bank.reset()
+    rb = bank.run(U, Y, 1.0, ll_steps=True)
+    for k, mk in enumerate(models):
+        cfg = _cfg(mk, N, thr=0.1, seed=100 + k)
+        g = _capi.FilterHandle(cfg)
+        g.reset()
+        rg = g.run(U, Y, 1.0, ll_steps=True)
+        assert rg["ll"] == rb["ll"][k]
+        assert np.array_equal(rg["ll_steps"].view(np.uint64), rb["ll_steps"][:, k].copy().view(np.uint64))
+
+
+def test_python_api_mirror_smoke():
+    """The mirrored reference API (names of src/LowLevelParticleFilters.jl:3) end to end."""
+    rng = np.random.default_rng(0)
+    A = np.array([[0.97043, -0.097368], [0.09736, 0.970437]]); B = np.array([[0.1], [0.0]]); Cm = np.array([[0.0, 1.0]])
+    df = llpf_amd.MvNormal(np.zeros(2), 0.01); dg = llpf_amd.MvNormal(np.zeros(1), 1.0); d0 = llpf_amd.MvNormal(np.array([1.0, 1.0]), 4.0)
+    pf = llpf_amd.ParticleFilter(1000, llpf_amd.LinearDynamics(A, B), llpf_amd.LinearMeasurement(Cm), df, dg, d0, rng=3)
+    assert not llpf_amd.shouldresample(pf)                          # test/runtests.jl:274
+    x, u, y = llpf_amd.simulate(pf, 100, llpf_amd.MvNormal(np.zeros(1), 1.0), rng=rng)
+    ll, _ = pf(u[0], y[0])
+    assert np.isfinite(ll)
+    sol = llpf_amd.forward_trajectory(pf, u, y)
+    assert sol.x.shape == (100, 1000, 2) and sol.w.shape == (100, 1000) and np.isfinite(sol.ll)
+    xh, ll2 = llpf_amd.mean_trajectory(pf, u, y)
+    assert xh.shape == (100, 2)
+    assert np.mean((xh - x) ** 2) < 5
+    assert abs(llpf_amd.loglik(pf, u, y) - sol.ll) < 30
+    assert llpf_amd.num_particles(pf) == 1000 and llpf_amd.particles(pf).shape == (1000, 2)
+    j = llpf_amd.resample(pf)
+    assert j.shape == (1000,) and j.min() >= 0 and j.max() < 1000
+    assert abs(llpf_amd.effective_particles(np.full(10, 0.1)) - 10) < 1e-9
