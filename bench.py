@@ -1,0 +1,174 @@
+"""bench.py — throughput of the particle-filter hot path on MI355X.
+
+One "step" = one loglik-style pass of the hot path over one batch of synthetic input: reset! followed by
+T filter timesteps (correct! + predict!, reference src/filtering.jl:164-168,140-153) for N particles,
+enqueued on the device through the C ABI (llpf_run).  Metric: particle-steps/s = ranks * K * N * T / time.
+
+Default workload = BASELINE.json configs[1]: 2-D linear-Gaussian ParticleFilter (the reference's test
+system, test/runtests.jl:255-266), N = 1e6, T = 1000, systematic resampling at every step
+(resample_threshold = 1.0, so the scan/expansion kernel runs in all T steps).
+
+N > 1 GPUs: one process per GPU (torch.distributed, backend nccl = RCCL); every rank runs its own
+independent filter instance (different Philox key) and the only collective is an all-reduce of the
+log-likelihoods after each pass — weak scaling.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np
+
+
+def build_workload(name, n_particles, T):
+    import models as M
+    from llpf_amd import _structs as S
+    if name == "lg":
+        model = M.lg_test_model()
+        _, U, Y = M.simulate_lg(model, T, seed=1)
+        kind, thr = S.PARTICLE_FILTER, 1.0
+        label = "C2: 2-D linear-Gaussian ParticleFilter (test/runtests.jl:255-266 system), N=%d, T=%d, systematic, resample every step" % (n_particles, T)
+    elif name == "quadtank":
+        model = M.quadtank_model()
+        U, Y = M.quadtank_data(T, seed=2)
+        kind, thr = S.ADVANCED_PARTICLE_FILTER, 0.5
+        label = "C3: quad-tank AdvancedParticleFilter RK4x2, N=%d, T=%d, systematic, threshold 0.5" % (n_particles, T)
+    else:
+        raise ValueError(name)
+    return model, U, Y, kind, thr, label
+
+
+def cpu_baseline(model, U, Y, kind, thr, n_particles, budget_steps):
+    """The reference-order oracle (literal CPU restatement, 1 thread — the reference's ParticleFilter path is
+    single-threaded, src/PFtypes.jl:107-139) timed on a bounded sample of the same workload."""
+    import oracle_binding as ob
+    from llpf_amd import _structs as S
+    cfg = S.make_config(model, n_particles, kind, S.RESAMPLE_SYSTEMATIC, thr, 1, 0)
+    o = ob.OracleFilter(cfg, ob.ORDER_REFERENCE)
+    o.reset()
+    Ts = min(budget_steps, len(Y))
+    t0 = time.perf_counter()
+    o.run(U[:Ts], Y[:Ts], 1.0)
+    dt = time.perf_counter() - t0
+    return {"value": n_particles * Ts / dt, "unit": "particle-steps/s", "cores": 1, "kind": "port",
+            "sample": "first %d of the %d timesteps of the same workload at N=%d (%.1f s of CPU)" % (Ts, len(Y), n_particles, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="lg", choices=["lg", "quadtank"])
+    ap.add_argument("--particles", type=int, default=1000000)
+    ap.add_argument("--T", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=None, help="timesteps of the CPU baseline sample")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    dev = local_rank if world > 1 else 0
+
+    from llpf_amd import _capi, _structs as S
+    T = args.T if args.T else (1000 if args.workload == "lg" else 2000)
+    model, U, Y, kind, thr, label = build_workload(args.workload, args.particles, T)
+    N = args.particles
+    cfg = S.make_config(model, N, kind, S.RESAMPLE_SYSTEMATIC, thr, 1000 + rank, dev)
+    pf = _capi.FilterHandle(cfg)
+    ll_dev = torch.zeros(1, dtype=torch.float64, device="cuda:%d" % dev)
+
+    def one_pass():
+        pf.reset()
+        r = pf.run(U, Y, 1.0)
+        if world > 1:
+            ll_dev[0] = r["ll"]
+            dist.all_reduce(ll_dev)          # the global log-likelihood: the only collective of the path
+        return r["ll"]
+
+    for _ in range(args.warmup):
+        one_pass()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dev_ms = 0.0
+    for _ in range(args.steps):
+        ll = one_pass()
+        dev_ms += pf.last_run_ms()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda:%d" % dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    resamples = pf.resample_count()
+
+    # per-kernel durations with HIP events on the engine's own stream (separate passes so that the
+    # event records do not perturb the timed region above)
+    prof = None
+    if rank == 0:
+        pf.set_profiling(True)
+        for _ in range(max(1, min(args.steps, 3))):
+            pf.reset()
+            pf.run(U, Y, 1.0)
+        ms, cnt = pf.profile()
+        pf.set_profiling(False)
+        prof = (ms, cnt)
+
+    out = None
+    if rank == 0:
+        nx = model.nx
+        value = world * args.steps * N * T / dt
+        ms_cls, n_cls = prof
+        names = ["k_step(propagate+weight)", "k_norm(logsumexp partials)", "k_resample(scan+expand)", "k_finalize+other"]
+        kernel_us = {names[i]: (1e3 * ms_cls[i] / n_cls[i] if n_cls[i] else None) for i in range(4)}
+        # dominant kernel: k_step.  Algorithmic bytes per particle for a resampling step:
+        # gather-read xprev 8nx + write x 8nx + read ancestor 4 + write w 8
+        b_step = 16 * nx + 12
+        step_s = ms_cls[0] / n_cls[0] * 1e-3
+        achieved = N * b_step / step_s / 1e9
+        b_alg = 16 * nx + 40                         # whole-timestep algorithmic bytes
+        timestep_s = dt / (args.steps * T)
+        roof = {"bound": "hbm", "kernel": "k_step<MODE_PROP_WEIGHT>", "achieved": achieved, "peak": 8000.0,
+                "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                "bytes_per_launch": N * b_step, "avg_launch_us": step_s * 1e6,
+                "method": "hipEvent pairs around every launch on the engine stream, %d profiled passes after the timed region" % max(1, min(args.steps, 3)),
+                "whole_timestep": {"algorithmic_bytes": N * b_alg, "us": timestep_s * 1e6,
+                                   "achieved": N * b_alg / timestep_s / 1e9, "frac": N * b_alg / timestep_s / 8e12}}
+        out = {"metric": "particle-steps/s", "value": value, "unit": "particle-steps/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+               "data": "synthetic",
+               "config": {"workload": label, "particles": N, "timesteps": T, "nx": nx, "resample_threshold": thr,
+                          "resamples_per_pass": int(resamples), "parallelism": "independent filter per GPU, all-reduce of log-likelihood" if world > 1 else "1 GPU"},
+               "device_ms_per_step": dev_ms / args.steps, "kernel_us": kernel_us, "loglik": ll,
+               "roofline": roof}
+        if world == 1 and not args.no_cpu_baseline:
+            per = 1.0e7 if args.workload == "lg" else 2.0e6        # rough 1-core rate, to size a 10-30 s sample
+            cs = args.cpu_steps if args.cpu_steps else max(2, min(T, int(15 * per / N)))
+            out["cpu_baseline"] = cpu_baseline(model, U, Y, kind, thr, N, cs)
+            out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
