@@ -125,8 +125,10 @@ struct Bank {
     int cur = 0;
     double* d_w = nullptr;
     int32_t* d_anc = nullptr;
-    double* d_pmax = nullptr;
-    NormPartial* d_part = nullptr;
+    uint64_t* d_acc = nullptr;
+    uint64_t* d_tileq = nullptr;
+    double* d_xmpart = nullptr;
+    int parity = 0;                  // which max-accumulator set the NEXT weighting kernel writes
     double* d_uy = nullptr;          // staging for single-step u / y (2 * MAXD)
     double* d_U = nullptr;           // resident inputs of a run
     double* d_Y = nullptr;
@@ -160,7 +162,7 @@ struct Bank {
         b.mlogN = -llpf_log((double)N);
         b.models = d_models; b.scal = d_scal;
         b.xcur = d_x[cur]; b.xnext = d_x[cur ^ 1];
-        b.w = d_w; b.anc = d_anc; b.pmax = d_pmax; b.part = d_part;
+        b.w = d_w; b.anc = d_anc; b.acc = d_acc; b.tileq = d_tileq; b.xmpart = d_xmpart;
         return b;
     }
 };
@@ -177,7 +179,7 @@ static void free_bank(Bank& b) {
     hipSetDevice(b.device);
     if (b.stream) hipStreamSynchronize(b.stream);
     hipFree(b.d_models); hipFree(b.d_scal); hipFree(b.d_x[0]); hipFree(b.d_x[1]); hipFree(b.d_w);
-    hipFree(b.d_anc); hipFree(b.d_pmax); hipFree(b.d_part); hipFree(b.d_uy); hipFree(b.d_U); hipFree(b.d_Y);
+    hipFree(b.d_anc); hipFree(b.d_acc); hipFree(b.d_tileq); hipFree(b.d_xmpart); hipFree(b.d_uy); hipFree(b.d_U); hipFree(b.d_Y);
     hipFree(b.d_ll_steps); hipFree(b.d_xmean); hipFree(b.d_tmp);
     for (auto e : b.ev_pool) hipEventDestroy(e);
     for (auto& e : b.pending) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
@@ -257,6 +259,8 @@ static int bank_init_particles(Bank& b, bool is_reset) {
         if (!is_reset) { s.anc_ident = 1; s.last_resampled = 0; s.resample_count = 0; s.ll_total = 0.0; }
     }
     CHK(scal_upload(b, h));
+    HIPC(hipMemsetAsync(b.d_acc, 0, sizeof(uint64_t) * (size_t)b.F * ACC_WORDS, b.stream));
+    b.parity = 0;
     HIPC(launch_init(d, b.n_reset, is_reset ? 0 : 1, b.stream));
     b.n_reset++;
     b.t_index = is_reset ? 1 : 0;
@@ -307,15 +311,18 @@ static int bank_create(const llpf_config* cfg, const llpf_model* models, int F, 
     HIPC(hipMalloc(&b.d_x[1], sizeof(double) * FN * b.nx));
     HIPC(hipMalloc(&b.d_w, sizeof(double) * FN));
     HIPC(hipMalloc(&b.d_anc, sizeof(int32_t) * FN));
-    HIPC(hipMalloc(&b.d_pmax, sizeof(double) * (size_t)F * b.P1));
-    HIPC(hipMalloc(&b.d_part, sizeof(NormPartial) * (size_t)F * b.P2));
+    HIPC(hipMalloc(&b.d_acc, sizeof(uint64_t) * (size_t)F * ACC_WORDS));
+    HIPC(hipMalloc(&b.d_tileq, sizeof(uint64_t) * (size_t)F * b.P2));
+    HIPC(hipMalloc(&b.d_xmpart, sizeof(double) * (size_t)F * b.P2 * MAXD));
     HIPC(hipMalloc(&b.d_uy, sizeof(double) * 4 * MAXD));
     HIPC(hipMalloc(&b.d_tmp, sizeof(double) * (size_t)F * b.N * (b.nx > 1 ? b.nx : 1) + 64));
     HIPC(hipMemsetAsync(b.d_x[0], 0, sizeof(double) * FN * b.nx, b.stream));
     HIPC(hipMemsetAsync(b.d_x[1], 0, sizeof(double) * FN * b.nx, b.stream));
     HIPC(hipMemsetAsync(b.d_anc, 0, sizeof(int32_t) * FN, b.stream));
     HIPC(hipMemsetAsync(b.d_scal, 0, sizeof(FilterScal) * F, b.stream));
-    HIPC(hipMemsetAsync(b.d_part, 0, sizeof(NormPartial) * (size_t)F * b.P2, b.stream));
+    HIPC(hipMemsetAsync(b.d_acc, 0, sizeof(uint64_t) * (size_t)F * ACC_WORDS, b.stream));
+    HIPC(hipMemsetAsync(b.d_tileq, 0, sizeof(uint64_t) * (size_t)F * b.P2, b.stream));
+    HIPC(hipMemsetAsync(b.d_xmpart, 0, sizeof(double) * (size_t)F * b.P2 * MAXD, b.stream));
     HIPC(hipMemcpyAsync(b.d_models, hm.data(), sizeof(ModelD) * F, hipMemcpyHostToDevice, b.stream));
     HIPC(hipStreamSynchronize(b.stream));
     HIPC(hipEventCreate(&b.ev_run0));
@@ -344,11 +351,13 @@ static int bank_correct(Bank& b, const double* u, const double* y, double t, dou
     BankDev d = b.dev();
     StepArgs a{};
     a.u = b.d_uy; a.y = b.d_uy + MAXD; a.t_prop = t; a.t_meas = t; a.step = 0; a.has_y = has_y ? 1 : 0;
+    a.parity = b.parity;
     HIPC(launch_step(d, MODE_WEIGHT, a, b.stream));
-    HIPC(launch_norm(d, 0, b.stream));
-    FinalizeArgs fa{};
-    fa.ll_steps = nullptr; fa.xmean = nullptr; fa.k = 0; fa.keep_norm = 0; fa.accumulate = 0; fa.after_predict = 0;
-    HIPC(launch_finalize(d, fa, b.stream));
+    HIPC(launch_norm(d, b.parity, 0, b.stream));
+    ResArgs ra{};
+    ra.mode = RES_FINALIZE; ra.parity = b.parity; ra.M = (int32_t)b.N;
+    HIPC(launch_resample(d, ra, b.stream));
+    b.parity ^= 1;
     std::vector<FilterScal> h;
     CHK(scal_download(b, h));
     if (ll_out) for (int f = 0; f < b.F; ++f) ll_out[f] = h[f].ll;
@@ -361,10 +370,11 @@ static int bank_predict(Bank& b, const double* u, double t) {
     if (u) for (int i = 0; i < b.nu; ++i) hbuf[i] = u[i];
     HIPC(hipMemcpyAsync(b.d_uy, hbuf, sizeof(hbuf), hipMemcpyHostToDevice, b.stream));
     BankDev d = b.dev();
-    HIPC(launch_decide(d, b.stream));
-    HIPC(launch_resample(d, b.n_predict, nullptr, b.N, b.d_anc, nullptr, 0, 0, 0, b.stream));
+    ResArgs ra{};
+    ra.mode = RES_RESAMPLE; ra.parity = b.parity ^ 1; ra.step = b.n_predict; ra.M = (int32_t)b.N; ra.anc_out = b.d_anc;
+    HIPC(launch_resample(d, ra, b.stream));
     StepArgs a{};
-    a.u = b.d_uy; a.y = nullptr; a.t_prop = t; a.t_meas = t; a.step = b.n_predict; a.has_y = 0;
+    a.u = b.d_uy; a.y = nullptr; a.t_prop = t; a.t_meas = t; a.step = b.n_predict; a.has_y = 0; a.parity = b.parity;
     HIPC(launch_step(d, MODE_PROP, a, b.stream));
     HIPC(launch_post_predict(d, b.stream));
     b.cur ^= 1;
@@ -416,24 +426,29 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
         BankDev d = b.dev();
         StepArgs a{};
         a.u = b.nu > 0 ? b.d_U : nullptr; a.y = b.d_Y; a.t_prop = tk(0); a.t_meas = tk(0); a.step = 0; a.has_y = has_y(0) ? 1 : 0;
+        a.parity = b.parity;
         ProfScope ps(b, LLPF_PROF_PROPAGATE);
         HIPC(launch_step(d, MODE_WEIGHT, a, b.stream));
     }
     for (int64_t k = 0; k < T; ++k) {
         BankDev d = b.dev();
-        {   // logsumexp! of correct!(u_k, y_k)
+        const int par = b.parity;            // parity of the weighting that produced the current weights
+        b.parity ^= 1;
+        {   // logsumexp! of correct!(u_k, y_k): exp-weights and their sums
             ProfScope ps(b, LLPF_PROF_NORMALISE);
-            HIPC(launch_norm(d, want_xm, b.stream));
+            HIPC(launch_norm(d, par, want_xm, b.stream));
         }
-        {
-            ProfScope ps(b, LLPF_PROF_OTHER);
-            FinalizeArgs fa{};
-            fa.ll_steps = ll_steps ? b.d_ll_steps : nullptr;
-            fa.xmean = xmean ? b.d_xmean : nullptr;
-            fa.k = k; fa.keep_norm = 0; fa.accumulate = 1; fa.after_predict = (k > 0) ? 1 : 0;
-            HIPC(launch_finalize(d, fa, b.stream));
-        }
-        if (x_hist || w_hist || we_hist) {   // forward_trajectory history (reference src/filtering.jl:357-359); not a timed path
+        const bool hist = x_hist || w_hist || we_hist;
+        ResArgs ra{};
+        ra.parity = par; ra.step = b.n_predict; ra.M = (int32_t)b.N; ra.anc_out = b.d_anc;
+        ra.accumulate = 1; ra.want_xmean = want_xm;
+        ra.ll_steps = ll_steps ? b.d_ll_steps : nullptr;
+        ra.xmean = xmean ? b.d_xmean : nullptr;
+        ra.k = k;
+        if (hist) {   // forward_trajectory history (reference src/filtering.jl:357-359) needs the normalised state
+                      // between correct! and predict!: split finalize and resample.  Not a timed path.
+            ra.mode = RES_FINALIZE;
+            HIPC(launch_resample(d, ra, b.stream));
             if (x_hist) {
                 HIPC(launch_soa2aos(d, b.d_x[b.cur], b.d_tmp, b.stream));
                 HIPC(hipMemcpyAsync(x_hist + (size_t)k * b.N * b.nx, b.d_tmp, sizeof(double) * b.N * b.nx, hipMemcpyDeviceToHost, b.stream));
@@ -449,16 +464,20 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
                 HIPC(hipMemcpyAsync(we_hist + (size_t)k * b.N, b.d_tmp, sizeof(double) * b.N, hipMemcpyDeviceToHost, b.stream));
                 HIPC(hipStreamSynchronize(b.stream));
             }
-        }
-        {   // predict!(u_k): resample if the device-side decision says so ...
+            ra.mode = RES_RESAMPLE;
+            ra.accumulate = 0; ra.ll_steps = nullptr; ra.xmean = nullptr;
+            HIPC(launch_resample(d, ra, b.stream));
+        } else {      // scalars of correct!(u_k, y_k) + shouldresample + resample of predict!(u_k), one launch
+            ra.mode = RES_FINALIZE | RES_RESAMPLE;
             ProfScope ps(b, LLPF_PROF_RESAMPLE);
-            HIPC(launch_resample(d, b.n_predict, nullptr, b.N, b.d_anc, nullptr, 0, 0, 0, b.stream));
+            HIPC(launch_resample(d, ra, b.stream));
         }
         {   // ... propagate, fused with the weighting of correct!(u_{k+1}, y_{k+1})
             StepArgs a{};
             a.u = b.nu > 0 ? b.d_U + k * b.nu : nullptr;
             a.t_prop = tk(k);
             a.step = b.n_predict;
+            a.parity = b.parity;
             ProfScope ps(b, LLPF_PROF_PROPAGATE);
             if (k + 1 < T) {
                 a.y = b.d_Y + (k + 1) * b.ny; a.t_meas = tk(k + 1); a.has_y = has_y(k + 1) ? 1 : 0;
@@ -521,12 +540,15 @@ static int bank_set_weights(Bank& b, const double* w) {
     CHK(scal_download(b, h));
     for (auto& s : h) { s.uniform = 0; s.norm_pending = 0; s.status = 0; }
     CHK(scal_upload(b, h));
+    HIPC(hipMemsetAsync(b.d_acc, 0, sizeof(uint64_t) * (size_t)b.F * ACC_WORDS, b.stream));
+    b.parity = 0;
     BankDev d = b.dev();
-    HIPC(launch_max(d, b.stream));
-    HIPC(launch_norm(d, 0, b.stream));
-    FinalizeArgs fa{};
-    fa.keep_norm = 1; fa.accumulate = 0; fa.after_predict = 0;
-    HIPC(launch_finalize(d, fa, b.stream));
+    HIPC(launch_max(d, b.parity, b.stream));
+    HIPC(launch_norm(d, b.parity, 0, b.stream));
+    ResArgs ra{};
+    ra.mode = RES_FINALIZE; ra.parity = b.parity; ra.M = (int32_t)b.N; ra.keep_norm = 1;
+    HIPC(launch_resample(d, ra, b.stream));
+    b.parity ^= 1;
     CHK(scal_download(b, h));
     return check_status(b, h);
 }
@@ -626,8 +648,10 @@ int llpf_get_bins(llpf_filter* f, double* dst) {
     Bank& b = f->bank;
     CHK(use_device(b));
     BankDev d = b.dev();
-    HIPC(launch_decide(d, b.stream));
-    HIPC(launch_resample(d, b.n_predict, nullptr, b.N, b.d_anc, b.d_tmp, 1, 1, 0, b.stream));
+    ResArgs ra{};
+    ra.mode = RES_RESAMPLE; ra.step = b.n_predict; ra.M = (int32_t)b.N; ra.anc_out = b.d_anc;
+    ra.bins_out = b.d_tmp; ra.only_bins = 1; ra.force = 1;
+    HIPC(launch_resample(d, ra, b.stream));
     HIPC(hipMemcpyAsync(dst, b.d_tmp, sizeof(double) * b.N, hipMemcpyDeviceToHost, b.stream));
     HIPC(hipStreamSynchronize(b.stream));
     return LLPF_OK;
@@ -646,10 +670,17 @@ int llpf_set_weights(llpf_filter* f, const double* w) { NEEDF(f); return bank_se
 static int scal0(llpf_filter* f, FilterScal* out, bool decide) {
     Bank& b = f->bank;
     CHK(use_device(b));
-    if (decide) HIPC(launch_decide(b.dev(), b.stream));
     std::vector<FilterScal> h;
     CHK(scal_download(b, h));
     *out = h[0];
+    if (decide && !out->status) {   // shouldresample on the stored state (reference src/resample.jl:5-10)
+        if (out->uniform) {
+            const double wev = 1.0 / (double)b.N;
+            out->ess = 1.0 / ((double)b.N * (wev * wev));
+        }
+        const double thr = b.cfg.resample_threshold;
+        out->do_resample = (thr == 1.0) ? 1 : (out->ess < (double)b.N * thr ? 1 : 0);
+    }
     return LLPF_OK;
 }
 int llpf_effective_particles(llpf_filter* f, double* ess) {
@@ -807,7 +838,9 @@ int llpf_resample(int32_t device, int32_t strategy, const double* we, int64_t n,
         s[0].uniform = 0; s[0].anc_ident = 0; s[0].status = 0; s[0].do_resample = 1;
         CHK(scal_upload(b, s));
         // ancestors are written relative to a row of stride Ns; the scratch bank has one filter, so row 0
-        HIPC(launch_resample(b.dev(), 0, d_U, m, d_j, nullptr, 0, 1, 1, b.stream));
+        ResArgs ra{};
+        ra.mode = RES_RESAMPLE; ra.M = (int32_t)m; ra.Uexp = d_U; ra.anc_out = d_j; ra.force = 1; ra.src_values = 1;
+        HIPC(launch_resample(b.dev(), ra, b.stream));
         HIPC(hipMemcpyAsync(j32.data(), d_j, sizeof(int32_t) * m, hipMemcpyDeviceToHost, b.stream));
         HIPC(hipStreamSynchronize(b.stream));
         for (int64_t i = 0; i < m; ++i) j[i] = j32[i];

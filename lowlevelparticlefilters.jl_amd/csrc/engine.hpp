@@ -8,8 +8,12 @@
 //                                normalisation (w - m) - l of reference src/utils.jl:20,24 is applied
 //                                lazily by whoever reads them, using the per-filter scalars)
 //   anc    [F][Ns]         i32   ancestor indices j (reference src/PFtypes.jl:14, Int64 there)
-//   pmax   [F][P1]         fp64  per-block maxima of w written by the weighting kernel
-//   part   [F][P2]         NormPartial   per-tile fixed-point sums written by the normalise kernel
+//   acc    [F][ACC_WORDS]  u64   cross-block accumulators, sharded 8 ways, one 128-B line per (word, shard):
+//                                running max of w (order-preserving key, double-buffered by weighting parity)
+//                                and the fixed-point sums of the exp-weights in 43-bit limbs
+//                                (integer adds commute => bit-reproducible)
+//   tileq  [F][P2]         u64   per-tile sums of the resampling quanta (tile prefix for the scan kernel)
+//   xmpart [F][P2][8]      fp64  per-tile sums e_i x_i (weighted_mean output only; never fed back)
 //   scal   [F]             FilterScal    per-filter scalars (maxw, log1p(s), 1/(s+1), ESS, flags, ...)
 // Ns = N rounded up to a multiple of TILE (padding lanes carry zero weight).
 // The exp-weights `we` and the cumulative `bins` of the reference (src/PFtypes.jl:12,15) are never
@@ -29,10 +33,22 @@ namespace llpf {
 constexpr int MAXD = LLPF_MAX_DIM;
 constexpr int BLOCK = 256;            // 4 wave64 per workgroup
 constexpr int STEP_PPT = 2;           // particles per thread per iteration in the step kernel (16-B vectors)
-constexpr int STEP_ITERS = 2;         // iterations per block  -> 1024 particles per block
+constexpr int STEP_ITERS = 1;         // iterations per block  -> 512 particles per block
 constexpr int STEP_TILE = BLOCK * STEP_PPT * STEP_ITERS;
-constexpr int NORM_IPT = 8;           // items per thread in normalise / resample kernels
-constexpr int TILE = BLOCK * NORM_IPT;   // 2048 particles per tile: normalise and resample MUST share it
+constexpr int NORM_IPT = 4;           // items per thread in normalise / resample kernels
+constexpr int TILE = BLOCK * NORM_IPT;   // 1024 particles per tile: normalise and resample MUST share it
+
+// Cross-block accumulators, per filter.  Every (word, shard) pair lives on its own 128-byte line: device-scope
+// atomics to one line serialise at ~11 ns each (measured: 8 shards sharing a line cost +11..15 us per launch),
+// so a launch of ~1000-2000 blocks puts only ~120-250 atomics on any line, spread over its whole duration.
+constexpr int NSHARD = 8;
+constexpr int ACC_STRIDE = 16;                  // u64 per (word, shard) slot = 128 B
+constexpr int ACC_PM = 0;                       // words 0,1 : max keys of the two weighting parities
+constexpr int ACC_S = 2;                        // words 2..4: sum fix96(e)   in 43-bit limbs
+constexpr int ACC_E2 = 5;                       // words 5..7: sum fix96(e^2) in 43-bit limbs
+constexpr int ACC_BAD = 8;                      // word  8   : count of NaN exp-weights
+constexpr int ACC_NWORDS = 9;
+constexpr int ACC_WORDS = ACC_NWORDS * NSHARD * ACC_STRIDE;   // u64 per filter (9 KB)
 
 // derived Gaussian (host-prepared): mirrors oracle/llpf_oracle.c:gaussd field for field
 struct GaussD {
@@ -51,15 +67,6 @@ struct ModelD {
     int32_t supersample, pad0;
     double Ts;
     GaussD df, dg, d0;
-};
-
-// per-tile partial sums of the normalise kernel (all integer => order independent)
-struct NormPartial {
-    uint64_t S_lo, S_hi;      // sum fix96(e_i)
-    uint64_t E2_lo, E2_hi;    // sum fix96(e_i^2)
-    uint64_t Q;               // sum q64(e_i, K)
-    uint64_t bad;             // number of NaN exp-weights seen
-    double xm[MAXD];          // sum e_i * x_i[d]  (fp64, fixed order; output only, never fed back)
 };
 
 struct FilterScal {
@@ -93,8 +100,8 @@ struct BankDev {
     int32_t nx, nu, ny;
     int32_t strategy;
     int32_t model_id;
-    int32_t P1;          // step-kernel blocks per filter (pmax entries)
-    int32_t P2;          // tiles per filter (NormPartial entries)
+    int32_t P1;          // step-kernel blocks per filter
+    int32_t P2;          // tiles per filter (tileq / xmpart entries)
     double thr;          // resample_threshold
     double log1N;        // log(1/N)   (reset_weights!, reference src/utils.jl:75)
     double mlogN;        // -log(N)    (reset!,         reference src/filtering.jl:11)
@@ -104,8 +111,9 @@ struct BankDev {
     double* xnext;       // [F][NX][Ns] written by propagate
     double* w;           // [F][Ns]
     int32_t* anc;        // [F][Ns]
-    double* pmax;        // [F][P1]
-    NormPartial* part;   // [F][P2]
+    uint64_t* acc;       // [F][ACC_WORDS]
+    uint64_t* tileq;     // [F][P2]
+    double* xmpart;      // [F][P2][MAXD]
 };
 
 enum StepMode { MODE_WEIGHT = 0, MODE_PROP = 1, MODE_PROP_WEIGHT = 2 };
@@ -117,28 +125,41 @@ struct StepArgs {
     double t_meas;         // time passed to measurement
     uint32_t step;         // Philox step counter of this predict!
     int32_t has_y;         // 0: measurement missing (weights pass through)
+    int32_t parity;        // which max-accumulator set this weighting writes
 };
 
-struct FinalizeArgs {
+enum { RES_FINALIZE = 1, RES_RESAMPLE = 2 };
+
+// arguments of the resample(+finalize) kernel
+struct ResArgs {
+    int32_t mode;          // RES_FINALIZE: derive the scalars of logsumexp!/ESS/shouldresample from the accumulators
+                           // RES_RESAMPLE: scan + ancestor expansion (if the decision says so, or `force`)
+    int32_t parity;        // parity of the weighting whose maxima are in acc
+    int32_t K;             // fraction bits of the resampling quanta
+    int32_t force;         // resample regardless of the decision
+    int32_t only_bins;     // write bins_out and stop
+    int32_t src_values;    // w[] holds plain values in [0,1] (standalone resample(we)), not log-weights
+    int32_t keep_norm;     // leave norm_pending = 0 (set_weights path: w stays as installed)
+    int32_t accumulate;    // ll_total += ll
+    int32_t want_xmean;
+    uint32_t step;         // Philox step of this predict!
+    int32_t M;             // number of outputs
+    const double* Uexp;    // explicit uniforms (1 or M) or nullptr -> Philox
+    int32_t* anc_out;
+    double* bins_out;
     double* ll_steps;      // [T][F] or nullptr
     double* xmean;         // [T][F][nx] or nullptr
     int64_t k;             // step index into ll_steps / xmean
-    int32_t keep_norm;     // 1: leave norm_pending = 0 (set_weights path: w stays as installed)
-    int32_t accumulate;    // 1: ll_total += ll
-    int32_t after_predict; // 1: a predict! ran since the last finalize: do its bookkeeping (state.j, resample count)
 };
 
 // launchers (kernels.hip)
 hipError_t launch_init(const BankDev& b, uint32_t step, int init_anc, hipStream_t s);
 hipError_t launch_wmean(const BankDev& b, double* out /* [F][nx] */, hipStream_t s);
 hipError_t launch_step(const BankDev& b, int mode, const StepArgs& a, hipStream_t s);
-hipError_t launch_max(const BankDev& b, hipStream_t s);                       // fills pmax from current w state
-hipError_t launch_norm(const BankDev& b, int want_xmean, hipStream_t s);
-hipError_t launch_finalize(const BankDev& b, const FinalizeArgs& a, hipStream_t s);
-hipError_t launch_decide(const BankDev& b, hipStream_t s);
+hipError_t launch_max(const BankDev& b, int parity, hipStream_t s);           // maxima of the raw w into acc
+hipError_t launch_norm(const BankDev& b, int parity, int want_xmean, hipStream_t s);
 hipError_t launch_post_predict(const BankDev& b, hipStream_t s);
-hipError_t launch_resample(const BankDev& b, uint32_t step, const double* Uexp, int64_t M,
-                           int32_t* anc_out, double* bins_out, int only_bins, int force, int src_values, hipStream_t s);
+hipError_t launch_resample(const BankDev& b, const ResArgs& a, hipStream_t s);
 hipError_t launch_materialize(const BankDev& b, double* w_out, double* we_out, hipStream_t s);
 hipError_t launch_soa2aos(const BankDev& b, const double* xsrc, double* dst, hipStream_t s);
 hipError_t launch_aos2soa(const BankDev& b, const double* src, double* xdst, hipStream_t s);

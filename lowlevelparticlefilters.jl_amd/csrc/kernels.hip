@@ -1,16 +1,19 @@
 // kernels.hip — hand-written gfx950 kernels of the particle-filter step.
 //
-// One filter step (correct! then predict!, reference src/filtering.jl:164-168, 140-153) is
-//   k_norm      : max-reduce of the block maxima, e_i = exp(w_i - m), fixed-point sums of e, e^2 and of the
-//                 resampling quanta per 2048-particle tile                     (logsumexp!, utils.jl:18-27;
+// One filter step (correct! then predict!, reference src/filtering.jl:164-168, 140-153) is three launches:
+//   k_norm      : m = max w (from the sharded max accumulators), e_i = exp(w_i - m); fixed-point sums of e and e^2
+//                 go to sharded integer accumulators, the per-tile sum of the resampling quanta to tileq
+//                                                                              (logsumexp!, utils.jl:18-27;
 //                                                                               effective_particles, resample.jl:1-2)
-//   k_finalize  : one block per filter sums the tile partials -> log1p(s), 1/(s+1), ll, ESS, resample decision
-//   k_resample  : per tile: integer inclusive scan of the quanta (tile prefix comes from k_norm's partials, so no
-//                 look-back / spinning), bins = cum/total, ancestor COUNTS c(bins) for the systematic / stratified
-//                 thresholds, then expansion of the counts into ancestor indices through LDS
-//                                                                              (resample, resample.jl:17-61)
+//   k_resample  : every block derives the scalars log1p(s), 1/(s+1), ESS and the shouldresample decision from the
+//                 accumulators (block 0 publishes them); if resampling: per 1024-particle tile an integer inclusive
+//                 scan of the quanta (tile prefix = masked sum of tileq, so no look-back / spinning),
+//                 bins = cum * (1/total), ancestor COUNTS c(bins) for the systematic / stratified thresholds,
+//                 expansion of the counts into ancestor indices by head-flag scatter + max-scan in LDS
+//                                                                              (resample, resample.jl:5-61)
 //   k_step      : gather x[anc[i]] -> dynamics -> + Philox/Box–Muller process noise -> store x (SoA, 16-B vectors)
-//                 -> w = w_prev + logpdf(y_next - g(x)) -> block max            (propagate_particles!, PFtypes.jl:122-139;
+//                 -> w = w_prev + logpdf(y_next - g(x)) -> block max -> atomicMax  (propagate_particles!,
+//                                                                               PFtypes.jl:122-139;
 //                                                                               measurement_equation!, :107-120)
 // All particle data is fp64 structure-of-arrays; wave64; 256-thread workgroups; grid = (tiles, filters).
 // Compiled with -ffp-contract=off: the arithmetic is the same IEEE sequence as oracle/llpf_oracle.c (device order).
@@ -263,11 +266,64 @@ __global__ __launch_bounds__(BLOCK) void k_init(BankDev b, const ModelD* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_step — fused propagate + weight + block max
+// cross-block accumulators (see engine.hpp): order-preserving max key, limb-wise integer sums
+// ------------------------------------------------------------------------------------------------
+DEV uint64_t max_key(double x) {           // monotone map double -> u64; NaN (positive) maps above +inf,
+    const uint64_t u = llpf_d2u(x);        // so a NaN weight wins the max like Julia's findmax; key 0 is below -inf
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ULL);
+}
+DEV double max_unkey(uint64_t k) {
+    return llpf_u2d((k >> 63) ? (k & 0x7fffffffffffffffULL) : ~k);
+}
+DEV uint64_t* acc_slot(uint64_t* acc, int word, int shard) { return acc + ((size_t)word * NSHARD + shard) * ACC_STRIDE; }
+DEV const uint64_t* acc_slot(const uint64_t* acc, int word, int shard) { return acc + ((size_t)word * NSHARD + shard) * ACC_STRIDE; }
+
+DEV void acc_max(uint64_t* acc, int parity, double blockmax, bool any_nan) {
+    const uint64_t key = any_nan ? max_key(llpf_u2d(0x7ff8000000000000ULL)) : max_key(blockmax);
+    atomicMax(reinterpret_cast<unsigned long long*>(acc_slot(acc, ACC_PM + parity, blockIdx.x & (NSHARD - 1))),
+              (unsigned long long)key);
+}
+// every wave combines the NSHARD copies of the running max itself (lanes 0..7 load, 3 shuffles, broadcast)
+DEV double acc_read_max_wave(const uint64_t* acc, int parity) {
+    const int lane = threadIdx.x & 63;
+    uint64_t k = (lane < NSHARD) ? *acc_slot(acc, ACC_PM + parity, lane) : 0;
+#pragma unroll
+    for (int o = 1; o < NSHARD; o <<= 1) {
+        const uint64_t t = (uint64_t)__shfl_xor((unsigned long long)k, o, 64);
+        k = t > k ? t : k;
+    }
+    k = (uint64_t)__shfl((unsigned long long)k, 0, 64);
+    return max_unkey(k);
+}
+// zero the sum accumulators of one filter (threads 0 .. 7*NSHARD-1 of one block)
+DEV void acc_clear_sums(uint64_t* acc) {
+    if (threadIdx.x < (ACC_NWORDS - ACC_S) * NSHARD)
+        *acc_slot(acc, ACC_S + threadIdx.x / NSHARD, threadIdx.x % NSHARD) = 0;
+}
+constexpr uint64_t M43 = ((uint64_t)1 << 43) - 1;
+DEV void acc_add_u128(uint64_t* acc, int word0, llpf_u128 v) {
+    const int sh = blockIdx.x & (NSHARD - 1);
+    const uint64_t limb[3] = {v.lo & M43, ((v.lo >> 43) | (v.hi << 21)) & M43, v.hi >> 22};
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        if (limb[k]) atomicAdd(reinterpret_cast<unsigned long long*>(acc_slot(acc, word0 + k, sh)), (unsigned long long)limb[k]);
+}
+// limb sums (each already summed over shards) -> 128-bit value
+DEV llpf_u128 acc_combine_u128(uint64_t a0, uint64_t a1, uint64_t a2) {
+    llpf_u128 r = {a0, 0}, t;
+    t.lo = a1 << 43; t.hi = a1 >> 21;
+    r = llpf_u128_add(r, t);
+    t.lo = 0; t.hi = a2 << 22;
+    r = llpf_u128_add(r, t);
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_step — fused propagate + weight + running max
 // ------------------------------------------------------------------------------------------------
 template <class Model, int NX, int NY, int MODE>
 __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restrict__ models,
-                                                 const FilterScal* __restrict__ scal, StepArgs a) {
+                                                 const FilterScal* scal, StepArgs a) {
     __shared__ double sm_max[BLOCK / 64];
     const int f = blockIdx.y;
     const ModelD* md = models + f;
@@ -282,6 +338,9 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
     double* w = b.w + (size_t)f * Ns;
     const int32_t* __restrict__ anc = b.anc + (size_t)f * Ns;
 
+    // a normalise kernel always follows a weighting: zero its sum accumulators (all their readers are done)
+    if (MODE != MODE_PROP && blockIdx.x == 0) acc_clear_sums(b.acc + (size_t)f * ACC_WORDS);
+
     Model model;
     model.prepare(md, a.u, a.t_prop);
     double y[NY];
@@ -291,6 +350,7 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
     }
 
     double bmax = -LLPF_INF;
+    bool bad = false;
 #pragma unroll 1
     for (int it = 0; it < STEP_ITERS; ++it) {
         const int64_t i0 = ((int64_t)blockIdx.x * STEP_ITERS + it) * (BLOCK * STEP_PPT) + (int64_t)threadIdx.x * STEP_PPT;
@@ -362,6 +422,7 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
                 }
                 if (i0 + p >= N) wv = -LLPF_INF;   // padding lanes carry zero weight
                 wn[p] = wv;
+                bad = bad || (wv != wv);
                 bmax = llpf_fmax(bmax, wv);
             }
             double2 wo;
@@ -372,57 +433,54 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
     }
     if (MODE != MODE_PROP) {
         const double r = block_max(bmax, sm_max);
-        if (threadIdx.x == 0) b.pmax[(size_t)f * b.P1 + blockIdx.x] = r;
+        const int anybad = __syncthreads_or(bad ? 1 : 0);
+        if (threadIdx.x == 0) acc_max(b.acc + (size_t)f * ACC_WORDS, a.parity, r, anybad != 0);
+    }
+    if (MODE != MODE_WEIGHT && blockIdx.x == 0 && threadIdx.x == 0) {
+        // bookkeeping of this predict! (fields no block of this kernel reads): state.j == 1:N unless resampled
+        FilterScal* scw = b.scal + f;
+        scw->anc_ident = do_res ? 0 : 1;
+        scw->last_resampled = do_res;
+        scw->resample_count += do_res;
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_max — block maxima of the raw log-weights (used when no weighting kernel produced them:
-// llpf_set_weights, llpf_logsumexp)
+// k_max — maxima of the raw log-weights (when no weighting kernel produced them: llpf_set_weights,
+// llpf_logsumexp); also zeroes the sum accumulators like a weighting kernel does
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_max(BankDev b) {
+__global__ __launch_bounds__(BLOCK) void k_max(BankDev b, int parity) {
     __shared__ double sm_max[BLOCK / 64];
     const int f = blockIdx.y;
     const double* w = b.w + (size_t)f * b.Ns;
+    if (blockIdx.x == 0) acc_clear_sums(b.acc + (size_t)f * ACC_WORDS);
     double bmax = -LLPF_INF;
+    bool bad = false;
 #pragma unroll
     for (int it = 0; it < STEP_ITERS; ++it) {
         const int64_t i0 = ((int64_t)blockIdx.x * STEP_ITERS + it) * (BLOCK * STEP_PPT) + (int64_t)threadIdx.x * STEP_PPT;
         const double2 wv = *reinterpret_cast<const double2*>(w + i0);
-        if (i0 < b.N) bmax = llpf_fmax(bmax, wv.x);
-        if (i0 + 1 < b.N) bmax = llpf_fmax(bmax, wv.y);
+        if (i0 < b.N) { bmax = llpf_fmax(bmax, wv.x); bad = bad || (wv.x != wv.x); }
+        if (i0 + 1 < b.N) { bmax = llpf_fmax(bmax, wv.y); bad = bad || (wv.y != wv.y); }
     }
     const double r = block_max(bmax, sm_max);
-    if (threadIdx.x == 0) b.pmax[(size_t)f * b.P1 + blockIdx.x] = r;
-}
-
-// max over the per-block maxima of one filter (every block of a consumer kernel recomputes it)
-DEV double reduce_pmax(const double* __restrict__ pm, int P1, double* sm) {
-    double v = -LLPF_INF;
-    for (int k = threadIdx.x; k < P1; k += BLOCK) v = llpf_fmax(v, pm[k]);
-    return block_max(v, sm);
+    const int anybad = __syncthreads_or(bad ? 1 : 0);
+    if (threadIdx.x == 0) acc_max(b.acc + (size_t)f * ACC_WORDS, parity, r, anybad != 0);
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_norm — exp-weights and their exact sums per tile  (logsumexp! utils.jl:18-27, sum_all_but :66-71,
+// k_norm — exp-weights and their exact sums  (logsumexp! utils.jl:18-27, sum_all_but :66-71,
 // effective_particles resample.jl:1-2; optional weighted_mean filtering.jl:541-549)
 // ------------------------------------------------------------------------------------------------
 template <int NX, bool XMEAN>
-__global__ __launch_bounds__(BLOCK) void k_norm(BankDev b, int K) {
-    __shared__ double sm_max[BLOCK / 64];
+__global__ __launch_bounds__(BLOCK) void k_norm(BankDev b, int K, int parity) {
     __shared__ uint64_t sm_u[BLOCK / 64][6];
     __shared__ double sm_x[BLOCK / 64][MAXD];
     const int f = blockIdx.y;
     const int tile = blockIdx.x;
-    const double m = reduce_pmax(b.pmax + (size_t)f * b.P1, b.P1, sm_max);
+    uint64_t* acc = b.acc + (size_t)f * ACC_WORDS;
     const double* __restrict__ w = b.w + (size_t)f * b.Ns;
     const double* __restrict__ xc = b.xcur + (size_t)f * NX * b.Ns;
-
-    llpf_u128 S = {0, 0}, E2 = {0, 0};
-    uint64_t Q = 0, bad = 0;
-    double xm[NX > 0 ? NX : 1];
-#pragma unroll
-    for (int d = 0; d < NX; ++d) xm[d] = 0.0;
 
     double2 wv[NORM_IPT / 2];
 #pragma unroll
@@ -430,6 +488,13 @@ __global__ __launch_bounds__(BLOCK) void k_norm(BankDev b, int K) {
         const int64_t i0 = (int64_t)tile * TILE + (int64_t)k * (BLOCK * 2) + threadIdx.x * 2;
         wv[k] = *reinterpret_cast<const double2*>(w + i0);
     }
+    const double m = acc_read_max_wave(acc, parity);
+
+    llpf_u128 S = {0, 0}, E2 = {0, 0};
+    uint64_t Q = 0, bad = 0;
+    double xm[NX > 0 ? NX : 1];
+#pragma unroll
+    for (int d = 0; d < NX; ++d) xm[d] = 0.0;
 #pragma unroll
     for (int k = 0; k < NORM_IPT / 2; ++k) {
         const int64_t i0 = (int64_t)tile * TILE + (int64_t)k * (BLOCK * 2) + threadIdx.x * 2;
@@ -481,218 +546,221 @@ __global__ __launch_bounds__(BLOCK) void k_norm(BankDev b, int K) {
             q += sm_u[k][4];
             bd += sm_u[k][5];
         }
-        NormPartial* o = b.part + (size_t)f * b.P2 + tile;
-        o->S_lo = s.lo; o->S_hi = s.hi; o->E2_lo = e2.lo; o->E2_hi = e2.hi; o->Q = q; o->bad = bd;
+        acc_add_u128(acc, ACC_S, s);
+        acc_add_u128(acc, ACC_E2, e2);
+        if (bd) atomicAdd(reinterpret_cast<unsigned long long*>(acc_slot(acc, ACC_BAD, blockIdx.x & (NSHARD - 1))), (unsigned long long)bd);
+        b.tileq[(size_t)f * b.P2 + tile] = q;
         if (XMEAN) {
             for (int d = 0; d < NX; ++d) {
-                double acc = sm_x[0][d];
-                for (int k = 1; k < BLOCK / 64; ++k) acc = acc + sm_x[k][d];
-                o->xm[d] = acc;
+                double a = sm_x[0][d];
+                for (int k = 1; k < BLOCK / 64; ++k) a = a + sm_x[k][d];
+                b.xmpart[((size_t)f * b.P2 + tile) * MAXD + d] = a;
             }
         }
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// k_finalize — per filter: scalars of logsumexp!, ESS, shouldresample (resample.jl:5-10)
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_finalize(BankDev b, FinalizeArgs a, int K, int nx_out, int after_predict) {
-    __shared__ double sm_max[BLOCK / 64];
-    __shared__ uint64_t sm_u[BLOCK / 64][6];
-    __shared__ double sm_x[BLOCK / 64][MAXD];
-    const int f = blockIdx.x;
-    const double m = reduce_pmax(b.pmax + (size_t)f * b.P1, b.P1, sm_max);
-    const NormPartial* __restrict__ part = b.part + (size_t)f * b.P2;
-    llpf_u128 S = {0, 0}, E2 = {0, 0};
-    uint64_t Q = 0, bad = 0;
-    double xm[MAXD];
-#pragma unroll
-    for (int d = 0; d < MAXD; ++d) xm[d] = 0.0;
-    for (int p = threadIdx.x; p < b.P2; p += BLOCK) {
-        llpf_u128 t1 = {part[p].S_lo, part[p].S_hi}, t2 = {part[p].E2_lo, part[p].E2_hi};
-        S = llpf_u128_add(S, t1);
-        E2 = llpf_u128_add(E2, t2);
-        Q += part[p].Q;
-        bad += part[p].bad;
-        if (a.xmean) {
-#pragma unroll
-            for (int d = 0; d < MAXD; ++d)
-                if (d < nx_out) xm[d] = xm[d] + part[p].xm[d];
-        }
-    }
-    S = wave_sum_u128(S);
-    E2 = wave_sum_u128(E2);
-    Q = wave_sum_u64(Q);
-    bad = wave_sum_u64(bad);
-    if (a.xmean) {
-#pragma unroll
-        for (int d = 0; d < MAXD; ++d) xm[d] = wave_sum_f64(xm[d]);
-    }
-    const int lane = threadIdx.x & 63, wvid = threadIdx.x >> 6;
-    if (lane == 0) {
-        sm_u[wvid][0] = S.lo; sm_u[wvid][1] = S.hi;
-        sm_u[wvid][2] = E2.lo; sm_u[wvid][3] = E2.hi;
-        sm_u[wvid][4] = Q; sm_u[wvid][5] = bad;
-#pragma unroll
-        for (int d = 0; d < MAXD; ++d) sm_x[wvid][d] = xm[d];
-    }
-    __syncthreads();
-    if (threadIdx.x != 0) return;
-    llpf_u128 s128 = {sm_u[0][0], sm_u[0][1]}, e128 = {sm_u[0][2], sm_u[0][3]};
-    uint64_t q = sm_u[0][4], bd = sm_u[0][5];
-    for (int k = 1; k < BLOCK / 64; ++k) {
-        llpf_u128 t1 = {sm_u[k][0], sm_u[k][1]}, t2 = {sm_u[k][2], sm_u[k][3]};
-        s128 = llpf_u128_add(s128, t1);
-        e128 = llpf_u128_add(e128, t2);
-        q += sm_u[k][4];
-        bd += sm_u[k][5];
-    }
-    FilterScal* sc = b.scal + f;
-    if (after_predict) {   // bookkeeping of the predict! that ran since the last finalize
-        const int r = sc->do_resample;
-        sc->anc_ident = r ? 0 : 1;
-        sc->last_resampled = r;
-        sc->resample_count += r;
-    }
-    double s, l, inv, ll, ess, e2;
-    int status = 0;
-    if (bd != 0 || s128.hi < ((uint64_t)1 << 32)) {   // max is -Inf / NaN, or NaN weights: degenerate
-        s = llpf_u2d(0x7ff8000000000000ULL);
-        l = s; inv = s; ll = s; ess = s; e2 = s;
-        status = LLPF_ERR_DEGENERATE;
-    } else {
-        s = llpf_fix96_to_double(llpf_fix96_minus_one(s128));   // sum_all_but: exact, one rounding
-        l = llpf_log1p_nonneg(s);
-        inv = 1.0 / (s + 1.0);
-        ll = l + m;
-        e2 = llpf_fix96_to_double(e128);
-        ess = 1.0 / (e2 * (inv * inv));
-    }
-    sc->m = m; sc->s = s; sc->l = l; sc->inv = inv; sc->ll = ll; sc->ess = ess; sc->e2 = e2;
-    sc->totQ = q;
-    sc->K = K;
-    sc->uniform = 0;
-    sc->norm_pending = a.keep_norm ? 0 : 1;
-    if (status) sc->status = status;
-    int dr = 0;
-    if (!status) dr = (b.thr == 1.0) ? 1 : (ess < (double)b.N * b.thr ? 1 : 0);
-    sc->do_resample = dr;
-    if (a.accumulate) sc->ll_total = sc->ll_total + ll;
-    if (a.ll_steps) a.ll_steps[(size_t)a.k * b.F + f] = ll;
-    if (a.xmean) {
-        for (int d = 0; d < nx_out; ++d) {
-            double acc = sm_x[0][d];
-            for (int k = 1; k < BLOCK / 64; ++k) acc = acc + sm_x[k][d];
-            a.xmean[((size_t)a.k * b.F + f) * nx_out + d] = acc * inv;
-        }
-    }
-}
-
-// shouldresample for a predict! that is not preceded by a correct! in the same launch sequence
-__global__ void k_decide(BankDev b, int K) {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= b.F) return;
-    FilterScal* sc = b.scal + f;
-    if (sc->status) { sc->do_resample = 0; return; }
-    double ess;
-    if (sc->uniform) {
-        const double wev = 1.0 / (double)b.N;
-        ess = 1.0 / ((double)b.N * (wev * wev));
-        sc->ess = ess;
-        sc->K = K;
-    } else {
-        ess = sc->ess;
-    }
-    sc->do_resample = (b.thr == 1.0) ? 1 : (ess < (double)b.N * b.thr ? 1 : 0);
-}
-
-// bookkeeping after a propagate-only predict! (reset_weights! when it resampled)
+// after a propagate-only predict!: reset_weights! if it resampled (reference src/utils.jl:73-79)
 __global__ void k_post_predict(BankDev b) {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= b.F) return;
     FilterScal* sc = b.scal + f;
-    const int r = sc->do_resample;
-    if (r) {
+    if (sc->do_resample) {
         sc->uniform = 1;
         sc->wconst = b.log1N;
-        sc->m = 0.0;                 // maxw[] = 0, reference src/utils.jl:77
+        sc->m = 0.0;                 // maxw[] = 0
         sc->norm_pending = 0;
     }
-    sc->anc_ident = r ? 0 : 1;
-    sc->last_resampled = r;
-    sc->resample_count += r;
     sc->do_resample = 0;
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_resample — scan + ancestor counts + expansion, one tile per block
+// k_resample — [finalize] + scan + ancestor counts + expansion, one tile per block
 // ------------------------------------------------------------------------------------------------
 enum { SRC_FILTER = 0, SRC_VALUES = 1 };
 
-struct ThrSys {   // systematic thresholds: s[i] = fl(r + fl(i0 * (1/M)))  (resample.jl:23-24)
-    double r, step, Md;
-    int64_t M;
-    DEV double at(int64_t i0) const { return r + (double)i0 * step; }
-    DEV int64_t estimate(double v) const {
-        double e = (v - r) * Md;
-        if (!(e > 0.0)) return 0;
-        if (e >= Md) return M;
-        return (int64_t)e + 1;
+// Thresholds are non-decreasing in i0.  count(v) = #{ i0 in [0,M) : thr(i0) < v } is evaluated with a closed
+// form whenever v is not within `delta` (in index units) of a threshold, and with the exact predicate otherwise:
+// thr(i0) differs from its real-arithmetic value (r + i0/M resp. (i0+U)/M) by < 4 ulp(1), i.e. by < M * 1e-15 in
+// index units, far below delta, so both paths give the count defined by the reference's comparison `s[i] < bins[b]`.
+struct ThrSys {   // systematic: s[i] = fl(r + fl(i0 * (1/M)))  (resample.jl:23-24, Julia StepRangeLen getindex)
+    double r, step, Md, delta;
+    int32_t M;
+    DEV double at(int32_t i0) const { return r + (double)i0 * step; }
+    DEV int32_t count(double v) const {
+        const double e = (v - r) * Md;
+        if (e <= -delta) return 0;
+        if (e >= Md + delta) return M;
+        const double fl = __builtin_floor(e);
+        const double fr = e - fl;
+        int32_t c = (int32_t)fl + 1;
+        c = c < 0 ? 0 : (c > M ? M : c);
+        if (fr > delta && fr < 1.0 - delta && e > 0.0) return c;
+        while (c < M && at(c) < v) ++c;
+        while (c > 0 && !(at(c - 1) < v)) --c;
+        return c;
     }
 };
-struct ThrStrat { // stratified thresholds: u_i = (i0 + rand()) / M * bins[N], bins[N] = 1  (resample.jl:49)
-    double Md;
-    int64_t M;
+struct ThrStrat { // stratified: u_i = (i0 + rand()) / M * bins[N]  (resample.jl:49)
+    double Md, delta, binsN;
+    int32_t M;
     uint32_t step, k0, k1;
     const double* Uexp;
-    DEV double at(int64_t i0) const {
+    DEV double at(int32_t i0) const {
         const double U = Uexp ? Uexp[i0] : llpf_uniform_idx((uint32_t)i0, step, LLPF_STREAM_STRATIFY, k0, k1);
-        return ((double)i0 + U) / Md * 1.0;
+        return ((double)i0 + U) / Md * binsN;
     }
-    DEV int64_t estimate(double v) const {
-        double e = v * Md;
-        if (!(e > 0.0)) return 0;
-        if (e >= Md) return M;
-        return (int64_t)e;
+    DEV int32_t count(double v) const {
+        const double e = v * Md;
+        if (e <= -delta) return 0;
+        if (e >= Md + delta) return M;
+        const double fl = __builtin_floor(e);
+        const double fr = e - fl;
+        int32_t c = (int32_t)fl;
+        c = c < 0 ? 0 : (c > M ? M : c);
+        if (fr > delta && fr < 1.0 - delta && e > 0.0 && c < M) return at(c) < v ? c + 1 : c;
+        while (c < M && at(c) < v) ++c;
+        while (c > 0 && !(at(c - 1) < v)) --c;
+        return c;
     }
 };
 
-// c(v) = #{ i0 in [0,M) : thr(i0) < v } for non-decreasing thr
-template <class Thr>
-DEV int64_t count_below(const Thr& th, double v) {
-    int64_t c = th.estimate(v);
-    while (c < th.M && th.at(c) < v) ++c;
-    while (c > 0 && !(th.at(c - 1) < v)) --c;
-    return c;
-}
+struct ResScal {       // block-uniform scalars of a resample launch
+    double m, invTd;
+    uint64_t tot;
+    int32_t do_res, status, uniform;
+};
 
 template <int STRATEGY, int SRC>
-__global__ __launch_bounds__(BLOCK) void k_resample(BankDev b, int K, uint32_t step, const double* __restrict__ Uexp,
-                                                     int64_t M, int32_t* anc_out, double* bins_out, int only_bins, int force) {
+__global__ __launch_bounds__(BLOCK) void k_resample(BankDev b, ResArgs a) {
     __shared__ uint64_t sm_w[BLOCK / 64][2];
     __shared__ uint32_t cl[TILE];
+    __shared__ uint32_t owner[TILE];
     __shared__ uint64_t sm_pref[2];
+    __shared__ double sm_d[4];
+    __shared__ int32_t sm_i[4];
+    __shared__ uint64_t sm_acc[ACC_NWORDS];
     const int f = blockIdx.y;
-    const FilterScal* sc = b.scal + f;
-    if (!force && !sc->do_resample) return;
-    if (sc->status) return;
     const int tile = blockIdx.x;
+    FilterScal* sc = b.scal + f;
+    uint64_t* acc = b.acc + (size_t)f * ACC_WORDS;
     const int64_t N = b.N;
     const int lane = threadIdx.x & 63, wvid = threadIdx.x >> 6;
-    const bool uniform = (SRC == SRC_FILTER) && sc->uniform;
 
-    // 1. exclusive prefix of this tile and total, from the per-tile sums of k_norm (no look-back)
+    // issue the tile's weight loads first: they do not depend on anything computed below
+    const double* __restrict__ w = b.w + (size_t)f * b.Ns;
+    const int64_t ib = (int64_t)tile * TILE + (int64_t)threadIdx.x * NORM_IPT;
+    double2 wv[NORM_IPT / 2];
+    if (a.mode & RES_RESAMPLE) {
+#pragma unroll
+        for (int k = 0; k < NORM_IPT / 2; ++k) wv[k] = *reinterpret_cast<const double2*>(w + ib + 2 * k);
+    }
+
+    // 0. scalars of logsumexp! / effective_particles / shouldresample — every block derives them (cheap, and
+    //    bit-identical because the sums are integers); block 0 publishes them for the next kernels
+    if (a.mode & RES_FINALIZE) {
+        // threads 0..71 each fetch one (word, shard) slot; 3 shuffles combine the 8 shards of a word
+        const int word = threadIdx.x / NSHARD, shard = threadIdx.x % NSHARD;
+        uint64_t v = (threadIdx.x < ACC_NWORDS * NSHARD) ? *acc_slot(acc, word, shard) : 0;
+#pragma unroll
+        for (int o = 1; o < NSHARD; o <<= 1) {
+            const uint64_t t = (uint64_t)__shfl_xor((unsigned long long)v, o, 64);
+            v = (word < ACC_S) ? (t > v ? t : v) : v + t;
+        }
+        if (threadIdx.x < ACC_NWORDS * NSHARD && shard == 0) sm_acc[word] = v;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        double m, s, l, inv, ll, ess, e2;
+        int status = 0, uniform, dr;
+        if (a.mode & RES_FINALIZE) {
+            m = max_unkey(sm_acc[ACC_PM + a.parity]);
+            const llpf_u128 s128 = acc_combine_u128(sm_acc[ACC_S], sm_acc[ACC_S + 1], sm_acc[ACC_S + 2]);
+            const llpf_u128 e128 = acc_combine_u128(sm_acc[ACC_E2], sm_acc[ACC_E2 + 1], sm_acc[ACC_E2 + 2]);
+            const uint64_t bd = sm_acc[ACC_BAD];
+            if (bd != 0 || s128.hi < ((uint64_t)1 << 32)) {   // max is -Inf / NaN, or NaN weights: degenerate
+                s = llpf_u2d(0x7ff8000000000000ULL);
+                l = s; inv = s; ll = s; ess = s; e2 = s;
+                status = LLPF_ERR_DEGENERATE;
+            } else {
+                s = llpf_fix96_to_double(llpf_fix96_minus_one(s128));   // sum_all_but: exact, one rounding
+                l = llpf_log1p_nonneg(s);
+                inv = 1.0 / (s + 1.0);
+                ll = l + m;
+                e2 = llpf_fix96_to_double(e128);
+                ess = 1.0 / (e2 * (inv * inv));
+            }
+            uniform = 0;
+            dr = status ? 0 : ((b.thr == 1.0) ? 1 : (ess < (double)N * b.thr ? 1 : 0));
+            if (tile == 0) {
+                sc->m = m; sc->s = s; sc->l = l; sc->inv = inv; sc->ll = ll; sc->ess = ess; sc->e2 = e2;
+                sc->K = a.K;
+                sc->uniform = 0;
+                sc->norm_pending = a.keep_norm ? 0 : 1;
+                if (status) sc->status = status;
+                sc->do_resample = dr;
+                if (a.accumulate) sc->ll_total = sc->ll_total + ll;
+                if (a.ll_steps) a.ll_steps[(size_t)a.k * b.F + f] = ll;
+                // the next weighting kernel writes the other max-accumulator set: clear it now
+#pragma unroll
+                for (int q = 0; q < NSHARD; ++q) *acc_slot(acc, ACC_PM + (a.parity ^ 1), q) = 0;
+            }
+            if (!status) status = sc->status;
+        } else {
+            // predict! without a preceding correct! in this launch sequence: decide from the stored state
+            m = sc->m; inv = sc->inv; status = sc->status; uniform = sc->uniform;
+            if (uniform) {
+                const double wev = 1.0 / (double)N;
+                ess = 1.0 / ((double)N * (wev * wev));
+            } else {
+                ess = sc->ess;
+            }
+            dr = status ? 0 : ((b.thr == 1.0) ? 1 : (ess < (double)N * b.thr ? 1 : 0));
+            if (tile == 0 && !a.only_bins && SRC == SRC_FILTER) { sc->do_resample = dr; if (uniform) sc->ess = ess; }
+        }
+        sm_d[0] = m;
+        sm_d[1] = inv;
+        sm_i[0] = dr; sm_i[1] = status; sm_i[2] = uniform;
+    }
+    __syncthreads();
+    const double m = sm_d[0];
+    const double inv = sm_d[1];
+    const int do_res = sm_i[0], status = sm_i[1];
+    const bool uniform = (SRC == SRC_FILTER) && sm_i[2];
+
+    // weighted_mean output (fixed-order fp64 sum of the tile partials; tile 0 only)
+    if ((a.mode & RES_FINALIZE) && a.xmean && tile == 0) {
+        const double* xp = b.xmpart + (size_t)f * b.P2 * MAXD;
+        for (int d = 0; d < b.nx; ++d) {
+            double accx = 0.0;
+            for (int p = threadIdx.x; p < b.P2; p += BLOCK) accx = accx + xp[(size_t)p * MAXD + d];
+            accx = wave_sum_f64(accx);
+            if (lane == 0) sm_w[wvid][0] = llpf_d2u(accx);
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                double t = llpf_u2d(sm_w[0][0]);
+                for (int k = 1; k < BLOCK / 64; ++k) t = t + llpf_u2d(sm_w[k][0]);
+                a.xmean[((size_t)a.k * b.F + f) * b.nx + d] = t * inv;
+            }
+            __syncthreads();
+        }
+    }
+    if (!(a.mode & RES_RESAMPLE)) return;
+    if (status) return;
+    if (!a.force && !do_res) return;
+
+    // 1. exclusive prefix of this tile and total of the quanta, from the per-tile sums (no look-back, no spinning)
     uint64_t prefix, tot;
     if (uniform) {
-        const uint64_t Qc = llpf_q64(1.0 / (double)N, K);
+        const uint64_t Qc = llpf_q64(1.0 / (double)N, a.K);
         const int64_t before = (int64_t)tile * TILE < N ? (int64_t)tile * TILE : N;
         prefix = (uint64_t)before * Qc;
         tot = (uint64_t)N * Qc;
     } else {
-        const NormPartial* __restrict__ part = b.part + (size_t)f * b.P2;
+        const uint64_t* __restrict__ tq = b.tileq + (size_t)f * b.P2;
         uint64_t pre = 0, all = 0;
         for (int p = threadIdx.x; p < b.P2; p += BLOCK) {
-            const uint64_t q = part[p].Q;
+            const uint64_t q = tq[p];
             all += q;
             if (p < tile) pre += q;
         }
@@ -713,14 +781,8 @@ __global__ __launch_bounds__(BLOCK) void k_resample(BankDev b, int K, uint32_t s
     if (tot == 0) return;
 
     // 2. quanta of this thread's NORM_IPT consecutive particles, inclusive scan
-    const double* __restrict__ w = b.w + (size_t)f * b.Ns;
-    const int64_t ib = (int64_t)tile * TILE + (int64_t)threadIdx.x * NORM_IPT;
-    const double m = sc->m;
     uint64_t cq[NORM_IPT];
     {
-        double2 wv[NORM_IPT / 2];
-#pragma unroll
-        for (int k = 0; k < NORM_IPT / 2; ++k) wv[k] = *reinterpret_cast<const double2*>(w + ib + 2 * k);
         uint64_t run = 0;
 #pragma unroll
         for (int k = 0; k < NORM_IPT; ++k) {
@@ -729,13 +791,13 @@ __global__ __launch_bounds__(BLOCK) void k_resample(BankDev b, int K, uint32_t s
             if (SRC == SRC_VALUES) v = wk;
             else if (uniform) v = 1.0 / (double)N;
             else v = llpf_exp(wk - m);
-            uint64_t q = llpf_q64(v, K);
+            uint64_t q = llpf_q64(v, a.K);
             if (ib + k >= N) q = 0;
             run += q;
             cq[k] = run;
         }
     }
-    uint64_t tsum = cq[NORM_IPT - 1];
+    const uint64_t tsum = cq[NORM_IPT - 1];
     uint64_t incl = tsum;                              // wave inclusive scan of thread totals
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -750,55 +812,108 @@ __global__ __launch_bounds__(BLOCK) void k_resample(BankDev b, int K, uint32_t s
         if (k < wvid) wave_off += sm_w[k][0];
     const uint64_t excl = prefix + wave_off + (incl - tsum);
 
-    // 3. bins and ancestor counts
+    // 3. bins = fl(fl(cum) * fl(1/fl(total))) and ancestor counts
     const double Td = (double)tot;
-    const FilterScal* scf = sc;
+    const double invTd = 1.0 / Td;
+    const double binsN = Td * invTd;                   // bins[N]: 1 or 1 - 2^-53
+    const int32_t M = a.M;
     uint32_t cnt[NORM_IPT];
-    int64_t c_start;
+    int32_t c_start;
     if (STRATEGY == LLPF_RESAMPLE_SYSTEMATIC) {
         ThrSys th;
-        const double U = Uexp ? Uexp[0] : llpf_uniform_step(step, LLPF_STREAM_RESAMPLE, scf->k0, scf->k1);
+        const double U = a.Uexp ? a.Uexp[0] : llpf_uniform_step(a.step, LLPF_STREAM_RESAMPLE, sc->k0, sc->k1);
         th.M = M; th.Md = (double)M; th.step = 1.0 / (double)M;
-        th.r = U * 1.0 / (double)N;                    // r = rand()*bins[end]/N with bins[end] == 1
+        th.delta = 1e-9 + th.Md * 1e-13;
+        th.r = U * binsN / (double)N;                  // r = rand()*bins[end]/N  (resample.jl:23)
 #pragma unroll
         for (int k = 0; k < NORM_IPT; ++k) {
-            const double bin = (double)(excl + cq[k]) / Td;
-            if (bins_out && ib + k < N) bins_out[(size_t)f * N + ib + k] = bin;
-            cnt[k] = only_bins ? 0u : (uint32_t)count_below(th, bin);
+            const double bin = (double)(excl + cq[k]) * invTd;
+            if (a.bins_out && ib + k < N) a.bins_out[(size_t)f * N + ib + k] = bin;
+            cnt[k] = a.only_bins ? 0u : (uint32_t)th.count(bin);
         }
-        c_start = only_bins ? 0 : count_below(th, (double)prefix / Td);
+        c_start = a.only_bins ? 0 : th.count((double)prefix * invTd);
     } else {
         ThrStrat th;
-        th.M = M; th.Md = (double)M; th.step = step; th.k0 = scf->k0; th.k1 = scf->k1; th.Uexp = Uexp;
+        th.M = M; th.Md = (double)M; th.step = a.step; th.k0 = sc->k0; th.k1 = sc->k1; th.Uexp = a.Uexp;
+        th.delta = 1e-9 + th.Md * 1e-13;
+        th.binsN = binsN;
 #pragma unroll
         for (int k = 0; k < NORM_IPT; ++k) {
-            const double bin = (double)(excl + cq[k]) / Td;
-            if (bins_out && ib + k < N) bins_out[(size_t)f * N + ib + k] = bin;
-            cnt[k] = only_bins ? 0u : (uint32_t)count_below(th, bin);
+            const double bin = (double)(excl + cq[k]) * invTd;
+            if (a.bins_out && ib + k < N) a.bins_out[(size_t)f * N + ib + k] = bin;
+            cnt[k] = a.only_bins ? 0u : (uint32_t)th.count(bin);
         }
-        c_start = only_bins ? 0 : count_below(th, (double)prefix / Td);
+        c_start = a.only_bins ? 0 : th.count((double)prefix * invTd);
     }
-    if (only_bins) return;
+    if (a.only_bins) return;
 #pragma unroll
     for (int k = 0; k < NORM_IPT; ++k) cl[threadIdx.x * NORM_IPT + k] = cnt[k];
     __syncthreads();
 
-    // 4. expansion: output o is produced by the first source k of this tile with cl[k] > o
-    const int64_t c_end = cl[TILE - 1];
-    int32_t* ao = anc_out + (size_t)f * b.Ns;
-    for (int64_t o = c_start + threadIdx.x; o < c_end; o += BLOCK) {
-        int lo = 0, hi = TILE - 1;
-        const uint32_t ov = (uint32_t)o;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (cl[mid] > ov) hi = mid; else lo = mid + 1;
+    // 4. expansion.  Source k of this tile produces outputs [cl[k-1], cl[k]) (cl[-1] = c_start).  Per chunk of TILE
+    //    outputs: every source that starts in the chunk drops its index at its first output, an inclusive
+    //    max-scan spreads it over its run, and the chunk is stored with coalesced 4-byte stores.
+    const int32_t c_end = (int32_t)cl[TILE - 1];
+    int32_t* ao = a.anc_out + (size_t)f * b.Ns;
+    for (int32_t cb = c_start; cb < c_end; cb += TILE) {
+#pragma unroll
+        for (int k = 0; k < NORM_IPT; ++k) owner[k * BLOCK + threadIdx.x] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NORM_IPT; ++k) {
+            const int kk = threadIdx.x * NORM_IPT + k;
+            const int32_t hi = (int32_t)cnt[k];
+            const int32_t lo = (k == 0) ? (kk == 0 ? c_start : (int32_t)cl[kk - 1]) : (int32_t)cnt[k - 1];
+            if (hi > lo && lo >= cb && lo < cb + TILE) owner[lo - cb] = (uint32_t)kk + 1;
         }
-        ao[o] = (int32_t)((int64_t)tile * TILE + lo);
+        if (cb != c_start && threadIdx.x == 0) {       // run that started in an earlier chunk: first source with cl > cb
+            int lo = 0, hi = TILE - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if ((int32_t)cl[mid] > cb) hi = mid; else lo = mid + 1;
+            }
+            if (owner[0] == 0) owner[0] = (uint32_t)lo + 1;
+        }
+        __syncthreads();
+        uint32_t ow[NORM_IPT];
+        uint32_t run = 0;
+#pragma unroll
+        for (int k = 0; k < NORM_IPT; ++k) {
+            const uint32_t v = owner[threadIdx.x * NORM_IPT + k];
+            run = v > run ? v : run;
+            ow[k] = run;
+        }
+        uint32_t inc = run;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)inc, o, 64);
+            if (lane >= o) inc = t > inc ? t : inc;
+        }
+        uint32_t excl_run = (uint32_t)__shfl_up((int)inc, 1, 64);
+        if (lane == 0) excl_run = 0;
+        if (lane == 63) sm_w[wvid][1] = inc;
+        __syncthreads();
+        uint32_t woff = 0;
+#pragma unroll
+        for (int k = 0; k < BLOCK / 64; ++k)
+            if (k < wvid) { const uint32_t t = (uint32_t)sm_w[k][1]; woff = t > woff ? t : woff; }
+        const uint32_t base = woff > excl_run ? woff : excl_run;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NORM_IPT; ++k) owner[threadIdx.x * NORM_IPT + k] = ow[k] > base ? ow[k] : base;
+        __syncthreads();
+        const int32_t nout = (c_end - cb) < TILE ? (c_end - cb) : TILE;
+#pragma unroll
+        for (int k = 0; k < NORM_IPT; ++k) {
+            const int32_t o = k * BLOCK + threadIdx.x;
+            if (o < nout) ao[cb + o] = (int32_t)((int64_t)tile * TILE + (owner[o] - 1));
+        }
+        __syncthreads();
     }
     // outputs whose threshold is >= bins[N] are never written by the reference (j keeps its previous
     // value); the previous value is only materialised here if it was the identity 1:N
-    if (tile == b.P2 - 1 && sc->anc_ident) {
-        for (int64_t o = c_end + threadIdx.x; o < M; o += BLOCK) ao[o] = (int32_t)o;
+    if (tile == b.P2 - 1 && sc->anc_ident && SRC == SRC_FILTER) {
+        for (int32_t o = c_end + threadIdx.x; o < M; o += BLOCK) ao[o] = o;
     }
 }
 
@@ -819,8 +934,7 @@ __global__ __launch_bounds__(BLOCK) void k_qpart(BankDev b, int K) {
     if (threadIdx.x == 0) {
         uint64_t q = 0;
         for (int k = 0; k < BLOCK / 64; ++k) q += sm_w[k];
-        NormPartial* o = b.part + (size_t)f * b.P2 + tile;
-        o->S_lo = 0; o->S_hi = 0; o->E2_lo = 0; o->E2_hi = 0; o->Q = q; o->bad = 0;
+        b.tileq[(size_t)f * b.P2 + tile] = q;
     }
 }
 
@@ -991,55 +1105,42 @@ hipError_t launch_step(const BankDev& b, int mode, const StepArgs& a, hipStream_
     }
 }
 
-hipError_t launch_max(const BankDev& b, hipStream_t s) {
-    hipLaunchKernelGGL(k_max, dim3((unsigned)b.P1, (unsigned)b.F, 1), dim3(BLOCK), 0, s, b);
+hipError_t launch_max(const BankDev& b, int parity, hipStream_t s) {
+    hipLaunchKernelGGL(k_max, dim3((unsigned)b.P1, (unsigned)b.F, 1), dim3(BLOCK), 0, s, b, parity);
     return hipGetLastError();
 }
 
-static int bank_K(const BankDev& b) { return llpf_qbits(b.N); }
-
-hipError_t launch_norm(const BankDev& b, int want_xmean, hipStream_t s) {
+hipError_t launch_norm(const BankDev& b, int parity, int want_xmean, hipStream_t s) {
     dim3 g((unsigned)b.P2, (unsigned)b.F, 1);
-    const int K = bank_K(b);
-    if (!want_xmean) { hipLaunchKernelGGL((k_norm<0, false>), g, dim3(BLOCK), 0, s, b, K); return hipGetLastError(); }
+    const int K = llpf_qbits(b.N);
+    if (!want_xmean) { hipLaunchKernelGGL((k_norm<0, false>), g, dim3(BLOCK), 0, s, b, K, parity); return hipGetLastError(); }
     switch (b.nx) {
-        case 1: hipLaunchKernelGGL((k_norm<1, true>), g, dim3(BLOCK), 0, s, b, K); break;
-        case 2: hipLaunchKernelGGL((k_norm<2, true>), g, dim3(BLOCK), 0, s, b, K); break;
-        case 3: hipLaunchKernelGGL((k_norm<3, true>), g, dim3(BLOCK), 0, s, b, K); break;
-        case 4: hipLaunchKernelGGL((k_norm<4, true>), g, dim3(BLOCK), 0, s, b, K); break;
+        case 1: hipLaunchKernelGGL((k_norm<1, true>), g, dim3(BLOCK), 0, s, b, K, parity); break;
+        case 2: hipLaunchKernelGGL((k_norm<2, true>), g, dim3(BLOCK), 0, s, b, K, parity); break;
+        case 3: hipLaunchKernelGGL((k_norm<3, true>), g, dim3(BLOCK), 0, s, b, K, parity); break;
+        case 4: hipLaunchKernelGGL((k_norm<4, true>), g, dim3(BLOCK), 0, s, b, K, parity); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
 
-hipError_t launch_finalize(const BankDev& b, const FinalizeArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_finalize, dim3((unsigned)b.F), dim3(BLOCK), 0, s, b, a, bank_K(b), b.nx, a.after_predict);
-    return hipGetLastError();
-}
-
-hipError_t launch_decide(const BankDev& b, hipStream_t s) {
-    hipLaunchKernelGGL(k_decide, dim3((unsigned)((b.F + 63) / 64)), dim3(64), 0, s, b, bank_K(b));
-    return hipGetLastError();
-}
 hipError_t launch_post_predict(const BankDev& b, hipStream_t s) {
     hipLaunchKernelGGL(k_post_predict, dim3((unsigned)((b.F + 63) / 64)), dim3(64), 0, s, b);
     return hipGetLastError();
 }
 
-hipError_t launch_resample(const BankDev& b, uint32_t step, const double* Uexp, int64_t M,
-                           int32_t* anc_out, double* bins_out, int only_bins, int force, int src_values, hipStream_t s) {
-    dim3 g((unsigned)b.P2, (unsigned)b.F, 1);
-    const int K = bank_K(b);
-    const int strategy = b.strategy;
-    const int src = src_values ? SRC_VALUES : SRC_FILTER;
-    const int frc = force;
-    if (src == SRC_VALUES) hipLaunchKernelGGL(k_qpart, g, dim3(BLOCK), 0, s, b, K);
-    if (strategy == LLPF_RESAMPLE_SYSTEMATIC) {
-        if (src == SRC_FILTER) hipLaunchKernelGGL((k_resample<LLPF_RESAMPLE_SYSTEMATIC, SRC_FILTER>), g, dim3(BLOCK), 0, s, b, K, step, Uexp, M, anc_out, bins_out, only_bins, frc);
-        else hipLaunchKernelGGL((k_resample<LLPF_RESAMPLE_SYSTEMATIC, SRC_VALUES>), g, dim3(BLOCK), 0, s, b, K, step, Uexp, M, anc_out, bins_out, only_bins, frc);
+hipError_t launch_resample(const BankDev& b, const ResArgs& a0, hipStream_t s) {
+    ResArgs a = a0;
+    a.K = llpf_qbits(b.N);
+    // a finalize-only launch needs just one block per filter
+    dim3 g((a.mode & RES_RESAMPLE) ? (unsigned)b.P2 : 1u, (unsigned)b.F, 1);
+    if (a.src_values) hipLaunchKernelGGL(k_qpart, dim3((unsigned)b.P2, (unsigned)b.F, 1), dim3(BLOCK), 0, s, b, a.K);
+    if (b.strategy == LLPF_RESAMPLE_SYSTEMATIC) {
+        if (!a.src_values) hipLaunchKernelGGL((k_resample<LLPF_RESAMPLE_SYSTEMATIC, SRC_FILTER>), g, dim3(BLOCK), 0, s, b, a);
+        else hipLaunchKernelGGL((k_resample<LLPF_RESAMPLE_SYSTEMATIC, SRC_VALUES>), g, dim3(BLOCK), 0, s, b, a);
     } else {
-        if (src == SRC_FILTER) hipLaunchKernelGGL((k_resample<LLPF_RESAMPLE_STRATIFIED, SRC_FILTER>), g, dim3(BLOCK), 0, s, b, K, step, Uexp, M, anc_out, bins_out, only_bins, frc);
-        else hipLaunchKernelGGL((k_resample<LLPF_RESAMPLE_STRATIFIED, SRC_VALUES>), g, dim3(BLOCK), 0, s, b, K, step, Uexp, M, anc_out, bins_out, only_bins, frc);
+        if (!a.src_values) hipLaunchKernelGGL((k_resample<LLPF_RESAMPLE_STRATIFIED, SRC_FILTER>), g, dim3(BLOCK), 0, s, b, a);
+        else hipLaunchKernelGGL((k_resample<LLPF_RESAMPLE_STRATIFIED, SRC_VALUES>), g, dim3(BLOCK), 0, s, b, a);
     }
     return hipGetLastError();
 }

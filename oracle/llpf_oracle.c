@@ -383,21 +383,21 @@ int orc_resample(int strategy, const double* we, int64_t n, int64_t m, const dou
             }
         }
     } else {
-        /* device order: bins[b] = fl( fl(sum_{k<=b} Q_k) / fl(sum_k Q_k) ), Q_k = floor(we_k 2^K): an
-         * integer (associative) cumulative sum, so bins[N-1] == 1.0 exactly and any parallel blocking
-         * gives the same bits.  The search is restated through the count function
-         * c(v) = #{ i : thr_i < v } (thr is non-decreasing in i), which is what the expansion kernel
-         * evaluates; j[i] = first b with thr_i < bins[b] exactly as in the reference. */
+        /* device order: bins[b] = fl( fl(sum_{k<=b} Q_k) * fl(1 / fl(sum_k Q_k)) ), Q_k = floor(we_k 2^K): an
+         * integer (associative) cumulative sum, so any parallel blocking gives the same bits, and
+         * bins[N-1] = fl(T * fl(1/T)) is 1 or 1 - 2^-53.  j[i] = first b with thr_i < bins[b], exactly the
+         * reference's search (the GPU evaluates it through counts c(v) = #{ i : thr_i < v }). */
         int K = llpf_qbits(n);
         uint64_t cum = 0, tot = 0;
         for (int64_t i = 0; i < n; ++i) tot += llpf_q64(we[i], K);
         if (tot == 0) { if (!bins) free(b); return -1; }
         double Td = (double)tot;
+        double invTd = 1.0 / Td;
         for (int64_t i = 0; i < n; ++i) {
             cum += llpf_q64(we[i], K);
-            b[i] = (double)cum / Td;
+            b[i] = (double)cum * invTd;
         }
-        double binsN = 1.0;
+        double binsN = Td * invTd;
         if (strategy == LLPF_RESAMPLE_SYSTEMATIC) c.r = U[0] * binsN / (double)n;
         int64_t bo = 0;
         for (int64_t i = 0; i < m; ++i) {
@@ -573,16 +573,18 @@ static void filter_resample_dev(orc_filter* f, const double* U) {
     int64_t n = f->N;
     uint64_t cum = 0;
     double Td = (double)f->dn.totQ;
+    double invTd = 1.0 / Td;
     for (int64_t i = 0; i < n; ++i) {
         cum += llpf_q64(f->e[i], f->dn.K);
-        f->bins[i] = (double)cum / Td;
+        f->bins[i] = (double)cum * invTd;
     }
+    double binsN = Td * invTd;
     thr_ctx c;
     c.strategy = f->cfg.resampling_strategy; c.m = n; c.U = U; c.step = 1.0 / (double)n;
-    c.r = (c.strategy == LLPF_RESAMPLE_SYSTEMATIC) ? U[0] * 1.0 / (double)n : 0.0;
+    c.r = (c.strategy == LLPF_RESAMPLE_SYSTEMATIC) ? U[0] * binsN / (double)n : 0.0;
     int64_t bo = 0;
     for (int64_t i = 0; i < n; ++i) {
-        double si = thr_at(&c, i, 1.0);
+        double si = thr_at(&c, i, binsN);
         for (int64_t k = bo; k < n; ++k) {
             if (si < f->bins[k]) { f->j[i] = k; bo = k; break; }
         }
