@@ -1,0 +1,176 @@
+# LLPFAmd.jl — thin `ccall` layer over libllpf_hip.so (include/llpf.h) exposing the hot-path verbs of
+# LowLevelParticleFilters.jl.  Julia is not available in the build image, so this file is NOT exercised by
+# the test-suite; every call below is mirrored one-to-one by lowlevelparticlefilters.jl_amd/_capi.py, which is.
+#
+# Usage (inside a session that has LowLevelParticleFilters loaded):
+#     include("LLPFAmd.jl"); using .LLPFAmd
+#     pf = GPUParticleFilter(1_000_000, LinearGaussianModel(A, B, C), df, dg, d0; resample_threshold = 0.1)
+#     ll = loglik(pf, u, y);  sol = forward_trajectory(pf, u, y)
+module LLPFAmd
+
+using LinearAlgebra
+export GPUParticleFilter, LinearGaussianModel, QuadTankModel, GaussianSpec,
+       reset!, predict!, correct!, update!, loglik, forward_trajectory, particles, weights, expweights,
+       num_particles, index, effective_particles, shouldresample, weighted_mean
+
+const LIB = get(ENV, "LLPF_HIP_LIB", joinpath(@__DIR__, "..", "libllpf_hip.so"))
+const MAXD = 8
+
+# ---- plain-data mirrors of include/llpf.h (field order and padding identical) ------------------------------
+struct CGaussian
+    dim::Int32
+    kind::Int32                       # 0 ScalMat, 1 PDiagMat, 2 PDMat
+    mu::NTuple{8,Float64}
+    cov::NTuple{64,Float64}
+end
+struct CModel
+    model_id::Int32; nx::Int32; nu::Int32; ny::Int32
+    A::NTuple{64,Float64}; B::NTuple{64,Float64}; C::NTuple{64,Float64}
+    qt::NTuple{16,Float64}
+    supersample::Int32; reserved::Int32
+    Ts::Float64
+    df::CGaussian; dg::CGaussian; d0::CGaussian
+end
+struct CConfig
+    struct_size::UInt32; filter_kind::Int32
+    n_particles::Int64
+    resampling_strategy::Int32; device::Int32
+    resample_threshold::Float64
+    seed::UInt64
+    model::CModel
+end
+struct CRunOutputs
+    ll_steps::Ptr{Float64}; xmean::Ptr{Float64}; x_hist::Ptr{Float64}; w_hist::Ptr{Float64}; we_hist::Ptr{Float64}
+end
+
+pad(v, n) = ntuple(i -> i <= length(v) ? Float64(v[i]) : 0.0, n)
+rowmajor(M) = vec(permutedims(Matrix{Float64}(M)))          # Julia is column-major, the ABI is row-major
+
+"Gaussian density N(mu, Sigma); Sigma::Real => ScalMat, ::AbstractVector => PDiagMat, ::AbstractMatrix => PDMat"
+struct GaussianSpec
+    mu::Vector{Float64}
+    cov
+end
+function cgauss(g::GaussianSpec)
+    n = length(g.mu)
+    if g.cov isa Real
+        CGaussian(n, 0, pad(g.mu, 8), pad([g.cov], 64))
+    elseif g.cov isa AbstractVector
+        CGaussian(n, 1, pad(g.mu, 8), pad(g.cov, 64))
+    else
+        CGaussian(n, 2, pad(g.mu, 8), pad(rowmajor(g.cov), 64))
+    end
+end
+
+struct LinearGaussianModel; A; B; C; end                     # dynamics A*x .+ B*u, measurement C*x
+struct QuadTankModel; consts::NTuple{16,Float64}; supersample::Int; end
+QuadTankModel(; supersample = 2) = QuadTankModel(
+    (1.6, 1.6, 9.81, 4.9, 4.9, 4.9, 4.9, 0.03, 0.03, 0.03, 0.03, 0.2, 0.2, 500.0, 2.0, 1e-3), supersample)
+
+function cmodel(m::LinearGaussianModel, df, dg, d0, Ts)
+    nx = size(m.A, 1); nu = size(m.B, 2); ny = size(m.C, 1)
+    CModel(0, nx, nu, ny, pad(rowmajor(m.A), 64), pad(rowmajor(m.B), 64), pad(rowmajor(m.C), 64),
+           ntuple(_ -> 0.0, 16), 1, 0, Ts, cgauss(df), cgauss(dg), cgauss(d0))
+end
+cmodel(m::QuadTankModel, df, dg, d0, Ts) =
+    CModel(1, 4, 2, 2, ntuple(_ -> 0.0, 64), ntuple(_ -> 0.0, 64), ntuple(_ -> 0.0, 64), m.consts,
+           m.supersample, 0, Ts, cgauss(df), cgauss(dg), cgauss(d0))
+
+check(rc) = rc == 0 || error("llpf status $rc: " * unsafe_string(ccall((:llpf_last_error, LIB), Cstring, ())))
+
+# ---- the filter ------------------------------------------------------------------------------------------
+mutable struct GPUParticleFilter
+    h::Ptr{Cvoid}
+    N::Int; nx::Int; nu::Int; ny::Int; Ts::Float64
+    resample_threshold::Float64
+end
+
+"ParticleFilter(N, dynamics, measurement, df, dg, d0; ...) — reference src/PFtypes.jl:65-75"
+function GPUParticleFilter(N::Integer, model, df::GaussianSpec, dg::GaussianSpec, d0::GaussianSpec;
+                           resample_threshold = 0.1, stratified = false, seed = 0, Ts = 1.0, device = 0, advanced = false)
+    cm = cmodel(model, df, dg, d0, Float64(Ts))
+    cfg = Ref(CConfig(UInt32(sizeof(CConfig)), advanced ? 1 : 0, N, stratified ? 1 : 0, device,
+                      resample_threshold, UInt64(seed), cm))
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:llpf_create, LIB), Cint, (Ref{CConfig}, Ref{Ptr{Cvoid}}), cfg, h))
+    pf = GPUParticleFilter(h[], N, cm.nx, cm.nu, cm.ny, Ts, resample_threshold)
+    finalizer(p -> ccall((:llpf_destroy, LIB), Cint, (Ptr{Cvoid},), p.h), pf)
+    pf
+end
+
+num_particles(pf::GPUParticleFilter) = pf.N
+function index(pf::GPUParticleFilter)                          # index(pf) = state.t[], src/PFtypes.jl:314
+    t = Ref{Int64}(0); check(ccall((:llpf_index, LIB), Cint, (Ptr{Cvoid}, Ref{Int64}), pf.h, t)); Int(t[])
+end
+
+"reset!(pf) — src/filtering.jl:4-14"
+reset!(pf::GPUParticleFilter) = (check(ccall((:llpf_reset, LIB), Cint, (Ptr{Cvoid},), pf.h)); nothing)
+
+"correct!(pf,u,y,p,t) -> (ll, 0) — src/filtering.jl:164-168; y === missing skips the weighting"
+function correct!(pf::GPUParticleFilter, u, y, p = nothing, t = index(pf) * pf.Ts)
+    ll = Ref{Float64}(0)
+    uy = Vector{Float64}(u)
+    yp = (y === missing || any(ismissing, y)) ? Ptr{Float64}(C_NULL) : pointer(Vector{Float64}(y))
+    yv = yp == C_NULL ? Float64[] : Vector{Float64}(y)
+    GC.@preserve uy yv check(ccall((:llpf_correct, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Float64, Ref{Float64}),
+                                   pf.h, uy, isempty(yv) ? C_NULL : pointer(yv), Float64(t), ll))
+    ll[], 0
+end
+
+"predict!(pf,u,p,t) — src/filtering.jl:140-153"
+function predict!(pf::GPUParticleFilter, u, p = nothing, t = index(pf) * pf.Ts)
+    check(ccall((:llpf_predict, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Float64), pf.h, Vector{Float64}(u), Float64(t)))
+end
+
+"update!(pf,u,y,p,t) -> (ll, 0) — src/filtering.jl:181-185; also pf(u, y)"
+function update!(pf::GPUParticleFilter, u, y, p = nothing, t = index(pf) * pf.Ts)
+    ll = Ref{Float64}(0)
+    check(ccall((:llpf_update, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Float64, Ref{Float64}),
+                pf.h, Vector{Float64}(u), Vector{Float64}(y), Float64(t), ll))
+    ll[], 0
+end
+(pf::GPUParticleFilter)(u, y, p = nothing, t = index(pf) * pf.Ts) = update!(pf, u, y, p, t)
+
+rows(v) = Matrix{Float64}(reduce(hcat, v))                    # Vector of vectors -> (dim x T): column-major == ABI row-major
+
+function run!(pf::GPUParticleFilter, u, y, tindex0; history = false)
+    T = length(y)
+    U = rows(u); Y = rows(y)
+    ll = Ref{Float64}(0)
+    x = history ? Array{Float64}(undef, pf.nx, pf.N, T) : Float64[]
+    w = history ? Array{Float64}(undef, pf.N, T) : Float64[]
+    we = history ? Array{Float64}(undef, pf.N, T) : Float64[]
+    outs = Ref(CRunOutputs(C_NULL, C_NULL, history ? pointer(x) : C_NULL, history ? pointer(w) : C_NULL, history ? pointer(we) : C_NULL))
+    GC.@preserve U Y x w we check(ccall((:llpf_run, LIB), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64, Float64, Ref{Float64}, Ref{CRunOutputs}),
+        pf.h, U, Y, T, Float64(tindex0), ll, outs))
+    ll[], x, w, we
+end
+
+"loglik(pf,u,y,p) — src/smoothing.jl:227-230 (reset!, then t = index(pf)*Ts starting at 1)"
+loglik(pf::GPUParticleFilter, u, y, p = nothing) = (reset!(pf); run!(pf, u, y, 1.0)[1])
+
+"forward_trajectory(pf,u,y,p) — src/filtering.jl:343-365; returns (x[nx,N,T], w[N,T], we[N,T], ll)"
+function forward_trajectory(pf::GPUParticleFilter, u, y, p = nothing)
+    reset!(pf)
+    ll, x, w, we = run!(pf, u, y, 0.0; history = true)
+    # reinterpret(reshape, SVector{nx,Float64}, x) gives the reference's N x T Matrix{SVector}
+    (; x, w, we, ll, t = range(0, step = pf.Ts, length = length(y)))
+end
+
+function getvec(sym, pf, n)
+    out = Vector{Float64}(undef, n)
+    check(ccall((sym, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), pf.h, out)); out
+end
+particles(pf::GPUParticleFilter) = reshape(getvec(:llpf_get_particles, pf, pf.N * pf.nx), pf.nx, pf.N)
+weights(pf::GPUParticleFilter) = getvec(:llpf_get_weights, pf, pf.N)
+expweights(pf::GPUParticleFilter) = getvec(:llpf_get_expweights, pf, pf.N)
+weighted_mean(pf::GPUParticleFilter) = getvec(:llpf_weighted_mean, pf, pf.nx)
+function effective_particles(pf::GPUParticleFilter)
+    e = Ref{Float64}(0); check(ccall((:llpf_effective_particles, LIB), Cint, (Ptr{Cvoid}, Ref{Float64}), pf.h, e)); e[]
+end
+function shouldresample(pf::GPUParticleFilter)
+    r = Ref{Int32}(0); check(ccall((:llpf_shouldresample, LIB), Cint, (Ptr{Cvoid}, Ref{Int32}), pf.h, r)); r[] != 0
+end
+
+end # module

@@ -1,0 +1,87 @@
+"""The reference's statistical bounds for this path, restated on the oracle (test/runtests.jl:108-143,
+409-450, 553-599), at sizes the CPU suite can afford."""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from llpf_amd import _structs as S
+import models as M
+
+
+@pytest.mark.parametrize("order", [ob.ORDER_REFERENCE, ob.ORDER_DEVICE])
+@pytest.mark.parametrize("strategy", [S.RESAMPLE_SYSTEMATIC, S.RESAMPLE_STRATIFIED])
+def test_resample_proportions(order, strategy):
+    """test/runtests.jl:108-143: empirical index proportions over 10000 draws within 0.02 of we."""
+    we = np.array([0.1, 0.5, 0.1, 0.15, 0.15])
+    counts = np.zeros(5)
+    for d in range(10000):
+        U = ob.resample_uniforms(strategy, 5, 99, d)          # the Philox uniforms the filter path would use
+        j, _ = ob.resample(strategy, we, U, order=order)
+        counts += np.bincount(j, minlength=5)
+    assert np.allclose(counts / counts.sum(), we, atol=0.02)
+
+
+def test_pf_loglik_tracks_kalman_over_noise_sweep():
+    """test/runtests.jl:409-450: 11 noise levels, argmax of the PF log-likelihood in 5..7 (1-based) like the
+    Kalman filter's, and max |ll_KF - ll_PF| < 20  (the reference uses N=1000, T=2000; T=500 here)."""
+    svec = 10.0 ** np.linspace(-2, 0, 11)
+    true = M.lg_test_model(0.1)
+    _, U, Y = M.simulate_lg(true, 500, seed=0)
+    ll_pf, ll_kf = [], []
+    for s in svec:
+        m = M.lg_test_model(s)
+        cfg = S.make_config(m, 1000, resample_threshold=0.1, seed=11)
+        o = ob.OracleFilter(cfg, ob.ORDER_REFERENCE)
+        o.reset()
+        ll_pf.append(o.run(U, Y, 1.0)["ll"])
+        ll_kf.append(ob.kalman_loglik(m, U, Y))
+    ll_pf, ll_kf = np.array(ll_pf), np.array(ll_kf)
+    assert 4 <= int(np.argmax(ll_kf)) <= 6
+    assert 4 <= int(np.argmax(ll_pf)) <= 6
+    assert np.max(np.abs(ll_kf - ll_pf)) < 20
+
+
+def test_pf_loglik_converges_to_kalman():
+    """Monte-Carlo error of sum(ll) shrinks ~ 1/sqrt(N): calibrated from 8 seeds (SURVEY.md §4 take-away)."""
+    model = M.lg_c1_model()
+    _, U, Y = M.simulate_lg(model, 100)
+    kf = ob.kalman_loglik(model, U, Y)
+    errs = {}
+    for N in (500, 8000):
+        e = []
+        for seed in range(8):
+            cfg = S.make_config(model, N, resample_threshold=0.1, seed=seed)
+            o = ob.OracleFilter(cfg, ob.ORDER_DEVICE)
+            o.reset()
+            e.append(o.run(U, Y, 0.0)["ll"] - kf)
+        errs[N] = np.array(e)
+    assert np.std(errs[8000]) < 0.6 * np.std(errs[500])
+    assert abs(np.mean(errs[8000])) < 3 * np.std(errs[8000]) / np.sqrt(8) + 0.1
+
+
+def test_advanced_filter_mean_error():
+    """test/runtests.jl:553-599: 2-D linear system, N=500, T=200: mean state error small."""
+    model = M.lg_c1_model()
+    X, U, Y = M.simulate_lg(model, 200)
+    cfg = S.make_config(model, 500, S.ADVANCED_PARTICLE_FILTER, resample_threshold=0.5, seed=3)
+    o = ob.OracleFilter(cfg, ob.ORDER_REFERENCE)
+    o.reset()
+    r = o.run(U, Y, 0.0, xmean=True)
+    assert np.linalg.norm(np.mean(X - r["xmean"], axis=0)) < 5
+    assert np.mean((X - r["xmean"]) ** 2) < 2.0
+
+
+def test_reference_and_device_order_agree():
+    """The two arithmetic orders of the oracle on the same Philox inputs: fp within 1e-12, same ancestors."""
+    model = M.quadtank_model()
+    U, Y = M.quadtank_data(30)
+    cfg = S.make_config(model, 2000, S.ADVANCED_PARTICLE_FILTER, resample_threshold=0.5, seed=1)
+    od, orf = ob.OracleFilter(cfg, ob.ORDER_DEVICE), ob.OracleFilter(cfg, ob.ORDER_REFERENCE)
+    od.reset(); orf.reset()
+    rd = od.run(U, Y, 490.0, ll_steps=True, history=True)
+    rr = orf.run(U, Y, 490.0, ll_steps=True, history=True)
+    assert np.max(np.abs(rd["ll_steps"] - rr["ll_steps"])) < 1e-11
+    assert np.array_equal(od.ancestors(), orf.ancestors())
+    np.testing.assert_allclose(rd["we"], rr["we"], rtol=1e-11, atol=1e-300)
+    np.testing.assert_allclose(rd["x"], rr["x"], rtol=1e-12, atol=1e-12)
+    assert od.resample_count() == orf.resample_count() > 0
