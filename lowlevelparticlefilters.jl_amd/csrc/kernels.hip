@@ -498,16 +498,16 @@ __global__ __launch_bounds__(BLOCK) void k_norm(BankDev b, int K, int parity) {
 #pragma unroll
     for (int k = 0; k < NORM_IPT / 2; ++k) {
         const int64_t i0 = (int64_t)tile * TILE + (int64_t)k * (BLOCK * 2) + threadIdx.x * 2;
-        const double e0 = llpf_exp(wv[k].x - m);
-        const double e1 = llpf_exp(wv[k].y - m);
+        const double e0 = llpf_exp_le0(wv[k].x - m);
+        const double e1 = llpf_exp_le0(wv[k].y - m);
         bad += (e0 != e0) ? 1u : 0u;
         bad += (e1 != e1) ? 1u : 0u;
-        S = llpf_u128_add(S, llpf_fix96(e0));
-        S = llpf_u128_add(S, llpf_fix96(e1));
-        E2 = llpf_u128_add(E2, llpf_fix96(e0 * e0));
-        E2 = llpf_u128_add(E2, llpf_fix96(e1 * e1));
-        Q += llpf_q64(e0, K);
-        Q += llpf_q64(e1, K);
+        S = llpf_u128_add(S, llpf_fix96_unit(e0));
+        S = llpf_u128_add(S, llpf_fix96_unit(e1));
+        E2 = llpf_u128_add(E2, llpf_fix96_unit(e0 * e0));
+        E2 = llpf_u128_add(E2, llpf_fix96_unit(e1 * e1));
+        Q += llpf_q64_unit(e0, K);
+        Q += llpf_q64_unit(e1, K);
         if (XMEAN) {
 #pragma unroll
             for (int d = 0; d < NX; ++d) {
@@ -752,7 +752,7 @@ __global__ __launch_bounds__(BLOCK) void k_resample(BankDev b, ResArgs a) {
     // 1. exclusive prefix of this tile and total of the quanta, from the per-tile sums (no look-back, no spinning)
     uint64_t prefix, tot;
     if (uniform) {
-        const uint64_t Qc = llpf_q64(1.0 / (double)N, a.K);
+        const uint64_t Qc = llpf_q64_unit(1.0 / (double)N, a.K);
         const int64_t before = (int64_t)tile * TILE < N ? (int64_t)tile * TILE : N;
         prefix = (uint64_t)before * Qc;
         tot = (uint64_t)N * Qc;
@@ -790,8 +790,8 @@ __global__ __launch_bounds__(BLOCK) void k_resample(BankDev b, ResArgs a) {
             double v;
             if (SRC == SRC_VALUES) v = wk;
             else if (uniform) v = 1.0 / (double)N;
-            else v = llpf_exp(wk - m);
-            uint64_t q = llpf_q64(v, a.K);
+            else v = llpf_exp_le0(wk - m);
+            uint64_t q = llpf_q64_unit(v, a.K);
             if (ib + k >= N) q = 0;
             run += q;
             cq[k] = run;
@@ -926,7 +926,7 @@ __global__ __launch_bounds__(BLOCK) void k_qpart(BankDev b, int K) {
 #pragma unroll
     for (int k = 0; k < NORM_IPT; ++k) {
         const int64_t i = (int64_t)tile * TILE + (int64_t)k * BLOCK + threadIdx.x;
-        if (i < b.N) Q += llpf_q64(w[i], K);
+        if (i < b.N) Q += llpf_q64_unit(w[i], K);
     }
     Q = wave_sum_u64(Q);
     if ((threadIdx.x & 63) == 0) sm_w[threadIdx.x >> 6] = Q;
@@ -954,7 +954,7 @@ __global__ __launch_bounds__(BLOCK) void k_materialize(BankDev b, double* w_out,
         we = 1.0 / (double)b.N;
     } else {
         wv = sc->norm_pending ? (wr - sc->m) - sc->l : wr;
-        we = llpf_exp(wr - sc->m) * sc->inv;
+        we = llpf_exp_le0(wr - sc->m) * sc->inv;
     }
     if (w_out) w_out[(size_t)f * b.N + i] = wv;
     if (we_out) we_out[(size_t)f * b.N + i] = we;
@@ -993,7 +993,7 @@ __global__ __launch_bounds__(BLOCK) void k_wmean(BankDev b, double* out) {
     for (int d = 0; d < MAXD; ++d) acc[d] = 0.0;
     for (int64_t i = threadIdx.x; i < b.N; i += BLOCK) {
         const double wr = b.w[(size_t)f * b.Ns + i];
-        const double we = sc->uniform ? 1.0 / (double)b.N : llpf_exp(wr - sc->m) * sc->inv;
+        const double we = sc->uniform ? 1.0 / (double)b.N : llpf_exp_le0(wr - sc->m) * sc->inv;
 #pragma unroll
         for (int d = 0; d < MAXD; ++d)
             if (d < b.nx) acc[d] = acc[d] + xc[(size_t)d * b.Ns + i] * we;
@@ -1030,6 +1030,7 @@ __global__ void k_selftest_math(int which, const double* __restrict__ in, double
         case 5: r = llpf_sqrt(x); break;
         case 6: r = 1.0 / x; break;
         case 7: r = (double)llpf_d2u(x); break;
+        case 8: r = llpf_exp_le0(x); break;
         default: r = 0.0;
     }
     out[i] = r;

@@ -44,16 +44,12 @@ LLPF_HD double llpf_pow2i(int k) { return llpf_u2d((uint64_t)(k + 1023) << 52); 
 /* exp(x).  k = rint(x/ln2), r = x - k ln2 (two-term Cody–Waite with fma), degree-13 Taylor
  * polynomial on |r| <= ln2/2 (truncation 4e-18 relative), result scaled by 2^k in two exact
  * steps so that a subnormal result is rounded once.  exp(0) == 1 exactly. */
-LLPF_HD double llpf_exp(double x) {
-    if (x != x) return x;
-    if (x > 709.782712893384) return LLPF_INF;
-    if (x < -745.2) return 0.0;
+LLPF_HD double llpf_exp_core(double xc) {      /* xc in [-746, 709.78] or NaN */
     const double LOG2E  = 1.44269504088896338700e+00;
     const double LN2_HI = 6.93147180369123816490e-01;
     const double LN2_LO = 1.90821492927058770002e-10;
-    double kf = llpf_rint(x * LOG2E);
-    int k = (int)kf;
-    double r = llpf_fma(-kf, LN2_HI, x);
+    double kf = llpf_rint(xc * LOG2E);
+    double r = llpf_fma(-kf, LN2_HI, xc);
     r = llpf_fma(-kf, LN2_LO, r);
     /* q(r) = 1/2! + r/3! + ... + r^11/13! */
     double q = 1.6059043836821613e-10;              /* 1/13! */
@@ -70,8 +66,22 @@ LLPF_HD double llpf_exp(double x) {
     q = llpf_fma(q, r, 0.5);                        /* 1/2!  */
     double p = llpf_fma(r * r, q, r);               /* r + r^2 q(r) */
     double y = 1.0 + p;
+    /* kf is an integer in [-1077, 1024] (or NaN, in which case y is NaN and the scale factors are irrelevant
+     * but must not trap: the conversion below is done on a clamped copy) */
+    double kc = kf == kf ? kf : 0.0;
+    int k = (int)kc;
     int k1 = k / 2, k2 = k - k1;
     return (y * llpf_pow2i(k1)) * llpf_pow2i(k2);
+}
+
+LLPF_HD double llpf_exp(double x) {
+    if (x > 709.782712893384) return LLPF_INF;
+    return llpf_exp_core(x < -746.0 ? -746.0 : x);  /* NaN falls through the clamp and propagates */
+}
+
+/* exp for arguments known to be <= 0 (exp-weights exp(w - max w)); no overflow branch */
+LLPF_HD double llpf_exp_le0(double x) {
+    return llpf_exp_core(x < -746.0 ? -746.0 : x);
 }
 
 /* log(x) for x > 0 (fdlibm algorithm: x = 2^k (1+f), s = f/(2+f), log(1+f) = f - hfsq + s (hfsq + R(s^2))).
@@ -103,11 +113,11 @@ LLPF_HD double llpf_log(double x) {
     double s = f / (2.0 + f);
     double z = s * s;
     double w = z * z;
-    double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
-    double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    double t1 = w * llpf_fma(w, llpf_fma(w, Lg6, Lg4), Lg2);
+    double t2 = z * llpf_fma(w, llpf_fma(w, llpf_fma(w, Lg7, Lg5), Lg3), Lg1);
     double R = t2 + t1;
     double dk = (double)k;
-    return s * (hfsq + R) + dk * LN2_LO - hfsq + f + dk * LN2_HI;
+    return llpf_fma(dk, LN2_HI, (llpf_fma(s, hfsq + R, dk * LN2_LO) - hfsq) + f);
 }
 
 /* log1p(s) for s >= 0 (the only use: s = sum of exp-weights minus the maximum's 1,
@@ -127,9 +137,9 @@ LLPF_HD double llpf_ksin(double x, double y) {
                  S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
     double z = x * x;
     double w = z * z;
-    double r = S2 + z * (S3 + z * S4) + z * w * (S5 + z * S6);
+    double r = llpf_fma(z * w, llpf_fma(z, S6, S5), llpf_fma(z, llpf_fma(z, S4, S3), S2));
     double v = z * x;
-    return x - ((z * (0.5 * y - v * r) - y) - v * S1);
+    return x - ((z * llpf_fma(-v, r, 0.5 * y) - y) - v * S1);
 }
 LLPF_HD double llpf_kcos(double x, double y) {
     const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
@@ -137,10 +147,10 @@ LLPF_HD double llpf_kcos(double x, double y) {
                  C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
     double z = x * x;
     double w = z * z;
-    double r = z * (C1 + z * (C2 + z * C3)) + (w * w) * (C4 + z * (C5 + z * C6));
+    double r = llpf_fma(w * w, llpf_fma(z, llpf_fma(z, C6, C5), C4), z * llpf_fma(z, llpf_fma(z, C3, C2), C1));
     double hz = 0.5 * z;
     w = 1.0 - hz;
-    return w + (((1.0 - w) - hz) + (z * r - x * y));
+    return w + (((1.0 - w) - hz) + llpf_fma(z, r, -(x * y)));
 }
 
 /* sin(2 pi u), cos(2 pi u) for u in [0,1).  Quadrant reduction is exact (4u and 4u - rint(4u)

@@ -58,6 +58,31 @@ LLPF_HD uint64_t llpf_q64(double e, int K) {
     return rs >= 53 ? 0 : (M >> rs);
 }
 
+/* Branch-free forms for arguments in [0, 1] (exp-weights and their squares), used in the hot loops.
+ * With Y = mantissa << 11 (bit 63 set):  e * 2^96 = (Y * 2^64) >> (1054 - E)  and  e * 2^K = Y >> (1086 - K - E).
+ * Exact for every e in [0, 2); anything else — negative, >= 2, inf, NaN (and subnormals) — maps to 0. */
+LLPF_HD llpf_u128 llpf_fix96_unit(double e) {
+    const uint64_t u = llpf_d2u(e);
+    const int E = (int)(u >> 52);                      /* sign bit included: negative => E >= 2048 */
+    const uint64_t Y = ((u << 11) | 0x8000000000000000ULL);
+    const int rs = 1054 - E;                           /* >= 31 for e <= 1 */
+    const int ok = (E >= 1) & (E <= 1023);
+    llpf_u128 r;
+    const uint64_t hi = rs < 64 ? (Y >> (rs & 63)) : 0;
+    const uint64_t lo = rs < 64 ? (Y << ((64 - rs) & 63)) : (rs < 128 ? (Y >> ((rs - 64) & 63)) : 0);
+    r.hi = ok ? hi : 0;
+    r.lo = ok ? lo : 0;
+    return r;
+}
+LLPF_HD uint64_t llpf_q64_unit(double e, int K) {
+    const uint64_t u = llpf_d2u(e);
+    const int E = (int)(u >> 52);
+    const uint64_t Y = ((u << 11) | 0x8000000000000000ULL);
+    const int rs = 1086 - K - E;                       /* >= 1 for e <= 1, K <= 62 */
+    const int ok = (E >= 1) & (E <= 1023) & (rs < 64);
+    return ok ? (Y >> (rs & 63)) : 0;
+}
+
 /* number of fraction bits used for the 64-bit resampling bins of an N-particle filter */
 LLPF_HD int llpf_qbits(int64_t n) {
     int lg = 0;

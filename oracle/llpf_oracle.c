@@ -282,11 +282,11 @@ static void dev_expsum(const double* w, double* e, int64_t n, devnorm* o) {
     uint64_t Q = 0;
     int K = llpf_qbits(n);
     for (int64_t i = 0; i < n; ++i) {
-        double ei = llpf_exp(w[i] - m);
+        double ei = llpf_exp_le0(w[i] - m);
         e[i] = ei;
-        S = llpf_u128_add(S, llpf_fix96(ei));
-        E2 = llpf_u128_add(E2, llpf_fix96(ei * ei));
-        Q += llpf_q64(ei, K);
+        S = llpf_u128_add(S, llpf_fix96_unit(ei));
+        E2 = llpf_u128_add(E2, llpf_fix96_unit(ei * ei));
+        Q += llpf_q64_unit(ei, K);
     }
     o->m = m;
     o->K = K;
@@ -389,12 +389,12 @@ int orc_resample(int strategy, const double* we, int64_t n, int64_t m, const dou
          * reference's search (the GPU evaluates it through counts c(v) = #{ i : thr_i < v }). */
         int K = llpf_qbits(n);
         uint64_t cum = 0, tot = 0;
-        for (int64_t i = 0; i < n; ++i) tot += llpf_q64(we[i], K);
+        for (int64_t i = 0; i < n; ++i) tot += llpf_q64_unit(we[i], K);
         if (tot == 0) { if (!bins) free(b); return -1; }
         double Td = (double)tot;
         double invTd = 1.0 / Td;
         for (int64_t i = 0; i < n; ++i) {
-            cum += llpf_q64(we[i], K);
+            cum += llpf_q64_unit(we[i], K);
             b[i] = (double)cum * invTd;
         }
         double binsN = Td * invTd;
@@ -575,7 +575,7 @@ static void filter_resample_dev(orc_filter* f, const double* U) {
     double Td = (double)f->dn.totQ;
     double invTd = 1.0 / Td;
     for (int64_t i = 0; i < n; ++i) {
-        cum += llpf_q64(f->e[i], f->dn.K);
+        cum += llpf_q64_unit(f->e[i], f->dn.K);
         f->bins[i] = (double)cum * invTd;
     }
     double binsN = Td * invTd;
@@ -865,6 +865,7 @@ void orc_math_vec(int which, const double* in, double* out, int64_t n) {
             case 5: out[i] = llpf_sqrt(x); break;
             case 6: out[i] = 1.0 / x; break;
             case 7: out[i] = (double)llpf_d2u(x); break;
+            case 8: out[i] = llpf_exp_le0(x); break;
             default: out[i] = NAN;
         }
     }
@@ -882,6 +883,11 @@ void orc_fix96(double e, uint64_t* lo_hi) {
     lo_hi[0] = r.lo; lo_hi[1] = r.hi;
 }
 uint64_t orc_q64(double e, int K) { return llpf_q64(e, K); }
+void orc_fix96_unit(double e, uint64_t* lo_hi) {
+    llpf_u128 r = llpf_fix96_unit(e);
+    lo_hi[0] = r.lo; lo_hi[1] = r.hi;
+}
+uint64_t orc_q64_unit(double e, int K) { return llpf_q64_unit(e, K); }
 double orc_u128_to_double(uint64_t lo, uint64_t hi) {
     llpf_u128 a; a.lo = lo; a.hi = hi;
     return llpf_u128_to_double(a);

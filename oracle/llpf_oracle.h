@@ -94,6 +94,8 @@ void   orc_philox_block(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint
 void   orc_normals(uint64_t seed, uint32_t step, uint32_t stream, int nd, double* out, int64_t n);
 void   orc_fix96(double e, uint64_t* lo_hi);
 uint64_t orc_q64(double e, int K);
+void   orc_fix96_unit(double e, uint64_t* lo_hi);
+uint64_t orc_q64_unit(double e, int K);
 double orc_u128_to_double(uint64_t lo, uint64_t hi);
 
 #ifdef __cplusplus

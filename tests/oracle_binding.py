@@ -80,6 +80,9 @@ def load():
     lib.orc_fix96.argtypes = [C.c_double, C.POINTER(C.c_uint64)]
     lib.orc_q64.restype = C.c_uint64
     lib.orc_q64.argtypes = [C.c_double, C.c_int]
+    lib.orc_fix96_unit.argtypes = [C.c_double, C.POINTER(C.c_uint64)]
+    lib.orc_q64_unit.restype = C.c_uint64
+    lib.orc_q64_unit.argtypes = [C.c_double, C.c_int]
     lib.orc_u128_to_double.restype = C.c_double
     lib.orc_u128_to_double.argtypes = [C.c_uint64, C.c_uint64]
     return lib

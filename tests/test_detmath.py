@@ -25,6 +25,9 @@ def test_exp_accuracy_and_specials():
     sp = ob.math_vec(0, np.array([0.0, -0.0, -1e-300, -745.0, -746.0, 710.0, np.nan, -np.inf]))
     assert sp[0] == 1.0 and sp[1] == 1.0 and sp[2] == 1.0
     assert sp[3] == 5e-324 and sp[4] == 0.0 and np.isinf(sp[5]) and np.isnan(sp[6]) and sp[7] == 0.0
+    xn = np.concatenate([x[x <= 0], [-745.0, -745.2, -746.0, -800.0, -1e6, -np.inf, 0.0]])
+    assert np.array_equal(ob.math_vec(8, xn), ob.math_vec(0, xn))      # exp_le0 == exp on its domain
+    assert np.isnan(ob.math_vec(8, np.array([np.nan]))[0])
     # monotone on a fine grid around 0 (the exp-weights of near-maximal particles)
     g = np.linspace(-1e-3, 0, 100001)
     assert np.all(np.diff(ob.math_vec(0, g)) >= 0)
@@ -100,9 +103,16 @@ def test_fixed_point_conversions_exact():
         got = lo_hi[0] + (lo_hi[1] << 64)
         exp = int(Fraction(float(e)) * (1 << 96)) if e >= 2.0 ** -1022 else 0      # floor for positive values
         assert got == exp, e
+        L.orc_fix96_unit(float(e), lo_hi)
+        assert lo_hi[0] + (lo_hi[1] << 64) == exp, e            # branch-free form for [0,1]
         for K in (31, 42, 62):
             exp_q = int(Fraction(float(e)) * (1 << K)) if e >= 2.0 ** -1022 else 0
             assert L.orc_q64(float(e), K) == exp_q
+            assert L.orc_q64_unit(float(e), K) == exp_q
+    for bad in (-0.5, 2.5, np.inf, np.nan, -np.inf):            # outside [0,2) -> 0 in the unit forms
+        lo_hi = (C.c_uint64 * 2)()
+        L.orc_fix96_unit(float(bad), lo_hi)
+        assert lo_hi[0] == 0 and lo_hi[1] == 0 and L.orc_q64_unit(float(bad), 40) == 0
     # 128-bit -> double conversion is round-to-nearest-even
     for _ in range(3000):
         bits = int(rng.integers(1, 128))
