@@ -126,6 +126,7 @@ struct Bank {
     double* d_w = nullptr;
     int32_t* d_anc = nullptr;
     uint64_t* d_acc = nullptr;
+    uint64_t* d_quanta = nullptr;
     uint64_t* d_tileq = nullptr;
     double* d_xmpart = nullptr;
     int parity = 0;                  // which max-accumulator set the NEXT weighting kernel writes
@@ -162,7 +163,7 @@ struct Bank {
         b.mlogN = -llpf_log((double)N);
         b.models = d_models; b.scal = d_scal;
         b.xcur = d_x[cur]; b.xnext = d_x[cur ^ 1];
-        b.w = d_w; b.anc = d_anc; b.acc = d_acc; b.tileq = d_tileq; b.xmpart = d_xmpart;
+        b.w = d_w; b.anc = d_anc; b.acc = d_acc; b.quanta = d_quanta; b.tileq = d_tileq; b.xmpart = d_xmpart;
         return b;
     }
 };
@@ -179,7 +180,7 @@ static void free_bank(Bank& b) {
     hipSetDevice(b.device);
     if (b.stream) hipStreamSynchronize(b.stream);
     hipFree(b.d_models); hipFree(b.d_scal); hipFree(b.d_x[0]); hipFree(b.d_x[1]); hipFree(b.d_w);
-    hipFree(b.d_anc); hipFree(b.d_acc); hipFree(b.d_tileq); hipFree(b.d_xmpart); hipFree(b.d_uy); hipFree(b.d_U); hipFree(b.d_Y);
+    hipFree(b.d_anc); hipFree(b.d_acc); hipFree(b.d_quanta); hipFree(b.d_tileq); hipFree(b.d_xmpart); hipFree(b.d_uy); hipFree(b.d_U); hipFree(b.d_Y);
     hipFree(b.d_ll_steps); hipFree(b.d_xmean); hipFree(b.d_tmp);
     for (auto e : b.ev_pool) hipEventDestroy(e);
     for (auto& e : b.pending) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
@@ -312,6 +313,7 @@ static int bank_create(const llpf_config* cfg, const llpf_model* models, int F, 
     HIPC(hipMalloc(&b.d_w, sizeof(double) * FN));
     HIPC(hipMalloc(&b.d_anc, sizeof(int32_t) * FN));
     HIPC(hipMalloc(&b.d_acc, sizeof(uint64_t) * (size_t)F * ACC_WORDS));
+    HIPC(hipMalloc(&b.d_quanta, sizeof(uint64_t) * FN));
     HIPC(hipMalloc(&b.d_tileq, sizeof(uint64_t) * (size_t)F * b.P2));
     HIPC(hipMalloc(&b.d_xmpart, sizeof(double) * (size_t)F * b.P2 * MAXD));
     HIPC(hipMalloc(&b.d_uy, sizeof(double) * 4 * MAXD));
@@ -321,6 +323,7 @@ static int bank_create(const llpf_config* cfg, const llpf_model* models, int F, 
     HIPC(hipMemsetAsync(b.d_anc, 0, sizeof(int32_t) * FN, b.stream));
     HIPC(hipMemsetAsync(b.d_scal, 0, sizeof(FilterScal) * F, b.stream));
     HIPC(hipMemsetAsync(b.d_acc, 0, sizeof(uint64_t) * (size_t)F * ACC_WORDS, b.stream));
+    HIPC(hipMemsetAsync(b.d_quanta, 0, sizeof(uint64_t) * FN, b.stream));
     HIPC(hipMemsetAsync(b.d_tileq, 0, sizeof(uint64_t) * (size_t)F * b.P2, b.stream));
     HIPC(hipMemsetAsync(b.d_xmpart, 0, sizeof(double) * (size_t)F * b.P2 * MAXD, b.stream));
     HIPC(hipMemcpyAsync(b.d_models, hm.data(), sizeof(ModelD) * F, hipMemcpyHostToDevice, b.stream));

@@ -506,8 +506,12 @@ __global__ __launch_bounds__(BLOCK) void k_norm(BankDev b, int K, int parity) {
         S = llpf_u128_add(S, llpf_fix96_unit(e1));
         E2 = llpf_u128_add(E2, llpf_fix96_unit(e0 * e0));
         E2 = llpf_u128_add(E2, llpf_fix96_unit(e1 * e1));
-        Q += llpf_q64_unit(e0, K);
-        Q += llpf_q64_unit(e1, K);
+        ulonglong2 qv;
+        qv.x = llpf_q64_unit(e0, K);
+        qv.y = llpf_q64_unit(e1, K);
+        *reinterpret_cast<ulonglong2*>(b.quanta + (size_t)f * b.Ns + i0) = qv;
+        Q += qv.x;
+        Q += qv.y;
         if (XMEAN) {
 #pragma unroll
             for (int d = 0; d < NX; ++d) {
@@ -647,13 +651,13 @@ __global__ __launch_bounds__(BLOCK) void k_resample(BankDev b, ResArgs a) {
     const int64_t N = b.N;
     const int lane = threadIdx.x & 63, wvid = threadIdx.x >> 6;
 
-    // issue the tile's weight loads first: they do not depend on anything computed below
-    const double* __restrict__ w = b.w + (size_t)f * b.Ns;
+    // issue the tile's quanta loads first: they do not depend on anything computed below
+    const uint64_t* __restrict__ qsrc = b.quanta + (size_t)f * b.Ns;
     const int64_t ib = (int64_t)tile * TILE + (int64_t)threadIdx.x * NORM_IPT;
-    double2 wv[NORM_IPT / 2];
+    ulonglong2 qv[NORM_IPT / 2];
     if (a.mode & RES_RESAMPLE) {
 #pragma unroll
-        for (int k = 0; k < NORM_IPT / 2; ++k) wv[k] = *reinterpret_cast<const double2*>(w + ib + 2 * k);
+        for (int k = 0; k < NORM_IPT / 2; ++k) qv[k] = *reinterpret_cast<const ulonglong2*>(qsrc + ib + 2 * k);
     }
 
     // 0. scalars of logsumexp! / effective_particles / shouldresample — every block derives them (cheap, and
@@ -723,7 +727,6 @@ __global__ __launch_bounds__(BLOCK) void k_resample(BankDev b, ResArgs a) {
         sm_i[0] = dr; sm_i[1] = status; sm_i[2] = uniform;
     }
     __syncthreads();
-    const double m = sm_d[0];
     const double inv = sm_d[1];
     const int do_res = sm_i[0], status = sm_i[1];
     const bool uniform = (SRC == SRC_FILTER) && sm_i[2];
@@ -780,18 +783,14 @@ __global__ __launch_bounds__(BLOCK) void k_resample(BankDev b, ResArgs a) {
     }
     if (tot == 0) return;
 
-    // 2. quanta of this thread's NORM_IPT consecutive particles, inclusive scan
+    // 2. quanta of this thread's NORM_IPT consecutive particles (written by k_norm / k_qpart), inclusive scan
     uint64_t cq[NORM_IPT];
     {
+        const uint64_t Qc = uniform ? llpf_q64_unit(1.0 / (double)N, a.K) : 0;
         uint64_t run = 0;
 #pragma unroll
         for (int k = 0; k < NORM_IPT; ++k) {
-            const double wk = (k & 1) ? wv[k / 2].y : wv[k / 2].x;
-            double v;
-            if (SRC == SRC_VALUES) v = wk;
-            else if (uniform) v = 1.0 / (double)N;
-            else v = llpf_exp_le0(wk - m);
-            uint64_t q = llpf_q64_unit(v, a.K);
+            uint64_t q = uniform ? Qc : ((k & 1) ? qv[k / 2].y : qv[k / 2].x);
             if (ib + k >= N) q = 0;
             run += q;
             cq[k] = run;
@@ -926,7 +925,9 @@ __global__ __launch_bounds__(BLOCK) void k_qpart(BankDev b, int K) {
 #pragma unroll
     for (int k = 0; k < NORM_IPT; ++k) {
         const int64_t i = (int64_t)tile * TILE + (int64_t)k * BLOCK + threadIdx.x;
-        if (i < b.N) Q += llpf_q64_unit(w[i], K);
+        const uint64_t q = (i < b.N) ? llpf_q64_unit(w[i], K) : 0;
+        b.quanta[(size_t)f * b.Ns + i] = q;
+        Q += q;
     }
     Q = wave_sum_u64(Q);
     if ((threadIdx.x & 63) == 0) sm_w[threadIdx.x >> 6] = Q;
