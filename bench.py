@@ -136,19 +136,19 @@ def main():
         nx = model.nx
         value = world * args.steps * N * T / dt
         ms_cls, n_cls = prof
-        names = ["k_step(propagate+weight)", "k_norm(logsumexp partials)", "k_resample(scan+expand)", "k_finalize+other"]
+        names = ["k_resprop(finalize+resample+propagate+weight)", "k_norm(exp-weights, sums, quanta)", "k_resample(standalone)", "other"]
         kernel_us = {names[i]: (1e3 * ms_cls[i] / n_cls[i] if n_cls[i] else None) for i in range(4)}
-        # dominant kernel: k_step.  Algorithmic bytes per particle for a resampling step:
-        # gather-read xprev 8nx + write x 8nx + read ancestor 4 + write w 8
-        b_step = 16 * nx + 12
+        # dominant kernel: the fused k_resprop.  Algorithmic bytes per particle of a resampling timestep:
+        # read quanta 8 + read x[anc] 8nx + write x 8nx + write ancestor 4 + write w 8
+        b_step = 16 * nx + 20
         step_s = ms_cls[0] / n_cls[0] * 1e-3
         achieved = N * b_step / step_s / 1e9
         b_alg = 16 * nx + 40                         # whole-timestep algorithmic bytes
         timestep_s = dt / (args.steps * T)
-        roof = {"bound": "hbm", "kernel": "k_step<MODE_PROP_WEIGHT>", "achieved": achieved, "peak": 8000.0,
+        roof = {"bound": "hbm", "kernel": "k_resprop", "achieved": achieved, "peak": 8000.0,
                 "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
                 "bytes_per_launch": N * b_step, "avg_launch_us": step_s * 1e6,
-                "method": "hipEvent pairs around every launch on the engine stream, %d profiled passes after the timed region" % max(1, min(args.steps, 3)),
+                "method": "hipEvent pairs around every launch on the engine stream, %d profiled passes after the timed region (each pair adds ~2-3 us to the launch it brackets)" % max(1, min(args.steps, 3)),
                 "whole_timestep": {"algorithmic_bytes": N * b_alg, "us": timestep_s * 1e6,
                                    "achieved": N * b_alg / timestep_s / 1e9, "frac": N * b_alg / timestep_s / 8e12}}
         out = {"metric": "particle-steps/s", "value": value, "unit": "particle-steps/s", "n_gpus": world,

@@ -129,7 +129,7 @@ struct Bank {
     uint64_t* d_quanta = nullptr;
     uint64_t* d_tileq = nullptr;
     double* d_xmpart = nullptr;
-    int parity = 0;                  // which max-accumulator set the NEXT weighting kernel writes
+    int parity = 0;                  // accumulator slot (0..2) the NEXT weighting kernel writes (engine.hpp ACC_NSLOT)
     double* d_uy = nullptr;          // staging for single-step u / y (2 * MAXD)
     double* d_U = nullptr;           // resident inputs of a run
     double* d_Y = nullptr;
@@ -360,7 +360,7 @@ static int bank_correct(Bank& b, const double* u, const double* y, double t, dou
     ResArgs ra{};
     ra.mode = RES_FINALIZE; ra.parity = b.parity; ra.M = (int32_t)b.N;
     HIPC(launch_resample(d, ra, b.stream));
-    b.parity ^= 1;
+    b.parity = (b.parity + 1) % ACC_NSLOT;
     std::vector<FilterScal> h;
     CHK(scal_download(b, h));
     if (ll_out) for (int f = 0; f < b.F; ++f) ll_out[f] = h[f].ll;
@@ -374,7 +374,7 @@ static int bank_predict(Bank& b, const double* u, double t) {
     HIPC(hipMemcpyAsync(b.d_uy, hbuf, sizeof(hbuf), hipMemcpyHostToDevice, b.stream));
     BankDev d = b.dev();
     ResArgs ra{};
-    ra.mode = RES_RESAMPLE; ra.parity = b.parity ^ 1; ra.step = b.n_predict; ra.M = (int32_t)b.N; ra.anc_out = b.d_anc;
+    ra.mode = RES_RESAMPLE; ra.parity = (b.parity + ACC_NSLOT - 1) % ACC_NSLOT; ra.step = b.n_predict; ra.M = (int32_t)b.N; ra.anc_out = b.d_anc;
     HIPC(launch_resample(d, ra, b.stream));
     StepArgs a{};
     a.u = b.d_uy; a.y = nullptr; a.t_prop = t; a.t_meas = t; a.step = b.n_predict; a.has_y = 0; a.parity = b.parity;
@@ -436,7 +436,7 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
     for (int64_t k = 0; k < T; ++k) {
         BankDev d = b.dev();
         const int par = b.parity;            // parity of the weighting that produced the current weights
-        b.parity ^= 1;
+        b.parity = (b.parity + 1) % ACC_NSLOT;
         {   // logsumexp! of correct!(u_k, y_k): exp-weights and their sums
             ProfScope ps(b, LLPF_PROF_NORMALISE);
             HIPC(launch_norm(d, par, want_xm, b.stream));
@@ -470,25 +470,22 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
             ra.mode = RES_RESAMPLE;
             ra.accumulate = 0; ra.ll_steps = nullptr; ra.xmean = nullptr;
             HIPC(launch_resample(d, ra, b.stream));
-        } else {      // scalars of correct!(u_k, y_k) + shouldresample + resample of predict!(u_k), one launch
-            ra.mode = RES_FINALIZE | RES_RESAMPLE;
-            ProfScope ps(b, LLPF_PROF_RESAMPLE);
-            HIPC(launch_resample(d, ra, b.stream));
         }
-        {   // ... propagate, fused with the weighting of correct!(u_{k+1}, y_{k+1})
-            StepArgs a{};
-            a.u = b.nu > 0 ? b.d_U + k * b.nu : nullptr;
-            a.t_prop = tk(k);
-            a.step = b.n_predict;
-            a.parity = b.parity;
+        StepArgs st{};
+        st.u = b.nu > 0 ? b.d_U + k * b.nu : nullptr;
+        st.t_prop = tk(k);
+        st.step = b.n_predict;
+        st.parity = b.parity;
+        const bool weight = (k + 1 < T);
+        if (weight) { st.y = b.d_Y + (k + 1) * b.ny; st.t_meas = tk(k + 1); st.has_y = has_y(k + 1) ? 1 : 0; }
+        else { st.y = nullptr; st.t_meas = tk(k); st.has_y = 0; }
+        if (hist) {   // unfused: the state between correct! and predict! was exposed above
             ProfScope ps(b, LLPF_PROF_PROPAGATE);
-            if (k + 1 < T) {
-                a.y = b.d_Y + (k + 1) * b.ny; a.t_meas = tk(k + 1); a.has_y = has_y(k + 1) ? 1 : 0;
-                HIPC(launch_step(d, MODE_PROP_WEIGHT, a, b.stream));
-            } else {
-                a.y = nullptr; a.t_meas = tk(k); a.has_y = 0;
-                HIPC(launch_step(d, MODE_PROP, a, b.stream));
-            }
+            HIPC(launch_step(d, weight ? MODE_PROP_WEIGHT : MODE_PROP, st, b.stream));
+        } else {      // scalars of correct!(u_k, y_k) + shouldresample + resample + propagate of predict!(u_k)
+                      // + weighting of correct!(u_{k+1}, y_{k+1}): one launch
+            ProfScope ps(b, LLPF_PROF_PROPAGATE);
+            HIPC(launch_resprop(d, ra, st, weight ? 1 : 0, b.stream));
         }
         b.cur ^= 1;
         b.n_predict++;
@@ -551,7 +548,7 @@ static int bank_set_weights(Bank& b, const double* w) {
     ResArgs ra{};
     ra.mode = RES_FINALIZE; ra.parity = b.parity; ra.M = (int32_t)b.N; ra.keep_norm = 1;
     HIPC(launch_resample(d, ra, b.stream));
-    b.parity ^= 1;
+    b.parity = (b.parity + 1) % ACC_NSLOT;
     CHK(scal_download(b, h));
     return check_status(b, h);
 }

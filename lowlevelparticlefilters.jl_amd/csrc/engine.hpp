@@ -45,12 +45,20 @@ constexpr int TILE = BLOCK * NORM_IPT;   // 1024 particles per tile: normalise a
 // so a launch of ~1000-2000 blocks puts only ~120-250 atomics on any line, spread over its whole duration.
 constexpr int NSHARD = 8;
 constexpr int ACC_STRIDE = 16;                  // u64 per (word, shard) slot = 128 B
-constexpr int ACC_PM = 0;                       // words 0,1 : max keys of the two weighting parities
-constexpr int ACC_S = 2;                        // words 2..4: sum fix96(e)   in 43-bit limbs
-constexpr int ACC_E2 = 5;                       // words 5..7: sum fix96(e^2) in 43-bit limbs
-constexpr int ACC_BAD = 8;                      // word  8   : count of NaN exp-weights
-constexpr int ACC_NWORDS = 9;
-constexpr int ACC_WORDS = ACC_NWORDS * NSHARD * ACC_STRIDE;   // u64 per filter (9 KB)
+// Every word exists three times ("slots").  A weighting kernel at timestep k accumulates its maximum into slot
+// (k+1)%3 while — in the fused kernel — other blocks of the SAME launch are still reading slot k%3; the reader
+// clears slot (k+2)%3, whose last reader finished two launches ago.  No grid-wide synchronisation is needed.
+constexpr int ACC_NSLOT = 3;
+constexpr int ACC_NWORDS = 24;
+__host__ __device__ constexpr int ACC_PM(int p) { return p; }            // max key
+__host__ __device__ constexpr int ACC_S(int p) { return 3 + 3 * p; }     // 3 limbs (43 bit) of sum fix96(e)
+__host__ __device__ constexpr int ACC_E2(int p) { return 12 + 3 * p; }   // 3 limbs of sum fix96(e^2)
+__host__ __device__ constexpr int ACC_BAD(int p) { return 21 + p; }      // count of NaN exp-weights
+// the 8 words of one slot in the order the reader's lane groups fetch them
+__host__ __device__ constexpr int acc_word_of_group(int g, int p) {
+    return g == 0 ? ACC_PM(p) : (g <= 3 ? ACC_S(p) + (g - 1) : (g <= 6 ? ACC_E2(p) + (g - 4) : ACC_BAD(p)));
+}
+constexpr int ACC_WORDS = ACC_NWORDS * NSHARD * ACC_STRIDE;   // u64 per filter (24 KB)
 
 // derived Gaussian (host-prepared): mirrors oracle/llpf_oracle.c:gaussd field for field
 struct GaussD {
@@ -128,7 +136,7 @@ struct StepArgs {
     double t_meas;         // time passed to measurement
     uint32_t step;         // Philox step counter of this predict!
     int32_t has_y;         // 0: measurement missing (weights pass through)
-    int32_t parity;        // which max-accumulator set this weighting writes
+    int32_t parity;        // accumulator slot (0..2) this weighting writes its maximum to
 };
 
 enum { RES_FINALIZE = 1, RES_RESAMPLE = 2 };
@@ -137,7 +145,7 @@ enum { RES_FINALIZE = 1, RES_RESAMPLE = 2 };
 struct ResArgs {
     int32_t mode;          // RES_FINALIZE: derive the scalars of logsumexp!/ESS/shouldresample from the accumulators
                            // RES_RESAMPLE: scan + ancestor expansion (if the decision says so, or `force`)
-    int32_t parity;        // parity of the weighting whose maxima are in acc
+    int32_t parity;        // accumulator slot (0..2) of the weighting that produced the current weights
     int32_t K;             // fraction bits of the resampling quanta
     int32_t force;         // resample regardless of the decision
     int32_t only_bins;     // write bins_out and stop
@@ -163,6 +171,8 @@ hipError_t launch_max(const BankDev& b, int parity, hipStream_t s);           //
 hipError_t launch_norm(const BankDev& b, int parity, int want_xmean, hipStream_t s);
 hipError_t launch_post_predict(const BankDev& b, hipStream_t s);
 hipError_t launch_resample(const BankDev& b, const ResArgs& a, hipStream_t s);
+// fused finalize + resample + propagate [+ weight]: one launch for predict!(u_k) and the weighting of correct!(u_{k+1}, y_{k+1})
+hipError_t launch_resprop(const BankDev& b, const ResArgs& a, const StepArgs& st, int weight, hipStream_t s);
 hipError_t launch_materialize(const BankDev& b, double* w_out, double* we_out, hipStream_t s);
 hipError_t launch_soa2aos(const BankDev& b, const double* xsrc, double* dst, hipStream_t s);
 hipError_t launch_aos2soa(const BankDev& b, const double* src, double* xdst, hipStream_t s);

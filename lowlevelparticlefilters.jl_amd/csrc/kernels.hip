@@ -280,13 +280,13 @@ DEV const uint64_t* acc_slot(const uint64_t* acc, int word, int shard) { return 
 
 DEV void acc_max(uint64_t* acc, int parity, double blockmax, bool any_nan) {
     const uint64_t key = any_nan ? max_key(llpf_u2d(0x7ff8000000000000ULL)) : max_key(blockmax);
-    atomicMax(reinterpret_cast<unsigned long long*>(acc_slot(acc, ACC_PM + parity, blockIdx.x & (NSHARD - 1))),
+    atomicMax(reinterpret_cast<unsigned long long*>(acc_slot(acc, ACC_PM(parity), blockIdx.x & (NSHARD - 1))),
               (unsigned long long)key);
 }
 // every wave combines the NSHARD copies of the running max itself (lanes 0..7 load, 3 shuffles, broadcast)
 DEV double acc_read_max_wave(const uint64_t* acc, int parity) {
     const int lane = threadIdx.x & 63;
-    uint64_t k = (lane < NSHARD) ? *acc_slot(acc, ACC_PM + parity, lane) : 0;
+    uint64_t k = (lane < NSHARD) ? *acc_slot(acc, ACC_PM(parity), lane) : 0;
 #pragma unroll
     for (int o = 1; o < NSHARD; o <<= 1) {
         const uint64_t t = (uint64_t)__shfl_xor((unsigned long long)k, o, 64);
@@ -294,11 +294,6 @@ DEV double acc_read_max_wave(const uint64_t* acc, int parity) {
     }
     k = (uint64_t)__shfl((unsigned long long)k, 0, 64);
     return max_unkey(k);
-}
-// zero the sum accumulators of one filter (threads 0 .. 7*NSHARD-1 of one block)
-DEV void acc_clear_sums(uint64_t* acc) {
-    if (threadIdx.x < (ACC_NWORDS - ACC_S) * NSHARD)
-        *acc_slot(acc, ACC_S + threadIdx.x / NSHARD, threadIdx.x % NSHARD) = 0;
 }
 constexpr uint64_t M43 = ((uint64_t)1 << 43) - 1;
 DEV void acc_add_u128(uint64_t* acc, int word0, llpf_u128 v) {
@@ -338,8 +333,6 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
     double* w = b.w + (size_t)f * Ns;
     const int32_t* __restrict__ anc = b.anc + (size_t)f * Ns;
 
-    // a normalise kernel always follows a weighting: zero its sum accumulators (all their readers are done)
-    if (MODE != MODE_PROP && blockIdx.x == 0) acc_clear_sums(b.acc + (size_t)f * ACC_WORDS);
 
     Model model;
     model.prepare(md, a.u, a.t_prop);
@@ -453,7 +446,6 @@ __global__ __launch_bounds__(BLOCK) void k_max(BankDev b, int parity) {
     __shared__ double sm_max[BLOCK / 64];
     const int f = blockIdx.y;
     const double* w = b.w + (size_t)f * b.Ns;
-    if (blockIdx.x == 0) acc_clear_sums(b.acc + (size_t)f * ACC_WORDS);
     double bmax = -LLPF_INF;
     bool bad = false;
 #pragma unroll
@@ -550,9 +542,9 @@ __global__ __launch_bounds__(BLOCK) void k_norm(BankDev b, int K, int parity) {
             q += sm_u[k][4];
             bd += sm_u[k][5];
         }
-        acc_add_u128(acc, ACC_S, s);
-        acc_add_u128(acc, ACC_E2, e2);
-        if (bd) atomicAdd(reinterpret_cast<unsigned long long*>(acc_slot(acc, ACC_BAD, blockIdx.x & (NSHARD - 1))), (unsigned long long)bd);
+        acc_add_u128(acc, ACC_S(parity), s);
+        acc_add_u128(acc, ACC_E2(parity), e2);
+        if (bd) atomicAdd(reinterpret_cast<unsigned long long*>(acc_slot(acc, ACC_BAD(parity), blockIdx.x & (NSHARD - 1))), (unsigned long long)bd);
         b.tileq[(size_t)f * b.P2 + tile] = q;
         if (XMEAN) {
             for (int d = 0; d < NX; ++d) {
@@ -629,168 +621,164 @@ struct ThrStrat { // stratified: u_i = (i0 + rand()) / M * bins[N]  (resample.jl
     }
 };
 
-struct ResScal {       // block-uniform scalars of a resample launch
-    double m, invTd;
-    uint64_t tot;
-    int32_t do_res, status, uniform;
+// ---- shared machinery of the resample kernels -----------------------------------------------------------------
+struct ResShared {                 // LDS scratch
+    uint64_t red[BLOCK / 64][4];
+    uint64_t accw[8];
+    double dval[4];
+    uint32_t cl[TILE];
+};
+struct ResHead {                   // block-uniform results of res_head()
+    double m, s, e2;               // max, sum_{i != argmax} e_i, sum e_i^2 of the current weights
+    uint64_t prefix, tot;          // exclusive prefix of this tile's quanta, total of all quanta
+    int dr, status, uniform;
 };
 
-template <int STRATEGY, int SRC>
-__global__ __launch_bounds__(BLOCK) void k_resample(BankDev b, ResArgs a) {
-    __shared__ uint64_t sm_w[BLOCK / 64][2];
-    __shared__ uint32_t cl[TILE];
-    __shared__ uint32_t owner[TILE];
-    __shared__ uint64_t sm_pref[2];
-    __shared__ double sm_d[4];
-    __shared__ int32_t sm_i[4];
-    __shared__ uint64_t sm_acc[ACC_NWORDS];
-    const int f = blockIdx.y;
-    const int tile = blockIdx.x;
+// shouldresample (reference src/resample.jl:5-10) without the division: ESS = (s+1)^2 / sum(e^2) < N*thr
+DEV int decide_resample(double thr, double N, double s, double e2) {
+    if (thr == 1.0) return 1;
+    const double sp1 = s + 1.0;
+    return (sp1 * sp1 < (N * thr) * e2) ? 1 : 0;
+}
+
+// Head of a resample launch: all global loads are issued first (accumulator slots, per-tile quanta sums), one
+// __syncthreads, then EVERY thread derives the block-uniform scalars (integer sums => identical everywhere).
+// Tile 0 publishes the scalars of logsumexp! / effective_particles / shouldresample for later kernels.
+template <int SRC>
+DEV ResHead res_head(const BankDev& b, const ResArgs& a, int f, int tile, ResShared& sh) {
     FilterScal* sc = b.scal + f;
     uint64_t* acc = b.acc + (size_t)f * ACC_WORDS;
-    const int64_t N = b.N;
     const int lane = threadIdx.x & 63, wvid = threadIdx.x >> 6;
+    const double Nd = (double)b.N;
+    ResHead h;
+    const bool fin = (a.mode & RES_FINALIZE) != 0;
+    const bool unif0 = (SRC == SRC_FILTER) && !fin && sc->uniform;
 
-    // issue the tile's quanta loads first: they do not depend on anything computed below
-    const uint64_t* __restrict__ qsrc = b.quanta + (size_t)f * b.Ns;
-    const int64_t ib = (int64_t)tile * TILE + (int64_t)threadIdx.x * NORM_IPT;
-    ulonglong2 qv[NORM_IPT / 2];
-    if (a.mode & RES_RESAMPLE) {
-#pragma unroll
-        for (int k = 0; k < NORM_IPT / 2; ++k) qv[k] = *reinterpret_cast<const ulonglong2*>(qsrc + ib + 2 * k);
-    }
-
-    // 0. scalars of logsumexp! / effective_particles / shouldresample — every block derives them (cheap, and
-    //    bit-identical because the sums are integers); block 0 publishes them for the next kernels
-    if (a.mode & RES_FINALIZE) {
-        // threads 0..71 each fetch one (word, shard) slot; 3 shuffles combine the 8 shards of a word
-        const int word = threadIdx.x / NSHARD, shard = threadIdx.x % NSHARD;
-        uint64_t v = (threadIdx.x < ACC_NWORDS * NSHARD) ? *acc_slot(acc, word, shard) : 0;
-#pragma unroll
-        for (int o = 1; o < NSHARD; o <<= 1) {
-            const uint64_t t = (uint64_t)__shfl_xor((unsigned long long)v, o, 64);
-            v = (word < ACC_S) ? (t > v ? t : v) : v + t;
-        }
-        if (threadIdx.x < ACC_NWORDS * NSHARD && shard == 0) sm_acc[word] = v;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        double m, s, l, inv, ll, ess, e2;
-        int status = 0, uniform, dr;
-        if (a.mode & RES_FINALIZE) {
-            m = max_unkey(sm_acc[ACC_PM + a.parity]);
-            const llpf_u128 s128 = acc_combine_u128(sm_acc[ACC_S], sm_acc[ACC_S + 1], sm_acc[ACC_S + 2]);
-            const llpf_u128 e128 = acc_combine_u128(sm_acc[ACC_E2], sm_acc[ACC_E2 + 1], sm_acc[ACC_E2 + 2]);
-            const uint64_t bd = sm_acc[ACC_BAD];
-            if (bd != 0 || s128.hi < ((uint64_t)1 << 32)) {   // max is -Inf / NaN, or NaN weights: degenerate
-                s = llpf_u2d(0x7ff8000000000000ULL);
-                l = s; inv = s; ll = s; ess = s; e2 = s;
-                status = LLPF_ERR_DEGENERATE;
-            } else {
-                s = llpf_fix96_to_double(llpf_fix96_minus_one(s128));   // sum_all_but: exact, one rounding
-                l = llpf_log1p_nonneg(s);
-                inv = 1.0 / (s + 1.0);
-                ll = l + m;
-                e2 = llpf_fix96_to_double(e128);
-                ess = 1.0 / (e2 * (inv * inv));
-            }
-            uniform = 0;
-            dr = status ? 0 : ((b.thr == 1.0) ? 1 : (ess < (double)N * b.thr ? 1 : 0));
-            if (tile == 0) {
-                sc->m = m; sc->s = s; sc->l = l; sc->inv = inv; sc->ll = ll; sc->ess = ess; sc->e2 = e2;
-                sc->K = a.K;
-                sc->uniform = 0;
-                sc->norm_pending = a.keep_norm ? 0 : 1;
-                if (status) sc->status = status;
-                sc->do_resample = dr;
-                if (a.accumulate) sc->ll_total = sc->ll_total + ll;
-                if (a.ll_steps) a.ll_steps[(size_t)a.k * b.F + f] = ll;
-                // the next weighting kernel writes the other max-accumulator set: clear it now
-#pragma unroll
-                for (int q = 0; q < NSHARD; ++q) *acc_slot(acc, ACC_PM + (a.parity ^ 1), q) = 0;
-            }
-            if (!status) status = sc->status;
-        } else {
-            // predict! without a preceding correct! in this launch sequence: decide from the stored state
-            m = sc->m; inv = sc->inv; status = sc->status; uniform = sc->uniform;
-            if (uniform) {
-                const double wev = 1.0 / (double)N;
-                ess = 1.0 / ((double)N * (wev * wev));
-            } else {
-                ess = sc->ess;
-            }
-            dr = status ? 0 : ((b.thr == 1.0) ? 1 : (ess < (double)N * b.thr ? 1 : 0));
-            if (tile == 0 && !a.only_bins && SRC == SRC_FILTER) { sc->do_resample = dr; if (uniform) sc->ess = ess; }
-        }
-        sm_d[0] = m;
-        sm_d[1] = inv;
-        sm_i[0] = dr; sm_i[1] = status; sm_i[2] = uniform;
-    }
-    __syncthreads();
-    const double inv = sm_d[1];
-    const int do_res = sm_i[0], status = sm_i[1];
-    const bool uniform = (SRC == SRC_FILTER) && sm_i[2];
-
-    // weighted_mean output (fixed-order fp64 sum of the tile partials; tile 0 only)
-    if ((a.mode & RES_FINALIZE) && a.xmean && tile == 0) {
-        const double* xp = b.xmpart + (size_t)f * b.P2 * MAXD;
-        for (int d = 0; d < b.nx; ++d) {
-            double accx = 0.0;
-            for (int p = threadIdx.x; p < b.P2; p += BLOCK) accx = accx + xp[(size_t)p * MAXD + d];
-            accx = wave_sum_f64(accx);
-            if (lane == 0) sm_w[wvid][0] = llpf_d2u(accx);
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                double t = llpf_u2d(sm_w[0][0]);
-                for (int k = 1; k < BLOCK / 64; ++k) t = t + llpf_u2d(sm_w[k][0]);
-                a.xmean[((size_t)a.k * b.F + f) * b.nx + d] = t * inv;
-            }
-            __syncthreads();
-        }
-    }
-    if (!(a.mode & RES_RESAMPLE)) return;
-    if (status) return;
-    if (!a.force && !do_res) return;
-
-    // 1. exclusive prefix of this tile and total of the quanta, from the per-tile sums (no look-back, no spinning)
-    uint64_t prefix, tot;
-    if (uniform) {
-        const uint64_t Qc = llpf_q64_unit(1.0 / (double)N, a.K);
-        const int64_t before = (int64_t)tile * TILE < N ? (int64_t)tile * TILE : N;
-        prefix = (uint64_t)before * Qc;
-        tot = (uint64_t)N * Qc;
-    } else {
+    // loads
+    // wave 0: lane group g (8 lanes = 8 shards) fetches word g of this parity's accumulator set
+    uint64_t accv = 0;
+    const int grp = threadIdx.x / NSHARD, shard = threadIdx.x % NSHARD;
+    if (fin && threadIdx.x < 64) accv = *acc_slot(acc, acc_word_of_group(grp, a.parity), shard);
+    if (fin && tile == 0 && threadIdx.x >= 64 && threadIdx.x < 128)
+        *acc_slot(acc, acc_word_of_group(grp - 8, (a.parity + 2) % ACC_NSLOT), shard) = 0;   // clear the slot after next
+    uint64_t pre = 0, all = 0;
+    if ((a.mode & RES_RESAMPLE) && !unif0) {
         const uint64_t* __restrict__ tq = b.tileq + (size_t)f * b.P2;
-        uint64_t pre = 0, all = 0;
         for (int p = threadIdx.x; p < b.P2; p += BLOCK) {
             const uint64_t q = tq[p];
             all += q;
             if (p < tile) pre += q;
         }
-        pre = wave_sum_u64(pre);
-        all = wave_sum_u64(all);
-        if (lane == 0) { sm_w[wvid][0] = pre; sm_w[wvid][1] = all; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint64_t p0 = 0, a0 = 0;
-            for (int k = 0; k < BLOCK / 64; ++k) { p0 += sm_w[k][0]; a0 += sm_w[k][1]; }
-            sm_pref[0] = p0; sm_pref[1] = a0;
-        }
-        __syncthreads();
-        prefix = sm_pref[0];
-        tot = sm_pref[1];
-        __syncthreads();
     }
-    if (tot == 0) return;
+    // reductions
+    if (fin) {
+#pragma unroll
+        for (int o = 1; o < NSHARD; o <<= 1) {
+            const uint64_t t = (uint64_t)__shfl_xor((unsigned long long)accv, o, 64);
+            accv = (grp == 0) ? (t > accv ? t : accv) : accv + t;
+        }
+        if (threadIdx.x < 64 && shard == 0) sh.accw[grp] = accv;
+    }
+    pre = wave_sum_u64(pre);
+    all = wave_sum_u64(all);
+    if (lane == 0) { sh.red[wvid][0] = pre; sh.red[wvid][1] = all; }
+    __syncthreads();
+    h.prefix = 0; h.tot = 0;
+#pragma unroll
+    for (int k = 0; k < BLOCK / 64; ++k) { h.prefix += sh.red[k][0]; h.tot += sh.red[k][1]; }
 
-    // 2. quanta of this thread's NORM_IPT consecutive particles (written by k_norm / k_qpart), inclusive scan
+    h.status = 0;
+    double l = 0.0, inv = 1.0, ll = 0.0;
+    if (fin) {
+        h.m = max_unkey(sh.accw[0]);
+        const llpf_u128 s128 = acc_combine_u128(sh.accw[1], sh.accw[2], sh.accw[3]);
+        const llpf_u128 e128 = acc_combine_u128(sh.accw[4], sh.accw[5], sh.accw[6]);
+        if (sh.accw[7] != 0 || s128.hi < ((uint64_t)1 << 32)) {   // max is -Inf / NaN, or NaN weights: degenerate
+            h.s = llpf_u2d(0x7ff8000000000000ULL);
+            h.e2 = h.s;
+            h.status = LLPF_ERR_DEGENERATE;
+        } else {
+            h.s = llpf_fix96_to_double(llpf_fix96_minus_one(s128));     // sum_all_but: exact, one rounding
+            h.e2 = llpf_fix96_to_double(e128);
+        }
+        h.uniform = 0;
+        h.dr = h.status ? 0 : decide_resample(b.thr, Nd, h.s, h.e2);
+        if (tile == 0 && threadIdx.x == 0) {
+            double ess;
+            if (h.status) { l = h.s; inv = h.s; ll = h.s; ess = h.s; }
+            else {
+                l = llpf_log1p_nonneg(h.s);
+                inv = 1.0 / (h.s + 1.0);
+                ll = l + h.m;
+                ess = ((h.s + 1.0) * (h.s + 1.0)) / h.e2;
+            }
+            sc->m = h.m; sc->s = h.s; sc->l = l; sc->inv = inv; sc->ll = ll; sc->ess = ess; sc->e2 = h.e2;
+            sc->K = a.K;
+            sc->uniform = 0;
+            sc->norm_pending = a.keep_norm ? 0 : 1;
+            if (h.status) sc->status = h.status;
+            sc->do_resample = h.dr;
+            if (a.accumulate) sc->ll_total = sc->ll_total + ll;
+            if (a.ll_steps) a.ll_steps[(size_t)a.k * b.F + f] = ll;
+            sh.dval[0] = inv;
+        }
+        if (!h.status) h.status = sc->status;          // sticky until reset! (written above only when non-zero)
+    } else {
+        // predict! without a preceding correct! in this launch sequence: decide from the stored state
+        h.m = sc->m; h.s = sc->s; h.e2 = sc->e2; h.status = sc->status; h.uniform = (SRC == SRC_FILTER) ? sc->uniform : 0;
+        if (h.uniform) {
+            const double wev = 1.0 / Nd;
+            const double ess = 1.0 / (Nd * (wev * wev));
+            h.dr = (b.thr == 1.0) ? 1 : (ess < Nd * b.thr ? 1 : 0);
+            if (tile == 0 && threadIdx.x == 0 && !a.only_bins) sc->ess = ess;
+            const uint64_t Qc = llpf_q64_unit(1.0 / Nd, a.K);
+            const int64_t before = (int64_t)tile * TILE < b.N ? (int64_t)tile * TILE : b.N;
+            h.prefix = (uint64_t)before * Qc;
+            h.tot = (uint64_t)b.N * Qc;
+        } else {
+            h.dr = h.status ? 0 : decide_resample(b.thr, Nd, h.s, h.e2);
+        }
+        if (SRC == SRC_FILTER && tile == 0 && threadIdx.x == 0 && !a.only_bins) sc->do_resample = h.dr;
+    }
+
+    // weighted_mean output (fixed-order fp64 sum of the tile partials; tile 0 only)
+    if (fin && a.xmean && tile == 0) {
+        __syncthreads();
+        const double invb = sh.dval[0];
+        const double* xp = b.xmpart + (size_t)f * b.P2 * MAXD;
+        for (int d = 0; d < b.nx; ++d) {
+            double accx = 0.0;
+            for (int p = threadIdx.x; p < b.P2; p += BLOCK) accx = accx + xp[(size_t)p * MAXD + d];
+            accx = wave_sum_f64(accx);
+            __syncthreads();
+            if (lane == 0) sh.red[wvid][2] = llpf_d2u(accx);
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                double t = llpf_u2d(sh.red[0][2]);
+                for (int k = 1; k < BLOCK / 64; ++k) t = t + llpf_u2d(sh.red[k][2]);
+                a.xmean[((size_t)a.k * b.F + f) * b.nx + d] = t * invb;
+            }
+        }
+    }
+    return h;
+}
+
+// Scan of this tile's quanta + ancestor counts.  On return sh.cl[k] = c(bins[k]) for the tile's TILE sources
+// (after a __syncthreads), and [c_start, c_end) is the range of outputs this tile produces.
+template <int STRATEGY>
+DEV void res_counts(const BankDev& b, const ResArgs& a, int f, int tile, const ResHead& h, const ulonglong2* qv,
+                    ResShared& sh, int32_t& c_start, int32_t& c_end) {
+    const FilterScal* sc = b.scal + f;
+    const int64_t N = b.N;
+    const int lane = threadIdx.x & 63, wvid = threadIdx.x >> 6;
+    const int64_t ib = (int64_t)tile * TILE + (int64_t)threadIdx.x * NORM_IPT;
     uint64_t cq[NORM_IPT];
     {
-        const uint64_t Qc = uniform ? llpf_q64_unit(1.0 / (double)N, a.K) : 0;
+        const uint64_t Qc = h.uniform ? llpf_q64_unit(1.0 / (double)N, a.K) : 0;
         uint64_t run = 0;
 #pragma unroll
         for (int k = 0; k < NORM_IPT; ++k) {
-            uint64_t q = uniform ? Qc : ((k & 1) ? qv[k / 2].y : qv[k / 2].x);
+            uint64_t q = h.uniform ? Qc : ((k & 1) ? qv[k / 2].y : qv[k / 2].x);
             if (ib + k >= N) q = 0;
             run += q;
             cq[k] = run;
@@ -803,21 +791,20 @@ __global__ __launch_bounds__(BLOCK) void k_resample(BankDev b, ResArgs a) {
         const uint64_t t = (uint64_t)__shfl_up((unsigned long long)incl, o, 64);
         if (lane >= o) incl += t;
     }
-    if (lane == 63) sm_w[wvid][0] = incl;
+    if (lane == 63) sh.red[wvid][3] = incl;
     __syncthreads();
     uint64_t wave_off = 0;
 #pragma unroll
     for (int k = 0; k < BLOCK / 64; ++k)
-        if (k < wvid) wave_off += sm_w[k][0];
-    const uint64_t excl = prefix + wave_off + (incl - tsum);
+        if (k < wvid) wave_off += sh.red[k][3];
+    const uint64_t excl = h.prefix + wave_off + (incl - tsum);
 
-    // 3. bins = fl(fl(cum) * fl(1/fl(total))) and ancestor counts
-    const double Td = (double)tot;
+    // bins = fl(fl(cum) * fl(1/fl(total))) and ancestor counts
+    const double Td = (double)h.tot;
     const double invTd = 1.0 / Td;
     const double binsN = Td * invTd;                   // bins[N]: 1 or 1 - 2^-53
     const int32_t M = a.M;
     uint32_t cnt[NORM_IPT];
-    int32_t c_start;
     if (STRATEGY == LLPF_RESAMPLE_SYSTEMATIC) {
         ThrSys th;
         const double U = a.Uexp ? a.Uexp[0] : llpf_uniform_step(a.step, LLPF_STREAM_RESAMPLE, sc->k0, sc->k1);
@@ -830,7 +817,7 @@ __global__ __launch_bounds__(BLOCK) void k_resample(BankDev b, ResArgs a) {
             if (a.bins_out && ib + k < N) a.bins_out[(size_t)f * N + ib + k] = bin;
             cnt[k] = a.only_bins ? 0u : (uint32_t)th.count(bin);
         }
-        c_start = a.only_bins ? 0 : th.count((double)prefix * invTd);
+        c_start = a.only_bins ? 0 : th.count((double)h.prefix * invTd);
     } else {
         ThrStrat th;
         th.M = M; th.Md = (double)M; th.step = a.step; th.k0 = sc->k0; th.k1 = sc->k1; th.Uexp = a.Uexp;
@@ -842,77 +829,180 @@ __global__ __launch_bounds__(BLOCK) void k_resample(BankDev b, ResArgs a) {
             if (a.bins_out && ib + k < N) a.bins_out[(size_t)f * N + ib + k] = bin;
             cnt[k] = a.only_bins ? 0u : (uint32_t)th.count(bin);
         }
-        c_start = a.only_bins ? 0 : th.count((double)prefix * invTd);
+        c_start = a.only_bins ? 0 : th.count((double)h.prefix * invTd);
     }
-    if (a.only_bins) return;
 #pragma unroll
-    for (int k = 0; k < NORM_IPT; ++k) cl[threadIdx.x * NORM_IPT + k] = cnt[k];
+    for (int k = 0; k < NORM_IPT; ++k) sh.cl[threadIdx.x * NORM_IPT + k] = cnt[k];
     __syncthreads();
+    c_end = (int32_t)sh.cl[TILE - 1];
+}
 
-    // 4. expansion.  Source k of this tile produces outputs [cl[k-1], cl[k]) (cl[-1] = c_start).  Per chunk of TILE
-    //    outputs: every source that starts in the chunk drops its index at its first output, an inclusive
-    //    max-scan spreads it over its run, and the chunk is stored with coalesced 4-byte stores.
-    const int32_t c_end = (int32_t)cl[TILE - 1];
-    int32_t* ao = a.anc_out + (size_t)f * b.Ns;
-    for (int32_t cb = c_start; cb < c_end; cb += TILE) {
+// output o (c_start <= o < c_end) is produced by the first source k of the tile with cl[k] > o
+DEV int res_owner(const uint32_t* cl, int32_t o) {
+    int lo = 0, hi = TILE - 1;
+    const uint32_t ov = (uint32_t)o;
 #pragma unroll
-        for (int k = 0; k < NORM_IPT; ++k) owner[k * BLOCK + threadIdx.x] = 0;
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < NORM_IPT; ++k) {
-            const int kk = threadIdx.x * NORM_IPT + k;
-            const int32_t hi = (int32_t)cnt[k];
-            const int32_t lo = (k == 0) ? (kk == 0 ? c_start : (int32_t)cl[kk - 1]) : (int32_t)cnt[k - 1];
-            if (hi > lo && lo >= cb && lo < cb + TILE) owner[lo - cb] = (uint32_t)kk + 1;
-        }
-        if (cb != c_start && threadIdx.x == 0) {       // run that started in an earlier chunk: first source with cl > cb
-            int lo = 0, hi = TILE - 1;
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if ((int32_t)cl[mid] > cb) hi = mid; else lo = mid + 1;
-            }
-            if (owner[0] == 0) owner[0] = (uint32_t)lo + 1;
-        }
-        __syncthreads();
-        uint32_t ow[NORM_IPT];
-        uint32_t run = 0;
-#pragma unroll
-        for (int k = 0; k < NORM_IPT; ++k) {
-            const uint32_t v = owner[threadIdx.x * NORM_IPT + k];
-            run = v > run ? v : run;
-            ow[k] = run;
-        }
-        uint32_t inc = run;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t t = (uint32_t)__shfl_up((int)inc, o, 64);
-            if (lane >= o) inc = t > inc ? t : inc;
-        }
-        uint32_t excl_run = (uint32_t)__shfl_up((int)inc, 1, 64);
-        if (lane == 0) excl_run = 0;
-        if (lane == 63) sm_w[wvid][1] = inc;
-        __syncthreads();
-        uint32_t woff = 0;
-#pragma unroll
-        for (int k = 0; k < BLOCK / 64; ++k)
-            if (k < wvid) { const uint32_t t = (uint32_t)sm_w[k][1]; woff = t > woff ? t : woff; }
-        const uint32_t base = woff > excl_run ? woff : excl_run;
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < NORM_IPT; ++k) owner[threadIdx.x * NORM_IPT + k] = ow[k] > base ? ow[k] : base;
-        __syncthreads();
-        const int32_t nout = (c_end - cb) < TILE ? (c_end - cb) : TILE;
-#pragma unroll
-        for (int k = 0; k < NORM_IPT; ++k) {
-            const int32_t o = k * BLOCK + threadIdx.x;
-            if (o < nout) ao[cb + o] = (int32_t)((int64_t)tile * TILE + (owner[o] - 1));
-        }
-        __syncthreads();
+    for (int it = 0; it < 10; ++it) {                  // TILE = 1024 = 2^10
+        const int mid = (lo + hi) >> 1;
+        const bool gt = cl[mid] > ov;
+        hi = gt ? mid : hi;
+        lo = gt ? lo : mid + 1;
     }
+    return lo;
+}
+static_assert(TILE == 1024, "res_owner assumes 2^10 sources per tile");
+
+template <int STRATEGY, int SRC>
+__global__ __launch_bounds__(BLOCK) void k_resample(BankDev b, ResArgs a) {
+    __shared__ ResShared sh;
+    const int f = blockIdx.y;
+    const int tile = blockIdx.x;
+    const uint64_t* __restrict__ qsrc = b.quanta + (size_t)f * b.Ns;
+    const int64_t ib = (int64_t)tile * TILE + (int64_t)threadIdx.x * NORM_IPT;
+    ulonglong2 qv[NORM_IPT / 2];
+    if (a.mode & RES_RESAMPLE) {
+#pragma unroll
+        for (int k = 0; k < NORM_IPT / 2; ++k) qv[k] = *reinterpret_cast<const ulonglong2*>(qsrc + ib + 2 * k);
+    }
+    const ResHead h = res_head<SRC>(b, a, f, tile, sh);
+    if (!(a.mode & RES_RESAMPLE)) return;
+    if (h.status) return;
+    if (!a.force && !h.dr) return;
+    if (h.tot == 0) return;
+    int32_t c_start, c_end;
+    res_counts<STRATEGY>(b, a, f, tile, h, qv, sh, c_start, c_end);
+    if (a.only_bins) return;
+    int32_t* ao = a.anc_out + (size_t)f * b.Ns;
+    for (int32_t o = c_start + threadIdx.x; o < c_end; o += BLOCK)
+        ao[o] = (int32_t)((int64_t)tile * TILE + res_owner(sh.cl, o));
     // outputs whose threshold is >= bins[N] are never written by the reference (j keeps its previous
     // value); the previous value is only materialised here if it was the identity 1:N
-    if (tile == b.P2 - 1 && sc->anc_ident && SRC == SRC_FILTER) {
-        for (int32_t o = c_end + threadIdx.x; o < M; o += BLOCK) ao[o] = o;
+    if (tile == b.P2 - 1 && SRC == SRC_FILTER && b.scal[f].anc_ident) {
+        for (int32_t o = c_end + threadIdx.x; o < a.M; o += BLOCK) ao[o] = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_resprop — the fused predict!: finalize + shouldresample + resample + propagate [+ weight of the next
+// correct!] in ONE launch.  A block owns a tile of 1024 SOURCE particles; it derives which outputs its sources
+// produce ([c_start, c_end), from the ancestor counts) and propagates exactly those outputs, reading its
+// sources' states (an 8 KB window per dimension: L1/L2 hits) and writing x, w (and j, kept for the accessor and
+// for the reference's "stale j" corner) coalesced.  No ancestor array round trip, no separate propagate launch.
+// Load balance: a tile produces ~1024 outputs +- a few % for i.i.d.-like weights; a tile holding very heavy
+// particles loops over more 256-output chunks (worst case ESS -> 1: one block does everything; still far faster
+// than the serial reference).
+// The per-output arithmetic is the same sequence as k_step's, so fused and unfused paths are bit-identical.
+// ------------------------------------------------------------------------------------------------
+template <class Model, int NX, int NY, bool WEIGHT>
+struct PropCtx {
+    const BankDev& b;
+    const Model& model;
+    const ModelD* md;
+    const StepArgs& st;
+    const double* y;
+    const double* __restrict__ xc;
+    double* __restrict__ xn;
+    double* w;
+    uint32_t k0, k1;
+    // propagate output o from source src with previous log-weight wprev; returns the new log-weight
+    DEV double one(int64_t src, int64_t o, double wprev, bool& bad) const {
+        const int64_t Ns = b.Ns;
+        double xp[NX], fx[NX], xi[NX], nz[NX], xs[NX];
+#pragma unroll
+        for (int d = 0; d < NX; ++d) xp[d] = xc[(size_t)d * Ns + src];
+        model.dynamics(xp, fx);
+        llpf_normals((uint32_t)o, st.step, LLPF_STREAM_DYNAMICS, k0, k1, NX, xi);
+        gauss_sample<NX>(md->df, xi, nz);
+#pragma unroll
+        for (int d = 0; d < NX; ++d) {
+            xs[d] = fx[d] + nz[d];
+            xn[(size_t)d * Ns + o] = xs[d];
+        }
+        double wv = wprev;
+        if (WEIGHT) {
+            if (st.has_y) {
+                double g[NY], v[NY];
+                model.measurement(xs, g);
+#pragma unroll
+                for (int k = 0; k < NY; ++k) v[k] = y[k] - g[k];
+                wv = wv + gauss_logpdf<NY>(md->dg, v);
+            }
+            if (o >= b.N) wv = -LLPF_INF;
+            bad = bad || (wv != wv);
+            w[o] = wv;
+        }
+        return wv;
+    }
+};
+
+template <class Model, int NX, int NY, bool WEIGHT>
+__global__ __launch_bounds__(BLOCK) void k_resprop(BankDev b, const ModelD* __restrict__ models, ResArgs a, StepArgs st) {
+    __shared__ ResShared sh;
+    __shared__ double sm_max[BLOCK / 64];
+    const int f = blockIdx.y;
+    const int tile = blockIdx.x;
+    const int64_t Ns = b.Ns, N = b.N;
+    const ModelD* md = models + f;
+    FilterScal* sc = b.scal + f;
+    const uint64_t* __restrict__ qsrc = b.quanta + (size_t)f * Ns;
+    const int64_t ib = (int64_t)tile * TILE + (int64_t)threadIdx.x * NORM_IPT;
+    ulonglong2 qv[NORM_IPT / 2];
+#pragma unroll
+    for (int k = 0; k < NORM_IPT / 2; ++k) qv[k] = *reinterpret_cast<const ulonglong2*>(qsrc + ib + 2 * k);
+    const int anc_ident_prev = sc->anc_ident;          // written only at the very end of this kernel (tile 0)
+
+    const ResHead h = res_head<SRC_FILTER>(b, a, f, tile, sh);
+    if (h.status) return;
+
+    Model model;
+    model.prepare(md, st.u, st.t_prop);
+    double y[NY];
+#pragma unroll
+    for (int k = 0; k < NY; ++k) y[k] = (WEIGHT && st.has_y) ? st.y[k] : 0.0;
+    PropCtx<Model, NX, NY, WEIGHT> pc{b, model, md, st, y, b.xcur + (size_t)f * NX * Ns, b.xnext + (size_t)f * NX * Ns,
+                                      b.w + (size_t)f * Ns, sc->k0, sc->k1};
+    int32_t* anc = b.anc + (size_t)f * Ns;
+    double bmax = -LLPF_INF;
+    bool bad = false;
+
+    if (h.dr && h.tot != 0) {
+        int32_t c_start, c_end;
+        if (b.strategy == LLPF_RESAMPLE_SYSTEMATIC) res_counts<LLPF_RESAMPLE_SYSTEMATIC>(b, a, f, tile, h, qv, sh, c_start, c_end);
+        else res_counts<LLPF_RESAMPLE_STRATIFIED>(b, a, f, tile, h, qv, sh, c_start, c_end);
+        for (int32_t o = c_start + threadIdx.x; o < c_end; o += BLOCK) {
+            const int64_t src = (int64_t)tile * TILE + res_owner(sh.cl, o);
+            anc[o] = (int32_t)src;
+            bmax = llpf_fmax(bmax, pc.one(src, o, b.log1N, bad));      // reset_weights!: w = log(1/N)
+        }
+        if (tile == b.P2 - 1) {        // thresholds >= bins[N]: the reference leaves j[i] untouched (resample.jl:25-34)
+            for (int32_t o = c_end + threadIdx.x; o < a.M; o += BLOCK) {
+                const int64_t src = anc_ident_prev ? o : anc[o];
+                anc[o] = (int32_t)src;
+                bmax = llpf_fmax(bmax, pc.one(src, o, b.log1N, bad));
+            }
+        }
+    } else {
+        // no resampling: s.j .= 1:N, every particle propagates itself; weights keep their normalised value
+        const double l = llpf_log1p_nonneg(h.s);
+#pragma unroll 1
+        for (int k = 0; k < NORM_IPT; ++k) {
+            const int64_t o = (int64_t)tile * TILE + (int64_t)k * BLOCK + threadIdx.x;
+            double wprev = 0.0;
+            if (WEIGHT) wprev = (pc.w[o] - h.m) - l;                   // lazy w .-= offset ; w .-= log1p(s)
+            bmax = llpf_fmax(bmax, pc.one(o, o, wprev, bad));
+        }
+    }
+    if (WEIGHT) {
+        const double r = block_max(bmax, sm_max);
+        const int anybad = __syncthreads_or(bad ? 1 : 0);
+        if (threadIdx.x == 0) acc_max(b.acc + (size_t)f * ACC_WORDS, st.parity, r, anybad != 0);
+    }
+    __syncthreads();
+    if (tile == b.P2 - 1 && threadIdx.x == 0) {        // bookkeeping of this predict! (by the only block that reads anc_ident)
+        const int r = (h.dr && h.tot != 0) ? 1 : 0;
+        sc->anc_ident = r ? 0 : 1;
+        sc->last_resampled = r;
+        sc->resample_count += r;
     }
 }
 
@@ -1145,6 +1235,37 @@ hipError_t launch_resample(const BankDev& b, const ResArgs& a0, hipStream_t s) {
         else hipLaunchKernelGGL((k_resample<LLPF_RESAMPLE_STRATIFIED, SRC_VALUES>), g, dim3(BLOCK), 0, s, b, a);
     }
     return hipGetLastError();
+}
+
+template <class Model, int NX, int NY>
+static hipError_t launch_resprop_t(const BankDev& b, const ResArgs& a, const StepArgs& st, int weight, hipStream_t s) {
+    dim3 g((unsigned)b.P2, (unsigned)b.F, 1);
+    if (weight) hipLaunchKernelGGL((k_resprop<Model, NX, NY, true>), g, dim3(BLOCK), 0, s, b, b.models, a, st);
+    else hipLaunchKernelGGL((k_resprop<Model, NX, NY, false>), g, dim3(BLOCK), 0, s, b, b.models, a, st);
+    return hipGetLastError();
+}
+template <int NX>
+static hipError_t launch_resprop_lg_ny(const BankDev& b, const ResArgs& a, const StepArgs& st, int weight, hipStream_t s) {
+    switch (b.ny) {
+        case 1: return launch_resprop_t<LinGauss<NX, 1>, NX, 1>(b, a, st, weight, s);
+        case 2: return launch_resprop_t<LinGauss<NX, 2>, NX, 2>(b, a, st, weight, s);
+        case 3: return launch_resprop_t<LinGauss<NX, 3>, NX, 3>(b, a, st, weight, s);
+        case 4: return launch_resprop_t<LinGauss<NX, 4>, NX, 4>(b, a, st, weight, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+hipError_t launch_resprop(const BankDev& b, const ResArgs& a0, const StepArgs& st, int weight, hipStream_t s) {
+    ResArgs a = a0;
+    a.K = llpf_qbits(b.N);
+    a.mode = RES_FINALIZE | RES_RESAMPLE;
+    if (b.model_id == LLPF_MODEL_QUADTANK_RK4) return launch_resprop_t<QuadTank<4, 2>, 4, 2>(b, a, st, weight, s);
+    switch (b.nx) {
+        case 1: return launch_resprop_lg_ny<1>(b, a, st, weight, s);
+        case 2: return launch_resprop_lg_ny<2>(b, a, st, weight, s);
+        case 3: return launch_resprop_lg_ny<3>(b, a, st, weight, s);
+        case 4: return launch_resprop_lg_ny<4>(b, a, st, weight, s);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 hipError_t launch_materialize(const BankDev& b, double* w_out, double* we_out, hipStream_t s) {

@@ -548,8 +548,8 @@ double orc_correct(orc_filter* f, const double* u, const double* y, double t) {
 
 static double filter_ess(const orc_filter* f) {
     if (f->order == ORC_ORDER_DEVICE && f->dn_valid) {
-        /* sum(we^2) = inv^2 * sum(e^2), with sum(e^2) exact in fixed point */
-        return 1.0 / (f->dn.e2 * (f->dn.inv * f->dn.inv));
+        /* 1/sum(we^2) with we = e/(s+1): (s+1)^2 / sum(e^2), sum(e^2) exact in fixed point */
+        return ((f->dn.s + 1.0) * (f->dn.s + 1.0)) / f->dn.e2;
     }
     if (f->order == ORC_ORDER_DEVICE) {
         /* uniform weights: we = 1/N exactly representable product N * (1/N)^2 */
@@ -564,6 +564,11 @@ double orc_filter_ess(const orc_filter* f) { return filter_ess(f); }
 int orc_shouldresample(const orc_filter* f) {
     if (f->cfg.resample_threshold == 1.0) return 1;
     double th = (double)f->N * f->cfg.resample_threshold;
+    if (f->order == ORC_ORDER_DEVICE && f->dn_valid) {
+        /* the same test without the division: (s+1)^2 < N thr sum(e^2) */
+        double sp1 = f->dn.s + 1.0;
+        return sp1 * sp1 < th * f->dn.e2;
+    }
     return filter_ess(f) < th;
 }
 
