@@ -965,32 +965,39 @@ __global__ __launch_bounds__(BLOCK) void k_resprop(BankDev b, const ModelD* __re
     double bmax = -LLPF_INF;
     bool bad = false;
 
-    if (h.dr && h.tot != 0) {
-        int32_t c_start, c_end;
+    // One loop over the outputs this block produces (the per-output body is instantiated once):
+    //   resampling : outputs [c_start, c_end) from the ancestor counts, source = tile's owner of the output;
+    //                the last tile also takes [c_end, M): thresholds >= bins[N], for which the reference leaves
+    //                j[i] untouched (resample.jl:25-34) -> previous ancestor (identity if the last predict! did
+    //                not resample)
+    //   otherwise  : s.j .= 1:N, the tile's own particles (padding lanes included so that their weight stays -Inf)
+    const bool res = h.dr && h.tot != 0;
+    int64_t first, last;
+    int32_t c_end = 0;
+    double l = 0.0;
+    if (res) {
+        int32_t c_start;
         if (b.strategy == LLPF_RESAMPLE_SYSTEMATIC) res_counts<LLPF_RESAMPLE_SYSTEMATIC>(b, a, f, tile, h, qv, sh, c_start, c_end);
         else res_counts<LLPF_RESAMPLE_STRATIFIED>(b, a, f, tile, h, qv, sh, c_start, c_end);
-        for (int32_t o = c_start + threadIdx.x; o < c_end; o += BLOCK) {
-            const int64_t src = (int64_t)tile * TILE + res_owner(sh.cl, o);
-            anc[o] = (int32_t)src;
-            bmax = llpf_fmax(bmax, pc.one(src, o, b.log1N, bad));      // reset_weights!: w = log(1/N)
-        }
-        if (tile == b.P2 - 1) {        // thresholds >= bins[N]: the reference leaves j[i] untouched (resample.jl:25-34)
-            for (int32_t o = c_end + threadIdx.x; o < a.M; o += BLOCK) {
-                const int64_t src = anc_ident_prev ? o : anc[o];
-                anc[o] = (int32_t)src;
-                bmax = llpf_fmax(bmax, pc.one(src, o, b.log1N, bad));
-            }
-        }
+        first = c_start;
+        last = (tile == b.P2 - 1) ? (int64_t)a.M : (int64_t)c_end;
     } else {
-        // no resampling: s.j .= 1:N, every particle propagates itself; weights keep their normalised value
-        const double l = llpf_log1p_nonneg(h.s);
+        l = llpf_log1p_nonneg(h.s);
+        first = (int64_t)tile * TILE;
+        last = first + TILE;
+    }
 #pragma unroll 1
-        for (int k = 0; k < NORM_IPT; ++k) {
-            const int64_t o = (int64_t)tile * TILE + (int64_t)k * BLOCK + threadIdx.x;
-            double wprev = 0.0;
-            if (WEIGHT) wprev = (pc.w[o] - h.m) - l;                   // lazy w .-= offset ; w .-= log1p(s)
-            bmax = llpf_fmax(bmax, pc.one(o, o, wprev, bad));
+    for (int64_t o = first + threadIdx.x; o < last; o += BLOCK) {
+        int64_t src = o;
+        double wprev = b.log1N;                                        // reset_weights!: w = log(1/N)
+        if (res) {
+            if (o < c_end) src = (int64_t)tile * TILE + res_owner(sh.cl, (int32_t)o);
+            else src = anc_ident_prev ? o : (int64_t)anc[o];
+            anc[o] = (int32_t)src;
+        } else if (WEIGHT) {
+            wprev = (pc.w[o] - h.m) - l;                               // lazy w .-= offset ; w .-= log1p(s)
         }
+        bmax = llpf_fmax(bmax, pc.one(src, o, wprev, bad));
     }
     if (WEIGHT) {
         const double r = block_max(bmax, sm_max);
