@@ -3,6 +3,8 @@
 // There is deliberately NO CPU implementation behind these entry points: without a gfx950 device every
 // constructor fails with LLPF_ERR_NO_DEVICE.
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <memory>
@@ -448,6 +450,13 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
         ra.ll_steps = ll_steps ? b.d_ll_steps : nullptr;
         ra.xmean = xmean ? b.d_xmean : nullptr;
         ra.k = k;
+        static const char* dbg_env = getenv("LLPF_DEBUG_TIMING");      // developer aid: phase timestamps of timestep #dbg_env
+        uint64_t* d_dbg = nullptr;
+        if (dbg_env && k == atoll(dbg_env) && !hist) {
+            HIPC(hipMalloc(&d_dbg, sizeof(uint64_t) * 8 * b.P2));
+            HIPC(hipMemsetAsync(d_dbg, 0, sizeof(uint64_t) * 8 * b.P2, b.stream));
+            ra.dbg = d_dbg;
+        }
         if (hist) {   // forward_trajectory history (reference src/filtering.jl:357-359) needs the normalised state
                       // between correct! and predict!: split finalize and resample.  Not a timed path.
             ra.mode = RES_FINALIZE;
@@ -486,6 +495,20 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
                       // + weighting of correct!(u_{k+1}, y_{k+1}): one launch
             ProfScope ps(b, LLPF_PROF_PROPAGATE);
             HIPC(launch_resprop(d, ra, st, weight ? 1 : 0, b.stream));
+        }
+        if (d_dbg) {
+            std::vector<uint64_t> hd((size_t)8 * b.P2);
+            HIPC(hipMemcpyAsync(hd.data(), d_dbg, sizeof(uint64_t) * hd.size(), hipMemcpyDeviceToHost, b.stream));
+            HIPC(hipStreamSynchronize(b.stream));
+            FILE* fp = fopen("gpurun_out/llpf_timing.txt", "w");
+            if (fp) {
+                for (int t = 0; t < b.P2; ++t) {
+                    for (int q = 0; q < 6; ++q) fprintf(fp, "%llu ", (unsigned long long)hd[(size_t)t * 8 + q]);
+                    fprintf(fp, "\n");
+                }
+                fclose(fp);
+            }
+            hipFree(d_dbg);
         }
         b.cur ^= 1;
         b.n_predict++;

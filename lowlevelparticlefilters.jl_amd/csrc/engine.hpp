@@ -161,6 +161,7 @@ struct ResArgs {
     double* ll_steps;      // [T][F] or nullptr
     double* xmean;         // [T][F][nx] or nullptr
     int64_t k;             // step index into ll_steps / xmean
+    uint64_t* dbg;         // optional [P2][8] phase timestamps of one launch (s_memrealtime, 100 MHz), or nullptr
 };
 
 // launchers (kernels.hip)

@@ -984,10 +984,12 @@ __global__ __launch_bounds__(BLOCK) void k_resprop(BankDev b, const ModelD* __re
     ulonglong2 qv[NORM_IPT / 2];
 #pragma unroll
     for (int k = 0; k < NORM_IPT / 2; ++k) qv[k] = *reinterpret_cast<const ulonglong2*>(qsrc + ib + 2 * k);
-    const int anc_ident_prev = sc->anc_ident;          // written only at the very end of this kernel (tile 0)
-
+    const int anc_ident_prev = sc->anc_ident;          // written only at the very end of this kernel (last tile)
+#define LLPF_STAMP(i) if (a.dbg && threadIdx.x == 0 && f == 0) a.dbg[(size_t)tile * 8 + (i)] = wall_clock64()
+    LLPF_STAMP(0);
     const ResHead h = res_head<SRC_FILTER>(b, a, f, tile, sh);
     if (h.status) return;
+    LLPF_STAMP(1);
 
     Model model;
     model.prepare(md, st.u, st.t_prop);
@@ -1021,6 +1023,8 @@ __global__ __launch_bounds__(BLOCK) void k_resprop(BankDev b, const ModelD* __re
         first = (int64_t)tile * TILE;
         last = first + TILE;
     }
+    LLPF_STAMP(2);
+    if (a.dbg && threadIdx.x == 0 && f == 0) a.dbg[(size_t)tile * 8 + 5] = (uint64_t)(last - first);
 #pragma unroll 1
     for (int64_t o = first + threadIdx.x; o < last; o += BLOCK) {
         int64_t src = o;
@@ -1034,12 +1038,15 @@ __global__ __launch_bounds__(BLOCK) void k_resprop(BankDev b, const ModelD* __re
         }
         bmax = llpf_fmax(bmax, pc.one(src, o, wprev, bad));
     }
+    LLPF_STAMP(3);
     if (WEIGHT) {
         const double r = block_max(bmax, sm_max);
         const int anybad = __syncthreads_or(bad ? 1 : 0);
         if (threadIdx.x == 0) acc_max(b.acc + (size_t)f * ACC_WORDS, st.parity, r, anybad != 0);
     }
     __syncthreads();
+    LLPF_STAMP(4);
+#undef LLPF_STAMP
     if (tile == b.P2 - 1 && threadIdx.x == 0) {        // bookkeeping of this predict! (by the only block that reads anc_ident)
         const int r = (h.dr && h.tot != 0) ? 1 : 0;
         sc->anc_ident = r ? 0 : 1;
