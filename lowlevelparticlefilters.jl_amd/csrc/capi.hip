@@ -358,7 +358,7 @@ static int bank_correct(Bank& b, const double* u, const double* y, double t, dou
     a.u = b.d_uy; a.y = b.d_uy + MAXD; a.t_prop = t; a.t_meas = t; a.step = 0; a.has_y = has_y ? 1 : 0;
     a.parity = b.parity;
     HIPC(launch_step(d, MODE_WEIGHT, a, b.stream));
-    HIPC(launch_norm(d, b.parity, 0, b.stream));
+    HIPC(launch_norm(d, b.parity, 0, 1, b.n_predict, b.stream));
     ResArgs ra{};
     ra.mode = RES_FINALIZE; ra.parity = b.parity; ra.M = (int32_t)b.N;
     HIPC(launch_resample(d, ra, b.stream));
@@ -441,12 +441,12 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
         b.parity = (b.parity + 1) % ACC_NSLOT;
         {   // logsumexp! of correct!(u_k, y_k): exp-weights and their sums
             ProfScope ps(b, LLPF_PROF_NORMALISE);
-            HIPC(launch_norm(d, par, want_xm, b.stream));
+            HIPC(launch_norm(d, par, want_xm, b.cfg.resample_threshold != 1.0 ? 1 : 0, b.n_predict, b.stream));
         }
         const bool hist = x_hist || w_hist || we_hist;
         ResArgs ra{};
         ra.parity = par; ra.step = b.n_predict; ra.M = (int32_t)b.N; ra.anc_out = b.d_anc;
-        ra.accumulate = 1; ra.want_xmean = want_xm;
+        ra.accumulate = 1; ra.want_xmean = want_xm; ra.u_from_scal = 1;
         ra.ll_steps = ll_steps ? b.d_ll_steps : nullptr;
         ra.xmean = xmean ? b.d_xmean : nullptr;
         ra.k = k;
@@ -567,7 +567,7 @@ static int bank_set_weights(Bank& b, const double* w) {
     b.parity = 0;
     BankDev d = b.dev();
     HIPC(launch_max(d, b.parity, b.stream));
-    HIPC(launch_norm(d, b.parity, 0, b.stream));
+    HIPC(launch_norm(d, b.parity, 0, 1, b.n_predict, b.stream));
     ResArgs ra{};
     ra.mode = RES_FINALIZE; ra.parity = b.parity; ra.M = (int32_t)b.N; ra.keep_norm = 1;
     HIPC(launch_resample(d, ra, b.stream));
@@ -693,6 +693,7 @@ int llpf_set_weights(llpf_filter* f, const double* w) { NEEDF(f); return bank_se
 static int scal0(llpf_filter* f, FilterScal* out, bool decide) {
     Bank& b = f->bank;
     CHK(use_device(b));
+    if (decide) HIPC(launch_ess(b.dev(), b.stream));   // sum e^2 may have been skipped by the hot loop (threshold 1)
     std::vector<FilterScal> h;
     CHK(scal_download(b, h));
     *out = h[0];

@@ -100,6 +100,9 @@ struct FilterScal {
     int32_t pad0;
     int64_t resample_count;
     uint32_t k0, k1;     // Philox key of this filter
+    double u_sys;        // the uniform of the coming systematic resample (computed once per step by the normalise kernel)
+    int32_t e2_valid;    // sum e^2 / ESS were accumulated for the current weights (skipped when resample_threshold == 1)
+    int32_t pad1;
 };
 
 // arguments common to the step-path kernels
@@ -153,6 +156,7 @@ struct ResArgs {
     int32_t keep_norm;     // leave norm_pending = 0 (set_weights path: w stays as installed)
     int32_t accumulate;    // ll_total += ll
     int32_t want_xmean;
+    int32_t u_from_scal;   // systematic offset U was precomputed into scal[f].u_sys by the normalise kernel
     uint32_t step;         // Philox step of this predict!
     int32_t M;             // number of outputs
     const double* Uexp;    // explicit uniforms (1 or M) or nullptr -> Philox
@@ -169,7 +173,8 @@ hipError_t launch_init(const BankDev& b, uint32_t step, int init_anc, hipStream_
 hipError_t launch_wmean(const BankDev& b, double* out /* [F][nx] */, hipStream_t s);
 hipError_t launch_step(const BankDev& b, int mode, const StepArgs& a, hipStream_t s);
 hipError_t launch_max(const BankDev& b, int parity, hipStream_t s);           // maxima of the raw w into acc
-hipError_t launch_norm(const BankDev& b, int parity, int want_xmean, hipStream_t s);
+hipError_t launch_norm(const BankDev& b, int parity, int want_xmean, int need_e2, uint32_t step, hipStream_t s);
+hipError_t launch_ess(const BankDev& b, hipStream_t s);   // on-demand sum e^2 / ESS of the current weights (accessor path)
 hipError_t launch_post_predict(const BankDev& b, hipStream_t s);
 hipError_t launch_resample(const BankDev& b, const ResArgs& a, hipStream_t s);
 // fused finalize + resample + propagate [+ weight]: one launch for predict!(u_k) and the weighting of correct!(u_{k+1}, y_{k+1})

@@ -505,8 +505,8 @@ __global__ __launch_bounds__(BLOCK) void k_max(BankDev b, int parity) {
 // k_norm — exp-weights and their exact sums  (logsumexp! utils.jl:18-27, sum_all_but :66-71,
 // effective_particles resample.jl:1-2; optional weighted_mean filtering.jl:541-549)
 // ------------------------------------------------------------------------------------------------
-template <int NX, bool XMEAN>
-__global__ __launch_bounds__(BLOCK) void k_norm(BankDev b, int K, int parity) {
+template <int NX, bool XMEAN, bool NEED_E2>
+__global__ __launch_bounds__(BLOCK) void k_norm(BankDev b, int K, int parity, uint32_t step) {
     __shared__ uint64_t sm_u[BLOCK / 64][6];
     __shared__ double sm_x[BLOCK / 64][MAXD];
     const int f = blockIdx.y;
@@ -537,8 +537,10 @@ __global__ __launch_bounds__(BLOCK) void k_norm(BankDev b, int K, int parity) {
         bad += (e1 != e1) ? 1u : 0u;
         S = llpf_u128_add(S, llpf_fix96_unit(e0));
         S = llpf_u128_add(S, llpf_fix96_unit(e1));
-        E2 = llpf_u128_add(E2, llpf_fix96_unit(e0 * e0));
-        E2 = llpf_u128_add(E2, llpf_fix96_unit(e1 * e1));
+        if (NEED_E2) {
+            E2 = llpf_u128_add(E2, llpf_fix96_unit(e0 * e0));
+            E2 = llpf_u128_add(E2, llpf_fix96_unit(e1 * e1));
+        }
         ulonglong2 qv;
         qv.x = llpf_q64_unit(e0, K);
         qv.y = llpf_q64_unit(e1, K);
@@ -555,7 +557,7 @@ __global__ __launch_bounds__(BLOCK) void k_norm(BankDev b, int K, int parity) {
         }
     }
     S = wave_sum_u128(S);
-    E2 = wave_sum_u128(E2);
+    if (NEED_E2) E2 = wave_sum_u128(E2);
     Q = wave_sum_u64(Q);
     bad = wave_sum_u64(bad);
     if (XMEAN) {
@@ -584,7 +586,12 @@ __global__ __launch_bounds__(BLOCK) void k_norm(BankDev b, int K, int parity) {
             bd += sm_u[k][5];
         }
         acc_add_u128(acc, ACC_S(parity), s);
-        acc_add_u128(acc, ACC_E2(parity), e2);
+        if (NEED_E2) acc_add_u128(acc, ACC_E2(parity), e2);
+        if (tile == 0) {   // the single uniform a systematic resample of this step consumes (reference: rand(), resample.jl:23)
+            FilterScal* sc = b.scal + f;
+            sc->u_sys = llpf_uniform_step(step, LLPF_STREAM_RESAMPLE, sc->k0, sc->k1);
+            sc->e2_valid = NEED_E2 ? 1 : 0;
+        }
         if (bd) atomicAdd(reinterpret_cast<unsigned long long*>(acc_slot(acc, ACC_BAD(parity), blockIdx.x & (NSHARD - 1))), (unsigned long long)bd);
         b.tileq[(size_t)f * b.P2 + tile] = q;
         if (XMEAN) {
@@ -594,6 +601,32 @@ __global__ __launch_bounds__(BLOCK) void k_norm(BankDev b, int K, int parity) {
                 b.xmpart[((size_t)f * b.P2 + tile) * MAXD + d] = a;
             }
         }
+    }
+}
+
+// accessor path: sum e^2 (fixed point) and ESS of the current weights when the hot loop skipped them
+__global__ __launch_bounds__(BLOCK) void k_ess(BankDev b) {
+    __shared__ uint64_t sm_u[BLOCK / 64][2];
+    const int f = blockIdx.x;
+    FilterScal* sc = b.scal + f;
+    if (sc->uniform || sc->e2_valid || sc->status) return;
+    const double* w = b.w + (size_t)f * b.Ns;
+    const double m = sc->m;
+    llpf_u128 E2 = {0, 0};
+    for (int64_t i = threadIdx.x; i < b.N; i += BLOCK) {
+        const double e = llpf_exp_le0(w[i] - m);
+        E2 = llpf_u128_add(E2, llpf_fix96_unit(e * e));
+    }
+    E2 = wave_sum_u128(E2);
+    if ((threadIdx.x & 63) == 0) { sm_u[threadIdx.x >> 6][0] = E2.lo; sm_u[threadIdx.x >> 6][1] = E2.hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        llpf_u128 t = {sm_u[0][0], sm_u[0][1]};
+        for (int k = 1; k < BLOCK / 64; ++k) { llpf_u128 u = {sm_u[k][0], sm_u[k][1]}; t = llpf_u128_add(t, u); }
+        const double e2 = llpf_fix96_to_double(t);
+        sc->e2 = e2;
+        sc->ess = ((sc->s + 1.0) * (sc->s + 1.0)) / e2;
+        sc->e2_valid = 1;
     }
 }
 
@@ -739,7 +772,7 @@ DEV ResHead res_head(const BankDev& b, const ResArgs& a, int f, int tile, ResSha
             h.status = LLPF_ERR_DEGENERATE;
         } else {
             h.s = llpf_fix96_to_double(llpf_fix96_minus_one(s128));     // sum_all_but: exact, one rounding
-            h.e2 = llpf_fix96_to_double(e128);
+            h.e2 = sc->e2_valid ? llpf_fix96_to_double(e128) : -1.0;    // -1: not accumulated (threshold 1: not needed)
         }
         h.uniform = 0;
         h.dr = h.status ? 0 : decide_resample(b.thr, Nd, h.s, h.e2);
@@ -750,7 +783,7 @@ DEV ResHead res_head(const BankDev& b, const ResArgs& a, int f, int tile, ResSha
                 l = llpf_log1p_nonneg(h.s);
                 inv = 1.0 / (h.s + 1.0);
                 ll = l + h.m;
-                ess = ((h.s + 1.0) * (h.s + 1.0)) / h.e2;
+                ess = h.e2 > 0.0 ? ((h.s + 1.0) * (h.s + 1.0)) / h.e2 : -1.0;
             }
             sc->m = h.m; sc->s = h.s; sc->l = l; sc->inv = inv; sc->ll = ll; sc->ess = ess; sc->e2 = h.e2;
             sc->K = a.K;
@@ -842,7 +875,7 @@ DEV void res_counts(const BankDev& b, const ResArgs& a, int f, int tile, const R
     uint32_t cnt[NORM_IPT];
     if (STRATEGY == LLPF_RESAMPLE_SYSTEMATIC) {
         ThrSys th;
-        const double U = a.Uexp ? a.Uexp[0] : llpf_uniform_step(a.step, LLPF_STREAM_RESAMPLE, sc->k0, sc->k1);
+        const double U = a.Uexp ? a.Uexp[0] : (a.u_from_scal ? sc->u_sys : llpf_uniform_step(a.step, LLPF_STREAM_RESAMPLE, sc->k0, sc->k1));
         th.M = M; th.Md = (double)M; th.step = 1.0 / (double)M;
         th.delta = 1e-9 + th.Md * 1e-13;
         th.r = U * binsN / (double)N;                  // r = rand()*bins[end]/N  (resample.jl:23)
@@ -1251,17 +1284,26 @@ hipError_t launch_max(const BankDev& b, int parity, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_norm(const BankDev& b, int parity, int want_xmean, hipStream_t s) {
+template <int NX, bool XMEAN>
+static void launch_norm_e2(const BankDev& b, int parity, int need_e2, uint32_t step, hipStream_t s) {
     dim3 g((unsigned)b.P2, (unsigned)b.F, 1);
     const int K = llpf_qbits(b.N);
-    if (!want_xmean) { hipLaunchKernelGGL((k_norm<0, false>), g, dim3(BLOCK), 0, s, b, K, parity); return hipGetLastError(); }
+    if (need_e2) hipLaunchKernelGGL((k_norm<NX, XMEAN, true>), g, dim3(BLOCK), 0, s, b, K, parity, step);
+    else hipLaunchKernelGGL((k_norm<NX, XMEAN, false>), g, dim3(BLOCK), 0, s, b, K, parity, step);
+}
+hipError_t launch_norm(const BankDev& b, int parity, int want_xmean, int need_e2, uint32_t step, hipStream_t s) {
+    if (!want_xmean) { launch_norm_e2<0, false>(b, parity, need_e2, step, s); return hipGetLastError(); }
     switch (b.nx) {
-        case 1: hipLaunchKernelGGL((k_norm<1, true>), g, dim3(BLOCK), 0, s, b, K, parity); break;
-        case 2: hipLaunchKernelGGL((k_norm<2, true>), g, dim3(BLOCK), 0, s, b, K, parity); break;
-        case 3: hipLaunchKernelGGL((k_norm<3, true>), g, dim3(BLOCK), 0, s, b, K, parity); break;
-        case 4: hipLaunchKernelGGL((k_norm<4, true>), g, dim3(BLOCK), 0, s, b, K, parity); break;
+        case 1: launch_norm_e2<1, true>(b, parity, need_e2, step, s); break;
+        case 2: launch_norm_e2<2, true>(b, parity, need_e2, step, s); break;
+        case 3: launch_norm_e2<3, true>(b, parity, need_e2, step, s); break;
+        case 4: launch_norm_e2<4, true>(b, parity, need_e2, step, s); break;
         default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+hipError_t launch_ess(const BankDev& b, hipStream_t s) {
+    hipLaunchKernelGGL(k_ess, dim3((unsigned)b.F), dim3(BLOCK), 0, s, b);
     return hipGetLastError();
 }
 
