@@ -136,16 +136,19 @@ def main():
         nx = model.nx
         value = world * args.steps * N * T / dt
         ms_cls, n_cls = prof
-        names = ["k_resprop(finalize+resample+propagate+weight)", "k_norm(exp-weights, sums, quanta)", "k_resample(standalone)", "other"]
+        fused = not n_cls[2]                      # no standalone resample launches => the fused k_resprop ran
+        names = ["k_resprop(finalize+resample+propagate+weight)" if fused else "k_step(propagate+weight)",
+                 "k_norm(exp-weights, sums, quanta)", "k_resample(finalize+scan+counts+ancestors)", "other"]
         kernel_us = {names[i]: (1e3 * ms_cls[i] / n_cls[i] if n_cls[i] else None) for i in range(4)}
-        # dominant kernel: the fused k_resprop.  Algorithmic bytes per particle of a resampling timestep:
-        # read quanta 8 + read x[anc] 8nx + write x 8nx + write ancestor 4 + write w 8
-        b_step = 16 * nx + 20
+        # dominant kernel and its algorithmic bytes per particle of a resampling timestep:
+        #   fused k_resprop: read quanta 8 + read x[anc] 8nx + write x 8nx + write ancestor 4 + write w 8
+        #   k_step         : read ancestor 4 + read x[anc] 8nx + write x 8nx + write w 8
+        b_step = 16 * nx + (20 if fused else 12)
         step_s = ms_cls[0] / n_cls[0] * 1e-3
         achieved = N * b_step / step_s / 1e9
         b_alg = 16 * nx + 40                         # whole-timestep algorithmic bytes
         timestep_s = dt / (args.steps * T)
-        roof = {"bound": "hbm", "kernel": "k_resprop", "achieved": achieved, "peak": 8000.0,
+        roof = {"bound": "hbm", "kernel": "k_resprop" if fused else "k_step<MODE_PROP_WEIGHT>", "achieved": achieved, "peak": 8000.0,
                 "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
                 "bytes_per_launch": N * b_step, "avg_launch_us": step_s * 1e6,
                 "method": "hipEvent pairs around every launch on the engine stream, %d profiled passes after the timed region (each pair adds ~2-3 us to the launch it brackets)" % max(1, min(args.steps, 3)),

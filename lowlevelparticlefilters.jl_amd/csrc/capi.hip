@@ -444,6 +444,15 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
             HIPC(launch_norm(d, par, want_xm, b.cfg.resample_threshold != 1.0 ? 1 : 0, b.n_predict, b.stream));
         }
         const bool hist = x_hist || w_hist || we_hist;
+        // Fused (one launch: finalize + resample + propagate + weight, a block propagates the outputs of its own
+        // source tile) or balanced two-launch form (ancestors to HBM, then a uniform propagate).  The fused form saves
+        // a launch and the ancestor round trip but its propagate work follows the weight distribution; models whose
+        // dynamics dominate the timestep (quad-tank RK4: 32 fp64 sqrt per particle) and whose ESS is small run faster
+        // balanced (measured: 72.6 vs 121 us per timestep at N = 1e6), the linear-Gaussian model faster fused
+        // (31.1 vs 33.5 us).  LLPF_UNFUSED=0/1 overrides for experiments.
+        static const char* unf_env = getenv("LLPF_UNFUSED");
+        const bool heavy_dynamics = b.cfg.model.model_id == LLPF_MODEL_QUADTANK_RK4;
+        const bool unfused = hist || (unf_env ? atoi(unf_env) != 0 : heavy_dynamics);
         ResArgs ra{};
         ra.parity = par; ra.step = b.n_predict; ra.M = (int32_t)b.N; ra.anc_out = b.d_anc;
         ra.accumulate = 1; ra.want_xmean = want_xm; ra.u_from_scal = 1;
@@ -488,7 +497,12 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
         const bool weight = (k + 1 < T);
         if (weight) { st.y = b.d_Y + (k + 1) * b.ny; st.t_meas = tk(k + 1); st.has_y = has_y(k + 1) ? 1 : 0; }
         else { st.y = nullptr; st.t_meas = tk(k); st.has_y = 0; }
-        if (hist) {   // unfused: the state between correct! and predict! was exposed above
+        if (!hist && unfused) {   // balanced two-launch form: ancestors to HBM, then a uniform propagate
+            ra.mode = RES_FINALIZE | RES_RESAMPLE;
+            ProfScope ps(b, LLPF_PROF_RESAMPLE);
+            HIPC(launch_resample(d, ra, b.stream));
+        }
+        if (unfused) {
             ProfScope ps(b, LLPF_PROF_PROPAGATE);
             HIPC(launch_step(d, weight ? MODE_PROP_WEIGHT : MODE_PROP, st, b.stream));
         } else {      // scalars of correct!(u_k, y_k) + shouldresample + resample + propagate of predict!(u_k)
