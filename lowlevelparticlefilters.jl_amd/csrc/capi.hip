@@ -459,6 +459,8 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
         ra.ll_steps = ll_steps ? b.d_ll_steps : nullptr;
         ra.xmean = xmean ? b.d_xmean : nullptr;
         ra.k = k;
+        static const char* abl_env = getenv("LLPF_ABLATE");
+        ra.ablate = abl_env ? atoi(abl_env) : 0;
         static const char* dbg_env = getenv("LLPF_DEBUG_TIMING");      // developer aid: phase timestamps of timestep #dbg_env
         uint64_t* d_dbg = nullptr;
         if (dbg_env && k == atoll(dbg_env) && !hist) {

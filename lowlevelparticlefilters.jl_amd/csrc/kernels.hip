@@ -972,14 +972,22 @@ struct PropCtx {
     double* __restrict__ xn;
     double* w;
     uint32_t k0, k1;
+    int ablate;
     // propagate output o from source src with previous log-weight wprev; returns the new log-weight
     DEV double one(int64_t src, int64_t o, double wprev, bool& bad) const {
         const int64_t Ns = b.Ns;
         double xp[NX], fx[NX], xi[NX], nz[NX], xs[NX];
 #pragma unroll
         for (int d = 0; d < NX; ++d) xp[d] = xc[(size_t)d * Ns + src];
+#ifdef LLPF_DEVTOOLS   /* ablation switches for performance experiments (results invalid); not in production builds */
+        if (!(ablate & 4)) model.dynamics(xp, fx);
+        else { for (int d = 0; d < NX; ++d) fx[d] = xp[d]; }
+        if (!(ablate & 1)) llpf_normals((uint32_t)o, st.step, LLPF_STREAM_DYNAMICS, k0, k1, NX, xi);
+        else { for (int d = 0; d < NX; ++d) xi[d] = 0.25 * (double)(o & 7); }
+#else
         model.dynamics(xp, fx);
         llpf_normals((uint32_t)o, st.step, LLPF_STREAM_DYNAMICS, k0, k1, NX, xi);
+#endif
         gauss_sample<NX>(md->df, xi, nz);
 #pragma unroll
         for (int d = 0; d < NX; ++d) {
@@ -988,7 +996,11 @@ struct PropCtx {
         }
         double wv = wprev;
         if (WEIGHT) {
+#ifdef LLPF_DEVTOOLS
+            if (st.has_y && !(ablate & 4)) {
+#else
             if (st.has_y) {
+#endif
                 double g[NY], v[NY];
                 model.measurement(xs, g);
 #pragma unroll
@@ -1030,7 +1042,7 @@ __global__ __launch_bounds__(BLOCK) void k_resprop(BankDev b, const ModelD* __re
 #pragma unroll
     for (int k = 0; k < NY; ++k) y[k] = (WEIGHT && st.has_y) ? st.y[k] : 0.0;
     PropCtx<Model, NX, NY, WEIGHT> pc{b, model, md, st, y, b.xcur + (size_t)f * NX * Ns, b.xnext + (size_t)f * NX * Ns,
-                                      b.w + (size_t)f * Ns, sc->k0, sc->k1};
+                                      b.w + (size_t)f * Ns, sc->k0, sc->k1, a.ablate};
     int32_t* anc = b.anc + (size_t)f * Ns;
     double bmax = -LLPF_INF;
     bool bad = false;
@@ -1063,7 +1075,11 @@ __global__ __launch_bounds__(BLOCK) void k_resprop(BankDev b, const ModelD* __re
         int64_t src = o;
         double wprev = b.log1N;                                        // reset_weights!: w = log(1/N)
         if (res) {
+#ifdef LLPF_DEVTOOLS
+            if (o < c_end) src = (int64_t)tile * TILE + ((a.ablate & 2) ? (int)((o - first) & (TILE - 1)) : res_owner(sh.cl, (int32_t)o));
+#else
             if (o < c_end) src = (int64_t)tile * TILE + res_owner(sh.cl, (int32_t)o);
+#endif
             else src = anc_ident_prev ? o : (int64_t)anc[o];
             anc[o] = (int32_t)src;
         } else if (WEIGHT) {
