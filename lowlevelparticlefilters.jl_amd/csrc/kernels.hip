@@ -1220,6 +1220,9 @@ __global__ void k_selftest_math(int which, const double* __restrict__ in, double
         case 6: r = 1.0 / x; break;
         case 7: r = (double)llpf_d2u(x); break;
         case 8: r = llpf_exp_le0(x); break;
+        case 9: r = llpf_log_unit(x); break;
+        case 10: llpf_sincos2pi_fast(x, &s, &c); r = s; break;
+        case 11: llpf_sincos2pi_fast(x, &s, &c); r = c; break;
         default: r = 0.0;
     }
     out[i] = r;

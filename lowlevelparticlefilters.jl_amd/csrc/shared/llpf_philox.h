@@ -15,6 +15,7 @@
 #define LLPF_PHILOX_H
 
 #include "llpf_detmath.h"
+#include "llpf_rngmath.h"
 
 enum {
     LLPF_STREAM_INIT     = 0,   /* reset!: x0 ~ d0                      (filtering.jl:4-14)   */
@@ -63,9 +64,9 @@ LLPF_HD void llpf_normal_pair(uint32_t idx, uint32_t step, uint32_t sub, uint32_
     llpf_philox4 r = llpf_philox4x32_10(idx, step, sub, stream, k0, k1);
     double u1 = llpf_u01_open(r.v[0], r.v[1]);
     double u2 = llpf_u01_half(r.v[2], r.v[3]);
-    double rad = llpf_sqrt(-2.0 * llpf_log(u1));
+    double rad = llpf_sqrt(-2.0 * llpf_log_unit(u1));
     double sn, cs;
-    llpf_sincos2pi(u2, &sn, &cs);
+    llpf_sincos2pi_fast(u2, &sn, &cs);
     *z0 = rad * cs;
     *z1 = rad * sn;
 }

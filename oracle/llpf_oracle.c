@@ -871,6 +871,9 @@ void orc_math_vec(int which, const double* in, double* out, int64_t n) {
             case 6: out[i] = 1.0 / x; break;
             case 7: out[i] = (double)llpf_d2u(x); break;
             case 8: out[i] = llpf_exp_le0(x); break;
+            case 9: out[i] = llpf_log_unit(x); break;
+            case 10: llpf_sincos2pi_fast(x, &s, &c); out[i] = s; break;
+            case 11: llpf_sincos2pi_fast(x, &s, &c); out[i] = c; break;
             default: out[i] = NAN;
         }
     }

@@ -63,6 +63,24 @@ def test_sincos2pi_accuracy():
     np.testing.assert_allclose(s * s + c * c, 1.0, rtol=0, atol=4e-16)
 
 
+def test_rng_fast_log_and_sincos():
+    """Table-driven forms used only inside the Box-Muller transform (llpf_rngmath.h)."""
+    rng = np.random.default_rng(7)
+    u = np.concatenate([(rng.integers(0, 2 ** 53, 400000) + 1) * 2.0 ** -53, 1 - rng.uniform(0, 1e-6, 50000),
+                        rng.uniform(0.7, 1, 200000), [1.0, 2.0 ** -53, 0.75, 0.5, 1 - 2.0 ** -53]])
+    l = ob.math_vec(9, u)
+    ref = np.log(u.astype(LD))
+    assert np.all(l <= 0) and ob.math_vec(9, np.array([1.0]))[0] == 0.0
+    assert np.all(np.abs(l.astype(LD) - ref) <= LD(1.2e-16) + 2 * np.spacing(np.abs(l)).astype(LD))
+    near1 = np.abs(u - 1) < 1 / 130
+    assert _ulp_err(l[near1 & (l != 0)], ref[near1 & (l != 0)]) < 2.0          # exact-relative around u = 1
+    uu = np.concatenate([rng.uniform(0, 1, 400000), [0, 0.25, 0.5, 0.75, 1 / 64, 0.5 - 2 ** -54]])
+    s, c = ob.math_vec(10, uu), ob.math_vec(11, uu)
+    a = uu.astype(LD) * LD(2) * LD("3.14159265358979323846264338327950288")
+    assert np.max(np.abs(s.astype(LD) - np.sin(a))) < 2e-16 and np.max(np.abs(c.astype(LD) - np.cos(a))) < 2e-16
+    assert s[-6] == 0.0 and c[-6] == 1.0 and s[-5] == 1.0 and c[-4] == -1.0 and s[-3] == -1.0
+
+
 def test_philox_known_answers():
     """Random123 kat_vectors, philox4x32 with 10 rounds."""
     L = ob.lib()

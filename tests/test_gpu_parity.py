@@ -38,6 +38,9 @@ def test_device_math_bit_identical_to_host():
         6: 10.0 ** rng.uniform(-300, 300, 100000) * rng.choice([-1.0, 1.0], 100000),
         7: rng.uniform(0, 1, 100000) * 10.0 ** rng.uniform(-5, 5, 100000),
         8: np.concatenate([rng.uniform(-760, 0, 200000), [0.0, -745.2, -746.0, -1e9, -np.inf]]),
+        9: np.concatenate([(rng.integers(0, 2 ** 53, 200000) + 1) * 2.0 ** -53, [1.0, 2.0 ** -53, 0.75]]),
+        10: rng.uniform(0, 1, 200000),
+        11: rng.uniform(0, 1, 200000),
     }
     for which, x in cases.items():
         host = ob.math_vec(which, x)
