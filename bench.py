@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--workload", default="lg", choices=["lg", "quadtank"])
     ap.add_argument("--particles", type=int, default=1000000)
     ap.add_argument("--T", type=int, default=None)
+    ap.add_argument("--threshold", type=float, default=None, help="resample_threshold override")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=None, help="timesteps of the CPU baseline sample")
     args = ap.parse_args()
@@ -86,6 +87,9 @@ def main():
     from llpf_amd import _capi, _structs as S
     T = args.T if args.T else (1000 if args.workload == "lg" else 2000)
     model, U, Y, kind, thr, label = build_workload(args.workload, args.particles, T)
+    if args.threshold is not None:
+        thr = args.threshold
+        label += " [resample_threshold overridden to %g]" % thr
     N = args.particles
     cfg = S.make_config(model, N, kind, S.RESAMPLE_SYSTEMATIC, thr, 1000 + rank, dev)
     pf = _capi.FilterHandle(cfg)
@@ -154,6 +158,15 @@ def main():
                 "method": "hipEvent pairs around every launch on the engine stream, %d profiled passes after the timed region (each pair adds ~2-3 us to the launch it brackets)" % max(1, min(args.steps, 3)),
                 "whole_timestep": {"algorithmic_bytes": N * b_alg, "us": timestep_s * 1e6,
                                    "achieved": N * b_alg / timestep_s / 1e9, "frac": N * b_alg / timestep_s / 8e12}}
+        # HBM traffic of the dominant kernel from the committed PMC profile of this same workload (cannot be collected
+        # inside bench.py: rocprofv3 --pmc needs its own passes); only quoted when shapes match
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01c_pmc_traffic.json")))
+            if fused and pm["n_particles"] == N and pm["nx"] == nx and args.workload == "lg":
+                roof["traffic"] = pm["k_resprop"]["bytes"]
+                roof["traffic_source"] = pm["source"] + "; " + pm["correction"]
+        except Exception:
+            pass
         out = {"metric": "particle-steps/s", "value": value, "unit": "particle-steps/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
