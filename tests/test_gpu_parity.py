@@ -381,3 +381,99 @@ def test_python_api_mirror_smoke():
     j = llpf_amd.resample(pf)
     assert j.shape == (1000,) and j.min() >= 0 and j.max() < 1000
     assert abs(llpf_amd.effective_particles(np.full(10, 0.1)) - 10) < 1e-9
+
+
+def test_full_size_properties_c2():
+    """BASELINE config C2 at full size (N = 1e6, T = 1000): size-independent properties instead of an oracle run.
+    Reproducibility (same key -> same bits), normalisation, sorted in-range ancestors, and the particle filter's
+    log-likelihood against the closed-form Kalman value (Monte-Carlo error ~ sqrt(T/N))."""
+    model = M.lg_test_model()
+    _, U, Y = M.simulate_lg(model, 1000, seed=1)
+    N = 1000000
+    lls = []
+    for rep in range(2):
+        g = _capi.FilterHandle(_cfg(model, N, thr=1.0, seed=2024))
+        g.reset()
+        r = g.run(U, Y, 1.0, ll_steps=True)
+        lls.append(r["ll_steps"].copy())
+        if rep == 0:
+            we = g.expweights()
+            assert abs(we.sum() - 1.0) < 1e-12 and np.all(we == we[0])        # last predict! resampled: uniform
+            j = g.ancestors()
+            assert j.min() >= 0 and j.max() < N and np.all(np.diff(j) >= 0)
+            assert g.resample_count() == 1000 and g.index() == 1001
+            x = g.particles()
+            assert np.all(np.isfinite(x))
+    assert np.array_equal(lls[0].view(np.uint64), lls[1].view(np.uint64))
+    kf = ob.kalman_loglik(model, U, Y)
+    assert abs(lls[0].sum() - kf) < 0.5, (lls[0].sum(), kf)
+    # a different key gives a different (but statistically equivalent) answer
+    g = _capi.FilterHandle(_cfg(model, N, thr=1.0, seed=2025))
+    g.reset()
+    ll2 = g.run(U, Y, 1.0)["ll"]
+    assert ll2 != lls[0].sum() and abs(ll2 - kf) < 0.5
+
+
+def test_full_size_properties_c3_quadtank():
+    """BASELINE config C3 model at N = 1e6 (T = 300 across the t > 500 switch): finite, reproducible, every step
+    resamples (ESS << N), weights normalised after a correct!."""
+    model = M.quadtank_model()
+    U, Y = M.quadtank_data(300)
+    cfg = _cfg(model, 1000000, thr=0.5, kind=S.ADVANCED_PARTICLE_FILTER, seed=5)
+    g = _capi.FilterHandle(cfg)
+    g.reset()
+    r1 = g.run(U, Y, 350.0, ll_steps=True, xmean=True)
+    assert np.all(np.isfinite(r1["ll_steps"])) and np.all(np.isfinite(r1["xmean"]))
+    assert g.resample_count() == 300
+    ll = g.correct(U[0], Y[0], 650.0)
+    we = g.expweights()
+    assert np.isfinite(ll) and abs(we.sum() - 1.0) < 1e-12 and g.ess() < 0.05 * 1000000
+    g2 = _capi.FilterHandle(cfg)
+    g2.reset()
+    r2 = g2.run(U, Y, 350.0, ll_steps=True)
+    assert np.array_equal(r1["ll_steps"].view(np.uint64), r2["ll_steps"].view(np.uint64))
+    # tracks the simulated tank levels: posterior mean of the measured states close to the measurements
+    assert np.max(np.abs(r1["xmean"][50:, :2] - Y[50:])) < 0.1
+
+
+def test_invalid_run_arguments():
+    model = M.lg_test_model()
+    g = _capi.FilterHandle(_cfg(model, 100))
+    with pytest.raises(_capi.LLPFError):
+        g.run(np.zeros((0, 1)), np.zeros((0, 1)), 0.0)           # empty trajectory
+    cfg = _cfg(S.make_lg_model(np.eye(5) * 0.5, None, np.eye(5), S.make_gaussian(np.zeros(5), 1.0),
+                               S.make_gaussian(np.zeros(5), 1.0), S.make_gaussian(np.zeros(5), 1.0)), 100)
+    with pytest.raises(_capi.LLPFError):
+        _capi.FilterHandle(cfg)                                  # nx = 5: no kernel instantiated
+
+
+def test_bank_shares_of_a_sharded_sweep_match_single_bank():
+    """The 8-GPU sharding of config C4 in miniature: banks built from round-robin shards of a sweep (what each rank
+    runs, lowlevelparticlefilters.jl_amd/distributed.py) reproduce the log-likelihoods of the whole bank."""
+    from llpf_amd import distributed as D
+    svec = 10.0 ** np.linspace(-2, 0, 12)
+    models = [M.lg_test_model(s) for s in svec]
+    _, U, Y = M.simulate_lg(models[5], 60)
+    N = 5000
+
+    class Bank:
+        def __init__(self, ms, owned):
+            # a shard keeps the global filter index in its Philox key: one single-filter bank per owned filter
+            self.h = [_capi.BankHandle(_cfg(m, N, thr=0.1, seed=300 + k), [m]) for m, k in zip(ms, owned)]
+
+        def reset(self):
+            for h in self.h:
+                h.reset()
+
+        def run(self, U, Y, t0):
+            return {"ll": np.array([h.run(U, Y, t0)["ll"][0] for h in self.h])}
+    whole = _capi.BankHandle(_cfg(models[0], N, thr=0.1, seed=300), models)
+    whole.reset()
+    ll_whole = whole.run(U, Y, 1.0)["ll"]
+    got = np.zeros(12)
+    for rank in range(4):
+        own = D.shard_indices(12, rank, 4)
+        b = Bank([models[k] for k in own], own)
+        b.reset()
+        got[own] = b.run(U, Y, 1.0)["ll"]
+    assert np.array_equal(got, ll_whole)
