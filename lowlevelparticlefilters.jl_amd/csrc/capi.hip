@@ -128,8 +128,10 @@ struct Bank {
     double* d_w = nullptr;
     int32_t* d_anc = nullptr;
     uint64_t* d_acc = nullptr;
-    uint64_t* d_quanta = nullptr;
+    uint64_t* d_quanta[2] = {nullptr, nullptr};
+    int qcur = 0;                    // quanta buffer that holds the quanta of the current weights
     uint64_t* d_tileq = nullptr;
+    uint32_t* d_flag = nullptr;
     double* d_xmpart = nullptr;
     int parity = 0;                  // accumulator slot (0..2) the NEXT weighting kernel writes (engine.hpp ACC_NSLOT)
     double* d_uy = nullptr;          // staging for single-step u / y (2 * MAXD)
@@ -165,7 +167,8 @@ struct Bank {
         b.mlogN = -llpf_log((double)N);
         b.models = d_models; b.scal = d_scal;
         b.xcur = d_x[cur]; b.xnext = d_x[cur ^ 1];
-        b.w = d_w; b.anc = d_anc; b.acc = d_acc; b.quanta = d_quanta; b.tileq = d_tileq; b.xmpart = d_xmpart;
+        b.w = d_w; b.anc = d_anc; b.acc = d_acc; b.quanta = d_quanta[qcur]; b.quanta_next = d_quanta[qcur ^ 1]; b.tileq = d_tileq;
+        b.bank_flag = d_flag; b.xmpart = d_xmpart;
         return b;
     }
 };
@@ -182,7 +185,7 @@ static void free_bank(Bank& b) {
     hipSetDevice(b.device);
     if (b.stream) hipStreamSynchronize(b.stream);
     hipFree(b.d_models); hipFree(b.d_scal); hipFree(b.d_x[0]); hipFree(b.d_x[1]); hipFree(b.d_w);
-    hipFree(b.d_anc); hipFree(b.d_acc); hipFree(b.d_quanta); hipFree(b.d_tileq); hipFree(b.d_xmpart); hipFree(b.d_uy); hipFree(b.d_U); hipFree(b.d_Y);
+    hipFree(b.d_anc); hipFree(b.d_acc); hipFree(b.d_quanta[0]); hipFree(b.d_quanta[1]); hipFree(b.d_tileq); hipFree(b.d_flag); hipFree(b.d_xmpart); hipFree(b.d_uy); hipFree(b.d_U); hipFree(b.d_Y);
     hipFree(b.d_ll_steps); hipFree(b.d_xmean); hipFree(b.d_tmp);
     for (auto e : b.ev_pool) hipEventDestroy(e);
     for (auto& e : b.pending) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
@@ -258,11 +261,14 @@ static int bank_init_particles(Bank& b, bool is_reset) {
         s.status = 0;
         s.m = 0.0; s.s = 0.0; s.l = 0.0; s.inv = 1.0; s.ll = 0.0; s.e2 = 0.0;
         s.ess = 0.0;
+        s.stot = 1.0; s.mtrue = 0.0; s.wmax = s.wconst; s.off_next = 0.0; s.fast = 0; s.fallback = 0; s.fb_step = 0; s.e2_valid = 0;
         s.K = llpf_qbits(b.N);
         if (!is_reset) { s.anc_ident = 1; s.last_resampled = 0; s.resample_count = 0; s.ll_total = 0.0; }
     }
     CHK(scal_upload(b, h));
     HIPC(hipMemsetAsync(b.d_acc, 0, sizeof(uint64_t) * (size_t)b.F * ACC_WORDS, b.stream));
+    HIPC(hipMemsetAsync(b.d_tileq, 0, sizeof(uint64_t) * (size_t)ACC_NSLOT * b.F * b.P2, b.stream));
+    HIPC(hipMemsetAsync(b.d_flag, 0, sizeof(uint32_t) * 4, b.stream));
     b.parity = 0;
     HIPC(launch_init(d, b.n_reset, is_reset ? 0 : 1, b.stream));
     b.n_reset++;
@@ -315,9 +321,11 @@ static int bank_create(const llpf_config* cfg, const llpf_model* models, int F, 
     HIPC(hipMalloc(&b.d_w, sizeof(double) * FN));
     HIPC(hipMalloc(&b.d_anc, sizeof(int32_t) * FN));
     HIPC(hipMalloc(&b.d_acc, sizeof(uint64_t) * (size_t)F * ACC_WORDS));
-    HIPC(hipMalloc(&b.d_quanta, sizeof(uint64_t) * FN));
-    HIPC(hipMalloc(&b.d_tileq, sizeof(uint64_t) * (size_t)F * b.P2));
-    HIPC(hipMalloc(&b.d_xmpart, sizeof(double) * (size_t)F * b.P2 * MAXD));
+    HIPC(hipMalloc(&b.d_quanta[0], sizeof(uint64_t) * FN));
+    HIPC(hipMalloc(&b.d_quanta[1], sizeof(uint64_t) * FN));
+    HIPC(hipMalloc(&b.d_tileq, sizeof(uint64_t) * (size_t)ACC_NSLOT * F * b.P2));
+    HIPC(hipMalloc(&b.d_flag, sizeof(uint32_t) * 4));
+    HIPC(hipMalloc(&b.d_xmpart, sizeof(double) * (size_t)F * b.P1 * MAXD));
     HIPC(hipMalloc(&b.d_uy, sizeof(double) * 4 * MAXD));
     HIPC(hipMalloc(&b.d_tmp, sizeof(double) * (size_t)F * b.N * (b.nx > 1 ? b.nx : 1) + 64));
     HIPC(hipMemsetAsync(b.d_x[0], 0, sizeof(double) * FN * b.nx, b.stream));
@@ -325,9 +333,11 @@ static int bank_create(const llpf_config* cfg, const llpf_model* models, int F, 
     HIPC(hipMemsetAsync(b.d_anc, 0, sizeof(int32_t) * FN, b.stream));
     HIPC(hipMemsetAsync(b.d_scal, 0, sizeof(FilterScal) * F, b.stream));
     HIPC(hipMemsetAsync(b.d_acc, 0, sizeof(uint64_t) * (size_t)F * ACC_WORDS, b.stream));
-    HIPC(hipMemsetAsync(b.d_quanta, 0, sizeof(uint64_t) * FN, b.stream));
-    HIPC(hipMemsetAsync(b.d_tileq, 0, sizeof(uint64_t) * (size_t)F * b.P2, b.stream));
-    HIPC(hipMemsetAsync(b.d_xmpart, 0, sizeof(double) * (size_t)F * b.P2 * MAXD, b.stream));
+    HIPC(hipMemsetAsync(b.d_quanta[0], 0, sizeof(uint64_t) * FN, b.stream));
+    HIPC(hipMemsetAsync(b.d_quanta[1], 0, sizeof(uint64_t) * FN, b.stream));
+    HIPC(hipMemsetAsync(b.d_tileq, 0, sizeof(uint64_t) * (size_t)ACC_NSLOT * F * b.P2, b.stream));
+    HIPC(hipMemsetAsync(b.d_flag, 0, sizeof(uint32_t) * 4, b.stream));
+    HIPC(hipMemsetAsync(b.d_xmpart, 0, sizeof(double) * (size_t)F * b.P1 * MAXD, b.stream));
     HIPC(hipMemcpyAsync(b.d_models, hm.data(), sizeof(ModelD) * F, hipMemcpyHostToDevice, b.stream));
     HIPC(hipStreamSynchronize(b.stream));
     HIPC(hipEventCreate(&b.ev_run0));
@@ -345,6 +355,42 @@ static int check_status(Bank& b, std::vector<FilterScal>& h) {
     return LLPF_OK;
 }
 
+// ---- exact-form redo of a normalisation whose bound test failed ------------------------------------------------
+// zero the exp-sum words of accumulator slot `slot` for the filters in `fl`
+static int clear_slot_sums(Bank& b, int slot, const std::vector<int>& fl) {
+    for (int f : fl) {
+        uint64_t* acc = b.d_acc + (size_t)f * ACC_WORDS;
+        const int words[3] = {ACC_S(slot), ACC_E2(slot), ACC_BAD(slot)};
+        const int nw[3] = {3, 3, 1};
+        for (int q = 0; q < 3; ++q)
+            HIPC(hipMemsetAsync(acc + (size_t)words[q] * NSHARD * ACC_STRIDE, 0, sizeof(uint64_t) * nw[q] * NSHARD * ACC_STRIDE, b.stream));
+    }
+    return LLPF_OK;
+}
+// which filters asked for the exact form (and at which run-step); clears nothing
+static int poll_fallback(Bank& b, std::vector<int>& fl, int64_t& kf) {
+    uint32_t flag = 0;
+    HIPC(hipMemcpyAsync(&flag, b.d_flag, sizeof(flag), hipMemcpyDeviceToHost, b.stream));
+    HIPC(hipStreamSynchronize(b.stream));
+    fl.clear();
+    kf = -1;
+    if (!flag) return LLPF_OK;
+    kf = (int64_t)flag - 1;
+    std::vector<FilterScal> h;
+    CHK(scal_download(b, h));
+    for (int f = 0; f < b.F; ++f) if (h[f].fallback) fl.push_back(f);
+    return LLPF_OK;
+}
+static int clear_fallback(Bank& b, const std::vector<int>& fl) {
+    std::vector<FilterScal> h;
+    CHK(scal_download(b, h));
+    for (int f : fl) h[f].fallback = 0;
+    CHK(scal_upload(b, h));
+    HIPC(hipMemsetAsync(b.d_flag, 0, sizeof(uint32_t) * 4, b.stream));
+    return LLPF_OK;
+}
+static int need_e2(const Bank& b) { return b.cfg.resample_threshold != 1.0 ? 1 : 0; }
+
 // ---- single steps -------------------------------------------------------------------------------
 static int bank_correct(Bank& b, const double* u, const double* y, double t, double* ll_out /* [F] */) {
     CHK(use_device(b));
@@ -353,16 +399,30 @@ static int bank_correct(Bank& b, const double* u, const double* y, double t, dou
     if (u) for (int i = 0; i < b.nu; ++i) hbuf[i] = u[i];
     if (has_y) for (int i = 0; i < b.ny; ++i) hbuf[MAXD + i] = y[i];
     HIPC(hipMemcpyAsync(b.d_uy, hbuf, sizeof(hbuf), hipMemcpyHostToDevice, b.stream));
-    BankDev d = b.dev();
-    StepArgs a{};
-    a.u = b.d_uy; a.y = b.d_uy + MAXD; a.t_prop = t; a.t_meas = t; a.step = 0; a.has_y = has_y ? 1 : 0;
-    a.parity = b.parity;
-    HIPC(launch_step(d, MODE_WEIGHT, a, b.stream));
-    HIPC(launch_norm(d, b.parity, 0, 1, b.n_predict, b.stream));
-    ResArgs ra{};
-    ra.mode = RES_FINALIZE; ra.parity = b.parity; ra.M = (int32_t)b.N;
-    HIPC(launch_resample(d, ra, b.stream));
+    const int slot = b.parity;
+    {
+        BankDev d = b.dev();
+        StepArgs a{};
+        a.u = b.d_uy; a.y = b.d_uy + MAXD; a.t_prop = t; a.t_meas = t; a.step = 0; a.has_y = has_y ? 1 : 0;
+        a.parity = slot; a.need_e2 = 1; a.K = llpf_qbits(b.N); a.k = 0; a.next_step = b.n_predict; a.accumulate = 1;
+        HIPC(launch_step(d, MODE_WEIGHT, a, b.stream));     // weights + exp-sums against the bound + quanta
+    }
+    b.qcur ^= 1;
     b.parity = (b.parity + 1) % ACC_NSLOT;
+    BankDev d = b.dev();
+    ResArgs ra{};
+    ra.mode = RES_FINALIZE; ra.parity = slot; ra.M = (int32_t)b.N; ra.fast_head = 1; ra.k = 0;
+    HIPC(launch_resample(d, ra, b.stream));
+    std::vector<int> fl;
+    int64_t kf;
+    CHK(poll_fallback(b, fl, kf));
+    if (!fl.empty()) {   // bound test failed: exact-max normalisation of the same weights
+        CHK(clear_slot_sums(b, slot, fl));
+        HIPC(launch_norm(d, slot, 0, 1, b.n_predict, 1, 0, 0, b.stream));
+        ra.fast_head = 0; ra.only_fallback = 1;
+        HIPC(launch_resample(d, ra, b.stream));
+        CHK(clear_fallback(b, fl));
+    }
     std::vector<FilterScal> h;
     CHK(scal_download(b, h));
     if (ll_out) for (int f = 0; f < b.F; ++f) ll_out[f] = h[f].ll;
@@ -376,10 +436,12 @@ static int bank_predict(Bank& b, const double* u, double t) {
     HIPC(hipMemcpyAsync(b.d_uy, hbuf, sizeof(hbuf), hipMemcpyHostToDevice, b.stream));
     BankDev d = b.dev();
     ResArgs ra{};
-    ra.mode = RES_RESAMPLE; ra.parity = (b.parity + ACC_NSLOT - 1) % ACC_NSLOT; ra.step = b.n_predict; ra.M = (int32_t)b.N; ra.anc_out = b.d_anc;
+    ra.mode = RES_RESAMPLE; ra.parity = (b.parity + ACC_NSLOT - 1) % ACC_NSLOT; ra.step = b.n_predict; ra.M = (int32_t)b.N;
+    ra.anc_out = b.d_anc; ra.k = 0;
     HIPC(launch_resample(d, ra, b.stream));
     StepArgs a{};
     a.u = b.d_uy; a.y = nullptr; a.t_prop = t; a.t_meas = t; a.step = b.n_predict; a.has_y = 0; a.parity = b.parity;
+    a.K = llpf_qbits(b.N); a.k = 0;
     HIPC(launch_step(d, MODE_PROP, a, b.stream));
     HIPC(launch_post_predict(d, b.stream));
     b.cur ^= 1;
@@ -423,55 +485,148 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
     }
     const double Ts = b.cfg.model.Ts;
     const int want_xm = xmean ? 1 : 0;
+    const int K = llpf_qbits(b.N);
+    const int ne2 = need_e2(b);
+    const bool hist = x_hist || w_hist || we_hist;
     auto has_y = [&](int64_t k) { return !(Y[k * b.ny] != Y[k * b.ny]); };
     auto tk = [&](int64_t k) { return (t_index0 + (double)k) * Ts; };
+    // Fused (one launch: finalize + resample + propagate + weight, a block propagates the outputs of its own source
+    // tile) or balanced form (ancestors to HBM, then a uniform propagate).  The fused form saves a launch and the
+    // ancestor round trip but its propagate work follows the weight distribution; models whose dynamics dominate the
+    // timestep (quad-tank RK4: 32 fp64 sqrt per particle) and whose ESS is small run faster balanced (measured 69 vs
+    // 121 us per timestep at N = 1e6), the linear-Gaussian model faster fused.  LLPF_UNFUSED=0/1 overrides.
+    static const char* unf_env = getenv("LLPF_UNFUSED");
+    const bool heavy_dynamics = b.cfg.model.model_id == LLPF_MODEL_QUADTANK_RK4;
+    const bool unfused = hist || (unf_env ? atoi(unf_env) != 0 : heavy_dynamics);
+    // Where the exp-sums / quanta of freshly computed weights are formed (identical results either way): inside the
+    // weighting phase (one launch per timestep: best when one filter of ~1e6 particles cannot fill the chip and the
+    // dependent-launch latency dominates) or by a streaming k_norm launch in bound form (the fused kernel then keeps
+    // its registers for the propagate and runs at higher occupancy: best when many filters saturate the SIMDs).
+    // Measured on MI355X: C2 single filter 29.4 vs 30.2 us, bank 128 x 1e5: 4.3e10 vs 5.0e10 particle-steps/s.
+    const char* sch_env = getenv("LLPF_SCHEDULE");       // "merged" | "split" override
+    const bool merged = hist || (sch_env ? (strcmp(sch_env, "merged") == 0) : ((int64_t)b.F * b.Ns <= ((int64_t)3 << 20)));
+    static const char* abl_env = getenv("LLPF_ABLATE");
+    static const char* dbg_env = getenv("LLPF_DEBUG_TIMING");
 
-    HIPC(hipEventRecord(b.ev_run0, b.stream));
-    {   // weighting of the first correct!
-        BankDev d = b.dev();
-        StepArgs a{};
-        a.u = b.nu > 0 ? b.d_U : nullptr; a.y = b.d_Y; a.t_prop = tk(0); a.t_meas = tk(0); a.step = 0; a.has_y = has_y(0) ? 1 : 0;
-        a.parity = b.parity;
-        ProfScope ps(b, LLPF_PROF_PROPAGATE);
-        HIPC(launch_step(d, MODE_WEIGHT, a, b.stream));
-    }
-    for (int64_t k = 0; k < T; ++k) {
-        BankDev d = b.dev();
-        const int par = b.parity;            // parity of the weighting that produced the current weights
-        b.parity = (b.parity + 1) % ACC_NSLOT;
-        {   // logsumexp! of correct!(u_k, y_k): exp-weights and their sums
-            ProfScope ps(b, LLPF_PROF_NORMALISE);
-            HIPC(launch_norm(d, par, want_xm, b.cfg.resample_threshold != 1.0 ? 1 : 0, b.n_predict, b.stream));
-        }
-        const bool hist = x_hist || w_hist || we_hist;
-        // Fused (one launch: finalize + resample + propagate + weight, a block propagates the outputs of its own
-        // source tile) or balanced two-launch form (ancestors to HBM, then a uniform propagate).  The fused form saves
-        // a launch and the ancestor round trip but its propagate work follows the weight distribution; models whose
-        // dynamics dominate the timestep (quad-tank RK4: 32 fp64 sqrt per particle) and whose ESS is small run faster
-        // balanced (measured: 72.6 vs 121 us per timestep at N = 1e6), the linear-Gaussian model faster fused
-        // (31.1 vs 33.5 us).  LLPF_UNFUSED=0/1 overrides for experiments.
-        static const char* unf_env = getenv("LLPF_UNFUSED");
-        const bool heavy_dynamics = b.cfg.model.model_id == LLPF_MODEL_QUADTANK_RK4;
-        const bool unfused = hist || (unf_env ? atoi(unf_env) != 0 : heavy_dynamics);
+    // host-side state of run-step k (the device may have to be re-driven from a step whose bound test failed)
+    const int cur0 = b.cur, qcur0 = b.qcur, par0 = b.parity;
+    const uint32_t np0 = b.n_predict;
+    const int64_t ti0 = b.t_index;
+    auto at_step = [&](int64_t k) {      // state in which step k's head runs (initial weighting done, k steps done)
+        b.cur = cur0 ^ (int)(k & 1);
+        b.qcur = qcur0 ^ 1 ^ (int)(k & 1);
+        b.parity = (par0 + 1 + (int)(k % ACC_NSLOT)) % ACC_NSLOT;      // slot the weighting of step k writes
+        b.n_predict = np0 + (uint32_t)k;
+        b.t_index = ti0 + k;
+    };
+    auto head_slot = [&](int64_t k) { return (par0 + (int)(k % ACC_NSLOT)) % ACC_NSLOT; };
+
+    auto res_args = [&](int64_t k, bool fast) {
         ResArgs ra{};
-        ra.parity = par; ra.step = b.n_predict; ra.M = (int32_t)b.N; ra.anc_out = b.d_anc;
+        ra.parity = head_slot(k); ra.step = b.n_predict; ra.M = (int32_t)b.N; ra.anc_out = b.d_anc;
         ra.accumulate = 1; ra.want_xmean = want_xm; ra.u_from_scal = 1;
         ra.ll_steps = ll_steps ? b.d_ll_steps : nullptr;
         ra.xmean = xmean ? b.d_xmean : nullptr;
-        ra.k = k;
-        static const char* abl_env = getenv("LLPF_ABLATE");
+        ra.k = k; ra.fast_head = fast ? 1 : 0;
         ra.ablate = abl_env ? atoi(abl_env) : 0;
-        static const char* dbg_env = getenv("LLPF_DEBUG_TIMING");      // developer aid: phase timestamps of timestep #dbg_env
-        uint64_t* d_dbg = nullptr;
-        if (dbg_env && k == atoll(dbg_env) && !hist) {
-            HIPC(hipMalloc(&d_dbg, sizeof(uint64_t) * 8 * b.P2));
-            HIPC(hipMemsetAsync(d_dbg, 0, sizeof(uint64_t) * 8 * b.P2, b.stream));
-            ra.dbg = d_dbg;
+        return ra;
+    };
+    auto step_args = [&](int64_t k) {
+        StepArgs st{};
+        st.u = b.nu > 0 ? b.d_U + k * b.nu : nullptr;
+        st.t_prop = tk(k);
+        st.step = b.n_predict;
+        st.parity = b.parity;
+        st.need_e2 = ne2; st.K = K; st.k = k; st.next_step = b.n_predict + 1; st.want_xmean = want_xm; st.accumulate = merged ? 1 : 0;
+        const bool weight = (k + 1 < T);
+        if (weight) { st.y = b.d_Y + (k + 1) * b.ny; st.t_meas = tk(k + 1); st.has_y = has_y(k + 1) ? 1 : 0; }
+        else { st.y = nullptr; st.t_meas = tk(k); st.has_y = 0; }
+        return st;
+    };
+    // one timestep in the given form; `fast`: the head consumes the bound-offset sums of the previous weighting,
+    // otherwise the exact-max sums of a k_norm launched just before (redo of a failed step, or weighted means)
+    auto launch_timestep = [&](int64_t k, bool fast, int only_fb) -> int {
+        at_step(k);
+        BankDev d = b.dev();
+        ResArgs ra = res_args(k, fast);
+        ra.only_fallback = only_fb;
+        StepArgs st = step_args(k);
+        const bool weight = (k + 1 < T);
+        if (fast && !merged) {   // split schedule: the sums of the current weights in bound form, as a streaming launch
+            ProfScope ps(b, LLPF_PROF_NORMALISE);
+            HIPC(launch_norm(d, ra.parity, want_xm, ne2, b.n_predict, 0, 1, k, b.stream));
         }
-        if (hist) {   // forward_trajectory history (reference src/filtering.jl:357-359) needs the normalised state
-                      // between correct! and predict!: split finalize and resample.  Not a timed path.
+        if (!fast) {
+            ProfScope ps(b, LLPF_PROF_NORMALISE);
+            HIPC(launch_norm(d, ra.parity, want_xm, 1, b.n_predict, only_fb, 0, k, b.stream));
+        }
+        if (unfused) {
+            {
+                ra.mode = RES_FINALIZE | RES_RESAMPLE;
+                ProfScope ps(b, LLPF_PROF_RESAMPLE);
+                HIPC(launch_resample(d, ra, b.stream));
+            }
+            ProfScope ps(b, LLPF_PROF_PROPAGATE);
+            st.only_fallback = only_fb;
+            HIPC(launch_step(d, weight ? MODE_PROP_WEIGHT : MODE_PROP, st, b.stream));
+        } else {
+            uint64_t* d_dbg = nullptr;
+            if (dbg_env && k == atoll(dbg_env)) {
+                HIPC(hipMalloc(&d_dbg, sizeof(uint64_t) * 8 * b.P2));
+                HIPC(hipMemsetAsync(d_dbg, 0, sizeof(uint64_t) * 8 * b.P2, b.stream));
+                ra.dbg = d_dbg;
+            }
+            st.only_fallback = only_fb;
+            ProfScope ps(b, LLPF_PROF_PROPAGATE);
+            HIPC(launch_resprop(d, ra, st, weight ? 1 : 0, b.stream));
+            if (d_dbg) {
+                std::vector<uint64_t> hd((size_t)8 * b.P2);
+                HIPC(hipMemcpyAsync(hd.data(), d_dbg, sizeof(uint64_t) * hd.size(), hipMemcpyDeviceToHost, b.stream));
+                HIPC(hipStreamSynchronize(b.stream));
+                FILE* fp = fopen("gpurun_out/llpf_timing.txt", "w");
+                if (fp) {
+                    for (int t = 0; t < b.P2; ++t) {
+                        for (int q = 0; q < 6; ++q) fprintf(fp, "%llu ", (unsigned long long)hd[(size_t)t * 8 + q]);
+                        fprintf(fp, "\n");
+                    }
+                    fclose(fp);
+                }
+                hipFree(d_dbg);
+            }
+        }
+        return LLPF_OK;
+    };
+
+    HIPC(hipEventRecord(b.ev_run0, b.stream));
+    {   // weighting of the first correct! (exp-sums against the bound, quanta, tile sums: no separate normalise pass)
+        BankDev d = b.dev();
+        StepArgs a{};
+        a.u = b.nu > 0 ? b.d_U : nullptr; a.y = b.d_Y; a.t_prop = tk(0); a.t_meas = tk(0); a.step = 0; a.has_y = has_y(0) ? 1 : 0;
+        a.parity = par0; a.need_e2 = ne2; a.K = K; a.k = 0; a.next_step = np0; a.want_xmean = want_xm; a.accumulate = merged ? 1 : 0;
+        ProfScope ps(b, LLPF_PROF_PROPAGATE);
+        HIPC(launch_step(d, MODE_WEIGHT, a, b.stream));
+    }
+    if (hist) {
+        // step-synchronous form: the normalised state between correct! and predict! is copied out
+        // (forward_trajectory history, reference src/filtering.jl:357-359).  Same arithmetic as the asynchronous
+        // loop below (bound-offset form, exact redo when its test fails); not a timed path.
+        for (int64_t k = 0; k < T; ++k) {
+            at_step(k);
+            BankDev d = b.dev();
+            ResArgs ra = res_args(k, true);
             ra.mode = RES_FINALIZE;
             HIPC(launch_resample(d, ra, b.stream));
+            std::vector<int> fl;
+            int64_t kf;
+            CHK(poll_fallback(b, fl, kf));
+            if (!fl.empty()) {
+                CHK(clear_slot_sums(b, ra.parity, fl));
+                HIPC(launch_norm(d, ra.parity, want_xm, 1, b.n_predict, 1, 0, k, b.stream));
+                ra.fast_head = 0; ra.only_fallback = 1;
+                HIPC(launch_resample(d, ra, b.stream));
+                ra.only_fallback = 0;
+                CHK(clear_fallback(b, fl));
+            }
             if (x_hist) {
                 HIPC(launch_soa2aos(d, b.d_x[b.cur], b.d_tmp, b.stream));
                 HIPC(hipMemcpyAsync(x_hist + (size_t)k * b.N * b.nx, b.d_tmp, sizeof(double) * b.N * b.nx, hipMemcpyDeviceToHost, b.stream));
@@ -490,46 +645,27 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
             ra.mode = RES_RESAMPLE;
             ra.accumulate = 0; ra.ll_steps = nullptr; ra.xmean = nullptr;
             HIPC(launch_resample(d, ra, b.stream));
+            StepArgs st = step_args(k);
+            HIPC(launch_step(d, (k + 1 < T) ? MODE_PROP_WEIGHT : MODE_PROP, st, b.stream));
         }
-        StepArgs st{};
-        st.u = b.nu > 0 ? b.d_U + k * b.nu : nullptr;
-        st.t_prop = tk(k);
-        st.step = b.n_predict;
-        st.parity = b.parity;
-        const bool weight = (k + 1 < T);
-        if (weight) { st.y = b.d_Y + (k + 1) * b.ny; st.t_meas = tk(k + 1); st.has_y = has_y(k + 1) ? 1 : 0; }
-        else { st.y = nullptr; st.t_meas = tk(k); st.has_y = 0; }
-        if (!hist && unfused) {   // balanced two-launch form: ancestors to HBM, then a uniform propagate
-            ra.mode = RES_FINALIZE | RES_RESAMPLE;
-            ProfScope ps(b, LLPF_PROF_RESAMPLE);
-            HIPC(launch_resample(d, ra, b.stream));
+    } else {
+        int64_t k0 = 0;
+        while (k0 < T) {
+            for (int64_t k = k0; k < T; ++k) CHK(launch_timestep(k, true, 0));
+            std::vector<int> fl;
+            int64_t kf;
+            CHK(poll_fallback(b, fl, kf));
+            if (fl.empty()) break;
+            // step kf of the flagged filters: exact-max normalisation of the same weights, then the step again
+            CHK(clear_slot_sums(b, head_slot(kf), fl));
+            CHK(launch_timestep(kf, false, 1));
+            CHK(clear_fallback(b, fl));
+            k0 = kf + 1;
         }
-        if (unfused) {
-            ProfScope ps(b, LLPF_PROF_PROPAGATE);
-            HIPC(launch_step(d, weight ? MODE_PROP_WEIGHT : MODE_PROP, st, b.stream));
-        } else {      // scalars of correct!(u_k, y_k) + shouldresample + resample + propagate of predict!(u_k)
-                      // + weighting of correct!(u_{k+1}, y_{k+1}): one launch
-            ProfScope ps(b, LLPF_PROF_PROPAGATE);
-            HIPC(launch_resprop(d, ra, st, weight ? 1 : 0, b.stream));
-        }
-        if (d_dbg) {
-            std::vector<uint64_t> hd((size_t)8 * b.P2);
-            HIPC(hipMemcpyAsync(hd.data(), d_dbg, sizeof(uint64_t) * hd.size(), hipMemcpyDeviceToHost, b.stream));
-            HIPC(hipStreamSynchronize(b.stream));
-            FILE* fp = fopen("gpurun_out/llpf_timing.txt", "w");
-            if (fp) {
-                for (int t = 0; t < b.P2; ++t) {
-                    for (int q = 0; q < 6; ++q) fprintf(fp, "%llu ", (unsigned long long)hd[(size_t)t * 8 + q]);
-                    fprintf(fp, "\n");
-                }
-                fclose(fp);
-            }
-            hipFree(d_dbg);
-        }
-        b.cur ^= 1;
-        b.n_predict++;
-        b.t_index++;
     }
+    at_step(T);
+    b.qcur = qcur0 ^ (int)(T & 1);                           // the last step has no weighting phase: no quanta swap
+    b.parity = (par0 + (int)(T % ACC_NSLOT)) % ACC_NSLOT;
     {
         BankDev d = b.dev();
         ProfScope ps(b, LLPF_PROF_OTHER);
@@ -580,12 +716,13 @@ static int bank_set_weights(Bank& b, const double* w) {
     for (auto& s : h) { s.uniform = 0; s.norm_pending = 0; s.status = 0; }
     CHK(scal_upload(b, h));
     HIPC(hipMemsetAsync(b.d_acc, 0, sizeof(uint64_t) * (size_t)b.F * ACC_WORDS, b.stream));
+    HIPC(hipMemsetAsync(b.d_tileq, 0, sizeof(uint64_t) * (size_t)ACC_NSLOT * b.F * b.P2, b.stream));
     b.parity = 0;
     BankDev d = b.dev();
     HIPC(launch_max(d, b.parity, b.stream));
-    HIPC(launch_norm(d, b.parity, 0, 1, b.n_predict, b.stream));
+    HIPC(launch_norm(d, b.parity, 0, 1, b.n_predict, 0, 0, 0, b.stream));
     ResArgs ra{};
-    ra.mode = RES_FINALIZE; ra.parity = b.parity; ra.M = (int32_t)b.N; ra.keep_norm = 1;
+    ra.mode = RES_FINALIZE; ra.parity = b.parity; ra.M = (int32_t)b.N; ra.keep_norm = 1; ra.fast_head = 0;
     HIPC(launch_resample(d, ra, b.stream));
     b.parity = (b.parity + 1) % ACC_NSLOT;
     CHK(scal_download(b, h));
@@ -689,6 +826,7 @@ int llpf_get_bins(llpf_filter* f, double* dst) {
     BankDev d = b.dev();
     ResArgs ra{};
     ra.mode = RES_RESAMPLE; ra.step = b.n_predict; ra.M = (int32_t)b.N; ra.anc_out = b.d_anc;
+    ra.parity = (b.parity + ACC_NSLOT - 1) % ACC_NSLOT;
     ra.bins_out = b.d_tmp; ra.only_bins = 1; ra.force = 1;
     HIPC(launch_resample(d, ra, b.stream));
     HIPC(hipMemcpyAsync(dst, b.d_tmp, sizeof(double) * b.N, hipMemcpyDeviceToHost, b.stream));
@@ -748,7 +886,7 @@ int llpf_maxw(llpf_filter* f, double* maxw) {
     NEEDF(f);
     FilterScal s;
     CHK(scal0(f, &s, false));
-    if (maxw) *maxw = s.m;
+    if (maxw) *maxw = s.mtrue;
     return LLPF_OK;
 }
 int llpf_weighted_mean(llpf_filter* f, double* xh) {

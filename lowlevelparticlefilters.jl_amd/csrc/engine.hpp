@@ -15,7 +15,7 @@
 //   quanta [F][Ns]         u64   q_i = floor(exp(w_i - m) 2^K), written by the normalise kernel so that the scan
 //                                kernel does not recompute exp (8 B/particle of extra traffic buys ~60 VALU instr.)
 //   tileq  [F][P2]         u64   per-tile sums of the resampling quanta (tile prefix for the scan kernel)
-//   xmpart [F][P2][8]      fp64  per-tile sums e_i x_i (weighted_mean output only; never fed back)
+//   xmpart [F][P1][8]      fp64  per-block sums e_i x_i (weighted_mean output only; never fed back)
 //   scal   [F]             FilterScal    per-filter scalars (maxw, log1p(s), 1/(s+1), ESS, flags, ...)
 // Ns = N rounded up to a multiple of TILE (padding lanes carry zero weight).
 // The exp-weights `we` and the cumulative `bins` of the reference (src/PFtypes.jl:12,15) are never
@@ -100,7 +100,16 @@ struct FilterScal {
     int32_t pad0;
     int64_t resample_count;
     uint32_t k0, k1;     // Philox key of this filter
-    double u_sys;        // the uniform of the coming systematic resample (computed once per step by the normalise kernel)
+    double u_sys;        // the uniform of the coming systematic resample (computed once per step)
+    double stot;         // sum of exp(w - m) over ALL particles in the form the last normalisation used (exact form: s + 1)
+    double mtrue;        // true maximum of the raw log-weights (state.maxw[]); m above is the OFFSET (bound or maximum)
+    double wmax;         // maximum of the current normalised / uniform log-weights: input of the next bound
+    double off_next;     // offset (bound) the last weighting kernel used for its exp-sums
+    int32_t fast;        // last normalisation used the bound-offset form
+    int32_t fallback;    // a fast head found sum exp(w - bound) < 2^-10: the host must redo this step in exact form
+    int64_t fb_step;     // run-step index of that head
+    int32_t xm_parts;    // number of per-block partial sums in xmpart written by the last weighting / normalise kernel
+    int32_t pad2;
     int32_t e2_valid;    // sum e^2 / ESS were accumulated for the current weights (skipped when resample_threshold == 1)
     int32_t pad1;
 };
@@ -125,9 +134,12 @@ struct BankDev {
     double* w;           // [F][Ns]
     int32_t* anc;        // [F][Ns]
     uint64_t* acc;       // [F][ACC_WORDS]
-    uint64_t* quanta;    // [F][Ns]
-    uint64_t* tileq;     // [F][P2]
-    double* xmpart;      // [F][P2][MAXD]
+    uint64_t* quanta;    // [F][Ns]  quanta of the CURRENT weights (read by the scan)
+    uint64_t* quanta_next; // [F][Ns] written by a weighting phase (ping-pong: other blocks may still read `quanta`)
+    uint64_t* tileq;     // [ACC_NSLOT][F][P2] per-tile quanta sums, one set per accumulator slot
+    uint32_t* bank_flag; // [1] 0, or 1 + the run-step index at which some filter's bound test failed: every later
+                         //     launch of the run is a no-op until the host has redone that step in exact form
+    double* xmpart;      // [F][P1][MAXD]
 };
 
 enum StepMode { MODE_WEIGHT = 0, MODE_PROP = 1, MODE_PROP_WEIGHT = 2 };
@@ -139,7 +151,16 @@ struct StepArgs {
     double t_meas;         // time passed to measurement
     uint32_t step;         // Philox step counter of this predict!
     int32_t has_y;         // 0: measurement missing (weights pass through)
-    int32_t parity;        // accumulator slot (0..2) this weighting writes its maximum to
+    int32_t parity;        // accumulator slot (0..2) this weighting writes its maximum, exp-sums and tile sums to
+    int32_t need_e2;       // accumulate sum e^2 (ESS) — not needed when resample_threshold == 1
+    int32_t K;             // fraction bits of the quanta
+    int32_t only_fallback; // exact redo of one step: only filters whose `fallback` flag is set take part
+    int64_t k;             // run-step index of this launch (for the bank_flag epoch test)
+    uint32_t next_step;    // Philox step of the predict! that follows this weighting (its systematic offset is precomputed)
+    int32_t want_xmean;    // also accumulate per-block sums e_i x_i for the weighted-mean output of the next finalize
+    int32_t accumulate;    // 1: this weighting kernel also computes the exp-sums / quanta / tile sums of its weights (one launch
+                           //    per timestep); 0: a k_norm launch in bound form does (better when the chip is saturated)
+    int32_t pad3;
 };
 
 enum { RES_FINALIZE = 1, RES_RESAMPLE = 2 };
@@ -156,6 +177,8 @@ struct ResArgs {
     int32_t keep_norm;     // leave norm_pending = 0 (set_weights path: w stays as installed)
     int32_t accumulate;    // ll_total += ll
     int32_t want_xmean;
+    int32_t fast_head;     // the accumulators of slot `parity` are in bound-offset form (written by a weighting phase)
+    int32_t only_fallback; // exact redo of one step: only filters whose `fallback` flag is set take part
     int32_t u_from_scal;   // systematic offset U was precomputed into scal[f].u_sys by the normalise kernel
     uint32_t step;         // Philox step of this predict!
     int32_t M;             // number of outputs
@@ -174,7 +197,9 @@ hipError_t launch_init(const BankDev& b, uint32_t step, int init_anc, hipStream_
 hipError_t launch_wmean(const BankDev& b, double* out /* [F][nx] */, hipStream_t s);
 hipError_t launch_step(const BankDev& b, int mode, const StepArgs& a, hipStream_t s);
 hipError_t launch_max(const BankDev& b, int parity, hipStream_t s);           // maxima of the raw w into acc
-hipError_t launch_norm(const BankDev& b, int parity, int want_xmean, int need_e2, uint32_t step, hipStream_t s);
+// exp-weights, their fixed-point sums, quanta and tile sums of the current weights; offset = the maximum (exact form)
+// or, with bound = 1, the analytic bound published by the weighting kernel (same results as an accumulating weighting)
+hipError_t launch_norm(const BankDev& b, int parity, int want_xmean, int need_e2, uint32_t step, int only_fallback, int bound, int64_t kstep, hipStream_t s);
 hipError_t launch_ess(const BankDev& b, hipStream_t s);   // on-demand sum e^2 / ESS of the current weights (accessor path)
 hipError_t launch_post_predict(const BankDev& b, hipStream_t s);
 hipError_t launch_resample(const BankDev& b, const ResArgs& a, hipStream_t s);

@@ -354,6 +354,76 @@ DEV llpf_u128 acc_combine_u128(uint64_t a0, uint64_t a1, uint64_t a2) {
     return r;
 }
 
+DEV uint64_t* tileq_slot(const BankDev& b, int slot, int f) { return b.tileq + ((size_t)slot * b.F + f) * b.P2; }
+
+// a launch of run-step k is a no-op when an EARLIER launch flagged a failed bound test (flag = 1 + its step)
+DEV bool run_is_stopped(const BankDev& b, int64_t k) {
+    const uint32_t fl = *b.bank_flag;
+    return fl != 0 && (int64_t)(fl - 1) < k;
+}
+
+// Exp-sums of freshly computed weights against the analytic bound `off` (see oracle/llpf_oracle.c:dev_norm_bound):
+// e = exp(w - off) <= 1, S += fix96(e), [E2 += fix96(e^2)], quantum q = floor(e 2^K).
+struct WeightAcc {
+    llpf_u128 S, E2;
+    uint64_t bad;
+    DEV void init() { S.lo = 0; S.hi = 0; E2.lo = 0; E2.hi = 0; bad = 0; }
+    DEV uint64_t add(double w, double off, int K, bool need_e2, double* e_out = nullptr) {
+        const double e = llpf_exp_le0(w - off);
+        if (e_out) *e_out = e;
+        bad += (e != e) ? 1u : 0u;
+        S = llpf_u128_add(S, llpf_fix96_unit(e));
+        if (need_e2) E2 = llpf_u128_add(E2, llpf_fix96_unit(e * e));
+        return llpf_q64_unit(e, K);
+    }
+    // block-wide totals into the sharded accumulators of `slot`; sm: [BLOCK/64][5] u64 of LDS
+    DEV void flush(uint64_t* acc, int slot, bool need_e2, uint64_t (*sm)[5]) {
+        llpf_u128 s = wave_sum_u128(S), e2 = {0, 0};
+        if (need_e2) e2 = wave_sum_u128(E2);
+        const uint64_t bd = wave_sum_u64(bad);
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        __syncthreads();
+        if (lane == 0) { sm[wv][0] = s.lo; sm[wv][1] = s.hi; sm[wv][2] = e2.lo; sm[wv][3] = e2.hi; sm[wv][4] = bd; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            llpf_u128 ts = {sm[0][0], sm[0][1]}, te = {sm[0][2], sm[0][3]};
+            uint64_t tb = sm[0][4];
+            for (int k = 1; k < BLOCK / 64; ++k) {
+                llpf_u128 a1 = {sm[k][0], sm[k][1]}, a2 = {sm[k][2], sm[k][3]};
+                ts = llpf_u128_add(ts, a1);
+                te = llpf_u128_add(te, a2);
+                tb += sm[k][4];
+            }
+            acc_add_u128(acc, ACC_S(slot), ts);
+            if (need_e2) acc_add_u128(acc, ACC_E2(slot), te);
+            if (tb) atomicAdd(reinterpret_cast<unsigned long long*>(acc_slot(acc, ACC_BAD(slot), blockIdx.x & (NSHARD - 1))), (unsigned long long)tb);
+        }
+    }
+};
+
+// fixed-order fp64 block sum of the per-thread partial sums e_i x_i (weighted-mean output only; never fed back)
+template <int NX>
+DEV void block_store_xm(const double* xm, double* dst /* [MAXD] */, double (*smx)[MAXD]) {
+    double v[NX];
+#pragma unroll
+    for (int d = 0; d < NX; ++d) v[d] = wave_sum_f64(xm[d]);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int d = 0; d < NX; ++d) smx[wv][d] = v[d];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int d = 0; d < NX; ++d) {
+            double a = smx[0][d];
+            for (int k = 1; k < BLOCK / 64; ++k) a = a + smx[k][d];
+            dst[d] = a;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_step — fused propagate + weight + running max
 // ------------------------------------------------------------------------------------------------
@@ -361,9 +431,13 @@ template <class Model, int NX, int NY, int MODE>
 __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restrict__ models,
                                                  const FilterScal* scal, StepArgs a) {
     __shared__ double sm_max[BLOCK / 64];
+    __shared__ uint64_t sm_acc[BLOCK / 64][5];
+    __shared__ double sm_x[BLOCK / 64][MAXD];
     const int f = blockIdx.y;
     const ModelD* md = models + f;
     const FilterScal* sc = scal + f;
+    if (run_is_stopped(b, a.k)) return;
+    if (a.only_fallback ? !sc->fallback : (sc->fallback != 0)) return;   // redo launches take the flagged filters, all others skip them
     const int do_res = (MODE != MODE_WEIGHT) ? sc->do_resample : 0;
     const int uniform = sc->uniform, pend = sc->norm_pending;
     const double m = sc->m, l = sc->l, wconst = sc->wconst;
@@ -385,6 +459,18 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
 
     double bmax = -LLPF_INF;
     bool bad = false;
+    // bound of the weights this kernel produces: max of the previous (normalised) weights + the density's peak
+    double off = 0.0;
+    WeightAcc wacc;
+    uint64_t qsum = 0;
+    double xm[NX];
+#pragma unroll
+    for (int d = 0; d < NX; ++d) xm[d] = 0.0;
+    if (MODE != MODE_PROP) {
+        const double wmx = do_res ? b.log1N : (uniform ? wconst : sc->wmax);
+        off = a.has_y ? wmx + md->dg.c0 : wmx;
+        wacc.init();
+    }
 #pragma unroll 1
     for (int it = 0; it < STEP_ITERS; ++it) {
         const int64_t i0 = ((int64_t)blockIdx.x * STEP_ITERS + it) * (BLOCK * STEP_PPT) + (int64_t)threadIdx.x * STEP_PPT;
@@ -463,12 +549,44 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
             wo.x = wn[0];
             wo.y = wn[1];
             *reinterpret_cast<double2*>(w + i0) = wo;
+            if (a.accumulate) {   // merged schedule: exp-sums, quanta and tile sums of the new weights formed here
+                ulonglong2 qv;
+                double e0, e1;
+                qv.x = wacc.add(wn[0], off, a.K, a.need_e2 != 0, &e0);
+                qv.y = wacc.add(wn[1], off, a.K, a.need_e2 != 0, &e1);
+                *reinterpret_cast<ulonglong2*>(b.quanta_next + (size_t)f * Ns + i0) = qv;
+                qsum += qv.x + qv.y;
+                if (a.want_xmean) {
+#pragma unroll
+                    for (int d = 0; d < NX; ++d) { xm[d] = xm[d] + xs[0][d] * e0; xm[d] = xm[d] + xs[1][d] * e1; }
+                }
+            }
         }
     }
     if (MODE != MODE_PROP) {
         const double r = block_max(bmax, sm_max);
         const int anybad = __syncthreads_or(bad ? 1 : 0);
         if (threadIdx.x == 0) acc_max(b.acc + (size_t)f * ACC_WORDS, a.parity, r, anybad != 0);
+        if (a.accumulate) wacc.flush(b.acc + (size_t)f * ACC_WORDS, a.parity, a.need_e2 != 0, sm_acc);
+        if (a.accumulate && a.want_xmean) block_store_xm<NX>(xm, b.xmpart + ((size_t)f * b.P1 + blockIdx.x) * MAXD, sm_x);
+        // all particles of this block lie in one 1024-particle tile
+        qsum = wave_sum_u64(qsum);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) sm_acc[threadIdx.x >> 6][0] = qsum;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint64_t q = 0;
+            for (int k = 0; k < BLOCK / 64; ++k) q += sm_acc[k][0];
+            const int64_t tile = ((int64_t)blockIdx.x * STEP_TILE) / TILE;
+            if (q) atomicAdd(reinterpret_cast<unsigned long long*>(tileq_slot(b, a.parity, f) + tile), (unsigned long long)q);
+            if (blockIdx.x == 0) {
+                FilterScal* scw = b.scal + f;
+                if (a.accumulate) scw->xm_parts = b.P1;
+                scw->off_next = off;
+                scw->e2_valid = a.need_e2;
+                scw->u_sys = llpf_uniform_step(a.next_step, LLPF_STREAM_RESAMPLE, k0, k1);
+            }
+        }
     }
     if (MODE != MODE_WEIGHT && blockIdx.x == 0 && threadIdx.x == 0) {
         // bookkeeping of this predict! (fields no block of this kernel reads): state.j == 1:N unless resampled
@@ -506,11 +624,14 @@ __global__ __launch_bounds__(BLOCK) void k_max(BankDev b, int parity) {
 // effective_particles resample.jl:1-2; optional weighted_mean filtering.jl:541-549)
 // ------------------------------------------------------------------------------------------------
 template <int NX, bool XMEAN, bool NEED_E2>
-__global__ __launch_bounds__(BLOCK) void k_norm(BankDev b, int K, int parity, uint32_t step) {
+__global__ __launch_bounds__(BLOCK) void k_norm(BankDev b, int K, int parity, uint32_t step, int only_fallback, int bound, int64_t kstep) {
     __shared__ uint64_t sm_u[BLOCK / 64][6];
     __shared__ double sm_x[BLOCK / 64][MAXD];
     const int f = blockIdx.y;
     const int tile = blockIdx.x;
+    if (only_fallback && !b.scal[f].fallback) return;
+    if (bound && run_is_stopped(b, kstep)) return;
+    if (bound && b.scal[f].fallback) return;
     uint64_t* acc = b.acc + (size_t)f * ACC_WORDS;
     const double* __restrict__ w = b.w + (size_t)f * b.Ns;
     const double* __restrict__ xc = b.xcur + (size_t)f * NX * b.Ns;
@@ -521,7 +642,7 @@ __global__ __launch_bounds__(BLOCK) void k_norm(BankDev b, int K, int parity, ui
         const int64_t i0 = (int64_t)tile * TILE + (int64_t)k * (BLOCK * 2) + threadIdx.x * 2;
         wv[k] = *reinterpret_cast<const double2*>(w + i0);
     }
-    const double m = acc_read_max_wave(acc, parity);
+    const double m = bound ? b.scal[f].off_next : acc_read_max_wave(acc, parity);
 
     llpf_u128 S = {0, 0}, E2 = {0, 0};
     uint64_t Q = 0, bad = 0;
@@ -591,14 +712,15 @@ __global__ __launch_bounds__(BLOCK) void k_norm(BankDev b, int K, int parity, ui
             FilterScal* sc = b.scal + f;
             sc->u_sys = llpf_uniform_step(step, LLPF_STREAM_RESAMPLE, sc->k0, sc->k1);
             sc->e2_valid = NEED_E2 ? 1 : 0;
+            sc->xm_parts = b.P2;
         }
         if (bd) atomicAdd(reinterpret_cast<unsigned long long*>(acc_slot(acc, ACC_BAD(parity), blockIdx.x & (NSHARD - 1))), (unsigned long long)bd);
-        b.tileq[(size_t)f * b.P2 + tile] = q;
+        tileq_slot(b, parity, f)[tile] = q;
         if (XMEAN) {
             for (int d = 0; d < NX; ++d) {
                 double a = sm_x[0][d];
                 for (int k = 1; k < BLOCK / 64; ++k) a = a + sm_x[k][d];
-                b.xmpart[((size_t)f * b.P2 + tile) * MAXD + d] = a;
+                b.xmpart[((size_t)f * b.P1 + tile) * MAXD + d] = a;
             }
         }
     }
@@ -625,7 +747,7 @@ __global__ __launch_bounds__(BLOCK) void k_ess(BankDev b) {
         for (int k = 1; k < BLOCK / 64; ++k) { llpf_u128 u = {sm_u[k][0], sm_u[k][1]}; t = llpf_u128_add(t, u); }
         const double e2 = llpf_fix96_to_double(t);
         sc->e2 = e2;
-        sc->ess = ((sc->s + 1.0) * (sc->s + 1.0)) / e2;
+        sc->ess = (sc->stot * sc->stot) / e2;
         sc->e2_valid = 1;
     }
 }
@@ -638,7 +760,9 @@ __global__ void k_post_predict(BankDev b) {
     if (sc->do_resample) {
         sc->uniform = 1;
         sc->wconst = b.log1N;
-        sc->m = 0.0;                 // maxw[] = 0
+        sc->m = 0.0;
+        sc->mtrue = 0.0;             // maxw[] = 0
+        sc->wmax = b.log1N;
         sc->norm_pending = 0;
     }
     sc->do_resample = 0;
@@ -703,17 +827,22 @@ struct ResShared {                 // LDS scratch
     uint32_t cl[TILE];
 };
 struct ResHead {                   // block-uniform results of res_head()
-    double m, s, e2;               // max, sum_{i != argmax} e_i, sum e_i^2 of the current weights
+    double a;                      // offset of the pending normalisation (bound or maximum)
+    double mtrue;                  // true maximum of the raw weights
+    double s;                      // exact form only: sum_{i != argmax} e_i
+    double stot, e2;               // sum e_i (all particles), sum e_i^2 (-1: not accumulated)
     uint64_t prefix, tot;          // exclusive prefix of this tile's quanta, total of all quanta
-    int dr, status, uniform;
+    int dr, status, uniform, fast;
 };
+enum { RES_STATUS_FALLBACK = 100 };   // internal: bound test failed, the host redoes this step in exact form
 
-// shouldresample (reference src/resample.jl:5-10) without the division: ESS = (s+1)^2 / sum(e^2) < N*thr
-DEV int decide_resample(double thr, double N, double s, double e2) {
+// shouldresample (reference src/resample.jl:5-10) without the division: ESS = stot^2 / sum(e^2) < N*thr
+DEV int decide_resample(double thr, double N, double stot, double e2) {
     if (thr == 1.0) return 1;
-    const double sp1 = s + 1.0;
-    return (sp1 * sp1 < (N * thr) * e2) ? 1 : 0;
+    return (stot * stot < (N * thr) * e2) ? 1 : 0;
 }
+// log(sum exp(w - a)) in the form the normalisation was accumulated in
+DEV double head_log(const ResHead& h) { return h.fast ? llpf_log(h.stot) : llpf_log1p_nonneg(h.s); }
 
 // Head of a resample launch: all global loads are issued first (accumulator slots, per-tile quanta sums), one
 // __syncthreads, then EVERY thread derives the block-uniform scalars (integer sums => identical everywhere).
@@ -728,23 +857,27 @@ DEV ResHead res_head(const BankDev& b, const ResArgs& a, int f, int tile, ResSha
     const bool fin = (a.mode & RES_FINALIZE) != 0;
     const bool unif0 = (SRC == SRC_FILTER) && !fin && sc->uniform;
 
-    // loads
-    // wave 0: lane group g (8 lanes = 8 shards) fetches word g of this parity's accumulator set
+    // loads.  wave 0: lane group g (8 lanes = 8 shards) fetches word g of this slot's accumulator set
     uint64_t accv = 0;
     const int grp = threadIdx.x / NSHARD, shard = threadIdx.x % NSHARD;
     if (fin && threadIdx.x < 64) accv = *acc_slot(acc, acc_word_of_group(grp, a.parity), shard);
-    if (fin && tile == 0 && threadIdx.x >= 64 && threadIdx.x < 128)
-        *acc_slot(acc, acc_word_of_group(grp - 8, (a.parity + 2) % ACC_NSLOT), shard) = 0;   // clear the slot after next
     uint64_t pre = 0, all = 0;
     if ((a.mode & RES_RESAMPLE) && !unif0) {
-        const uint64_t* __restrict__ tq = b.tileq + (size_t)f * b.P2;
+        const uint64_t* __restrict__ tq = tileq_slot(b, a.parity, f);
         for (int p = threadIdx.x; p < b.P2; p += BLOCK) {
             const uint64_t q = tq[p];
             all += q;
             if (p < tile) pre += q;
         }
     }
-    // reductions
+    if (fin) {
+        // clear the slot after next (its last reader finished two launches ago): accumulator words and tile sums
+        const int clr = (a.parity + 2) % ACC_NSLOT;
+        if (tile == 0 && threadIdx.x >= 64 && threadIdx.x < 128) *acc_slot(acc, acc_word_of_group(grp - 8, clr), shard) = 0;
+        uint64_t* tqc = tileq_slot(b, clr, f);
+        if (gridDim.x == (unsigned)b.P2) { if (threadIdx.x == 0) tqc[tile] = 0; }
+        else { for (int p = threadIdx.x; p < b.P2; p += BLOCK) tqc[p] = 0; }      // finalize-only launch: one block
+    }
     if (fin && wvid == 0) {
         // combine the 8 shards of each word inside its group of 8 lanes: xor 1, xor 2 (quad_perm), xor 4 (half mirror)
 #define LLPF_ACCSTEP(CTRL) { const uint64_t t = dpp_u64<CTRL, 0xF, false>(accv, accv); accv = (grp == 0) ? (t > accv ? t : accv) : accv + t; }
@@ -761,44 +894,68 @@ DEV ResHead res_head(const BankDev& b, const ResArgs& a, int f, int tile, ResSha
     for (int k = 0; k < BLOCK / 64; ++k) { h.prefix += sh.red[k][0]; h.tot += sh.red[k][1]; }
 
     h.status = 0;
-    double l = 0.0, inv = 1.0, ll = 0.0;
+    h.s = 0.0;
     if (fin) {
-        h.m = max_unkey(sh.accw[0]);
+        h.fast = a.fast_head;
+        h.mtrue = max_unkey(sh.accw[0]);
         const llpf_u128 s128 = acc_combine_u128(sh.accw[1], sh.accw[2], sh.accw[3]);
         const llpf_u128 e128 = acc_combine_u128(sh.accw[4], sh.accw[5], sh.accw[6]);
-        if (sh.accw[7] != 0 || s128.hi < ((uint64_t)1 << 32)) {   // max is -Inf / NaN, or NaN weights: degenerate
-            h.s = llpf_u2d(0x7ff8000000000000ULL);
-            h.e2 = h.s;
-            h.status = LLPF_ERR_DEGENERATE;
-        } else {
-            h.s = llpf_fix96_to_double(llpf_fix96_minus_one(s128));     // sum_all_but: exact, one rounding
-            h.e2 = sc->e2_valid ? llpf_fix96_to_double(e128) : -1.0;    // -1: not accumulated (threshold 1: not needed)
-        }
-        h.uniform = 0;
-        h.dr = h.status ? 0 : decide_resample(b.thr, Nd, h.s, h.e2);
-        if (tile == 0 && threadIdx.x == 0) {
-            double ess;
-            if (h.status) { l = h.s; inv = h.s; ll = h.s; ess = h.s; }
-            else {
-                l = llpf_log1p_nonneg(h.s);
-                inv = 1.0 / (h.s + 1.0);
-                ll = l + h.m;
-                ess = h.e2 > 0.0 ? ((h.s + 1.0) * (h.s + 1.0)) / h.e2 : -1.0;
+        const bool bad = sh.accw[7] != 0;
+        if (h.fast) {
+            h.a = sc->off_next;                                   // published by the weighting kernel that filled this slot
+            if (bad || s128.hi < ((uint64_t)1 << 22)) {           // sum exp(w - bound) < 2^-10, or NaN weights
+                h.status = RES_STATUS_FALLBACK;
+                h.stot = 0.0;
+            } else {
+                h.stot = llpf_fix96_to_double(s128);
             }
-            sc->m = h.m; sc->s = h.s; sc->l = l; sc->inv = inv; sc->ll = ll; sc->ess = ess; sc->e2 = h.e2;
-            sc->K = a.K;
-            sc->uniform = 0;
-            sc->norm_pending = a.keep_norm ? 0 : 1;
-            if (h.status) sc->status = h.status;
-            sc->do_resample = h.dr;
-            if (a.accumulate) sc->ll_total = sc->ll_total + ll;
-            if (a.ll_steps) a.ll_steps[(size_t)a.k * b.F + f] = ll;
-            sh.dval[0] = inv;
+        } else {
+            h.a = h.mtrue;
+            if (bad || s128.hi < ((uint64_t)1 << 32)) {           // max is -Inf / NaN, or NaN weights: degenerate
+                h.stot = llpf_u2d(0x7ff8000000000000ULL);
+                h.s = h.stot;
+                h.status = LLPF_ERR_DEGENERATE;
+            } else {
+                h.s = llpf_fix96_to_double(llpf_fix96_minus_one(s128));     // sum_all_but: exact, one rounding
+                h.stot = h.s + 1.0;
+            }
+        }
+        h.e2 = sc->e2_valid ? llpf_fix96_to_double(e128) : -1.0;  // -1: not accumulated (threshold 1: not needed)
+        h.uniform = 0;
+        h.dr = h.status ? 0 : decide_resample(b.thr, Nd, h.stot, h.e2);
+        if (tile == 0 && threadIdx.x == 0) {
+            if (h.status == RES_STATUS_FALLBACK) {
+                sc->fallback = 1;
+                sc->fb_step = a.k;
+                *b.bank_flag = (uint32_t)(a.k + 1);
+            } else {
+                double l, inv, ll, ess;
+                if (h.status) { l = h.stot; inv = h.stot; ll = h.stot; ess = h.stot; }
+                else {
+                    l = head_log(h);
+                    inv = 1.0 / h.stot;
+                    ll = l + h.a;
+                    ess = h.e2 > 0.0 ? (h.stot * h.stot) / h.e2 : -1.0;
+                }
+                sc->m = h.a; sc->mtrue = h.mtrue; sc->s = h.s; sc->stot = h.stot; sc->l = l; sc->inv = inv; sc->ll = ll;
+                sc->ess = ess; sc->e2 = h.e2; sc->fast = h.fast;
+                sc->wmax = (h.mtrue - h.a) - l;                   // normalised weight of the best particle
+                sc->K = a.K;
+                sc->uniform = 0;
+                sc->norm_pending = a.keep_norm ? 0 : 1;
+                if (a.keep_norm) sc->wmax = h.mtrue;              // set_weights: w stays as installed
+                if (h.status) sc->status = h.status;
+                sc->do_resample = h.dr;
+                if (a.accumulate) sc->ll_total = sc->ll_total + ll;
+                if (a.ll_steps) a.ll_steps[(size_t)a.k * b.F + f] = ll;
+                sh.dval[0] = inv;
+            }
         }
         if (!h.status) h.status = sc->status;          // sticky until reset! (written above only when non-zero)
     } else {
         // predict! without a preceding correct! in this launch sequence: decide from the stored state
-        h.m = sc->m; h.s = sc->s; h.e2 = sc->e2; h.status = sc->status; h.uniform = (SRC == SRC_FILTER) ? sc->uniform : 0;
+        h.a = sc->m; h.mtrue = sc->mtrue; h.s = sc->s; h.stot = sc->stot; h.e2 = sc->e2; h.fast = sc->fast;
+        h.status = sc->status; h.uniform = (SRC == SRC_FILTER) ? sc->uniform : 0;
         if (h.uniform) {
             const double wev = 1.0 / Nd;
             const double ess = 1.0 / (Nd * (wev * wev));
@@ -809,19 +966,20 @@ DEV ResHead res_head(const BankDev& b, const ResArgs& a, int f, int tile, ResSha
             h.prefix = (uint64_t)before * Qc;
             h.tot = (uint64_t)b.N * Qc;
         } else {
-            h.dr = h.status ? 0 : decide_resample(b.thr, Nd, h.s, h.e2);
+            h.dr = h.status ? 0 : decide_resample(b.thr, Nd, h.stot, h.e2);
         }
         if (SRC == SRC_FILTER && tile == 0 && threadIdx.x == 0 && !a.only_bins) sc->do_resample = h.dr;
     }
 
     // weighted_mean output (fixed-order fp64 sum of the tile partials; tile 0 only)
-    if (fin && a.xmean && tile == 0) {
+    if (fin && a.xmean && tile == 0 && !h.status) {
         __syncthreads();
         const double invb = sh.dval[0];
-        const double* xp = b.xmpart + (size_t)f * b.P2 * MAXD;
+        const double* xp = b.xmpart + (size_t)f * b.P1 * MAXD;
+        const int nparts = sc->xm_parts;
         for (int d = 0; d < b.nx; ++d) {
             double accx = 0.0;
-            for (int p = threadIdx.x; p < b.P2; p += BLOCK) accx = accx + xp[(size_t)p * MAXD + d];
+            for (int p = threadIdx.x; p < nparts; p += BLOCK) accx = accx + xp[(size_t)p * MAXD + d];
             accx = wave_sum_f64(accx);
             __syncthreads();
             if (lane == 0) sh.red[wvid][2] = llpf_d2u(accx);
@@ -925,6 +1083,8 @@ __global__ __launch_bounds__(BLOCK) void k_resample(BankDev b, ResArgs a) {
     __shared__ ResShared sh;
     const int f = blockIdx.y;
     const int tile = blockIdx.x;
+    if (SRC == SRC_FILTER && run_is_stopped(b, a.k)) return;
+    if (SRC == SRC_FILTER && (a.only_fallback ? !b.scal[f].fallback : (b.scal[f].fallback != 0))) return;
     const uint64_t* __restrict__ qsrc = b.quanta + (size_t)f * b.Ns;
     const int64_t ib = (int64_t)tile * TILE + (int64_t)threadIdx.x * NORM_IPT;
     ulonglong2 qv[NORM_IPT / 2];
@@ -973,10 +1133,12 @@ struct PropCtx {
     double* w;
     uint32_t k0, k1;
     int ablate;
+    double off;            // bound of the new weights (offset of their exp-sums)
+    uint64_t* qnext;       // quanta of the new weights
     // propagate output o from source src with previous log-weight wprev; returns the new log-weight
-    DEV double one(int64_t src, int64_t o, double wprev, bool& bad) const {
+    DEV double one(int64_t src, int64_t o, double wprev, bool& bad, double* xs) const {
         const int64_t Ns = b.Ns;
-        double xp[NX], fx[NX], xi[NX], nz[NX], xs[NX];
+        double xp[NX], fx[NX], xi[NX], nz[NX];
 #pragma unroll
         for (int d = 0; d < NX; ++d) xp[d] = xc[(size_t)d * Ns + src];
 #ifdef LLPF_DEVTOOLS   /* ablation switches for performance experiments (results invalid); not in production builds */
@@ -1015,15 +1177,43 @@ struct PropCtx {
     }
 };
 
-template <class Model, int NX, int NY, bool WEIGHT>
+// per-thread running sum of quanta keyed by destination tile; flushed to LDS (first 8 tiles of the block's output
+// range) or straight to the global tile sums (heavier blocks) whenever the tile changes
+struct TileSum {
+    int64_t tcur;
+    uint64_t run;
+    DEV void init() { tcur = -1; run = 0; }
+    DEV void flush(uint64_t* sh_tq, uint64_t* tq_global, int64_t tbase) {
+        if (run) {
+            const int64_t idx = tcur - tbase;
+            if (idx >= 0 && idx < 8) atomicAdd(reinterpret_cast<unsigned long long*>(sh_tq + idx), (unsigned long long)run);
+            else atomicAdd(reinterpret_cast<unsigned long long*>(tq_global + tcur), (unsigned long long)run);
+        }
+        run = 0;
+    }
+    DEV void add(int64_t o, uint64_t q, uint64_t* sh_tq, uint64_t* tq_global, int64_t tbase) {
+        const int64_t t = o >> 10;
+        if (t != tcur) { flush(sh_tq, tq_global, tbase); tcur = t; }
+        run += q;
+    }
+};
+static_assert(TILE == 1024, "TileSum assumes 1024-particle tiles");
+
+template <class Model, int NX, int NY, bool WEIGHT, bool ACC>
 __global__ __launch_bounds__(BLOCK) void k_resprop(BankDev b, const ModelD* __restrict__ models, ResArgs a, StepArgs st) {
     __shared__ ResShared sh;
     __shared__ double sm_max[BLOCK / 64];
+    __shared__ uint64_t sm_acc[BLOCK / 64][5];
+    __shared__ uint64_t sh_tq[8];
+    __shared__ double sm_x[BLOCK / 64][MAXD];
     const int f = blockIdx.y;
     const int tile = blockIdx.x;
     const int64_t Ns = b.Ns, N = b.N;
     const ModelD* md = models + f;
     FilterScal* sc = b.scal + f;
+    if (run_is_stopped(b, a.k)) return;
+    if (a.only_fallback ? !sc->fallback : (sc->fallback != 0)) return;
+    if (threadIdx.x < 8) sh_tq[threadIdx.x] = 0;
     const uint64_t* __restrict__ qsrc = b.quanta + (size_t)f * Ns;
     const int64_t ib = (int64_t)tile * TILE + (int64_t)threadIdx.x * NORM_IPT;
     ulonglong2 qv[NORM_IPT / 2];
@@ -1042,7 +1232,7 @@ __global__ __launch_bounds__(BLOCK) void k_resprop(BankDev b, const ModelD* __re
 #pragma unroll
     for (int k = 0; k < NY; ++k) y[k] = (WEIGHT && st.has_y) ? st.y[k] : 0.0;
     PropCtx<Model, NX, NY, WEIGHT> pc{b, model, md, st, y, b.xcur + (size_t)f * NX * Ns, b.xnext + (size_t)f * NX * Ns,
-                                      b.w + (size_t)f * Ns, sc->k0, sc->k1, a.ablate};
+                                      b.w + (size_t)f * Ns, sc->k0, sc->k1, a.ablate, 0.0, b.quanta_next + (size_t)f * Ns};
     int32_t* anc = b.anc + (size_t)f * Ns;
     double bmax = -LLPF_INF;
     bool bad = false;
@@ -1057,6 +1247,14 @@ __global__ __launch_bounds__(BLOCK) void k_resprop(BankDev b, const ModelD* __re
     int64_t first, last;
     int32_t c_end = 0;
     double l = 0.0;
+    WeightAcc wacc;
+    TileSum ts;
+    wacc.init();
+    ts.init();
+    double xm[NX];
+#pragma unroll
+    for (int d = 0; d < NX; ++d) xm[d] = 0.0;
+    uint64_t* tq_next = tileq_slot(b, st.parity, f);
     if (res) {
         int32_t c_start;
         if (b.strategy == LLPF_RESAMPLE_SYSTEMATIC) res_counts<LLPF_RESAMPLE_SYSTEMATIC>(b, a, f, tile, h, qv, sh, c_start, c_end);
@@ -1064,10 +1262,15 @@ __global__ __launch_bounds__(BLOCK) void k_resprop(BankDev b, const ModelD* __re
         first = c_start;
         last = (tile == b.P2 - 1) ? (int64_t)a.M : (int64_t)c_end;
     } else {
-        l = llpf_log1p_nonneg(h.s);
+        l = head_log(h);
         first = (int64_t)tile * TILE;
         last = first + TILE;
     }
+    {   // bound of the weights produced below: max of the previous (normalised) weights + the density's peak
+        const double wmx = res ? b.log1N : (h.mtrue - h.a) - l;
+        pc.off = (WEIGHT && st.has_y) ? wmx + md->dg.c0 : wmx;
+    }
+    const int64_t tbase = first >> 10;
     LLPF_STAMP(2);
     if (a.dbg && threadIdx.x == 0 && f == 0) a.dbg[(size_t)tile * 8 + 5] = (uint64_t)(last - first);
 #pragma unroll 1
@@ -1083,15 +1286,41 @@ __global__ __launch_bounds__(BLOCK) void k_resprop(BankDev b, const ModelD* __re
             else src = anc_ident_prev ? o : (int64_t)anc[o];
             anc[o] = (int32_t)src;
         } else if (WEIGHT) {
-            wprev = (pc.w[o] - h.m) - l;                               // lazy w .-= offset ; w .-= log1p(s)
+            wprev = (pc.w[o] - h.a) - l;                               // lazy w .-= offset ; w .-= log(sum)
         }
-        bmax = llpf_fmax(bmax, pc.one(src, o, wprev, bad));
+        double xs[NX];
+        const double wv = pc.one(src, o, wprev, bad, xs);
+        bmax = llpf_fmax(bmax, wv);
+        if (WEIGHT && ACC) {
+            double e;
+            const uint64_t q = wacc.add(wv, pc.off, st.K, st.need_e2 != 0, &e);
+            pc.qnext[o] = q;
+            ts.add(o, q, sh_tq, tq_next, tbase);
+            if (st.want_xmean) {
+#pragma unroll
+                for (int d = 0; d < NX; ++d) xm[d] = xm[d] + xs[d] * e;
+            }
+        }
     }
+    if (WEIGHT && ACC) ts.flush(sh_tq, tq_next, tbase);
     LLPF_STAMP(3);
     if (WEIGHT) {
         const double r = block_max(bmax, sm_max);
         const int anybad = __syncthreads_or(bad ? 1 : 0);
         if (threadIdx.x == 0) acc_max(b.acc + (size_t)f * ACC_WORDS, st.parity, r, anybad != 0);
+        if (ACC) {
+            wacc.flush(b.acc + (size_t)f * ACC_WORDS, st.parity, st.need_e2 != 0, sm_acc);
+            __syncthreads();
+            if (threadIdx.x < 8 && sh_tq[threadIdx.x])
+                atomicAdd(reinterpret_cast<unsigned long long*>(tq_next + tbase + threadIdx.x), (unsigned long long)sh_tq[threadIdx.x]);
+            if (st.want_xmean) block_store_xm<NX>(xm, b.xmpart + ((size_t)f * b.P1 + tile) * MAXD, sm_x);
+        }
+        if (tile == 0 && threadIdx.x == 0) {
+            if (ACC) sc->xm_parts = b.P2;
+            sc->off_next = pc.off;
+            sc->e2_valid = st.need_e2;
+            sc->u_sys = llpf_uniform_step(st.next_step, LLPF_STREAM_RESAMPLE, sc->k0, sc->k1);
+        }
     }
     __syncthreads();
     LLPF_STAMP(4);
@@ -1123,7 +1352,7 @@ __global__ __launch_bounds__(BLOCK) void k_qpart(BankDev b, int K) {
     if (threadIdx.x == 0) {
         uint64_t q = 0;
         for (int k = 0; k < BLOCK / 64; ++k) q += sm_w[k];
-        b.tileq[(size_t)f * b.P2 + tile] = q;
+        tileq_slot(b, 0, f)[tile] = q;      // scratch bank of the standalone resample(we): slot 0
     }
 }
 
@@ -1304,19 +1533,19 @@ hipError_t launch_max(const BankDev& b, int parity, hipStream_t s) {
 }
 
 template <int NX, bool XMEAN>
-static void launch_norm_e2(const BankDev& b, int parity, int need_e2, uint32_t step, hipStream_t s) {
+static void launch_norm_e2(const BankDev& b, int parity, int need_e2, uint32_t step, int only_fallback, int bound, int64_t kstep, hipStream_t s) {
     dim3 g((unsigned)b.P2, (unsigned)b.F, 1);
     const int K = llpf_qbits(b.N);
-    if (need_e2) hipLaunchKernelGGL((k_norm<NX, XMEAN, true>), g, dim3(BLOCK), 0, s, b, K, parity, step);
-    else hipLaunchKernelGGL((k_norm<NX, XMEAN, false>), g, dim3(BLOCK), 0, s, b, K, parity, step);
+    if (need_e2) hipLaunchKernelGGL((k_norm<NX, XMEAN, true>), g, dim3(BLOCK), 0, s, b, K, parity, step, only_fallback, bound, kstep);
+    else hipLaunchKernelGGL((k_norm<NX, XMEAN, false>), g, dim3(BLOCK), 0, s, b, K, parity, step, only_fallback, bound, kstep);
 }
-hipError_t launch_norm(const BankDev& b, int parity, int want_xmean, int need_e2, uint32_t step, hipStream_t s) {
-    if (!want_xmean) { launch_norm_e2<0, false>(b, parity, need_e2, step, s); return hipGetLastError(); }
+hipError_t launch_norm(const BankDev& b, int parity, int want_xmean, int need_e2, uint32_t step, int only_fallback, int bound, int64_t kstep, hipStream_t s) {
+    if (!want_xmean) { launch_norm_e2<0, false>(b, parity, need_e2, step, only_fallback, bound, kstep, s); return hipGetLastError(); }
     switch (b.nx) {
-        case 1: launch_norm_e2<1, true>(b, parity, need_e2, step, s); break;
-        case 2: launch_norm_e2<2, true>(b, parity, need_e2, step, s); break;
-        case 3: launch_norm_e2<3, true>(b, parity, need_e2, step, s); break;
-        case 4: launch_norm_e2<4, true>(b, parity, need_e2, step, s); break;
+        case 1: launch_norm_e2<1, true>(b, parity, need_e2, step, only_fallback, bound, kstep, s); break;
+        case 2: launch_norm_e2<2, true>(b, parity, need_e2, step, only_fallback, bound, kstep, s); break;
+        case 3: launch_norm_e2<3, true>(b, parity, need_e2, step, only_fallback, bound, kstep, s); break;
+        case 4: launch_norm_e2<4, true>(b, parity, need_e2, step, only_fallback, bound, kstep, s); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -1350,8 +1579,9 @@ hipError_t launch_resample(const BankDev& b, const ResArgs& a0, hipStream_t s) {
 template <class Model, int NX, int NY>
 static hipError_t launch_resprop_t(const BankDev& b, const ResArgs& a, const StepArgs& st, int weight, hipStream_t s) {
     dim3 g((unsigned)b.P2, (unsigned)b.F, 1);
-    if (weight) hipLaunchKernelGGL((k_resprop<Model, NX, NY, true>), g, dim3(BLOCK), 0, s, b, b.models, a, st);
-    else hipLaunchKernelGGL((k_resprop<Model, NX, NY, false>), g, dim3(BLOCK), 0, s, b, b.models, a, st);
+    if (weight && st.accumulate) hipLaunchKernelGGL((k_resprop<Model, NX, NY, true, true>), g, dim3(BLOCK), 0, s, b, b.models, a, st);
+    else if (weight) hipLaunchKernelGGL((k_resprop<Model, NX, NY, true, false>), g, dim3(BLOCK), 0, s, b, b.models, a, st);
+    else hipLaunchKernelGGL((k_resprop<Model, NX, NY, false, false>), g, dim3(BLOCK), 0, s, b, b.models, a, st);
     return hipGetLastError();
 }
 template <int NX>

@@ -273,7 +273,10 @@ static double sum_all_but(double* we, int64_t n, int64_t i) {
 
 /* device-order core: from raw log-weights w (unchanged) produce e_i = exp(w_i - m) and the exact
  * fixed-point sums; returns s = sum_{i != argmax} e_i rounded once */
-typedef struct { double m, s, l, inv, e2; uint64_t totQ; int K; } devnorm;
+/* weights are held as raw values plus a pending normalisation (a, b): w_norm = (w - a) - b, we = exp(w - a) * inv.
+ *   exact form: a = max w, stot = fl(s + 1) with s = sum_{i != argmax} exp(w_i - a), b = log1p(s)   (utils.jl:18-27)
+ *   fast  form: a = analytic upper bound of max w, stot = sum_i exp(w_i - a), b = log(stot)          (see dev_norm_bound) */
+typedef struct { double m, s, l, inv, e2, stot, mtrue; uint64_t totQ; int K; int fast; } devnorm;
 
 static void dev_expsum(const double* w, double* e, int64_t n, devnorm* o) {
     double m = w[0];
@@ -294,8 +297,50 @@ static void dev_expsum(const double* w, double* e, int64_t n, devnorm* o) {
     if (S.hi >= ((uint64_t)1 << 32)) o->s = llpf_fix96_to_double(llpf_fix96_minus_one(S));
     else o->s = llpf_u2d(0x7ff8000000000000ULL);              /* max is -Inf/NaN: degenerate */
     o->l = llpf_log1p_nonneg(o->s);
-    o->inv = 1.0 / (o->s + 1.0);
+    o->stot = o->s + 1.0;
+    o->inv = 1.0 / o->stot;
     o->e2 = llpf_fix96_to_double(E2);
+    o->mtrue = m;
+    o->fast = 0;
+}
+
+/* Device order, weighting path: normalisation against an ANALYTIC bound instead of the maximum, so that the GPU
+ * needs no separate max pass between the weighting and the sums (one launch per timestep).
+ * For the built-in Gaussian measurement densities logpdf <= c0, hence every new weight w_i = w_prev_i + logpdf_i
+ * satisfies w_i <= off := max(w_prev) + c0 (also after rounding: fl is monotone), and e_i = exp(w_i - off) <= 1.
+ * If the exact fixed-point sum S = sum e_i is at least 2^-10 (the particle cloud is not more than ~3.7 sigma from
+ * the measurement in likelihood terms) the offset `off` replaces the maximum everywhere (logsumexp is invariant to the
+ * offset; only roundings differ, by ~1e-16): ll = off + log(S), w_norm = (w - off) - log(S), we = e / S,
+ * ESS = S^2 / sum(e^2), resampling quanta floor(e 2^K).  Otherwise the exact-max form above is used for this step. */
+static void dev_norm_bound(const double* w, double* e, int64_t n, double off, devnorm* o) {
+    double m = w[0];
+    for (int64_t i = 1; i < n; ++i) m = llpf_fmax(m, w[i]);
+    llpf_u128 S = {0, 0}, E2 = {0, 0};
+    uint64_t Q = 0;
+    int K = llpf_qbits(n);
+    int bad = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        double ei = llpf_exp_le0(w[i] - off);
+        if (ei != ei) bad = 1;
+        e[i] = ei;
+        S = llpf_u128_add(S, llpf_fix96_unit(ei));
+        E2 = llpf_u128_add(E2, llpf_fix96_unit(ei * ei));
+        Q += llpf_q64_unit(ei, K);
+    }
+    if (bad || S.hi < ((uint64_t)1 << 22)) {         /* S < 2^-10 (or NaN weights): exact-max form for this step */
+        dev_expsum(w, e, n, o);
+        return;
+    }
+    o->m = off;
+    o->K = K;
+    o->totQ = Q;
+    o->stot = llpf_fix96_to_double(S);
+    o->s = o->stot - 1.0;
+    o->l = llpf_log(o->stot);
+    o->inv = 1.0 / o->stot;
+    o->e2 = llpf_fix96_to_double(E2);
+    o->mtrue = m;
+    o->fast = 1;
 }
 
 /* ll = logsumexp!(w, we [, maxw]) — src/utils.jl:18-27 */
@@ -435,9 +480,11 @@ struct orc_filter {
     int last_resampled;
     int64_t resample_count;
     int degenerate;
+    int64_t n_exact_steps;      /* device order: weightings whose bound test failed (exact-max form used) */
     /* device-order scalars of the last normalisation */
     devnorm dn;
     int dn_valid;
+    double wmax;                /* max of the current (normalised / uniform / installed) log-weights: the bound's input */
     double *xi_buf, *U_buf;
 };
 
@@ -452,6 +499,7 @@ static void fill_uniform_weights(orc_filter* f, double wval) {
     double wev = 1.0 / (double)f->N;
     for (int64_t i = 0; i < f->N; ++i) { f->w[i] = wval; f->we[i] = wev; }
     f->dn_valid = 0;
+    f->wmax = wval;
 }
 
 static void init_particles(orc_filter* f, const double* xi) {
@@ -513,17 +561,19 @@ void orc_reset(orc_filter* f) {
 }
 
 /* normalisation of the current raw log-weights in the filter's order */
-static double filter_logsumexp(orc_filter* f) {
+static double filter_logsumexp(orc_filter* f, double off) {
     if (f->order == ORC_ORDER_DEVICE) {
-        dev_expsum(f->w, f->e, f->N, &f->dn);
+        dev_norm_bound(f->w, f->e, f->N, off, &f->dn);
         f->dn_valid = 1;
+        if (!f->dn.fast) f->n_exact_steps++;
         for (int64_t i = 0; i < f->N; ++i) {
             f->we[i] = f->e[i] * f->dn.inv;
             f->w[i] = (f->w[i] - f->dn.m) - f->dn.l;
         }
-        f->maxw = f->dn.m;
+        f->maxw = f->dn.mtrue;
+        f->wmax = (f->dn.mtrue - f->dn.m) - f->dn.l;          /* the normalised weight of the best particle */
         double ll = f->dn.l + f->dn.m;
-        if (!(ll == ll) || f->dn.m == -LLPF_INF) f->degenerate = 1;
+        if (!(ll == ll) || f->dn.mtrue == -LLPF_INF) f->degenerate = 1;
         return ll;
     }
     double ll = orc_logsumexp(f->w, f->we, f->N, ORC_ORDER_REFERENCE, &f->maxw);
@@ -535,7 +585,9 @@ static double filter_logsumexp(orc_filter* f) {
  * :226-239 (Advanced: w[i] += measurement_likelihood(x[i],u,y,p,t), which for the built-in models is
  * logpdf(dg, y - g(x))) */
 double orc_correct(orc_filter* f, const double* u, const double* y, double t) {
-    if (y != NULL && y[0] == y[0]) {                           /* any(ismissing, y) && return w */
+    const int has_y = (y != NULL && y[0] == y[0]);
+    const double off = has_y ? f->wmax + f->dg.c0 : f->wmax;   /* device order: upper bound of the new weights */
+    if (has_y) {                                               /* any(ismissing, y) && return w */
         for (int64_t i = 0; i < f->N; ++i) {
             double g[MAXD], v[MAXD];
             orc_measurement(&f->cfg.model, f->x + i * f->nx, u, t, g);
@@ -543,13 +595,13 @@ double orc_correct(orc_filter* f, const double* u, const double* y, double t) {
             f->w[i] += gauss_logpdf(&f->dg, v);
         }
     }
-    return filter_logsumexp(f);
+    return filter_logsumexp(f, off);
 }
 
 static double filter_ess(const orc_filter* f) {
     if (f->order == ORC_ORDER_DEVICE && f->dn_valid) {
         /* 1/sum(we^2) with we = e/(s+1): (s+1)^2 / sum(e^2), sum(e^2) exact in fixed point */
-        return ((f->dn.s + 1.0) * (f->dn.s + 1.0)) / f->dn.e2;
+        return (f->dn.stot * f->dn.stot) / f->dn.e2;
     }
     if (f->order == ORC_ORDER_DEVICE) {
         /* uniform weights: we = 1/N exactly representable product N * (1/N)^2 */
@@ -566,8 +618,7 @@ int orc_shouldresample(const orc_filter* f) {
     double th = (double)f->N * f->cfg.resample_threshold;
     if (f->order == ORC_ORDER_DEVICE && f->dn_valid) {
         /* the same test without the division: (s+1)^2 < N thr sum(e^2) */
-        double sp1 = f->dn.s + 1.0;
-        return sp1 * sp1 < th * f->dn.e2;
+        return f->dn.stot * f->dn.stot < th * f->dn.e2;
     }
     return filter_ess(f) < th;
 }
@@ -698,6 +749,7 @@ void orc_set_weights(orc_filter* f, const double* w) {
         f->dn_valid = 1;
         for (int64_t i = 0; i < n; ++i) f->we[i] = f->e[i] * f->dn.inv;
         f->maxw = f->dn.m;
+        f->wmax = f->dn.m;                                     /* w is kept as installed */
     } else {
         double* tmp = (double*)malloc(8 * (size_t)n);
         memcpy(tmp, w, 8 * (size_t)n);
@@ -710,6 +762,7 @@ int orc_last_resampled(const orc_filter* f) { return f->last_resampled; }
 double orc_maxw(const orc_filter* f) { return f->maxw; }
 int64_t orc_resample_count(const orc_filter* f) { return f->resample_count; }
 int orc_degenerate(const orc_filter* f) { return f->degenerate; }
+int64_t orc_exact_steps(const orc_filter* f) { return f->n_exact_steps; }
 
 double orc_gauss_logpdf(const llpf_gaussian* g, const double* x) {
     gaussd d;

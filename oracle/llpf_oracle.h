@@ -70,6 +70,7 @@ int    orc_last_resampled(const orc_filter* f);
 double orc_maxw(const orc_filter* f);
 int64_t orc_resample_count(const orc_filter* f);
 int    orc_degenerate(const orc_filter* f);
+int64_t orc_exact_steps(const orc_filter* f);   /* device order: weightings normalised in exact-max form (bound test failed) */
 
 /* array primitives */
 double orc_logsumexp(double* w, double* we, int64_t n, int order, double* maxw);

@@ -56,6 +56,8 @@ def load():
     lib.orc_resample_count.restype = C.c_int64
     lib.orc_resample_count.argtypes = [C.c_void_p]
     lib.orc_degenerate.argtypes = [C.c_void_p]
+    lib.orc_exact_steps.restype = C.c_int64
+    lib.orc_exact_steps.argtypes = [C.c_void_p]
     lib.orc_logsumexp.restype = C.c_double
     lib.orc_logsumexp.argtypes = [_dp, _dp, C.c_int64, C.c_int, _dp]
     lib.orc_expnormalize.argtypes = [_dp, _dp, C.c_int64]
@@ -220,6 +222,9 @@ class OracleFilter:
 
     def resample_count(self):
         return self.L.orc_resample_count(self.h)
+
+    def exact_steps(self):
+        return self.L.orc_exact_steps(self.h)
 
     def weighted_mean(self):
         a = np.empty(self.nx)

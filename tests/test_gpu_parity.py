@@ -477,3 +477,101 @@ def test_bank_shares_of_a_sharded_sweep_match_single_bank():
         b.reset()
         got[own] = b.run(U, Y, 1.0)["ll"]
     assert np.array_equal(got, ll_whole)
+
+
+@pytest.mark.parametrize("thr", [0.1, 1.0])
+@pytest.mark.parametrize("N", [500, 30000])
+def test_outlier_measurements_take_the_exact_form(thr, N):
+    """Measurements far outside the particle cloud make sum exp(w - bound) < 2^-10: those steps are redone in the
+    exact-max form (device) / evaluated in it (oracle); every bit still agrees, and so does the reference order."""
+    model = M.lg_c1_model()
+    _, U, Y = M.simulate_lg(model, 60)
+    Y[0] += 25.0                      # already the first correct!
+    Y[20] += 40.0
+    Y[21] -= 35.0                     # two consecutive steps
+    Y[45] += 12.0
+    cfg = _cfg(model, N, thr=thr)
+    g = _capi.FilterHandle(cfg)
+    o = ob.OracleFilter(cfg, ob.ORDER_DEVICE)
+    r = ob.OracleFilter(cfg, ob.ORDER_REFERENCE)
+    for h in (g, o, r):
+        h.reset()
+    rg = g.run(U, Y, 0.0, ll_steps=True, xmean=True)
+    ro = o.run(U, Y, 0.0, ll_steps=True, xmean=True)
+    rr = r.run(U, Y, 0.0, ll_steps=True)
+    assert o.exact_steps() >= 3
+    assert np.array_equal(rg["ll_steps"].view(np.uint64), ro["ll_steps"].view(np.uint64))
+    np.testing.assert_allclose(rg["xmean"], ro["xmean"], rtol=1e-11, atol=1e-12)
+    _compare_state(g, o)
+    assert np.max(np.abs(rg["ll_steps"] - rr["ll_steps"])) <= 1e-9 * np.max(np.abs(rr["ll_steps"]))
+    # single-step entry points and the history path take the same decisions
+    g2 = _capi.FilterHandle(cfg)
+    g2.reset()
+    lls = []
+    for k in range(60):
+        lls.append(g2.correct(U[k], Y[k], float(k)))
+        g2.predict(U[k], float(k))
+    assert np.array_equal(np.array(lls).view(np.uint64), rg["ll_steps"].view(np.uint64))
+    g3 = _capi.FilterHandle(cfg)
+    g3.reset()
+    r3 = g3.run(U, Y, 0.0, history=True)
+    assert r3["ll"] == rg["ll"]
+    _compare_state(g3, o)
+
+
+def test_bank_with_one_outlier_filter():
+    """In a bank only the filter whose bound test fails is redone; the others are untouched by the redo."""
+    models = [M.lg_test_model(s) for s in (0.05, 0.1, 0.2, 0.4)]
+    _, U, Y = M.simulate_lg(models[1], 40)
+    Y[17] += 9.0                      # an outlier that is much worse for the small-noise filters
+    N = 4000
+    bank = _capi.BankHandle(_cfg(models[0], N, thr=0.1, seed=900), models)
+    bank.reset()
+    rb = bank.run(U, Y, 1.0, ll_steps=True)
+    n_exact = 0
+    for k, mk in enumerate(models):
+        cfg = _cfg(mk, N, thr=0.1, seed=900 + k)
+        o = ob.OracleFilter(cfg, ob.ORDER_DEVICE)
+        o.reset()
+        ro = o.run(U, Y, 1.0, ll_steps=True)
+        n_exact += o.exact_steps()
+        assert np.array_equal(ro["ll_steps"].view(np.uint64), rb["ll_steps"][:, k].copy().view(np.uint64)), k
+    assert n_exact >= 1
+
+
+@pytest.mark.parametrize("schedule", ["merged", "split"])
+def test_schedules_are_bit_identical(schedule, monkeypatch):
+    """The exp-sums of new weights are formed either inside the weighting phase ("merged": one launch per step) or
+    by a streaming normalise launch in the same bound-offset form ("split": chosen for large banks); both must give
+    the oracle's bits, including a step whose bound test fails and is redone in exact-max form."""
+    monkeypatch.setenv("LLPF_SCHEDULE", schedule)
+    models = [M.lg_test_model(s) for s in (0.05, 0.1, 0.2, 0.4)]
+    _, U, Y = M.simulate_lg(models[1], 40)
+    Y[17] += 9.0
+    N = 5000
+    for strategy in (0, 1):
+        cfg0 = _cfg(models[0], N, thr=0.5, seed=1200)
+        cfg0.resampling_strategy = strategy
+        bank = _capi.BankHandle(cfg0, models)
+        bank.reset()
+        rb = bank.run(U, Y, 1.0, ll_steps=True)
+        n_exact = 0
+        for k, mk in enumerate(models):
+            cfg = _cfg(mk, N, thr=0.5, seed=1200 + k)
+            cfg.resampling_strategy = strategy
+            o = ob.OracleFilter(cfg, ob.ORDER_DEVICE)
+            o.reset()
+            ro = o.run(U, Y, 1.0, ll_steps=True)
+            n_exact += o.exact_steps()
+            assert np.array_equal(ro["ll_steps"].view(np.uint64), rb["ll_steps"][:, k].copy().view(np.uint64)), (strategy, k)
+        assert n_exact >= 1
+    # single filter, final state bit-exact
+    cfg = _cfg(models[2], 3000, thr=1.0, seed=77)
+    g = _capi.FilterHandle(cfg)
+    o = ob.OracleFilter(cfg, ob.ORDER_DEVICE)
+    g.reset(); o.reset()
+    rg = g.run(U, Y, 0.0, ll_steps=True, xmean=True)
+    ro = o.run(U, Y, 0.0, ll_steps=True, xmean=True)
+    assert np.array_equal(rg["ll_steps"].view(np.uint64), ro["ll_steps"].view(np.uint64))
+    np.testing.assert_allclose(rg["xmean"], ro["xmean"], rtol=1e-9, atol=1e-11)   # output-only fp64 sum, never fed back
+    _compare_state(g, o)
