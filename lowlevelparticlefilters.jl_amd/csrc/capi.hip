@@ -169,6 +169,7 @@ struct Bank {
         b.xcur = d_x[cur]; b.xnext = d_x[cur ^ 1];
         b.w = d_w; b.anc = d_anc; b.acc = d_acc; b.quanta = d_quanta[qcur]; b.quanta_next = d_quanta[qcur ^ 1]; b.tileq = d_tileq;
         b.bank_flag = d_flag; b.xmpart = d_xmpart;
+        b.anc_slot = (int32_t)(n_predict & 1u); b.pad0 = 0;
         return b;
     }
 };
@@ -209,6 +210,10 @@ static int scal_upload(Bank& b, const std::vector<FilterScal>& h) {
 static void set_keys(Bank& b, std::vector<FilterScal>& h, uint64_t seed) {
     b.seed = seed;
     b.n_reset = 0;
+    for (int f = 0; f < b.F; ++f) {
+        const int32_t cur = h[f].anc_ident_s[b.n_predict & 1u];     // the entry index restarts with the step counter
+        h[f].anc_ident_s[0] = cur; h[f].anc_ident_s[1] = cur;
+    }
     b.n_predict = 0;
     for (int f = 0; f < b.F; ++f) {
         const uint64_t s = seed + (uint64_t)f;
@@ -261,9 +266,10 @@ static int bank_init_particles(Bank& b, bool is_reset) {
         s.status = 0;
         s.m = 0.0; s.s = 0.0; s.l = 0.0; s.inv = 1.0; s.ll = 0.0; s.e2 = 0.0;
         s.ess = 0.0;
-        s.stot = 1.0; s.mtrue = 0.0; s.wmax = s.wconst; s.off_next = 0.0; s.fast = 0; s.fallback = 0; s.fb_step = 0; s.e2_valid = 0;
+        s.stot = 1.0; s.mtrue = 0.0; s.wmax = s.wconst; s.fast = 0; s.fallback = 0; s.fb_step = 0; s.e2_valid = 0;
+        for (int p = 0; p < ACC_NSLOT; ++p) { s.off_slot[p] = 0.0; s.u_slot[p] = 0.0; s.e2v_slot[p] = 0; }
         s.K = llpf_qbits(b.N);
-        if (!is_reset) { s.anc_ident = 1; s.last_resampled = 0; s.resample_count = 0; s.ll_total = 0.0; }
+        if (!is_reset) { s.anc_ident_s[0] = s.anc_ident_s[1] = 1; s.last_resampled = 0; s.resample_count = 0; s.ll_total = 0.0; }
     }
     CHK(scal_upload(b, h));
     HIPC(hipMemsetAsync(b.d_acc, 0, sizeof(uint64_t) * (size_t)b.F * ACC_WORDS, b.stream));
@@ -282,7 +288,8 @@ static int bank_create(const llpf_config* cfg, const llpf_model* models, int F, 
     if (cfg->struct_size != sizeof(llpf_config)) return fail(LLPF_ERR_ARG, "llpf_config.struct_size mismatch (ABI)");
     if (F < 1) return fail(LLPF_ERR_ARG, "n_filters must be >= 1");
     const llpf_model& m0 = models ? models[0] : cfg->model;
-    if (cfg->n_particles < 1 || cfg->n_particles > ((int64_t)1 << 30)) return fail(LLPF_ERR_ARG, "n_particles must be in 1..2^30");
+    if (cfg->n_particles < 1 || cfg->n_particles > ((int64_t)1 << 29) - 2 * TILE)   // 32-bit byte offsets into a particle plane
+        return fail(LLPF_ERR_ARG, "n_particles must be in 1..2^29-2048");
     if (m0.nx < 1 || m0.nx > MAXD || m0.ny < 1 || m0.ny > MAXD || m0.nu < 0 || m0.nu > MAXD) return fail(LLPF_ERR_ARG, "bad dimensions");
     if (!step_supported(m0.model_id, m0.nx, m0.ny))
         return fail(LLPF_ERR_ARG, "no kernel instantiated for this model/dimension (linear-Gaussian nx,ny in 1..4; quad-tank 4/2)");
@@ -1013,7 +1020,7 @@ int llpf_resample(int32_t device, int32_t strategy, const double* we, int64_t n,
         HIPC(hipMemcpyAsync(d_U, U, sizeof(double) * nU, hipMemcpyHostToDevice, b.stream));
         std::vector<FilterScal> s;
         CHK(scal_download(b, s));
-        s[0].uniform = 0; s[0].anc_ident = 0; s[0].status = 0; s[0].do_resample = 1;
+        s[0].uniform = 0; s[0].anc_ident_s[0] = s[0].anc_ident_s[1] = 0; s[0].status = 0; s[0].do_resample = 1;
         CHK(scal_upload(b, s));
         // ancestors are written relative to a row of stride Ns; the scratch bank has one filter, so row 0
         ResArgs ra{};

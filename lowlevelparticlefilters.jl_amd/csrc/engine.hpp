@@ -94,24 +94,23 @@ struct FilterScal {
     int32_t uniform;     // weights are uniform (after reset! / after a resampling predict!)
     int32_t norm_pending;// w holds raw values; normalised value is (w - m) - l
     int32_t do_resample; // decision of shouldresample for the next propagate
-    int32_t anc_ident;   // state.j == 1:N (last predict! did not resample)
+    int32_t anc_ident_s[2]; // state.j == 1:N (last predict! did not resample); [n_predict & 1] is current, the predict! in flight writes the other
     int32_t status;      // 0 ok, LLPF_ERR_DEGENERATE
     int32_t last_resampled;
-    int32_t pad0;
     int64_t resample_count;
     uint32_t k0, k1;     // Philox key of this filter
-    double u_sys;        // the uniform of the coming systematic resample (computed once per step)
+    double u_slot[ACC_NSLOT];   // the uniform of the systematic resample that consumes accumulator slot p (computed once per step)
     double stot;         // sum of exp(w - m) over ALL particles in the form the last normalisation used (exact form: s + 1)
     double mtrue;        // true maximum of the raw log-weights (state.maxw[]); m above is the OFFSET (bound or maximum)
     double wmax;         // maximum of the current normalised / uniform log-weights: input of the next bound
-    double off_next;     // offset (bound) the last weighting kernel used for its exp-sums
+    double off_slot[ACC_NSLOT]; // offset (bound) the weighting kernel that filled accumulator slot p used for its exp-sums
     int32_t fast;        // last normalisation used the bound-offset form
     int32_t fallback;    // a fast head found sum exp(w - bound) < 2^-10: the host must redo this step in exact form
     int64_t fb_step;     // run-step index of that head
     int32_t xm_parts;    // number of per-block partial sums in xmpart written by the last weighting / normalise kernel
     int32_t pad2;
-    int32_t e2_valid;    // sum e^2 / ESS were accumulated for the current weights (skipped when resample_threshold == 1)
-    int32_t pad1;
+    int32_t e2_valid;    // sum e^2 / ESS are known for the current (finalized) weights (skipped when resample_threshold == 1)
+    int32_t e2v_slot[ACC_NSLOT]; // sum e^2 was accumulated into accumulator slot p
 };
 
 // arguments common to the step-path kernels
@@ -140,6 +139,8 @@ struct BankDev {
     uint32_t* bank_flag; // [1] 0, or 1 + the run-step index at which some filter's bound test failed: every later
                          //     launch of the run is a no-op until the host has redone that step in exact form
     double* xmpart;      // [F][P1][MAXD]
+    int32_t anc_slot;    // n_predict & 1: index of the current FilterScal::anc_ident_s entry
+    int32_t pad0;
 };
 
 enum StepMode { MODE_WEIGHT = 0, MODE_PROP = 1, MODE_PROP_WEIGHT = 2 };

@@ -582,16 +582,16 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
             if (blockIdx.x == 0) {
                 FilterScal* scw = b.scal + f;
                 if (a.accumulate) scw->xm_parts = b.P1;
-                scw->off_next = off;
-                scw->e2_valid = a.need_e2;
-                scw->u_sys = llpf_uniform_step(a.next_step, LLPF_STREAM_RESAMPLE, k0, k1);
+                scw->off_slot[a.parity] = off;
+                scw->e2v_slot[a.parity] = a.need_e2;
+                scw->u_slot[a.parity] = llpf_uniform_step(a.next_step, LLPF_STREAM_RESAMPLE, k0, k1);
             }
         }
     }
     if (MODE != MODE_WEIGHT && blockIdx.x == 0 && threadIdx.x == 0) {
         // bookkeeping of this predict! (fields no block of this kernel reads): state.j == 1:N unless resampled
         FilterScal* scw = b.scal + f;
-        scw->anc_ident = do_res ? 0 : 1;
+        scw->anc_ident_s[b.anc_slot ^ 1] = do_res ? 0 : 1;
         scw->last_resampled = do_res;
         scw->resample_count += do_res;
     }
@@ -642,7 +642,7 @@ __global__ __launch_bounds__(BLOCK) void k_norm(BankDev b, int K, int parity, ui
         const int64_t i0 = (int64_t)tile * TILE + (int64_t)k * (BLOCK * 2) + threadIdx.x * 2;
         wv[k] = *reinterpret_cast<const double2*>(w + i0);
     }
-    const double m = bound ? b.scal[f].off_next : acc_read_max_wave(acc, parity);
+    const double m = bound ? b.scal[f].off_slot[parity] : acc_read_max_wave(acc, parity);
 
     llpf_u128 S = {0, 0}, E2 = {0, 0};
     uint64_t Q = 0, bad = 0;
@@ -710,8 +710,8 @@ __global__ __launch_bounds__(BLOCK) void k_norm(BankDev b, int K, int parity, ui
         if (NEED_E2) acc_add_u128(acc, ACC_E2(parity), e2);
         if (tile == 0) {   // the single uniform a systematic resample of this step consumes (reference: rand(), resample.jl:23)
             FilterScal* sc = b.scal + f;
-            sc->u_sys = llpf_uniform_step(step, LLPF_STREAM_RESAMPLE, sc->k0, sc->k1);
-            sc->e2_valid = NEED_E2 ? 1 : 0;
+            sc->u_slot[parity] = llpf_uniform_step(step, LLPF_STREAM_RESAMPLE, sc->k0, sc->k1);
+            sc->e2v_slot[parity] = NEED_E2 ? 1 : 0;
             sc->xm_parts = b.P2;
         }
         if (bd) atomicAdd(reinterpret_cast<unsigned long long*>(acc_slot(acc, ACC_BAD(parity), blockIdx.x & (NSHARD - 1))), (unsigned long long)bd);
@@ -834,7 +834,7 @@ struct ResHead {                   // block-uniform results of res_head()
     uint64_t prefix, tot;          // exclusive prefix of this tile's quanta, total of all quanta
     int dr, status, uniform, fast;
 };
-enum { RES_STATUS_FALLBACK = 100 };   // internal: bound test failed, the host redoes this step in exact form
+enum { RES_STATUS_FALLBACK = 100, RES_STATUS_SKIP = 101 };   // SKIP: this launch is a no-op for the filter   // internal: bound test failed, the host redoes this step in exact form
 
 // shouldresample (reference src/resample.jl:5-10) without the division: ESS = stot^2 / sum(e^2) < N*thr
 DEV int decide_resample(double thr, double N, double stot, double e2) {
@@ -847,8 +847,11 @@ DEV double head_log(const ResHead& h) { return h.fast ? llpf_log(h.stot) : llpf_
 // Head of a resample launch: all global loads are issued first (accumulator slots, per-tile quanta sums), one
 // __syncthreads, then EVERY thread derives the block-uniform scalars (integer sums => identical everywhere).
 // Tile 0 publishes the scalars of logsumexp! / effective_particles / shouldresample for later kernels.
+// `defer_skip`: the caller fetched the run's stop flag and the filter's fallback flag without waiting for them; the
+// launch-is-a-no-op test is made here after the barrier, so that those two loads overlap all the others.
 template <int SRC>
-DEV ResHead res_head(const BankDev& b, const ResArgs& a, int f, int tile, ResShared& sh) {
+DEV ResHead res_head(const BankDev& b, const ResArgs& a, int f, int tile, ResShared& sh,
+                     bool defer_skip = false, uint32_t stop_flag = 0, int fb_flag = 0) {
     FilterScal* sc = b.scal + f;
     uint64_t* acc = b.acc + (size_t)f * ACC_WORDS;
     const int lane = threadIdx.x & 63, wvid = threadIdx.x >> 6;
@@ -856,6 +859,10 @@ DEV ResHead res_head(const BankDev& b, const ResArgs& a, int f, int tile, ResSha
     ResHead h;
     const bool fin = (a.mode & RES_FINALIZE) != 0;
     const bool unif0 = (SRC == SRC_FILTER) && !fin && sc->uniform;
+    // scalars of the previous launch that are needed after the barrier below: fetched now, with the other loads
+    const double off_pre = sc->off_slot[a.parity];
+    const int e2v_pre = sc->e2v_slot[a.parity];
+    const int status_pre = sc->status;
 
     // loads.  wave 0: lane group g (8 lanes = 8 shards) fetches word g of this slot's accumulator set
     uint64_t accv = 0;
@@ -870,14 +877,6 @@ DEV ResHead res_head(const BankDev& b, const ResArgs& a, int f, int tile, ResSha
             if (p < tile) pre += q;
         }
     }
-    if (fin) {
-        // clear the slot after next (its last reader finished two launches ago): accumulator words and tile sums
-        const int clr = (a.parity + 2) % ACC_NSLOT;
-        if (tile == 0 && threadIdx.x >= 64 && threadIdx.x < 128) *acc_slot(acc, acc_word_of_group(grp - 8, clr), shard) = 0;
-        uint64_t* tqc = tileq_slot(b, clr, f);
-        if (gridDim.x == (unsigned)b.P2) { if (threadIdx.x == 0) tqc[tile] = 0; }
-        else { for (int p = threadIdx.x; p < b.P2; p += BLOCK) tqc[p] = 0; }      // finalize-only launch: one block
-    }
     if (fin && wvid == 0) {
         // combine the 8 shards of each word inside its group of 8 lanes: xor 1, xor 2 (quad_perm), xor 4 (half mirror)
 #define LLPF_ACCSTEP(CTRL) { const uint64_t t = dpp_u64<CTRL, 0xF, false>(accv, accv); accv = (grp == 0) ? (t > accv ? t : accv) : accv + t; }
@@ -889,12 +888,23 @@ DEV ResHead res_head(const BankDev& b, const ResArgs& a, int f, int tile, ResSha
     all = wave_sum_u64(all);
     if (lane == 0) { sh.red[wvid][0] = pre; sh.red[wvid][1] = all; }
     __syncthreads();
+    h.status = 0;
+    h.s = 0.0;
+    if (defer_skip) {
+        const bool stopped = stop_flag != 0 && (int64_t)(stop_flag - 1) < a.k;
+        if (stopped || (a.only_fallback ? !fb_flag : (fb_flag != 0))) { h.status = RES_STATUS_SKIP; return h; }
+    }
     h.prefix = 0; h.tot = 0;
 #pragma unroll
     for (int k = 0; k < BLOCK / 64; ++k) { h.prefix += sh.red[k][0]; h.tot += sh.red[k][1]; }
-
-    h.status = 0;
-    h.s = 0.0;
+    if (fin) {
+        // clear the slot after next (its last reader finished two launches ago): accumulator words and tile sums
+        const int clr = (a.parity + 2) % ACC_NSLOT;
+        if (tile == 0 && threadIdx.x >= 64 && threadIdx.x < 128) *acc_slot(acc, acc_word_of_group(grp - 8, clr), shard) = 0;
+        uint64_t* tqc = tileq_slot(b, clr, f);
+        if (gridDim.x == (unsigned)b.P2) { if (threadIdx.x == 0) tqc[tile] = 0; }
+        else { for (int p = threadIdx.x; p < b.P2; p += BLOCK) tqc[p] = 0; }      // finalize-only launch: one block
+    }
     if (fin) {
         h.fast = a.fast_head;
         h.mtrue = max_unkey(sh.accw[0]);
@@ -902,7 +912,7 @@ DEV ResHead res_head(const BankDev& b, const ResArgs& a, int f, int tile, ResSha
         const llpf_u128 e128 = acc_combine_u128(sh.accw[4], sh.accw[5], sh.accw[6]);
         const bool bad = sh.accw[7] != 0;
         if (h.fast) {
-            h.a = sc->off_next;                                   // published by the weighting kernel that filled this slot
+            h.a = off_pre;                                        // published by the weighting kernel that filled this slot
             if (bad || s128.hi < ((uint64_t)1 << 22)) {           // sum exp(w - bound) < 2^-10, or NaN weights
                 h.status = RES_STATUS_FALLBACK;
                 h.stot = 0.0;
@@ -920,7 +930,8 @@ DEV ResHead res_head(const BankDev& b, const ResArgs& a, int f, int tile, ResSha
                 h.stot = h.s + 1.0;
             }
         }
-        h.e2 = sc->e2_valid ? llpf_fix96_to_double(e128) : -1.0;  // -1: not accumulated (threshold 1: not needed)
+        const int e2v = e2v_pre;
+        h.e2 = e2v ? llpf_fix96_to_double(e128) : -1.0;           // -1: not accumulated (threshold 1: not needed)
         h.uniform = 0;
         h.dr = h.status ? 0 : decide_resample(b.thr, Nd, h.stot, h.e2);
         if (tile == 0 && threadIdx.x == 0) {
@@ -938,7 +949,7 @@ DEV ResHead res_head(const BankDev& b, const ResArgs& a, int f, int tile, ResSha
                     ess = h.e2 > 0.0 ? (h.stot * h.stot) / h.e2 : -1.0;
                 }
                 sc->m = h.a; sc->mtrue = h.mtrue; sc->s = h.s; sc->stot = h.stot; sc->l = l; sc->inv = inv; sc->ll = ll;
-                sc->ess = ess; sc->e2 = h.e2; sc->fast = h.fast;
+                sc->ess = ess; sc->e2 = h.e2; sc->fast = h.fast; sc->e2_valid = e2v;
                 sc->wmax = (h.mtrue - h.a) - l;                   // normalised weight of the best particle
                 sc->K = a.K;
                 sc->uniform = 0;
@@ -951,7 +962,7 @@ DEV ResHead res_head(const BankDev& b, const ResArgs& a, int f, int tile, ResSha
                 sh.dval[0] = inv;
             }
         }
-        if (!h.status) h.status = sc->status;          // sticky until reset! (written above only when non-zero)
+        if (!h.status) h.status = status_pre;          // sticky until reset! (written above only when non-zero)
     } else {
         // predict! without a preceding correct! in this launch sequence: decide from the stored state
         h.a = sc->m; h.mtrue = sc->mtrue; h.s = sc->s; h.stot = sc->stot; h.e2 = sc->e2; h.fast = sc->fast;
@@ -1033,7 +1044,7 @@ DEV void res_counts(const BankDev& b, const ResArgs& a, int f, int tile, const R
     uint32_t cnt[NORM_IPT];
     if (STRATEGY == LLPF_RESAMPLE_SYSTEMATIC) {
         ThrSys th;
-        const double U = a.Uexp ? a.Uexp[0] : (a.u_from_scal ? sc->u_sys : llpf_uniform_step(a.step, LLPF_STREAM_RESAMPLE, sc->k0, sc->k1));
+        const double U = a.Uexp ? a.Uexp[0] : (a.u_from_scal ? sc->u_slot[a.parity] : llpf_uniform_step(a.step, LLPF_STREAM_RESAMPLE, sc->k0, sc->k1));
         th.M = M; th.Md = (double)M; th.step = 1.0 / (double)M;
         th.delta = 1e-9 + th.Md * 1e-13;
         th.r = U * binsN / (double)N;                  // r = rand()*bins[end]/N  (resample.jl:23)
@@ -1065,16 +1076,17 @@ DEV void res_counts(const BankDev& b, const ResArgs& a, int f, int tile, const R
 
 // output o (c_start <= o < c_end) is produced by the first source k of the tile with cl[k] > o
 DEV int res_owner(const uint32_t* cl, int32_t o) {
-    int lo = 0, hi = TILE - 1;
+    // branch-free descent in power-of-two steps: p4 = 4 * #{k : cl[k] <= o} (cl is non-decreasing and o < cl[TILE-1]).
+    // The probe address is one VGPR (p4) + an immediate LDS offset, so a step is ds_read + compare + select + add.
     const uint32_t ov = (uint32_t)o;
+    const char* base = reinterpret_cast<const char*>(cl);
+    uint32_t p4 = 0;
 #pragma unroll
-    for (int it = 0; it < 10; ++it) {                  // TILE = 1024 = 2^10
-        const int mid = (lo + hi) >> 1;
-        const bool gt = cl[mid] > ov;
-        hi = gt ? mid : hi;
-        lo = gt ? lo : mid + 1;
+    for (int step = TILE / 2; step >= 1; step >>= 1) {
+        const uint32_t v = *reinterpret_cast<const uint32_t*>(base + p4 + (uint32_t)(step - 1) * 4u);
+        p4 += (v <= ov) ? (uint32_t)step * 4u : 0u;
     }
-    return lo;
+    return (int)(p4 >> 2);
 }
 static_assert(TILE == 1024, "res_owner assumes 2^10 sources per tile");
 
@@ -1105,7 +1117,7 @@ __global__ __launch_bounds__(BLOCK) void k_resample(BankDev b, ResArgs a) {
         ao[o] = (int32_t)((int64_t)tile * TILE + res_owner(sh.cl, o));
     // outputs whose threshold is >= bins[N] are never written by the reference (j keeps its previous
     // value); the previous value is only materialised here if it was the identity 1:N
-    if (tile == b.P2 - 1 && SRC == SRC_FILTER && b.scal[f].anc_ident) {
+    if (tile == b.P2 - 1 && SRC == SRC_FILTER && b.scal[f].anc_ident_s[b.anc_slot]) {
         for (int32_t o = c_end + threadIdx.x; o < a.M; o += BLOCK) ao[o] = o;
     }
 }
@@ -1121,6 +1133,13 @@ __global__ __launch_bounds__(BLOCK) void k_resample(BankDev b, ResArgs a) {
 // than the serial reference).
 // The per-output arithmetic is the same sequence as k_step's, so fused and unfused paths are bit-identical.
 // ------------------------------------------------------------------------------------------------
+template <class T> DEV T ld_off(const T* base, uint32_t byte_off) {
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+template <class T> DEV void st_off(T* base, uint32_t byte_off, T v) {
+    *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
+
 template <class Model, int NX, int NY, bool WEIGHT>
 struct PropCtx {
     const BankDev& b;
@@ -1136,25 +1155,27 @@ struct PropCtx {
     double off;            // bound of the new weights (offset of their exp-sums)
     uint64_t* qnext;       // quanta of the new weights
     // propagate output o from source src with previous log-weight wprev; returns the new log-weight
-    DEV double one(int64_t src, int64_t o, double wprev, bool& bad, double* xs) const {
+    // Addresses are a uniform plane base (SGPRs) + a 32-bit byte offset (one VGPR): Ns * 8 < 2^32 is checked at create.
+    DEV double one(uint32_t src, uint32_t o, double wprev, bool& bad, double* xs) const {
         const int64_t Ns = b.Ns;
+        const uint32_t so = src << 3, oo = o << 3;
         double xp[NX], fx[NX], xi[NX], nz[NX];
 #pragma unroll
-        for (int d = 0; d < NX; ++d) xp[d] = xc[(size_t)d * Ns + src];
+        for (int d = 0; d < NX; ++d) xp[d] = ld_off(xc + (size_t)d * Ns, so);
 #ifdef LLPF_DEVTOOLS   /* ablation switches for performance experiments (results invalid); not in production builds */
         if (!(ablate & 4)) model.dynamics(xp, fx);
         else { for (int d = 0; d < NX; ++d) fx[d] = xp[d]; }
-        if (!(ablate & 1)) llpf_normals((uint32_t)o, st.step, LLPF_STREAM_DYNAMICS, k0, k1, NX, xi);
+        if (!(ablate & 1)) llpf_normals(o, st.step, LLPF_STREAM_DYNAMICS, k0, k1, NX, xi);
         else { for (int d = 0; d < NX; ++d) xi[d] = 0.25 * (double)(o & 7); }
 #else
         model.dynamics(xp, fx);
-        llpf_normals((uint32_t)o, st.step, LLPF_STREAM_DYNAMICS, k0, k1, NX, xi);
+        llpf_normals(o, st.step, LLPF_STREAM_DYNAMICS, k0, k1, NX, xi);
 #endif
         gauss_sample<NX>(md->df, xi, nz);
 #pragma unroll
         for (int d = 0; d < NX; ++d) {
             xs[d] = fx[d] + nz[d];
-            xn[(size_t)d * Ns + o] = xs[d];
+            st_off(xn + (size_t)d * Ns, oo, xs[d]);
         }
         double wv = wprev;
         if (WEIGHT) {
@@ -1169,9 +1190,9 @@ struct PropCtx {
                 for (int k = 0; k < NY; ++k) v[k] = y[k] - g[k];
                 wv = wv + gauss_logpdf<NY>(md->dg, v);
             }
-            if (o >= b.N) wv = -LLPF_INF;
+            if (o >= (uint32_t)b.N) wv = -LLPF_INF;
             bad = bad || (wv != wv);
-            w[o] = wv;
+            st_off(w, oo, wv);
         }
         return wv;
     }
@@ -1180,19 +1201,19 @@ struct PropCtx {
 // per-thread running sum of quanta keyed by destination tile; flushed to LDS (first 8 tiles of the block's output
 // range) or straight to the global tile sums (heavier blocks) whenever the tile changes
 struct TileSum {
-    int64_t tcur;
+    int32_t tcur;
     uint64_t run;
     DEV void init() { tcur = -1; run = 0; }
-    DEV void flush(uint64_t* sh_tq, uint64_t* tq_global, int64_t tbase) {
+    DEV void flush(uint64_t* sh_tq, uint64_t* tq_global, int32_t tbase) {
         if (run) {
-            const int64_t idx = tcur - tbase;
+            const int32_t idx = tcur - tbase;
             if (idx >= 0 && idx < 8) atomicAdd(reinterpret_cast<unsigned long long*>(sh_tq + idx), (unsigned long long)run);
             else atomicAdd(reinterpret_cast<unsigned long long*>(tq_global + tcur), (unsigned long long)run);
         }
         run = 0;
     }
-    DEV void add(int64_t o, uint64_t q, uint64_t* sh_tq, uint64_t* tq_global, int64_t tbase) {
-        const int64_t t = o >> 10;
+    DEV void add(uint32_t o, uint64_t q, uint64_t* sh_tq, uint64_t* tq_global, int32_t tbase) {
+        const int32_t t = (int32_t)(o >> 10);
         if (t != tcur) { flush(sh_tq, tq_global, tbase); tcur = t; }
         run += q;
     }
@@ -1211,28 +1232,28 @@ __global__ __launch_bounds__(BLOCK) void k_resprop(BankDev b, const ModelD* __re
     const int64_t Ns = b.Ns, N = b.N;
     const ModelD* md = models + f;
     FilterScal* sc = b.scal + f;
-    if (run_is_stopped(b, a.k)) return;
-    if (a.only_fallback ? !sc->fallback : (sc->fallback != 0)) return;
+    const uint32_t stop_flag = *b.bank_flag;           // tested in res_head, after all other loads are in flight
+    const int fb_flag = sc->fallback;
     if (threadIdx.x < 8) sh_tq[threadIdx.x] = 0;
     const uint64_t* __restrict__ qsrc = b.quanta + (size_t)f * Ns;
     const int64_t ib = (int64_t)tile * TILE + (int64_t)threadIdx.x * NORM_IPT;
     ulonglong2 qv[NORM_IPT / 2];
 #pragma unroll
     for (int k = 0; k < NORM_IPT / 2; ++k) qv[k] = *reinterpret_cast<const ulonglong2*>(qsrc + ib + 2 * k);
-    const int anc_ident_prev = sc->anc_ident;          // written only at the very end of this kernel (last tile)
+    const int anc_ident_prev = sc->anc_ident_s[b.anc_slot];   // this launch writes the other entry
 #define LLPF_STAMP(i) if (a.dbg && threadIdx.x == 0 && f == 0) a.dbg[(size_t)tile * 8 + (i)] = wall_clock64()
     LLPF_STAMP(0);
-    const ResHead h = res_head<SRC_FILTER>(b, a, f, tile, sh);
-    if (h.status) return;
-    LLPF_STAMP(1);
-
-    Model model;
+    Model model;                                       // particle-independent terms: their loads overlap the head's
     model.prepare(md, st.u, st.t_prop);
     double y[NY];
 #pragma unroll
     for (int k = 0; k < NY; ++k) y[k] = (WEIGHT && st.has_y) ? st.y[k] : 0.0;
+    const uint32_t key0 = sc->k0, key1 = sc->k1;
+    const ResHead h = res_head<SRC_FILTER>(b, a, f, tile, sh, true, stop_flag, fb_flag);
+    if (h.status) return;
+    LLPF_STAMP(1);
     PropCtx<Model, NX, NY, WEIGHT> pc{b, model, md, st, y, b.xcur + (size_t)f * NX * Ns, b.xnext + (size_t)f * NX * Ns,
-                                      b.w + (size_t)f * Ns, sc->k0, sc->k1, a.ablate, 0.0, b.quanta_next + (size_t)f * Ns};
+                                      b.w + (size_t)f * Ns, key0, key1, a.ablate, 0.0, b.quanta_next + (size_t)f * Ns};
     int32_t* anc = b.anc + (size_t)f * Ns;
     double bmax = -LLPF_INF;
     bool bad = false;
@@ -1270,23 +1291,24 @@ __global__ __launch_bounds__(BLOCK) void k_resprop(BankDev b, const ModelD* __re
         const double wmx = res ? b.log1N : (h.mtrue - h.a) - l;
         pc.off = (WEIGHT && st.has_y) ? wmx + md->dg.c0 : wmx;
     }
-    const int64_t tbase = first >> 10;
+    const int32_t tbase = (int32_t)(first >> 10);
     LLPF_STAMP(2);
     if (a.dbg && threadIdx.x == 0 && f == 0) a.dbg[(size_t)tile * 8 + 5] = (uint64_t)(last - first);
+    const uint32_t tile0 = (uint32_t)tile * TILE, ulast = (uint32_t)last, ucend = (uint32_t)c_end;
 #pragma unroll 1
-    for (int64_t o = first + threadIdx.x; o < last; o += BLOCK) {
-        int64_t src = o;
+    for (uint32_t o = (uint32_t)first + threadIdx.x; o < ulast; o += BLOCK) {
+        uint32_t src = o;
         double wprev = b.log1N;                                        // reset_weights!: w = log(1/N)
         if (res) {
 #ifdef LLPF_DEVTOOLS
-            if (o < c_end) src = (int64_t)tile * TILE + ((a.ablate & 2) ? (int)((o - first) & (TILE - 1)) : res_owner(sh.cl, (int32_t)o));
+            if (o < ucend) src = tile0 + ((a.ablate & 2) ? ((o - (uint32_t)first) & (TILE - 1)) : (uint32_t)res_owner(sh.cl, (int32_t)o));
 #else
-            if (o < c_end) src = (int64_t)tile * TILE + res_owner(sh.cl, (int32_t)o);
+            if (o < ucend) src = tile0 + (uint32_t)res_owner(sh.cl, (int32_t)o);
 #endif
-            else src = anc_ident_prev ? o : (int64_t)anc[o];
-            anc[o] = (int32_t)src;
+            else src = anc_ident_prev ? o : (uint32_t)ld_off(anc, o << 2);
+            st_off(anc, o << 2, (int32_t)src);
         } else if (WEIGHT) {
-            wprev = (pc.w[o] - h.a) - l;                               // lazy w .-= offset ; w .-= log(sum)
+            wprev = (ld_off(pc.w, o << 3) - h.a) - l;                  // lazy w .-= offset ; w .-= log(sum)
         }
         double xs[NX];
         const double wv = pc.one(src, o, wprev, bad, xs);
@@ -1294,7 +1316,7 @@ __global__ __launch_bounds__(BLOCK) void k_resprop(BankDev b, const ModelD* __re
         if (WEIGHT && ACC) {
             double e;
             const uint64_t q = wacc.add(wv, pc.off, st.K, st.need_e2 != 0, &e);
-            pc.qnext[o] = q;
+            st_off(pc.qnext, o << 3, q);
             ts.add(o, q, sh_tq, tq_next, tbase);
             if (st.want_xmean) {
 #pragma unroll
@@ -1317,9 +1339,9 @@ __global__ __launch_bounds__(BLOCK) void k_resprop(BankDev b, const ModelD* __re
         }
         if (tile == 0 && threadIdx.x == 0) {
             if (ACC) sc->xm_parts = b.P2;
-            sc->off_next = pc.off;
-            sc->e2_valid = st.need_e2;
-            sc->u_sys = llpf_uniform_step(st.next_step, LLPF_STREAM_RESAMPLE, sc->k0, sc->k1);
+            sc->off_slot[st.parity] = pc.off;
+            sc->e2v_slot[st.parity] = st.need_e2;
+            sc->u_slot[st.parity] = llpf_uniform_step(st.next_step, LLPF_STREAM_RESAMPLE, sc->k0, sc->k1);
         }
     }
     __syncthreads();
@@ -1327,7 +1349,7 @@ __global__ __launch_bounds__(BLOCK) void k_resprop(BankDev b, const ModelD* __re
 #undef LLPF_STAMP
     if (tile == b.P2 - 1 && threadIdx.x == 0) {        // bookkeeping of this predict! (by the only block that reads anc_ident)
         const int r = (h.dr && h.tot != 0) ? 1 : 0;
-        sc->anc_ident = r ? 0 : 1;
+        sc->anc_ident_s[b.anc_slot ^ 1] = r ? 0 : 1;
         sc->last_resampled = r;
         sc->resample_count += r;
     }
@@ -1397,7 +1419,7 @@ __global__ __launch_bounds__(BLOCK) void k_anc64(BankDev b, int64_t* dst) {
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= b.N) return;
     const FilterScal* sc = b.scal + f;
-    dst[(size_t)f * b.N + i] = sc->anc_ident ? i : (int64_t)b.anc[(size_t)f * b.Ns + i];
+    dst[(size_t)f * b.N + i] = sc->anc_ident_s[b.anc_slot] ? i : (int64_t)b.anc[(size_t)f * b.Ns + i];
 }
 
 // weighted_mean(pf) accessor — reference src/filtering.jl:541-549,568.  One block per filter, fixed order.

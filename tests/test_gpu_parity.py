@@ -575,3 +575,34 @@ def test_schedules_are_bit_identical(schedule, monkeypatch):
     assert np.array_equal(rg["ll_steps"].view(np.uint64), ro["ll_steps"].view(np.uint64))
     np.testing.assert_allclose(rg["xmean"], ro["xmean"], rtol=1e-9, atol=1e-11)   # output-only fp64 sum, never fed back
     _compare_state(g, o)
+
+
+@pytest.mark.parametrize("schedule", ["merged", "split"])
+def test_launches_larger_than_the_resident_set(schedule, monkeypatch):
+    """More workgroups than the chip holds at once (~1000-2000): blocks of a launch that start after other blocks of
+    the SAME launch have finished must still read the previous step's scalars (offset, systematic uniform, ancestor
+    identity flag live in per-slot entries).  A bank of 48 x 65536 particles (3072 tiles) against the same filters
+    run one at a time (64 tiles each, all resident), bit for bit; and one filter of 4.2e6 particles against the
+    device-order oracle."""
+    monkeypatch.setenv("LLPF_SCHEDULE", schedule)
+    F, N, T = 48, 65536, 24
+    models = [M.lg_test_model(0.05 + 0.01 * k) for k in range(F)]
+    _, U, Y = M.simulate_lg(models[5], T)
+    for thr in (1.0, 0.3):
+        bank = _capi.BankHandle(_cfg(models[0], N, thr=thr, seed=4100), models)
+        bank.reset()
+        rb = bank.run(U, Y, 1.0, ll_steps=True)
+        for k in (0, 1, 17, 30, 46, 47):
+            g = _capi.FilterHandle(_cfg(models[k], N, thr=thr, seed=4100 + k))
+            g.reset()
+            rg = g.run(U, Y, 1.0, ll_steps=True)
+            assert np.array_equal(rg["ll_steps"].view(np.uint64), rb["ll_steps"][:, k].copy().view(np.uint64)), (thr, k)
+    N = 4200000
+    cfg = _cfg(models[3], N, thr=0.5, seed=4200)
+    g = _capi.FilterHandle(cfg)
+    o = ob.OracleFilter(cfg, ob.ORDER_DEVICE)
+    g.reset(); o.reset()
+    rg = g.run(U[:8], Y[:8], 1.0, ll_steps=True)
+    ro = o.run(U[:8], Y[:8], 1.0, ll_steps=True)
+    assert np.array_equal(rg["ll_steps"].view(np.uint64), ro["ll_steps"].view(np.uint64))
+    assert g.resample_count() == o.resample_count() >= 1
