@@ -12,7 +12,7 @@ import numpy as np
 from . import _structs as S
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libllpf_hip.so")
+LIB_PATH = os.environ.get("LLPF_LIB") or os.path.join(_HERE, "libllpf_hip.so")   # LLPF_LIB: A/B builds of the same engine (tools/)
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int64)

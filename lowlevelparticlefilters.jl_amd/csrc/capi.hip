@@ -70,6 +70,7 @@ static int gauss_prepare(const llpf_gaussian* g, GaussD* d) {
         d->scal = g->cov[0];
         if (!(d->scal > 0.0)) return -1;
         d->sqrtscal = llpf_sqrt(d->scal);
+        d->invscal = 1.0 / d->scal;
         logdet = (double)n * llpf_log(d->scal);
         for (int i = 0; i < n; ++i) d->L[i * MAXD + i] = d->sqrtscal;
     } else if (g->kind == LLPF_COV_DIAG) {
@@ -83,6 +84,7 @@ static int gauss_prepare(const llpf_gaussian* g, GaussD* d) {
         }
     } else if (g->kind == LLPF_COV_FULL) {
         if (chol_lower(g->cov, n, d->L) != 0) return -1;
+        for (int i = 0; i < n; ++i) d->invLd[i] = 1.0 / d->L[i * MAXD + i];
         double dd = 0.0;
         for (int i = 0; i < n; ++i) dd = (i == 0) ? llpf_log(d->L[i * MAXD + i]) : dd + llpf_log(d->L[i * MAXD + i]);
         logdet = dd + dd;

@@ -65,7 +65,8 @@ struct GaussD {
     int32_t dim, kind;
     double mu[MAXD];
     double L[MAXD * MAXD];
-    double scal, sqrtscal;
+    double scal, sqrtscal, invscal;   // invscal = 1/scal: the device order multiplies (reference divides, utils.jl:110)
+    double invLd[MAXD];               // 1 / L[i][i] for the two triangular solves of the full-covariance form
     double diag[MAXD], invdiag[MAXD], sqrtdiag[MAXD];
     double c0;
 };

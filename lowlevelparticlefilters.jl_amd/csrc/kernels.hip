@@ -138,7 +138,7 @@ DEV double gauss_logpdf(const GaussD& g, const double* x) {
         double dot = d[0] * d[0];
 #pragma unroll
         for (int i = 1; i < ND; ++i) dot = dot + d[i] * d[i];
-        q = dot / g.scal;
+        q = dot * g.invscal;
     } else if (kind == LLPF_COV_DIAG) {
         double s = (d[0] * d[0]) * g.invdiag[0];
 #pragma unroll
@@ -151,14 +151,14 @@ DEV double gauss_logpdf(const GaussD& g, const double* x) {
             double acc = d[i];
 #pragma unroll
             for (int j = 0; j < i; ++j) acc = acc - g.L[i * MAXD + j] * z[j];
-            z[i] = acc / g.L[i * MAXD + i];
+            z[i] = acc * g.invLd[i];
         }
 #pragma unroll
         for (int i = ND - 1; i >= 0; --i) {
             double acc = z[i];
 #pragma unroll
             for (int j = i + 1; j < ND; ++j) acc = acc - g.L[j * MAXD + i] * z2[j];
-            z2[i] = acc / g.L[i * MAXD + i];
+            z2[i] = acc * g.invLd[i];
         }
         double dot = d[0] * z2[0];
 #pragma unroll

@@ -28,6 +28,8 @@ typedef struct {
     double mu[MAXD];
     double L[MAXD * MAXD];      /* lower Cholesky factor (FULL) */
     double scal, sqrtscal;      /* ScalMat value and its sqrt   */
+    double invscal, invLd[MAXD];/* device order: reciprocals, the divisions of invquad become multiplications */
+    int dev;                    /* ORC_ORDER_DEVICE */
     double diag[MAXD], invdiag[MAXD], sqrtdiag[MAXD];
     double c0;                  /* mvnormal_c0: -(k log2pi + logdet Sigma)/2, src/utils.jl:254-257 */
 } gaussd;
@@ -54,6 +56,7 @@ static int gauss_prepare(const llpf_gaussian* g, gaussd* d, int order) {
     memset(d, 0, sizeof(*d));
     d->dim = g->dim;
     d->kind = g->kind;
+    d->dev = (order == ORC_ORDER_DEVICE);
     int n = g->dim;
     if (n < 1 || n > MAXD) return -1;
     for (int i = 0; i < n; ++i) d->mu[i] = g->mu[i];
@@ -65,6 +68,7 @@ static int gauss_prepare(const llpf_gaussian* g, gaussd* d, int order) {
         d->scal = g->cov[0];
         if (!(d->scal > 0.0)) return -1;
         d->sqrtscal = sqrt(d->scal);
+        d->invscal = 1.0 / d->scal;
         logdet = (double)n * LOGF(d->scal);                 /* PDMats: logdet(ScalMat) = dim*log(value) */
         for (int i = 0; i < n; ++i) d->L[i * MAXD + i] = d->sqrtscal;
     } else if (g->kind == LLPF_COV_DIAG) {
@@ -78,6 +82,7 @@ static int gauss_prepare(const llpf_gaussian* g, gaussd* d, int order) {
         }
     } else if (g->kind == LLPF_COV_FULL) {
         if (chol_lower(g->cov, n, d->L) != 0) return -1;
+        for (int i = 0; i < n; ++i) d->invLd[i] = 1.0 / d->L[i * MAXD + i];
         double dd = 0.0;
         for (int i = 0; i < n; ++i) dd = (i == 0) ? LOGF(d->L[i * MAXD + i]) : dd + LOGF(d->L[i * MAXD + i]);
         logdet = dd + dd;                                     /* logdet(::Cholesky) */
@@ -99,7 +104,7 @@ static double gauss_logpdf(const gaussd* g, const double* x) {
     if (g->kind == LLPF_COV_SCAL) {
         double dot = d[0] * d[0];
         for (int i = 1; i < n; ++i) dot = dot + d[i] * d[i];
-        q = dot / g->scal;
+        q = g->dev ? dot * g->invscal : dot / g->scal;
     } else if (g->kind == LLPF_COV_DIAG) {
         double s = (d[0] * d[0]) * g->invdiag[0];
         for (int i = 1; i < n; ++i) s = s + (d[i] * d[i]) * g->invdiag[i];
@@ -109,12 +114,12 @@ static double gauss_logpdf(const gaussd* g, const double* x) {
         for (int i = 0; i < n; ++i) {                         /* L \ d */
             double acc = d[i];
             for (int j = 0; j < i; ++j) acc = acc - g->L[i * MAXD + j] * z[j];
-            z[i] = acc / g->L[i * MAXD + i];
+            z[i] = g->dev ? acc * g->invLd[i] : acc / g->L[i * MAXD + i];
         }
         for (int i = n - 1; i >= 0; --i) {                    /* L' \ z */
             double acc = z[i];
             for (int j = i + 1; j < n; ++j) acc = acc - g->L[j * MAXD + i] * z2[j];
-            z2[i] = acc / g->L[i * MAXD + i];
+            z2[i] = g->dev ? acc * g->invLd[i] : acc / g->L[i * MAXD + i];
         }
         double dot = d[0] * z2[0];
         for (int i = 1; i < n; ++i) dot = dot + d[i] * z2[i];
