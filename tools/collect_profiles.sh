@@ -1,0 +1,30 @@
+#!/bin/bash
+# Collect the round's measurement artefacts on the GPU box (run through gpurun from the repo root):
+#   tools/collect_profiles.sh <tag>      e.g. r01d
+# Writes everything under gpurun_out/<tag>/ ; copy the summaries into profiles/ afterwards.
+#   1. bench lines (C2 default, C2 with the reference's default threshold 0.1, C3 quad-tank, one-GPU share of C4)
+#   2. rocprofv3 --kernel-trace of the default bench command, summarised per kernel (tools/rocprof_summary.py)
+#   3. rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (never combined with other traces), per-kernel
+#      averages per dispatch (tools/rocprof_pmc_summary.py)
+set -u
+TAG=${1:-prof}
+ROOT=$PWD
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+python bench.py > $OUT/bench_c2.json 2> $OUT/bench_c2.err
+python bench.py --threshold 0.1 --no-cpu-baseline > $OUT/bench_c2_thr01.json 2>> $OUT/bench_c2.err
+python bench.py --workload quadtank > $OUT/bench_c3_quadtank.json 2>> $OUT/bench_c2.err
+python tools/bench_bank.py > $OUT/bench_c4_bank_128x1e5_one_gpu.json 2>> $OUT/bench_c2.err
+python tools/bench_bank.py --thr 1.0 > $OUT/bench_c4_bank_128x1e5_thr1.json 2>> $OUT/bench_c2.err
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace -d $OUT/kt -o kt -- python $ROOT/bench.py --no-cpu-baseline > $OUT/kt.log 2>&1
+rocprofv3 --kernel-trace -d $OUT/kt_bank -o kt -- python $ROOT/tools/bench_bank.py > $OUT/kt_bank.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o p -- python $ROOT/bench.py --steps 1 --warmup 0 --T 200 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o p -- python $ROOT/bench.py --steps 1 --warmup 0 --T 200 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_ANY -d $OUT/pmc_sq -o p -- python $ROOT/bench.py --steps 1 --warmup 0 --T 200 --no-cpu-baseline > $OUT/pmc_sq.log 2>&1
+cd $ROOT
+python tools/rocprof_summary.py $(find $OUT/kt -name "*.db" | head -1) > $OUT/kernel_stats.txt
+python tools/rocprof_summary.py $(find $OUT/kt_bank -name "*.db" | head -1) > $OUT/kernel_stats_bank.txt
+python tools/rocprof_pmc_summary.py $OUT/pmc_traffic.txt $(find $OUT/pmc_fetch -name "*.db" | head -1) $(find $OUT/pmc_write -name "*.db" | head -1) $(find $OUT/pmc_sq -name "*.db" | head -1)
+rm -rf $OUT/kt $OUT/kt_bank $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq
+ls -la $OUT
