@@ -19,6 +19,15 @@
 
 #define MAXD LLPF_MAX_DIM
 
+/* Optional OpenMP over the per-particle loops (weighting, propagation, noise, elementwise exp): an upper bound for
+ * what the reference could reach with its `threads=true` option (src/PFtypes.jl:226-259 @threads :static); the
+ * reductions and the resampling scan stay serial, so results do not depend on the thread count.  Default 1 thread =
+ * the reference's ParticleFilter path. */
+static int g_threads = 1;
+void orc_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
+int  orc_get_threads(void) { return g_threads; }
+#define ORC_PAR _Pragma("omp parallel for schedule(static) num_threads(g_threads)")
+
 /* ------------------------------------------------------------------------------------------
  * Gaussian densities — src/utils.jl:241-270 (SimpleMvNormal), PDMats shims src/utils.jl:110-113,
  * ext/LowLevelParticleFiltersDistributionsExt.jl:16,80 (Distributions.MvNormal path)
@@ -362,12 +371,16 @@ double orc_logsumexp(double* w, double* we, int64_t n, int order, double* maxw) 
     }
     int64_t maxind;
     double offset = jl_findmax(w, n, &maxind);                /* :19 */
+    ORC_PAR
     for (int64_t i = 0; i < n; ++i) w[i] -= offset;           /* :20 */
+    ORC_PAR
     for (int64_t i = 0; i < n; ++i) we[i] = exp(w[i]);        /* :21 exp_map!, :3-7 */
     double s = sum_all_but(we, n, maxind);                    /* :22 */
     double sc = 1.0 / (s + 1.0);
+    ORC_PAR
     for (int64_t i = 0; i < n; ++i) we[i] *= sc;              /* :23 */
     double l = log1p(s);
+    ORC_PAR
     for (int64_t i = 0; i < n; ++i) w[i] -= l;                /* :24 */
     if (maxw) *maxw = offset;                                 /* :25 */
     return l + offset;                                        /* :26 */
@@ -515,6 +528,7 @@ static void init_particles(orc_filter* f, const double* xi) {
 }
 
 static void gen_normals(orc_filter* f, uint32_t step, uint32_t stream, double* out) {
+    ORC_PAR
     for (int64_t i = 0; i < f->N; ++i)
         llpf_normals((uint32_t)i, step, stream, f->k0, f->k1, f->nx, out + i * f->nx);
 }
@@ -593,6 +607,7 @@ double orc_correct(orc_filter* f, const double* u, const double* y, double t) {
     const int has_y = (y != NULL && y[0] == y[0]);
     const double off = has_y ? f->wmax + f->dg.c0 : f->wmax;   /* device order: upper bound of the new weights */
     if (has_y) {                                               /* any(ismissing, y) && return w */
+        ORC_PAR
         for (int64_t i = 0; i < f->N; ++i) {
             double g[MAXD], v[MAXD];
             orc_measurement(&f->cfg.model, f->x + i * f->nx, u, t, g);
@@ -662,6 +677,7 @@ void orc_predict_explicit(orc_filter* f, const double* u, double t, const double
         if (f->order == ORC_ORDER_DEVICE && f->dn_valid) filter_resample_dev(f, U);
         else orc_resample(f->cfg.resampling_strategy, f->we, N, N, U, f->j, f->bins, f->order);
         /* propagate_particles!(pf,u,j,p,t) — src/PFtypes.jl:122-139 (PF), :242-259 (Advanced) */
+        ORC_PAR
         for (int64_t i = 0; i < N; ++i) {
             double fx[MAXD], nz[MAXD];
             orc_dynamics(&f->cfg.model, f->xprev + f->j[i] * nx, u, t, fx);
@@ -675,6 +691,7 @@ void orc_predict_explicit(orc_filter* f, const double* u, double t, const double
     } else {
         for (int64_t i = 0; i < N; ++i) f->j[i] = i;          /* s.j .= 1:N, :148 */
         /* propagate_particles!(pf,u,p,t) — DistributionsExt:83-93 (PF), src/PFtypes.jl:276-289 (Advanced) */
+        ORC_PAR
         for (int64_t i = 0; i < N; ++i) {
             double fx[MAXD], nz[MAXD];
             orc_dynamics(&f->cfg.model, f->xprev + i * nx, u, t, fx);

@@ -72,6 +72,10 @@ int64_t orc_resample_count(const orc_filter* f);
 int    orc_degenerate(const orc_filter* f);
 int64_t orc_exact_steps(const orc_filter* f);   /* device order: weightings normalised in exact-max form (bound test failed) */
 
+/* OpenMP threads for the per-particle loops (default 1; results are independent of the count) */
+void   orc_set_threads(int n);
+int    orc_get_threads(void);
+
 /* array primitives */
 double orc_logsumexp(double* w, double* we, int64_t n, int order, double* maxw);
 void   orc_expnormalize(double* we, double* w, int64_t n);

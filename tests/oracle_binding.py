@@ -56,6 +56,8 @@ def load():
     lib.orc_resample_count.restype = C.c_int64
     lib.orc_resample_count.argtypes = [C.c_void_p]
     lib.orc_degenerate.argtypes = [C.c_void_p]
+    lib.orc_set_threads.argtypes = [C.c_int]
+    lib.orc_get_threads.restype = C.c_int
     lib.orc_exact_steps.restype = C.c_int64
     lib.orc_exact_steps.argtypes = [C.c_void_p]
     lib.orc_logsumexp.restype = C.c_double
@@ -98,6 +100,11 @@ def lib():
     if _lib is None:
         _lib = load()
     return _lib
+
+
+def set_threads(n):
+    """OpenMP threads of the oracle's per-particle loops (results do not depend on it)."""
+    lib().orc_set_threads(int(n))
 
 
 def dptr(a):
