@@ -144,6 +144,27 @@ typedef struct llpf_run_outputs {
 int  llpf_run(llpf_filter* f, const double* U, const double* Y, int64_t T, double t_index0,
               double* ll_total, const llpf_run_outputs* outs);
 
+/* ---- AuxiliaryParticleFilter{ParticleFilter} (reference src/PFtypes.jl:38-49) ------------------------------
+ * The same handle (filter_kind LLPF_PARTICLE_FILTER) driven through the auxiliary verbs; reset!, accessors and
+ * resampling strategy are those of the wrapped filter (PFtypes.jl:299 @forward).  expweights(pf) between an aux
+ * predict! and the next correct! returns lambda, as the reference's `we` buffer does (filtering.jl:200-203).
+ *   llpf_aux_correct  correct!(pf::AuxiliaryParticleFilter,u,y,p,t)      src/filtering.jl:170-174 (logsumexp! only:
+ *                     the measurement was applied by the preceding predict!, y is not used)
+ *   llpf_aux_predict  predict!(pf::AuxiliaryParticleFilter,u,y1,p,t)     src/filtering.jl:195-217 (noise-free
+ *                     propagate, lambda = logpdf(dg, y1 - g(x)), expnormalize!(w + lambda), resample (always),
+ *                     permute, add_noise!, w = lambda - log N); y1 NULL or NaN = missing.  Weights still waiting
+ *                     for their correct! are normalised first.
+ *   llpf_aux_update   update!(pf::AuxiliaryParticleFilter,u,y,y1,p,t)    src/filtering.jl:187-191
+ *   llpf_aux_run      mode 0: forward_trajectory(pf::AuxiliaryParticleFilter,u,y,p)  src/filtering.jl:367-384
+ *                     mode 1: loglik(pf::AuxiliaryParticleFilter,u,y,p)              src/smoothing.jl:232-236
+ *                     (call llpf_reset first; t_k = k * Ts; one host round trip per timestep)
+ * The AuxiliaryParticleFilter{AdvancedParticleFilter} variant (filtering.jl:219-234) is not provided. */
+int  llpf_aux_correct(llpf_filter* f, double* ll);
+int  llpf_aux_predict(llpf_filter* f, const double* u, const double* y1, double t);
+int  llpf_aux_update(llpf_filter* f, const double* u, const double* y1, double t, double* ll);
+int  llpf_aux_run(llpf_filter* f, const double* U, const double* Y, int64_t T, int32_t mode,
+                  double* ll_total, const llpf_run_outputs* outs);
+
 /* ---- accessors (reference src/PFtypes.jl:296-334) --------------------------------------- */
 int  llpf_num_particles(const llpf_filter* f, int64_t* n);                /* num_particles(pf) */
 int  llpf_index(const llpf_filter* f, int64_t* t);                        /* index(pf) = state.t[] */
@@ -185,6 +206,9 @@ int  llpf_bank_seed(llpf_bank* b, uint64_t seed);
 /* as llpf_run, shared U / Y, ll_total has n_filters entries; ll_steps (optional) is [T * n_filters] */
 int  llpf_bank_run(llpf_bank* b, const double* U, const double* Y, int64_t T, double t_index0,
                    double* ll_total, double* ll_steps);
+/* as llpf_aux_run for every filter of the bank (the ML sweep over AuxiliaryParticleFilters, test/runtests.jl:419-423) */
+int  llpf_bank_aux_run(llpf_bank* b, const double* U, const double* Y, int64_t T, int32_t mode,
+                       double* ll_total, double* ll_steps);
 
 /* ---- measurement ------------------------------------------------------------------------ */
 /* when enabled, every kernel launch of llpf_run / llpf_bank_run is bracketed by hipEvents on the

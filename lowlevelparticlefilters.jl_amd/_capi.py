@@ -28,6 +28,11 @@ SYMBOLS = {
     "llpf_predict": [_vp, _dp, C.c_double],
     "llpf_update": [_vp, _dp, _dp, C.c_double, _dp],
     "llpf_run": [_vp, _dp, _dp, C.c_int64, C.c_double, _dp, C.POINTER(S.RunOutputs)],
+    "llpf_aux_correct": [_vp, _dp],
+    "llpf_aux_predict": [_vp, _dp, _dp, C.c_double],
+    "llpf_aux_update": [_vp, _dp, _dp, C.c_double, _dp],
+    "llpf_aux_run": [_vp, _dp, _dp, C.c_int64, C.c_int32, _dp, C.POINTER(S.RunOutputs)],
+    "llpf_bank_aux_run": [_vp, _dp, _dp, C.c_int64, C.c_int32, _dp, _dp],
     "llpf_num_particles": [_vp, _ip],
     "llpf_index": [_vp, _ip],
     "llpf_get_particles": [_vp, _dp],
@@ -207,6 +212,45 @@ class FilterHandle:
         res["ll"] = ll.value
         return res
 
+    # --- AuxiliaryParticleFilter verbs (reference src/filtering.jl:170-217) ---
+    def aux_correct(self):
+        ll = C.c_double(0)
+        check(self.L.llpf_aux_correct(self.h, C.byref(ll)))
+        return ll.value
+
+    def aux_predict(self, u, y1, t):
+        u, y1 = self._u(u), self._y(y1)
+        check(self.L.llpf_aux_predict(self.h, dptr(u), dptr(y1), float(t)))
+
+    def aux_update(self, u, y1, t):
+        u, y1 = self._u(u), self._y(y1)
+        ll = C.c_double(0)
+        check(self.L.llpf_aux_update(self.h, dptr(u), dptr(y1), float(t), C.byref(ll)))
+        return ll.value
+
+    def run_aux(self, U, Y, mode=0, ll_steps=False, xmean=False, history=False):
+        """mode 0: forward_trajectory loop, mode 1: loglik loop of the AuxiliaryParticleFilter (after reset)."""
+        Y = f64(Y).reshape(-1, self.ny)
+        T = Y.shape[0]
+        U = f64(U).reshape(T, self.nu) if self.nu else None
+        outs = S.RunOutputs()
+        res = {}
+        if ll_steps:
+            res["ll_steps"] = np.zeros(T)
+            outs.ll_steps = dptr(res["ll_steps"])
+        if xmean:
+            res["xmean"] = np.zeros((T, self.nx))
+            outs.xmean = dptr(res["xmean"])
+        if history:
+            res["x"] = np.zeros((T, self.N, self.nx))
+            res["w"] = np.zeros((T, self.N))
+            res["we"] = np.zeros((T, self.N))
+            outs.x_hist, outs.w_hist, outs.we_hist = dptr(res["x"]), dptr(res["w"]), dptr(res["we"])
+        ll = C.c_double(0)
+        check(self.L.llpf_aux_run(self.h, dptr(U), dptr(Y), T, int(mode), C.byref(ll), C.byref(outs)))
+        res["ll"] = ll.value
+        return res
+
     # --- accessors ---
     def index(self):
         t = C.c_int64(0)
@@ -332,6 +376,15 @@ class BankHandle:
         ll = np.zeros(self.F)
         lls = np.zeros((T, self.F)) if ll_steps else None
         check(self.L.llpf_bank_run(self.h, dptr(U), dptr(Y), T, float(t_index0), dptr(ll), dptr(lls)))
+        return {"ll": ll, "ll_steps": lls}
+
+    def run_aux(self, U, Y, mode=1, ll_steps=False):
+        Y = f64(Y).reshape(-1, self.ny)
+        T = Y.shape[0]
+        U = f64(U).reshape(T, self.nu) if self.nu else None
+        ll = np.zeros(self.F)
+        lls = np.zeros((T, self.F)) if ll_steps else None
+        check(self.L.llpf_bank_aux_run(self.h, dptr(U), dptr(Y), T, int(mode), dptr(ll), dptr(lls)))
         return {"ll": ll, "ll_steps": lls}
 
     def last_run_ms(self):

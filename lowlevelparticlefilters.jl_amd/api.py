@@ -23,7 +23,7 @@ from . import _structs as S
 __all__ = [
     "MvNormal", "ResampleSystematic", "ResampleStratified",
     "LinearDynamics", "LinearMeasurement", "QuadTankDynamics", "QuadTankMeasurement", "GaussianLikelihood",
-    "ParticleFilter", "AdvancedParticleFilter", "FilterBank", "ParticleFilteringSolution",
+    "ParticleFilter", "AdvancedParticleFilter", "AuxiliaryParticleFilter", "FilterBank", "ParticleFilteringSolution",
     "reset", "predict", "correct", "update", "forward_trajectory", "mean_trajectory", "loglik",
     "particles", "weights", "expweights", "state", "num_particles", "index", "effective_particles",
     "shouldresample", "resample", "weighted_mean", "logsumexp", "simulate", "parameters",
@@ -214,6 +214,28 @@ class AdvancedParticleFilter(_AbstractParticleFilter):
         self.measurement_likelihood = measurement_likelihood
 
 
+class AuxiliaryParticleFilter:
+    """AuxiliaryParticleFilter(args...; kwargs...) = AuxiliaryParticleFilter(ParticleFilter(args...; kwargs...)) or
+    AuxiliaryParticleFilter(pf) — reference src/PFtypes.jl:38-49.  Everything but predict!/correct!/update!/
+    forward_trajectory/loglik is forwarded to the wrapped filter (PFtypes.jl:101-105, 299)."""
+
+    def __init__(self, *args, **kwargs):
+        if len(args) == 1 and not kwargs and isinstance(args[0], _AbstractParticleFilter):
+            pf = args[0]
+        else:
+            pf = ParticleFilter(*args, **kwargs)
+        if isinstance(pf, AdvancedParticleFilter):
+            raise NotImplementedError("AuxiliaryParticleFilter{AdvancedParticleFilter} (reference src/filtering.jl:219-234) is not provided")
+        object.__setattr__(self, "pf", pf)
+
+    def __getattr__(self, name):            # getproperty forwarding, src/PFtypes.jl:101-105
+        return getattr(object.__getattribute__(self, "pf"), name)
+
+    # pf(u, y, y1, p, t): update! (reference src/filtering.jl:239)
+    def __call__(self, u, y, y1, p=None, t=None):
+        return update(self, u, y, y1, p, t)
+
+
 class _StateView:
     """Read-only view with the reference's PFstate field names (src/PFtypes.jl:8-17)."""
 
@@ -251,34 +273,60 @@ def _t(pf, t):
     return pf._h.index() * pf.Ts if t is None else float(t)
 
 
-def predict(pf, u, p=None, t=None):
-    """predict!(pf, u, p, t = index(pf)*Ts) — reference src/filtering.jl:140-153."""
-    pf._h.predict(u, _t(pf, t))
+def _pt(args, kw, skip):
+    """(p, t) from the trailing positional / keyword arguments of a verb."""
+    rest = list(args[skip:])
+    p = rest[0] if len(rest) > 0 else kw.get("p")
+    t = rest[1] if len(rest) > 1 else kw.get("t")
+    return p, t
+
+
+def predict(pf, u, *args, **kw):
+    """predict!(pf, u, p, t = index(pf)*Ts) — reference src/filtering.jl:140-153;
+    predict!(pf::AuxiliaryParticleFilter, u, y1, p, t) — :195-217 (y1 = the NEXT measurement)."""
+    if isinstance(pf, AuxiliaryParticleFilter):
+        y1 = args[0] if args else kw.get("y1")
+        pf._h.aux_predict(u, y1, _t(pf, _pt(args, kw, 1)[1]))
+        return
+    pf._h.predict(u, _t(pf, _pt(args, kw, 0)[1]))
 
 
 def correct(pf, u, y, p=None, t=None):
-    """ll, 0 = correct!(pf, u, y, p, t) — reference src/filtering.jl:164-168.  y=None means missing."""
+    """ll, 0 = correct!(pf, u, y, p, t) — reference src/filtering.jl:164-168.  y=None means missing.
+    For an AuxiliaryParticleFilter (:170-174) only logsumexp! runs: the measurement update was done in predict!."""
+    if isinstance(pf, AuxiliaryParticleFilter):
+        return pf._h.aux_correct(), 0
     return pf._h.correct(u, y, _t(pf, t)), 0
 
 
-def update(pf, u, y, p=None, t=None):
-    """ll, 0 = update!(pf, u, y, p, t) — reference src/filtering.jl:181-185."""
-    return pf._h.update(u, y, _t(pf, t)), 0
+def update(pf, u, y, *args, **kw):
+    """ll, 0 = update!(pf, u, y, p, t) — reference src/filtering.jl:181-185;
+    update!(pf::AuxiliaryParticleFilter, u, y, y1, p, t) — :187-191."""
+    if isinstance(pf, AuxiliaryParticleFilter):
+        y1 = args[0] if args else kw.get("y1")
+        return pf._h.aux_update(u, y1, _t(pf, _pt(args, kw, 1)[1])), 0
+    return pf._h.update(u, y, _t(pf, _pt(args, kw, 0)[1])), 0
 
 
 def forward_trajectory(pf, u, y, p=None):
-    """sol = forward_trajectory(pf, u, y, p) — reference src/filtering.jl:343-365.  The whole T-step loop is
-    enqueued on the device; callbacks of the reference signature are not supported (a fused on-device loop
-    cannot call back into the host) — drive update() step by step if they are needed."""
+    """sol = forward_trajectory(pf, u, y, p) — reference src/filtering.jl:343-365 (:367-384 for the auxiliary
+    filter).  The whole T-step loop is enqueued on the device; callbacks of the reference signature are not
+    supported (a fused on-device loop cannot call back into the host) — drive update() step by step if needed."""
     reset(pf)
-    r = pf._h.run(u, y, t_index0=0.0, history=True)
+    if isinstance(pf, AuxiliaryParticleFilter):
+        r = pf._h.run_aux(u, y, mode=0, history=True)
+    else:
+        r = pf._h.run(u, y, t_index0=0.0, history=True)
     return ParticleFilteringSolution(pf, u, y, r["x"], r["w"], r["we"], r["ll"])
 
 
 def loglik(pf, u, y, p=None):
     """loglik(pf, u, y, p) — reference src/smoothing.jl:227-230 (reset!, then sum of update! with
-    t = index(pf)*Ts, i.e. the first step is at t = 1*Ts)."""
+    t = index(pf)*Ts, i.e. the first step is at t = 1*Ts); :232-236 for the auxiliary filter (t = (k-1)*Ts, the
+    last step is an update! of the wrapped filter)."""
     reset(pf)
+    if isinstance(pf, AuxiliaryParticleFilter):
+        return pf._h.run_aux(u, y, mode=1)["ll"]
     return pf._h.run(u, y, t_index0=1.0)["ll"]
 
 

@@ -135,6 +135,9 @@ struct Bank {
     uint64_t* d_tileq = nullptr;
     uint32_t* d_flag = nullptr;
     double* d_xmpart = nullptr;
+    double* d_lam = nullptr;          // [F][Ns] lambda of the AuxiliaryParticleFilter predict! (allocated on first use)
+    bool aux_pending = false;         // w holds lambda - log N of an aux predict!; their exp-sums wait in slot (parity+2)%3
+    bool we_is_lambda = false;        // expweights(pf) returns lambda until the next correct! (the reference keeps it in `we`)
     int parity = 0;                  // accumulator slot (0..2) the NEXT weighting kernel writes (engine.hpp ACC_NSLOT)
     double* d_uy = nullptr;          // staging for single-step u / y (2 * MAXD)
     double* d_U = nullptr;           // resident inputs of a run
@@ -170,7 +173,7 @@ struct Bank {
         b.models = d_models; b.scal = d_scal;
         b.xcur = d_x[cur]; b.xnext = d_x[cur ^ 1];
         b.w = d_w; b.anc = d_anc; b.acc = d_acc; b.quanta = d_quanta[qcur]; b.quanta_next = d_quanta[qcur ^ 1]; b.tileq = d_tileq;
-        b.bank_flag = d_flag; b.xmpart = d_xmpart;
+        b.bank_flag = d_flag; b.xmpart = d_xmpart; b.lam = d_lam;
         b.anc_slot = (int32_t)(n_predict & 1u); b.pad0 = 0;
         return b;
     }
@@ -188,7 +191,7 @@ static void free_bank(Bank& b) {
     hipSetDevice(b.device);
     if (b.stream) hipStreamSynchronize(b.stream);
     hipFree(b.d_models); hipFree(b.d_scal); hipFree(b.d_x[0]); hipFree(b.d_x[1]); hipFree(b.d_w);
-    hipFree(b.d_anc); hipFree(b.d_acc); hipFree(b.d_quanta[0]); hipFree(b.d_quanta[1]); hipFree(b.d_tileq); hipFree(b.d_flag); hipFree(b.d_xmpart); hipFree(b.d_uy); hipFree(b.d_U); hipFree(b.d_Y);
+    hipFree(b.d_anc); hipFree(b.d_acc); hipFree(b.d_quanta[0]); hipFree(b.d_quanta[1]); hipFree(b.d_tileq); hipFree(b.d_flag); hipFree(b.d_xmpart); hipFree(b.d_lam); hipFree(b.d_uy); hipFree(b.d_U); hipFree(b.d_Y);
     hipFree(b.d_ll_steps); hipFree(b.d_xmean); hipFree(b.d_tmp);
     for (auto e : b.ev_pool) hipEventDestroy(e);
     for (auto& e : b.pending) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
@@ -254,6 +257,7 @@ static void prof_collect(Bank& b) {
 }
 
 static int bank_init_particles(Bank& b, bool is_reset) {
+    b.aux_pending = false; b.we_is_lambda = false;
     // constructor (src/PFtypes.jl:65-75): x ~ d0, w = log(1/N), j = 1:N, t = 0
     // reset!      (src/filtering.jl:4-14): x ~ d0, w = -log N, we = 1/N, t = 1   (j untouched)
     std::vector<FilterScal> h;
@@ -403,6 +407,7 @@ static int need_e2(const Bank& b) { return b.cfg.resample_threshold != 1.0 ? 1 :
 // ---- single steps -------------------------------------------------------------------------------
 static int bank_correct(Bank& b, const double* u, const double* y, double t, double* ll_out /* [F] */) {
     CHK(use_device(b));
+    b.aux_pending = false; b.we_is_lambda = false;      // new weights supersede pending aux sums
     const bool has_y = (y != nullptr) && !(y[0] != y[0]);
     double hbuf[2 * MAXD] = {0};
     if (u) for (int i = 0; i < b.nu; ++i) hbuf[i] = u[i];
@@ -479,6 +484,7 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
     if (!Y) return fail(LLPF_ERR_ARG, "Y is null");
     if (b.nu > 0 && !U) return fail(LLPF_ERR_ARG, "U is null");
     if ((x_hist || w_hist || we_hist) && b.F != 1) return fail(LLPF_ERR_ARG, "history outputs need a single filter");
+    b.aux_pending = false; b.we_is_lambda = false;
     CHK(ensure(&b.d_U, &b.capU, (size_t)T * (b.nu > 0 ? b.nu : 1)));
     CHK(ensure(&b.d_Y, &b.capY, (size_t)T * b.ny));
     if (b.nu > 0) HIPC(hipMemcpyAsync(b.d_U, U, sizeof(double) * T * b.nu, hipMemcpyHostToDevice, b.stream));
@@ -696,6 +702,202 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
     return check_status(b, h);
 }
 
+// ---- AuxiliaryParticleFilter{ParticleFilter} (reference src/filtering.jl:170-217, 367-384; smoothing.jl:232-236) ----
+// correct!(pf::AuxiliaryParticleFilter): ll = logsumexp!(state) only.  Weights produced by an aux predict! have their
+// exp-sums (against the bound c0 - log N) waiting in an accumulator slot: one finalize launch.  Any other weights
+// (uniform after reset!, already normalised, installed) are normalised in the exact-max form.
+static int bank_aux_correct(Bank& b, double* ll_out /* [F] or null */, double* d_xmean, int64_t k) {
+    CHK(use_device(b));
+    const int K = llpf_qbits(b.N);
+    if (b.aux_pending) {
+        const int slot = (b.parity + ACC_NSLOT - 1) % ACC_NSLOT;
+        BankDev d = b.dev();
+        ResArgs ra{};
+        ra.mode = RES_FINALIZE; ra.parity = slot; ra.M = (int32_t)b.N; ra.fast_head = 1; ra.k = 0; ra.K = K;
+        ra.xmean = d_xmean; ra.want_xmean = d_xmean ? 1 : 0; ra.k = k;
+        HIPC(launch_resample(d, ra, b.stream));
+        std::vector<int> fl;
+        int64_t kf;
+        CHK(poll_fallback(b, fl, kf));
+        if (!fl.empty()) {   // bound test failed: exact-max normalisation of the same weights (their max is in the slot)
+            CHK(clear_slot_sums(b, slot, fl));
+            HIPC(launch_norm(d, slot, d_xmean ? 1 : 0, 1, b.n_predict, 1, 0, 0, b.stream));
+            ra.fast_head = 0; ra.only_fallback = 1;
+            HIPC(launch_resample(d, ra, b.stream));
+            CHK(clear_fallback(b, fl));
+        }
+    } else {
+        {
+            BankDev d = b.dev();
+            HIPC(launch_bake_weights(d, b.stream));
+        }
+        std::vector<FilterScal> h;
+        CHK(scal_download(b, h));
+        for (auto& s : h) { s.uniform = 0; s.norm_pending = 0; }
+        CHK(scal_upload(b, h));
+        HIPC(hipMemsetAsync(b.d_acc, 0, sizeof(uint64_t) * (size_t)b.F * ACC_WORDS, b.stream));
+        HIPC(hipMemsetAsync(b.d_tileq, 0, sizeof(uint64_t) * (size_t)ACC_NSLOT * b.F * b.P2, b.stream));
+        b.parity = 0;
+        BankDev d = b.dev();
+        HIPC(launch_max(d, b.parity, b.stream));
+        HIPC(launch_norm(d, b.parity, d_xmean ? 1 : 0, 1, b.n_predict, 0, 0, 0, b.stream));
+        ResArgs ra{};
+        ra.mode = RES_FINALIZE; ra.parity = b.parity; ra.M = (int32_t)b.N; ra.fast_head = 0; ra.K = K;
+        ra.xmean = d_xmean; ra.want_xmean = d_xmean ? 1 : 0; ra.k = k;
+        HIPC(launch_resample(d, ra, b.stream));
+        b.parity = (b.parity + 1) % ACC_NSLOT;
+    }
+    b.aux_pending = false;
+    b.we_is_lambda = false;
+    std::vector<FilterScal> h;
+    CHK(scal_download(b, h));
+    if (ll_out) for (int f = 0; f < b.F; ++f) ll_out[f] = h[f].ll;
+    return check_status(b, h);
+}
+
+// predict!(pf::AuxiliaryParticleFilter, u, y1, p, t): two launches —
+//   k_step<MODE_AUX>  x' = f(x) (no noise), lambda = logpdf(dg, y1 - g(x')), w <- w_norm + lambda, exp-sums of w
+//   k_resprop<AUX>    expnormalize! (head) + resample (always) + x = x'[j] + noise, w = lambda - log N, exp-sums
+// d_u / d_y1 are device pointers
+static int aux_predict_dev(Bank& b, const double* d_u, const double* d_y1, bool has_y1, double t, int want_xm) {
+    if (b.aux_pending) CHK(bank_aux_correct(b, nullptr, nullptr, 0));   // contract: predict! works on normalised weights
+    if (!b.d_lam) {
+        HIPC(hipMalloc(&b.d_lam, sizeof(double) * (size_t)b.F * b.Ns));
+        HIPC(hipMemsetAsync(b.d_lam, 0, sizeof(double) * (size_t)b.F * b.Ns, b.stream));
+    }
+    const int K = llpf_qbits(b.N);
+    const int slot1 = b.parity;
+    {
+        BankDev d = b.dev();
+        StepArgs a{};
+        a.u = d_u; a.y = d_y1; a.t_prop = t; a.t_meas = t; a.step = b.n_predict; a.has_y = has_y1 ? 1 : 0;
+        a.parity = slot1; a.need_e2 = 0; a.K = K; a.k = 0; a.next_step = b.n_predict; a.accumulate = 1;
+        HIPC(launch_step(d, MODE_AUX, a, b.stream));
+    }
+    b.parity = (b.parity + 1) % ACC_NSLOT;
+    b.qcur ^= 1;
+    b.cur ^= 1;                                   // the noise-free prediction is the source of the second half
+    {
+        BankDev d = b.dev();
+        ResArgs ra{};
+        ra.mode = RES_FINALIZE | RES_RESAMPLE; ra.parity = slot1; ra.step = b.n_predict; ra.M = (int32_t)b.N;
+        ra.anc_out = b.d_anc; ra.force = 1; ra.fast_head = 1; ra.u_from_scal = 1; ra.K = K; ra.k = 0;
+        StepArgs st{};
+        st.u = nullptr; st.y = nullptr; st.t_prop = t; st.t_meas = t; st.step = b.n_predict; st.has_y = 0;
+        st.parity = b.parity; st.need_e2 = 0; st.K = K; st.k = 0; st.next_step = b.n_predict + 1;
+        st.want_xmean = want_xm; st.accumulate = 1; st.aux = has_y1 ? 2 : 1;
+        HIPC(launch_resprop(d, ra, st, 1, b.stream));
+        std::vector<int> fl;
+        int64_t kf;
+        CHK(poll_fallback(b, fl, kf));
+        if (!fl.empty()) {   // expnormalize! of w + lambda in the exact-max form, then the second half again
+            CHK(clear_slot_sums(b, slot1, fl));
+            HIPC(launch_norm(d, slot1, 0, 0, b.n_predict, 1, 0, 0, b.stream));
+            ra.fast_head = 0; ra.only_fallback = 1; st.only_fallback = 1;
+            HIPC(launch_resprop(d, ra, st, 1, b.stream));
+            CHK(clear_fallback(b, fl));
+        }
+    }
+    b.parity = (b.parity + 1) % ACC_NSLOT;
+    b.qcur ^= 1;
+    b.cur ^= 1;
+    b.n_predict++;
+    b.t_index++;
+    b.aux_pending = true;
+    b.we_is_lambda = true;
+    return LLPF_OK;
+}
+
+static int bank_aux_predict(Bank& b, const double* u, const double* y1, double t) {
+    CHK(use_device(b));
+    const bool has_y = (y1 != nullptr) && !(y1[0] != y1[0]);
+    double hbuf[2 * MAXD] = {0};
+    if (u) for (int i = 0; i < b.nu; ++i) hbuf[i] = u[i];
+    if (has_y) for (int i = 0; i < b.ny; ++i) hbuf[MAXD + i] = y1[i];
+    HIPC(hipMemcpyAsync(b.d_uy, hbuf, sizeof(hbuf), hipMemcpyHostToDevice, b.stream));
+    CHK(aux_predict_dev(b, b.d_uy, b.d_uy + MAXD, has_y, t, 0));
+    HIPC(hipStreamSynchronize(b.stream));
+    std::vector<FilterScal> h;
+    CHK(scal_download(b, h));
+    return check_status(b, h);
+}
+
+static int bank_correct(Bank& b, const double* u, const double* y, double t, double* ll_out);
+static int bank_predict(Bank& b, const double* u, double t);
+
+// mode 0: the loop of forward_trajectory(pf::AuxiliaryParticleFilter) (src/filtering.jl:367-384, after reset!)
+// mode 1: the loop of loglik(pf::AuxiliaryParticleFilter) (src/smoothing.jl:232-236): T-1 aux updates, then one update!
+//         of the wrapped ParticleFilter on (u[end], y[end]).  Step-synchronous (one host round trip per timestep).
+static int bank_aux_run(Bank& b, const double* U, const double* Y, int64_t T, int mode, double* ll_total /* [F] */,
+                        double* ll_steps, double* xmean, double* x_hist, double* w_hist, double* we_hist) {
+    CHK(use_device(b));
+    if (T < 1) return fail(LLPF_ERR_ARG, "T must be >= 1");
+    if (!Y) return fail(LLPF_ERR_ARG, "Y is null");
+    if (b.nu > 0 && !U) return fail(LLPF_ERR_ARG, "U is null");
+    if (mode != 0 && mode != 1) return fail(LLPF_ERR_ARG, "mode must be 0 (forward_trajectory) or 1 (loglik)");
+    if ((x_hist || w_hist || we_hist) && b.F != 1) return fail(LLPF_ERR_ARG, "history outputs need a single filter");
+    CHK(ensure(&b.d_U, &b.capU, (size_t)T * (b.nu > 0 ? b.nu : 1)));
+    CHK(ensure(&b.d_Y, &b.capY, (size_t)T * b.ny));
+    if (b.nu > 0) HIPC(hipMemcpyAsync(b.d_U, U, sizeof(double) * T * b.nu, hipMemcpyHostToDevice, b.stream));
+    HIPC(hipMemcpyAsync(b.d_Y, Y, sizeof(double) * T * b.ny, hipMemcpyHostToDevice, b.stream));
+    if (xmean) CHK(ensure(&b.d_xmean, &b.cap_xm, (size_t)T * b.F * b.nx));
+    const double Ts = b.cfg.model.Ts;
+    std::vector<double> tot(b.F, 0.0), lls(b.F, 0.0);
+    b.run_resamples = 0;
+    {
+        std::vector<FilterScal> h;
+        CHK(scal_download(b, h));
+        for (int f = 0; f < b.F; ++f) b.run_resamples -= h[f].resample_count;
+    }
+    HIPC(hipEventRecord(b.ev_run0, b.stream));
+    for (int64_t k = 0; k < T; ++k) {
+        const double ti = (double)k * Ts;
+        if (mode == 1 && k == T - 1) {
+            CHK(bank_correct(b, b.nu > 0 ? U + k * b.nu : nullptr, Y + k * b.ny, ti, lls.data()));
+            CHK(bank_predict(b, b.nu > 0 ? U + k * b.nu : nullptr, ti));
+        } else {
+            CHK(bank_aux_correct(b, lls.data(), xmean ? b.d_xmean : nullptr, k));
+            BankDev d = b.dev();
+            if (x_hist) {
+                HIPC(launch_soa2aos(d, b.d_x[b.cur], b.d_tmp, b.stream));
+                HIPC(hipMemcpyAsync(x_hist + (size_t)k * b.N * b.nx, b.d_tmp, sizeof(double) * b.N * b.nx, hipMemcpyDeviceToHost, b.stream));
+                HIPC(hipStreamSynchronize(b.stream));
+            }
+            if (w_hist) {
+                HIPC(launch_materialize(d, b.d_tmp, nullptr, b.stream));
+                HIPC(hipMemcpyAsync(w_hist + (size_t)k * b.N, b.d_tmp, sizeof(double) * b.N, hipMemcpyDeviceToHost, b.stream));
+                HIPC(hipStreamSynchronize(b.stream));
+            }
+            if (we_hist) {
+                HIPC(launch_materialize(d, nullptr, b.d_tmp, b.stream));
+                HIPC(hipMemcpyAsync(we_hist + (size_t)k * b.N, b.d_tmp, sizeof(double) * b.N, hipMemcpyDeviceToHost, b.stream));
+                HIPC(hipStreamSynchronize(b.stream));
+            }
+            if (k < T - 1) {
+                const double* yk1 = Y + (k + 1) * b.ny;
+                const bool has_y1 = !(yk1[0] != yk1[0]);
+                CHK(aux_predict_dev(b, b.nu > 0 ? b.d_U + k * b.nu : nullptr, b.d_Y + (k + 1) * b.ny, has_y1, ti, xmean ? 1 : 0));
+            }
+        }
+        for (int f = 0; f < b.F; ++f) {
+            tot[f] += lls[f];
+            if (ll_steps) ll_steps[(size_t)k * b.F + f] = lls[f];
+        }
+    }
+    HIPC(hipEventRecord(b.ev_run1, b.stream));
+    if (xmean) HIPC(hipMemcpyAsync(xmean, b.d_xmean, sizeof(double) * T * b.F * b.nx, hipMemcpyDeviceToHost, b.stream));
+    std::vector<FilterScal> h;
+    CHK(scal_download(b, h));
+    float ms = 0.f;
+    HIPC(hipEventElapsedTime(&ms, b.ev_run0, b.ev_run1));
+    b.last_run_ms = ms;
+    for (int f = 0; f < b.F; ++f) {
+        if (ll_total) ll_total[f] = tot[f];
+        b.run_resamples += h[f].resample_count;
+    }
+    return check_status(b, h);
+}
+
 // ---- accessors ----------------------------------------------------------------------------------
 static int bank_get_particles(Bank& b, double* dst) {
     CHK(use_device(b));
@@ -707,6 +909,12 @@ static int bank_get_particles(Bank& b, double* dst) {
 }
 static int bank_get_w(Bank& b, double* dst, bool expw) {
     CHK(use_device(b));
+    if (expw && b.we_is_lambda) {     // after an aux predict! the reference's `we` holds lambda (src/filtering.jl:200-203)
+        HIPC(hipMemcpy2DAsync(dst, sizeof(double) * b.N, b.d_lam, sizeof(double) * b.Ns, sizeof(double) * b.N, b.F,
+                              hipMemcpyDeviceToHost, b.stream));
+        HIPC(hipStreamSynchronize(b.stream));
+        return LLPF_OK;
+    }
     BankDev d = b.dev();
     HIPC(launch_materialize(d, expw ? nullptr : b.d_tmp, expw ? b.d_tmp : nullptr, b.stream));
     HIPC(hipMemcpyAsync(dst, b.d_tmp, sizeof(double) * (size_t)b.F * b.N, hipMemcpyDeviceToHost, b.stream));
@@ -716,6 +924,7 @@ static int bank_get_w(Bank& b, double* dst, bool expw) {
 
 static int bank_set_weights(Bank& b, const double* w) {
     CHK(use_device(b));
+    b.aux_pending = false; b.we_is_lambda = false;
     std::vector<double> stage((size_t)b.F * b.Ns, -INFINITY);
     for (int f = 0; f < b.F; ++f) memcpy(stage.data() + (size_t)f * b.Ns, w + (size_t)f * b.N, sizeof(double) * b.N);
     HIPC(hipMemcpyAsync(b.d_w, stage.data(), sizeof(double) * stage.size(), hipMemcpyHostToDevice, b.stream));
@@ -810,6 +1019,35 @@ int llpf_run(llpf_filter* f, const double* U, const double* Y, int64_t T, double
                       o ? o->x_hist : nullptr, o ? o->w_hist : nullptr, o ? o->we_hist : nullptr);
     if (ll_total) *ll_total = lt;
     return rc;
+}
+
+int llpf_aux_correct(llpf_filter* f, double* ll) {
+    NEEDF(f);
+    double l = 0.0;
+    int rc = bank_aux_correct(f->bank, &l, nullptr, 0);
+    if (ll) *ll = l;
+    return rc;
+}
+int llpf_aux_predict(llpf_filter* f, const double* u, const double* y1, double t) { NEEDF(f); return bank_aux_predict(f->bank, u, y1, t); }
+int llpf_aux_update(llpf_filter* f, const double* u, const double* y1, double t, double* ll) {
+    NEEDF(f);
+    int rc = llpf_aux_correct(f, ll);
+    if (rc != LLPF_OK) return rc;
+    return bank_aux_predict(f->bank, u, y1, t);
+}
+int llpf_aux_run(llpf_filter* f, const double* U, const double* Y, int64_t T, int32_t mode,
+                 double* ll_total, const llpf_run_outputs* o) {
+    NEEDF(f);
+    double lt = 0.0;
+    int rc = bank_aux_run(f->bank, U, Y, T, mode, &lt, o ? o->ll_steps : nullptr, o ? o->xmean : nullptr,
+                          o ? o->x_hist : nullptr, o ? o->w_hist : nullptr, o ? o->we_hist : nullptr);
+    if (ll_total) *ll_total = lt;
+    return rc;
+}
+int llpf_bank_aux_run(llpf_bank* b, const double* U, const double* Y, int64_t T, int32_t mode,
+                      double* ll_total, double* ll_steps) {
+    if (!b) return fail(LLPF_ERR_ARG, "null bank");
+    return bank_aux_run(b->bank, U, Y, T, mode, ll_total, ll_steps, nullptr, nullptr, nullptr, nullptr);
 }
 
 int llpf_num_particles(const llpf_filter* f, int64_t* n) { NEEDF(f); if (n) *n = f->bank.N; return LLPF_OK; }

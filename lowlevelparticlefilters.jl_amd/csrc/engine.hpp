@@ -140,11 +140,14 @@ struct BankDev {
     uint32_t* bank_flag; // [1] 0, or 1 + the run-step index at which some filter's bound test failed: every later
                          //     launch of the run is a no-op until the host has redone that step in exact form
     double* xmpart;      // [F][P1][MAXD]
+    double* lam;         // [F][Ns] lambda of the AuxiliaryParticleFilter predict! (nullptr until first used)
     int32_t anc_slot;    // n_predict & 1: index of the current FilterScal::anc_ident_s entry
     int32_t pad0;
 };
 
-enum StepMode { MODE_WEIGHT = 0, MODE_PROP = 1, MODE_PROP_WEIGHT = 2 };
+// MODE_AUX: first half of the AuxiliaryParticleFilter predict! (reference src/filtering.jl:195-205): noise-free
+// propagate of every particle (no ancestors), lambda = logpdf(y1 - g(x)), w <- w_norm + lambda, exp-sums of the new w
+enum StepMode { MODE_WEIGHT = 0, MODE_PROP = 1, MODE_PROP_WEIGHT = 2, MODE_AUX = 3 };
 
 struct StepArgs {
     const double* u;       // device pointer to u of the propagate (nu doubles) or nullptr
@@ -162,7 +165,7 @@ struct StepArgs {
     int32_t want_xmean;    // also accumulate per-block sums e_i x_i for the weighted-mean output of the next finalize
     int32_t accumulate;    // 1: this weighting kernel also computes the exp-sums / quanta / tile sums of its weights (one launch
                            //    per timestep); 0: a k_norm launch in bound form does (better when the chip is saturated)
-    int32_t pad3;
+    int32_t aux;           // second half of the AuxiliaryParticleFilter predict! (k_resprop<AUX>): 1 = y1 missing, 2 = y1 present
 };
 
 enum { RES_FINALIZE = 1, RES_RESAMPLE = 2 };
@@ -207,6 +210,7 @@ hipError_t launch_post_predict(const BankDev& b, hipStream_t s);
 hipError_t launch_resample(const BankDev& b, const ResArgs& a, hipStream_t s);
 // fused finalize + resample + propagate [+ weight]: one launch for predict!(u_k) and the weighting of correct!(u_{k+1}, y_{k+1})
 hipError_t launch_resprop(const BankDev& b, const ResArgs& a, const StepArgs& st, int weight, hipStream_t s);
+hipError_t launch_bake_weights(const BankDev& b, hipStream_t s);   // w[] <- the normalised / uniform values it stands for (padding -Inf)
 hipError_t launch_materialize(const BankDev& b, double* w_out, double* we_out, hipStream_t s);
 hipError_t launch_soa2aos(const BankDev& b, const double* xsrc, double* dst, hipStream_t s);
 hipError_t launch_aos2soa(const BankDev& b, const double* src, double* xdst, hipStream_t s);

@@ -438,7 +438,7 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
     const FilterScal* sc = scal + f;
     if (run_is_stopped(b, a.k)) return;
     if (a.only_fallback ? !sc->fallback : (sc->fallback != 0)) return;   // redo launches take the flagged filters, all others skip them
-    const int do_res = (MODE != MODE_WEIGHT) ? sc->do_resample : 0;
+    const int do_res = (MODE != MODE_WEIGHT && MODE != MODE_AUX) ? sc->do_resample : 0;
     const int uniform = sc->uniform, pend = sc->norm_pending;
     const double m = sc->m, l = sc->l, wconst = sc->wconst;
     const uint32_t k0 = sc->k0, k1 = sc->k1;
@@ -496,10 +496,15 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
             for (int p = 0; p < STEP_PPT; ++p) {
                 double fx[NX], xi[NX], nz[NX];
                 model.dynamics(xp[p], fx);
-                llpf_normals((uint32_t)(i0 + p), a.step, LLPF_STREAM_DYNAMICS, k0, k1, NX, xi);
-                gauss_sample<NX>(md->df, xi, nz);
+                if (MODE == MODE_AUX) {            // propagate_particles!(pf, u, p, t, nothing): no noise
 #pragma unroll
-                for (int d = 0; d < NX; ++d) xs[p][d] = fx[d] + nz[d];
+                    for (int d = 0; d < NX; ++d) xs[p][d] = fx[d];
+                } else {
+                    llpf_normals((uint32_t)(i0 + p), a.step, LLPF_STREAM_DYNAMICS, k0, k1, NX, xi);
+                    gauss_sample<NX>(md->df, xi, nz);
+#pragma unroll
+                    for (int d = 0; d < NX; ++d) xs[p][d] = fx[d] + nz[d];
+                }
             }
 #pragma unroll
             for (int d = 0; d < NX; ++d) {
@@ -530,10 +535,22 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
                 wp[1] = pend ? (wv.y - m) - l : wv.y;
             }
             double wn[STEP_PPT];
+            double lamv[STEP_PPT];
 #pragma unroll
             for (int p = 0; p < STEP_PPT; ++p) {
                 double wv = wp[p];
-                if (a.has_y) {
+                if (MODE == MODE_AUX) {            // lambda .= 0; lambda += logpdf; w .+= lambda  (filtering.jl:201-204)
+                    double lam = 0.0;
+                    if (a.has_y) {
+                        double g[NY], v[NY];
+                        model.measurement(xs[p], g);
+#pragma unroll
+                        for (int k = 0; k < NY; ++k) v[k] = y[k] - g[k];
+                        lam = lam + gauss_logpdf<NY>(md->dg, v);
+                    }
+                    lamv[p] = lam;
+                    wv = wv + lam;
+                } else if (a.has_y) {
                     double g[NY], v[NY];
                     model.measurement(xs[p], g);
 #pragma unroll
@@ -549,6 +566,12 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
             wo.x = wn[0];
             wo.y = wn[1];
             *reinterpret_cast<double2*>(w + i0) = wo;
+            if (MODE == MODE_AUX) {
+                double2 lo;
+                lo.x = lamv[0];
+                lo.y = lamv[1];
+                *reinterpret_cast<double2*>(b.lam + (size_t)f * Ns + i0) = lo;
+            }
             if (a.accumulate) {   // merged schedule: exp-sums, quanta and tile sums of the new weights formed here
                 ulonglong2 qv;
                 double e0, e1;
@@ -588,7 +611,7 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
             }
         }
     }
-    if (MODE != MODE_WEIGHT && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (MODE != MODE_WEIGHT && MODE != MODE_AUX && blockIdx.x == 0 && threadIdx.x == 0) {
         // bookkeeping of this predict! (fields no block of this kernel reads): state.j == 1:N unless resampled
         FilterScal* scw = b.scal + f;
         scw->anc_ident_s[b.anc_slot ^ 1] = do_res ? 0 : 1;
@@ -1140,6 +1163,17 @@ template <class T> DEV void st_off(T* base, uint32_t byte_off, T v) {
     *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off) = v;
 }
 
+// placeholder model of the AuxiliaryParticleFilter's second half: the dynamics were applied by k_step<MODE_AUX>
+template <int NX>
+struct NoModel {
+    DEV void prepare(const ModelD*, const double*, double) {}
+    DEV void dynamics(const double* x, double* out) const {
+#pragma unroll
+        for (int d = 0; d < NX; ++d) out[d] = x[d];
+    }
+    DEV void measurement(const double*, double*) const {}
+};
+
 template <class Model, int NX, int NY, bool WEIGHT>
 struct PropCtx {
     const BankDev& b;
@@ -1220,7 +1254,7 @@ struct TileSum {
 };
 static_assert(TILE == 1024, "TileSum assumes 1024-particle tiles");
 
-template <class Model, int NX, int NY, bool WEIGHT, bool ACC>
+template <class Model, int NX, int NY, bool WEIGHT, bool ACC, bool AUX = false>
 __global__ __launch_bounds__(BLOCK) void k_resprop(BankDev b, const ModelD* __restrict__ models, ResArgs a, StepArgs st) {
     __shared__ ResShared sh;
     __shared__ double sm_max[BLOCK / 64];
@@ -1264,7 +1298,7 @@ __global__ __launch_bounds__(BLOCK) void k_resprop(BankDev b, const ModelD* __re
     //                j[i] untouched (resample.jl:25-34) -> previous ancestor (identity if the last predict! did
     //                not resample)
     //   otherwise  : s.j .= 1:N, the tile's own particles (padding lanes included so that their weight stays -Inf)
-    const bool res = h.dr && h.tot != 0;
+    const bool res = (h.dr || a.force) && h.tot != 0;
     int64_t first, last;
     int32_t c_end = 0;
     double l = 0.0;
@@ -1291,6 +1325,10 @@ __global__ __launch_bounds__(BLOCK) void k_resprop(BankDev b, const ModelD* __re
         const double wmx = res ? b.log1N : (h.mtrue - h.a) - l;
         pc.off = (WEIGHT && st.has_y) ? wmx + md->dg.c0 : wmx;
     }
+    const double lN = -b.mlogN;
+    const double aux_off = ((st.aux == 2) ? md->dg.c0 : 0.0) - lN;     // lambda - log N <= c0 - log N (lambda = 0 if y1 is missing)
+    if (AUX) pc.off = aux_off;
+    const double* lamp = AUX ? b.lam + (size_t)f * Ns : nullptr;
     const int32_t tbase = (int32_t)(first >> 10);
     LLPF_STAMP(2);
     if (a.dbg && threadIdx.x == 0 && f == 0) a.dbg[(size_t)tile * 8 + 5] = (uint64_t)(last - first);
@@ -1307,6 +1345,9 @@ __global__ __launch_bounds__(BLOCK) void k_resprop(BankDev b, const ModelD* __re
 #endif
             else src = anc_ident_prev ? o : (uint32_t)ld_off(anc, o << 2);
             st_off(anc, o << 2, (int32_t)src);
+            if (AUX) wprev = ld_off(lamp, o << 3) - lN;               // s.w[i] = lambda[i] - log N (unresampled index, filtering.jl:209-213)
+        } else if (AUX) {
+            wprev = ld_off(lamp, o << 3) - lN;
         } else if (WEIGHT) {
             wprev = (ld_off(pc.w, o << 3) - h.a) - l;                  // lazy w .-= offset ; w .-= log(sum)
         }
@@ -1338,6 +1379,11 @@ __global__ __launch_bounds__(BLOCK) void k_resprop(BankDev b, const ModelD* __re
             if (st.want_xmean) block_store_xm<NX>(xm, b.xmpart + ((size_t)f * b.P1 + tile) * MAXD, sm_x);
         }
         if (tile == 0 && threadIdx.x == 0) {
+            if (AUX) {     // the weights just written are final values (no pending normalisation); aux_off bounds them
+                sc->norm_pending = 0;
+                sc->uniform = 0;
+                sc->wmax = aux_off;
+            }
             if (ACC) sc->xm_parts = b.P2;
             sc->off_slot[st.parity] = pc.off;
             sc->e2v_slot[st.parity] = st.need_e2;
@@ -1348,7 +1394,7 @@ __global__ __launch_bounds__(BLOCK) void k_resprop(BankDev b, const ModelD* __re
     LLPF_STAMP(4);
 #undef LLPF_STAMP
     if (tile == b.P2 - 1 && threadIdx.x == 0) {        // bookkeeping of this predict! (by the only block that reads anc_ident)
-        const int r = (h.dr && h.tot != 0) ? 1 : 0;
+        const int r = res ? 1 : 0;
         sc->anc_ident_s[b.anc_slot ^ 1] = r ? 0 : 1;
         sc->last_resampled = r;
         sc->resample_count += r;
@@ -1398,6 +1444,19 @@ __global__ __launch_bounds__(BLOCK) void k_materialize(BankDev b, double* w_out,
     }
     if (w_out) w_out[(size_t)f * b.N + i] = wv;
     if (we_out) we_out[(size_t)f * b.N + i] = we;
+}
+
+// w[] <- the values it stands for (uniform constant / lazily normalised / as stored); padding lanes -Inf.  The
+// host clears the `uniform` / `norm_pending` flags afterwards.
+__global__ __launch_bounds__(BLOCK) void k_bake_weights(BankDev b) {
+    const int f = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= b.Ns) return;
+    const FilterScal* sc = b.scal + f;
+    double* w = b.w + (size_t)f * b.Ns;
+    double wv = -LLPF_INF;
+    if (i < b.N) wv = sc->uniform ? sc->wconst : (sc->norm_pending ? (w[i] - sc->m) - sc->l : w[i]);
+    w[i] = wv;
 }
 
 __global__ __launch_bounds__(BLOCK) void k_soa2aos(BankDev b, const double* __restrict__ xsrc, double* dst) {
@@ -1521,6 +1580,7 @@ static hipError_t launch_step_t(const BankDev& b, int mode, const StepArgs& a, h
         case MODE_WEIGHT: hipLaunchKernelGGL((k_step<Model, NX, NY, MODE_WEIGHT>), g, dim3(BLOCK), 0, s, b, b.models, b.scal, a); break;
         case MODE_PROP: hipLaunchKernelGGL((k_step<Model, NX, NY, MODE_PROP>), g, dim3(BLOCK), 0, s, b, b.models, b.scal, a); break;
         case MODE_PROP_WEIGHT: hipLaunchKernelGGL((k_step<Model, NX, NY, MODE_PROP_WEIGHT>), g, dim3(BLOCK), 0, s, b, b.models, b.scal, a); break;
+        case MODE_AUX: hipLaunchKernelGGL((k_step<Model, NX, NY, MODE_AUX>), g, dim3(BLOCK), 0, s, b, b.models, b.scal, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -1601,7 +1661,8 @@ hipError_t launch_resample(const BankDev& b, const ResArgs& a0, hipStream_t s) {
 template <class Model, int NX, int NY>
 static hipError_t launch_resprop_t(const BankDev& b, const ResArgs& a, const StepArgs& st, int weight, hipStream_t s) {
     dim3 g((unsigned)b.P2, (unsigned)b.F, 1);
-    if (weight && st.accumulate) hipLaunchKernelGGL((k_resprop<Model, NX, NY, true, true>), g, dim3(BLOCK), 0, s, b, b.models, a, st);
+    if (st.aux) hipLaunchKernelGGL((k_resprop<NoModel<NX>, NX, 1, true, true, true>), g, dim3(BLOCK), 0, s, b, b.models, a, st);
+    else if (weight && st.accumulate) hipLaunchKernelGGL((k_resprop<Model, NX, NY, true, true>), g, dim3(BLOCK), 0, s, b, b.models, a, st);
     else if (weight) hipLaunchKernelGGL((k_resprop<Model, NX, NY, true, false>), g, dim3(BLOCK), 0, s, b, b.models, a, st);
     else hipLaunchKernelGGL((k_resprop<Model, NX, NY, false, false>), g, dim3(BLOCK), 0, s, b, b.models, a, st);
     return hipGetLastError();
@@ -1630,6 +1691,10 @@ hipError_t launch_resprop(const BankDev& b, const ResArgs& a0, const StepArgs& s
     }
 }
 
+hipError_t launch_bake_weights(const BankDev& b, hipStream_t s) {
+    hipLaunchKernelGGL(k_bake_weights, grid1(b.Ns, b.F), dim3(BLOCK), 0, s, b);
+    return hipGetLastError();
+}
 hipError_t launch_materialize(const BankDev& b, double* w_out, double* we_out, hipStream_t s) {
     hipLaunchKernelGGL(k_materialize, grid1(b.N, b.F), dim3(BLOCK), 0, s, b, w_out, we_out);
     return hipGetLastError();

@@ -503,6 +503,10 @@ struct orc_filter {
     devnorm dn;
     int dn_valid;
     double wmax;                /* max of the current (normalised / uniform / installed) log-weights: the bound's input */
+    /* AuxiliaryParticleFilter (src/filtering.jl:170-217) */
+    double* lam;                /* lambda of the last aux predict! (the reference keeps it in `we`) */
+    int aux_pending;            /* w holds lambda - log N of an aux predict!, not yet normalised */
+    double aux_off;             /* device order: upper bound of those weights */
     double *xi_buf, *U_buf;
 };
 
@@ -562,7 +566,7 @@ orc_filter* orc_create(const llpf_config* cfg, int order) {
 void orc_destroy(orc_filter* f) {
     if (!f) return;
     free(f->x); free(f->xprev); free(f->w); free(f->we); free(f->bins); free(f->e); free(f->j);
-    free(f->xi_buf); free(f->U_buf); free(f);
+    free(f->xi_buf); free(f->U_buf); free(f->lam); free(f);
 }
 
 void orc_seed(orc_filter* f, uint64_t seed) { set_key(f, seed); }
@@ -570,6 +574,7 @@ void orc_seed(orc_filter* f, uint64_t seed) { set_key(f, seed); }
 /* reset!(pf) — src/filtering.jl:4-14 */
 void orc_reset_explicit(orc_filter* f, const double* xi) {
     init_particles(f, xi);
+    f->aux_pending = 0;
     fill_uniform_weights(f, f->order == ORC_ORDER_DEVICE ? -llpf_log((double)f->N) : -log((double)f->N));
     f->t = 1;
 }
@@ -580,11 +585,15 @@ void orc_reset(orc_filter* f) {
 }
 
 /* normalisation of the current raw log-weights in the filter's order */
-static double filter_logsumexp(orc_filter* f, double off) {
+static double filter_logsumexp(orc_filter* f, double off, int bound) {
     if (f->order == ORC_ORDER_DEVICE) {
-        dev_norm_bound(f->w, f->e, f->N, off, &f->dn);
+        if (bound) {
+            dev_norm_bound(f->w, f->e, f->N, off, &f->dn);
+            if (!f->dn.fast) f->n_exact_steps++;
+        } else {
+            dev_expsum(f->w, f->e, f->N, &f->dn);              /* no bound known for these weights: exact-max form */
+        }
         f->dn_valid = 1;
-        if (!f->dn.fast) f->n_exact_steps++;
         for (int64_t i = 0; i < f->N; ++i) {
             f->we[i] = f->e[i] * f->dn.inv;
             f->w[i] = (f->w[i] - f->dn.m) - f->dn.l;
@@ -615,7 +624,8 @@ double orc_correct(orc_filter* f, const double* u, const double* y, double t) {
             f->w[i] += gauss_logpdf(&f->dg, v);
         }
     }
-    return filter_logsumexp(f, off);
+    f->aux_pending = 0;
+    return filter_logsumexp(f, off, 1);
 }
 
 static double filter_ess(const orc_filter* f) {
@@ -719,6 +729,124 @@ void orc_predict(orc_filter* f, const double* u, double t) {
 double orc_update(orc_filter* f, const double* u, const double* y, double t) {
     double ll = orc_correct(f, u, y, t);
     orc_predict(f, u, t);
+    return ll;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * AuxiliaryParticleFilter{ParticleFilter} — src/PFtypes.jl:38-49, src/filtering.jl:170-217, 367-384,
+ * src/smoothing.jl:232-236.  (The {AdvancedParticleFilter} variant, filtering.jl:219-234, discards
+ * lambda and re-propagates with noise; not restated.)
+ * ---------------------------------------------------------------------------------------- */
+/* correct!(pf::AuxiliaryParticleFilter, u, y, p, t) — src/filtering.jl:170-174: the measurement update was done in
+ * the predict step, only ll = logsumexp!(state) remains (so y of the very first call is never used). */
+double orc_aux_correct(orc_filter* f) {
+    const int pend = f->aux_pending;
+    f->aux_pending = 0;
+    /* device order: weights produced by an aux predict! are bounded by aux_off (lambda <= c0); anything else
+     * (uniform after reset!, already normalised, installed) is normalised in the exact-max form */
+    return filter_logsumexp(f, f->aux_off, pend);
+}
+
+/* predict!(pf::AuxiliaryParticleFilter, u, y1, p, t) — src/filtering.jl:195-217 */
+void orc_aux_predict(orc_filter* f, const double* u, const double* y1, double t) {
+    const int64_t N = f->N;
+    const int nx = f->nx;
+    const uint32_t step = f->n_predict++;
+    gen_normals(f, step, LLPF_STREAM_DYNAMICS, f->xi_buf);
+    if (f->cfg.resampling_strategy == LLPF_RESAMPLE_SYSTEMATIC)
+        f->U_buf[0] = llpf_uniform_step(step, LLPF_STREAM_RESAMPLE, f->k0, f->k1);
+    else
+        for (int64_t i = 0; i < N; ++i)
+            f->U_buf[i] = llpf_uniform_idx((uint32_t)i, step, LLPF_STREAM_STRATIFY, f->k0, f->k1);
+    if (f->aux_pending) orc_aux_correct(f);                   /* (engine contract: weights are normalised first) */
+    if (!f->lam) f->lam = (double*)calloc((size_t)N, 8);
+    const int has_y = (y1 != NULL && y1[0] == y1[0]);
+    const int dev = f->order == ORC_ORDER_DEVICE;
+    /* propagate_particles!(pf.pf, u, p, t, nothing): x[i] = f(xprev[i], u, p, t), no noise — src/PFtypes.jl:261-274 */
+    ORC_PAR
+    for (int64_t i = 0; i < N; ++i) orc_dynamics(&f->cfg.model, f->xprev + i * nx, u, t, f->x + i * nx);
+    /* lambda = s.we; lambda .= 0; measurement_equation!(pf.pf, u, y1, p, t, lambda) — :201-203 */
+    ORC_PAR
+    for (int64_t i = 0; i < N; ++i) {
+        double lam = 0.0;
+        if (has_y) {
+            double g[MAXD], v[MAXD];
+            orc_measurement(&f->cfg.model, f->x + i * nx, u, t, g);
+            for (int k = 0; k < f->ny; ++k) v[k] = y1[k] - g[k];
+            lam += gauss_logpdf(&f->dg, v);
+        }
+        f->lam[i] = lam;
+        f->w[i] += lam;                                        /* s.w .+= lambda, :204 */
+    }
+    /* expnormalize!(s.w) (w used as buffer, :205) ; j = resample(strategy, s.w, s.j, s.bins), :206 */
+    if (dev) {
+        const double off = has_y ? f->wmax + f->dg.c0 : f->wmax;
+        dev_norm_bound(f->w, f->e, N, off, &f->dn);
+        if (!f->dn.fast) f->n_exact_steps++;
+        f->dn_valid = 1;
+        filter_resample_dev(f, f->U_buf);
+    } else {
+        orc_expnormalize_inplace(f->w, N);
+        orc_resample(f->cfg.resampling_strategy, f->w, N, N, f->U_buf, f->j, f->bins, ORC_ORDER_REFERENCE);
+    }
+    /* permute_with_buffer!(s.x, s.xprev, j): buf[i] = x[j[i]]; copyto!(x, buf) — src/utils.jl:81-86 */
+    for (int64_t i = 0; i < N; ++i)
+        for (int d = 0; d < nx; ++d) f->xprev[i * nx + d] = f->x[f->j[i] * nx + d];
+    /* add_noise!(pf.pf): x[i] += rand!(rng, df, noise) — src/PFtypes.jl:143-155 */
+    ORC_PAR
+    for (int64_t i = 0; i < N; ++i) {
+        double nz[MAXD];
+        gauss_sample(&f->df, f->xi_buf + i * nx, nz);
+        for (int d = 0; d < nx; ++d) f->x[i * nx + d] = f->xprev[i * nx + d] + nz[d];
+    }
+    /* s.w[i] = lambda[i] - log(N)  ("note unresampled lambda[i] instead of lambda[j[i]]", :209-213) */
+    const double lN = dev ? llpf_log((double)N) : log((double)N);
+    for (int64_t i = 0; i < N; ++i) {
+        f->w[i] = f->lam[i] - lN;
+        f->we[i] = f->lam[i];                                  /* the reference's `we` now holds lambda */
+    }
+    f->t += 1;                                                /* :215 */
+    memcpy(f->xprev, f->x, sizeof(double) * (size_t)N * nx);  /* :216 */
+    f->dn_valid = 0;
+    f->aux_pending = 1;
+    f->aux_off = (has_y ? f->dg.c0 : 0.0) - lN;
+    f->wmax = f->aux_off;                                      /* an upper bound of the current log-weights */
+    f->last_resampled = 1;
+    f->resample_count++;
+}
+
+/* update!(pf::AuxiliaryParticleFilter, u, y, y1, p, t) — src/filtering.jl:187-191 */
+double orc_aux_update(orc_filter* f, const double* u, const double* y1, double t) {
+    double ll = orc_aux_correct(f);
+    orc_aux_predict(f, u, y1, t);
+    return ll;
+}
+
+/* mode 0: forward_trajectory(pf::AuxiliaryParticleFilter, u, y, p) — src/filtering.jl:367-384 (after reset!)
+ * mode 1: loglik(pf::AuxiliaryParticleFilter, u, y, p) — src/smoothing.jl:232-236: T-1 aux updates, then one update!
+ *         of the wrapped ParticleFilter on (u[end], y[end]) */
+double orc_run_aux(orc_filter* f, const double* U, const double* Y, int64_t T, int mode,
+                   double* ll_steps, double* xmean, double* x_hist, double* w_hist, double* we_hist) {
+    double ll = 0.0;
+    size_t N = (size_t)f->N;
+    const double Ts = f->cfg.model.Ts;
+    for (int64_t k = 0; k < T; ++k) {
+        const double ti = (double)k * Ts;
+        const double* u = U + k * f->nu;
+        double lli;
+        if (mode == 1 && k == T - 1) {
+            lli = orc_update(f, u, Y + k * f->ny, ti);        /* pf.pf(u[end], y[end], p, (T-1)*Ts) */
+        } else {
+            lli = orc_aux_correct(f);
+            if (xmean) orc_weighted_mean(f, xmean + k * f->nx);
+            if (x_hist) memcpy(x_hist + (size_t)k * N * f->nx, f->x, 8 * N * f->nx);
+            if (w_hist) memcpy(w_hist + (size_t)k * N, f->w, 8 * N);
+            if (we_hist) memcpy(we_hist + (size_t)k * N, f->we, 8 * N);
+            if (k < T - 1) orc_aux_predict(f, u, Y + (k + 1) * f->ny, ti);
+        }
+        ll += lli;
+        if (ll_steps) ll_steps[k] = lli;
+    }
     return ll;
 }
 

@@ -53,6 +53,14 @@ double orc_update(orc_filter* f, const double* u, const double* y, double t);
 double orc_run(orc_filter* f, const double* U, const double* Y, int64_t T, double t_index0,
                double* ll_steps, double* xmean, double* x_hist, double* w_hist, double* we_hist);
 
+/* AuxiliaryParticleFilter{ParticleFilter}: correct! (logsumexp only), predict! with the look-ahead measurement y1,
+ * update!, and the loops of forward_trajectory (mode 0) / loglik (mode 1) */
+double orc_aux_correct(orc_filter* f);
+void   orc_aux_predict(orc_filter* f, const double* u, const double* y1 /* NULL = missing */, double t);
+double orc_aux_update(orc_filter* f, const double* u, const double* y1, double t);
+double orc_run_aux(orc_filter* f, const double* U, const double* Y, int64_t T, int mode,
+                   double* ll_steps, double* xmean, double* x_hist, double* w_hist, double* we_hist);
+
 int64_t orc_num_particles(const orc_filter* f);
 int64_t orc_index(const orc_filter* f);
 void   orc_get_particles(const orc_filter* f, double* dst);

@@ -38,6 +38,13 @@ def load():
     lib.orc_update.argtypes = [C.c_void_p, _dp, _dp, C.c_double]
     lib.orc_run.restype = C.c_double
     lib.orc_run.argtypes = [C.c_void_p, _dp, _dp, C.c_int64, C.c_double, _dp, _dp, _dp, _dp, _dp]
+    lib.orc_aux_correct.restype = C.c_double
+    lib.orc_aux_correct.argtypes = [C.c_void_p]
+    lib.orc_aux_predict.argtypes = [C.c_void_p, _dp, _dp, C.c_double]
+    lib.orc_aux_update.restype = C.c_double
+    lib.orc_aux_update.argtypes = [C.c_void_p, _dp, _dp, C.c_double]
+    lib.orc_run_aux.restype = C.c_double
+    lib.orc_run_aux.argtypes = [C.c_void_p, _dp, _dp, C.c_int64, C.c_int, _dp, _dp, _dp, _dp, _dp]
     lib.orc_num_particles.restype = C.c_int64
     lib.orc_num_particles.argtypes = [C.c_void_p]
     lib.orc_index.restype = C.c_int64
@@ -177,6 +184,33 @@ class OracleFilter:
                             dptr(xh), dptr(wh), dptr(weh))
         out.update(ll=ll, ll_steps=lls, xmean=xm, x=xh, w=wh, we=weh)
         return out
+
+    # AuxiliaryParticleFilter verbs (src/filtering.jl:170-217)
+    def aux_correct(self):
+        return self.L.orc_aux_correct(self.h)
+
+    def aux_predict(self, u, y1, t):
+        u = _f64(u)
+        yy = None if y1 is None else _f64(y1)
+        self.L.orc_aux_predict(self.h, dptr(u), dptr(yy), float(t))
+
+    def aux_update(self, u, y1, t):
+        u = _f64(u)
+        yy = None if y1 is None else _f64(y1)
+        return self.L.orc_aux_update(self.h, dptr(u), dptr(yy), float(t))
+
+    def run_aux(self, U, Y, mode=0, ll_steps=False, xmean=False, history=False):
+        """mode 0: forward_trajectory loop, mode 1: loglik loop (after reset!)."""
+        U = _f64(U).reshape(-1, max(self.nu, 1)) if self.nu else np.zeros((len(Y), 0))
+        Y = _f64(Y).reshape(-1, self.ny)
+        T = Y.shape[0]
+        lls = np.zeros(T) if ll_steps else None
+        xm = np.zeros((T, self.nx)) if xmean else None
+        xh = np.zeros((T, self.N, self.nx)) if history else None
+        wh = np.zeros((T, self.N)) if history else None
+        weh = np.zeros((T, self.N)) if history else None
+        ll = self.L.orc_run_aux(self.h, dptr(U), dptr(Y), T, int(mode), dptr(lls), dptr(xm), dptr(xh), dptr(wh), dptr(weh))
+        return dict(ll=ll, ll_steps=lls, xmean=xm, x=xh, w=wh, we=weh)
 
     def particles(self):
         a = np.empty((self.N, self.nx))

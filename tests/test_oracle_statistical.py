@@ -85,3 +85,61 @@ def test_reference_and_device_order_agree():
     np.testing.assert_allclose(rd["we"], rr["we"], rtol=1e-11, atol=1e-300)
     np.testing.assert_allclose(rd["x"], rr["x"], rtol=1e-12, atol=1e-12)
     assert od.resample_count() == orf.resample_count() > 0
+
+
+def test_aux_filter_loglik_tracks_kalman_over_noise_sweep():
+    """test/runtests.jl:419-423, 441-446: loglik of AuxiliaryParticleFilters over the dynamics-noise sweep
+    svec = exp10.(LinRange(-2, 0, 11)) at N = 1000, T = 2000: argmax in 5..7 and |ll_KF - ll_APF| < 20."""
+    import ctypes as C
+    base = M.lg_test_model(0.1)
+    _, U, Y = M.simulate_lg(base, 2000, seed=3)
+    svec = 10 ** np.linspace(-2, 0, 11)
+    lls, kfs = [], []
+    for k, s in enumerate(svec):
+        m = M.lg_test_model(s)
+        cfg = S.make_config(m, 1000, S.PARTICLE_FILTER, S.RESAMPLE_SYSTEMATIC, 0.1, 11 + k, 0)
+        o = ob.OracleFilter(cfg, ob.ORDER_REFERENCE)
+        o.reset()
+        lls.append(o.run_aux(U, Y, mode=1)["ll"])
+        kfs.append(ob.lib().orc_kalman_loglik(C.byref(m), ob.dptr(np.ascontiguousarray(U)), ob.dptr(np.ascontiguousarray(Y)), 2000))
+    lls, kfs = np.array(lls), np.array(kfs)
+    assert 5 <= np.argmax(lls) + 1 <= 7
+    assert 5 <= np.argmax(kfs) + 1 <= 7
+    assert np.max(np.abs(lls - kfs)) < 20
+
+
+def test_aux_filter_semantics_and_orders():
+    """correct! of the auxiliary filter ignores y (the first call after reset! returns logsumexp of uniform
+    weights ~ 0, src/filtering.jl:170-174); predict! always resamples and leaves w = lambda - log N, we = lambda
+    (:200-213); a fresh filter does not want to resample (test/runtests.jl:275); both arithmetic orders agree."""
+    m = M.lg_test_model(0.1)
+    _, U, Y = M.simulate_lg(m, 50, seed=4)
+    N = 2000
+    for strategy in (S.RESAMPLE_SYSTEMATIC, S.RESAMPLE_STRATIFIED):
+        cfg = S.make_config(m, N, S.PARTICLE_FILTER, strategy, 0.1, 21, 0)
+        r = []
+        for order in (ob.ORDER_REFERENCE, ob.ORDER_DEVICE):
+            o = ob.OracleFilter(cfg, order)
+            assert not o.shouldresample()
+            o.reset()
+            ll0 = o.aux_correct()
+            assert abs(ll0) < 1e-12
+            o.aux_predict(U[0], Y[1], 0.0)
+            assert o.last_resampled() and o.index() == 2
+            lam = o.expweights()
+            np.testing.assert_allclose(o.weights(), lam - np.log(N), rtol=0, atol=1e-13)
+            assert np.all(lam <= 0.5 * np.log(1 / (2 * np.pi)) + 1e-12)      # lambda = logpdf(N(0,1)) <= c0
+            ll1 = o.aux_correct()
+            assert abs(np.sum(o.expweights()) - 1.0) < 1e-12 and np.isfinite(ll1)
+            o.reset()
+            r.append(o.run_aux(U, Y, mode=0, ll_steps=True, history=True))
+        assert np.max(np.abs(r[0]["ll_steps"] - r[1]["ll_steps"])) < 1e-10
+        np.testing.assert_allclose(r[0]["x"], r[1]["x"], rtol=0, atol=1e-12)
+        assert r[0]["ll_steps"][0] == r[1]["ll_steps"][0] or abs(r[0]["ll_steps"][0]) < 1e-12
+        # missing look-ahead measurement: lambda = 0, weights stay uniform
+        o = ob.OracleFilter(cfg, ob.ORDER_DEVICE)
+        o.reset(); o.aux_correct()
+        o.aux_predict(U[0], None, 0.0)
+        assert np.all(o.expweights() == 0.0)
+        np.testing.assert_allclose(o.weights(), -np.log(N), rtol=0, atol=1e-13)
+        assert abs(o.aux_correct()) < 1e-12
