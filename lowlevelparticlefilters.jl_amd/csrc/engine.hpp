@@ -192,7 +192,8 @@ struct ResArgs {
     double* bins_out;
     double* ll_steps;      // [T][F] or nullptr
     double* xmean;         // [T][F][nx] or nullptr
-    int64_t k;             // step index into ll_steps / xmean
+    int64_t k;             // epoch of this launch within a run (for the bank_flag stop test; recorded by a failed bound test)
+    int64_t row;           // row of ll_steps / xmean this finalize writes
     int32_t ablate;        // developer aid (LLPF_ABLATE): bit0 skip RNG, bit1 skip owner search, bit2 skip model math; results invalid
     uint64_t* dbg;         // optional [P2][8] phase timestamps of one launch (s_memrealtime, 100 MHz), or nullptr
 };

@@ -981,7 +981,7 @@ DEV ResHead res_head(const BankDev& b, const ResArgs& a, int f, int tile, ResSha
                 if (h.status) sc->status = h.status;
                 sc->do_resample = h.dr;
                 if (a.accumulate) sc->ll_total = sc->ll_total + ll;
-                if (a.ll_steps) a.ll_steps[(size_t)a.k * b.F + f] = ll;
+                if (a.ll_steps) a.ll_steps[(size_t)a.row * b.F + f] = ll;
                 sh.dval[0] = inv;
             }
         }
@@ -1021,7 +1021,7 @@ DEV ResHead res_head(const BankDev& b, const ResArgs& a, int f, int tile, ResSha
             if (threadIdx.x == 0) {
                 double t = llpf_u2d(sh.red[0][2]);
                 for (int k = 1; k < BLOCK / 64; ++k) t = t + llpf_u2d(sh.red[k][2]);
-                a.xmean[((size_t)a.k * b.F + f) * b.nx + d] = t * invb;
+                a.xmean[((size_t)a.row * b.F + f) * b.nx + d] = t * invb;
             }
         }
     }

@@ -695,3 +695,35 @@ def test_aux_filter_bank():
         o.reset()
         ro = o.run_aux(U, Y, mode=1, ll_steps=True)
         assert np.array_equal(ro["ll_steps"].view(np.uint64), rb["ll_steps"][:, k].copy().view(np.uint64)), k
+
+
+def test_aux_filter_async_run_with_several_outliers():
+    """The asynchronous loglik / forward loop of the auxiliary filter (all launches enqueued, one poll): outliers that
+    make the look-ahead normalisation AND the next correct! fall back to the exact-max form, several times per run,
+    in a bank where only some filters are affected; T = 1 and T = 2 edge cases."""
+    models = [M.lg_test_model(s) for s in (0.03, 0.1, 0.3)]
+    _, U, Y = M.simulate_lg(models[1], 80, seed=8)
+    Y = Y.copy()
+    Y[10] += 12.0; Y[11] -= 9.0; Y[50] += 15.0; Y[51] = np.nan; Y[79] += 10.0
+    N = 2500
+    for mode in (0, 1):
+        bank = _capi.BankHandle(_cfg(models[0], N, S.RESAMPLE_STRATIFIED, 0.1, seed=77), models)
+        bank.reset()
+        rb = bank.run_aux(U, Y, mode=mode, ll_steps=True)
+        n_exact = 0
+        for k, mk in enumerate(models):
+            o = ob.OracleFilter(_cfg(mk, N, S.RESAMPLE_STRATIFIED, 0.1, seed=77 + k), ob.ORDER_DEVICE)
+            o.reset()
+            ro = o.run_aux(U, Y, mode=mode, ll_steps=True)
+            n_exact += o.exact_steps()
+            assert np.array_equal(ro["ll_steps"].view(np.uint64), rb["ll_steps"][:, k].copy().view(np.uint64)), (mode, k)
+            assert ro["ll"] == rb["ll"][k]
+        assert n_exact >= 4
+    for T in (1, 2):
+        for mode in (0, 1):
+            cfg = _cfg(models[1], 1000, seed=5)
+            g = _capi.FilterHandle(cfg); o = ob.OracleFilter(cfg, ob.ORDER_DEVICE)
+            g.reset(); o.reset()
+            rg = g.run_aux(U[:T], Y[:T], mode, ll_steps=True); ro = o.run_aux(U[:T], Y[:T], mode, ll_steps=True)
+            assert np.array_equal(rg["ll_steps"].view(np.uint64), ro["ll_steps"].view(np.uint64)), (T, mode)
+            _compare_state(g, o)
