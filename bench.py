@@ -39,12 +39,17 @@ def build_workload(name, n_particles, T):
         U, Y = M.quadtank_data(T, seed=2)
         kind, thr = S.ADVANCED_PARTICLE_FILTER, 0.5
         label = "C3: quad-tank AdvancedParticleFilter RK4x2, N=%d, T=%d, systematic, threshold 0.5" % (n_particles, T)
+    elif name == "aux":
+        model = M.lg_test_model()
+        _, U, Y = M.simulate_lg(model, T, seed=1)
+        kind, thr = S.PARTICLE_FILTER, 0.1
+        label = "AuxiliaryParticleFilter loglik (src/smoothing.jl:232-236) on the C2 system, N=%d, T=%d, systematic (always resamples)" % (n_particles, T)
     else:
         raise ValueError(name)
     return model, U, Y, kind, thr, label
 
 
-def cpu_baseline(model, U, Y, kind, thr, n_particles, budget_steps, seed, ll_gpu=None):
+def cpu_baseline(model, U, Y, kind, thr, n_particles, budget_steps, seed, ll_gpu=None, aux=False):
     """The reference-order oracle (literal CPU restatement) timed on a bounded sample of the same workload:
     1 thread (the reference's ParticleFilter path is single-threaded, src/PFtypes.jl:107-139) and, as an upper bound
     for its `threads=true` option, OpenMP over the per-particle loops (scan and sums stay serial).
@@ -65,7 +70,7 @@ def cpu_baseline(model, U, Y, kind, thr, n_particles, budget_steps, seed, ll_gpu
         o = ob.OracleFilter(cfg, ob.ORDER_REFERENCE)
         o.reset()
         t0 = time.perf_counter()
-        r = o.run(U[:Ts], Y[:Ts], 1.0, ll_steps=True)
+        r = o.run_aux(U[:Ts], Y[:Ts], 0, ll_steps=True) if aux else o.run(U[:Ts], Y[:Ts], 1.0, ll_steps=True)
         dt = time.perf_counter() - t0
         res[label] = {"value": n_particles * Ts / dt, "unit": "particle-steps/s", "cores": threads, "kind": "port",
                       "sample": "first %d of the %d timesteps of the same workload at N=%d (%.1f s of CPU)" % (Ts, len(Y), n_particles, dt)}
@@ -86,7 +91,7 @@ def cpu_baseline(model, U, Y, kind, thr, n_particles, budget_steps, seed, ll_gpu
         Td = min(20, Ts)
         o = ob.OracleFilter(cfg, ob.ORDER_DEVICE)
         o.reset()
-        r = o.run(U[:Td], Y[:Td], 1.0, ll_steps=True)
+        r = o.run_aux(U[:Td], Y[:Td], 0, ll_steps=True) if aux else o.run(U[:Td], Y[:Td], 1.0, ll_steps=True)
         d = np.abs(np.asarray(ll_gpu[:Td]) - r["ll_steps"])
         res["accuracy"]["vs_device_order_oracle"] = {
             "timesteps": int(Td), "max_abs_dll_per_step": float(d.max()),
@@ -101,7 +106,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="lg", choices=["lg", "quadtank"])
+    ap.add_argument("--workload", default="lg", choices=["lg", "quadtank", "aux"])
     ap.add_argument("--particles", type=int, default=1000000)
     ap.add_argument("--T", type=int, default=None)
     ap.add_argument("--threshold", type=float, default=None, help="resample_threshold override")
@@ -121,7 +126,7 @@ def main():
     dev = local_rank if world > 1 else 0
 
     from llpf_amd import _capi, _structs as S
-    T = args.T if args.T else (1000 if args.workload == "lg" else 2000)
+    T = args.T if args.T else (2000 if args.workload == "quadtank" else 1000)
     model, U, Y, kind, thr, label = build_workload(args.workload, args.particles, T)
     if args.threshold is not None:
         thr = args.threshold
@@ -131,9 +136,14 @@ def main():
     pf = _capi.FilterHandle(cfg)
     ll_dev = torch.zeros(1, dtype=torch.float64, device="cuda:%d" % dev)
 
+    aux = args.workload == "aux"
+
+    def run_once(h, **kw):
+        return h.run_aux(U, Y, 1, **kw) if aux else h.run(U, Y, 1.0, **kw)
+
     def one_pass():
         pf.reset()
-        r = pf.run(U, Y, 1.0)
+        r = run_once(pf)
         if world > 1:
             ll_dev[0] = r["ll"]
             dist.all_reduce(ll_dev)          # the global log-likelihood: the only collective of the path
@@ -166,7 +176,7 @@ def main():
         pf.set_profiling(True)
         for _ in range(max(1, min(args.steps, 3))):
             pf.reset()
-            pf.run(U, Y, 1.0)
+            run_once(pf)
         ms, cnt = pf.profile()
         pf.set_profiling(False)
         prof = (ms, cnt)
@@ -176,9 +186,12 @@ def main():
         nx = model.nx
         value = world * args.steps * N * T / dt
         ms_cls, n_cls = prof
-        fused = not n_cls[2]                      # no standalone resample launches => the fused k_resprop ran
+        fused = aux or not n_cls[2]               # no standalone resample launches => the fused k_resprop ran
         names = ["k_resprop(finalize+resample+propagate+weight)" if fused else "k_step(propagate+weight)",
                  "k_norm(exp-weights, sums, quanta)", "k_resample(finalize+scan+counts+ancestors)", "other"]
+        if aux:
+            names = ["k_resprop<AUX>(expnormalize+resample+permute+noise+weights)", "k_step<MODE_AUX>(noise-free propagate + look-ahead lambda)",
+                     "finalize(logsumexp of lambda - log N)", "other"]
         kernel_us = {names[i]: (1e3 * ms_cls[i] / n_cls[i] if n_cls[i] else None) for i in range(4)}
         # Dominant kernel and its algorithmic bytes.
         #   one-launch timestep (fused k_resprop that also forms the exp-sums: no k_norm launches): the launch IS the
@@ -188,8 +201,13 @@ def main():
         #   fused k_resprop + separate k_norm : k_resprop moves 16nx + 20 (no quanta write)
         #   k_step (balanced propagate+weight): read ancestor 4 + gather x 8nx + write x 8nx + write w 8 [+ quanta 8]
         b_alg = 16 * nx + 40                         # whole-timestep algorithmic bytes
-        one_launch = fused and not n_cls[1]
-        if one_launch:
+        one_launch = fused and not n_cls[1] and not aux
+        if aux:
+            # k_step<MODE_AUX>: read x 8nx + read w 8 + write x' 8nx + write lambda 8 + write w 8 + write quanta 8
+            # k_resprop<AUX>  : read quanta 8 + gather x' 8nx + write x 8nx + read lambda 8 + write w 8 + anc 4 + quanta 8
+            b_step = b_model = 16 * nx + 36
+            b_alg = 32 * nx + 68
+        elif one_launch:
             b_step, b_model = b_alg, 16 * nx + 28
         elif fused:
             b_step = b_model = 16 * nx + 20
@@ -237,9 +255,9 @@ def main():
             cs = args.cpu_steps if args.cpu_steps else max(2, min(T, int(10 * per / N)))
             pf2 = _capi.FilterHandle(cfg)          # a fresh handle: same Philox counters as a fresh oracle (first reset!)
             pf2.reset()
-            ll_gpu = pf2.run(U, Y, 1.0, ll_steps=True)["ll_steps"]
+            ll_gpu = run_once(pf2, ll_steps=True)["ll_steps"]
             del pf2
-            out.update(cpu_baseline(model, U, Y, kind, thr, N, cs, 1000 + rank, ll_gpu))
+            out.update(cpu_baseline(model, U, Y, kind, thr, N, min(cs, T - 1), 1000 + rank, ll_gpu, aux))
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     if world > 1:

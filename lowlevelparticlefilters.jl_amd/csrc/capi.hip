@@ -717,6 +717,7 @@ static int aux_launch_finalize(Bank& b, bool fast, int only_fb, int64_t epoch, i
     ra.mode = RES_FINALIZE; ra.parity = slot; ra.M = (int32_t)b.N; ra.fast_head = fast ? 1 : 0; ra.K = llpf_qbits(b.N);
     ra.k = epoch; ra.row = row; ra.only_fallback = only_fb;
     ra.ll_steps = o.d_ll_steps; ra.xmean = o.d_xmean; ra.want_xmean = o.d_xmean ? 1 : 0; ra.accumulate = o.accumulate;
+    ProfScope ps(b, LLPF_PROF_RESAMPLE);
     HIPC(launch_resample(d, ra, b.stream));
     return LLPF_OK;
 }
@@ -728,6 +729,7 @@ static int aux_launch_look(Bank& b, const double* d_u, const double* d_y1, bool 
     a.u = d_u; a.y = d_y1; a.t_prop = t; a.t_meas = t; a.step = b.n_predict; a.has_y = has_y1 ? 1 : 0;
     a.parity = b.parity; a.need_e2 = 0; a.K = llpf_qbits(b.N); a.k = epoch; a.next_step = b.n_predict; a.accumulate = 1;
     a.only_fallback = only_fb;
+    ProfScope ps(b, LLPF_PROF_NORMALISE);
     HIPC(launch_step(d, MODE_AUX, a, b.stream));
     return LLPF_OK;
 }
@@ -746,6 +748,7 @@ static int aux_launch_resprop(Bank& b, bool has_y1, double t, bool fast, int onl
     st.t_prop = t; st.t_meas = t; st.step = b.n_predict; st.has_y = 0; st.parity = b.parity; st.need_e2 = 0; st.K = K;
     st.k = epoch; st.next_step = b.n_predict + 1; st.want_xmean = want_xm; st.accumulate = 1; st.aux = has_y1 ? 2 : 1;
     st.only_fallback = only_fb;
+    ProfScope ps(b, LLPF_PROF_PROPAGATE);
     HIPC(launch_resprop(d, ra, st, 1, b.stream));
     return LLPF_OK;
 }
@@ -959,6 +962,7 @@ static int bank_aux_run(Bank& b, const double* U, const double* Y, int64_t T, in
     float ms = 0.f;
     HIPC(hipEventElapsedTime(&ms, b.ev_run0, b.ev_run1));
     b.last_run_ms = ms;
+    if (b.profiling) prof_collect(b);
     for (int f = 0; f < b.F; ++f) {
         if (mode == 1) hl[(size_t)(T - 1) * b.F + f] = last[f];
         double tot = 0.0;

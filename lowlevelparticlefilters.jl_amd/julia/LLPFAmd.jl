@@ -9,7 +9,7 @@
 module LLPFAmd
 
 using LinearAlgebra
-export GPUParticleFilter, LinearGaussianModel, QuadTankModel, GaussianSpec,
+export GPUParticleFilter, GPUAuxiliaryParticleFilter, LinearGaussianModel, QuadTankModel, GaussianSpec,
        reset!, predict!, correct!, update!, loglik, forward_trajectory, particles, weights, expweights,
        num_particles, index, effective_particles, shouldresample, weighted_mean
 
@@ -156,6 +156,58 @@ function forward_trajectory(pf::GPUParticleFilter, u, y, p = nothing)
     ll, x, w, we = run!(pf, u, y, 0.0; history = true)
     # reinterpret(reshape, SVector{nx,Float64}, x) gives the reference's N x T Matrix{SVector}
     (; x, w, we, ll, t = range(0, step = pf.Ts, length = length(y)))
+end
+
+# ---- AuxiliaryParticleFilter{ParticleFilter} (reference src/PFtypes.jl:38-49) -----------------------------------
+"AuxiliaryParticleFilter(pf): the same device handle driven through the auxiliary verbs"
+struct GPUAuxiliaryParticleFilter
+    pf::GPUParticleFilter
+end
+Base.getproperty(a::GPUAuxiliaryParticleFilter, s::Symbol) = s === :pf ? getfield(a, :pf) : getproperty(getfield(a, :pf), s)
+reset!(a::GPUAuxiliaryParticleFilter) = reset!(a.pf)
+index(a::GPUAuxiliaryParticleFilter) = index(a.pf)
+
+"correct!(pf::AuxiliaryParticleFilter,u,y,p,t) -> (ll, 0) — src/filtering.jl:170-174 (logsumexp! only)"
+function correct!(a::GPUAuxiliaryParticleFilter, u, y, p = nothing, t = index(a) * a.Ts)
+    ll = Ref{Float64}(0)
+    check(ccall((:llpf_aux_correct, LIB), Cint, (Ptr{Cvoid}, Ref{Float64}), a.pf.h, ll))
+    ll[], 0
+end
+"predict!(pf::AuxiliaryParticleFilter,u,y1,p,t) — src/filtering.jl:195-217"
+function predict!(a::GPUAuxiliaryParticleFilter, u, y1, p = nothing, t = index(a) * a.Ts)
+    yv = (y1 === missing || any(ismissing, y1)) ? Float64[] : Vector{Float64}(y1)
+    GC.@preserve yv check(ccall((:llpf_aux_predict, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Float64),
+                                a.pf.h, Vector{Float64}(u), isempty(yv) ? C_NULL : pointer(yv), Float64(t)))
+end
+"update!(pf::AuxiliaryParticleFilter,u,y,y1,p,t) -> (ll, 0) — src/filtering.jl:187-191; also pfa(u, y, y1)"
+function update!(a::GPUAuxiliaryParticleFilter, u, y, y1, p = nothing, t = index(a) * a.Ts)
+    ll_e = correct!(a, u, y, p, t)
+    predict!(a, u, y1, p, t)
+    ll_e
+end
+(a::GPUAuxiliaryParticleFilter)(u, y, y1, p = nothing, t = index(a) * a.Ts) = update!(a, u, y, y1, p, t)
+
+function run_aux!(a::GPUAuxiliaryParticleFilter, u, y, mode; history = false)
+    pf = a.pf
+    T = length(y)
+    U = rows(u); Y = rows(y)
+    ll = Ref{Float64}(0)
+    x = history ? Array{Float64}(undef, pf.nx, pf.N, T) : Float64[]
+    w = history ? Array{Float64}(undef, pf.N, T) : Float64[]
+    we = history ? Array{Float64}(undef, pf.N, T) : Float64[]
+    outs = Ref(CRunOutputs(C_NULL, C_NULL, history ? pointer(x) : C_NULL, history ? pointer(w) : C_NULL, history ? pointer(we) : C_NULL))
+    GC.@preserve U Y x w we check(ccall((:llpf_aux_run, LIB), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64, Int32, Ref{Float64}, Ref{CRunOutputs}),
+        pf.h, U, Y, T, Int32(mode), ll, outs))
+    ll[], x, w, we
+end
+"loglik(pf::AuxiliaryParticleFilter,u,y,p) — src/smoothing.jl:232-236"
+loglik(a::GPUAuxiliaryParticleFilter, u, y, p = nothing) = (reset!(a); run_aux!(a, u, y, 1)[1])
+"forward_trajectory(pf::AuxiliaryParticleFilter,u,y,p) — src/filtering.jl:367-384"
+function forward_trajectory(a::GPUAuxiliaryParticleFilter, u, y, p = nothing)
+    reset!(a)
+    ll, x, w, we = run_aux!(a, u, y, 0; history = true)
+    (; x, w, we, ll, t = range(0, step = a.Ts, length = length(y)))
 end
 
 function getvec(sym, pf, n)
