@@ -101,12 +101,99 @@ def cpu_baseline(model, U, Y, kind, thr, n_particles, budget_steps, seed, ll_gpu
     return res
 
 
+def main_bank(args, rank, world, dev):
+    """BASELINE config C4: a sweep of independent linear-Gaussian filters (dynamics-noise level s_k, reference
+    test/runtests.jl:412-417), filters sharded round-robin over ranks (filter k -> rank k mod world), 128 x N=1e5 per
+    GPU by default, shared u / y; the only collective is the all-reduce of the per-filter log-likelihood vector."""
+    import torch
+    import torch.distributed as dist
+    import models as M
+    from llpf_amd import _capi, _structs as S
+    from llpf_amd.distributed import shard_indices, allreduce_logliks
+    T = args.T if args.T else 1000
+    N = args.particles if args.particles != 1000000 else 100000
+    thr = 0.1 if args.threshold is None else args.threshold
+    F = args.filters_per_gpu * world
+    svec = 10.0 ** np.linspace(-2, 0, F)
+    owned = shard_indices(F, rank, world)
+    models = [M.lg_test_model(svec[k]) for k in owned]
+    _, U, Y = M.simulate_lg(M.lg_test_model(0.1), T, seed=1)
+    cfg = S.make_config(models[0], N, S.PARTICLE_FILTER, S.RESAMPLE_SYSTEMATIC, thr, 5 + 100000 * rank, dev)
+    bank = _capi.BankHandle(cfg, models)
+    device = torch.device("cuda", dev)
+
+    def one_pass():
+        bank.reset()
+        r = bank.run(U, Y, 1.0)
+        return allreduce_logliks(r["ll"], owned, F, device)
+
+    for _ in range(args.warmup):
+        one_pass()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dev_ms = 0.0
+    for _ in range(args.steps):
+        ll_all, ll_sum = one_pass()
+        dev_ms += bank.last_run_ms()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank == 0:
+        bank.set_profiling(True)
+        bank.reset()
+        bank.run(U, Y, 1.0)
+        ms_cls, n_cls = bank.profile()
+        bank.set_profiling(False)
+        nx = 2
+        Fl = len(owned)
+        value = args.steps * F * N * T / dt
+        timestep_s = dt / (args.steps * T)
+        # split schedule (DESIGN.md 4): k_resprop moves 16nx+20 B per particle (read quanta 8, gather + store x 16nx,
+        # ancestor 4, w 8), k_norm 16 (read w, write quanta)
+        step_s = ms_cls[0] / n_cls[0] * 1e-3
+        b_step = 16 * nx + 20
+        b_alg = 16 * nx + 40
+        achieved = Fl * N * b_step / step_s / 1e9
+        out = {"metric": "particle-steps/s", "value": value, "unit": "particle-steps/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "C4: sweep of %d linear-Gaussian ParticleFilters x N=%d, T=%d, threshold %g, %d per GPU" % (F, N, T, thr, args.filters_per_gpu),
+                          "filters": F, "particles": N, "timesteps": T, "nx": nx, "resample_threshold": thr,
+                          "resamples_per_pass_rank0": int(bank.resample_count()),
+                          "parallelism": "filters sharded round-robin over %d GPU(s), all-reduce of the log-likelihood vector" % world},
+               "device_ms_per_step": dev_ms / args.steps,
+               "kernel_us": {"k_resprop": 1e3 * ms_cls[0] / n_cls[0], "k_norm": (1e3 * ms_cls[1] / n_cls[1]) if n_cls[1] else None},
+               "argmax_sigma": float(svec[int(np.argmax(ll_all))]), "loglik_sum": ll_sum,
+               "roofline": {"bound": "hbm", "kernel": "k_resprop", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                            "frac": achieved / 8000.0, "traffic": None, "bytes_per_launch": Fl * N * b_step,
+                            "avg_launch_us": step_s * 1e6,
+                            "method": "hipEvent pairs around every launch on the engine stream, one profiled pass after the timed region",
+                            "whole_timestep": {"algorithmic_bytes": Fl * N * b_alg, "us": timestep_s * 1e6,
+                                               "achieved": Fl * N * b_alg / timestep_s / 1e9, "frac": Fl * N * b_alg / timestep_s / 8e12}}}
+        if world == 1 and not args.no_cpu_baseline:
+            cs = args.cpu_steps if args.cpu_steps else 1000
+            out.update(cpu_baseline(models[len(models) // 2], U, Y, S.PARTICLE_FILTER, thr, N, min(cs, T), 77, None))
+            out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="lg", choices=["lg", "quadtank", "aux"])
+    ap.add_argument("--workload", default="lg", choices=["lg", "quadtank", "aux", "bank"])
+    ap.add_argument("--filters-per-gpu", type=int, default=128, help="bank workload (BASELINE config C4): filters per GPU")
     ap.add_argument("--particles", type=int, default=1000000)
     ap.add_argument("--T", type=int, default=None)
     ap.add_argument("--threshold", type=float, default=None, help="resample_threshold override")
@@ -125,6 +212,8 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     dev = local_rank if world > 1 else 0
 
+    if args.workload == "bank":
+        return main_bank(args, rank, world, dev)
     from llpf_amd import _capi, _structs as S
     T = args.T if args.T else (2000 if args.workload == "quadtank" else 1000)
     model, U, Y, kind, thr, label = build_workload(args.workload, args.particles, T)
