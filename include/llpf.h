@@ -87,7 +87,7 @@ typedef struct llpf_model {
     llpf_gaussian initial_density;            /* d0 */
 } llpf_model;
 
-enum { LLPF_RESAMPLE_SYSTEMATIC = 0, LLPF_RESAMPLE_STRATIFIED = 1 };   /* reference src/LowLevelParticleFilters.jl:43-46 */
+enum { LLPF_RESAMPLE_SYSTEMATIC = 0, LLPF_RESAMPLE_STRATIFIED = 1, LLPF_RESAMPLE_RESIDUAL = 2 };   /* reference src/LowLevelParticleFilters.jl:43-46 */
 enum { LLPF_PARTICLE_FILTER = 0, LLPF_ADVANCED_PARTICLE_FILTER = 1 };
 
 typedef struct llpf_config {
@@ -185,9 +185,10 @@ int  llpf_maxw(llpf_filter* f, double* maxw);                             /* sta
 /* ---- exported array primitives (operate on caller-owned host vectors, computed on the GPU) */
 /* ll = logsumexp!(w, we) — reference src/utils.jl:18-27 */
 int  llpf_logsumexp(int32_t device, double* w, double* we, int64_t n, double* ll);
-/* j = resample(strategy, we, M) — reference src/resample.jl:12-61.  U holds the uniform draws the
- * reference takes from the global rand(): 1 value (systematic) or m values (stratified).  j is
- * in/out: entries whose threshold is never met keep their input value, as in the reference. */
+/* j = resample(strategy, we, M) — reference src/resample.jl:12-117.  U holds the uniform draws the
+ * reference takes from the global rand(): 1 value (systematic) or m values (stratified; residual: U[i] is the
+ * draw of output i, read only for the outputs after the deterministic copies).  j is in/out: entries whose
+ * threshold is never met keep their input value, as in the reference. */
 int  llpf_resample(int32_t device, int32_t strategy, const double* we, int64_t n, int64_t m,
                    const double* U, int64_t* j /* m, 0-based */);
 /* the uniforms the filter path draws for its resample at Philox step `step` (host evaluation of the

@@ -8,7 +8,7 @@ MAX_DIM = 8
 
 COV_SCAL, COV_DIAG, COV_FULL = 0, 1, 2
 MODEL_LINEAR_GAUSSIAN, MODEL_QUADTANK_RK4 = 0, 1
-RESAMPLE_SYSTEMATIC, RESAMPLE_STRATIFIED = 0, 1
+RESAMPLE_SYSTEMATIC, RESAMPLE_STRATIFIED, RESAMPLE_RESIDUAL = 0, 1, 2
 PARTICLE_FILTER, ADVANCED_PARTICLE_FILTER = 0, 1
 
 QT_NAMES = ["k1", "k2", "g", "A1", "A2", "A3", "A4", "a1", "a2", "a3", "a4",

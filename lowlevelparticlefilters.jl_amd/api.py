@@ -23,7 +23,7 @@ from . import _structs as S
 __all__ = [
     "MvNormal", "ResampleSystematic", "ResampleStratified",
     "LinearDynamics", "LinearMeasurement", "QuadTankDynamics", "QuadTankMeasurement", "GaussianLikelihood",
-    "ParticleFilter", "AdvancedParticleFilter", "AuxiliaryParticleFilter", "FilterBank", "ParticleFilteringSolution",
+    "ResampleResidual", "ParticleFilter", "AdvancedParticleFilter", "AuxiliaryParticleFilter", "FilterBank", "ParticleFilteringSolution",
     "reset", "predict", "correct", "update", "forward_trajectory", "mean_trajectory", "loglik",
     "particles", "weights", "expweights", "state", "num_particles", "index", "effective_particles",
     "shouldresample", "resample", "weighted_mean", "logsumexp", "simulate", "parameters",
@@ -73,6 +73,10 @@ class ResampleSystematic:      # reference src/LowLevelParticleFilters.jl:44
 
 class ResampleStratified:      # reference src/LowLevelParticleFilters.jl:45
     code = S.RESAMPLE_STRATIFIED
+
+
+class ResampleResidual:        # reference src/LowLevelParticleFilters.jl:46, src/resample.jl:63-117
+    code = S.RESAMPLE_RESIDUAL
 
 
 class LinearDynamics:

@@ -135,6 +135,7 @@ struct Bank {
     uint64_t* d_tileq = nullptr;
     uint32_t* d_flag = nullptr;
     double* d_xmpart = nullptr;
+    uint64_t* d_rtile = nullptr;      // [F][2][P2] residual resampling: per-tile counts / residual sums and their prefixes
     double* d_lam = nullptr;          // [F][Ns] lambda of the AuxiliaryParticleFilter predict! (allocated on first use)
     bool aux_pending = false;         // w holds lambda - log N of an aux predict!; their exp-sums wait in slot (parity+2)%3
     bool we_is_lambda = false;        // expweights(pf) returns lambda until the next correct! (the reference keeps it in `we`)
@@ -173,7 +174,7 @@ struct Bank {
         b.models = d_models; b.scal = d_scal;
         b.xcur = d_x[cur]; b.xnext = d_x[cur ^ 1];
         b.w = d_w; b.anc = d_anc; b.acc = d_acc; b.quanta = d_quanta[qcur]; b.quanta_next = d_quanta[qcur ^ 1]; b.tileq = d_tileq;
-        b.bank_flag = d_flag; b.xmpart = d_xmpart; b.lam = d_lam;
+        b.bank_flag = d_flag; b.xmpart = d_xmpart; b.lam = d_lam; b.rtile = d_rtile;
         b.anc_slot = (int32_t)(n_predict & 1u); b.pad0 = 0;
         return b;
     }
@@ -191,7 +192,7 @@ static void free_bank(Bank& b) {
     hipSetDevice(b.device);
     if (b.stream) hipStreamSynchronize(b.stream);
     hipFree(b.d_models); hipFree(b.d_scal); hipFree(b.d_x[0]); hipFree(b.d_x[1]); hipFree(b.d_w);
-    hipFree(b.d_anc); hipFree(b.d_acc); hipFree(b.d_quanta[0]); hipFree(b.d_quanta[1]); hipFree(b.d_tileq); hipFree(b.d_flag); hipFree(b.d_xmpart); hipFree(b.d_lam); hipFree(b.d_uy); hipFree(b.d_U); hipFree(b.d_Y);
+    hipFree(b.d_anc); hipFree(b.d_acc); hipFree(b.d_quanta[0]); hipFree(b.d_quanta[1]); hipFree(b.d_tileq); hipFree(b.d_flag); hipFree(b.d_xmpart); hipFree(b.d_lam); hipFree(b.d_rtile); hipFree(b.d_uy); hipFree(b.d_U); hipFree(b.d_Y);
     hipFree(b.d_ll_steps); hipFree(b.d_xmean); hipFree(b.d_tmp);
     for (auto e : b.ev_pool) hipEventDestroy(e);
     for (auto& e : b.pending) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
@@ -299,8 +300,9 @@ static int bank_create(const llpf_config* cfg, const llpf_model* models, int F, 
     if (m0.nx < 1 || m0.nx > MAXD || m0.ny < 1 || m0.ny > MAXD || m0.nu < 0 || m0.nu > MAXD) return fail(LLPF_ERR_ARG, "bad dimensions");
     if (!step_supported(m0.model_id, m0.nx, m0.ny))
         return fail(LLPF_ERR_ARG, "no kernel instantiated for this model/dimension (linear-Gaussian nx,ny in 1..4; quad-tank 4/2)");
-    if (cfg->resampling_strategy != LLPF_RESAMPLE_SYSTEMATIC && cfg->resampling_strategy != LLPF_RESAMPLE_STRATIFIED)
-        return fail(LLPF_ERR_ARG, "resampling_strategy must be systematic or stratified");
+    if (cfg->resampling_strategy != LLPF_RESAMPLE_SYSTEMATIC && cfg->resampling_strategy != LLPF_RESAMPLE_STRATIFIED &&
+        cfg->resampling_strategy != LLPF_RESAMPLE_RESIDUAL)
+        return fail(LLPF_ERR_ARG, "resampling_strategy must be systematic, stratified or residual");
     if (!(cfg->resample_threshold >= 0.0 && cfg->resample_threshold <= 1.0)) return fail(LLPF_ERR_ARG, "resample_threshold must be in [0,1]");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
@@ -339,6 +341,8 @@ static int bank_create(const llpf_config* cfg, const llpf_model* models, int F, 
     HIPC(hipMalloc(&b.d_tileq, sizeof(uint64_t) * (size_t)ACC_NSLOT * F * b.P2));
     HIPC(hipMalloc(&b.d_flag, sizeof(uint32_t) * 4));
     HIPC(hipMalloc(&b.d_xmpart, sizeof(double) * (size_t)F * b.P1 * MAXD));
+    HIPC(hipMalloc(&b.d_rtile, sizeof(uint64_t) * (size_t)F * 2 * b.P2));
+    HIPC(hipMemsetAsync(b.d_rtile, 0, sizeof(uint64_t) * (size_t)F * 2 * b.P2, b.stream));
     HIPC(hipMalloc(&b.d_uy, sizeof(double) * 4 * MAXD));
     HIPC(hipMalloc(&b.d_tmp, sizeof(double) * (size_t)F * b.N * (b.nx > 1 ? b.nx : 1) + 64));
     HIPC(hipMemsetAsync(b.d_x[0], 0, sizeof(double) * FN * b.nx, b.stream));
@@ -512,7 +516,9 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
     // 121 us per timestep at N = 1e6), the linear-Gaussian model faster fused.  LLPF_UNFUSED=0/1 overrides.
     static const char* unf_env = getenv("LLPF_UNFUSED");
     const bool heavy_dynamics = b.cfg.model.model_id == LLPF_MODEL_QUADTANK_RK4;
-    const bool unfused = hist || (unf_env ? atoi(unf_env) != 0 : heavy_dynamics);
+    // residual resampling produces unsorted ancestors (copies first, multinomial draws after): always the balanced form
+    const bool residual = b.cfg.resampling_strategy == LLPF_RESAMPLE_RESIDUAL;
+    const bool unfused = hist || residual || (unf_env ? atoi(unf_env) != 0 : heavy_dynamics);
     // Where the exp-sums / quanta of freshly computed weights are formed (identical results either way): inside the
     // weighting phase (one launch per timestep: best when one filter of ~1e6 particles cannot fill the chip and the
     // dependent-launch latency dominates) or by a streaming k_norm launch in bound form (the fused kernel then keeps
@@ -799,6 +805,7 @@ static int bank_aux_correct(Bank& b, double* ll_out /* [F] or null */, const Aux
 
 // Single-call predict!(pf::AuxiliaryParticleFilter, u, y1, p, t): synchronous.  d_u / d_y1 are device pointers.
 static int aux_predict_dev(Bank& b, const double* d_u, const double* d_y1, bool has_y1, double t, int want_xm) {
+    if (b.cfg.resampling_strategy == LLPF_RESAMPLE_RESIDUAL) return fail(LLPF_ERR_ARG, "the auxiliary filter supports systematic and stratified resampling");
     if (b.aux_pending) CHK(bank_aux_correct(b, nullptr, AuxOuts{}, 0));   // contract: predict! works on normalised weights
     CHK(aux_ensure_lam(b));
     CHK(aux_launch_look(b, d_u, d_y1, has_y1, t, 0, 0));
@@ -857,6 +864,7 @@ static int bank_aux_run(Bank& b, const double* U, const double* Y, int64_t T, in
     HIPC(hipMemcpyAsync(b.d_Y, Y, sizeof(double) * T * b.ny, hipMemcpyHostToDevice, b.stream));
     CHK(ensure(&b.d_ll_steps, &b.cap_ll, (size_t)T * b.F));
     if (xmean) CHK(ensure(&b.d_xmean, &b.cap_xm, (size_t)T * b.F * b.nx));
+    if (b.cfg.resampling_strategy == LLPF_RESAMPLE_RESIDUAL) return fail(LLPF_ERR_ARG, "the auxiliary filter supports systematic and stratified resampling");
     CHK(aux_ensure_lam(b));
     const double Ts = b.cfg.model.Ts;
     const bool hist = x_hist || w_hist || we_hist;

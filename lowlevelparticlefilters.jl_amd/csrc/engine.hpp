@@ -141,6 +141,7 @@ struct BankDev {
                          //     launch of the run is a no-op until the host has redone that step in exact form
     double* xmpart;      // [F][P1][MAXD]
     double* lam;         // [F][Ns] lambda of the AuxiliaryParticleFilter predict! (nullptr until first used)
+    uint64_t* rtile;     // [F][2][P2] residual resampling: per-tile copy counts / residual sums, then their inclusive prefixes
     int32_t anc_slot;    // n_predict & 1: index of the current FilterScal::anc_ident_s entry
     int32_t pad0;
 };

@@ -83,6 +83,43 @@ LLPF_HD uint64_t llpf_q64_unit(double e, int K) {
     return ok ? (Y >> (rs & 63)) : 0;
 }
 
+/* 64 x 64 -> 128 bit product */
+LLPF_HD llpf_u128 llpf_mul64(uint64_t a, uint64_t b) {
+    llpf_u128 r;
+#if defined(__HIP_DEVICE_COMPILE__)
+    r.lo = a * b;
+    r.hi = __umul64hi(a, b);
+#else
+    unsigned __int128 p = (unsigned __int128)a * b;
+    r.lo = (uint64_t)p;
+    r.hi = (uint64_t)(p >> 64);
+#endif
+    return r;
+}
+LLPF_HD int llpf_u128_lt(llpf_u128 a, llpf_u128 b) { return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo); }
+LLPF_HD llpf_u128 llpf_u128_sub(llpf_u128 a, llpf_u128 b) {
+    llpf_u128 r;
+    r.lo = a.lo - b.lo;
+    r.hi = a.hi - b.hi - (a.lo < b.lo ? 1u : 0u);
+    return r;
+}
+/* c = floor(q * m / Q) and rem = q * m - c * Q, exactly, for Q >= 1 and c < 2^52 (residual resampling: q a quantum,
+ * m the number of outputs, Q the total of the quanta).  A double estimate is corrected with 128-bit products. */
+LLPF_HD uint64_t llpf_muldiv_floor(uint64_t q, uint64_t m, uint64_t Q, uint64_t* rem) {
+    const llpf_u128 P = llpf_mul64(q, m);
+    uint64_t c = (uint64_t)(((double)q * (double)m) / (double)Q);
+    llpf_u128 CQ = llpf_mul64(c, Q);
+    while (llpf_u128_lt(P, CQ)) { --c; CQ = llpf_mul64(c, Q); }
+    llpf_u128 d = llpf_u128_sub(P, CQ);
+    while (d.hi != 0 || d.lo >= Q) {
+        ++c;
+        const llpf_u128 Qv = {Q, 0};
+        d = llpf_u128_sub(d, Qv);
+    }
+    *rem = d.lo;
+    return c;
+}
+
 /* number of fraction bits used for the 64-bit resampling bins of an N-particle filter */
 LLPF_HD int llpf_qbits(int64_t n) {
     int lg = 0;

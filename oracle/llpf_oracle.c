@@ -428,8 +428,78 @@ static double thr_at(const thr_ctx* c, int64_t i0, double binsN) {
     return ((double)i0 + c->U[i0]) / (double)c->m * binsN;
 }
 
+/* resample(::Type{ResampleResidual}, we, j, bins, M) — src/resample.jl:63-117.  U[m] is the uniform of output m
+ * (the reference draws rand() for m = num+1..M in order; only those entries are read).
+ * Device order: the weights are the integer quanta q_i (total Q), so the copy counts floor(q_i M / Q) and the
+ * residuals q_i M - c_i Q are exact integers; the residuals are kept to K bits (>> ceil(log2 N)) so that their
+ * cumulative sum fits 63 bits, and the multinomial part searches bins = fl(fl(cum) * fl(1/fl(total))) like the
+ * other strategies.  `q` (device order): the quanta, or NULL to derive them from `we` with llpf_q64_unit. */
+static int resample_residual(const double* we, const uint64_t* q, int64_t n, int64_t m, const double* U,
+                             int64_t* j, double* b, int order) {
+    if (order == ORC_ORDER_REFERENCE) {
+        double wsum = 0.0;
+        for (int64_t i = 0; i < n; ++i) wsum += we[i];                     /* :66-69 */
+        double inv_wsum = 1.0 / wsum;
+        int64_t num = 0;
+        for (int64_t i = 0; i < n; ++i) {                                  /* :75-84 */
+            double nw = we[i] * inv_wsum * (double)m;
+            int64_t cnt = (int64_t)floor(nw);
+            b[i] = nw - (double)cnt;
+            for (int64_t k = 0; k < cnt && num < m; ++k) j[num++] = i;
+        }
+        if (num == m) return 0;                                            /* :86-88 */
+        double rsum = 0.0;
+        for (int64_t i = 0; i < n; ++i) rsum += b[i];                      /* :90-93 */
+        double inv_rsum = 1.0 / rsum;
+        for (int64_t i = 0; i < n; ++i) b[i] *= inv_rsum;                  /* :95-98 */
+        for (int64_t i = 1; i < n; ++i) b[i] += b[i - 1];                  /* :100-103 */
+        for (int64_t mm = num; mm < m; ++mm) {                             /* :105-114 */
+            double u = U[mm];
+            for (int64_t i = 0; i < n; ++i)
+                if (u < b[i]) { j[mm] = i; break; }
+        }
+        return 0;
+    }
+    int K = llpf_qbits(n);
+    int L = 62 - K;                                                        /* ceil(log2 n) */
+    uint64_t Q = 0;
+    for (int64_t i = 0; i < n; ++i) Q += q ? q[i] : llpf_q64_unit(we[i], K);
+    if (Q == 0) return -1;
+    int64_t num = 0;
+    uint64_t totr = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        uint64_t qi = q ? q[i] : llpf_q64_unit(we[i], K), rem;
+        uint64_t cnt = llpf_muldiv_floor(qi, (uint64_t)m, Q, &rem);
+        totr += rem >> L;
+        for (uint64_t k = 0; k < cnt && num < m; ++k) j[num++] = i;
+    }
+    if (num == m || totr == 0) { for (int64_t i = 0; i < n; ++i) b[i] = 0.0; return 0; }
+    double Td = (double)totr, invTd = 1.0 / Td;
+    uint64_t cum = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        uint64_t qi = q ? q[i] : llpf_q64_unit(we[i], K), rem;
+        llpf_muldiv_floor(qi, (uint64_t)m, Q, &rem);
+        cum += rem >> L;
+        b[i] = (double)cum * invTd;
+    }
+    for (int64_t mm = num; mm < m; ++mm) {
+        double u = U[mm];
+        /* first i with u < bins[i] (bins non-decreasing): the reference's linear search */
+        int64_t lo = 0, hi = n;
+        while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (u < b[mid]) hi = mid; else lo = mid + 1; }
+        if (lo < n) j[mm] = lo;
+    }
+    return 0;
+}
+
 int orc_resample(int strategy, const double* we, int64_t n, int64_t m, const double* U,
                  int64_t* j, double* bins, int order) {
+    if (strategy == LLPF_RESAMPLE_RESIDUAL) {
+        double* bb = bins ? bins : (double*)malloc(sizeof(double) * (size_t)n);
+        int rc = resample_residual(we, NULL, n, m, U, j, bb, order);
+        if (!bins) free(bb);
+        return rc;
+    }
     thr_ctx c;
     c.strategy = strategy; c.m = m; c.U = U; c.step = 1.0 / (double)m; c.r = 0.0;
     double* b = bins ? bins : (double*)malloc(sizeof(double) * (size_t)n);
@@ -657,6 +727,13 @@ int orc_shouldresample(const orc_filter* f) {
  * (scale-invariant: bins = cumQ/totQ), so that the GPU needs no normalised-weight array */
 static void filter_resample_dev(orc_filter* f, const double* U) {
     int64_t n = f->N;
+    if (f->cfg.resampling_strategy == LLPF_RESAMPLE_RESIDUAL) {
+        uint64_t* q = (uint64_t*)malloc(8 * (size_t)n);
+        for (int64_t i = 0; i < n; ++i) q[i] = llpf_q64_unit(f->e[i], f->dn.K);
+        resample_residual(NULL, q, n, n, U, f->j, f->bins, ORC_ORDER_DEVICE);
+        free(q);
+        return;
+    }
     uint64_t cum = 0;
     double Td = (double)f->dn.totQ;
     double invTd = 1.0 / Td;

@@ -9,7 +9,7 @@ import models as M
 
 
 @pytest.mark.parametrize("order", [ob.ORDER_REFERENCE, ob.ORDER_DEVICE])
-@pytest.mark.parametrize("strategy", [S.RESAMPLE_SYSTEMATIC, S.RESAMPLE_STRATIFIED])
+@pytest.mark.parametrize("strategy", [S.RESAMPLE_SYSTEMATIC, S.RESAMPLE_STRATIFIED, S.RESAMPLE_RESIDUAL])
 def test_resample_proportions(order, strategy):
     """test/runtests.jl:108-143: empirical index proportions over 10000 draws within 0.02 of we."""
     we = np.array([0.1, 0.5, 0.1, 0.15, 0.15])
@@ -143,3 +143,39 @@ def test_aux_filter_semantics_and_orders():
         assert np.all(o.expweights() == 0.0)
         np.testing.assert_allclose(o.weights(), -np.log(N), rtol=0, atol=1e-13)
         assert abs(o.aux_correct()) < 1e-12
+
+
+def test_residual_resampling_structure():
+    """resample(ResampleResidual, we) — src/resample.jl:63-117: floor(N we_i) deterministic copies in source order, then
+    multinomial draws on the residuals; uniform weights give 1:N without any draw; both orders agree."""
+    rng = np.random.default_rng(2)
+    for n, m in ((5000, 5000), (777, 777), (1000, 400), (300, 1000)):
+        w = rng.standard_normal(n) * 1.5
+        we = np.exp(w - w.max()); we /= we.sum()
+        U = ob.resample_uniforms(S.RESAMPLE_RESIDUAL, m, 7, 3)
+        jr, _ = ob.resample(S.RESAMPLE_RESIDUAL, we, U, m, ob.ORDER_REFERENCE)
+        jd, _ = ob.resample(S.RESAMPLE_RESIDUAL, we, U, m, ob.ORDER_DEVICE)
+        assert np.sum(jr != jd) <= 1
+        num = int(np.floor(we * m - 1e-9).clip(0).sum())          # at least this many deterministic copies, in source order
+        assert np.all(np.diff(jd[:num]) >= 0)
+        assert jd.min() >= 0 and jd.max() < n
+        assert np.all(np.bincount(jd, minlength=n) >= np.floor(we * m - 1e-9).astype(int))
+    we = np.full(64, 1 / 64)
+    j, _ = ob.resample(S.RESAMPLE_RESIDUAL, we, np.zeros(64), order=ob.ORDER_DEVICE)
+    assert np.array_equal(j, np.arange(64))
+
+
+def test_residual_strategy_filter_tracks_kalman():
+    """A ParticleFilter with resampling_strategy = ResampleResidual: log-likelihood within the reference's bound of
+    the Kalman filter's (test/runtests.jl:445) and the two orders agree."""
+    m = M.lg_test_model(0.1)
+    _, U, Y = M.simulate_lg(m, 400, seed=6)
+    cfg = S.make_config(m, 1000, S.PARTICLE_FILTER, S.RESAMPLE_RESIDUAL, 0.5, 3, 0)
+    lls = []
+    for order in (ob.ORDER_REFERENCE, ob.ORDER_DEVICE):
+        o = ob.OracleFilter(cfg, order)
+        o.reset()
+        lls.append(o.run(U, Y, 1.0, ll_steps=True)["ll_steps"])
+        assert o.resample_count() > 5
+    assert np.max(np.abs(lls[0] - lls[1])) < 1e-10
+    assert abs(lls[0].sum() - ob.kalman_loglik(m, U, Y)) < 20
