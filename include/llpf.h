@@ -165,6 +165,16 @@ int  llpf_aux_update(llpf_filter* f, const double* u, const double* y1, double t
 int  llpf_aux_run(llpf_filter* f, const double* U, const double* Y, int64_t T, int32_t mode,
                   double* ll_total, const llpf_run_outputs* outs);
 
+/* ---- particle smoother ---------------------------------------------------------------------------------------
+ * xb, ll = smooth(pf, xf, wf, wef, ll, M, u, y, p) — reference src/smoothing.jl:116-143: forward-filtering backward
+ * simulation.  xf [T*N*nx], wf / wef [T*N] are the history outputs of llpf_run (forward_trajectory); U is T x nu.
+ * The time-T indices are j = resample(strategy, wef[:,T], M) (:123); for t = T-1 .. 1 and every trajectory m:
+ * wb[n] = wf[n,t] + logpdf(df, xb[m,t+1] - f(xf[n,t],u[t],p,(t-1)Ts)), i = draw_one_categorical(wb)
+ * (src/resample.jl:128-152), xb[m,t] = xf[i,t] — O(M N T) density evaluations, one block per trajectory.
+ * xb is [T*M*nx] (time-major), idx (optional) [T*M] the 0-based particle index behind every sample.  M <= N. */
+int  llpf_smooth(llpf_filter* f, int64_t M, const double* U, int64_t T, const double* xf, const double* wf,
+                 const double* wef, double* xb, int64_t* idx);
+
 /* ---- accessors (reference src/PFtypes.jl:296-334) --------------------------------------- */
 int  llpf_num_particles(const llpf_filter* f, int64_t* n);                /* num_particles(pf) */
 int  llpf_index(const llpf_filter* f, int64_t* t);                        /* index(pf) = state.t[] */

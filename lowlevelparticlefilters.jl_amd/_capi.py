@@ -28,6 +28,7 @@ SYMBOLS = {
     "llpf_predict": [_vp, _dp, C.c_double],
     "llpf_update": [_vp, _dp, _dp, C.c_double, _dp],
     "llpf_run": [_vp, _dp, _dp, C.c_int64, C.c_double, _dp, C.POINTER(S.RunOutputs)],
+    "llpf_smooth": [_vp, C.c_int64, _dp, C.c_int64, _dp, _dp, _dp, _dp, _ip],
     "llpf_aux_correct": [_vp, _dp],
     "llpf_aux_predict": [_vp, _dp, _dp, C.c_double],
     "llpf_aux_update": [_vp, _dp, _dp, C.c_double, _dp],
@@ -211,6 +212,16 @@ class FilterHandle:
         check(self.L.llpf_run(self.h, dptr(U), dptr(Y), T, float(t_index0), C.byref(ll), C.byref(outs)))
         res["ll"] = ll.value
         return res
+
+    def smooth(self, M, U, xf, wf, wef):
+        """xb [T, M, nx], idx [T, M]: smooth(pf, xf, wf, wef, ll, M, u, y) — reference src/smoothing.jl:116-143."""
+        xf, wf, wef = f64(xf), f64(wf), f64(wef)
+        T = wf.shape[0]
+        U = f64(U).reshape(T, self.nu) if self.nu else None
+        xb = np.zeros((T, int(M), self.nx))
+        idx = np.zeros((T, int(M)), dtype=np.int64)
+        check(self.L.llpf_smooth(self.h, int(M), dptr(U), T, dptr(xf), dptr(wf), dptr(wef), dptr(xb), iptr(idx)))
+        return xb, idx
 
     # --- AuxiliaryParticleFilter verbs (reference src/filtering.jl:170-217) ---
     def aux_correct(self):

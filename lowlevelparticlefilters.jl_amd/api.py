@@ -23,7 +23,7 @@ from . import _structs as S
 __all__ = [
     "MvNormal", "ResampleSystematic", "ResampleStratified",
     "LinearDynamics", "LinearMeasurement", "QuadTankDynamics", "QuadTankMeasurement", "GaussianLikelihood",
-    "ResampleResidual", "ParticleFilter", "AdvancedParticleFilter", "AuxiliaryParticleFilter", "FilterBank", "ParticleFilteringSolution",
+    "ResampleResidual", "smooth", "smoothed_mean", "smoothed_cov", "smoothed_trajs", "ParticleFilter", "AdvancedParticleFilter", "AuxiliaryParticleFilter", "FilterBank", "ParticleFilteringSolution",
     "reset", "predict", "correct", "update", "forward_trajectory", "mean_trajectory", "loglik",
     "particles", "weights", "expweights", "state", "num_particles", "index", "effective_particles",
     "shouldresample", "resample", "weighted_mean", "logsumexp", "simulate", "parameters",
@@ -332,6 +332,35 @@ def loglik(pf, u, y, p=None):
     if isinstance(pf, AuxiliaryParticleFilter):
         return pf._h.run_aux(u, y, mode=1)["ll"]
     return pf._h.run(u, y, t_index0=1.0)["ll"]
+
+
+def smooth(pf, *args):
+    """xb, ll = smooth(pf, M, u, y, p) / smooth(pf, xf, wf, wef, ll, M, u, y, p) — forward filtering, backward
+    simulation (reference src/smoothing.jl:103-143).  xb is [T, M, nx]."""
+    if len(args) >= 7:
+        xf, wf, wef, ll, M, u, y = args[:7]
+    else:
+        M, u, y = args[:3]
+        sol = forward_trajectory(pf, u, y)
+        xf, wf, wef, ll = sol.x, sol.w, sol.we, sol.ll
+    xb, _ = pf._h.smooth(M, u, xf, wf, wef)
+    return xb, ll
+
+
+def smoothed_mean(xb):
+    """smoothed_mean(xb) — reference src/smoothing.jl:356-361; returns [nx, T] like the reference's hcat."""
+    return np.asarray(xb).mean(axis=1).T
+
+
+def smoothed_cov(xb):
+    """smoothed_cov(xb) — reference src/smoothing.jl:368-372: list of T covariance matrices (normalised by M-1)."""
+    xb = np.asarray(xb)
+    return [np.atleast_2d(np.cov(xb[t].T)) for t in range(xb.shape[0])]
+
+
+def smoothed_trajs(xb):
+    """smoothed_trajs(xb) — reference src/smoothing.jl:379-383: array (nx, M, T)."""
+    return np.ascontiguousarray(np.transpose(np.asarray(xb), (2, 1, 0)))
 
 
 def mean_trajectory(pf, u=None, y=None, p=None):

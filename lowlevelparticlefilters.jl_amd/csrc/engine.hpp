@@ -212,6 +212,21 @@ hipError_t launch_post_predict(const BankDev& b, hipStream_t s);
 hipError_t launch_resample(const BankDev& b, const ResArgs& a, hipStream_t s);
 // fused finalize + resample + propagate [+ weight]: one launch for predict!(u_k) and the weighting of correct!(u_{k+1}, y_{k+1})
 hipError_t launch_resprop(const BankDev& b, const ResArgs& a, const StepArgs& st, int weight, hipStream_t s);
+// FFBS smoother (reference src/smoothing.jl:116-143): one backward step t for all M trajectories
+struct SmoothArgs {
+    const double* xf_t;     // [N][nx] filter particles at time t (AoS, as forward_trajectory returns them)
+    const double* wf_t;     // [N] normalised log-weights at time t
+    const double* u;        // device pointer to u[t]
+    double t;               // time passed to the dynamics
+    double* fx;             // [nx][Ns] scratch: f(xf[n,t], u[t], p, t)
+    const double* xb_next;  // [M][nx] smoothed samples at t+1
+    double* xb_t;           // [M][nx] out
+    int64_t* idx_t;         // [M] out: index of the particle behind every sample
+    int32_t M;
+    uint32_t step;          // Philox step of the draws (= t)
+};
+hipError_t launch_smooth_fx(const BankDev& b, const SmoothArgs& a, hipStream_t s);
+hipError_t launch_smooth_draw(const BankDev& b, const SmoothArgs& a, hipStream_t s);
 hipError_t launch_bake_weights(const BankDev& b, hipStream_t s);   // w[] <- the normalised / uniform values it stands for (padding -Inf)
 hipError_t launch_materialize(const BankDev& b, double* w_out, double* we_out, hipStream_t s);
 hipError_t launch_soa2aos(const BankDev& b, const double* xsrc, double* dst, hipStream_t s);

@@ -22,7 +22,9 @@ enum {
     LLPF_STREAM_DYNAMICS = 1,   /* process noise in propagate_particles! (PFtypes.jl:122-139) */
     LLPF_STREAM_RESAMPLE = 2,   /* systematic offset rand()              (resample.jl:23)     */
     LLPF_STREAM_STRATIFY = 3,   /* stratified per-stratum rand()         (resample.jl:49)     */
-    LLPF_STREAM_MEASURE  = 4    /* host-side simulate() measurement noise                     */
+    LLPF_STREAM_MEASURE  = 4,   /* host-side simulate() measurement noise                     */
+    LLPF_STREAM_SMOOTH   = 5,   /* backward simulation: rand() of draw_one_categorical (resample.jl:137) */
+    LLPF_STREAM_SMOOTH_INIT = 6 /* backward simulation: rand() of the time-T resample (smoothing.jl:123) */
 };
 
 typedef struct { uint32_t v[4]; } llpf_philox4;

@@ -927,6 +927,86 @@ double orc_run_aux(orc_filter* f, const double* U, const double* Y, int64_t T, i
     return ll;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Forward-filtering backward-simulation smoother — smooth(pf, xf, wf, wef, ll, M, u, y, p), src/smoothing.jl:116-143
+ * ---------------------------------------------------------------------------------------- */
+/* i = draw_one_categorical(pf, w) — src/resample.jl:128-152 (0-based result; w: log-weights, clobbered).
+ * Reference order: logsumexp!(w, bins), serial cumsum, s = rand()*bins[end], the two half-range linear searches with
+ * `<=`.  Device order: quanta of exp(w - max w), bins = fl(fl(cum) fl(1/fl(total))), first b with s <= bins[b]. */
+int64_t orc_draw_one_categorical(double* w, double* bins, int64_t n, double u, int order) {
+    if (order == ORC_ORDER_REFERENCE) {
+        orc_logsumexp(w, bins, n, ORC_ORDER_REFERENCE, NULL);
+        for (int64_t i = 1; i < n; ++i) bins[i] += bins[i - 1];
+        double s = u * bins[n - 1];
+        int64_t mid = n / 2;                                   /* 1-based midpoint */
+        if (mid >= 1 && s < bins[mid - 1]) {
+            for (int64_t b = 1; b <= mid; ++b) if (s <= bins[b - 1]) return b - 1;
+        } else {
+            for (int64_t b = (mid >= 1 ? mid : 1); b <= n; ++b) if (s <= bins[b - 1]) return b - 1;
+        }
+        return n - 1;
+    }
+    double m = w[0];
+    for (int64_t i = 1; i < n; ++i) m = llpf_fmax(m, w[i]);
+    const int K = llpf_qbits(n);
+    uint64_t tot = 0;
+    for (int64_t i = 0; i < n; ++i) tot += llpf_q64_unit(llpf_exp_le0(w[i] - m), K);
+    const double Td = (double)tot, invTd = 1.0 / Td;
+    const double s = u * (Td * invTd);
+    uint64_t cum = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        cum += llpf_q64_unit(llpf_exp_le0(w[i] - m), K);
+        bins[i] = (double)cum * invTd;
+        if (s <= bins[i]) return i;
+    }
+    return n - 1;
+}
+
+/* xf [T][N][nx], wf / wef [T][N] (forward_trajectory history), U [T][nu]; xb [T][M][nx], idx [T][M] (optional: the
+ * particle index behind every smoothed sample).  Uniforms: Philox streams SMOOTH_INIT (time-T resample) and SMOOTH
+ * (one per (t, m) draw) under the filter's key — the reference uses the global rand(). */
+int orc_smooth(orc_filter* f, int64_t M, const double* U, int64_t T, const double* xf, const double* wf,
+               const double* wef, double* xb, int64_t* idx) {
+    const int64_t N = f->N;
+    const int nx = f->nx;
+    if (M < 1 || M > N || T < 1) return -1;                   /* @assert M <= N, src/smoothing.jl:121 */
+    const int strategy = f->cfg.resampling_strategy;
+    double* Ures = (double*)malloc(8 * (size_t)(M > 1 ? M : 1));
+    if (strategy == LLPF_RESAMPLE_SYSTEMATIC) Ures[0] = llpf_uniform_step((uint32_t)T, LLPF_STREAM_SMOOTH_INIT, f->k0, f->k1);
+    else for (int64_t i = 0; i < M; ++i) Ures[i] = llpf_uniform_idx((uint32_t)i, (uint32_t)T, LLPF_STREAM_SMOOTH_INIT, f->k0, f->k1);
+    int64_t* j = (int64_t*)calloc((size_t)M, 8);
+    double* bins = (double*)malloc(8 * (size_t)N);
+    /* j = resample(pf.resampling_strategy, wef[:,T], M), :123 */
+    int rc = orc_resample(strategy, wef + (size_t)(T - 1) * N, N, M, Ures, j, bins, f->order);
+    if (rc) { free(Ures); free(j); free(bins); return rc; }
+    for (int64_t m = 0; m < M; ++m) {
+        memcpy(xb + ((size_t)(T - 1) * M + m) * nx, xf + ((size_t)(T - 1) * N + j[m]) * nx, 8 * (size_t)nx);
+        if (idx) idx[(size_t)(T - 1) * M + m] = j[m];
+    }
+    double* fx = (double*)malloc(8 * (size_t)N * nx);
+    double* wb = (double*)malloc(8 * (size_t)N);
+    for (int64_t t = T - 2; t >= 0; --t) {
+        const double ti = (double)t * f->cfg.model.Ts;        /* ti = (t-1)*pf.Ts with 1-based t, :129 */
+        const double* u = U + t * f->nu;
+        ORC_PAR
+        for (int64_t n = 0; n < N; ++n) orc_dynamics(&f->cfg.model, xf + ((size_t)t * N + n) * nx, u, ti, fx + n * nx);
+        for (int64_t m = 0; m < M; ++m) {
+            const double* xn = xb + ((size_t)(t + 1) * M + m) * nx;
+            for (int64_t n = 0; n < N; ++n) {                  /* wb[n] = wf[n,t] + logpdf(df, xb[m,t+1] - f(xf[n,t],u[t],p,ti)), :133-135 */
+                double v[MAXD];
+                for (int d = 0; d < nx; ++d) v[d] = xn[d] - fx[n * nx + d];
+                wb[n] = wf[(size_t)t * N + n] + gauss_logpdf(&f->df, v);
+            }
+            const double ud = llpf_uniform_idx((uint32_t)m, (uint32_t)t, LLPF_STREAM_SMOOTH, f->k0, f->k1);
+            const int64_t i = orc_draw_one_categorical(wb, bins, N, ud, f->order);
+            memcpy(xb + ((size_t)t * M + m) * nx, xf + ((size_t)t * N + i) * nx, 8 * (size_t)nx);
+            if (idx) idx[(size_t)t * M + m] = i;
+        }
+    }
+    free(Ures); free(j); free(bins); free(fx); free(wb);
+    return 0;
+}
+
 /* weighted_mean(x, we) — src/filtering.jl:541-549 */
 void orc_weighted_mean(const orc_filter* f, double* xh) {
     for (int d = 0; d < f->nx; ++d) xh[d] = 0.0;

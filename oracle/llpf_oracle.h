@@ -61,6 +61,11 @@ double orc_aux_update(orc_filter* f, const double* u, const double* y1, double t
 double orc_run_aux(orc_filter* f, const double* U, const double* Y, int64_t T, int mode,
                    double* ll_steps, double* xmean, double* x_hist, double* w_hist, double* we_hist);
 
+/* FFBS particle smoother: smooth(pf, xf, wf, wef, ll, M, u, y, p) and draw_one_categorical (0-based) */
+int64_t orc_draw_one_categorical(double* w, double* bins, int64_t n, double u, int order);
+int    orc_smooth(orc_filter* f, int64_t M, const double* U, int64_t T, const double* xf, const double* wf,
+                  const double* wef, double* xb, int64_t* idx);
+
 int64_t orc_num_particles(const orc_filter* f);
 int64_t orc_index(const orc_filter* f);
 void   orc_get_particles(const orc_filter* f, double* dst);

@@ -45,6 +45,9 @@ def load():
     lib.orc_aux_update.argtypes = [C.c_void_p, _dp, _dp, C.c_double]
     lib.orc_run_aux.restype = C.c_double
     lib.orc_run_aux.argtypes = [C.c_void_p, _dp, _dp, C.c_int64, C.c_int, _dp, _dp, _dp, _dp, _dp]
+    lib.orc_draw_one_categorical.restype = C.c_int64
+    lib.orc_draw_one_categorical.argtypes = [_dp, _dp, C.c_int64, C.c_double, C.c_int]
+    lib.orc_smooth.argtypes = [C.c_void_p, C.c_int64, _dp, C.c_int64, _dp, _dp, _dp, _dp, _ip]
     lib.orc_num_particles.restype = C.c_int64
     lib.orc_num_particles.argtypes = [C.c_void_p]
     lib.orc_index.restype = C.c_int64
@@ -212,6 +215,18 @@ class OracleFilter:
         ll = self.L.orc_run_aux(self.h, dptr(U), dptr(Y), T, int(mode), dptr(lls), dptr(xm), dptr(xh), dptr(wh), dptr(weh))
         return dict(ll=ll, ll_steps=lls, xmean=xm, x=xh, w=wh, we=weh)
 
+    def smooth(self, M, U, xf, wf, wef):
+        """xb [T, M, nx], idx [T, M] of smooth(pf, xf, wf, wef, ll, M, u, y) (src/smoothing.jl:116-143)."""
+        xf, wf, wef = _f64(xf), _f64(wf), _f64(wef)
+        T = wf.shape[0]
+        U = _f64(U).reshape(T, max(self.nu, 1)) if self.nu else np.zeros((T, 1))
+        xb = np.zeros((T, M, self.nx))
+        idx = np.zeros((T, M), dtype=np.int64)
+        rc = self.L.orc_smooth(self.h, int(M), dptr(U), T, dptr(xf), dptr(wf), dptr(wef), dptr(xb), iptr(idx))
+        if rc != 0:
+            raise ValueError("orc_smooth failed (%d)" % rc)
+        return xb, idx
+
     def particles(self):
         a = np.empty((self.N, self.nx))
         self.L.orc_get_particles(self.h, dptr(a))
@@ -271,6 +286,12 @@ class OracleFilter:
         a = np.empty(self.nx)
         self.L.orc_weighted_mean(self.h, dptr(a))
         return a
+
+
+def draw_one_categorical(w, u, order=ORDER_REFERENCE):
+    w = _f64(w).copy()
+    bins = np.zeros(w.size)
+    return lib().orc_draw_one_categorical(dptr(w), dptr(bins), w.size, float(u), order)
 
 
 def logsumexp(w, order=ORDER_REFERENCE):

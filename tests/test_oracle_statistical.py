@@ -179,3 +179,29 @@ def test_residual_strategy_filter_tracks_kalman():
         assert o.resample_count() > 5
     assert np.max(np.abs(lls[0] - lls[1])) < 1e-10
     assert abs(lls[0].sum() - ob.kalman_loglik(m, U, Y)) < 20
+
+
+def test_particle_smoother_and_draw_one_categorical():
+    """smooth(pf, M, u, y) — test/runtests.jl:314-317: size (M, T) and mean(abs2, x - smoothed_mean) < 5;
+    draw_one_categorical (src/resample.jl:128-152) draws index i with probability softmax(w)_i; both orders agree."""
+    rng = np.random.default_rng(0)
+    w = np.log(np.array([0.1, 0.5, 0.1, 0.15, 0.15])) + 3.0
+    for order in (ob.ORDER_REFERENCE, ob.ORDER_DEVICE):
+        counts = np.bincount([ob.draw_one_categorical(w, u, order) for u in rng.uniform(size=20000)], minlength=5)
+        assert np.allclose(counts / counts.sum(), [0.1, 0.5, 0.1, 0.15, 0.15], atol=0.02)
+    assert ob.draw_one_categorical(w, 1.0, ob.ORDER_DEVICE) == 4 and ob.draw_one_categorical(w, 0.0, ob.ORDER_REFERENCE) == 0
+    model = M.lg_test_model(0.1)
+    X, U, Y = M.simulate_lg(model, 200, seed=2)
+    cfg = S.make_config(model, 1000, S.PARTICLE_FILTER, S.RESAMPLE_SYSTEMATIC, 0.1, 3, 0)
+    res = []
+    for order in (ob.ORDER_REFERENCE, ob.ORDER_DEVICE):
+        o = ob.OracleFilter(cfg, order)
+        o.reset()
+        r = o.run(U, Y, 0.0, history=True)
+        xb, idx = o.smooth(100, U, r["x"], r["w"], r["we"])
+        assert xb.shape == (200, 100, 2)
+        assert np.mean((X - xb.mean(axis=1)) ** 2) < 5
+        assert np.mean((X - xb.mean(axis=1)) ** 2) < np.mean((X - np.einsum("tnd,tn->td", r["x"], r["we"])) ** 2)
+        assert np.array_equal(xb, r["x"][np.arange(200)[:, None], idx])
+        res.append(idx)
+    assert np.mean(res[0] != res[1]) < 0.01
