@@ -39,6 +39,21 @@ def build_workload(name, n_particles, T):
         U, Y = M.quadtank_data(T, seed=2)
         kind, thr = S.ADVANCED_PARTICLE_FILTER, 0.5
         label = "C3: quad-tank AdvancedParticleFilter RK4x2, N=%d, T=%d, systematic, threshold 0.5" % (n_particles, T)
+    elif name == "rbpf":
+        g = S.make_gaussian
+        # the mixed linear/nonlinear system of the reference's test/test_rbpf.jl:5-31 (1 + 1 states, An = 0.5)
+        model = S.make_rb_model([[1.0]], np.zeros((1, 0)), [[0.5]], [[0.95]], np.zeros((1, 0)), [[1.0]], [[1.0]],
+                                g(np.zeros(1), np.array([[0.01]])), [[0.01]], g(np.zeros(1), np.array([[0.1]])),
+                                g(np.array([1.0]), np.array([[0.01]])), g(np.array([1.0]), np.array([[1.0]])))
+        rng = np.random.default_rng(1)
+        xn = xl = 1.0
+        Y = np.zeros((T, 1))
+        for t in range(T):
+            Y[t] = xn + xl + np.sqrt(0.1) * rng.standard_normal()
+            xn, xl = xn + 0.5 * xl + 0.1 * rng.standard_normal(), 0.95 * xl + 0.1 * rng.standard_normal()
+        U = np.zeros((T, 0))
+        kind, thr = S.PARTICLE_FILTER, 0.1
+        label = "RBPF (test/test_rbpf.jl:5-31 system: 1 nonlinear + 1 linear state, An = 0.5), N=%d, T=%d, threshold 0.1" % (n_particles, T)
     elif name == "aux":
         model = M.lg_test_model()
         _, U, Y = M.simulate_lg(model, T, seed=1)
@@ -192,7 +207,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="lg", choices=["lg", "quadtank", "aux", "bank"])
+    ap.add_argument("--workload", default="lg", choices=["lg", "quadtank", "aux", "bank", "rbpf"])
     ap.add_argument("--filters-per-gpu", type=int, default=128, help="bank workload (BASELINE config C4): filters per GPU")
     ap.add_argument("--particles", type=int, default=1000000)
     ap.add_argument("--T", type=int, default=None)

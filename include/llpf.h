@@ -33,7 +33,7 @@ extern "C" {
 #endif
 
 #define LLPF_VERSION_MAJOR 0
-#define LLPF_VERSION_MINOR 1
+#define LLPF_VERSION_MINOR 2
 #define LLPF_MAX_DIM 8
 
 /* status codes */
@@ -62,7 +62,13 @@ typedef struct llpf_gaussian {
 /* built-in models */
 enum {
     LLPF_MODEL_LINEAR_GAUSSIAN = 0,  /* f = A x + B u, g = C x  (reference examples/example_lineargaussian.jl:28-29) */
-    LLPF_MODEL_QUADTANK_RK4    = 1   /* quad-tank, RK4          (reference examples/example_quadtank.jl:8-35, src/utils.jl:220-237) */
+    LLPF_MODEL_QUADTANK_RK4    = 1,  /* quad-tank, RK4          (reference examples/example_quadtank.jl:8-35, src/utils.jl:220-237) */
+    /* Rao-Blackwellized particle filter with constant matrices (reference src/rbpf.jl:63-283, "model 2" of :92-98):
+     *   xn' = Fn xn + Bn u + An xl + wn,  wn ~ dynamics_density (R1n)     xl' = Al xl + Bl u + wl,  wl ~ linear_noise (R1l)
+     *   y   = Gn xn + Cl xl + e,          e  ~ measurement_density (R2)
+     * state x = [xn; xl] (nx = nxn + nxl <= 4); A = [Fn An; 0 Al], B = [Bn; Bl], C = [Gn Cl];
+     * initial_density = d0n (dimension nxn), linear_initial = d0l (the inner KalmanFilter's d0). */
+    LLPF_MODEL_RB_LINEAR       = 2
 };
 
 /* quadtank constant slots in llpf_model.qt[] */
@@ -80,11 +86,13 @@ typedef struct llpf_model {
     double  C[LLPF_MAX_DIM * LLPF_MAX_DIM];   /* ny x nx row-major                   */
     double  qt[LLPF_QT_COUNT];                /* quad-tank constants                 */
     int32_t supersample;                      /* rk4 supersample (reference src/utils.jl:220) */
-    int32_t reserved;
+    int32_t nxn;                              /* LLPF_MODEL_RB_LINEAR: number of nonlinear states (else 0) */
     double  Ts;                               /* sample time (reference src/PFtypes.jl:33) */
-    llpf_gaussian dynamics_density;           /* df */
-    llpf_gaussian measurement_density;        /* dg */
-    llpf_gaussian initial_density;            /* d0 */
+    llpf_gaussian dynamics_density;           /* df  (RB: R1n, dimension nxn) */
+    llpf_gaussian measurement_density;        /* dg  (RB: R2) */
+    llpf_gaussian initial_density;            /* d0  (RB: d0n, dimension nxn) */
+    llpf_gaussian linear_noise;               /* RB only: N(0, R1l), dimension nx - nxn (kf.R1) */
+    llpf_gaussian linear_initial;             /* RB only: d0l, dimension nx - nxn (kf.d0)       */
 } llpf_model;
 
 enum { LLPF_RESAMPLE_SYSTEMATIC = 0, LLPF_RESAMPLE_STRATIFIED = 1, LLPF_RESAMPLE_RESIDUAL = 2 };   /* reference src/LowLevelParticleFilters.jl:43-46 */
@@ -164,6 +172,15 @@ int  llpf_aux_predict(llpf_filter* f, const double* u, const double* y1, double 
 int  llpf_aux_update(llpf_filter* f, const double* u, const double* y1, double t, double* ll);
 int  llpf_aux_run(llpf_filter* f, const double* U, const double* Y, int64_t T, int32_t mode,
                   double* ll_total, const llpf_run_outputs* outs);
+
+/* ---- Rao-Blackwellized particle filter (model_id LLPF_MODEL_RB_LINEAR) ---------------------------------------
+ * RBPF(N, kf, dynamics, nl_measurement_model, R1n, d0n; An, ...) — reference src/rbpf.jl:63-144 with constant
+ * matrices ("singleR", :176/:247: one covariance recursion serves all particles; it runs on the host and only its
+ * gains are sent to the device).  The ordinary verbs drive it: llpf_reset = reset! (:146-160), llpf_correct = correct!
+ * (:235-283: w += logpdf(N(0,S), e), xl += K e — or, when C == 0, logpdf(R2, e) and the reference's reuse of the inner
+ * filter's untouched x, R), llpf_predict = predict! (:163-232), llpf_run = forward_trajectory / loglik.  Particles
+ * are [xn; xl].  An != 0 needs nxn == 1 (the right division by Nt, :212, is implemented for a scalar). */
+int  llpf_rb_get_covariance(llpf_filter* f, double* R /* nxl*nxl row-major: x[1].R */);
 
 /* ---- particle smoother ---------------------------------------------------------------------------------------
  * xb, ll = smooth(pf, xf, wf, wef, ll, M, u, y, p) — reference src/smoothing.jl:116-143: forward-filtering backward

@@ -29,6 +29,7 @@ SYMBOLS = {
     "llpf_update": [_vp, _dp, _dp, C.c_double, _dp],
     "llpf_run": [_vp, _dp, _dp, C.c_int64, C.c_double, _dp, C.POINTER(S.RunOutputs)],
     "llpf_smooth": [_vp, C.c_int64, _dp, C.c_int64, _dp, _dp, _dp, _dp, _ip],
+    "llpf_rb_get_covariance": [_vp, _dp],
     "llpf_aux_correct": [_vp, _dp],
     "llpf_aux_predict": [_vp, _dp, _dp, C.c_double],
     "llpf_aux_update": [_vp, _dp, _dp, C.c_double, _dp],
@@ -212,6 +213,13 @@ class FilterHandle:
         check(self.L.llpf_run(self.h, dptr(U), dptr(Y), T, float(t_index0), C.byref(ll), C.byref(outs)))
         res["ll"] = ll.value
         return res
+
+    def rb_covariance(self):
+        """x[1].R of an RBPF: the covariance of the linear substate shared by all particles."""
+        nl = self.nx - self.cfg.model.nxn
+        a = np.zeros((nl, nl))
+        check(self.L.llpf_rb_get_covariance(self.h, dptr(a)))
+        return a
 
     def smooth(self, M, U, xf, wf, wef):
         """xb [T, M, nx], idx [T, M]: smooth(pf, xf, wf, wef, ll, M, u, y) — reference src/smoothing.jl:116-143."""

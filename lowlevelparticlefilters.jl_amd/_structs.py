@@ -7,7 +7,7 @@ import numpy as np
 MAX_DIM = 8
 
 COV_SCAL, COV_DIAG, COV_FULL = 0, 1, 2
-MODEL_LINEAR_GAUSSIAN, MODEL_QUADTANK_RK4 = 0, 1
+MODEL_LINEAR_GAUSSIAN, MODEL_QUADTANK_RK4, MODEL_RB_LINEAR = 0, 1, 2
 RESAMPLE_SYSTEMATIC, RESAMPLE_STRATIFIED, RESAMPLE_RESIDUAL = 0, 1, 2
 PARTICLE_FILTER, ADVANCED_PARTICLE_FILTER = 0, 1
 
@@ -25,10 +25,10 @@ class Model(C.Structure):
     _fields_ = [("model_id", C.c_int32), ("nx", C.c_int32), ("nu", C.c_int32), ("ny", C.c_int32),
                 ("A", C.c_double * 64), ("B", C.c_double * 64), ("C", C.c_double * 64),
                 ("qt", C.c_double * QT_COUNT),
-                ("supersample", C.c_int32), ("reserved", C.c_int32),
+                ("supersample", C.c_int32), ("nxn", C.c_int32),
                 ("Ts", C.c_double),
                 ("dynamics_density", Gaussian), ("measurement_density", Gaussian),
-                ("initial_density", Gaussian)]
+                ("initial_density", Gaussian), ("linear_noise", Gaussian), ("linear_initial", Gaussian)]
 
 
 class Config(C.Structure):
@@ -126,6 +126,46 @@ def make_lg_model(A, B, Cm, df, dg, d0, Ts=1.0):
     m.dynamics_density, m.measurement_density, m.initial_density = df, dg, d0
     if df.dim != nx or d0.dim != nx or dg.dim != ny:
         raise ValueError("density dimensions do not match the model")
+    return m
+
+
+def make_rb_model(Fn, Bn, An, Al, Bl, Gn, Cl, R1n, R1l, R2, d0n, d0l, Ts=1.0):
+    """Rao-Blackwellized model with constant matrices (reference src/rbpf.jl:92-98):
+    xn' = Fn xn + Bn u + An xl + wn, xl' = Al xl + Bl u + wl, y = Gn xn + Cl xl + e.
+    An / Cl may be None (no coupling).  R1n, R2, d0n, d0l are Gaussian structs (make_gaussian); R1l is a matrix."""
+    Fn = np.atleast_2d(np.asarray(Fn, dtype=np.float64)); Al = np.atleast_2d(np.asarray(Al, dtype=np.float64))
+    nn, nl = Fn.shape[0], Al.shape[0]
+    nx = nn + nl
+    Gn = np.asarray(Gn, dtype=np.float64).reshape(-1, nn)
+    ny = Gn.shape[0]
+    An = np.zeros((nn, nl)) if An is None else np.asarray(An, dtype=np.float64).reshape(nn, nl)
+    Cl = np.zeros((ny, nl)) if Cl is None else np.asarray(Cl, dtype=np.float64).reshape(ny, nl)
+    Bn = np.zeros((nn, 0)) if Bn is None else np.asarray(Bn, dtype=np.float64).reshape(nn, -1)
+    nu = Bn.shape[1]
+    Bl = np.zeros((nl, nu)) if Bl is None else np.asarray(Bl, dtype=np.float64).reshape(nl, nu)
+    if nx > 4 or ny > 4 or nn < 1 or nl < 1:
+        raise ValueError("RB model: 1 <= nxn, 1 <= nxl, nxn + nxl <= 4, ny <= 4")
+    A = np.block([[Fn, An], [np.zeros((nl, nn)), Al]])
+    B = np.vstack([Bn, Bl])
+    Cm = np.hstack([Gn, Cl])
+    m = Model()
+    m.model_id = MODEL_RB_LINEAR
+    m.nx, m.nu, m.ny, m.nxn = nx, nu, ny, nn
+    for r in range(nx):
+        for c in range(nx):
+            m.A[r * nx + c] = A[r, c]
+        for c in range(nu):
+            m.B[r * nu + c] = B[r, c]
+    for r in range(ny):
+        for c in range(nx):
+            m.C[r * nx + c] = Cm[r, c]
+    m.supersample = 1
+    m.Ts = float(Ts)
+    m.dynamics_density, m.measurement_density, m.initial_density = R1n, R2, d0n
+    m.linear_noise = make_gaussian(np.zeros(nl), np.atleast_2d(np.asarray(R1l, dtype=np.float64)), COV_FULL)
+    m.linear_initial = d0l
+    if R1n.dim != nn or d0n.dim != nn or R2.dim != ny or d0l.dim != nl:
+        raise ValueError("density dimensions do not match the RB model")
     return m
 
 

@@ -23,7 +23,7 @@ from . import _structs as S
 __all__ = [
     "MvNormal", "ResampleSystematic", "ResampleStratified",
     "LinearDynamics", "LinearMeasurement", "QuadTankDynamics", "QuadTankMeasurement", "GaussianLikelihood",
-    "ResampleResidual", "smooth", "smoothed_mean", "smoothed_cov", "smoothed_trajs", "ParticleFilter", "AdvancedParticleFilter", "AuxiliaryParticleFilter", "FilterBank", "ParticleFilteringSolution",
+    "ResampleResidual", "KalmanFilter", "RBMeasurementModel", "RBPF", "smooth", "smoothed_mean", "smoothed_cov", "smoothed_trajs", "ParticleFilter", "AdvancedParticleFilter", "AuxiliaryParticleFilter", "FilterBank", "ParticleFilteringSolution",
     "reset", "predict", "correct", "update", "forward_trajectory", "mean_trajectory", "loglik",
     "particles", "weights", "expweights", "state", "num_particles", "index", "effective_particles",
     "shouldresample", "resample", "weighted_mean", "logsumexp", "simulate", "parameters",
@@ -216,6 +216,58 @@ class AdvancedParticleFilter(_AbstractParticleFilter):
         self._setup(N, dynamics, measurement, dynamics_density, measurement_likelihood.measurement_density,
                     initial_density, resample_threshold, resampling_strategy, rng, p, threads, Ts, nu, ny, device)
         self.measurement_likelihood = measurement_likelihood
+
+
+class KalmanFilter:
+    """KalmanFilter(A, B, C, D, R1, R2, d0) — descriptor of the inner filter of an RBPF (reference src/kalman.jl; only
+    constant matrices and D = 0 are supported)."""
+
+    def __init__(self, A, B, C, D, R1, R2, d0):
+        if np.any(np.asarray(D) != 0):
+            raise NotImplementedError("D != 0")
+        self.A, self.B, self.C, self.D = np.atleast_2d(np.asarray(A, float)), B, C, D
+        self.R1, self.R2, self.d0 = np.atleast_2d(np.asarray(R1, float)), np.atleast_2d(np.asarray(R2, float)), d0
+
+
+class RBMeasurementModel:
+    """RBMeasurementModel(measurement, R2, ny) — reference src/rbpf.jl:36-60; `measurement` is a LinearMeasurement
+    descriptor of the nonlinear state's contribution y = Gn xn (+ C xl + e)."""
+
+    def __init__(self, measurement, R2, ny):
+        self.measurement, self.R2, self.ny = measurement, R2, int(ny)
+
+
+class RBPF(_AbstractParticleFilter):
+    """RBPF(N, kf, dynamics, nl_measurement_model, R1n, d0n; An, nu, Ts, rng, resample_threshold) — the
+    Rao-Blackwellized ("marginalized") particle filter of reference src/rbpf.jl:63-144 with constant matrices:
+    dynamics = LinearDynamics(Fn, Bn) of the nonlinear substate, An the coupling matrix or None."""
+    kind = S.PARTICLE_FILTER
+
+    def __init__(self, N, kf, dynamics, nl_measurement_model, R1n, d0n, *, An=None, nu=-1, Ts=1.0, p=None, rng=None,
+                 resample_threshold=0.1, names=None, device=0):
+        as_g = lambda d: d.struct() if isinstance(d, MvNormal) else d
+        as_cov = lambda d, n: d if not isinstance(d, (np.ndarray, list)) else MvNormal(np.zeros(n), np.atleast_2d(np.asarray(d, float)))
+        nn = np.atleast_2d(np.asarray(dynamics.A, float)).shape[0]
+        R1n = as_cov(R1n, nn)
+        R2 = as_cov(nl_measurement_model.R2, nl_measurement_model.ny)
+        mm = nl_measurement_model.measurement
+        Gn = np.zeros((nl_measurement_model.ny, nn)) if mm is None else mm.C
+        self.kf, self.dynamics, self.nl_measurement_model, self.An, self.R1n, self.d0n = kf, dynamics, nl_measurement_model, An, R1n, d0n
+        self.resample_threshold = float(resample_threshold)
+        self.resampling_strategy = ResampleSystematic            # resampling_strategy(pf::RBPF), src/rbpf.jl:306
+        self.rng = 0 if rng is None else int(rng)
+        self.p, self.Ts, self.names, self.threads = p, float(Ts), names, False
+        self.measurement_likelihood = None
+        self._model = S.make_rb_model(dynamics.A, dynamics.B, An, kf.A, kf.B, Gn, kf.C, as_g(R1n), kf.R1, as_g(R2), as_g(d0n), as_g(kf.d0), Ts)
+        self.nx, self.nu, self.ny = self._model.nx, self._model.nu, self._model.ny
+        self._cfg = S.make_config(self._model, N, self.kind, S.RESAMPLE_SYSTEMATIC, resample_threshold, self.rng, device)
+        self._h = _capi.FilterHandle(self._cfg)
+        self.N = int(N)
+
+    @property
+    def covariance(self):
+        """x[1].R: the covariance of the linear substate (shared by all particles for constant matrices)."""
+        return self._h.rb_covariance()
 
 
 class AuxiliaryParticleFilter:

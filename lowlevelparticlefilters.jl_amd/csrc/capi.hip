@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "engine.hpp"
+#include "shared/llpf_rbkf.h"
 
 using namespace llpf;
 
@@ -109,8 +110,45 @@ static int model_prepare(const llpf_model* m, ModelD* d) {
     if (gauss_prepare(&m->dynamics_density, &d->df)) return -1;
     if (gauss_prepare(&m->measurement_density, &d->dg)) return -2;
     if (gauss_prepare(&m->initial_density, &d->d0)) return -3;
+    if (m->model_id == LLPF_MODEL_RB_LINEAR) {
+        // Rao-Blackwellized model: df = R1n and d0n have dimension nxn; reset! draws xn ~ d0n and sets xl = d0l.mu exactly
+        // (reference src/rbpf.jl:146-158): d0 becomes [mu_n; mu_l] + blockdiag(L_n, 0) xi
+        const int nn = m->nxn, nl = m->nx - m->nxn;
+        if (nn < 1 || nl < 1 || m->nx > 4) return -5;
+        if (d->df.dim != nn || d->d0.dim != nn || d->dg.dim != m->ny || m->linear_noise.dim != nl || m->linear_initial.dim != nl) return -4;
+        d->nxn = nn;
+        d->rb_zeroAn = 1; d->rb_zeroC = 1;
+        for (int r = 0; r < nn; ++r) for (int c = 0; c < nl; ++c) if (m->A[r * m->nx + nn + c] != 0.0) d->rb_zeroAn = 0;
+        for (int r = 0; r < m->ny; ++r) for (int c = 0; c < nl; ++c) if (m->C[r * m->nx + nn + c] != 0.0) d->rb_zeroC = 0;
+        if (!d->rb_zeroAn && nn != 1) return -6;       // L = (Al R An') / Nt is implemented for a scalar Nt
+        GaussD d0n = d->d0;
+        memset(&d->d0, 0, sizeof(d->d0));
+        d->d0.dim = m->nx; d->d0.kind = LLPF_COV_FULL;
+        for (int i = 0; i < nn; ++i) {
+            d->d0.mu[i] = d0n.mu[i];
+            for (int j = 0; j <= i; ++j)
+                d->d0.L[i * MAXD + j] = (d0n.kind == LLPF_COV_FULL) ? d0n.L[i * MAXD + j] : (i == j ? d0n.L[i * MAXD + i] : 0.0);
+        }
+        for (int i = 0; i < nl; ++i) d->d0.mu[nn + i] = m->linear_initial.mu[i];
+        GaussD tmp;
+        if (gauss_prepare(&m->linear_noise, &tmp)) return -7;
+        if (gauss_prepare(&m->linear_initial, &tmp)) return -8;
+        return 0;
+    }
     if (d->df.dim != m->nx || d->d0.dim != m->nx || d->dg.dim != m->ny) return -4;
     return 0;
+}
+
+// dense row-major covariance of a Gaussian descriptor
+static void gauss_cov_dense(const llpf_gaussian* g, double* S) {
+    const int n = g->dim;
+    for (int i = 0; i < n * n; ++i) S[i] = 0.0;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            if (g->kind == LLPF_COV_SCAL) S[i * n + j] = (i == j) ? g->cov[0] : 0.0;
+            else if (g->kind == LLPF_COV_DIAG) S[i * n + j] = (i == j) ? g->cov[i] : 0.0;
+            else S[i * n + j] = g->cov[i * n + j];
+        }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -135,6 +173,13 @@ struct Bank {
     uint64_t* d_tileq = nullptr;
     uint32_t* d_flag = nullptr;
     double* d_xmpart = nullptr;
+    // Rao-Blackwellized model: host side of the shared covariance recursion (csrc/shared/llpf_rbkf.h)
+    struct RBHost { double R[16], kfx[4], kfR[16]; };
+    std::vector<RBHost> rb;           // per filter: x[1].R and the inner KalmanFilter object's fields
+    std::vector<llpf_model> hmodels;  // the F model descriptors as given at create
+    RBStep* d_rb = nullptr;           // device: parameters of the single-step API ([2][F]) ...
+    RBStep* d_rbseq = nullptr;        // ... and of a run ([2T+1][F]: corr_0, pred_0, corr_1, ...)
+    size_t cap_rbseq = 0;
     uint64_t* d_rtile = nullptr;      // [F][2][P2] residual resampling: per-tile counts / residual sums and their prefixes
     double* d_lam = nullptr;          // [F][Ns] lambda of the AuxiliaryParticleFilter predict! (allocated on first use)
     bool aux_pending = false;         // w holds lambda - log N of an aux predict!; their exp-sums wait in slot (parity+2)%3
@@ -192,7 +237,7 @@ static void free_bank(Bank& b) {
     hipSetDevice(b.device);
     if (b.stream) hipStreamSynchronize(b.stream);
     hipFree(b.d_models); hipFree(b.d_scal); hipFree(b.d_x[0]); hipFree(b.d_x[1]); hipFree(b.d_w);
-    hipFree(b.d_anc); hipFree(b.d_acc); hipFree(b.d_quanta[0]); hipFree(b.d_quanta[1]); hipFree(b.d_tileq); hipFree(b.d_flag); hipFree(b.d_xmpart); hipFree(b.d_lam); hipFree(b.d_rtile); hipFree(b.d_uy); hipFree(b.d_U); hipFree(b.d_Y);
+    hipFree(b.d_anc); hipFree(b.d_acc); hipFree(b.d_quanta[0]); hipFree(b.d_quanta[1]); hipFree(b.d_tileq); hipFree(b.d_flag); hipFree(b.d_xmpart); hipFree(b.d_lam); hipFree(b.d_rtile); hipFree(b.d_rb); hipFree(b.d_rbseq); hipFree(b.d_uy); hipFree(b.d_U); hipFree(b.d_Y);
     hipFree(b.d_ll_steps); hipFree(b.d_xmean); hipFree(b.d_tmp);
     for (auto e : b.ev_pool) hipEventDestroy(e);
     for (auto& e : b.pending) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
@@ -259,6 +304,12 @@ static void prof_collect(Bank& b) {
 
 static int bank_init_particles(Bank& b, bool is_reset) {
     b.aux_pending = false; b.we_is_lambda = false;
+    for (size_t f = 0; f < b.rb.size(); ++f) {              // reset!(pf::RBPF): R = copy(pf.kf.d0.Sigma), src/rbpf.jl:152 (pf.kf itself is not reset)
+        double S0[16];
+        gauss_cov_dense(&b.hmodels[f].linear_initial, S0);
+        const int nl = b.nx - b.cfg.model.nxn;
+        for (int i = 0; i < nl * nl; ++i) b.rb[f].R[i] = S0[i];
+    }
     // constructor (src/PFtypes.jl:65-75): x ~ d0, w = log(1/N), j = 1:N, t = 0
     // reset!      (src/filtering.jl:4-14): x ~ d0, w = -log N, we = 1/N, t = 1   (j untouched)
     std::vector<FilterScal> h;
@@ -319,8 +370,10 @@ static int bank_create(const llpf_config* cfg, const llpf_model* models, int F, 
     b.P2 = (int)(b.Ns / TILE);
     b.device = cfg->device;
     std::vector<ModelD> hm(F);
+    b.hmodels.resize(F);
     for (int f = 0; f < F; ++f) {
         const llpf_model& mf = models ? models[f] : cfg->model;
+        b.hmodels[f] = mf;
         if (mf.model_id != m0.model_id || mf.nx != m0.nx || mf.nu != m0.nu || mf.ny != m0.ny)
             return fail(LLPF_ERR_ARG, "all filters of a bank must share model id and dimensions");
         int rc = model_prepare(&mf, &hm[f]);
@@ -342,6 +395,18 @@ static int bank_create(const llpf_config* cfg, const llpf_model* models, int F, 
     HIPC(hipMalloc(&b.d_flag, sizeof(uint32_t) * 4));
     HIPC(hipMalloc(&b.d_xmpart, sizeof(double) * (size_t)F * b.P1 * MAXD));
     HIPC(hipMalloc(&b.d_rtile, sizeof(uint64_t) * (size_t)F * 2 * b.P2));
+    if (m0.model_id == LLPF_MODEL_RB_LINEAR) {
+        HIPC(hipMalloc(&b.d_rb, sizeof(RBStep) * 2 * (size_t)F));
+        HIPC(hipMemsetAsync(b.d_rb, 0, sizeof(RBStep) * 2 * (size_t)F, b.stream));
+        b.rb.resize(F);
+        for (int f = 0; f < F; ++f) {                       // the inner KalmanFilter object: kf.x = d0.mu, kf.R = d0.Sigma
+            double S0[16];
+            gauss_cov_dense(&b.hmodels[f].linear_initial, S0);
+            const int nl = m0.nx - m0.nxn;
+            for (int i = 0; i < nl * nl; ++i) { b.rb[f].R[i] = S0[i]; b.rb[f].kfR[i] = S0[i]; }
+            for (int i = 0; i < nl; ++i) b.rb[f].kfx[i] = b.hmodels[f].linear_initial.mu[i];
+        }
+    }
     HIPC(hipMemsetAsync(b.d_rtile, 0, sizeof(uint64_t) * (size_t)F * 2 * b.P2, b.stream));
     HIPC(hipMalloc(&b.d_uy, sizeof(double) * 4 * MAXD));
     HIPC(hipMalloc(&b.d_tmp, sizeof(double) * (size_t)F * b.N * (b.nx > 1 ? b.nx : 1) + 64));
@@ -408,6 +473,60 @@ static int clear_fallback(Bank& b, const std::vector<int>& fl) {
 }
 static int need_e2(const Bank& b) { return b.cfg.resample_threshold != 1.0 ? 1 : 0; }
 
+// ---- Rao-Blackwellized model: the shared covariance recursion on the host (reference src/rbpf.jl:176-219, 247-279) ----
+static bool is_rb(const Bank& b) { return b.cfg.model.model_id == LLPF_MODEL_RB_LINEAR; }
+struct RBMats { int nn, nl, ny, zeroC, zeroAn; double An[16], Al[16], Cl[16], R1l[16], R1n[16], R2[16]; };
+static void rb_mats(const llpf_model& m, RBMats& o) {
+    const int nx = m.nx, nn = m.nxn, nl = nx - nn, ny = m.ny;
+    o.nn = nn; o.nl = nl; o.ny = ny; o.zeroAn = 1; o.zeroC = 1;
+    for (int r = 0; r < nn; ++r) for (int c = 0; c < nl; ++c) { o.An[r * nl + c] = m.A[r * nx + nn + c]; if (o.An[r * nl + c] != 0.0) o.zeroAn = 0; }
+    for (int r = 0; r < nl; ++r) for (int c = 0; c < nl; ++c) o.Al[r * nl + c] = m.A[(nn + r) * nx + nn + c];
+    for (int r = 0; r < ny; ++r) for (int c = 0; c < nl; ++c) { o.Cl[r * nl + c] = m.C[r * nx + nn + c]; if (o.Cl[r * nl + c] != 0.0) o.zeroC = 0; }
+    gauss_cov_dense(&m.linear_noise, o.R1l);
+    gauss_cov_dense(&m.dynamics_density, o.R1n);
+    gauss_cov_dense(&m.measurement_density, o.R2);
+}
+static double rb_sqrt_host(double x) { return llpf_sqrt(x); }
+// parameters of one correct! of filter f; advances the filter's shared covariance
+static int rb_corr_step(Bank& b, int f, RBStep& out) {
+    RBMats m;
+    rb_mats(b.hmodels[f], m);
+    memset(&out, 0, sizeof(out));
+    for (int i = 0; i < m.nl; ++i) out.kfx[i] = b.rb[f].kfx[i];
+    if (m.zeroC) {                                          // x[i] = RBParticle(xn, kf.x, kf.R) with an untouched kf, :279
+        for (int i = 0; i < m.nl * m.nl; ++i) b.rb[f].R[i] = b.rb[f].kfR[i];
+        return LLPF_OK;
+    }
+    double S[16], K[16], Rpost[16];
+    if (llpf_rb_gain(m.nl, m.ny, b.rb[f].R, m.Cl, m.R2, S, K, Rpost, rb_sqrt_host)) return fail(LLPF_ERR_DEGENERATE, "RBPF: innovation covariance not positive definite");
+    llpf_gaussian gs;
+    memset(&gs, 0, sizeof(gs));
+    gs.dim = m.ny; gs.kind = LLPF_COV_FULL;
+    for (int i = 0; i < m.ny * m.ny; ++i) gs.cov[i] = S[i];
+    if (gauss_prepare(&gs, &out.dS)) return fail(LLPF_ERR_DEGENERATE, "RBPF: innovation covariance not positive definite");
+    for (int i = 0; i < m.nl * m.ny; ++i) out.K[i] = K[i];
+    for (int i = 0; i < m.nl * m.nl; ++i) { b.rb[f].R[i] = Rpost[i]; b.rb[f].kfR[i] = Rpost[i]; }
+    return LLPF_OK;
+}
+// parameters of one predict! of filter f; advances the filter's shared covariance
+static int rb_pred_step(Bank& b, int f, RBStep& out) {
+    RBMats m;
+    rb_mats(b.hmodels[f], m);
+    memset(&out, 0, sizeof(out));
+    double L[16], R1[16];
+    if (llpf_rb_predcov(m.nl, m.nn, m.zeroAn, b.rb[f].R, m.Al, m.An, m.R1l, m.R1n, L, R1)) return fail(LLPF_ERR_ARG, "RBPF: An != 0 needs one nonlinear state");
+    for (int i = 0; i < m.nl * m.nn; ++i) out.L[i] = L[i];
+    for (int i = 0; i < m.nl * m.nl; ++i) b.rb[f].R[i] = R1[i];
+    return LLPF_OK;
+}
+static int rb_upload_single(Bank& b, bool corr) {
+    std::vector<RBStep> hs(b.F);
+    for (int f = 0; f < b.F; ++f) CHK(corr ? rb_corr_step(b, f, hs[f]) : rb_pred_step(b, f, hs[f]));
+    HIPC(hipMemcpyAsync(b.d_rb + (corr ? 0 : b.F), hs.data(), sizeof(RBStep) * b.F, hipMemcpyHostToDevice, b.stream));
+    HIPC(hipStreamSynchronize(b.stream));
+    return LLPF_OK;
+}
+
 // ---- single steps -------------------------------------------------------------------------------
 static int bank_correct(Bank& b, const double* u, const double* y, double t, double* ll_out /* [F] */) {
     CHK(use_device(b));
@@ -423,6 +542,7 @@ static int bank_correct(Bank& b, const double* u, const double* y, double t, dou
         StepArgs a{};
         a.u = b.d_uy; a.y = b.d_uy + MAXD; a.t_prop = t; a.t_meas = t; a.step = 0; a.has_y = has_y ? 1 : 0;
         a.parity = slot; a.need_e2 = 1; a.K = llpf_qbits(b.N); a.k = 0; a.next_step = b.n_predict; a.accumulate = 1;
+        if (is_rb(b) && has_y) { CHK(rb_upload_single(b, true)); a.rb_corr = b.d_rb; }
         HIPC(launch_step(d, MODE_WEIGHT, a, b.stream));     // weights + exp-sums against the bound + quanta
     }
     b.qcur ^= 1;
@@ -460,6 +580,7 @@ static int bank_predict(Bank& b, const double* u, double t) {
     StepArgs a{};
     a.u = b.d_uy; a.y = nullptr; a.t_prop = t; a.t_meas = t; a.step = b.n_predict; a.has_y = 0; a.parity = b.parity;
     a.K = llpf_qbits(b.N); a.k = 0;
+    if (is_rb(b)) { CHK(rb_upload_single(b, false)); a.rb_pred = b.d_rb + b.F; }
     HIPC(launch_step(d, MODE_PROP, a, b.stream));
     HIPC(launch_post_predict(d, b.stream));
     b.cur ^= 1;
@@ -518,7 +639,28 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
     const bool heavy_dynamics = b.cfg.model.model_id == LLPF_MODEL_QUADTANK_RK4;
     // residual resampling produces unsorted ancestors (copies first, multinomial draws after): always the balanced form
     const bool residual = b.cfg.resampling_strategy == LLPF_RESAMPLE_RESIDUAL;
-    const bool unfused = hist || residual || (unf_env ? atoi(unf_env) != 0 : heavy_dynamics);
+    const bool rbm = is_rb(b);
+    const bool unfused = hist || residual || rbm || (unf_env ? atoi(unf_env) != 0 : heavy_dynamics);
+    if (rbm) {
+        // the whole gain schedule of the run (data independent): corr_0, pred_0, corr_1, pred_1, ..., [F] each
+        const size_t need = (size_t)(2 * T + 1) * b.F;
+        if (b.cap_rbseq < need) {
+            if (b.d_rbseq) hipFree(b.d_rbseq);
+            b.d_rbseq = nullptr; b.cap_rbseq = 0;
+            HIPC(hipMalloc(&b.d_rbseq, sizeof(RBStep) * need));
+            b.cap_rbseq = need;
+        }
+        std::vector<RBStep> seq(need);
+        for (int64_t k = 0; k < T; ++k)
+            for (int f = 0; f < b.F; ++f) {
+                if (!(Y[k * b.ny] != Y[k * b.ny])) CHK(rb_corr_step(b, f, seq[(size_t)(2 * k) * b.F + f]));
+                else memset(&seq[(size_t)(2 * k) * b.F + f], 0, sizeof(RBStep));
+                CHK(rb_pred_step(b, f, seq[(size_t)(2 * k + 1) * b.F + f]));
+            }
+        memset(&seq[(size_t)(2 * T) * b.F], 0, sizeof(RBStep) * b.F);
+        HIPC(hipMemcpyAsync(b.d_rbseq, seq.data(), sizeof(RBStep) * need, hipMemcpyHostToDevice, b.stream));
+        HIPC(hipStreamSynchronize(b.stream));
+    }
     // Where the exp-sums / quanta of freshly computed weights are formed (identical results either way): inside the
     // weighting phase (one launch per timestep: best when one filter of ~1e6 particles cannot fill the chip and the
     // dependent-launch latency dominates) or by a streaming k_norm launch in bound form (the fused kernel then keeps
@@ -559,6 +701,7 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
         st.step = b.n_predict;
         st.parity = b.parity;
         st.need_e2 = ne2; st.K = K; st.k = k; st.next_step = b.n_predict + 1; st.want_xmean = want_xm; st.accumulate = merged ? 1 : 0;
+        if (rbm) { st.rb_pred = b.d_rbseq + (size_t)(2 * k + 1) * b.F; st.rb_corr = b.d_rbseq + (size_t)(2 * k + 2) * b.F; }
         const bool weight = (k + 1 < T);
         if (weight) { st.y = b.d_Y + (k + 1) * b.ny; st.t_meas = tk(k + 1); st.has_y = has_y(k + 1) ? 1 : 0; }
         else { st.y = nullptr; st.t_meas = tk(k); st.has_y = 0; }
@@ -624,6 +767,7 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
         StepArgs a{};
         a.u = b.nu > 0 ? b.d_U : nullptr; a.y = b.d_Y; a.t_prop = tk(0); a.t_meas = tk(0); a.step = 0; a.has_y = has_y(0) ? 1 : 0;
         a.parity = par0; a.need_e2 = ne2; a.K = K; a.k = 0; a.next_step = np0; a.want_xmean = want_xm; a.accumulate = merged ? 1 : 0;
+        if (rbm) a.rb_corr = b.d_rbseq;
         ProfScope ps(b, LLPF_PROF_PROPAGATE);
         HIPC(launch_step(d, MODE_WEIGHT, a, b.stream));
     }
@@ -805,6 +949,7 @@ static int bank_aux_correct(Bank& b, double* ll_out /* [F] or null */, const Aux
 
 // Single-call predict!(pf::AuxiliaryParticleFilter, u, y1, p, t): synchronous.  d_u / d_y1 are device pointers.
 static int aux_predict_dev(Bank& b, const double* d_u, const double* d_y1, bool has_y1, double t, int want_xm) {
+    if (is_rb(b)) return fail(LLPF_ERR_ARG, "the auxiliary filter is not defined for the Rao-Blackwellized model");
     if (b.cfg.resampling_strategy == LLPF_RESAMPLE_RESIDUAL) return fail(LLPF_ERR_ARG, "the auxiliary filter supports systematic and stratified resampling");
     if (b.aux_pending) CHK(bank_aux_correct(b, nullptr, AuxOuts{}, 0));   // contract: predict! works on normalised weights
     CHK(aux_ensure_lam(b));
@@ -989,6 +1134,7 @@ static int bank_smooth(Bank& b, int64_t M, const double* U, int64_t T, const dou
                        const double* wef, double* xb, int64_t* idx) {
     CHK(use_device(b));
     if (b.F != 1) return fail(LLPF_ERR_ARG, "smooth needs a single filter");
+    if (is_rb(b)) return fail(LLPF_ERR_ARG, "smooth is not defined for the Rao-Blackwellized model");
     if (M < 1 || M > b.N) return fail(LLPF_ERR_ARG, "M must be in 1..N (reference src/smoothing.jl:121)");
     if (T < 1 || !xf || !wf || !wef || !xb) return fail(LLPF_ERR_ARG, "bad arguments");
     if (b.nu > 0 && !U) return fail(LLPF_ERR_ARG, "U is null");
@@ -1204,6 +1350,14 @@ int llpf_bank_aux_run(llpf_bank* b, const double* U, const double* Y, int64_t T,
                       double* ll_total, double* ll_steps) {
     if (!b) return fail(LLPF_ERR_ARG, "null bank");
     return bank_aux_run(b->bank, U, Y, T, mode, ll_total, ll_steps, nullptr, nullptr, nullptr, nullptr);
+}
+
+int llpf_rb_get_covariance(llpf_filter* f, double* R) {
+    NEEDF(f);
+    if (!is_rb(f->bank)) return fail(LLPF_ERR_ARG, "not a Rao-Blackwellized filter");
+    const int nl = f->bank.nx - f->bank.cfg.model.nxn;
+    for (int i = 0; i < nl * nl; ++i) R[i] = f->bank.rb[0].R[i];
+    return LLPF_OK;
 }
 
 int llpf_smooth(llpf_filter* f, int64_t M, const double* U, int64_t T, const double* xf, const double* wf,

@@ -71,11 +71,22 @@ struct GaussD {
     double c0;
 };
 
+// Rao-Blackwellized filter with constant matrices (reference src/rbpf.jl): what one correct! / predict! needs from the
+// shared covariance recursion (computed on the host, csrc/shared/llpf_rbkf.h): N(0,S) and the gain K of the
+// measurement update, the gain L of the time update, and the inner KalmanFilter object's mean (C == 0 quirk, :279)
+struct RBStep {
+    GaussD dS;                 // SimpleMvNormal(PDMat(S, S_chol)), S = symmetrize(C R C') + R2
+    double K[MAXD * MAXD];     // nxl x ny, row-major dense (stride ny)
+    double L[MAXD * MAXD];     // nxl x nxn, row-major dense (stride nxn)
+    double kfx[MAXD];          // kf.x as the reference leaves it in every particle when C == 0
+};
+
 struct ModelD {
     int32_t model_id, nx, nu, ny;
     double A[MAXD * MAXD], B[MAXD * MAXD], C[MAXD * MAXD];
     double qt[LLPF_QT_COUNT];
-    int32_t supersample, pad0;
+    int32_t supersample, nxn;      // nxn: LLPF_MODEL_RB_LINEAR, number of nonlinear states (A = [Fn An; 0 Al], B = [Bn; Bl], C = [Gn Cl])
+    int32_t rb_zeroC, rb_zeroAn;   // iszero(C), iszero(An)  (reference src/rbpf.jl:175,244)
     double Ts;
     GaussD df, dg, d0;
 };
@@ -167,6 +178,8 @@ struct StepArgs {
     int32_t accumulate;    // 1: this weighting kernel also computes the exp-sums / quanta / tile sums of its weights (one launch
                            //    per timestep); 0: a k_norm launch in bound form does (better when the chip is saturated)
     int32_t aux;           // second half of the AuxiliaryParticleFilter predict! (k_resprop<AUX>): 1 = y1 missing, 2 = y1 present
+    const RBStep* rb_corr; // LLPF_MODEL_RB_LINEAR: [F] parameters of the weighting (correct!) of this launch
+    const RBStep* rb_pred; // LLPF_MODEL_RB_LINEAR: [F] parameters of the propagate (predict!) of this launch
 };
 
 enum { RES_FINALIZE = 1, RES_RESAMPLE = 2 };

@@ -176,6 +176,7 @@ DEV double gauss_logpdf(const GaussD& g, const double* x) {
 // ------------------------------------------------------------------------------------------------
 template <int NX, int NY>
 struct LinGauss {   // f = A x .+ B u ; g = C x   (reference examples/example_lineargaussian.jl:28-29)
+    static constexpr bool RB = false;
     const ModelD* md;
     double bu[NX];
     bool has_u;
@@ -213,8 +214,140 @@ struct LinGauss {   // f = A x .+ B u ; g = C x   (reference examples/example_li
     }
 };
 
+// Rao-Blackwellized filter with constant matrices (reference src/rbpf.jl:163-283): the particle is [xn; xl], the
+// covariance of xl is shared by all particles and advanced on the host (csrc/shared/llpf_rbkf.h).  A = [Fn An; 0 Al],
+// B = [Bn; Bl], C = [Gn Cl] (row stride NX / nu / NX).  Operation order identical to oracle/llpf_oracle.c:rb_*.
+template <int NX, int NY>
+struct RBLin {
+    static constexpr bool RB = true;
+    const ModelD* md;
+    const double* u;
+    int nn, nl, nu;
+    DEV void prepare(const ModelD* m, const double* __restrict__ uu, double /*t*/) {
+        md = m; u = uu; nn = m->nxn; nl = NX - m->nxn; nu = (uu != nullptr) ? m->nu : 0;
+    }
+    // the propagation of predict! (:185-224): xs = [fi + z ; Al xl + Bl u + L (z - An xl)]
+    DEV void rb_propagate(const double* xp, uint32_t idx, uint32_t step, uint32_t k0, uint32_t k1, const RBStep* rp, double* xs) const {
+        double xi[NX], nz[NX], fi[NX], xl1[NX];
+        llpf_normals(idx, step, LLPF_STREAM_DYNAMICS, k0, k1, nn, xi);
+        const GaussD& g = md->df;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            if (i < nn) {                                  // rand(pf.rng, pf.R1n) = mu + L xi
+                double v;
+                if (g.kind == LLPF_COV_SCAL) v = g.sqrtscal * xi[i];
+                else if (g.kind == LLPF_COV_DIAG) v = g.sqrtdiag[i] * xi[i];
+                else {
+                    v = g.L[i * MAXD + 0] * xi[0];
+#pragma unroll
+                    for (int j = 1; j < NX; ++j) if (j <= i) v = v + g.L[i * MAXD + j] * xi[j];
+                }
+                nz[i] = v + g.mu[i];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < NX; ++r) {
+            if (r < nn) {                                  // fi = Fn xn + Bn u
+                double a = md->A[r * NX] * xp[0];
+#pragma unroll
+                for (int c = 1; c < NX; ++c) if (c < nn) a = a + md->A[r * NX + c] * xp[c];
+                if (nu > 0) {
+                    double b2 = md->B[r * nu] * u[0];
+                    for (int c = 1; c < nu; ++c) b2 = b2 + md->B[r * nu + c] * u[c];
+                    a = a + b2;
+                }
+                fi[r] = a;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < NX; ++r) {
+            if (r < nl) {                                  // Al xl + Bl u
+                double a = md->A[(nn + r) * NX + nn] * xp[nn];
+#pragma unroll
+                for (int c = 1; c < NX; ++c) if (c < nl) a = a + md->A[(nn + r) * NX + nn + c] * xp[nn + c];
+                if (nu > 0) {
+                    double b2 = md->B[(nn + r) * nu] * u[0];
+                    for (int c = 1; c < nu; ++c) b2 = b2 + md->B[(nn + r) * nu + c] * u[c];
+                    a = a + b2;
+                }
+                xl1[r] = a;
+            }
+        }
+        if (md->rb_zeroAn) {
+#pragma unroll
+            for (int r = 0; r < NX; ++r) {
+                if (r < nn) xs[r] = fi[r] + nz[r];
+                else xs[r] = xl1[r - nn];
+            }
+        } else {
+            double Axl[NX], z[NX];
+#pragma unroll
+            for (int r = 0; r < NX; ++r) {
+                if (r < nn) {
+                    double a = md->A[r * NX + nn] * xp[nn];
+#pragma unroll
+                    for (int c = 1; c < NX; ++c) if (c < nl) a = a + md->A[r * NX + nn + c] * xp[nn + c];
+                    Axl[r] = a;
+                    z[r] = a + nz[r];
+                    xs[r] = fi[r] + z[r];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < NX; ++r) {
+                if (r < nl) {
+                    double a = rp->L[r * nn] * (z[0] - Axl[0]);
+#pragma unroll
+                    for (int c = 1; c < NX; ++c) if (c < nn) a = a + rp->L[r * nn + c] * (z[c] - Axl[c]);
+                    xs[nn + r] = xl1[r] + a;
+                }
+            }
+        }
+    }
+    // the per-particle part of correct! (:253-280): returns ll and applies the Kalman measurement update to xl
+    DEV double rb_weight(double* xs, const double* y, const RBStep* rc, bool first) const {
+        double yn[NY], yl[NY], e[NY];
+#pragma unroll
+        for (int r = 0; r < NY; ++r) {
+            double a = md->C[r * NX] * xs[0];
+#pragma unroll
+            for (int c = 1; c < NX; ++c) if (c < nn) a = a + md->C[r * NX + c] * xs[c];
+            yn[r] = a;
+            double b2 = md->C[r * NX + nn] * xs[nn];
+#pragma unroll
+            for (int c = 1; c < NX; ++c) if (c < nl) b2 = b2 + md->C[r * NX + nn + c] * xs[nn + c];
+            yl[r] = b2;
+        }
+        double ll;
+        if (!md->rb_zeroC) {
+#pragma unroll
+            for (int r = 0; r < NY; ++r) e[r] = first ? (y[r] - yn[r]) - yl[r] : y[r] - (yn[r] + yl[r]);
+            ll = gauss_logpdf<NY>(rc->dS, e);
+#pragma unroll
+            for (int r = 0; r < NX; ++r) {
+                if (r < nl) {
+                    double a = rc->K[r * NY] * e[0];
+#pragma unroll
+                    for (int c = 1; c < NY; ++c) a = a + rc->K[r * NY + c] * e[c];
+                    xs[nn + r] = xs[nn + r] + a;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < NY; ++r) e[r] = y[r] - (yn[r] + yl[r]);
+            ll = gauss_logpdf<NY>(md->dg, e);
+#pragma unroll
+            for (int r = 0; r < NX; ++r) if (r < nl) xs[nn + r] = rc->kfx[r];
+        }
+        return ll;
+    }
+    // unused generic hooks
+    DEV void dynamics(const double* x, double* out) const { for (int d = 0; d < NX; ++d) out[d] = x[d]; }
+    DEV void measurement(const double*, double*) const {}
+};
+
 template <int NX, int NY>
 struct QuadTank {   // reference examples/example_quadtank.jl:8-35 with rk4 of src/utils.jl:220-237
+    static constexpr bool RB = false;
     static_assert(NX == 4 && NY == 2, "quad-tank is 4 states / 2 outputs");
     // coefficients in the reference's evaluation order: (-a/A), (a/A), (gamma k / A)
     double c1a, c1a_sw, c1b, c1u, c2a, c2b, c2u, c3a, c3u, c4a, c4u;
@@ -468,7 +601,9 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
     for (int d = 0; d < NX; ++d) xm[d] = 0.0;
     if (MODE != MODE_PROP) {
         const double wmx = do_res ? b.log1N : (uniform ? wconst : sc->wmax);
-        off = a.has_y ? wmx + md->dg.c0 : wmx;
+        double c0w = md->dg.c0;
+        if constexpr (Model::RB) { if (!md->rb_zeroC) c0w = (a.rb_corr + f)->dS.c0; }   // peak of N(0, S) of this correct!
+        off = a.has_y ? wmx + c0w : wmx;
         wacc.init();
     }
 #pragma unroll 1
@@ -494,6 +629,10 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
             }
 #pragma unroll
             for (int p = 0; p < STEP_PPT; ++p) {
+                if constexpr (Model::RB) {
+                    model.rb_propagate(xp[p], (uint32_t)(i0 + p), a.step, k0, k1, a.rb_pred + f, xs[p]);
+                    continue;
+                }
                 double fx[NX], xi[NX], nz[NX];
                 model.dynamics(xp[p], fx);
                 if (MODE == MODE_AUX) {            // propagate_particles!(pf, u, p, t, nothing): no noise
@@ -506,12 +645,14 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
                     for (int d = 0; d < NX; ++d) xs[p][d] = fx[d] + nz[d];
                 }
             }
+            if (!(Model::RB && MODE == MODE_PROP_WEIGHT && a.has_y)) {
 #pragma unroll
-            for (int d = 0; d < NX; ++d) {
-                double2 v;
-                v.x = xs[0][d];
-                v.y = xs[1][d];
-                *reinterpret_cast<double2*>(xn + (size_t)d * Ns + i0) = v;
+                for (int d = 0; d < NX; ++d) {
+                    double2 v;
+                    v.x = xs[0][d];
+                    v.y = xs[1][d];
+                    *reinterpret_cast<double2*>(xn + (size_t)d * Ns + i0) = v;
+                }
             }
         } else {
 #pragma unroll
@@ -551,11 +692,15 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
                     lamv[p] = lam;
                     wv = wv + lam;
                 } else if (a.has_y) {
-                    double g[NY], v[NY];
-                    model.measurement(xs[p], g);
+                    if constexpr (Model::RB) {
+                        wv = wv + model.rb_weight(xs[p], y, a.rb_corr + f, i0 + p == 0);
+                    } else {
+                        double g[NY], v[NY];
+                        model.measurement(xs[p], g);
 #pragma unroll
-                    for (int k = 0; k < NY; ++k) v[k] = y[k] - g[k];
-                    wv = wv + gauss_logpdf<NY>(md->dg, v);
+                        for (int k = 0; k < NY; ++k) v[k] = y[k] - g[k];
+                        wv = wv + gauss_logpdf<NY>(md->dg, v);
+                    }
                 }
                 if (i0 + p >= N) wv = -LLPF_INF;   // padding lanes carry zero weight
                 wn[p] = wv;
@@ -566,6 +711,18 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
             wo.x = wn[0];
             wo.y = wn[1];
             *reinterpret_cast<double2*>(w + i0) = wo;
+            if constexpr (Model::RB) {             // correct! has updated xl (Kalman measurement update)
+                if (a.has_y) {
+                    double* xdst = (MODE == MODE_WEIGHT) ? const_cast<double*>(xc) : xn;
+#pragma unroll
+                    for (int d = 0; d < NX; ++d) {
+                        double2 v;
+                        v.x = xs[0][d];
+                        v.y = xs[1][d];
+                        *reinterpret_cast<double2*>(xdst + (size_t)d * Ns + i0) = v;
+                    }
+                }
+            }
             if (MODE == MODE_AUX) {
                 double2 lo;
                 lo.x = lamv[0];
@@ -1361,6 +1518,7 @@ template <class T> DEV void st_off(T* base, uint32_t byte_off, T v) {
 // placeholder model of the AuxiliaryParticleFilter's second half: the dynamics were applied by k_step<MODE_AUX>
 template <int NX>
 struct NoModel {
+    static constexpr bool RB = false;
     DEV void prepare(const ModelD*, const double*, double) {}
     DEV void dynamics(const double* x, double* out) const {
 #pragma unroll
@@ -1846,6 +2004,7 @@ static inline dim3 grid1(int64_t n, int F) { return dim3((unsigned)((n + BLOCK -
 
 bool step_supported(int model_id, int nx, int ny) {
     if (model_id == LLPF_MODEL_QUADTANK_RK4) return nx == 4 && ny == 2;
+    if (model_id == LLPF_MODEL_RB_LINEAR) return nx >= 2 && nx <= 4 && ny >= 1 && ny <= 4;
     if (model_id == LLPF_MODEL_LINEAR_GAUSSIAN) return nx >= 1 && nx <= 4 && ny >= 1 && ny <= 4;
     return false;
 }
@@ -1886,9 +2045,29 @@ static hipError_t launch_step_lg_ny(const BankDev& b, int mode, const StepArgs& 
     }
 }
 
+template <int NX>
+static hipError_t launch_step_rb_ny(const BankDev& b, int mode, const StepArgs& a, hipStream_t s) {
+    if (mode == MODE_AUX) return hipErrorInvalidValue;
+    switch (b.ny) {
+        case 1: return launch_step_t<RBLin<NX, 1>, NX, 1>(b, mode, a, s);
+        case 2: return launch_step_t<RBLin<NX, 2>, NX, 2>(b, mode, a, s);
+        case 3: return launch_step_t<RBLin<NX, 3>, NX, 3>(b, mode, a, s);
+        case 4: return launch_step_t<RBLin<NX, 4>, NX, 4>(b, mode, a, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
 hipError_t launch_step(const BankDev& b, int mode, const StepArgs& a, hipStream_t s) {
     const int model_id = b.model_id;
     if (model_id == LLPF_MODEL_QUADTANK_RK4) return launch_step_t<QuadTank<4, 2>, 4, 2>(b, mode, a, s);
+    if (model_id == LLPF_MODEL_RB_LINEAR) {
+        switch (b.nx) {
+            case 2: return launch_step_rb_ny<2>(b, mode, a, s);
+            case 3: return launch_step_rb_ny<3>(b, mode, a, s);
+            case 4: return launch_step_rb_ny<4>(b, mode, a, s);
+            default: return hipErrorInvalidValue;
+        }
+    }
     switch (b.nx) {
         case 1: return launch_step_lg_ny<1>(b, mode, a, s);
         case 2: return launch_step_lg_ny<2>(b, mode, a, s);

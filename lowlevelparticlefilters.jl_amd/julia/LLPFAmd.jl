@@ -27,9 +27,10 @@ struct CModel
     model_id::Int32; nx::Int32; nu::Int32; ny::Int32
     A::NTuple{64,Float64}; B::NTuple{64,Float64}; C::NTuple{64,Float64}
     qt::NTuple{16,Float64}
-    supersample::Int32; reserved::Int32
+    supersample::Int32; nxn::Int32
     Ts::Float64
     df::CGaussian; dg::CGaussian; d0::CGaussian
+    linear_noise::CGaussian; linear_initial::CGaussian      # LLPF_MODEL_RB_LINEAR only (zeroed otherwise)
 end
 struct CConfig
     struct_size::UInt32; filter_kind::Int32

@@ -18,6 +18,7 @@
 #include "../lowlevelparticlefilters.jl_amd/csrc/shared/llpf_philox.h"
 
 #define MAXD LLPF_MAX_DIM
+#include "../lowlevelparticlefilters.jl_amd/csrc/shared/llpf_rbkf.h"
 
 /* Optional OpenMP over the per-particle loops (weighting, propagation, noise, elementwise exp): an upper bound for
  * what the reference could reach with its `threads=true` option (src/PFtypes.jl:226-259 @threads :static); the
@@ -573,6 +574,15 @@ struct orc_filter {
     devnorm dn;
     int dn_valid;
     double wmax;                /* max of the current (normalised / uniform / installed) log-weights: the bound's input */
+    /* RBPF with constant matrices (src/rbpf.jl) */
+    struct {
+        int on, nn, nl, zeroC, zeroAn;
+        double Fn[16], Bn[16], An[16], Al[16], Bl[16], Gn[16], Cl[16], R1l[16], R1nS[16], R2S[16];
+        double R[16];                 /* the covariance shared by all particles (x[1].R, "singleR") */
+        double kfx[4], kfR[16];       /* fields x, R of the inner KalmanFilter object: never reset, reused as they are when C == 0 (:276) */
+        gaussd dS;                    /* N(0, S) of the last measurement update */
+        double K[16], L[16];
+    } rb;
     /* AuxiliaryParticleFilter (src/filtering.jl:170-217) */
     double* lam;                /* lambda of the last aux predict! (the reference keeps it in `we`) */
     int aux_pending;            /* w holds lambda - log N of an aux predict!, not yet normalised */
@@ -607,6 +617,162 @@ static void gen_normals(orc_filter* f, uint32_t step, uint32_t stream, double* o
         llpf_normals((uint32_t)i, step, stream, f->k0, f->k1, f->nx, out + i * f->nx);
 }
 
+/* ------------------------------------------------------------------------------------------
+ * RBPF with constant matrices — src/rbpf.jl:63-283 (IPD = IPM = AUGD = false; A, An, C, R1 plain matrices, so the
+ * "singleR" branches :176,:247 apply: one covariance recursion for all particles).
+ * ---------------------------------------------------------------------------------------- */
+static double rb_sqrt(double x) { return sqrt(x); }
+static void gauss_cov_full(const llpf_gaussian* g, double* S);
+
+static int rb_setup(orc_filter* f, int order) {
+    const llpf_model* m = &f->cfg.model;
+    const int nx = m->nx, nn = m->nxn, nl = nx - nn, nu = m->nu, ny = m->ny;
+    if (nn < 1 || nl < 1 || nx > LLPF_RB_MAX || ny > LLPF_RB_MAX) return -1;
+    f->rb.on = 1; f->rb.nn = nn; f->rb.nl = nl;
+    for (int r = 0; r < nn; ++r) {
+        for (int c = 0; c < nn; ++c) f->rb.Fn[r * nn + c] = m->A[r * nx + c];
+        for (int c = 0; c < nl; ++c) f->rb.An[r * nl + c] = m->A[r * nx + nn + c];
+        for (int c = 0; c < nu; ++c) f->rb.Bn[r * nu + c] = m->B[r * nu + c];
+    }
+    for (int r = 0; r < nl; ++r) {
+        for (int c = 0; c < nl; ++c) f->rb.Al[r * nl + c] = m->A[(nn + r) * nx + nn + c];
+        for (int c = 0; c < nu; ++c) f->rb.Bl[r * nu + c] = m->B[(nn + r) * nu + c];
+    }
+    for (int r = 0; r < ny; ++r) {
+        for (int c = 0; c < nn; ++c) f->rb.Gn[r * nn + c] = m->C[r * nx + c];
+        for (int c = 0; c < nl; ++c) f->rb.Cl[r * nl + c] = m->C[r * nx + nn + c];
+    }
+    f->rb.zeroAn = 1; for (int i = 0; i < nn * nl; ++i) if (f->rb.An[i] != 0.0) f->rb.zeroAn = 0;   /* iszero(An), :175 */
+    f->rb.zeroC = 1;  for (int i = 0; i < ny * nl; ++i) if (f->rb.Cl[i] != 0.0) f->rb.zeroC = 0;    /* iszero(C), :244 */
+    double tmp[64];
+    gauss_cov_full(&m->linear_noise, tmp);       for (int i = 0; i < nl * nl; ++i) f->rb.R1l[i] = tmp[i];
+    gauss_cov_full(&m->dynamics_density, tmp);   for (int i = 0; i < nn * nn; ++i) f->rb.R1nS[i] = tmp[i];
+    gauss_cov_full(&m->measurement_density, tmp);for (int i = 0; i < ny * ny; ++i) f->rb.R2S[i] = tmp[i];
+    gauss_cov_full(&m->linear_initial, tmp);
+    for (int i = 0; i < nl * nl; ++i) { f->rb.R[i] = tmp[i]; f->rb.kfR[i] = tmp[i]; }                /* kf.R = d0.Sigma */
+    for (int i = 0; i < nl; ++i) f->rb.kfx[i] = m->linear_initial.mu[i];                             /* kf.x = d0.mu    */
+    /* the density reset! draws from: xn ~ d0n, xl = d0l.mu exactly (:146-158): [mu_n; mu_l] + blockdiag(L_n, 0) xi */
+    gaussd d0n = f->d0;
+    memset(&f->d0, 0, sizeof(f->d0));
+    f->d0.dim = nx; f->d0.kind = LLPF_COV_FULL; f->d0.dev = (order == ORC_ORDER_DEVICE);
+    for (int i = 0; i < nn; ++i) {
+        f->d0.mu[i] = d0n.mu[i];
+        for (int j = 0; j <= i; ++j)
+            f->d0.L[i * MAXD + j] = (d0n.kind == LLPF_COV_FULL) ? d0n.L[i * MAXD + j] : (i == j ? d0n.L[i * MAXD + i] : 0.0);
+    }
+    for (int i = 0; i < nl; ++i) f->d0.mu[nn + i] = m->linear_initial.mu[i];
+    return 0;
+}
+
+/* correct!(pf::RBPF, u, y, p, t) — src/rbpf.jl:235-283 (weights only; logsumexp! by the caller) */
+static void rb_correct(orc_filter* f, const double* y) {
+    const int nn = f->rb.nn, nl = f->rb.nl, nx = f->nx, ny = f->ny;
+    const int dev = f->order == ORC_ORDER_DEVICE;
+    double Rpost[16];
+    if (!f->rb.zeroC) {
+        /* i == 1: kf.x = x[1].xl; kf.R = x[1].R; correct!(kf, u, y - yn, p, t) — S, K and the new R serve every particle */
+        double S[16];
+        llpf_rb_gain(nl, ny, f->rb.R, f->rb.Cl, f->rb.R2S, S, f->rb.K, Rpost, dev ? llpf_sqrt : rb_sqrt);
+        llpf_gaussian gs;
+        memset(&gs, 0, sizeof(gs));
+        gs.dim = ny; gs.kind = LLPF_COV_FULL;
+        for (int i = 0; i < ny * ny; ++i) gs.cov[i] = S[i];
+        gauss_prepare(&gs, &f->rb.dS, f->order);               /* SimpleMvNormal(PDMat(S, S_chol)) */
+    }
+    ORC_PAR
+    for (int64_t i = 0; i < f->N; ++i) {
+        double* x = f->x + i * nx;
+        double yn[4], yl[4], e[4];
+        for (int r = 0; r < ny; ++r) {                         /* yn = g(xn), yl = C xl, :254-255 */
+            double a = f->rb.Gn[r * nn] * x[0];
+            for (int c = 1; c < nn; ++c) a = a + f->rb.Gn[r * nn + c] * x[c];
+            yn[r] = a;
+            double b2 = f->rb.Cl[r * nl] * x[nn];
+            for (int c = 1; c < nl; ++c) b2 = b2 + f->rb.Cl[r * nl + c] * x[nn + c];
+            yl[r] = b2;
+        }
+        if (!f->rb.zeroC) {
+            /* particle 1 goes through correct!(kf, u, y - yn): e = (y - yn) - C x (filtering.jl:102); the others
+             * e = y - yh with yh = yn + yl (:266) */
+            for (int r = 0; r < ny; ++r) e[r] = (i == 0) ? (y[r] - yn[r]) - yl[r] : y[r] - (yn[r] + yl[r]);
+            f->w[i] += gauss_logpdf(&f->rb.dS, e);             /* w[i] += ll, :272 */
+            for (int r = 0; r < nl; ++r) {                     /* kf.x = xl + K e, :267 / filtering.jl:122 */
+                double a = f->rb.K[r * ny] * e[0];
+                for (int c = 1; c < ny; ++c) a = a + f->rb.K[r * ny + c] * e[c];
+                x[nn + r] = x[nn + r] + a;
+            }
+        } else {
+            for (int r = 0; r < ny; ++r) e[r] = y[r] - (yn[r] + yl[r]);
+            f->w[i] += gauss_logpdf(&f->dg, e);                /* extended_logpdf(R2, y - yh), :275-276 */
+            for (int r = 0; r < nl; ++r) x[nn + r] = f->rb.kfx[r];   /* x[i] = RBParticle(xn, kf.x, kf.R), :279: kf untouched */
+        }
+    }
+    if (!f->rb.zeroC) {
+        for (int i = 0; i < nl * nl; ++i) { f->rb.R[i] = Rpost[i]; f->rb.kfR[i] = Rpost[i]; }
+        for (int r = 0; r < nl; ++r) f->rb.kfx[r] = f->x[(f->N - 1) * nx + nn + r];   /* the object keeps the last particle's mean */
+    } else {
+        for (int i = 0; i < nl * nl; ++i) f->rb.R[i] = f->rb.kfR[i];
+    }
+    memcpy(f->xprev, f->x, sizeof(double) * (size_t)f->N * nx);   /* copyto!(s.xprev, s.x), :282 */
+}
+
+/* the propagation loop of predict!(pf::RBPF, ...) — src/rbpf.jl:180-224; xi: N x nx normals of which the first nn of
+ * every row are used */
+static void rb_propagate(orc_filter* f, const double* u, const double* xi, int res) {
+    const int nn = f->rb.nn, nl = f->rb.nl, nx = f->nx, nu = f->nu;
+    double R1[16];
+    llpf_rb_predcov(nl, nn, f->rb.zeroAn, f->rb.R, f->rb.Al, f->rb.An, f->rb.R1l, f->rb.R1nS, f->rb.L, R1);
+    ORC_PAR
+    for (int64_t i = 0; i < f->N; ++i) {
+        const double* xp = f->xprev + (res ? f->j[i] : i) * nx;
+        double fi[4], nz[4], xl1[4];
+        for (int r = 0; r < nn; ++r) {                         /* fi = f(xn, u, p, t) = Fn xn + Bn u */
+            double a = f->rb.Fn[r * nn] * xp[0];
+            for (int c = 1; c < nn; ++c) a = a + f->rb.Fn[r * nn + c] * xp[c];
+            if (nu > 0) {
+                double b2 = f->rb.Bn[r * nu] * u[0];
+                for (int c = 1; c < nu; ++c) b2 = b2 + f->rb.Bn[r * nu + c] * u[c];
+                a = a + b2;
+            }
+            fi[r] = a;
+        }
+        gauss_sample(&f->df, xi + i * nx, nz);                 /* rand(pf.rng, pf.R1n) */
+        for (int r = 0; r < nl; ++r) {                         /* Al*xl + Bl*u */
+            double a = f->rb.Al[r * nl] * xp[nn];
+            for (int c = 1; c < nl; ++c) a = a + f->rb.Al[r * nl + c] * xp[nn + c];
+            if (nu > 0) {
+                double b2 = f->rb.Bl[r * nu] * u[0];
+                for (int c = 1; c < nu; ++c) b2 = b2 + f->rb.Bl[r * nu + c] * u[c];
+                a = a + b2;
+            }
+            xl1[r] = a;
+        }
+        double* xo = f->x + i * nx;
+        if (f->rb.zeroAn) {
+            for (int r = 0; r < nn; ++r) xo[r] = fi[r] + nz[r];                 /* xn1 = fi + rand(R1n), :199 */
+            for (int r = 0; r < nl; ++r) xo[nn + r] = xl1[r];
+        } else {
+            double Axl[4] = {0, 0, 0, 0}, z[4] = {0, 0, 0, 0};
+            for (int r = 0; r < nn; ++r) {                     /* Axl = An xl; z = Axl + rand(R1n); xn1 = fi + z, :216-218 */
+                double a = f->rb.An[r * nl] * xp[nn];
+                for (int c = 1; c < nl; ++c) a = a + f->rb.An[r * nl + c] * xp[nn + c];
+                Axl[r] = a;
+                z[r] = a + nz[r];
+                xo[r] = fi[r] + z[r];
+            }
+            for (int r = 0; r < nl; ++r) {                     /* xl1 = Al xl + Bl u + L (z - Axl), :220 */
+                double a = f->rb.L[r * nn] * (z[0] - Axl[0]);
+                for (int c = 1; c < nn; ++c) a = a + f->rb.L[r * nn + c] * (z[c] - Axl[c]);
+                xo[nn + r] = xl1[r] + a;
+            }
+        }
+    }
+    for (int i = 0; i < nl * nl; ++i) f->rb.R[i] = R1[i];
+}
+
+/* shared covariance of the linear substate (x[1].R) */
+void orc_rb_get_R(const orc_filter* f, double* R) { for (int i = 0; i < f->rb.nl * f->rb.nl; ++i) R[i] = f->rb.R[i]; }
+
 orc_filter* orc_create(const llpf_config* cfg, int order) {
     orc_filter* f = (orc_filter*)calloc(1, sizeof(orc_filter));
     f->cfg = *cfg;
@@ -616,6 +782,7 @@ orc_filter* orc_create(const llpf_config* cfg, int order) {
     if (gauss_prepare(&cfg->model.dynamics_density, &f->df, order) ||
         gauss_prepare(&cfg->model.measurement_density, &f->dg, order) ||
         gauss_prepare(&cfg->model.initial_density, &f->d0, order)) { free(f); return NULL; }
+    if (cfg->model.model_id == LLPF_MODEL_RB_LINEAR && rb_setup(f, order)) { free(f); return NULL; }
     size_t N = (size_t)f->N;
     f->x = (double*)calloc(N * f->nx, 8); f->xprev = (double*)calloc(N * f->nx, 8);
     f->w = (double*)calloc(N, 8); f->we = (double*)calloc(N, 8);
@@ -685,6 +852,11 @@ static double filter_logsumexp(orc_filter* f, double off, int bound) {
 double orc_correct(orc_filter* f, const double* u, const double* y, double t) {
     const int has_y = (y != NULL && y[0] == y[0]);
     const double off = has_y ? f->wmax + f->dg.c0 : f->wmax;   /* device order: upper bound of the new weights */
+    if (f->rb.on && has_y) {
+        rb_correct(f, y);
+        f->aux_pending = 0;
+        return filter_logsumexp(f, f->wmax + (f->rb.zeroC ? f->dg.c0 : f->rb.dS.c0), 1);
+    }
     if (has_y) {                                               /* any(ismissing, y) && return w */
         ORC_PAR
         for (int64_t i = 0; i < f->N; ++i) {
@@ -759,6 +931,24 @@ void orc_predict_explicit(orc_filter* f, const double* u, double t, const double
     int64_t N = f->N;
     int nx = f->nx;
     int res = orc_shouldresample(f);
+    if (f->rb.on) {                                           /* predict!(pf::RBPF, ...) — src/rbpf.jl:163-232 */
+        if (res) {
+            if (f->order == ORC_ORDER_DEVICE && f->dn_valid) filter_resample_dev(f, U);
+            else orc_resample(f->cfg.resampling_strategy, f->we, N, N, U, f->j, f->bins, f->order);
+        } else {
+            for (int64_t i = 0; i < N; ++i) f->j[i] = i;
+        }
+        rb_propagate(f, u, xi, res);
+        if (res) {
+            fill_uniform_weights(f, f->order == ORC_ORDER_DEVICE ? llpf_log(1.0 / (double)N) : log(1.0 / (double)N));
+            f->maxw = 0.0;
+            f->resample_count++;
+        }
+        memcpy(f->xprev, f->x, sizeof(double) * (size_t)N * nx);
+        f->t += 1;
+        f->last_resampled = res;
+        return;
+    }
     if (res) {
         /* j = resample(pf) — src/resample.jl:12 */
         if (f->order == ORC_ORDER_DEVICE && f->dn_valid) filter_resample_dev(f, U);

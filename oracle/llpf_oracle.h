@@ -66,6 +66,9 @@ int64_t orc_draw_one_categorical(double* w, double* bins, int64_t n, double u, i
 int    orc_smooth(orc_filter* f, int64_t M, const double* U, int64_t T, const double* xf, const double* wf,
                   const double* wef, double* xb, int64_t* idx);
 
+/* RBPF (model_id LLPF_MODEL_RB_LINEAR): the covariance shared by all particles, nxl x nxl row-major */
+void   orc_rb_get_R(const orc_filter* f, double* R);
+
 int64_t orc_num_particles(const orc_filter* f);
 int64_t orc_index(const orc_filter* f);
 void   orc_get_particles(const orc_filter* f, double* dst);

@@ -48,6 +48,7 @@ def load():
     lib.orc_draw_one_categorical.restype = C.c_int64
     lib.orc_draw_one_categorical.argtypes = [_dp, _dp, C.c_int64, C.c_double, C.c_int]
     lib.orc_smooth.argtypes = [C.c_void_p, C.c_int64, _dp, C.c_int64, _dp, _dp, _dp, _dp, _ip]
+    lib.orc_rb_get_R.argtypes = [C.c_void_p, _dp]
     lib.orc_num_particles.restype = C.c_int64
     lib.orc_num_particles.argtypes = [C.c_void_p]
     lib.orc_index.restype = C.c_int64
@@ -226,6 +227,12 @@ class OracleFilter:
         if rc != 0:
             raise ValueError("orc_smooth failed (%d)" % rc)
         return xb, idx
+
+    def rb_R(self):
+        nl = self.nx - self.cfg.model.nxn
+        a = np.zeros((nl, nl))
+        self.L.orc_rb_get_R(self.h, dptr(a))
+        return a
 
     def particles(self):
         a = np.empty((self.N, self.nx))

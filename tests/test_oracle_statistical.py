@@ -205,3 +205,61 @@ def test_particle_smoother_and_draw_one_categorical():
         assert np.array_equal(xb, r["x"][np.arange(200)[:, None], idx])
         res.append(idx)
     assert np.mean(res[0] != res[1]) < 0.01
+
+
+def _rb_cases():
+    g = S.make_gaussian
+    A = np.array([[1, 0.1], [0, 1.0]]); B = np.array([[0.0], [1.0]]); Cm = np.array([[1.0, 0.0]])
+    Ts = 0.1
+    R1 = np.array([[Ts ** 4 / 4, Ts ** 3 / 2], [Ts ** 3 / 2, Ts ** 2]]) + 1e-6 * np.eye(2)
+    R2 = np.array([[10.0]])
+    rng = np.random.default_rng(0)
+    x0 = rng.standard_normal(2)
+    T = 500
+    U = rng.standard_normal((T, 1)); Y = np.zeros((T, 1)); x = x0 + np.sqrt(2) * rng.standard_normal(2)
+    L1 = np.linalg.cholesky(R1)
+    for t in range(T):
+        Y[t] = Cm @ x + np.sqrt(10) * rng.standard_normal(1)
+        x = A @ x + B @ U[t] + L1 @ rng.standard_normal(2)
+    kfm = S.make_lg_model(A, B, Cm, g(np.zeros(2), R1), g(np.zeros(1), R2), g(x0, 2 * np.eye(2)))
+    lin = S.make_rb_model([[1.0]], np.zeros((1, 1)), None, A, B, np.zeros((1, 1)), Cm, g(np.zeros(1), np.array([[1e-12]])), R1,
+                          g(np.zeros(1), R2), g(np.zeros(1), np.array([[1e-12]])), g(x0, 2 * np.eye(2)))
+    nonl = S.make_rb_model(A, B, None, [[0.0]], np.zeros((1, 1)), Cm, None, g(np.zeros(2), R1), [[1.0]], g(np.zeros(1), R2),
+                           g(x0, 2 * np.eye(2)), g(np.zeros(1), np.array([[1.0]])))
+    return kfm, U, Y, lin, nonl
+
+
+def test_rbpf_matches_kalman_filter():
+    """test/test_rbpf.jl:87-139: an RBPF whose whole state is linear reproduces the Kalman filter's log-likelihood
+    (here to rounding: every particle carries the same Kalman filter), and one whose whole state is nonlinear matches
+    it to rtol 1e-2; a mixed 1 + 1 system with An = 0.5 (:5-31) against the Kalman filter of the joint system."""
+    kfm, U, Y, lin, nonl = _rb_cases()
+    llkf = ob.kalman_loglik(kfm, U, Y)
+    for order in (ob.ORDER_REFERENCE, ob.ORDER_DEVICE):
+        o = ob.OracleFilter(S.make_config(lin, 500, S.PARTICLE_FILTER, S.RESAMPLE_SYSTEMATIC, 0.1, 3, 0), order)
+        o.reset()
+        assert abs(o.run(U, Y, 0.0)["ll"] - llkf) < 1e-8 * abs(llkf)
+        o = ob.OracleFilter(S.make_config(nonl, 500, S.PARTICLE_FILTER, S.RESAMPLE_SYSTEMATIC, 0.1, 3, 0), order)
+        o.reset()
+        assert abs(o.run(U, Y, 0.0)["ll"] - llkf) < 1e-2 * abs(llkf)
+    g = S.make_gaussian
+    mixed = S.make_rb_model([[1.0]], np.zeros((1, 0)), [[0.5]], [[0.95]], np.zeros((1, 0)), [[1.0]], [[1.0]], g(np.zeros(1), np.array([[0.01]])),
+                            [[0.01]], g(np.zeros(1), np.array([[0.1]])), g(np.array([1.0]), np.array([[0.01]])), g(np.array([1.0]), np.array([[1.0]])))
+    rng = np.random.default_rng(1)
+    xn, xl, T = 1.0, 1.0, 2000
+    Y1 = np.zeros((T, 1))
+    for t in range(T):
+        Y1[t] = xn + xl + np.sqrt(0.1) * rng.standard_normal()
+        xn, xl = xn + 0.5 * xl + 0.1 * rng.standard_normal(), 0.95 * xl + 0.1 * rng.standard_normal()
+    joint = S.make_lg_model(np.array([[1, 0.5], [0, 0.95]]), np.zeros((2, 0)), np.array([[1.0, 1.0]]), g(np.zeros(2), np.diag([0.01, 0.01])),
+                            g(np.zeros(1), np.array([[0.1]])), g(np.array([1.0, 1.0]), np.diag([0.01, 1.0])))
+    llj = ob.kalman_loglik(joint, np.zeros((T, 0)), Y1)
+    lls = []
+    for order in (ob.ORDER_REFERENCE, ob.ORDER_DEVICE):
+        o = ob.OracleFilter(S.make_config(mixed, 500, S.PARTICLE_FILTER, S.RESAMPLE_SYSTEMATIC, 0.1, 3, 0), order)
+        o.reset()
+        r = o.run(np.zeros((T, 0)), Y1, 0.0, ll_steps=True)
+        assert abs(r["ll"] - llj) < 1e-2 * abs(llj)
+        lls.append(r["ll_steps"])
+        assert o.rb_R().shape == (1, 1) and 0 < o.rb_R()[0, 0] < 1
+    assert np.max(np.abs(lls[0] - lls[1])) < 1e-10
