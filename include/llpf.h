@@ -165,7 +165,8 @@ int  llpf_run(llpf_filter* f, const double* U, const double* Y, int64_t T, doubl
  *   llpf_aux_update   update!(pf::AuxiliaryParticleFilter,u,y,y1,p,t)    src/filtering.jl:187-191
  *   llpf_aux_run      mode 0: forward_trajectory(pf::AuxiliaryParticleFilter,u,y,p)  src/filtering.jl:367-384
  *                     mode 1: loglik(pf::AuxiliaryParticleFilter,u,y,p)              src/smoothing.jl:232-236
- *                     (call llpf_reset first; t_k = k * Ts; one host round trip per timestep)
+ *                     (call llpf_reset first; t_k = k * Ts; all launches are enqueued back to back unless history
+ *                     outputs are requested)
  * The AuxiliaryParticleFilter{AdvancedParticleFilter} variant (filtering.jl:219-234) is not provided. */
 int  llpf_aux_correct(llpf_filter* f, double* ll);
 int  llpf_aux_predict(llpf_filter* f, const double* u, const double* y1, double t);
