@@ -1,0 +1,286 @@
+// host/bank.hpp — the Bank (F filters on one device / stream), creation, initialisation, profiling helpers.  Part of capi.hip (one translation unit).
+// ------------------------------------------------------------------------------------------------
+// Bank: F independent filters of N particles on one device / one stream
+// ------------------------------------------------------------------------------------------------
+struct Bank {
+    llpf_config cfg{};
+    int F = 0;
+    int64_t N = 0, Ns = 0;
+    int nx = 0, nu = 0, ny = 0, P1 = 0, P2 = 0;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    ModelD* d_models = nullptr;
+    FilterScal* d_scal = nullptr;
+    double* d_x[2] = {nullptr, nullptr};
+    int cur = 0;
+    double* d_w = nullptr;
+    int32_t* d_anc = nullptr;
+    uint64_t* d_acc = nullptr;
+    uint64_t* d_quanta[2] = {nullptr, nullptr};
+    int qcur = 0;                    // quanta buffer that holds the quanta of the current weights
+    uint64_t* d_tileq = nullptr;
+    uint32_t* d_flag = nullptr;
+    double* d_xmpart = nullptr;
+    // Rao-Blackwellized model: host side of the shared covariance recursion (csrc/shared/llpf_rbkf.h)
+    struct RBHost { double R[16], kfx[4], kfR[16]; };
+    std::vector<RBHost> rb;           // per filter: x[1].R and the inner KalmanFilter object's fields
+    std::vector<llpf_model> hmodels;  // the F model descriptors as given at create
+    RBStep* d_rb = nullptr;           // device: parameters of the single-step API ([2][F]) ...
+    RBStep* d_rbseq = nullptr;        // ... and of a run ([2T+1][F]: corr_0, pred_0, corr_1, ...)
+    size_t cap_rbseq = 0;
+    uint64_t* d_rtile = nullptr;      // [F][2][P2] residual resampling: per-tile counts / residual sums and their prefixes
+    double* d_lam = nullptr;          // [F][Ns] lambda of the AuxiliaryParticleFilter predict! (allocated on first use)
+    bool aux_pending = false;         // w holds lambda - log N of an aux predict!; their exp-sums wait in slot (parity+2)%3
+    bool we_is_lambda = false;        // expweights(pf) returns lambda until the next correct! (the reference keeps it in `we`)
+    int parity = 0;                  // accumulator slot (0..2) the NEXT weighting kernel writes (engine.hpp ACC_NSLOT)
+    double* d_uy = nullptr;          // staging for single-step u / y (2 * MAXD)
+    double* d_U = nullptr;           // resident inputs of a run
+    double* d_Y = nullptr;
+    size_t capU = 0, capY = 0;
+    double* d_ll_steps = nullptr;
+    double* d_xmean = nullptr;
+    size_t cap_ll = 0, cap_xm = 0;
+    double* d_tmp = nullptr;         // F*N*max(nx,1) doubles (also reinterpreted as int64 / double staging)
+    uint64_t seed = 0;
+    uint32_t n_reset = 0, n_predict = 0;
+    int64_t t_index = 0;
+    // measurement
+    bool profiling = false;
+    double prof_ms[LLPF_PROF_CLASSES] = {0, 0, 0, 0};
+    int64_t prof_n[LLPF_PROF_CLASSES] = {0, 0, 0, 0};
+    struct Ev { hipEvent_t a, b; int cls; };
+    std::vector<Ev> pending;
+    std::vector<hipEvent_t> ev_pool;
+    hipEvent_t ev_run0 = nullptr, ev_run1 = nullptr;
+    double last_run_ms = 0.0;
+    int64_t run_resamples = 0;
+
+    BankDev dev() const {
+        BankDev b;
+        b.N = N; b.Ns = Ns; b.F = F; b.nx = nx; b.nu = nu; b.ny = ny;
+        b.strategy = cfg.resampling_strategy;
+        b.model_id = cfg.model.model_id;
+        b.P1 = P1; b.P2 = P2;
+        b.thr = cfg.resample_threshold;
+        b.log1N = llpf_log(1.0 / (double)N);
+        b.mlogN = -llpf_log((double)N);
+        b.models = d_models; b.scal = d_scal;
+        b.xcur = d_x[cur]; b.xnext = d_x[cur ^ 1];
+        b.w = d_w; b.anc = d_anc; b.acc = d_acc; b.quanta = d_quanta[qcur]; b.quanta_next = d_quanta[qcur ^ 1]; b.tileq = d_tileq;
+        b.bank_flag = d_flag; b.xmpart = d_xmpart; b.lam = d_lam; b.rtile = d_rtile;
+        b.anc_slot = (int32_t)(n_predict & 1u); b.pad0 = 0;
+        return b;
+    }
+};
+
+struct llpf_filter { Bank bank; };
+struct llpf_bank { Bank bank; };
+
+static int use_device(const Bank& b) {
+    HIPC(hipSetDevice(b.device));
+    return LLPF_OK;
+}
+
+static void free_bank(Bank& b) {
+    hipSetDevice(b.device);
+    if (b.stream) hipStreamSynchronize(b.stream);
+    hipFree(b.d_models); hipFree(b.d_scal); hipFree(b.d_x[0]); hipFree(b.d_x[1]); hipFree(b.d_w);
+    hipFree(b.d_anc); hipFree(b.d_acc); hipFree(b.d_quanta[0]); hipFree(b.d_quanta[1]); hipFree(b.d_tileq); hipFree(b.d_flag); hipFree(b.d_xmpart); hipFree(b.d_lam); hipFree(b.d_rtile); hipFree(b.d_rb); hipFree(b.d_rbseq); hipFree(b.d_uy); hipFree(b.d_U); hipFree(b.d_Y);
+    hipFree(b.d_ll_steps); hipFree(b.d_xmean); hipFree(b.d_tmp);
+    for (auto e : b.ev_pool) hipEventDestroy(e);
+    for (auto& e : b.pending) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+    if (b.ev_run0) hipEventDestroy(b.ev_run0);
+    if (b.ev_run1) hipEventDestroy(b.ev_run1);
+    if (b.stream) hipStreamDestroy(b.stream);
+}
+
+static int scal_download(Bank& b, std::vector<FilterScal>& h) {
+    h.resize(b.F);
+    HIPC(hipMemcpyAsync(h.data(), b.d_scal, sizeof(FilterScal) * b.F, hipMemcpyDeviceToHost, b.stream));
+    HIPC(hipStreamSynchronize(b.stream));
+    return LLPF_OK;
+}
+static int scal_upload(Bank& b, const std::vector<FilterScal>& h) {
+    HIPC(hipMemcpyAsync(b.d_scal, h.data(), sizeof(FilterScal) * b.F, hipMemcpyHostToDevice, b.stream));
+    HIPC(hipStreamSynchronize(b.stream));
+    return LLPF_OK;
+}
+
+static void set_keys(Bank& b, std::vector<FilterScal>& h, uint64_t seed) {
+    b.seed = seed;
+    b.n_reset = 0;
+    for (int f = 0; f < b.F; ++f) {
+        const int32_t cur = h[f].anc_ident_s[b.n_predict & 1u];     // the entry index restarts with the step counter
+        h[f].anc_ident_s[0] = cur; h[f].anc_ident_s[1] = cur;
+    }
+    b.n_predict = 0;
+    for (int f = 0; f < b.F; ++f) {
+        const uint64_t s = seed + (uint64_t)f;
+        h[f].k0 = (uint32_t)s;
+        h[f].k1 = (uint32_t)(s >> 32);
+    }
+}
+
+// profiling helpers ------------------------------------------------------------------------------
+static hipEvent_t get_event(Bank& b) {
+    if (!b.ev_pool.empty()) { hipEvent_t e = b.ev_pool.back(); b.ev_pool.pop_back(); return e; }
+    hipEvent_t e;
+    hipEventCreate(&e);
+    return e;
+}
+struct ProfScope {
+    Bank& b; int cls; hipEvent_t e0 = nullptr;
+    ProfScope(Bank& bb, int c) : b(bb), cls(c) {
+        if (b.profiling) { e0 = get_event(b); hipEventRecord(e0, b.stream); }
+    }
+    ~ProfScope() {
+        if (b.profiling) { hipEvent_t e1 = get_event(b); hipEventRecord(e1, b.stream); b.pending.push_back({e0, e1, cls}); }
+    }
+};
+static void prof_collect(Bank& b) {
+    for (auto& e : b.pending) {
+        float ms = 0.f;
+        hipEventSynchronize(e.b);
+        hipEventElapsedTime(&ms, e.a, e.b);
+        b.prof_ms[e.cls] += ms;
+        b.prof_n[e.cls] += 1;
+        b.ev_pool.push_back(e.a);
+        b.ev_pool.push_back(e.b);
+    }
+    b.pending.clear();
+}
+
+static int bank_init_particles(Bank& b, bool is_reset) {
+    b.aux_pending = false; b.we_is_lambda = false;
+    for (size_t f = 0; f < b.rb.size(); ++f) {              // reset!(pf::RBPF): R = copy(pf.kf.d0.Sigma), src/rbpf.jl:152 (pf.kf itself is not reset)
+        double S0[16];
+        gauss_cov_dense(&b.hmodels[f].linear_initial, S0);
+        const int nl = b.nx - b.cfg.model.nxn;
+        for (int i = 0; i < nl * nl; ++i) b.rb[f].R[i] = S0[i];
+    }
+    // constructor (src/PFtypes.jl:65-75): x ~ d0, w = log(1/N), j = 1:N, t = 0
+    // reset!      (src/filtering.jl:4-14): x ~ d0, w = -log N, we = 1/N, t = 1   (j untouched)
+    std::vector<FilterScal> h;
+    CHK(scal_download(b, h));
+    BankDev d = b.dev();
+    for (int f = 0; f < b.F; ++f) {
+        FilterScal& s = h[f];
+        s.uniform = 1;
+        s.wconst = is_reset ? d.mlogN : d.log1N;
+        s.norm_pending = 0;
+        s.do_resample = 0;
+        s.status = 0;
+        s.m = 0.0; s.s = 0.0; s.l = 0.0; s.inv = 1.0; s.ll = 0.0; s.e2 = 0.0;
+        s.ess = 0.0;
+        s.stot = 1.0; s.mtrue = 0.0; s.wmax = s.wconst; s.fast = 0; s.fallback = 0; s.fb_step = 0; s.e2_valid = 0;
+        for (int p = 0; p < ACC_NSLOT; ++p) { s.off_slot[p] = 0.0; s.u_slot[p] = 0.0; s.e2v_slot[p] = 0; }
+        s.K = llpf_qbits(b.N);
+        if (!is_reset) { s.anc_ident_s[0] = s.anc_ident_s[1] = 1; s.last_resampled = 0; s.resample_count = 0; s.ll_total = 0.0; }
+    }
+    CHK(scal_upload(b, h));
+    HIPC(hipMemsetAsync(b.d_acc, 0, sizeof(uint64_t) * (size_t)b.F * ACC_WORDS, b.stream));
+    HIPC(hipMemsetAsync(b.d_tileq, 0, sizeof(uint64_t) * (size_t)ACC_NSLOT * b.F * b.P2, b.stream));
+    HIPC(hipMemsetAsync(b.d_flag, 0, sizeof(uint32_t) * 4, b.stream));
+    b.parity = 0;
+    HIPC(launch_init(d, b.n_reset, is_reset ? 0 : 1, b.stream));
+    b.n_reset++;
+    b.t_index = is_reset ? 1 : 0;
+    HIPC(hipStreamSynchronize(b.stream));
+    return LLPF_OK;
+}
+
+static int bank_create(const llpf_config* cfg, const llpf_model* models, int F, Bank& b) {
+    if (!cfg) return fail(LLPF_ERR_ARG, "null config");
+    if (cfg->struct_size != sizeof(llpf_config)) return fail(LLPF_ERR_ARG, "llpf_config.struct_size mismatch (ABI)");
+    if (F < 1) return fail(LLPF_ERR_ARG, "n_filters must be >= 1");
+    const llpf_model& m0 = models ? models[0] : cfg->model;
+    if (cfg->n_particles < 1 || cfg->n_particles > ((int64_t)1 << 29) - 2 * TILE)   // 32-bit byte offsets into a particle plane
+        return fail(LLPF_ERR_ARG, "n_particles must be in 1..2^29-2048");
+    if (m0.nx < 1 || m0.nx > MAXD || m0.ny < 1 || m0.ny > MAXD || m0.nu < 0 || m0.nu > MAXD) return fail(LLPF_ERR_ARG, "bad dimensions");
+    if (!step_supported(m0.model_id, m0.nx, m0.ny))
+        return fail(LLPF_ERR_ARG, "no kernel instantiated for this model/dimension (linear-Gaussian nx,ny in 1..4; quad-tank 4/2)");
+    if (cfg->resampling_strategy != LLPF_RESAMPLE_SYSTEMATIC && cfg->resampling_strategy != LLPF_RESAMPLE_STRATIFIED &&
+        cfg->resampling_strategy != LLPF_RESAMPLE_RESIDUAL)
+        return fail(LLPF_ERR_ARG, "resampling_strategy must be systematic, stratified or residual");
+    if (!(cfg->resample_threshold >= 0.0 && cfg->resample_threshold <= 1.0)) return fail(LLPF_ERR_ARG, "resample_threshold must be in [0,1]");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(LLPF_ERR_NO_DEVICE, "no HIP device visible; this engine has no CPU fallback");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(LLPF_ERR_ARG, "device ordinal out of range");
+
+    b.cfg = *cfg;
+    b.cfg.model = m0;
+    b.F = F;
+    b.N = cfg->n_particles;
+    b.Ns = (b.N + TILE - 1) / TILE * TILE;
+    b.nx = m0.nx; b.nu = m0.nu; b.ny = m0.ny;
+    b.P1 = (int)(b.Ns / STEP_TILE);
+    b.P2 = (int)(b.Ns / TILE);
+    b.device = cfg->device;
+    std::vector<ModelD> hm(F);
+    b.hmodels.resize(F);
+    for (int f = 0; f < F; ++f) {
+        const llpf_model& mf = models ? models[f] : cfg->model;
+        b.hmodels[f] = mf;
+        if (mf.model_id != m0.model_id || mf.nx != m0.nx || mf.nu != m0.nu || mf.ny != m0.ny)
+            return fail(LLPF_ERR_ARG, "all filters of a bank must share model id and dimensions");
+        int rc = model_prepare(&mf, &hm[f]);
+        if (rc) return fail(LLPF_ERR_ARG, "invalid density (covariance not positive definite or dimension mismatch), code " + std::to_string(rc));
+    }
+    HIPC(hipSetDevice(b.device));
+    HIPC(hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking));
+    const size_t FN = (size_t)F * b.Ns;
+    HIPC(hipMalloc(&b.d_models, sizeof(ModelD) * F));
+    HIPC(hipMalloc(&b.d_scal, sizeof(FilterScal) * F));
+    HIPC(hipMalloc(&b.d_x[0], sizeof(double) * FN * b.nx));
+    HIPC(hipMalloc(&b.d_x[1], sizeof(double) * FN * b.nx));
+    HIPC(hipMalloc(&b.d_w, sizeof(double) * FN));
+    HIPC(hipMalloc(&b.d_anc, sizeof(int32_t) * FN));
+    HIPC(hipMalloc(&b.d_acc, sizeof(uint64_t) * (size_t)F * ACC_WORDS));
+    HIPC(hipMalloc(&b.d_quanta[0], sizeof(uint64_t) * FN));
+    HIPC(hipMalloc(&b.d_quanta[1], sizeof(uint64_t) * FN));
+    HIPC(hipMalloc(&b.d_tileq, sizeof(uint64_t) * (size_t)ACC_NSLOT * F * b.P2));
+    HIPC(hipMalloc(&b.d_flag, sizeof(uint32_t) * 4));
+    HIPC(hipMalloc(&b.d_xmpart, sizeof(double) * (size_t)F * b.P1 * MAXD));
+    HIPC(hipMalloc(&b.d_rtile, sizeof(uint64_t) * (size_t)F * 2 * b.P2));
+    if (m0.model_id == LLPF_MODEL_RB_LINEAR) {
+        HIPC(hipMalloc(&b.d_rb, sizeof(RBStep) * 2 * (size_t)F));
+        HIPC(hipMemsetAsync(b.d_rb, 0, sizeof(RBStep) * 2 * (size_t)F, b.stream));
+        b.rb.resize(F);
+        for (int f = 0; f < F; ++f) {                       // the inner KalmanFilter object: kf.x = d0.mu, kf.R = d0.Sigma
+            double S0[16];
+            gauss_cov_dense(&b.hmodels[f].linear_initial, S0);
+            const int nl = m0.nx - m0.nxn;
+            for (int i = 0; i < nl * nl; ++i) { b.rb[f].R[i] = S0[i]; b.rb[f].kfR[i] = S0[i]; }
+            for (int i = 0; i < nl; ++i) b.rb[f].kfx[i] = b.hmodels[f].linear_initial.mu[i];
+        }
+    }
+    HIPC(hipMemsetAsync(b.d_rtile, 0, sizeof(uint64_t) * (size_t)F * 2 * b.P2, b.stream));
+    HIPC(hipMalloc(&b.d_uy, sizeof(double) * 4 * MAXD));
+    HIPC(hipMalloc(&b.d_tmp, sizeof(double) * (size_t)F * b.N * (b.nx > 1 ? b.nx : 1) + 64));
+    HIPC(hipMemsetAsync(b.d_x[0], 0, sizeof(double) * FN * b.nx, b.stream));
+    HIPC(hipMemsetAsync(b.d_x[1], 0, sizeof(double) * FN * b.nx, b.stream));
+    HIPC(hipMemsetAsync(b.d_anc, 0, sizeof(int32_t) * FN, b.stream));
+    HIPC(hipMemsetAsync(b.d_scal, 0, sizeof(FilterScal) * F, b.stream));
+    HIPC(hipMemsetAsync(b.d_acc, 0, sizeof(uint64_t) * (size_t)F * ACC_WORDS, b.stream));
+    HIPC(hipMemsetAsync(b.d_quanta[0], 0, sizeof(uint64_t) * FN, b.stream));
+    HIPC(hipMemsetAsync(b.d_quanta[1], 0, sizeof(uint64_t) * FN, b.stream));
+    HIPC(hipMemsetAsync(b.d_tileq, 0, sizeof(uint64_t) * (size_t)ACC_NSLOT * F * b.P2, b.stream));
+    HIPC(hipMemsetAsync(b.d_flag, 0, sizeof(uint32_t) * 4, b.stream));
+    HIPC(hipMemsetAsync(b.d_xmpart, 0, sizeof(double) * (size_t)F * b.P1 * MAXD, b.stream));
+    HIPC(hipMemcpyAsync(b.d_models, hm.data(), sizeof(ModelD) * F, hipMemcpyHostToDevice, b.stream));
+    HIPC(hipStreamSynchronize(b.stream));
+    HIPC(hipEventCreate(&b.ev_run0));
+    HIPC(hipEventCreate(&b.ev_run1));
+    std::vector<FilterScal> h;
+    CHK(scal_download(b, h));
+    set_keys(b, h, cfg->seed);
+    CHK(scal_upload(b, h));
+    return bank_init_particles(b, false);
+}
+
+static int check_status(Bank& b, std::vector<FilterScal>& h) {
+    for (int f = 0; f < b.F; ++f)
+        if (h[f].status) return fail(h[f].status, "degenerate weights (all -Inf or NaN) in filter " + std::to_string(f));
+    return LLPF_OK;
+}

@@ -1,0 +1,262 @@
+// host/run.hpp — the trajectory loop (forward_trajectory / loglik).  Part of capi.hip (one translation unit).
+// ---- the trajectory loop ------------------------------------------------------------------------
+static int ensure(double** p, size_t* cap, size_t n) {
+    if (*cap >= n && *p) return LLPF_OK;
+    if (*p) hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    HIPC(hipMalloc(p, sizeof(double) * (n ? n : 1)));
+    *cap = n;
+    return LLPF_OK;
+}
+
+static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double t_index0,
+                    double* ll_total /* [F] */, double* ll_steps /* [T][F] */, double* xmean /* [T][F][nx] */,
+                    double* x_hist, double* w_hist, double* we_hist) {
+    CHK(use_device(b));
+    if (T < 1) return fail(LLPF_ERR_ARG, "T must be >= 1");
+    if (!Y) return fail(LLPF_ERR_ARG, "Y is null");
+    if (b.nu > 0 && !U) return fail(LLPF_ERR_ARG, "U is null");
+    if ((x_hist || w_hist || we_hist) && b.F != 1) return fail(LLPF_ERR_ARG, "history outputs need a single filter");
+    b.aux_pending = false; b.we_is_lambda = false;
+    CHK(ensure(&b.d_U, &b.capU, (size_t)T * (b.nu > 0 ? b.nu : 1)));
+    CHK(ensure(&b.d_Y, &b.capY, (size_t)T * b.ny));
+    if (b.nu > 0) HIPC(hipMemcpyAsync(b.d_U, U, sizeof(double) * T * b.nu, hipMemcpyHostToDevice, b.stream));
+    HIPC(hipMemcpyAsync(b.d_Y, Y, sizeof(double) * T * b.ny, hipMemcpyHostToDevice, b.stream));
+    if (ll_steps) CHK(ensure(&b.d_ll_steps, &b.cap_ll, (size_t)T * b.F));
+    if (xmean) CHK(ensure(&b.d_xmean, &b.cap_xm, (size_t)T * b.F * b.nx));
+    {   // zero the running log-likelihood and remember the resample counter
+        std::vector<FilterScal> h;
+        CHK(scal_download(b, h));
+        b.run_resamples = 0;
+        for (int f = 0; f < b.F; ++f) { h[f].ll_total = 0.0; b.run_resamples -= h[f].resample_count; }
+        CHK(scal_upload(b, h));
+    }
+    const double Ts = b.cfg.model.Ts;
+    const int want_xm = xmean ? 1 : 0;
+    const int K = llpf_qbits(b.N);
+    const int ne2 = need_e2(b);
+    const bool hist = x_hist || w_hist || we_hist;
+    auto has_y = [&](int64_t k) { return !(Y[k * b.ny] != Y[k * b.ny]); };
+    auto tk = [&](int64_t k) { return (t_index0 + (double)k) * Ts; };
+    // Fused (one launch: finalize + resample + propagate + weight, a block propagates the outputs of its own source
+    // tile) or balanced form (ancestors to HBM, then a uniform propagate).  The fused form saves a launch and the
+    // ancestor round trip but its propagate work follows the weight distribution; models whose dynamics dominate the
+    // timestep (quad-tank RK4: 32 fp64 sqrt per particle) and whose ESS is small run faster balanced (measured 69 vs
+    // 121 us per timestep at N = 1e6), the linear-Gaussian model faster fused.  LLPF_UNFUSED=0/1 overrides.
+    static const char* unf_env = getenv("LLPF_UNFUSED");
+    const bool heavy_dynamics = b.cfg.model.model_id == LLPF_MODEL_QUADTANK_RK4;
+    // residual resampling produces unsorted ancestors (copies first, multinomial draws after): always the balanced form
+    const bool residual = b.cfg.resampling_strategy == LLPF_RESAMPLE_RESIDUAL;
+    const bool rbm = is_rb(b);
+    const bool unfused = hist || residual || rbm || (unf_env ? atoi(unf_env) != 0 : heavy_dynamics);
+    if (rbm) {
+        // the whole gain schedule of the run (data independent): corr_0, pred_0, corr_1, pred_1, ..., [F] each
+        const size_t need = (size_t)(2 * T + 1) * b.F;
+        if (b.cap_rbseq < need) {
+            if (b.d_rbseq) hipFree(b.d_rbseq);
+            b.d_rbseq = nullptr; b.cap_rbseq = 0;
+            HIPC(hipMalloc(&b.d_rbseq, sizeof(RBStep) * need));
+            b.cap_rbseq = need;
+        }
+        std::vector<RBStep> seq(need);
+        for (int64_t k = 0; k < T; ++k)
+            for (int f = 0; f < b.F; ++f) {
+                if (!(Y[k * b.ny] != Y[k * b.ny])) CHK(rb_corr_step(b, f, seq[(size_t)(2 * k) * b.F + f]));
+                else memset(&seq[(size_t)(2 * k) * b.F + f], 0, sizeof(RBStep));
+                CHK(rb_pred_step(b, f, seq[(size_t)(2 * k + 1) * b.F + f]));
+            }
+        memset(&seq[(size_t)(2 * T) * b.F], 0, sizeof(RBStep) * b.F);
+        HIPC(hipMemcpyAsync(b.d_rbseq, seq.data(), sizeof(RBStep) * need, hipMemcpyHostToDevice, b.stream));
+        HIPC(hipStreamSynchronize(b.stream));
+    }
+    // Where the exp-sums / quanta of freshly computed weights are formed (identical results either way): inside the
+    // weighting phase (one launch per timestep: best when one filter of ~1e6 particles cannot fill the chip and the
+    // dependent-launch latency dominates) or by a streaming k_norm launch in bound form (the fused kernel then keeps
+    // its registers for the propagate and runs at higher occupancy: best when many filters saturate the SIMDs).
+    // Measured on MI355X: C2 single filter 29.4 vs 30.2 us, bank 128 x 1e5: 4.3e10 vs 5.0e10 particle-steps/s.
+    const char* sch_env = getenv("LLPF_SCHEDULE");       // "merged" | "split" override
+    const bool merged = hist || (sch_env ? (strcmp(sch_env, "merged") == 0) : ((int64_t)b.F * b.Ns <= ((int64_t)3 << 20)));
+    static const char* abl_env = getenv("LLPF_ABLATE");
+    static const char* dbg_env = getenv("LLPF_DEBUG_TIMING");
+
+    // host-side state of run-step k (the device may have to be re-driven from a step whose bound test failed)
+    const int cur0 = b.cur, qcur0 = b.qcur, par0 = b.parity;
+    const uint32_t np0 = b.n_predict;
+    const int64_t ti0 = b.t_index;
+    auto at_step = [&](int64_t k) {      // state in which step k's head runs (initial weighting done, k steps done)
+        b.cur = cur0 ^ (int)(k & 1);
+        b.qcur = qcur0 ^ 1 ^ (int)(k & 1);
+        b.parity = (par0 + 1 + (int)(k % ACC_NSLOT)) % ACC_NSLOT;      // slot the weighting of step k writes
+        b.n_predict = np0 + (uint32_t)k;
+        b.t_index = ti0 + k;
+    };
+    auto head_slot = [&](int64_t k) { return (par0 + (int)(k % ACC_NSLOT)) % ACC_NSLOT; };
+
+    auto res_args = [&](int64_t k, bool fast) {
+        ResArgs ra{};
+        ra.parity = head_slot(k); ra.step = b.n_predict; ra.M = (int32_t)b.N; ra.anc_out = b.d_anc;
+        ra.accumulate = 1; ra.want_xmean = want_xm; ra.u_from_scal = 1;
+        ra.ll_steps = ll_steps ? b.d_ll_steps : nullptr;
+        ra.xmean = xmean ? b.d_xmean : nullptr;
+        ra.k = k; ra.row = k; ra.fast_head = fast ? 1 : 0;
+        ra.ablate = abl_env ? atoi(abl_env) : 0;
+        return ra;
+    };
+    auto step_args = [&](int64_t k) {
+        StepArgs st{};
+        st.u = b.nu > 0 ? b.d_U + k * b.nu : nullptr;
+        st.t_prop = tk(k);
+        st.step = b.n_predict;
+        st.parity = b.parity;
+        st.need_e2 = ne2; st.K = K; st.k = k; st.next_step = b.n_predict + 1; st.want_xmean = want_xm; st.accumulate = merged ? 1 : 0;
+        if (rbm) { st.rb_pred = b.d_rbseq + (size_t)(2 * k + 1) * b.F; st.rb_corr = b.d_rbseq + (size_t)(2 * k + 2) * b.F; }
+        const bool weight = (k + 1 < T);
+        if (weight) { st.y = b.d_Y + (k + 1) * b.ny; st.t_meas = tk(k + 1); st.has_y = has_y(k + 1) ? 1 : 0; }
+        else { st.y = nullptr; st.t_meas = tk(k); st.has_y = 0; }
+        return st;
+    };
+    // one timestep in the given form; `fast`: the head consumes the bound-offset sums of the previous weighting,
+    // otherwise the exact-max sums of a k_norm launched just before (redo of a failed step, or weighted means)
+    auto launch_timestep = [&](int64_t k, bool fast, int only_fb) -> int {
+        at_step(k);
+        BankDev d = b.dev();
+        ResArgs ra = res_args(k, fast);
+        ra.only_fallback = only_fb;
+        StepArgs st = step_args(k);
+        const bool weight = (k + 1 < T);
+        if (fast && !merged) {   // split schedule: the sums of the current weights in bound form, as a streaming launch
+            ProfScope ps(b, LLPF_PROF_NORMALISE);
+            HIPC(launch_norm(d, ra.parity, want_xm, ne2, b.n_predict, 0, 1, k, b.stream));
+        }
+        if (!fast) {
+            ProfScope ps(b, LLPF_PROF_NORMALISE);
+            HIPC(launch_norm(d, ra.parity, want_xm, 1, b.n_predict, only_fb, 0, k, b.stream));
+        }
+        if (unfused) {
+            {
+                ra.mode = RES_FINALIZE | RES_RESAMPLE;
+                ProfScope ps(b, LLPF_PROF_RESAMPLE);
+                HIPC(launch_resample(d, ra, b.stream));
+            }
+            ProfScope ps(b, LLPF_PROF_PROPAGATE);
+            st.only_fallback = only_fb;
+            HIPC(launch_step(d, weight ? MODE_PROP_WEIGHT : MODE_PROP, st, b.stream));
+        } else {
+            uint64_t* d_dbg = nullptr;
+            if (dbg_env && k == atoll(dbg_env)) {
+                HIPC(hipMalloc(&d_dbg, sizeof(uint64_t) * 8 * b.P2));
+                HIPC(hipMemsetAsync(d_dbg, 0, sizeof(uint64_t) * 8 * b.P2, b.stream));
+                ra.dbg = d_dbg;
+            }
+            st.only_fallback = only_fb;
+            ProfScope ps(b, LLPF_PROF_PROPAGATE);
+            HIPC(launch_resprop(d, ra, st, weight ? 1 : 0, b.stream));
+            if (d_dbg) {
+                std::vector<uint64_t> hd((size_t)8 * b.P2);
+                HIPC(hipMemcpyAsync(hd.data(), d_dbg, sizeof(uint64_t) * hd.size(), hipMemcpyDeviceToHost, b.stream));
+                HIPC(hipStreamSynchronize(b.stream));
+                FILE* fp = fopen("gpurun_out/llpf_timing.txt", "w");
+                if (fp) {
+                    for (int t = 0; t < b.P2; ++t) {
+                        for (int q = 0; q < 6; ++q) fprintf(fp, "%llu ", (unsigned long long)hd[(size_t)t * 8 + q]);
+                        fprintf(fp, "\n");
+                    }
+                    fclose(fp);
+                }
+                hipFree(d_dbg);
+            }
+        }
+        return LLPF_OK;
+    };
+
+    HIPC(hipEventRecord(b.ev_run0, b.stream));
+    {   // weighting of the first correct! (exp-sums against the bound, quanta, tile sums: no separate normalise pass)
+        BankDev d = b.dev();
+        StepArgs a{};
+        a.u = b.nu > 0 ? b.d_U : nullptr; a.y = b.d_Y; a.t_prop = tk(0); a.t_meas = tk(0); a.step = 0; a.has_y = has_y(0) ? 1 : 0;
+        a.parity = par0; a.need_e2 = ne2; a.K = K; a.k = 0; a.next_step = np0; a.want_xmean = want_xm; a.accumulate = merged ? 1 : 0;
+        if (rbm) a.rb_corr = b.d_rbseq;
+        ProfScope ps(b, LLPF_PROF_PROPAGATE);
+        HIPC(launch_step(d, MODE_WEIGHT, a, b.stream));
+    }
+    if (hist) {
+        // step-synchronous form: the normalised state between correct! and predict! is copied out
+        // (forward_trajectory history, reference src/filtering.jl:357-359).  Same arithmetic as the asynchronous
+        // loop below (bound-offset form, exact redo when its test fails); not a timed path.
+        for (int64_t k = 0; k < T; ++k) {
+            at_step(k);
+            BankDev d = b.dev();
+            ResArgs ra = res_args(k, true);
+            ra.mode = RES_FINALIZE;
+            HIPC(launch_resample(d, ra, b.stream));
+            std::vector<int> fl;
+            int64_t kf;
+            CHK(poll_fallback(b, fl, kf));
+            if (!fl.empty()) {
+                CHK(clear_slot_sums(b, ra.parity, fl));
+                HIPC(launch_norm(d, ra.parity, want_xm, 1, b.n_predict, 1, 0, k, b.stream));
+                ra.fast_head = 0; ra.only_fallback = 1;
+                HIPC(launch_resample(d, ra, b.stream));
+                ra.only_fallback = 0;
+                CHK(clear_fallback(b, fl));
+            }
+            if (x_hist) {
+                HIPC(launch_soa2aos(d, b.d_x[b.cur], b.d_tmp, b.stream));
+                HIPC(hipMemcpyAsync(x_hist + (size_t)k * b.N * b.nx, b.d_tmp, sizeof(double) * b.N * b.nx, hipMemcpyDeviceToHost, b.stream));
+                HIPC(hipStreamSynchronize(b.stream));
+            }
+            if (w_hist) {
+                HIPC(launch_materialize(d, b.d_tmp, nullptr, b.stream));
+                HIPC(hipMemcpyAsync(w_hist + (size_t)k * b.N, b.d_tmp, sizeof(double) * b.N, hipMemcpyDeviceToHost, b.stream));
+                HIPC(hipStreamSynchronize(b.stream));
+            }
+            if (we_hist) {
+                HIPC(launch_materialize(d, nullptr, b.d_tmp, b.stream));
+                HIPC(hipMemcpyAsync(we_hist + (size_t)k * b.N, b.d_tmp, sizeof(double) * b.N, hipMemcpyDeviceToHost, b.stream));
+                HIPC(hipStreamSynchronize(b.stream));
+            }
+            ra.mode = RES_RESAMPLE;
+            ra.accumulate = 0; ra.ll_steps = nullptr; ra.xmean = nullptr;
+            HIPC(launch_resample(d, ra, b.stream));
+            StepArgs st = step_args(k);
+            HIPC(launch_step(d, (k + 1 < T) ? MODE_PROP_WEIGHT : MODE_PROP, st, b.stream));
+        }
+    } else {
+        int64_t k0 = 0;
+        while (k0 < T) {
+            for (int64_t k = k0; k < T; ++k) CHK(launch_timestep(k, true, 0));
+            std::vector<int> fl;
+            int64_t kf;
+            CHK(poll_fallback(b, fl, kf));
+            if (fl.empty()) break;
+            // step kf of the flagged filters: exact-max normalisation of the same weights, then the step again
+            CHK(clear_slot_sums(b, head_slot(kf), fl));
+            CHK(launch_timestep(kf, false, 1));
+            CHK(clear_fallback(b, fl));
+            k0 = kf + 1;
+        }
+    }
+    at_step(T);
+    b.qcur = qcur0 ^ (int)(T & 1);                           // the last step has no weighting phase: no quanta swap
+    b.parity = (par0 + (int)(T % ACC_NSLOT)) % ACC_NSLOT;
+    {
+        BankDev d = b.dev();
+        ProfScope ps(b, LLPF_PROF_OTHER);
+        HIPC(launch_post_predict(d, b.stream));
+    }
+    HIPC(hipEventRecord(b.ev_run1, b.stream));
+    if (ll_steps) HIPC(hipMemcpyAsync(ll_steps, b.d_ll_steps, sizeof(double) * T * b.F, hipMemcpyDeviceToHost, b.stream));
+    if (xmean) HIPC(hipMemcpyAsync(xmean, b.d_xmean, sizeof(double) * T * b.F * b.nx, hipMemcpyDeviceToHost, b.stream));
+    std::vector<FilterScal> h;
+    CHK(scal_download(b, h));
+    float ms = 0.f;
+    HIPC(hipEventElapsedTime(&ms, b.ev_run0, b.ev_run1));
+    b.last_run_ms = ms;
+    if (b.profiling) prof_collect(b);
+    for (int f = 0; f < b.F; ++f) {
+        if (ll_total) ll_total[f] = h[f].ll_total;
+        b.run_resamples += h[f].resample_count;
+    }
+    return check_status(b, h);
+}

@@ -1,0 +1,314 @@
+// kernels/models.hpp — Gaussian densities and the model structs (LinGauss, RBLin, QuadTank).  Part of kernels.hip (one translation unit, namespace llpf).
+// ------------------------------------------------------------------------------------------------
+// Gaussian pieces — operation order identical to oracle/llpf_oracle.c gauss_sample / gauss_logpdf
+// (reference src/utils.jl:110-113, 252-268)
+// ------------------------------------------------------------------------------------------------
+template <int ND>
+DEV void gauss_sample(const GaussD& g, const double* xi, double* out) {
+    const int kind = g.kind;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+        double v;
+        if (kind == LLPF_COV_SCAL) v = g.sqrtscal * xi[i];
+        else if (kind == LLPF_COV_DIAG) v = g.sqrtdiag[i] * xi[i];
+        else {
+            v = g.L[i * MAXD + 0] * xi[0];
+#pragma unroll
+            for (int j = 1; j <= i; ++j) v = v + g.L[i * MAXD + j] * xi[j];
+        }
+        out[i] = v + g.mu[i];
+    }
+}
+
+template <int ND>
+DEV double gauss_logpdf(const GaussD& g, const double* x) {
+    double d[ND], q;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) d[i] = x[i] - g.mu[i];
+    const int kind = g.kind;
+    if (kind == LLPF_COV_SCAL) {
+        double dot = d[0] * d[0];
+#pragma unroll
+        for (int i = 1; i < ND; ++i) dot = dot + d[i] * d[i];
+        q = dot * g.invscal;
+    } else if (kind == LLPF_COV_DIAG) {
+        double s = (d[0] * d[0]) * g.invdiag[0];
+#pragma unroll
+        for (int i = 1; i < ND; ++i) s = s + (d[i] * d[i]) * g.invdiag[i];
+        q = s;
+    } else {
+        double z[ND], z2[ND];
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            double acc = d[i];
+#pragma unroll
+            for (int j = 0; j < i; ++j) acc = acc - g.L[i * MAXD + j] * z[j];
+            z[i] = acc * g.invLd[i];
+        }
+#pragma unroll
+        for (int i = ND - 1; i >= 0; --i) {
+            double acc = z[i];
+#pragma unroll
+            for (int j = i + 1; j < ND; ++j) acc = acc - g.L[j * MAXD + i] * z2[j];
+            z2[i] = acc * g.invLd[i];
+        }
+        double dot = d[0] * z2[0];
+#pragma unroll
+        for (int i = 1; i < ND; ++i) dot = dot + d[i] * z2[i];
+        q = dot;
+    }
+    return g.c0 - q / 2.0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Models.  A model is a struct with
+//   prepare(md, u, t)      once per thread (particle-independent terms)
+//   dynamics(x, out)       f(x,u,p,t) without noise
+//   measurement(x, out)    g(x,u,p,t)
+// ------------------------------------------------------------------------------------------------
+template <int NX, int NY>
+struct LinGauss {   // f = A x .+ B u ; g = C x   (reference examples/example_lineargaussian.jl:28-29)
+    static constexpr bool RB = false;
+    const ModelD* md;
+    double bu[NX];
+    bool has_u;
+    DEV void prepare(const ModelD* m, const double* __restrict__ u, double /*t*/) {
+        md = m;
+        const int nu = m->nu;
+        has_u = nu > 0 && u != nullptr;
+#pragma unroll
+        for (int r = 0; r < NX; ++r) {
+            double acc = 0.0;
+            if (has_u) {
+                acc = m->B[r * nu + 0] * u[0];
+                for (int c = 1; c < nu; ++c) acc = acc + m->B[r * nu + c] * u[c];
+            }
+            bu[r] = acc;
+        }
+    }
+    DEV void dynamics(const double* x, double* out) const {
+#pragma unroll
+        for (int r = 0; r < NX; ++r) {
+            double ax = md->A[r * NX + 0] * x[0];
+#pragma unroll
+            for (int c = 1; c < NX; ++c) ax = ax + md->A[r * NX + c] * x[c];
+            out[r] = has_u ? ax + bu[r] : ax;
+        }
+    }
+    DEV void measurement(const double* x, double* out) const {
+#pragma unroll
+        for (int r = 0; r < NY; ++r) {
+            double cx = md->C[r * NX + 0] * x[0];
+#pragma unroll
+            for (int c = 1; c < NX; ++c) cx = cx + md->C[r * NX + c] * x[c];
+            out[r] = cx;
+        }
+    }
+};
+
+// Rao-Blackwellized filter with constant matrices (reference src/rbpf.jl:163-283): the particle is [xn; xl], the
+// covariance of xl is shared by all particles and advanced on the host (csrc/shared/llpf_rbkf.h).  A = [Fn An; 0 Al],
+// B = [Bn; Bl], C = [Gn Cl] (row stride NX / nu / NX).  Operation order identical to oracle/llpf_oracle.c:rb_*.
+template <int NX, int NY>
+struct RBLin {
+    static constexpr bool RB = true;
+    const ModelD* md;
+    const double* u;
+    int nn, nl, nu;
+    DEV void prepare(const ModelD* m, const double* __restrict__ uu, double /*t*/) {
+        md = m; u = uu; nn = m->nxn; nl = NX - m->nxn; nu = (uu != nullptr) ? m->nu : 0;
+    }
+    // the propagation of predict! (:185-224): xs = [fi + z ; Al xl + Bl u + L (z - An xl)]
+    DEV void rb_propagate(const double* xp, uint32_t idx, uint32_t step, uint32_t k0, uint32_t k1, const RBStep* rp, double* xs) const {
+        double xi[NX], nz[NX], fi[NX], xl1[NX];
+        llpf_normals(idx, step, LLPF_STREAM_DYNAMICS, k0, k1, nn, xi);
+        const GaussD& g = md->df;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            if (i < nn) {                                  // rand(pf.rng, pf.R1n) = mu + L xi
+                double v;
+                if (g.kind == LLPF_COV_SCAL) v = g.sqrtscal * xi[i];
+                else if (g.kind == LLPF_COV_DIAG) v = g.sqrtdiag[i] * xi[i];
+                else {
+                    v = g.L[i * MAXD + 0] * xi[0];
+#pragma unroll
+                    for (int j = 1; j < NX; ++j) if (j <= i) v = v + g.L[i * MAXD + j] * xi[j];
+                }
+                nz[i] = v + g.mu[i];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < NX; ++r) {
+            if (r < nn) {                                  // fi = Fn xn + Bn u
+                double a = md->A[r * NX] * xp[0];
+#pragma unroll
+                for (int c = 1; c < NX; ++c) if (c < nn) a = a + md->A[r * NX + c] * xp[c];
+                if (nu > 0) {
+                    double b2 = md->B[r * nu] * u[0];
+                    for (int c = 1; c < nu; ++c) b2 = b2 + md->B[r * nu + c] * u[c];
+                    a = a + b2;
+                }
+                fi[r] = a;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < NX; ++r) {
+            if (r < nl) {                                  // Al xl + Bl u
+                double a = md->A[(nn + r) * NX + nn] * xp[nn];
+#pragma unroll
+                for (int c = 1; c < NX; ++c) if (c < nl) a = a + md->A[(nn + r) * NX + nn + c] * xp[nn + c];
+                if (nu > 0) {
+                    double b2 = md->B[(nn + r) * nu] * u[0];
+                    for (int c = 1; c < nu; ++c) b2 = b2 + md->B[(nn + r) * nu + c] * u[c];
+                    a = a + b2;
+                }
+                xl1[r] = a;
+            }
+        }
+        if (md->rb_zeroAn) {
+#pragma unroll
+            for (int r = 0; r < NX; ++r) {
+                if (r < nn) xs[r] = fi[r] + nz[r];
+                else xs[r] = xl1[r - nn];
+            }
+        } else {
+            double Axl[NX], z[NX];
+#pragma unroll
+            for (int r = 0; r < NX; ++r) {
+                if (r < nn) {
+                    double a = md->A[r * NX + nn] * xp[nn];
+#pragma unroll
+                    for (int c = 1; c < NX; ++c) if (c < nl) a = a + md->A[r * NX + nn + c] * xp[nn + c];
+                    Axl[r] = a;
+                    z[r] = a + nz[r];
+                    xs[r] = fi[r] + z[r];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < NX; ++r) {
+                if (r < nl) {
+                    double a = rp->L[r * nn] * (z[0] - Axl[0]);
+#pragma unroll
+                    for (int c = 1; c < NX; ++c) if (c < nn) a = a + rp->L[r * nn + c] * (z[c] - Axl[c]);
+                    xs[nn + r] = xl1[r] + a;
+                }
+            }
+        }
+    }
+    // the per-particle part of correct! (:253-280): returns ll and applies the Kalman measurement update to xl
+    DEV double rb_weight(double* xs, const double* y, const RBStep* rc, bool first) const {
+        double yn[NY], yl[NY], e[NY];
+#pragma unroll
+        for (int r = 0; r < NY; ++r) {
+            double a = md->C[r * NX] * xs[0];
+#pragma unroll
+            for (int c = 1; c < NX; ++c) if (c < nn) a = a + md->C[r * NX + c] * xs[c];
+            yn[r] = a;
+            double b2 = md->C[r * NX + nn] * xs[nn];
+#pragma unroll
+            for (int c = 1; c < NX; ++c) if (c < nl) b2 = b2 + md->C[r * NX + nn + c] * xs[nn + c];
+            yl[r] = b2;
+        }
+        double ll;
+        if (!md->rb_zeroC) {
+#pragma unroll
+            for (int r = 0; r < NY; ++r) e[r] = first ? (y[r] - yn[r]) - yl[r] : y[r] - (yn[r] + yl[r]);
+            ll = gauss_logpdf<NY>(rc->dS, e);
+#pragma unroll
+            for (int r = 0; r < NX; ++r) {
+                if (r < nl) {
+                    double a = rc->K[r * NY] * e[0];
+#pragma unroll
+                    for (int c = 1; c < NY; ++c) a = a + rc->K[r * NY + c] * e[c];
+                    xs[nn + r] = xs[nn + r] + a;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < NY; ++r) e[r] = y[r] - (yn[r] + yl[r]);
+            ll = gauss_logpdf<NY>(md->dg, e);
+#pragma unroll
+            for (int r = 0; r < NX; ++r) if (r < nl) xs[nn + r] = rc->kfx[r];
+        }
+        return ll;
+    }
+    // unused generic hooks
+    DEV void dynamics(const double* x, double* out) const { for (int d = 0; d < NX; ++d) out[d] = x[d]; }
+    DEV void measurement(const double*, double*) const {}
+};
+
+template <int NX, int NY>
+struct QuadTank {   // reference examples/example_quadtank.jl:8-35 with rk4 of src/utils.jl:220-237
+    static constexpr bool RB = false;
+    static_assert(NX == 4 && NY == 2, "quad-tank is 4 states / 2 outputs");
+    // coefficients in the reference's evaluation order: (-a/A), (a/A), (gamma k / A)
+    double c1a, c1a_sw, c1b, c1u, c2a, c2b, c2u, c3a, c3u, c4a, c4u;
+    double tg, eps, tsw, u0, u1, t0, Ts;
+    int ss;
+    DEV void prepare(const ModelD* m, const double* __restrict__ u, double t) {
+        const double* q = m->qt;
+        const double k1 = q[LLPF_QT_K1], k2 = q[LLPF_QT_K2], g = q[LLPF_QT_G];
+        const double A1 = q[LLPF_QT_A1], A2 = q[LLPF_QT_A2], A3 = q[LLPF_QT_A3], A4 = q[LLPF_QT_A4];
+        const double a1 = q[LLPF_QT_a1], a2 = q[LLPF_QT_a2], a3 = q[LLPF_QT_a3], a4 = q[LLPF_QT_a4];
+        const double g1 = q[LLPF_QT_GAMMA1], g2 = q[LLPF_QT_GAMMA2];
+        c1a = (-a1) / A1;
+        c1a_sw = (-(a1 * q[LLPF_QT_A1FACTOR])) / A1;
+        c1b = a3 / A1;
+        c1u = (g1 * k1) / A1;
+        c2a = (-a2) / A2;
+        c2b = a4 / A2;
+        c2u = (g2 * k2) / A2;
+        c3a = (-a3) / A3;
+        c3u = ((1.0 - g2) * k2) / A3;
+        c4a = (-a4) / A4;
+        c4u = ((1.0 - g1) * k1) / A4;
+        tg = 2.0 * g;
+        eps = q[LLPF_QT_EPS];
+        tsw = q[LLPF_QT_TSWITCH];
+        u0 = u[0];
+        u1 = u[1];
+        t0 = t;
+        ss = m->supersample < 1 ? 1 : m->supersample;
+        Ts = m->Ts / (double)ss;
+    }
+    DEV void rhs(const double* h, double t, double* xd) const {
+        double s[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            double v = tg * h[i];
+            s[i] = llpf_sqrt((v > 0.0 ? v : 0.0) + eps);
+        }
+        const double ca = (t > tsw) ? c1a_sw : c1a;
+        xd[0] = ca * s[0] + c1b * s[2] + c1u * u0;
+        xd[1] = c2a * s[1] + c2b * s[3] + c2u * u1;
+        xd[2] = c3a * s[2] + c3u * u1;
+        xd[3] = c4a * s[3] + c4u * u0;
+    }
+    DEV void dynamics(const double* x0, double* out) const {
+        double x[4], f1[4], f2[4], f3[4], f4[4], xt[4];
+        double t = t0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[i] = x0[i];
+        for (int it = 0; it < ss; ++it) {
+            rhs(x, t, f1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xt[i] = x[i] + (Ts / 2.0) * f1[i];
+            rhs(xt, t + Ts / 2.0, f2);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xt[i] = x[i] + (Ts / 2.0) * f2[i];
+            rhs(xt, t + Ts / 2.0, f3);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xt[i] = x[i] + Ts * f3[i];
+            rhs(xt, t + Ts, f4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) x[i] = x[i] + (Ts / 6.0) * (((f1[i] + 2.0 * f2[i]) + 2.0 * f3[i]) + f4[i]);
+            t = t + Ts;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) out[i] = x[i];
+    }
+    DEV void measurement(const double* x, double* out) const {
+        out[0] = x[0];
+        out[1] = x[1];
+    }
+};

@@ -1,0 +1,149 @@
+// kernels/norm.hpp — k_norm (exp-weights, fixed-point sums, quanta), k_ess, k_post_predict.  Part of kernels.hip (one translation unit, namespace llpf).
+// ------------------------------------------------------------------------------------------------
+// k_norm — exp-weights and their exact sums  (logsumexp! utils.jl:18-27, sum_all_but :66-71,
+// effective_particles resample.jl:1-2; optional weighted_mean filtering.jl:541-549)
+// ------------------------------------------------------------------------------------------------
+template <int NX, bool XMEAN, bool NEED_E2>
+__global__ __launch_bounds__(BLOCK) void k_norm(BankDev b, int K, int parity, uint32_t step, int only_fallback, int bound, int64_t kstep) {
+    __shared__ uint64_t sm_u[BLOCK / 64][6];
+    __shared__ double sm_x[BLOCK / 64][MAXD];
+    const int f = blockIdx.y;
+    const int tile = blockIdx.x;
+    if (only_fallback && !b.scal[f].fallback) return;
+    if (bound && run_is_stopped(b, kstep)) return;
+    if (bound && b.scal[f].fallback) return;
+    uint64_t* acc = b.acc + (size_t)f * ACC_WORDS;
+    const double* __restrict__ w = b.w + (size_t)f * b.Ns;
+    const double* __restrict__ xc = b.xcur + (size_t)f * NX * b.Ns;
+
+    double2 wv[NORM_IPT / 2];
+#pragma unroll
+    for (int k = 0; k < NORM_IPT / 2; ++k) {
+        const int64_t i0 = (int64_t)tile * TILE + (int64_t)k * (BLOCK * 2) + threadIdx.x * 2;
+        wv[k] = *reinterpret_cast<const double2*>(w + i0);
+    }
+    const double m = bound ? b.scal[f].off_slot[parity] : acc_read_max_wave(acc, parity);
+
+    llpf_u128 S = {0, 0}, E2 = {0, 0};
+    uint64_t Q = 0, bad = 0;
+    double xm[NX > 0 ? NX : 1];
+#pragma unroll
+    for (int d = 0; d < NX; ++d) xm[d] = 0.0;
+#pragma unroll
+    for (int k = 0; k < NORM_IPT / 2; ++k) {
+        const int64_t i0 = (int64_t)tile * TILE + (int64_t)k * (BLOCK * 2) + threadIdx.x * 2;
+        const double e0 = llpf_exp_le0(wv[k].x - m);
+        const double e1 = llpf_exp_le0(wv[k].y - m);
+        bad += (e0 != e0) ? 1u : 0u;
+        bad += (e1 != e1) ? 1u : 0u;
+        S = llpf_u128_add(S, llpf_fix96_unit(e0));
+        S = llpf_u128_add(S, llpf_fix96_unit(e1));
+        if (NEED_E2) {
+            E2 = llpf_u128_add(E2, llpf_fix96_unit(e0 * e0));
+            E2 = llpf_u128_add(E2, llpf_fix96_unit(e1 * e1));
+        }
+        ulonglong2 qv;
+        qv.x = llpf_q64_unit(e0, K);
+        qv.y = llpf_q64_unit(e1, K);
+        *reinterpret_cast<ulonglong2*>(b.quanta + (size_t)f * b.Ns + i0) = qv;
+        Q += qv.x;
+        Q += qv.y;
+        if (XMEAN) {
+#pragma unroll
+            for (int d = 0; d < NX; ++d) {
+                const double2 xv = *reinterpret_cast<const double2*>(xc + (size_t)d * b.Ns + i0);
+                xm[d] = xm[d] + xv.x * e0;
+                xm[d] = xm[d] + xv.y * e1;
+            }
+        }
+    }
+    S = wave_sum_u128(S);
+    if (NEED_E2) E2 = wave_sum_u128(E2);
+    Q = wave_sum_u64(Q);
+    bad = wave_sum_u64(bad);
+    if (XMEAN) {
+#pragma unroll
+        for (int d = 0; d < NX; ++d) xm[d] = wave_sum_f64(xm[d]);
+    }
+    const int lane = threadIdx.x & 63, wvid = threadIdx.x >> 6;
+    if (lane == 0) {
+        sm_u[wvid][0] = S.lo; sm_u[wvid][1] = S.hi;
+        sm_u[wvid][2] = E2.lo; sm_u[wvid][3] = E2.hi;
+        sm_u[wvid][4] = Q; sm_u[wvid][5] = bad;
+        if (XMEAN) {
+#pragma unroll
+            for (int d = 0; d < NX; ++d) sm_x[wvid][d] = xm[d];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        llpf_u128 s = {sm_u[0][0], sm_u[0][1]}, e2 = {sm_u[0][2], sm_u[0][3]};
+        uint64_t q = sm_u[0][4], bd = sm_u[0][5];
+        for (int k = 1; k < BLOCK / 64; ++k) {
+            llpf_u128 t1 = {sm_u[k][0], sm_u[k][1]}, t2 = {sm_u[k][2], sm_u[k][3]};
+            s = llpf_u128_add(s, t1);
+            e2 = llpf_u128_add(e2, t2);
+            q += sm_u[k][4];
+            bd += sm_u[k][5];
+        }
+        acc_add_u128(acc, ACC_S(parity), s);
+        if (NEED_E2) acc_add_u128(acc, ACC_E2(parity), e2);
+        if (tile == 0) {   // the single uniform a systematic resample of this step consumes (reference: rand(), resample.jl:23)
+            FilterScal* sc = b.scal + f;
+            sc->u_slot[parity] = llpf_uniform_step(step, LLPF_STREAM_RESAMPLE, sc->k0, sc->k1);
+            sc->e2v_slot[parity] = NEED_E2 ? 1 : 0;
+            sc->xm_parts = b.P2;
+        }
+        if (bd) atomicAdd(reinterpret_cast<unsigned long long*>(acc_slot(acc, ACC_BAD(parity), blockIdx.x & (NSHARD - 1))), (unsigned long long)bd);
+        tileq_slot(b, parity, f)[tile] = q;
+        if (XMEAN) {
+            for (int d = 0; d < NX; ++d) {
+                double a = sm_x[0][d];
+                for (int k = 1; k < BLOCK / 64; ++k) a = a + sm_x[k][d];
+                b.xmpart[((size_t)f * b.P1 + tile) * MAXD + d] = a;
+            }
+        }
+    }
+}
+
+// accessor path: sum e^2 (fixed point) and ESS of the current weights when the hot loop skipped them
+__global__ __launch_bounds__(BLOCK) void k_ess(BankDev b) {
+    __shared__ uint64_t sm_u[BLOCK / 64][2];
+    const int f = blockIdx.x;
+    FilterScal* sc = b.scal + f;
+    if (sc->uniform || sc->e2_valid || sc->status) return;
+    const double* w = b.w + (size_t)f * b.Ns;
+    const double m = sc->m;
+    llpf_u128 E2 = {0, 0};
+    for (int64_t i = threadIdx.x; i < b.N; i += BLOCK) {
+        const double e = llpf_exp_le0(w[i] - m);
+        E2 = llpf_u128_add(E2, llpf_fix96_unit(e * e));
+    }
+    E2 = wave_sum_u128(E2);
+    if ((threadIdx.x & 63) == 0) { sm_u[threadIdx.x >> 6][0] = E2.lo; sm_u[threadIdx.x >> 6][1] = E2.hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        llpf_u128 t = {sm_u[0][0], sm_u[0][1]};
+        for (int k = 1; k < BLOCK / 64; ++k) { llpf_u128 u = {sm_u[k][0], sm_u[k][1]}; t = llpf_u128_add(t, u); }
+        const double e2 = llpf_fix96_to_double(t);
+        sc->e2 = e2;
+        sc->ess = (sc->stot * sc->stot) / e2;
+        sc->e2_valid = 1;
+    }
+}
+
+// after a propagate-only predict!: reset_weights! if it resampled (reference src/utils.jl:73-79)
+__global__ void k_post_predict(BankDev b) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= b.F) return;
+    FilterScal* sc = b.scal + f;
+    if (sc->do_resample) {
+        sc->uniform = 1;
+        sc->wconst = b.log1N;
+        sc->m = 0.0;
+        sc->mtrue = 0.0;             // maxw[] = 0
+        sc->wmax = b.log1N;
+        sc->norm_pending = 0;
+    }
+    sc->do_resample = 0;
+}

@@ -1,0 +1,84 @@
+// kernels/reduce.hpp — wave / block reductions and scans on DPP.  Part of kernels.hip (one translation unit, namespace llpf).
+// ------------------------------------------------------------------------------------------------
+// wave / block reductions and scans (wave = 64 lanes) on DPP.
+// Measured on gfx950 (tools/inst_cost.hip): a ds_bpermute_b32 (what __shfl_* compiles to) costs ~10 ns of a SIMD's
+// time, a DPP-modified VALU move ~1 ns; a 64-lane reduction of one 64-bit value is 12 bpermutes vs 12 DPP moves.
+// Row = 16 lanes.  Inclusive scan: row_shr 1,2,4,8 (Hillis–Steele inside a row, out-of-row sources read as the
+// identity), then row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3.  Lane 63 ends with the total.
+// ------------------------------------------------------------------------------------------------
+#define DPP_ROW_SHR(n) (0x110 + (n))
+#define DPP_ROW_BCAST15 0x142
+#define DPP_ROW_BCAST31 0x143
+#define DPP_QUAD_XOR1 0xB1          /* quad_perm [1,0,3,2] */
+#define DPP_QUAD_XOR2 0x4E          /* quad_perm [2,3,0,1] */
+#define DPP_ROW_HALF_MIRROR 0x141
+
+template <int CTRL, int ROW_MASK, bool BOUND>
+DEV uint64_t dpp_u64(uint64_t old, uint64_t v) {
+    const int lo = __builtin_amdgcn_update_dpp((int)(uint32_t)old, (int)(uint32_t)v, CTRL, ROW_MASK, 0xF, BOUND);
+    const int hi = __builtin_amdgcn_update_dpp((int)(uint32_t)(old >> 32), (int)(uint32_t)(v >> 32), CTRL, ROW_MASK, 0xF, BOUND);
+    return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+DEV uint64_t readlane_u64(uint64_t v, int lane) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane);
+    return ((uint64_t)hi << 32) | lo;
+}
+// inclusive prefix sum over the wave
+DEV uint64_t wave_scan_u64(uint64_t x) {
+    x += dpp_u64<DPP_ROW_SHR(1), 0xF, true>(0, x);
+    x += dpp_u64<DPP_ROW_SHR(2), 0xF, true>(0, x);
+    x += dpp_u64<DPP_ROW_SHR(4), 0xF, true>(0, x);
+    x += dpp_u64<DPP_ROW_SHR(8), 0xF, true>(0, x);
+    x += dpp_u64<DPP_ROW_BCAST15, 0xA, false>(0, x);
+    x += dpp_u64<DPP_ROW_BCAST31, 0xC, false>(0, x);
+    return x;
+}
+DEV uint32_t wave_scan_max_u32(uint32_t x) {
+#define LLPF_MAXSTEP(CTRL, RM, BC) { const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, RM, 0xF, BC); x = t > x ? t : x; }
+    LLPF_MAXSTEP(DPP_ROW_SHR(1), 0xF, true) LLPF_MAXSTEP(DPP_ROW_SHR(2), 0xF, true) LLPF_MAXSTEP(DPP_ROW_SHR(4), 0xF, true)
+    LLPF_MAXSTEP(DPP_ROW_SHR(8), 0xF, true) LLPF_MAXSTEP(DPP_ROW_BCAST15, 0xA, false) LLPF_MAXSTEP(DPP_ROW_BCAST31, 0xC, false)
+#undef LLPF_MAXSTEP
+    return x;
+}
+// total over the wave, returned uniformly to every lane
+DEV uint64_t wave_sum_u64(uint64_t v) { return readlane_u64(wave_scan_u64(v), 63); }
+DEV llpf_u128 wave_sum_u128(llpf_u128 v) {
+    // sum the three 43-bit limbs separately (no carries between lanes), recombine: exact
+    const uint64_t M43 = ((uint64_t)1 << 43) - 1;
+    const uint64_t l0 = wave_sum_u64(v.lo & M43);
+    const uint64_t l1 = wave_sum_u64(((v.lo >> 43) | (v.hi << 21)) & M43);
+    const uint64_t l2 = wave_sum_u64(v.hi >> 22);
+    llpf_u128 r = {l0, 0}, t;
+    t.lo = l1 << 43; t.hi = l1 >> 21;
+    r = llpf_u128_add(r, t);
+    t.lo = 0; t.hi = l2 << 22;
+    return llpf_u128_add(r, t);
+}
+DEV double wave_max(double v) {
+    // running maximum with the same DPP sequence; out-of-row / masked lanes read the lane's own value
+    uint64_t x = llpf_d2u(v);
+#define LLPF_FMAXSTEP(CTRL, RM) { const double t = llpf_u2d(dpp_u64<CTRL, RM, false>(x, x)); const double c = llpf_u2d(x); x = llpf_d2u(llpf_fmax(c, t)); }
+    LLPF_FMAXSTEP(DPP_ROW_SHR(1), 0xF) LLPF_FMAXSTEP(DPP_ROW_SHR(2), 0xF) LLPF_FMAXSTEP(DPP_ROW_SHR(4), 0xF)
+    LLPF_FMAXSTEP(DPP_ROW_SHR(8), 0xF) LLPF_FMAXSTEP(DPP_ROW_BCAST15, 0xA) LLPF_FMAXSTEP(DPP_ROW_BCAST31, 0xC)
+#undef LLPF_FMAXSTEP
+    return llpf_u2d(readlane_u64(x, 63));
+}
+// fixed-order fp64 sum over the wave (used only for the weighted-mean output, never fed back)
+DEV double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = v + __shfl_xor(v, o, 64);
+    return v;
+}
+
+DEV double block_max(double v, double* sm /* [4] */) {
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sm[wv] = v;
+    __syncthreads();
+    double r = sm[0];
+#pragma unroll
+    for (int k = 1; k < BLOCK / 64; ++k) r = llpf_fmax(r, sm[k]);
+    return r;
+}

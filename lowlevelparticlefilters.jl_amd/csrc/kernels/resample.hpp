@@ -1,0 +1,354 @@
+// kernels/resample.hpp — head of the resample kernels, ancestor counts, k_resample.  Part of kernels.hip (one translation unit, namespace llpf).
+// ------------------------------------------------------------------------------------------------
+// k_resample — [finalize] + scan + ancestor counts + expansion, one tile per block
+// ------------------------------------------------------------------------------------------------
+enum { SRC_FILTER = 0, SRC_VALUES = 1 };
+
+// Thresholds are non-decreasing in i0.  count(v) = #{ i0 in [0,M) : thr(i0) < v } is evaluated with a closed
+// form whenever v is not within `delta` (in index units) of a threshold, and with the exact predicate otherwise:
+// thr(i0) differs from its real-arithmetic value (r + i0/M resp. (i0+U)/M) by < 4 ulp(1), i.e. by < M * 1e-15 in
+// index units, far below delta, so both paths give the count defined by the reference's comparison `s[i] < bins[b]`.
+struct ThrSys {   // systematic: s[i] = fl(r + fl(i0 * (1/M)))  (resample.jl:23-24, Julia StepRangeLen getindex)
+    double r, step, Md, delta;
+    int32_t M;
+    DEV double at(int32_t i0) const { return r + (double)i0 * step; }
+    DEV int32_t count(double v) const {
+        const double e = (v - r) * Md;
+        if (e <= -delta) return 0;
+        if (e >= Md + delta) return M;
+        const double fl = __builtin_floor(e);
+        const double fr = e - fl;
+        int32_t c = (int32_t)fl + 1;
+        c = c < 0 ? 0 : (c > M ? M : c);
+        if (fr > delta && fr < 1.0 - delta && e > 0.0) return c;
+        while (c < M && at(c) < v) ++c;
+        while (c > 0 && !(at(c - 1) < v)) --c;
+        return c;
+    }
+};
+struct ThrStrat { // stratified: u_i = (i0 + rand()) / M * bins[N]  (resample.jl:49)
+    double Md, delta, binsN;
+    int32_t M;
+    uint32_t step, k0, k1;
+    const double* Uexp;
+    DEV double at(int32_t i0) const {
+        const double U = Uexp ? Uexp[i0] : llpf_uniform_idx((uint32_t)i0, step, LLPF_STREAM_STRATIFY, k0, k1);
+        return ((double)i0 + U) / Md * binsN;
+    }
+    DEV int32_t count(double v) const {
+        const double e = v * Md;
+        if (e <= -delta) return 0;
+        if (e >= Md + delta) return M;
+        const double fl = __builtin_floor(e);
+        const double fr = e - fl;
+        int32_t c = (int32_t)fl;
+        c = c < 0 ? 0 : (c > M ? M : c);
+        if (fr > delta && fr < 1.0 - delta && e > 0.0 && c < M) return at(c) < v ? c + 1 : c;
+        while (c < M && at(c) < v) ++c;
+        while (c > 0 && !(at(c - 1) < v)) --c;
+        return c;
+    }
+};
+
+// ---- shared machinery of the resample kernels -----------------------------------------------------------------
+struct ResShared {                 // LDS scratch
+    uint64_t red[BLOCK / 64][4];
+    uint64_t accw[8];
+    double dval[4];
+    uint32_t cl[TILE];
+};
+struct ResHead {                   // block-uniform results of res_head()
+    double a;                      // offset of the pending normalisation (bound or maximum)
+    double mtrue;                  // true maximum of the raw weights
+    double s;                      // exact form only: sum_{i != argmax} e_i
+    double stot, e2;               // sum e_i (all particles), sum e_i^2 (-1: not accumulated)
+    uint64_t prefix, tot;          // exclusive prefix of this tile's quanta, total of all quanta
+    int dr, status, uniform, fast;
+};
+enum { RES_STATUS_FALLBACK = 100, RES_STATUS_SKIP = 101 };   // SKIP: this launch is a no-op for the filter   // internal: bound test failed, the host redoes this step in exact form
+
+// shouldresample (reference src/resample.jl:5-10) without the division: ESS = stot^2 / sum(e^2) < N*thr
+DEV int decide_resample(double thr, double N, double stot, double e2) {
+    if (thr == 1.0) return 1;
+    return (stot * stot < (N * thr) * e2) ? 1 : 0;
+}
+// log(sum exp(w - a)) in the form the normalisation was accumulated in
+DEV double head_log(const ResHead& h) { return h.fast ? llpf_log(h.stot) : llpf_log1p_nonneg(h.s); }
+
+// Head of a resample launch: all global loads are issued first (accumulator slots, per-tile quanta sums), one
+// __syncthreads, then EVERY thread derives the block-uniform scalars (integer sums => identical everywhere).
+// Tile 0 publishes the scalars of logsumexp! / effective_particles / shouldresample for later kernels.
+// `defer_skip`: the caller fetched the run's stop flag and the filter's fallback flag without waiting for them; the
+// launch-is-a-no-op test is made here after the barrier, so that those two loads overlap all the others.
+template <int SRC>
+DEV ResHead res_head(const BankDev& b, const ResArgs& a, int f, int tile, ResShared& sh,
+                     bool defer_skip = false, uint32_t stop_flag = 0, int fb_flag = 0) {
+    FilterScal* sc = b.scal + f;
+    uint64_t* acc = b.acc + (size_t)f * ACC_WORDS;
+    const int lane = threadIdx.x & 63, wvid = threadIdx.x >> 6;
+    const double Nd = (double)b.N;
+    ResHead h;
+    const bool fin = (a.mode & RES_FINALIZE) != 0;
+    const bool unif0 = (SRC == SRC_FILTER) && !fin && sc->uniform;
+    // scalars of the previous launch that are needed after the barrier below: fetched now, with the other loads
+    const double off_pre = sc->off_slot[a.parity];
+    const int e2v_pre = sc->e2v_slot[a.parity];
+    const int status_pre = sc->status;
+
+    // loads.  wave 0: lane group g (8 lanes = 8 shards) fetches word g of this slot's accumulator set
+    uint64_t accv = 0;
+    const int grp = threadIdx.x / NSHARD, shard = threadIdx.x % NSHARD;
+    if (fin && threadIdx.x < 64) accv = *acc_slot(acc, acc_word_of_group(grp, a.parity), shard);
+    uint64_t pre = 0, all = 0;
+    if ((a.mode & RES_RESAMPLE) && !unif0) {
+        const uint64_t* __restrict__ tq = tileq_slot(b, a.parity, f);
+        for (int p = threadIdx.x; p < b.P2; p += BLOCK) {
+            const uint64_t q = tq[p];
+            all += q;
+            if (p < tile) pre += q;
+        }
+    }
+    if (fin && wvid == 0) {
+        // combine the 8 shards of each word inside its group of 8 lanes: xor 1, xor 2 (quad_perm), xor 4 (half mirror)
+#define LLPF_ACCSTEP(CTRL) { const uint64_t t = dpp_u64<CTRL, 0xF, false>(accv, accv); accv = (grp == 0) ? (t > accv ? t : accv) : accv + t; }
+        LLPF_ACCSTEP(DPP_QUAD_XOR1) LLPF_ACCSTEP(DPP_QUAD_XOR2) LLPF_ACCSTEP(DPP_ROW_HALF_MIRROR)
+#undef LLPF_ACCSTEP
+        if (shard == 0) sh.accw[grp] = accv;
+    }
+    pre = wave_sum_u64(pre);
+    all = wave_sum_u64(all);
+    if (lane == 0) { sh.red[wvid][0] = pre; sh.red[wvid][1] = all; }
+    __syncthreads();
+    h.status = 0;
+    h.s = 0.0;
+    if (defer_skip) {
+        const bool stopped = stop_flag != 0 && (int64_t)(stop_flag - 1) < a.k;
+        if (stopped || (a.only_fallback ? !fb_flag : (fb_flag != 0))) { h.status = RES_STATUS_SKIP; return h; }
+    }
+    h.prefix = 0; h.tot = 0;
+#pragma unroll
+    for (int k = 0; k < BLOCK / 64; ++k) { h.prefix += sh.red[k][0]; h.tot += sh.red[k][1]; }
+    if (fin) {
+        // clear the slot after next (its last reader finished two launches ago): accumulator words and tile sums
+        const int clr = (a.parity + 2) % ACC_NSLOT;
+        if (tile == 0 && threadIdx.x >= 64 && threadIdx.x < 128) *acc_slot(acc, acc_word_of_group(grp - 8, clr), shard) = 0;
+        uint64_t* tqc = tileq_slot(b, clr, f);
+        if (gridDim.x == (unsigned)b.P2) { if (threadIdx.x == 0) tqc[tile] = 0; }
+        else { for (int p = threadIdx.x; p < b.P2; p += BLOCK) tqc[p] = 0; }      // finalize-only launch: one block
+    }
+    if (fin) {
+        h.fast = a.fast_head;
+        h.mtrue = max_unkey(sh.accw[0]);
+        const llpf_u128 s128 = acc_combine_u128(sh.accw[1], sh.accw[2], sh.accw[3]);
+        const llpf_u128 e128 = acc_combine_u128(sh.accw[4], sh.accw[5], sh.accw[6]);
+        const bool bad = sh.accw[7] != 0;
+        if (h.fast) {
+            h.a = off_pre;                                        // published by the weighting kernel that filled this slot
+            if (bad || s128.hi < ((uint64_t)1 << 22)) {           // sum exp(w - bound) < 2^-10, or NaN weights
+                h.status = RES_STATUS_FALLBACK;
+                h.stot = 0.0;
+            } else {
+                h.stot = llpf_fix96_to_double(s128);
+            }
+        } else {
+            h.a = h.mtrue;
+            if (bad || s128.hi < ((uint64_t)1 << 32)) {           // max is -Inf / NaN, or NaN weights: degenerate
+                h.stot = llpf_u2d(0x7ff8000000000000ULL);
+                h.s = h.stot;
+                h.status = LLPF_ERR_DEGENERATE;
+            } else {
+                h.s = llpf_fix96_to_double(llpf_fix96_minus_one(s128));     // sum_all_but: exact, one rounding
+                h.stot = h.s + 1.0;
+            }
+        }
+        const int e2v = e2v_pre;
+        h.e2 = e2v ? llpf_fix96_to_double(e128) : -1.0;           // -1: not accumulated (threshold 1: not needed)
+        h.uniform = 0;
+        h.dr = h.status ? 0 : decide_resample(b.thr, Nd, h.stot, h.e2);
+        if (tile == 0 && threadIdx.x == 0) {
+            if (h.status == RES_STATUS_FALLBACK) {
+                sc->fallback = 1;
+                sc->fb_step = a.k;
+                *b.bank_flag = (uint32_t)(a.k + 1);
+            } else {
+                double l, inv, ll, ess;
+                if (h.status) { l = h.stot; inv = h.stot; ll = h.stot; ess = h.stot; }
+                else {
+                    l = head_log(h);
+                    inv = 1.0 / h.stot;
+                    ll = l + h.a;
+                    ess = h.e2 > 0.0 ? (h.stot * h.stot) / h.e2 : -1.0;
+                }
+                sc->m = h.a; sc->mtrue = h.mtrue; sc->s = h.s; sc->stot = h.stot; sc->l = l; sc->inv = inv; sc->ll = ll;
+                sc->ess = ess; sc->e2 = h.e2; sc->fast = h.fast; sc->e2_valid = e2v;
+                sc->wmax = (h.mtrue - h.a) - l;                   // normalised weight of the best particle
+                sc->K = a.K;
+                sc->uniform = 0;
+                sc->norm_pending = a.keep_norm ? 0 : 1;
+                if (a.keep_norm) sc->wmax = h.mtrue;              // set_weights: w stays as installed
+                if (h.status) sc->status = h.status;
+                sc->do_resample = h.dr;
+                if (a.accumulate) sc->ll_total = sc->ll_total + ll;
+                if (a.ll_steps) a.ll_steps[(size_t)a.row * b.F + f] = ll;
+                sh.dval[0] = inv;
+            }
+        }
+        if (!h.status) h.status = status_pre;          // sticky until reset! (written above only when non-zero)
+    } else {
+        // predict! without a preceding correct! in this launch sequence: decide from the stored state
+        h.a = sc->m; h.mtrue = sc->mtrue; h.s = sc->s; h.stot = sc->stot; h.e2 = sc->e2; h.fast = sc->fast;
+        h.status = sc->status; h.uniform = (SRC == SRC_FILTER) ? sc->uniform : 0;
+        if (h.uniform) {
+            const double wev = 1.0 / Nd;
+            const double ess = 1.0 / (Nd * (wev * wev));
+            h.dr = (b.thr == 1.0) ? 1 : (ess < Nd * b.thr ? 1 : 0);
+            if (tile == 0 && threadIdx.x == 0 && !a.only_bins) sc->ess = ess;
+            const uint64_t Qc = llpf_q64_unit(1.0 / Nd, a.K);
+            const int64_t before = (int64_t)tile * TILE < b.N ? (int64_t)tile * TILE : b.N;
+            h.prefix = (uint64_t)before * Qc;
+            h.tot = (uint64_t)b.N * Qc;
+        } else {
+            h.dr = h.status ? 0 : decide_resample(b.thr, Nd, h.stot, h.e2);
+        }
+        if (SRC == SRC_FILTER && tile == 0 && threadIdx.x == 0 && !a.only_bins) sc->do_resample = h.dr;
+    }
+
+    // weighted_mean output (fixed-order fp64 sum of the tile partials; tile 0 only)
+    if (fin && a.xmean && tile == 0 && !h.status) {
+        __syncthreads();
+        const double invb = sh.dval[0];
+        const double* xp = b.xmpart + (size_t)f * b.P1 * MAXD;
+        const int nparts = sc->xm_parts;
+        for (int d = 0; d < b.nx; ++d) {
+            double accx = 0.0;
+            for (int p = threadIdx.x; p < nparts; p += BLOCK) accx = accx + xp[(size_t)p * MAXD + d];
+            accx = wave_sum_f64(accx);
+            __syncthreads();
+            if (lane == 0) sh.red[wvid][2] = llpf_d2u(accx);
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                double t = llpf_u2d(sh.red[0][2]);
+                for (int k = 1; k < BLOCK / 64; ++k) t = t + llpf_u2d(sh.red[k][2]);
+                a.xmean[((size_t)a.row * b.F + f) * b.nx + d] = t * invb;
+            }
+        }
+    }
+    return h;
+}
+
+// Scan of this tile's quanta + ancestor counts.  On return sh.cl[k] = c(bins[k]) for the tile's TILE sources
+// (after a __syncthreads), and [c_start, c_end) is the range of outputs this tile produces.
+template <int STRATEGY>
+DEV void res_counts(const BankDev& b, const ResArgs& a, int f, int tile, const ResHead& h, const ulonglong2* qv,
+                    ResShared& sh, int32_t& c_start, int32_t& c_end) {
+    const FilterScal* sc = b.scal + f;
+    const int64_t N = b.N;
+    const int lane = threadIdx.x & 63, wvid = threadIdx.x >> 6;
+    const int64_t ib = (int64_t)tile * TILE + (int64_t)threadIdx.x * NORM_IPT;
+    uint64_t cq[NORM_IPT];
+    {
+        const uint64_t Qc = h.uniform ? llpf_q64_unit(1.0 / (double)N, a.K) : 0;
+        uint64_t run = 0;
+#pragma unroll
+        for (int k = 0; k < NORM_IPT; ++k) {
+            uint64_t q = h.uniform ? Qc : ((k & 1) ? qv[k / 2].y : qv[k / 2].x);
+            if (ib + k >= N) q = 0;
+            run += q;
+            cq[k] = run;
+        }
+    }
+    const uint64_t tsum = cq[NORM_IPT - 1];
+    const uint64_t incl = wave_scan_u64(tsum);         // wave inclusive scan of thread totals
+    if (lane == 63) sh.red[wvid][3] = incl;
+    __syncthreads();
+    uint64_t wave_off = 0;
+#pragma unroll
+    for (int k = 0; k < BLOCK / 64; ++k)
+        if (k < wvid) wave_off += sh.red[k][3];
+    const uint64_t excl = h.prefix + wave_off + (incl - tsum);
+
+    // bins = fl(fl(cum) * fl(1/fl(total))) and ancestor counts
+    const double Td = (double)h.tot;
+    const double invTd = 1.0 / Td;
+    const double binsN = Td * invTd;                   // bins[N]: 1 or 1 - 2^-53
+    const int32_t M = a.M;
+    uint32_t cnt[NORM_IPT];
+    if (STRATEGY == LLPF_RESAMPLE_SYSTEMATIC) {
+        ThrSys th;
+        const double U = a.Uexp ? a.Uexp[0] : (a.u_from_scal ? sc->u_slot[a.parity] : llpf_uniform_step(a.step, LLPF_STREAM_RESAMPLE, sc->k0, sc->k1));
+        th.M = M; th.Md = (double)M; th.step = 1.0 / (double)M;
+        th.delta = 1e-9 + th.Md * 1e-13;
+        th.r = U * binsN / (double)N;                  // r = rand()*bins[end]/N  (resample.jl:23)
+#pragma unroll
+        for (int k = 0; k < NORM_IPT; ++k) {
+            const double bin = (double)(excl + cq[k]) * invTd;
+            if (a.bins_out && ib + k < N) a.bins_out[(size_t)f * N + ib + k] = bin;
+            cnt[k] = a.only_bins ? 0u : (uint32_t)th.count(bin);
+        }
+        c_start = a.only_bins ? 0 : th.count((double)h.prefix * invTd);
+    } else {
+        ThrStrat th;
+        th.M = M; th.Md = (double)M; th.step = a.step; th.k0 = sc->k0; th.k1 = sc->k1; th.Uexp = a.Uexp;
+        th.delta = 1e-9 + th.Md * 1e-13;
+        th.binsN = binsN;
+#pragma unroll
+        for (int k = 0; k < NORM_IPT; ++k) {
+            const double bin = (double)(excl + cq[k]) * invTd;
+            if (a.bins_out && ib + k < N) a.bins_out[(size_t)f * N + ib + k] = bin;
+            cnt[k] = a.only_bins ? 0u : (uint32_t)th.count(bin);
+        }
+        c_start = a.only_bins ? 0 : th.count((double)h.prefix * invTd);
+    }
+#pragma unroll
+    for (int k = 0; k < NORM_IPT; ++k) sh.cl[threadIdx.x * NORM_IPT + k] = cnt[k];
+    __syncthreads();
+    c_end = (int32_t)sh.cl[TILE - 1];
+}
+
+// output o (c_start <= o < c_end) is produced by the first source k of the tile with cl[k] > o
+DEV int res_owner(const uint32_t* cl, int32_t o) {
+    // branch-free descent in power-of-two steps: p4 = 4 * #{k : cl[k] <= o} (cl is non-decreasing and o < cl[TILE-1]).
+    // The probe address is one VGPR (p4) + an immediate LDS offset, so a step is ds_read + compare + select + add.
+    const uint32_t ov = (uint32_t)o;
+    const char* base = reinterpret_cast<const char*>(cl);
+    uint32_t p4 = 0;
+#pragma unroll
+    for (int step = TILE / 2; step >= 1; step >>= 1) {
+        const uint32_t v = *reinterpret_cast<const uint32_t*>(base + p4 + (uint32_t)(step - 1) * 4u);
+        p4 += (v <= ov) ? (uint32_t)step * 4u : 0u;
+    }
+    return (int)(p4 >> 2);
+}
+static_assert(TILE == 1024, "res_owner assumes 2^10 sources per tile");
+
+template <int STRATEGY, int SRC>
+__global__ __launch_bounds__(BLOCK) void k_resample(BankDev b, ResArgs a) {
+    __shared__ ResShared sh;
+    const int f = blockIdx.y;
+    const int tile = blockIdx.x;
+    if (SRC == SRC_FILTER && run_is_stopped(b, a.k)) return;
+    if (SRC == SRC_FILTER && (a.only_fallback ? !b.scal[f].fallback : (b.scal[f].fallback != 0))) return;
+    const uint64_t* __restrict__ qsrc = b.quanta + (size_t)f * b.Ns;
+    const int64_t ib = (int64_t)tile * TILE + (int64_t)threadIdx.x * NORM_IPT;
+    ulonglong2 qv[NORM_IPT / 2];
+    if (a.mode & RES_RESAMPLE) {
+#pragma unroll
+        for (int k = 0; k < NORM_IPT / 2; ++k) qv[k] = *reinterpret_cast<const ulonglong2*>(qsrc + ib + 2 * k);
+    }
+    const ResHead h = res_head<SRC>(b, a, f, tile, sh);
+    if (!(a.mode & RES_RESAMPLE)) return;
+    if (h.status) return;
+    if (!a.force && !h.dr) return;
+    if (h.tot == 0) return;
+    int32_t c_start, c_end;
+    res_counts<STRATEGY>(b, a, f, tile, h, qv, sh, c_start, c_end);
+    if (a.only_bins) return;
+    int32_t* ao = a.anc_out + (size_t)f * b.Ns;
+    for (int32_t o = c_start + threadIdx.x; o < c_end; o += BLOCK)
+        ao[o] = (int32_t)((int64_t)tile * TILE + res_owner(sh.cl, o));
+    // outputs whose threshold is >= bins[N] are never written by the reference (j keeps its previous
+    // value); the previous value is only materialised here if it was the identity 1:N
+    if (tile == b.P2 - 1 && SRC == SRC_FILTER && b.scal[f].anc_ident_s[b.anc_slot]) {
+        for (int32_t o = c_end + threadIdx.x; o < a.M; o += BLOCK) ao[o] = o;
+    }
+}

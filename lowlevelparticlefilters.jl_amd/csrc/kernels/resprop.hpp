@@ -1,0 +1,280 @@
+// kernels/resprop.hpp — k_resprop, the fused predict!.  Part of kernels.hip (one translation unit, namespace llpf).
+// ------------------------------------------------------------------------------------------------
+// k_resprop — the fused predict!: finalize + shouldresample + resample + propagate [+ weight of the next
+// correct!] in ONE launch.  A block owns a tile of 1024 SOURCE particles; it derives which outputs its sources
+// produce ([c_start, c_end), from the ancestor counts) and propagates exactly those outputs, reading its
+// sources' states (an 8 KB window per dimension: L1/L2 hits) and writing x, w (and j, kept for the accessor and
+// for the reference's "stale j" corner) coalesced.  No ancestor array round trip, no separate propagate launch.
+// Load balance: a tile produces ~1024 outputs +- a few % for i.i.d.-like weights; a tile holding very heavy
+// particles loops over more 256-output chunks (worst case ESS -> 1: one block does everything; still far faster
+// than the serial reference).
+// The per-output arithmetic is the same sequence as k_step's, so fused and unfused paths are bit-identical.
+// ------------------------------------------------------------------------------------------------
+template <class T> DEV T ld_off(const T* base, uint32_t byte_off) {
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+template <class T> DEV void st_off(T* base, uint32_t byte_off, T v) {
+    *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
+
+// placeholder model of the AuxiliaryParticleFilter's second half: the dynamics were applied by k_step<MODE_AUX>
+template <int NX>
+struct NoModel {
+    static constexpr bool RB = false;
+    DEV void prepare(const ModelD*, const double*, double) {}
+    DEV void dynamics(const double* x, double* out) const {
+#pragma unroll
+        for (int d = 0; d < NX; ++d) out[d] = x[d];
+    }
+    DEV void measurement(const double*, double*) const {}
+};
+
+template <class Model, int NX, int NY, bool WEIGHT>
+struct PropCtx {
+    const BankDev& b;
+    const Model& model;
+    const ModelD* md;
+    const StepArgs& st;
+    const double* y;
+    const double* __restrict__ xc;
+    double* __restrict__ xn;
+    double* w;
+    uint32_t k0, k1;
+    int ablate;
+    double off;            // bound of the new weights (offset of their exp-sums)
+    uint64_t* qnext;       // quanta of the new weights
+    // propagate output o from source src with previous log-weight wprev; returns the new log-weight
+    // Addresses are a uniform plane base (SGPRs) + a 32-bit byte offset (one VGPR): Ns * 8 < 2^32 is checked at create.
+    DEV double one(uint32_t src, uint32_t o, double wprev, bool& bad, double* xs) const {
+        const int64_t Ns = b.Ns;
+        const uint32_t so = src << 3, oo = o << 3;
+        double xp[NX], fx[NX], xi[NX], nz[NX];
+#pragma unroll
+        for (int d = 0; d < NX; ++d) xp[d] = ld_off(xc + (size_t)d * Ns, so);
+#ifdef LLPF_DEVTOOLS   /* ablation switches for performance experiments (results invalid); not in production builds */
+        if (!(ablate & 4)) model.dynamics(xp, fx);
+        else { for (int d = 0; d < NX; ++d) fx[d] = xp[d]; }
+        if (!(ablate & 1)) llpf_normals(o, st.step, LLPF_STREAM_DYNAMICS, k0, k1, NX, xi);
+        else { for (int d = 0; d < NX; ++d) xi[d] = 0.25 * (double)(o & 7); }
+#else
+        model.dynamics(xp, fx);
+        llpf_normals(o, st.step, LLPF_STREAM_DYNAMICS, k0, k1, NX, xi);
+#endif
+        gauss_sample<NX>(md->df, xi, nz);
+#pragma unroll
+        for (int d = 0; d < NX; ++d) {
+            xs[d] = fx[d] + nz[d];
+            st_off(xn + (size_t)d * Ns, oo, xs[d]);
+        }
+        double wv = wprev;
+        if (WEIGHT) {
+#ifdef LLPF_DEVTOOLS
+            if (st.has_y && !(ablate & 4)) {
+#else
+            if (st.has_y) {
+#endif
+                double g[NY], v[NY];
+                model.measurement(xs, g);
+#pragma unroll
+                for (int k = 0; k < NY; ++k) v[k] = y[k] - g[k];
+                wv = wv + gauss_logpdf<NY>(md->dg, v);
+            }
+            if (o >= (uint32_t)b.N) wv = -LLPF_INF;
+            bad = bad || (wv != wv);
+            st_off(w, oo, wv);
+        }
+        return wv;
+    }
+};
+
+// per-thread running sum of quanta keyed by destination tile; flushed to LDS (first 8 tiles of the block's output
+// range) or straight to the global tile sums (heavier blocks) whenever the tile changes
+struct TileSum {
+    int32_t tcur;
+    uint64_t run;
+    DEV void init() { tcur = -1; run = 0; }
+    DEV void flush(uint64_t* sh_tq, uint64_t* tq_global, int32_t tbase) {
+        if (run) {
+            const int32_t idx = tcur - tbase;
+            if (idx >= 0 && idx < 8) atomicAdd(reinterpret_cast<unsigned long long*>(sh_tq + idx), (unsigned long long)run);
+            else atomicAdd(reinterpret_cast<unsigned long long*>(tq_global + tcur), (unsigned long long)run);
+        }
+        run = 0;
+    }
+    DEV void add(uint32_t o, uint64_t q, uint64_t* sh_tq, uint64_t* tq_global, int32_t tbase) {
+        const int32_t t = (int32_t)(o >> 10);
+        if (t != tcur) { flush(sh_tq, tq_global, tbase); tcur = t; }
+        run += q;
+    }
+};
+static_assert(TILE == 1024, "TileSum assumes 1024-particle tiles");
+
+template <class Model, int NX, int NY, bool WEIGHT, bool ACC, bool AUX = false>
+__global__ __launch_bounds__(BLOCK) void k_resprop(BankDev b, const ModelD* __restrict__ models, ResArgs a, StepArgs st) {
+    __shared__ ResShared sh;
+    __shared__ double sm_max[BLOCK / 64];
+    __shared__ uint64_t sm_acc[BLOCK / 64][5];
+    __shared__ uint64_t sh_tq[8];
+    __shared__ double sm_x[BLOCK / 64][MAXD];
+    const int f = blockIdx.y;
+    const int tile = blockIdx.x;
+    const int64_t Ns = b.Ns;
+    const ModelD* md = models + f;
+    FilterScal* sc = b.scal + f;
+    const uint32_t stop_flag = *b.bank_flag;           // tested in res_head, after all other loads are in flight
+    const int fb_flag = sc->fallback;
+    if (threadIdx.x < 8) sh_tq[threadIdx.x] = 0;
+    const uint64_t* __restrict__ qsrc = b.quanta + (size_t)f * Ns;
+    const int64_t ib = (int64_t)tile * TILE + (int64_t)threadIdx.x * NORM_IPT;
+    ulonglong2 qv[NORM_IPT / 2];
+#pragma unroll
+    for (int k = 0; k < NORM_IPT / 2; ++k) qv[k] = *reinterpret_cast<const ulonglong2*>(qsrc + ib + 2 * k);
+    const int anc_ident_prev = sc->anc_ident_s[b.anc_slot];   // this launch writes the other entry
+#define LLPF_STAMP(i) if (a.dbg && threadIdx.x == 0 && f == 0) a.dbg[(size_t)tile * 8 + (i)] = wall_clock64()
+    LLPF_STAMP(0);
+    Model model;                                       // particle-independent terms: their loads overlap the head's
+    model.prepare(md, st.u, st.t_prop);
+    double y[NY];
+#pragma unroll
+    for (int k = 0; k < NY; ++k) y[k] = (WEIGHT && st.has_y) ? st.y[k] : 0.0;
+    const uint32_t key0 = sc->k0, key1 = sc->k1;
+    const ResHead h = res_head<SRC_FILTER>(b, a, f, tile, sh, true, stop_flag, fb_flag);
+    if (h.status) return;
+    LLPF_STAMP(1);
+    PropCtx<Model, NX, NY, WEIGHT> pc{b, model, md, st, y, b.xcur + (size_t)f * NX * Ns, b.xnext + (size_t)f * NX * Ns,
+                                      b.w + (size_t)f * Ns, key0, key1, a.ablate, 0.0, b.quanta_next + (size_t)f * Ns};
+    int32_t* anc = b.anc + (size_t)f * Ns;
+    double bmax = -LLPF_INF;
+    bool bad = false;
+
+    // One loop over the outputs this block produces (the per-output body is instantiated once):
+    //   resampling : outputs [c_start, c_end) from the ancestor counts, source = tile's owner of the output;
+    //                the last tile also takes [c_end, M): thresholds >= bins[N], for which the reference leaves
+    //                j[i] untouched (resample.jl:25-34) -> previous ancestor (identity if the last predict! did
+    //                not resample)
+    //   otherwise  : s.j .= 1:N, the tile's own particles (padding lanes included so that their weight stays -Inf)
+    const bool res = (h.dr || a.force) && h.tot != 0;
+    int64_t first, last;
+    int32_t c_end = 0;
+    double l = 0.0;
+    WeightAcc wacc;
+    TileSum ts;
+    wacc.init();
+    ts.init();
+    double xm[NX];
+#pragma unroll
+    for (int d = 0; d < NX; ++d) xm[d] = 0.0;
+    uint64_t* tq_next = tileq_slot(b, st.parity, f);
+    if (res) {
+        int32_t c_start;
+        if (b.strategy == LLPF_RESAMPLE_SYSTEMATIC) res_counts<LLPF_RESAMPLE_SYSTEMATIC>(b, a, f, tile, h, qv, sh, c_start, c_end);
+        else res_counts<LLPF_RESAMPLE_STRATIFIED>(b, a, f, tile, h, qv, sh, c_start, c_end);
+        first = c_start;
+        last = (tile == b.P2 - 1) ? (int64_t)a.M : (int64_t)c_end;
+    } else {
+        l = head_log(h);
+        first = (int64_t)tile * TILE;
+        last = first + TILE;
+    }
+    {   // bound of the weights produced below: max of the previous (normalised) weights + the density's peak
+        const double wmx = res ? b.log1N : (h.mtrue - h.a) - l;
+        pc.off = (WEIGHT && st.has_y) ? wmx + md->dg.c0 : wmx;
+    }
+    const double lN = -b.mlogN;
+    const double aux_off = ((st.aux == 2) ? md->dg.c0 : 0.0) - lN;     // lambda - log N <= c0 - log N (lambda = 0 if y1 is missing)
+    if (AUX) pc.off = aux_off;
+    const double* lamp = AUX ? b.lam + (size_t)f * Ns : nullptr;
+    const int32_t tbase = (int32_t)(first >> 10);
+    LLPF_STAMP(2);
+    if (a.dbg && threadIdx.x == 0 && f == 0) a.dbg[(size_t)tile * 8 + 5] = (uint64_t)(last - first);
+    const uint32_t tile0 = (uint32_t)tile * TILE, ulast = (uint32_t)last, ucend = (uint32_t)c_end;
+#pragma unroll 1
+    for (uint32_t o = (uint32_t)first + threadIdx.x; o < ulast; o += BLOCK) {
+        uint32_t src = o;
+        double wprev = b.log1N;                                        // reset_weights!: w = log(1/N)
+        if (res) {
+#ifdef LLPF_DEVTOOLS
+            if (o < ucend) src = tile0 + ((a.ablate & 2) ? ((o - (uint32_t)first) & (TILE - 1)) : (uint32_t)res_owner(sh.cl, (int32_t)o));
+#else
+            if (o < ucend) src = tile0 + (uint32_t)res_owner(sh.cl, (int32_t)o);
+#endif
+            else src = anc_ident_prev ? o : (uint32_t)ld_off(anc, o << 2);
+            st_off(anc, o << 2, (int32_t)src);
+            if (AUX) wprev = ld_off(lamp, o << 3) - lN;               // s.w[i] = lambda[i] - log N (unresampled index, filtering.jl:209-213)
+        } else if (AUX) {
+            wprev = ld_off(lamp, o << 3) - lN;
+        } else if (WEIGHT) {
+            wprev = (ld_off(pc.w, o << 3) - h.a) - l;                  // lazy w .-= offset ; w .-= log(sum)
+        }
+        double xs[NX];
+        const double wv = pc.one(src, o, wprev, bad, xs);
+        bmax = llpf_fmax(bmax, wv);
+        if (WEIGHT && ACC) {
+            double e;
+            const uint64_t q = wacc.add(wv, pc.off, st.K, st.need_e2 != 0, &e);
+            st_off(pc.qnext, o << 3, q);
+            ts.add(o, q, sh_tq, tq_next, tbase);
+            if (st.want_xmean) {
+#pragma unroll
+                for (int d = 0; d < NX; ++d) xm[d] = xm[d] + xs[d] * e;
+            }
+        }
+    }
+    if (WEIGHT && ACC) ts.flush(sh_tq, tq_next, tbase);
+    LLPF_STAMP(3);
+    if (WEIGHT) {
+        const double r = block_max(bmax, sm_max);
+        const int anybad = __syncthreads_or(bad ? 1 : 0);
+        if (threadIdx.x == 0) acc_max(b.acc + (size_t)f * ACC_WORDS, st.parity, r, anybad != 0);
+        if (ACC) {
+            wacc.flush(b.acc + (size_t)f * ACC_WORDS, st.parity, st.need_e2 != 0, sm_acc);
+            __syncthreads();
+            if (threadIdx.x < 8 && sh_tq[threadIdx.x])
+                atomicAdd(reinterpret_cast<unsigned long long*>(tq_next + tbase + threadIdx.x), (unsigned long long)sh_tq[threadIdx.x]);
+            if (st.want_xmean) block_store_xm<NX>(xm, b.xmpart + ((size_t)f * b.P1 + tile) * MAXD, sm_x);
+        }
+        if (tile == 0 && threadIdx.x == 0) {
+            if (AUX) {     // the weights just written are final values (no pending normalisation); aux_off bounds them
+                sc->norm_pending = 0;
+                sc->uniform = 0;
+                sc->wmax = aux_off;
+            }
+            if (ACC) sc->xm_parts = b.P2;
+            sc->off_slot[st.parity] = pc.off;
+            sc->e2v_slot[st.parity] = st.need_e2;
+            sc->u_slot[st.parity] = llpf_uniform_step(st.next_step, LLPF_STREAM_RESAMPLE, sc->k0, sc->k1);
+        }
+    }
+    __syncthreads();
+    LLPF_STAMP(4);
+#undef LLPF_STAMP
+    if (tile == b.P2 - 1 && threadIdx.x == 0) {        // bookkeeping of this predict! (by the only block that reads anc_ident)
+        const int r = res ? 1 : 0;
+        sc->anc_ident_s[b.anc_slot ^ 1] = r ? 0 : 1;
+        sc->last_resampled = r;
+        sc->resample_count += r;
+    }
+}
+
+// per-tile sums of the quanta of plain values (standalone resample(we))
+__global__ __launch_bounds__(BLOCK) void k_qpart(BankDev b, int K) {
+    __shared__ uint64_t sm_w[BLOCK / 64];
+    const int f = blockIdx.y, tile = blockIdx.x;
+    const double* __restrict__ w = b.w + (size_t)f * b.Ns;
+    uint64_t Q = 0;
+#pragma unroll
+    for (int k = 0; k < NORM_IPT; ++k) {
+        const int64_t i = (int64_t)tile * TILE + (int64_t)k * BLOCK + threadIdx.x;
+        const uint64_t q = (i < b.N) ? llpf_q64_unit(w[i], K) : 0;
+        b.quanta[(size_t)f * b.Ns + i] = q;
+        Q += q;
+    }
+    Q = wave_sum_u64(Q);
+    if ((threadIdx.x & 63) == 0) sm_w[threadIdx.x >> 6] = Q;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t q = 0;
+        for (int k = 0; k < BLOCK / 64; ++k) q += sm_w[k];
+        tileq_slot(b, 0, f)[tile] = q;      // scratch bank of the standalone resample(we): slot 0
+    }
+}

@@ -1,0 +1,242 @@
+// kernels/step.hpp — k_step (balanced propagate + weight) and k_max.  Part of kernels.hip (one translation unit, namespace llpf).
+// ------------------------------------------------------------------------------------------------
+// k_step — fused propagate + weight + running max
+// ------------------------------------------------------------------------------------------------
+template <class Model, int NX, int NY, int MODE>
+__global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restrict__ models,
+                                                 const FilterScal* scal, StepArgs a) {
+    __shared__ double sm_max[BLOCK / 64];
+    __shared__ uint64_t sm_acc[BLOCK / 64][5];
+    __shared__ double sm_x[BLOCK / 64][MAXD];
+    const int f = blockIdx.y;
+    const ModelD* md = models + f;
+    const FilterScal* sc = scal + f;
+    if (run_is_stopped(b, a.k)) return;
+    if (a.only_fallback ? !sc->fallback : (sc->fallback != 0)) return;   // redo launches take the flagged filters, all others skip them
+    const int do_res = (MODE != MODE_WEIGHT && MODE != MODE_AUX) ? sc->do_resample : 0;
+    const int uniform = sc->uniform, pend = sc->norm_pending;
+    const double m = sc->m, l = sc->l, wconst = sc->wconst;
+    const uint32_t k0 = sc->k0, k1 = sc->k1;
+    const int64_t Ns = b.Ns, N = b.N;
+    const double* __restrict__ xc = b.xcur + (size_t)f * NX * Ns;
+    double* __restrict__ xn = b.xnext + (size_t)f * NX * Ns;
+    double* w = b.w + (size_t)f * Ns;
+    const int32_t* __restrict__ anc = b.anc + (size_t)f * Ns;
+
+
+    Model model;
+    model.prepare(md, a.u, a.t_prop);
+    double y[NY];
+    if (MODE != MODE_PROP) {
+#pragma unroll
+        for (int k = 0; k < NY; ++k) y[k] = a.has_y ? a.y[k] : 0.0;
+    }
+
+    double bmax = -LLPF_INF;
+    bool bad = false;
+    // bound of the weights this kernel produces: max of the previous (normalised) weights + the density's peak
+    double off = 0.0;
+    WeightAcc wacc;
+    uint64_t qsum = 0;
+    double xm[NX];
+#pragma unroll
+    for (int d = 0; d < NX; ++d) xm[d] = 0.0;
+    if (MODE != MODE_PROP) {
+        const double wmx = do_res ? b.log1N : (uniform ? wconst : sc->wmax);
+        double c0w = md->dg.c0;
+        if constexpr (Model::RB) { if (!md->rb_zeroC) c0w = (a.rb_corr + f)->dS.c0; }   // peak of N(0, S) of this correct!
+        off = a.has_y ? wmx + c0w : wmx;
+        wacc.init();
+    }
+#pragma unroll 1
+    for (int it = 0; it < STEP_ITERS; ++it) {
+        const int64_t i0 = ((int64_t)blockIdx.x * STEP_ITERS + it) * (BLOCK * STEP_PPT) + (int64_t)threadIdx.x * STEP_PPT;
+        double xs[STEP_PPT][NX];
+        if (MODE != MODE_WEIGHT) {
+            double xp[STEP_PPT][NX];
+            if (do_res) {
+                const int2 av = *reinterpret_cast<const int2*>(anc + i0);
+#pragma unroll
+                for (int d = 0; d < NX; ++d) {
+                    xp[0][d] = xc[(size_t)d * Ns + av.x];
+                    xp[1][d] = xc[(size_t)d * Ns + av.y];
+                }
+            } else {
+#pragma unroll
+                for (int d = 0; d < NX; ++d) {
+                    const double2 v = *reinterpret_cast<const double2*>(xc + (size_t)d * Ns + i0);
+                    xp[0][d] = v.x;
+                    xp[1][d] = v.y;
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < STEP_PPT; ++p) {
+                if constexpr (Model::RB) {
+                    model.rb_propagate(xp[p], (uint32_t)(i0 + p), a.step, k0, k1, a.rb_pred + f, xs[p]);
+                    continue;
+                }
+                double fx[NX], xi[NX], nz[NX];
+                model.dynamics(xp[p], fx);
+                if (MODE == MODE_AUX) {            // propagate_particles!(pf, u, p, t, nothing): no noise
+#pragma unroll
+                    for (int d = 0; d < NX; ++d) xs[p][d] = fx[d];
+                } else {
+                    llpf_normals((uint32_t)(i0 + p), a.step, LLPF_STREAM_DYNAMICS, k0, k1, NX, xi);
+                    gauss_sample<NX>(md->df, xi, nz);
+#pragma unroll
+                    for (int d = 0; d < NX; ++d) xs[p][d] = fx[d] + nz[d];
+                }
+            }
+            if (!(Model::RB && MODE == MODE_PROP_WEIGHT && a.has_y)) {
+#pragma unroll
+                for (int d = 0; d < NX; ++d) {
+                    double2 v;
+                    v.x = xs[0][d];
+                    v.y = xs[1][d];
+                    *reinterpret_cast<double2*>(xn + (size_t)d * Ns + i0) = v;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int d = 0; d < NX; ++d) {
+                const double2 v = *reinterpret_cast<const double2*>(xc + (size_t)d * Ns + i0);
+                xs[0][d] = v.x;
+                xs[1][d] = v.y;
+            }
+        }
+        if (MODE != MODE_PROP) {
+            double wp[STEP_PPT];
+            if (do_res) {                          // reset_weights!: w = log(1/N)
+                wp[0] = b.log1N;
+                wp[1] = b.log1N;
+            } else if (uniform) {
+                wp[0] = wconst;
+                wp[1] = wconst;
+            } else {
+                const double2 wv = *reinterpret_cast<const double2*>(w + i0);
+                wp[0] = pend ? (wv.x - m) - l : wv.x;  // lazy w .-= offset ; w .-= log1p(s)
+                wp[1] = pend ? (wv.y - m) - l : wv.y;
+            }
+            double wn[STEP_PPT];
+            double lamv[STEP_PPT];
+#pragma unroll
+            for (int p = 0; p < STEP_PPT; ++p) {
+                double wv = wp[p];
+                if (MODE == MODE_AUX) {            // lambda .= 0; lambda += logpdf; w .+= lambda  (filtering.jl:201-204)
+                    double lam = 0.0;
+                    if (a.has_y) {
+                        double g[NY], v[NY];
+                        model.measurement(xs[p], g);
+#pragma unroll
+                        for (int k = 0; k < NY; ++k) v[k] = y[k] - g[k];
+                        lam = lam + gauss_logpdf<NY>(md->dg, v);
+                    }
+                    lamv[p] = lam;
+                    wv = wv + lam;
+                } else if (a.has_y) {
+                    if constexpr (Model::RB) {
+                        wv = wv + model.rb_weight(xs[p], y, a.rb_corr + f, i0 + p == 0);
+                    } else {
+                        double g[NY], v[NY];
+                        model.measurement(xs[p], g);
+#pragma unroll
+                        for (int k = 0; k < NY; ++k) v[k] = y[k] - g[k];
+                        wv = wv + gauss_logpdf<NY>(md->dg, v);
+                    }
+                }
+                if (i0 + p >= N) wv = -LLPF_INF;   // padding lanes carry zero weight
+                wn[p] = wv;
+                bad = bad || (wv != wv);
+                bmax = llpf_fmax(bmax, wv);
+            }
+            double2 wo;
+            wo.x = wn[0];
+            wo.y = wn[1];
+            *reinterpret_cast<double2*>(w + i0) = wo;
+            if constexpr (Model::RB) {             // correct! has updated xl (Kalman measurement update)
+                if (a.has_y) {
+                    double* xdst = (MODE == MODE_WEIGHT) ? const_cast<double*>(xc) : xn;
+#pragma unroll
+                    for (int d = 0; d < NX; ++d) {
+                        double2 v;
+                        v.x = xs[0][d];
+                        v.y = xs[1][d];
+                        *reinterpret_cast<double2*>(xdst + (size_t)d * Ns + i0) = v;
+                    }
+                }
+            }
+            if (MODE == MODE_AUX) {
+                double2 lo;
+                lo.x = lamv[0];
+                lo.y = lamv[1];
+                *reinterpret_cast<double2*>(b.lam + (size_t)f * Ns + i0) = lo;
+            }
+            if (a.accumulate) {   // merged schedule: exp-sums, quanta and tile sums of the new weights formed here
+                ulonglong2 qv;
+                double e0, e1;
+                qv.x = wacc.add(wn[0], off, a.K, a.need_e2 != 0, &e0);
+                qv.y = wacc.add(wn[1], off, a.K, a.need_e2 != 0, &e1);
+                *reinterpret_cast<ulonglong2*>(b.quanta_next + (size_t)f * Ns + i0) = qv;
+                qsum += qv.x + qv.y;
+                if (a.want_xmean) {
+#pragma unroll
+                    for (int d = 0; d < NX; ++d) { xm[d] = xm[d] + xs[0][d] * e0; xm[d] = xm[d] + xs[1][d] * e1; }
+                }
+            }
+        }
+    }
+    if (MODE != MODE_PROP) {
+        const double r = block_max(bmax, sm_max);
+        const int anybad = __syncthreads_or(bad ? 1 : 0);
+        if (threadIdx.x == 0) acc_max(b.acc + (size_t)f * ACC_WORDS, a.parity, r, anybad != 0);
+        if (a.accumulate) wacc.flush(b.acc + (size_t)f * ACC_WORDS, a.parity, a.need_e2 != 0, sm_acc);
+        if (a.accumulate && a.want_xmean) block_store_xm<NX>(xm, b.xmpart + ((size_t)f * b.P1 + blockIdx.x) * MAXD, sm_x);
+        // all particles of this block lie in one 1024-particle tile
+        qsum = wave_sum_u64(qsum);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) sm_acc[threadIdx.x >> 6][0] = qsum;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint64_t q = 0;
+            for (int k = 0; k < BLOCK / 64; ++k) q += sm_acc[k][0];
+            const int64_t tile = ((int64_t)blockIdx.x * STEP_TILE) / TILE;
+            if (q) atomicAdd(reinterpret_cast<unsigned long long*>(tileq_slot(b, a.parity, f) + tile), (unsigned long long)q);
+            if (blockIdx.x == 0) {
+                FilterScal* scw = b.scal + f;
+                if (a.accumulate) scw->xm_parts = b.P1;
+                scw->off_slot[a.parity] = off;
+                scw->e2v_slot[a.parity] = a.need_e2;
+                scw->u_slot[a.parity] = llpf_uniform_step(a.next_step, LLPF_STREAM_RESAMPLE, k0, k1);
+            }
+        }
+    }
+    if (MODE != MODE_WEIGHT && MODE != MODE_AUX && blockIdx.x == 0 && threadIdx.x == 0) {
+        // bookkeeping of this predict! (fields no block of this kernel reads): state.j == 1:N unless resampled
+        FilterScal* scw = b.scal + f;
+        scw->anc_ident_s[b.anc_slot ^ 1] = do_res ? 0 : 1;
+        scw->last_resampled = do_res;
+        scw->resample_count += do_res;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_max — maxima of the raw log-weights (when no weighting kernel produced them: llpf_set_weights,
+// llpf_logsumexp); also zeroes the sum accumulators like a weighting kernel does
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_max(BankDev b, int parity) {
+    __shared__ double sm_max[BLOCK / 64];
+    const int f = blockIdx.y;
+    const double* w = b.w + (size_t)f * b.Ns;
+    double bmax = -LLPF_INF;
+    bool bad = false;
+#pragma unroll
+    for (int it = 0; it < STEP_ITERS; ++it) {
+        const int64_t i0 = ((int64_t)blockIdx.x * STEP_ITERS + it) * (BLOCK * STEP_PPT) + (int64_t)threadIdx.x * STEP_PPT;
+        const double2 wv = *reinterpret_cast<const double2*>(w + i0);
+        if (i0 < b.N) { bmax = llpf_fmax(bmax, wv.x); bad = bad || (wv.x != wv.x); }
+        if (i0 + 1 < b.N) { bmax = llpf_fmax(bmax, wv.y); bad = bad || (wv.y != wv.y); }
+    }
+    const double r = block_max(bmax, sm_max);
+    const int anybad = __syncthreads_or(bad ? 1 : 0);
+    if (threadIdx.x == 0) acc_max(b.acc + (size_t)f * ACC_WORDS, parity, r, anybad != 0);
+}
