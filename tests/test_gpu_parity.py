@@ -5,8 +5,6 @@
  * against the REFERENCE-ORDER oracle (literal restatement) floating point must agree to the stated
    tolerances and ancestor indices may differ only at ulp-level ties (counted and bounded).
 """
-import ctypes as C
-
 import numpy as np
 import pytest
 
@@ -14,16 +12,9 @@ import llpf_amd
 from llpf_amd import _capi, _structs as S
 import models as M
 import oracle_binding as ob
+from gpu_common import TOL_LL_STEP, TOL_LL_SUM, TOL_WE_REL, cfg_of as _cfg, compare_state as _compare_state
 
 pytestmark = pytest.mark.gpu
-
-TOL_LL_STEP = 1e-10      # per-step |ll_gpu - ll_ref_order|   
-TOL_LL_SUM = 1e-8        # cumulative
-TOL_WE_REL = 1e-12       # max relative error of exp-weights vs reference order
-
-
-def _cfg(model, N, strategy=S.RESAMPLE_SYSTEMATIC, thr=0.1, seed=7, kind=S.PARTICLE_FILTER):
-    return S.make_config(model, N, kind, strategy, thr, seed, 0)
 
 
 def test_device_math_bit_identical_to_host():
@@ -54,20 +45,6 @@ def test_device_normals_bit_identical_to_host():
         dev = _capi.selftest_normals(12345, 17, 1, nd, 100000)
         assert np.array_equal(host.view(np.uint64), dev.view(np.uint64))
     assert abs(dev.mean()) < 0.01 and abs(dev.var() - 1.0) < 0.01
-
-
-def _compare_state(g, o, exact=True, we_rtol=0.0):
-    xg, xo = g.particles(), o.particles()
-    wg, wo = g.weights(), o.weights()
-    eg, eo = g.expweights(), o.expweights()
-    if exact:
-        assert np.array_equal(xg.view(np.uint64), xo.view(np.uint64)), "particles differ"
-        assert np.array_equal(wg.view(np.uint64), wo.view(np.uint64)), "log-weights differ"
-        assert np.array_equal(eg.view(np.uint64), eo.view(np.uint64)), "exp-weights differ"
-        assert np.array_equal(g.ancestors(), o.ancestors()), "ancestors differ"
-    else:
-        np.testing.assert_allclose(xg, xo, rtol=1e-12, atol=1e-12)
-        np.testing.assert_allclose(eg, eo, rtol=we_rtol, atol=1e-300)
 
 
 @pytest.mark.parametrize("strategy", [S.RESAMPLE_SYSTEMATIC, S.RESAMPLE_STRATIFIED])
@@ -606,314 +583,3 @@ def test_launches_larger_than_the_resident_set(schedule, monkeypatch):
     ro = o.run(U[:8], Y[:8], 1.0, ll_steps=True)
     assert np.array_equal(rg["ll_steps"].view(np.uint64), ro["ll_steps"].view(np.uint64))
     assert g.resample_count() == o.resample_count() >= 1
-
-
-# ---- AuxiliaryParticleFilter (reference src/filtering.jl:170-217, 367-384; smoothing.jl:232-236) -------------------
-@pytest.mark.parametrize("strategy", [S.RESAMPLE_SYSTEMATIC, S.RESAMPLE_STRATIFIED])
-def test_aux_filter_single_steps_bit_exact(strategy):
-    """correct! / predict! of the auxiliary filter step by step: ll, particles, log-weights, lambda (the reference's
-    `we` after predict!), ancestors — bit-identical to the device-order oracle; a missing look-ahead measurement."""
-    model = M.lg_c1_model()
-    _, U, Y = M.simulate_lg(model, 30)
-    cfg = _cfg(model, 3000, strategy, 0.1, seed=31)
-    g = _capi.FilterHandle(cfg)
-    o = ob.OracleFilter(cfg, ob.ORDER_DEVICE)
-    g.reset(); o.reset()
-    for k in range(12):
-        ll_g, ll_o = g.aux_correct(), o.aux_correct()
-        assert np.float64(ll_g).view(np.uint64) == np.float64(ll_o).view(np.uint64), k
-        _compare_state(g, o)
-        y1 = None if k == 5 else Y[k + 1]
-        g.aux_predict(U[k], y1, k * 1.0); o.aux_predict(U[k], y1, k * 1.0)
-        _compare_state(g, o)                      # w = lambda - log N, expweights = lambda, j, x
-        assert g.index() == o.index()
-    # the wrapped filter's update! on the same state (the last step of loglik, src/smoothing.jl:235)
-    ll_g, ll_o = g.update(U[12], Y[12], 12.0), o.update(U[12], Y[12], 12.0)
-    assert ll_g == ll_o
-    _compare_state(g, o)
-
-
-@pytest.mark.parametrize("mode", [0, 1])
-def test_aux_filter_trajectories(mode):
-    """forward_trajectory (mode 0, with history) and loglik (mode 1) loops of the auxiliary filter: bit-identical to
-    the device-order oracle, within tolerance of the reference-order one; includes an outlier (exact-max redo of
-    both normalisations) and a missing measurement."""
-    model = M.lg_test_model(0.1)
-    _, U, Y = M.simulate_lg(model, 60, seed=5)
-    Y = Y.copy()
-    Y[23] += 11.0
-    Y[40] = np.nan
-    cfg = _cfg(model, 4000, S.RESAMPLE_SYSTEMATIC, 0.1, seed=33)
-    g = _capi.FilterHandle(cfg); o = ob.OracleFilter(cfg, ob.ORDER_DEVICE); r = ob.OracleFilter(cfg, ob.ORDER_REFERENCE)
-    for h in (g, o, r):
-        h.reset()
-    hist = mode == 0
-    rg = g.run_aux(U, Y, mode, ll_steps=True, xmean=hist, history=hist)
-    ro = o.run_aux(U, Y, mode, ll_steps=True, xmean=hist, history=hist)
-    rr = r.run_aux(U, Y, mode, ll_steps=True)
-    assert np.array_equal(rg["ll_steps"].view(np.uint64), ro["ll_steps"].view(np.uint64))
-    assert rg["ll"] == ro["ll"]
-    assert o.exact_steps() >= 1
-    _compare_state(g, o)
-    if hist:
-        for key in ("x", "w", "we"):
-            assert np.array_equal(rg[key].view(np.uint64), ro[key].view(np.uint64)), key
-        np.testing.assert_allclose(rg["xmean"], ro["xmean"], rtol=1e-9, atol=1e-11)
-    assert np.max(np.abs(rg["ll_steps"] - rr["ll_steps"])) <= TOL_LL_STEP
-    assert g.resample_count() == o.resample_count()
-
-
-def test_aux_filter_api_and_kalman():
-    """The reference-shaped API (AuxiliaryParticleFilter(N, dynamics, ...), pfa(u, y, y1), loglik, forward_trajectory)
-    and the reference's statistical check: |ll_KF - ll_APF| < 20 at N = 1000, T = 2000 (test/runtests.jl:446)."""
-    A = np.array([[0.97043, -0.097368], [0.09736, 0.970437]]); B = np.array([[0.1], [0.0]]); Cm = np.array([[0.0, 1.0]])
-    df = llpf_amd.MvNormal(np.zeros(2), 0.1 ** 2); dg = llpf_amd.MvNormal(np.zeros(1), np.ones(1)); d0 = llpf_amd.MvNormal([0.3, -0.5], 4.0)
-    pfa = llpf_amd.AuxiliaryParticleFilter(1000, llpf_amd.LinearDynamics(A, B), llpf_amd.LinearMeasurement(Cm), df, dg, d0, rng=5)
-    assert not llpf_amd.shouldresample(pfa)
-    model = M.lg_test_model(0.1)
-    _, U, Y = M.simulate_lg(model, 2000, seed=3)
-    ll = llpf_amd.loglik(pfa, U, Y)
-    assert abs(ll - ob.kalman_loglik(model, U, Y)) < 20
-    llpf_amd.reset(pfa)
-    l0, _ = pfa(U[0], Y[0], Y[1])
-    assert abs(l0) < 1e-12 and llpf_amd.index(pfa) == 2
-    sol = llpf_amd.forward_trajectory(pfa, U[:20], Y[:20])
-    assert sol.x.shape == (20, 1000, 2) and np.allclose(sol.we.sum(axis=1), 1.0)
-
-
-def test_aux_filter_bank():
-    """Bank of auxiliary filters (the ML sweep of test/runtests.jl:419-423) == the filters run one at a time."""
-    models = [M.lg_test_model(s) for s in (0.05, 0.1, 0.2, 0.4)]
-    _, U, Y = M.simulate_lg(models[1], 40)
-    Y = Y.copy(); Y[17] += 9.0
-    N = 3000
-    bank = _capi.BankHandle(_cfg(models[0], N, thr=0.1, seed=950), models)
-    bank.reset()
-    rb = bank.run_aux(U, Y, mode=1, ll_steps=True)
-    for k, mk in enumerate(models):
-        o = ob.OracleFilter(_cfg(mk, N, thr=0.1, seed=950 + k), ob.ORDER_DEVICE)
-        o.reset()
-        ro = o.run_aux(U, Y, mode=1, ll_steps=True)
-        assert np.array_equal(ro["ll_steps"].view(np.uint64), rb["ll_steps"][:, k].copy().view(np.uint64)), k
-
-
-def test_aux_filter_async_run_with_several_outliers():
-    """The asynchronous loglik / forward loop of the auxiliary filter (all launches enqueued, one poll): outliers that
-    make the look-ahead normalisation AND the next correct! fall back to the exact-max form, several times per run,
-    in a bank where only some filters are affected; T = 1 and T = 2 edge cases."""
-    models = [M.lg_test_model(s) for s in (0.03, 0.1, 0.3)]
-    _, U, Y = M.simulate_lg(models[1], 80, seed=8)
-    Y = Y.copy()
-    Y[10] += 12.0; Y[11] -= 9.0; Y[50] += 15.0; Y[51] = np.nan; Y[79] += 10.0
-    N = 2500
-    for mode in (0, 1):
-        bank = _capi.BankHandle(_cfg(models[0], N, S.RESAMPLE_STRATIFIED, 0.1, seed=77), models)
-        bank.reset()
-        rb = bank.run_aux(U, Y, mode=mode, ll_steps=True)
-        n_exact = 0
-        for k, mk in enumerate(models):
-            o = ob.OracleFilter(_cfg(mk, N, S.RESAMPLE_STRATIFIED, 0.1, seed=77 + k), ob.ORDER_DEVICE)
-            o.reset()
-            ro = o.run_aux(U, Y, mode=mode, ll_steps=True)
-            n_exact += o.exact_steps()
-            assert np.array_equal(ro["ll_steps"].view(np.uint64), rb["ll_steps"][:, k].copy().view(np.uint64)), (mode, k)
-            assert ro["ll"] == rb["ll"][k]
-        assert n_exact >= 4
-    for T in (1, 2):
-        for mode in (0, 1):
-            cfg = _cfg(models[1], 1000, seed=5)
-            g = _capi.FilterHandle(cfg); o = ob.OracleFilter(cfg, ob.ORDER_DEVICE)
-            g.reset(); o.reset()
-            rg = g.run_aux(U[:T], Y[:T], mode, ll_steps=True); ro = o.run_aux(U[:T], Y[:T], mode, ll_steps=True)
-            assert np.array_equal(rg["ll_steps"].view(np.uint64), ro["ll_steps"].view(np.uint64)), (T, mode)
-            _compare_state(g, o)
-
-
-# ---- residual resampling (reference src/resample.jl:63-117) ---------------------------------------------------------
-@pytest.mark.parametrize("n,m", [(10, 10), (9, 9), (1000, 1000), (5000, 5000), (4097, 300), (300, 4097), (100000, 100000)])
-def test_standalone_residual_resample_matches_oracle(n, m):
-    rng = np.random.default_rng(n + m)
-    we = rng.exponential(size=n) ** 3
-    we /= we.sum()
-    U = rng.uniform(size=m)
-    j0 = np.full(m, 5, dtype=np.int64)
-    jg = _capi.resample(S.RESAMPLE_RESIDUAL, we, U, m, j0)
-    jd, _ = ob.resample(S.RESAMPLE_RESIDUAL, we, U, m, ob.ORDER_DEVICE, j0)
-    jr, _ = ob.resample(S.RESAMPLE_RESIDUAL, we, U, m, ob.ORDER_REFERENCE, j0)
-    assert np.array_equal(jg, jd)
-    assert np.sum(jg != jr) <= 1          # ulp-level ties only
-    assert jg.min() >= 0 and jg.max() < n
-    # uniform weights: every particle exactly once, no draw
-    we = np.full(n, 1.0 / n)
-    if m == n:
-        assert np.array_equal(_capi.resample(S.RESAMPLE_RESIDUAL, we, U, m), np.arange(n))
-
-
-@pytest.mark.parametrize("thr", [0.5, 1.0])
-def test_residual_strategy_trajectory_bit_exact(thr):
-    """ParticleFilter with resampling_strategy = ResampleResidual over whole trajectories (run loop, history, single
-    steps) and in a bank: bit-identical to the device-order oracle, tolerance against the reference order."""
-    model = M.lg_c1_model()
-    _, U, Y = M.simulate_lg(model, 80)
-    cfg = _cfg(model, 3000, S.RESAMPLE_RESIDUAL, thr, seed=41)
-    g = _capi.FilterHandle(cfg); o = ob.OracleFilter(cfg, ob.ORDER_DEVICE); r = ob.OracleFilter(cfg, ob.ORDER_REFERENCE)
-    for h in (g, o, r):
-        h.reset()
-    rg = g.run(U, Y, 0.0, ll_steps=True, history=True); ro = o.run(U, Y, 0.0, ll_steps=True, history=True)
-    rr = r.run(U, Y, 0.0, ll_steps=True)
-    assert np.array_equal(rg["ll_steps"].view(np.uint64), ro["ll_steps"].view(np.uint64))
-    for key in ("x", "w", "we"):
-        assert np.array_equal(rg[key].view(np.uint64), ro[key].view(np.uint64)), key
-    _compare_state(g, o)
-    assert g.resample_count() == o.resample_count() > 3
-    assert np.max(np.abs(rg["ll_steps"] - rr["ll_steps"])) <= TOL_LL_STEP
-    # asynchronous loop (no history) and single steps
-    g2 = _capi.FilterHandle(cfg); g2.reset()
-    r2 = g2.run(U, Y, 0.0, ll_steps=True)
-    assert np.array_equal(r2["ll_steps"].view(np.uint64), ro["ll_steps"].view(np.uint64))
-    g3 = _capi.FilterHandle(cfg); o3 = ob.OracleFilter(cfg, ob.ORDER_DEVICE)
-    g3.reset(); o3.reset()
-    for k in range(15):
-        assert g3.update(U[k], Y[k], k * 1.0) == o3.update(U[k], Y[k], k * 1.0)
-        assert np.array_equal(g3.ancestors(), o3.ancestors())
-    _compare_state(g3, o3)
-    # bank
-    models = [M.lg_test_model(s) for s in (0.05, 0.2)]
-    _, U2, Y2 = M.simulate_lg(models[0], 40)
-    bank = _capi.BankHandle(_cfg(models[0], 5000, S.RESAMPLE_RESIDUAL, thr, seed=43), models)
-    bank.reset()
-    rb = bank.run(U2, Y2, 1.0, ll_steps=True)
-    for k, mk in enumerate(models):
-        ok = ob.OracleFilter(_cfg(mk, 5000, S.RESAMPLE_RESIDUAL, thr, seed=43 + k), ob.ORDER_DEVICE)
-        ok.reset()
-        assert np.array_equal(ok.run(U2, Y2, 1.0, ll_steps=True)["ll_steps"].view(np.uint64), rb["ll_steps"][:, k].copy().view(np.uint64))
-
-
-# ---- FFBS particle smoother (reference src/smoothing.jl:103-143) -----------------------------------------------------
-@pytest.mark.parametrize("strategy", [S.RESAMPLE_SYSTEMATIC, S.RESAMPLE_STRATIFIED, S.RESAMPLE_RESIDUAL])
-def test_smoother_bit_exact(strategy):
-    """Backward simulation on the GPU == device-order oracle: every drawn index and every smoothed sample; ragged N
-    (not a multiple of the 1024-particle chunk), M < N, nx = 2 and the quad-tank model (nx = 4)."""
-    model = M.lg_test_model(0.1)
-    X, U, Y = M.simulate_lg(model, 60, seed=2)
-    cfg = _cfg(model, 2500, strategy, 0.1, seed=3)
-    g = _capi.FilterHandle(cfg); o = ob.OracleFilter(cfg, ob.ORDER_DEVICE)
-    g.reset(); o.reset()
-    rg = g.run(U, Y, 0.0, history=True); ro = o.run(U, Y, 0.0, history=True)
-    assert np.array_equal(rg["x"].view(np.uint64), ro["x"].view(np.uint64))
-    xg, ig = g.smooth(300, U, rg["x"], rg["w"], rg["we"])
-    xo, io = o.smooth(300, U, ro["x"], ro["w"], ro["we"])
-    assert np.array_equal(ig, io)
-    assert np.array_equal(xg.view(np.uint64), xo.view(np.uint64))
-    assert np.mean((X - xg.mean(axis=1)) ** 2) < 5                      # test/runtests.jl:317
-    if strategy == S.RESAMPLE_SYSTEMATIC:
-        qm = M.quadtank_model(); Uq, Yq = M.quadtank_data(25)
-        cq = _cfg(qm, 1500, strategy, 0.5, seed=9, kind=S.ADVANCED_PARTICLE_FILTER)
-        g = _capi.FilterHandle(cq); o = ob.OracleFilter(cq, ob.ORDER_DEVICE)
-        g.reset(); o.reset()
-        rg = g.run(Uq, Yq, 0.0, history=True); ro = o.run(Uq, Yq, 0.0, history=True)
-        xg, ig = g.smooth(64, Uq, rg["x"], rg["w"], rg["we"]); xo, io = o.smooth(64, Uq, ro["x"], ro["w"], ro["we"])
-        assert np.array_equal(ig, io) and np.array_equal(xg.view(np.uint64), xo.view(np.uint64))
-
-
-def test_smoother_api():
-    """smooth(pf, M, u, y) / smoothed_mean / smoothed_cov / smoothed_trajs with the reference's checks
-    (test/runtests.jl:314-330): size, mean error < 5, tr(cov) < 2."""
-    A = np.array([[0.97043, -0.097368], [0.09736, 0.970437]]); B = np.array([[0.1], [0.0]]); Cm = np.array([[0.0, 1.0]])
-    df = llpf_amd.MvNormal(np.zeros(2), 0.1 ** 2); dg = llpf_amd.MvNormal(np.zeros(1), np.ones(1)); d0 = llpf_amd.MvNormal([0.3, -0.5], 4.0)
-    pf = llpf_amd.ParticleFilter(1000, llpf_amd.LinearDynamics(A, B), llpf_amd.LinearMeasurement(Cm), df, dg, d0, rng=5)
-    X, U, Y = M.simulate_lg(M.lg_test_model(0.1), 200, seed=2)
-    xb, ll = llpf_amd.smooth(pf, 100, U, Y)
-    assert xb.shape == (200, 100, 2) and np.isfinite(ll)
-    xbm = llpf_amd.smoothed_mean(xb)
-    assert xbm.shape == (2, 200) and np.mean((X.T - xbm) ** 2) < 5
-    assert all(np.trace(Cv) < 2 for Cv in llpf_amd.smoothed_cov(xb))
-    assert llpf_amd.smoothed_trajs(xb).shape == (2, 100, 200)
-
-
-# ---- Rao-Blackwellized particle filter with constant matrices (reference src/rbpf.jl, test/test_rbpf.jl) ------------
-def _rb_models():
-    g = S.make_gaussian
-    A = np.array([[1, 0.1], [0, 1.0]]); B = np.array([[0.0], [1.0]]); Cm = np.array([[1.0, 0.0]])
-    Ts = 0.1
-    R1 = np.array([[Ts ** 4 / 4, Ts ** 3 / 2], [Ts ** 3 / 2, Ts ** 2]]) + 1e-6 * np.eye(2)
-    R2 = np.array([[10.0]])
-    rng = np.random.default_rng(0)
-    x0 = rng.standard_normal(2)
-    T = 300
-    U = rng.standard_normal((T, 1)); Y = np.zeros((T, 1)); x = x0 + np.sqrt(2) * rng.standard_normal(2)
-    L1 = np.linalg.cholesky(R1)
-    for t in range(T):
-        Y[t] = Cm @ x + np.sqrt(10) * rng.standard_normal(1)
-        x = A @ x + B @ U[t] + L1 @ rng.standard_normal(2)
-    kfm = S.make_lg_model(A, B, Cm, g(np.zeros(2), R1), g(np.zeros(1), R2), g(x0, 2 * np.eye(2)))
-    # test/test_rbpf.jl:87-116: everything linear (a fake nonlinear state; its zero covariance replaced by 1e-12)
-    lin = S.make_rb_model([[1.0]], np.zeros((1, 1)), None, A, B, np.zeros((1, 1)), Cm, g(np.zeros(1), np.array([[1e-12]])), R1,
-                          g(np.zeros(1), R2), g(np.zeros(1), np.array([[1e-12]])), g(x0, 2 * np.eye(2)))
-    # :118-139: everything nonlinear (a fake linear state, A0 = B0 = C0 = 0)
-    nonl = S.make_rb_model(A, B, None, [[0.0]], np.zeros((1, 1)), Cm, None, g(np.zeros(2), R1), [[1.0]], g(np.zeros(1), R2),
-                           g(x0, 2 * np.eye(2)), g(np.zeros(1), np.array([[1.0]])))
-    # :5-31: mixed 1 + 1 with An = 0.5
-    mixed = S.make_rb_model([[1.0]], np.zeros((1, 0)), [[0.5]], [[0.95]], np.zeros((1, 0)), [[1.0]], [[1.0]], g(np.zeros(1), np.array([[0.01]])),
-                            [[0.01]], g(np.zeros(1), np.array([[0.1]])), g(np.array([1.0]), np.array([[0.01]])), g(np.array([1.0]), np.array([[1.0]])))
-    rng = np.random.default_rng(1)
-    xn, xl = 1.0, 1.0
-    Y1 = np.zeros((T, 1))
-    for t in range(T):
-        Y1[t] = xn + xl + np.sqrt(0.1) * rng.standard_normal()
-        xn, xl = xn + 0.5 * xl + 0.1 * rng.standard_normal(), 0.95 * xl + 0.1 * rng.standard_normal()
-    return kfm, {"linear": (lin, U, Y), "nonlinear": (nonl, U, Y), "mixed": (mixed, np.zeros((T, 0)), Y1)}
-
-
-@pytest.mark.parametrize("name", ["linear", "nonlinear", "mixed"])
-def test_rbpf_bit_exact_and_kalman(name):
-    """The three configurations of the reference's test/test_rbpf.jl: whole trajectories (history, per-step ll, the
-    shared covariance) bit-identical to the device-order oracle, within tolerance of the reference-order one; single
-    steps; and the reference's check ll_RBPF ~ ll_KF (rtol 1e-2) where the system is linear."""
-    kfm, cases = _rb_models()
-    model, U, Y = cases[name]
-    cfg = _cfg(model, 500, S.RESAMPLE_SYSTEMATIC, 0.1, seed=3)
-    g = _capi.FilterHandle(cfg); o = ob.OracleFilter(cfg, ob.ORDER_DEVICE); r = ob.OracleFilter(cfg, ob.ORDER_REFERENCE)
-    _compare_state(g, o)
-    for h in (g, o, r):
-        h.reset()
-    _compare_state(g, o)
-    rg = g.run(U, Y, 0.0, ll_steps=True, history=True); ro = o.run(U, Y, 0.0, ll_steps=True, history=True)
-    rr = r.run(U, Y, 0.0, ll_steps=True)
-    assert np.array_equal(rg["ll_steps"].view(np.uint64), ro["ll_steps"].view(np.uint64))
-    for key in ("x", "w", "we"):
-        assert np.array_equal(rg[key].view(np.uint64), ro[key].view(np.uint64)), key
-    _compare_state(g, o)
-    assert np.array_equal(g.rb_covariance().view(np.uint64), o.rb_R().view(np.uint64))
-    assert np.max(np.abs(rg["ll_steps"] - rr["ll_steps"])) <= TOL_LL_STEP
-    if name != "mixed":
-        assert abs(rg["ll"] - ob.kalman_loglik(kfm, U, Y)) <= 1e-2 * abs(rg["ll"])          # test/test_rbpf.jl:110,139
-    # asynchronous loop and single steps
-    g2 = _capi.FilterHandle(cfg); g2.reset()
-    assert np.array_equal(g2.run(U, Y, 0.0, ll_steps=True)["ll_steps"].view(np.uint64), ro["ll_steps"].view(np.uint64))
-    g3 = _capi.FilterHandle(cfg); o3 = ob.OracleFilter(cfg, ob.ORDER_DEVICE)
-    g3.reset(); o3.reset()
-    for k in range(12):
-        assert g3.update(U[k], Y[k], k * 1.0) == o3.update(U[k], Y[k], k * 1.0)
-        _compare_state(g3, o3)
-
-
-def test_rbpf_api():
-    """RBPF(N, kf, dynamics, nl_measurement_model, R1n, d0n; An, ...) through the reference-shaped API: loglik close to
-    the Kalman filter's (test/test_rbpf.jl:110), forward_trajectory shapes, the shared covariance accessor."""
-    A = np.array([[1, 0.1], [0, 1.0]]); B = np.array([[0.0], [1.0]]); Cm = np.array([[1.0, 0.0]])
-    Ts = 0.1
-    R1 = np.array([[Ts ** 4 / 4, Ts ** 3 / 2], [Ts ** 3 / 2, Ts ** 2]]) + 1e-6 * np.eye(2)
-    R2 = np.array([[10.0]])
-    kfm, cases = _rb_models()
-    _, U, Y = cases["linear"]
-    x0 = S.gaussian_mean(kfm.initial_density)
-    kf = llpf_amd.KalmanFilter(A, B, Cm, 0, R1, R2, llpf_amd.MvNormal(x0, 2 * np.eye(2)))
-    mm = llpf_amd.RBMeasurementModel(llpf_amd.LinearMeasurement(np.zeros((1, 1))), R2, 1)
-    pf = llpf_amd.RBPF(500, kf, llpf_amd.LinearDynamics([[1.0]], np.zeros((1, 1))), mm, np.array([[1e-12]]),
-                       llpf_amd.MvNormal(np.zeros(1), np.array([[1e-12]])), An=None, nu=1, rng=4)
-    ll = llpf_amd.loglik(pf, U, Y)          # note: loglik runs at t = index*Ts, the model is time invariant
-    assert abs(ll - ob.kalman_loglik(kfm, U, Y)) <= 1e-2 * abs(ll)
-    sol = llpf_amd.forward_trajectory(pf, U[:30], Y[:30])
-    assert sol.x.shape == (30, 500, 3) and pf.covariance.shape == (2, 2)
-    assert np.allclose(sol.we.sum(axis=1), 1.0)
