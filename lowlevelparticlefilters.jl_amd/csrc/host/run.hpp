@@ -49,7 +49,7 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
     // residual resampling produces unsorted ancestors (copies first, multinomial draws after): always the balanced form
     const bool residual = b.cfg.resampling_strategy == LLPF_RESAMPLE_RESIDUAL;
     const bool rbm = is_rb(b);
-    const bool unfused = hist || residual || rbm || (unf_env ? atoi(unf_env) != 0 : heavy_dynamics);
+    const bool unfused = hist || residual || (unf_env ? atoi(unf_env) != 0 : heavy_dynamics);
     if (rbm) {
         // the whole gain schedule of the run (data independent): corr_0, pred_0, corr_1, pred_1, ..., [F] each
         const size_t need = (size_t)(2 * T + 1) * b.F;

@@ -192,11 +192,29 @@ static hipError_t launch_resprop_lg_ny(const BankDev& b, const ResArgs& a, const
         default: return hipErrorInvalidValue;
     }
 }
+template <int NX>
+static hipError_t launch_resprop_rb_ny(const BankDev& b, const ResArgs& a, const StepArgs& st, int weight, hipStream_t s) {
+    switch (b.ny) {
+        case 1: return launch_resprop_t<RBLin<NX, 1>, NX, 1>(b, a, st, weight, s);
+        case 2: return launch_resprop_t<RBLin<NX, 2>, NX, 2>(b, a, st, weight, s);
+        case 3: return launch_resprop_t<RBLin<NX, 3>, NX, 3>(b, a, st, weight, s);
+        case 4: return launch_resprop_t<RBLin<NX, 4>, NX, 4>(b, a, st, weight, s);
+        default: return hipErrorInvalidValue;
+    }
+}
 hipError_t launch_resprop(const BankDev& b, const ResArgs& a0, const StepArgs& st, int weight, hipStream_t s) {
     ResArgs a = a0;
     a.K = llpf_qbits(b.N);
     a.mode = RES_FINALIZE | RES_RESAMPLE;
     if (b.model_id == LLPF_MODEL_QUADTANK_RK4) return launch_resprop_t<QuadTank<4, 2>, 4, 2>(b, a, st, weight, s);
+    if (b.model_id == LLPF_MODEL_RB_LINEAR) {
+        switch (b.nx) {
+            case 2: return launch_resprop_rb_ny<2>(b, a, st, weight, s);
+            case 3: return launch_resprop_rb_ny<3>(b, a, st, weight, s);
+            case 4: return launch_resprop_rb_ny<4>(b, a, st, weight, s);
+            default: return hipErrorInvalidValue;
+        }
+    }
     switch (b.nx) {
         case 1: return launch_resprop_lg_ny<1>(b, a, st, weight, s);
         case 2: return launch_resprop_lg_ny<2>(b, a, st, weight, s);

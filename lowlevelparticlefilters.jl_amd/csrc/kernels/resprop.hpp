@@ -51,6 +51,19 @@ struct PropCtx {
         double xp[NX], fx[NX], xi[NX], nz[NX];
 #pragma unroll
         for (int d = 0; d < NX; ++d) xp[d] = ld_off(xc + (size_t)d * Ns, so);
+        if constexpr (Model::RB) {     // Rao-Blackwellized model: own noise structure, and correct! updates xl before the store
+            model.rb_propagate(xp, o, st.step, k0, k1, st.rb_pred + blockIdx.y, xs);
+            double wr = wprev;
+            if (WEIGHT) {
+                if (st.has_y) wr = wr + model.rb_weight(xs, y, st.rb_corr + blockIdx.y, o == 0);
+                if (o >= (uint32_t)b.N) wr = -LLPF_INF;
+                bad = bad || (wr != wr);
+                st_off(w, oo, wr);
+            }
+#pragma unroll
+            for (int d = 0; d < NX; ++d) st_off(xn + (size_t)d * Ns, oo, xs[d]);
+            return wr;
+        }
 #ifdef LLPF_DEVTOOLS   /* ablation switches for performance experiments (results invalid); not in production builds */
         if (!(ablate & 4)) model.dynamics(xp, fx);
         else { for (int d = 0; d < NX; ++d) fx[d] = xp[d]; }
@@ -178,7 +191,12 @@ __global__ __launch_bounds__(BLOCK) void k_resprop(BankDev b, const ModelD* __re
     }
     {   // bound of the weights produced below: max of the previous (normalised) weights + the density's peak
         const double wmx = res ? b.log1N : (h.mtrue - h.a) - l;
-        pc.off = (WEIGHT && st.has_y) ? wmx + md->dg.c0 : wmx;
+        if constexpr (Model::RB) {     // peak of N(0, S) of the coming correct! (or of R2 when C == 0)
+            const double c0w = md->rb_zeroC ? md->dg.c0 : (st.rb_corr + f)->dS.c0;
+            pc.off = (WEIGHT && st.has_y) ? wmx + c0w : wmx;
+        } else {
+            pc.off = (WEIGHT && st.has_y) ? wmx + md->dg.c0 : wmx;
+        }
     }
     const double lN = -b.mlogN;
     const double aux_off = ((st.aux == 2) ? md->dg.c0 : 0.0) - lN;     // lambda - log N <= c0 - log N (lambda = 0 if y1 is missing)

@@ -43,9 +43,12 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
     for (int d = 0; d < NX; ++d) xm[d] = 0.0;
     if (MODE != MODE_PROP) {
         const double wmx = do_res ? b.log1N : (uniform ? wconst : sc->wmax);
-        double c0w = md->dg.c0;
-        if constexpr (Model::RB) { if (!md->rb_zeroC) c0w = (a.rb_corr + f)->dS.c0; }   // peak of N(0, S) of this correct!
-        off = a.has_y ? wmx + c0w : wmx;
+        if constexpr (Model::RB) {     // peak of N(0, S) of this correct! (or of R2 when C == 0)
+            const double c0w = md->rb_zeroC ? md->dg.c0 : (a.rb_corr + f)->dS.c0;
+            off = a.has_y ? wmx + c0w : wmx;
+        } else {
+            off = a.has_y ? wmx + md->dg.c0 : wmx;
+        }
         wacc.init();
     }
 #pragma unroll 1
