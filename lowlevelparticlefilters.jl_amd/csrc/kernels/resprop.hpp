@@ -151,6 +151,7 @@ __global__ __launch_bounds__(BLOCK) void k_resprop(BankDev b, const ModelD* __re
 #pragma unroll
     for (int k = 0; k < NY; ++k) y[k] = (WEIGHT && st.has_y) ? st.y[k] : 0.0;
     const uint32_t key0 = sc->k0, key1 = sc->k1;
+    const double c0_pre = md->dg.c0;                   // fetched with the other loads: the bound below must not wait for it
     const ResHead h = res_head<SRC_FILTER>(b, a, f, tile, sh, true, stop_flag, fb_flag);
     if (h.status) return;
     LLPF_STAMP(1);
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(BLOCK) void k_resprop(BankDev b, const ModelD* __re
             const double c0w = md->rb_zeroC ? md->dg.c0 : (st.rb_corr + f)->dS.c0;
             pc.off = (WEIGHT && st.has_y) ? wmx + c0w : wmx;
         } else {
-            pc.off = (WEIGHT && st.has_y) ? wmx + md->dg.c0 : wmx;
+            pc.off = (WEIGHT && st.has_y) ? wmx + c0_pre : wmx;
         }
     }
     const double lN = -b.mlogN;
