@@ -583,3 +583,22 @@ def test_launches_larger_than_the_resident_set(schedule, monkeypatch):
     ro = o.run(U[:8], Y[:8], 1.0, ll_steps=True)
     assert np.array_equal(rg["ll_steps"].view(np.uint64), ro["ll_steps"].view(np.uint64))
     assert g.resample_count() == o.resample_count() >= 1
+
+
+def test_near_maximum_particle_count():
+    """3e8 particles (2.4 GB per state plane: byte offsets above 2^31, 292 969 tiles): the 32-bit offset addressing,
+    the tile-sum prefix over ~3e5 tiles and the 63-bit quanta total; checked through size-independent properties
+    (the per-step log-likelihood estimates the same quantity as a 1e6-particle run, to Monte-Carlo accuracy)."""
+    model = M.lg_test_model(0.1)
+    _, U, Y = M.simulate_lg(model, 4, seed=1)
+    big = _capi.FilterHandle(_cfg(model, 300_000_000, thr=1.0, seed=11))
+    big.reset()
+    rb = big.run(U, Y, 1.0, ll_steps=True, xmean=True)
+    small = _capi.FilterHandle(_cfg(model, 1_000_000, thr=1.0, seed=12))
+    small.reset()
+    rs = small.run(U, Y, 1.0, ll_steps=True, xmean=True)
+    assert np.all(np.isfinite(rb["ll_steps"])) and np.all(np.isfinite(rb["xmean"]))
+    assert np.max(np.abs(rb["ll_steps"] - rs["ll_steps"])) < 0.02
+    assert np.max(np.abs(rb["xmean"] - rs["xmean"])) < 0.02
+    assert big.resample_count() == 4
+    assert abs(big.ess() - 3e8) < 1.0          # after the last resampling predict! the weights are uniform
