@@ -23,7 +23,7 @@ from . import _structs as S
 __all__ = [
     "MvNormal", "ResampleSystematic", "ResampleStratified",
     "LinearDynamics", "LinearMeasurement", "QuadTankDynamics", "QuadTankMeasurement", "GaussianLikelihood",
-    "ResampleResidual", "KalmanFilter", "RBMeasurementModel", "RBPF", "smooth", "smoothed_mean", "smoothed_cov", "smoothed_trajs", "ParticleFilter", "AdvancedParticleFilter", "AuxiliaryParticleFilter", "FilterBank", "ParticleFilteringSolution",
+    "ResampleResidual", "weighted_cov", "mode_trajectory", "KalmanFilter", "RBMeasurementModel", "RBPF", "smooth", "smoothed_mean", "smoothed_cov", "smoothed_trajs", "ParticleFilter", "AdvancedParticleFilter", "AuxiliaryParticleFilter", "FilterBank", "ParticleFilteringSolution",
     "reset", "predict", "correct", "update", "forward_trajectory", "mean_trajectory", "loglik",
     "particles", "weights", "expweights", "state", "num_particles", "index", "effective_particles",
     "shouldresample", "resample", "weighted_mean", "logsumexp", "simulate", "parameters",
@@ -384,6 +384,31 @@ def loglik(pf, u, y, p=None):
     if isinstance(pf, AuxiliaryParticleFilter):
         return pf._h.run_aux(u, y, mode=1)["ll"]
     return pf._h.run(u, y, t_index0=1.0)["ll"]
+
+
+def weighted_cov(x, we=None):
+    """weighted_cov(x, we) / weighted_cov(sol) — reference src/filtering.jl:573-581: per time step the covariance of
+    the particles under probability weights with StatsBase's correction n / ((n - 1) sum(w)), n = count(w != 0)."""
+    if isinstance(x, ParticleFilteringSolution):
+        x, we = x.x, x.we
+    x, we = np.asarray(x), np.asarray(we)
+    out = []
+    for t in range(x.shape[0]):
+        w = we[t]
+        s = w.sum()
+        mu = (x[t] * w[:, None]).sum(axis=0) / s
+        d = x[t] - mu
+        n = np.count_nonzero(w)
+        out.append((d * w[:, None]).T @ d * (n / ((n - 1) * s)))
+    return out
+
+
+def mode_trajectory(x, we=None):
+    """mode_trajectory(sol) / (x, we) — reference src/filtering.jl:415,436: the particle with the largest weight, T x nx."""
+    if isinstance(x, ParticleFilteringSolution):
+        x, we = x.x, x.we
+    x, we = np.asarray(x), np.asarray(we)
+    return x[np.arange(x.shape[0]), np.argmax(we, axis=1)]
 
 
 def smooth(pf, *args):

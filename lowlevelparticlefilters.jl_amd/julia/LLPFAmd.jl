@@ -9,7 +9,7 @@
 module LLPFAmd
 
 using LinearAlgebra
-export GPUParticleFilter, GPUAuxiliaryParticleFilter, LinearGaussianModel, QuadTankModel, GaussianSpec,
+export GPUParticleFilter, GPUAuxiliaryParticleFilter, LinearGaussianModel, QuadTankModel, RBLinearModel, GaussianSpec, smooth,
        reset!, predict!, correct!, update!, loglik, forward_trajectory, particles, weights, expweights,
        num_particles, index, effective_particles, shouldresample, weighted_mean
 
@@ -63,7 +63,12 @@ function cgauss(g::GaussianSpec)
     end
 end
 
+const NOGAUSS = CGaussian(0, 0, ntuple(_ -> 0.0, 8), ntuple(_ -> 0.0, 64))    # unused density slot
+
 struct LinearGaussianModel; A; B; C; end                     # dynamics A*x .+ B*u, measurement C*x
+"""Rao-Blackwellized model with constant matrices (reference src/rbpf.jl:92-98): xn' = Fn xn + Bn u + An xl + wn,
+xl' = Al xl + Bl u + wl, y = Gn xn + Cl xl + e; R1l the covariance of wl, d0l the inner KalmanFilter's initial density."""
+struct RBLinearModel; Fn; Bn; An; Al; Bl; Gn; Cl; R1l; d0l::GaussianSpec; end
 struct QuadTankModel; consts::NTuple{16,Float64}; supersample::Int; end
 QuadTankModel(; supersample = 2) = QuadTankModel(
     (1.6, 1.6, 9.81, 4.9, 4.9, 4.9, 4.9, 0.03, 0.03, 0.03, 0.03, 0.2, 0.2, 500.0, 2.0, 1e-3), supersample)
@@ -71,11 +76,20 @@ QuadTankModel(; supersample = 2) = QuadTankModel(
 function cmodel(m::LinearGaussianModel, df, dg, d0, Ts)
     nx = size(m.A, 1); nu = size(m.B, 2); ny = size(m.C, 1)
     CModel(0, nx, nu, ny, pad(rowmajor(m.A), 64), pad(rowmajor(m.B), 64), pad(rowmajor(m.C), 64),
-           ntuple(_ -> 0.0, 16), 1, 0, Ts, cgauss(df), cgauss(dg), cgauss(d0))
+           ntuple(_ -> 0.0, 16), 1, 0, Ts, cgauss(df), cgauss(dg), cgauss(d0), NOGAUSS, NOGAUSS)
 end
 cmodel(m::QuadTankModel, df, dg, d0, Ts) =
     CModel(1, 4, 2, 2, ntuple(_ -> 0.0, 64), ntuple(_ -> 0.0, 64), ntuple(_ -> 0.0, 64), m.consts,
-           m.supersample, 0, Ts, cgauss(df), cgauss(dg), cgauss(d0))
+           m.supersample, 0, Ts, cgauss(df), cgauss(dg), cgauss(d0), NOGAUSS, NOGAUSS)
+# RBPF: df = R1n, dg = R2, d0 = d0n (all of the nonlinear substate's dimension); A = [Fn An; 0 Al], B = [Bn; Bl], C = [Gn Cl]
+function cmodel(m::RBLinearModel, df, dg, d0, Ts)
+    nn = size(m.Fn, 1); nl = size(m.Al, 1); nu = size(m.Bn, 2); ny = size(m.Gn, 1)
+    An = m.An === nothing ? zeros(nn, nl) : m.An
+    Cl = m.Cl === nothing ? zeros(ny, nl) : m.Cl
+    A = [m.Fn An; zeros(nl, nn) m.Al]; B = [m.Bn; m.Bl]; C = [m.Gn Cl]
+    CModel(2, nn + nl, nu, ny, pad(rowmajor(A), 64), pad(rowmajor(B), 64), pad(rowmajor(C), 64), ntuple(_ -> 0.0, 16),
+           1, nn, Ts, cgauss(df), cgauss(dg), cgauss(d0), cgauss(GaussianSpec(zeros(nl), Matrix{Float64}(m.R1l))), cgauss(m.d0l))
+end
 
 check(rc) = rc == 0 || error("llpf status $rc: " * unsafe_string(ccall((:llpf_last_error, LIB), Cstring, ())))
 
@@ -209,6 +223,18 @@ function forward_trajectory(a::GPUAuxiliaryParticleFilter, u, y, p = nothing)
     reset!(a)
     ll, x, w, we = run_aux!(a, u, y, 0; history = true)
     (; x, w, we, ll, t = range(0, step = a.Ts, length = length(y)))
+end
+
+"xb, ll = smooth(pf, M, u, y) — src/smoothing.jl:103-143 (forward filtering, backward simulation); xb is nx x M x T"
+function smooth(pf::GPUParticleFilter, M::Integer, u, y, p = nothing)
+    sol = forward_trajectory(pf, u, y)
+    T = length(y)
+    U = rows(u)
+    xb = Array{Float64}(undef, pf.nx, M, T)
+    GC.@preserve U check(ccall((:llpf_smooth, LIB), Cint,
+        (Ptr{Cvoid}, Int64, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int64}),
+        pf.h, M, U, T, sol.x, sol.w, sol.we, xb, C_NULL))
+    xb, sol.ll
 end
 
 function getvec(sym, pf, n)
