@@ -344,7 +344,7 @@ def main():
             flop = 730.0
             roof["compute"] = {"fp64_flop_per_particle_step": flop, "achieved_tflops": N * flop / step_s / 1e12,
                                "peak_tflops": 78.6, "frac": N * flop / step_s / 78.6e12,
-                               "note": "k_step is instruction-issue bound (about 700 fp64 + 700 other VALU instructions per particle); "
+                               "note": "k_step is instruction-issue bound (about 700 fp64 + 500 other VALU instructions per particle); "
                                        "the HBM figures above are reported as the contract asks but do not bound this workload"}
         # HBM traffic of the dominant kernel from the committed PMC profile of this same workload (cannot be collected
         # inside bench.py: rocprofv3 --pmc needs its own passes); only quoted when shapes match

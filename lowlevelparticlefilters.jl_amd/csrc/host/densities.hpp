@@ -68,6 +68,8 @@ static int model_prepare(const llpf_model* m, ModelD* d) {
     memcpy(d->qt, m->qt, sizeof(d->qt));
     d->supersample = m->supersample;
     d->Ts = m->Ts;
+    // the quad-tank right-hand side takes sqrt(max(x,0) + eps) with the special-case-free llpf_sqrt_pos
+    if (m->model_id == LLPF_MODEL_QUADTANK_RK4 && !(m->qt[LLPF_QT_EPS] > 1e-200)) return -9;
     if (gauss_prepare(&m->dynamics_density, &d->df)) return -1;
     if (gauss_prepare(&m->measurement_density, &d->dg)) return -2;
     if (gauss_prepare(&m->initial_density, &d->d0)) return -3;

@@ -276,7 +276,7 @@ struct QuadTank {   // reference examples/example_quadtank.jl:8-35 with rk4 of s
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             double v = tg * h[i];
-            s[i] = llpf_sqrt((v > 0.0 ? v : 0.0) + eps);
+            s[i] = llpf_sqrt_pos((v > 0.0 ? v : 0.0) + eps);        // argument >= eps = 1e-3 (ssqrt, example_quadtank.jl:19)
         }
         const double ca = (t > tsw) ? c1a_sw : c1a;
         xd[0] = ca * s[0] + c1b * s[2] + c1u * u0;

@@ -14,6 +14,7 @@ __global__ void k_selftest_math(int which, const double* __restrict__ in, double
         case 3: llpf_sincos2pi(x, &s, &c); r = s; break;
         case 4: llpf_sincos2pi(x, &s, &c); r = c; break;
         case 5: r = llpf_sqrt(x); break;
+        case 12: r = llpf_sqrt_pos(x); break;
         case 6: r = 1.0 / x; break;
         case 7: r = (double)llpf_d2u(x); break;
         case 8: r = llpf_exp_le0(x); break;

@@ -33,6 +33,26 @@ LLPF_HD uint64_t llpf_d2u(double x) { uint64_t u; __builtin_memcpy(&u, &x, 8); r
 LLPF_HD double   llpf_u2d(uint64_t u) { double x; __builtin_memcpy(&x, &u, 8); return x; }
 LLPF_HD double   llpf_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 LLPF_HD double   llpf_sqrt(double a) { return __builtin_sqrt(a); }
+/* sqrt(a) for a NORMAL, finite, strictly positive a that is neither tiny nor huge (2^-700 < a < 2^700): the
+ * correctly-rounded result, i.e. the same bits as llpf_sqrt.  On the device the compiler's IEEE expansion of sqrt
+ * spends 7 of its 17 instructions on scaling of denormal inputs and on 0 / inf / NaN; this is its core alone:
+ * y = rsq(a), g = a y, h = y/2, one Goldschmidt refinement of (g, h), two residual corrections of g. */
+#if defined(__HIP_DEVICE_COMPILE__)
+LLPF_HD double   llpf_sqrt_pos(double a) {
+    const double y  = __builtin_amdgcn_rsq(a);
+    const double g0 = a * y;
+    const double h0 = 0.5 * y;
+    const double r0 = __builtin_fma(-h0, g0, 0.5);
+    const double g1 = __builtin_fma(g0, r0, g0);
+    const double h1 = __builtin_fma(h0, r0, h0);
+    const double d0 = __builtin_fma(-g1, g1, a);
+    const double g2 = __builtin_fma(d0, h1, g1);
+    const double d1 = __builtin_fma(-g2, g2, a);
+    return __builtin_fma(d1, h1, g2);
+}
+#else
+LLPF_HD double   llpf_sqrt_pos(double a) { return __builtin_sqrt(a); }
+#endif
 LLPF_HD double   llpf_rint(double a) { return __builtin_rint(a); }
 LLPF_HD double   llpf_fmax(double a, double b) { return a > b ? a : b; }
 

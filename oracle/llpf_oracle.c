@@ -167,7 +167,7 @@ static void quadtank_rhs(const double* qt, const double* h, const double* u, dou
     double s[4];
     for (int i = 0; i < 4; ++i) {                                       /* ssqrt, :19 */
         double v = tg * h[i];
-        s[i] = sqrt((v > 0.0 ? v : 0.0) + eps);
+        s[i] = sqrt((v > 0.0 ? v : 0.0) + eps);                   /* the engine: llpf_sqrt_pos, same correctly-rounded value */
     }
     xd[0] = ((-a1) / A1) * s[0] + (a3 / A1) * s[2] + ((g1 * k1) / A1) * u[0];
     xd[1] = ((-a2) / A2) * s[1] + (a4 / A2) * s[3] + ((g2 * k2) / A2) * u[1];
@@ -1418,6 +1418,7 @@ void orc_math_vec(int which, const double* in, double* out, int64_t n) {
             case 3: llpf_sincos2pi(x, &s, &c); out[i] = s; break;
             case 4: llpf_sincos2pi(x, &s, &c); out[i] = c; break;
             case 5: out[i] = llpf_sqrt(x); break;
+            case 12: out[i] = llpf_sqrt_pos(x); break;
             case 6: out[i] = 1.0 / x; break;
             case 7: out[i] = (double)llpf_d2u(x); break;
             case 8: out[i] = llpf_exp_le0(x); break;

@@ -32,6 +32,7 @@ def test_device_math_bit_identical_to_host():
         9: np.concatenate([(rng.integers(0, 2 ** 53, 200000) + 1) * 2.0 ** -53, [1.0, 2.0 ** -53, 0.75]]),
         10: rng.uniform(0, 1, 200000),
         11: rng.uniform(0, 1, 200000),
+        12: np.concatenate([10.0 ** rng.uniform(-6, 6, 1000000), rng.uniform(1e-3, 200.0, 1000000), [1e-3, 1.0, 4.0, 2.0 ** -600, 2.0 ** 600]]),
     }
     for which, x in cases.items():
         host = ob.math_vec(which, x)
