@@ -603,3 +603,22 @@ def test_near_maximum_particle_count():
     assert np.max(np.abs(rb["xmean"] - rs["xmean"])) < 0.02
     assert big.resample_count() == 4
     assert abs(big.ess() - 3e8) < 1.0          # after the last resampling predict! the weights are uniform
+
+
+def test_c_client_of_the_abi():
+    """examples/loglik_c2.c: the boundary driven from plain C (include/llpf.h, no Python in the process): runs, and its
+    log-likelihood estimate does not depend on the particle count beyond Monte-Carlo error."""
+    import json, os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "loglik_c2")
+    if not os.path.exists(exe):
+        pytest.skip("examples/loglik_c2 not built (python -c 'import __graft_entry__ as g; g.build()')")
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(root, "lowlevelparticlefilters.jl_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    outs = []
+    for n in (20000, 200000):
+        r = subprocess.run([exe, str(n), "300", "7"], env=env, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert all(np.isfinite(o["loglik"]) for o in outs)
+    assert abs(outs[0]["loglik"] - outs[1]["loglik"]) < 3.0
+    assert outs[1]["particle_steps_per_s"] > 1e9
