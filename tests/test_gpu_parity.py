@@ -622,3 +622,36 @@ def test_c_client_of_the_abi():
     assert all(np.isfinite(o["loglik"]) for o in outs)
     assert abs(outs[0]["loglik"] - outs[1]["loglik"]) < 3.0
     assert outs[1]["particle_steps_per_s"] > 1e9
+
+
+def test_error_paths_of_the_newer_entry_points():
+    """Invalid uses are rejected with LLPF_ERR_ARG and a message (no exception crosses the ABI, nothing is computed):
+    residual resampling or the Rao-Blackwellized model with the auxiliary verbs, smooth with M > N or an RB model,
+    RB model shapes the kernels do not cover, a quad-tank model with eps = 0."""
+    model = M.lg_test_model(0.1)
+    _, U, Y = M.simulate_lg(model, 10)
+    g = _capi.FilterHandle(_cfg(model, 500, S.RESAMPLE_RESIDUAL, 0.5))
+    g.reset()
+    with pytest.raises(_capi.LLPFError):
+        g.aux_predict(U[0], Y[1], 0.0)
+    with pytest.raises(_capi.LLPFError):
+        g.run_aux(U, Y, 1)
+    g2 = _capi.FilterHandle(_cfg(model, 500))
+    g2.reset()
+    r = g2.run(U, Y, 0.0, history=True)
+    with pytest.raises(_capi.LLPFError):
+        g2.smooth(501, U, r["x"], r["w"], r["we"])
+    with pytest.raises(_capi.LLPFError):
+        g2.run_aux(U, Y, 2)
+    gs = S.make_gaussian
+    with pytest.raises(ValueError):
+        S.make_rb_model(np.eye(3), None, None, np.eye(2), None, np.zeros((1, 3)), None, gs(np.zeros(3), 1.0), np.eye(2),
+                        gs(np.zeros(1), 1.0), gs(np.zeros(3), 1.0), gs(np.zeros(2), 1.0))       # nxn + nxl > 4
+    rb2 = S.make_rb_model(np.eye(2), None, np.ones((2, 1)), [[0.9]], None, np.ones((1, 2)), [[1.0]], gs(np.zeros(2), 0.1), [[0.1]],
+                          gs(np.zeros(1), 1.0), gs(np.zeros(2), 1.0), gs(np.zeros(1), 1.0))      # An != 0 with two nonlinear states
+    with pytest.raises(_capi.LLPFError):
+        _capi.FilterHandle(_cfg(rb2, 100))
+    qt = M.quadtank_model()
+    qt.qt[S.QT_NAMES.index("eps")] = 0.0
+    with pytest.raises(_capi.LLPFError):
+        _capi.FilterHandle(_cfg(qt, 100, kind=S.ADVANCED_PARTICLE_FILTER))
