@@ -187,7 +187,7 @@ int llpf_get_bins(llpf_filter* f, double* dst) {
     CHK(use_device(b));
     BankDev d = b.dev();
     ResArgs ra{};
-    ra.mode = RES_RESAMPLE; ra.step = b.n_predict; ra.M = (int32_t)b.N; ra.anc_out = b.d_anc;
+    ra.mode = RES_RESAMPLE; ra.step = rel_step(b); ra.M = (int32_t)b.N; ra.anc_out = b.d_anc;
     ra.parity = (b.parity + ACC_NSLOT - 1) % ACC_NSLOT;
     ra.bins_out = b.d_tmp; ra.only_bins = 1; ra.force = 1;
     HIPC(launch_resample(d, ra, b.stream));

@@ -111,6 +111,8 @@ struct FilterScal {
     int32_t last_resampled;
     int64_t resample_count;
     uint32_t k0, k1;     // Philox key of this filter
+    uint32_t step_base;  // added to the Philox step arguments of every launch: a captured run (hipGraph) keeps its relative
+    uint32_t pad_sb;     //   steps while successive runs still draw fresh noise
     double u_slot[ACC_NSLOT];   // the uniform of the systematic resample that consumes accumulator slot p (computed once per step)
     double stot;         // sum of exp(w - m) over ALL particles in the form the last normalisation used (exact form: s + 1)
     double mtrue;        // true maximum of the raw log-weights (state.maxw[]); m above is the OFFSET (bound or maximum)

@@ -39,7 +39,7 @@ static int bank_set_weights(Bank& b, const double* w) {
     b.parity = 0;
     BankDev d = b.dev();
     HIPC(launch_max(d, b.parity, b.stream));
-    HIPC(launch_norm(d, b.parity, 0, 1, b.n_predict, 0, 0, 0, b.stream));
+    HIPC(launch_norm(d, b.parity, 0, 1, rel_step(b), 0, 0, 0, b.stream));
     ResArgs ra{};
     ra.mode = RES_FINALIZE; ra.parity = b.parity; ra.M = (int32_t)b.N; ra.keep_norm = 1; ra.fast_head = 0;
     HIPC(launch_resample(d, ra, b.stream));

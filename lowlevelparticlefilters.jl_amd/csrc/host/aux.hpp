@@ -9,7 +9,7 @@ struct AuxOuts { double* d_ll_steps = nullptr; double* d_xmean = nullptr; int ac
 static int aux_launch_finalize(Bank& b, bool fast, int only_fb, int64_t epoch, int64_t row, const AuxOuts& o) {
     const int slot = (b.parity + ACC_NSLOT - 1) % ACC_NSLOT;
     BankDev d = b.dev();
-    if (!fast) HIPC(launch_norm(d, slot, o.d_xmean ? 1 : 0, 1, b.n_predict, only_fb, 0, epoch, b.stream));
+    if (!fast) HIPC(launch_norm(d, slot, o.d_xmean ? 1 : 0, 1, rel_step(b), only_fb, 0, epoch, b.stream));
     ResArgs ra{};
     ra.mode = RES_FINALIZE; ra.parity = slot; ra.M = (int32_t)b.N; ra.fast_head = fast ? 1 : 0; ra.K = llpf_qbits(b.N);
     ra.k = epoch; ra.row = row; ra.only_fallback = only_fb;
@@ -23,8 +23,8 @@ static int aux_launch_finalize(Bank& b, bool fast, int only_fb, int64_t epoch, i
 static int aux_launch_look(Bank& b, const double* d_u, const double* d_y1, bool has_y1, double t, int only_fb, int64_t epoch) {
     BankDev d = b.dev();
     StepArgs a{};
-    a.u = d_u; a.y = d_y1; a.t_prop = t; a.t_meas = t; a.step = b.n_predict; a.has_y = has_y1 ? 1 : 0;
-    a.parity = b.parity; a.need_e2 = 0; a.K = llpf_qbits(b.N); a.k = epoch; a.next_step = b.n_predict; a.accumulate = 1;
+    a.u = d_u; a.y = d_y1; a.t_prop = t; a.t_meas = t; a.step = rel_step(b); a.has_y = has_y1 ? 1 : 0;
+    a.parity = b.parity; a.need_e2 = 0; a.K = llpf_qbits(b.N); a.k = epoch; a.next_step = rel_step(b); a.accumulate = 1;
     a.only_fallback = only_fb;
     ProfScope ps(b, LLPF_PROF_NORMALISE);
     HIPC(launch_step(d, MODE_AUX, a, b.stream));
@@ -36,14 +36,14 @@ static int aux_launch_resprop(Bank& b, bool has_y1, double t, bool fast, int onl
     const int slot1 = (b.parity + ACC_NSLOT - 1) % ACC_NSLOT;
     BankDev d = b.dev();
     const int K = llpf_qbits(b.N);
-    if (!fast) HIPC(launch_norm(d, slot1, 0, 0, b.n_predict, only_fb, 0, epoch, b.stream));
+    if (!fast) HIPC(launch_norm(d, slot1, 0, 0, rel_step(b), only_fb, 0, epoch, b.stream));
     ResArgs ra{};
-    ra.mode = RES_FINALIZE | RES_RESAMPLE; ra.parity = slot1; ra.step = b.n_predict; ra.M = (int32_t)b.N;
+    ra.mode = RES_FINALIZE | RES_RESAMPLE; ra.parity = slot1; ra.step = rel_step(b); ra.M = (int32_t)b.N;
     ra.anc_out = b.d_anc; ra.force = 1; ra.fast_head = fast ? 1 : 0; ra.u_from_scal = 1; ra.K = K; ra.k = epoch;
     ra.only_fallback = only_fb;
     StepArgs st{};
-    st.t_prop = t; st.t_meas = t; st.step = b.n_predict; st.has_y = 0; st.parity = b.parity; st.need_e2 = 0; st.K = K;
-    st.k = epoch; st.next_step = b.n_predict + 1; st.want_xmean = want_xm; st.accumulate = 1; st.aux = has_y1 ? 2 : 1;
+    st.t_prop = t; st.t_meas = t; st.step = rel_step(b); st.has_y = 0; st.parity = b.parity; st.need_e2 = 0; st.K = K;
+    st.k = epoch; st.next_step = rel_step(b) + 1; st.want_xmean = want_xm; st.accumulate = 1; st.aux = has_y1 ? 2 : 1;
     st.only_fallback = only_fb;
     ProfScope ps(b, LLPF_PROF_PROPAGATE);
     HIPC(launch_resprop(d, ra, st, 1, b.stream));

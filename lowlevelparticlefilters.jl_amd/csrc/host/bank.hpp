@@ -43,6 +43,20 @@ struct Bank {
     double* d_tmp = nullptr;         // F*N*max(nx,1) doubles (also reinterpreted as int64 / double staging)
     uint64_t seed = 0;
     uint32_t n_reset = 0, n_predict = 0;
+    uint32_t step_base = 0;           // value of FilterScal::step_base on the device: kernels add it to the step arguments
+    // Captured run loops (hipGraph): a chain of T dependent launches replays ~1 us per launch faster than it enqueues
+    // (tools/launch_floor.hip: 1.6 vs 2.8 us per dependent empty launch).  Keyed by everything a launch argument depends on.
+    struct RunGraph {
+        int64_t T; double t_index0; int par0, cur0, qcur0, flags, np_parity;
+        const void *dU, *dY, *dll, *dxm, *drb;
+        uint64_t yhash;
+        hipGraphExec_t exec;
+        bool same(const RunGraph& o) const {
+            return T == o.T && t_index0 == o.t_index0 && par0 == o.par0 && cur0 == o.cur0 && qcur0 == o.qcur0 && flags == o.flags &&
+                   np_parity == o.np_parity && dU == o.dU && dY == o.dY && dll == o.dll && dxm == o.dxm && drb == o.drb && yhash == o.yhash;
+        }
+    };
+    std::vector<RunGraph> graphs;
     int64_t t_index = 0;
     // measurement
     bool profiling = false;
@@ -73,6 +87,9 @@ struct Bank {
     }
 };
 
+// Philox step argument of a launch issued now (relative to the base the device adds)
+static inline uint32_t rel_step(const Bank& b) { return b.n_predict - b.step_base; }
+
 struct llpf_filter { Bank bank; };
 struct llpf_bank { Bank bank; };
 
@@ -84,6 +101,8 @@ static int use_device(const Bank& b) {
 static void free_bank(Bank& b) {
     hipSetDevice(b.device);
     if (b.stream) hipStreamSynchronize(b.stream);
+    for (auto& g : b.graphs) if (g.exec) hipGraphExecDestroy(g.exec);
+    b.graphs.clear();
     hipFree(b.d_models); hipFree(b.d_scal); hipFree(b.d_x[0]); hipFree(b.d_x[1]); hipFree(b.d_w);
     hipFree(b.d_anc); hipFree(b.d_acc); hipFree(b.d_quanta[0]); hipFree(b.d_quanta[1]); hipFree(b.d_tileq); hipFree(b.d_flag); hipFree(b.d_xmpart); hipFree(b.d_lam); hipFree(b.d_rtile); hipFree(b.d_rb); hipFree(b.d_rbseq); hipFree(b.d_uy); hipFree(b.d_U); hipFree(b.d_Y);
     hipFree(b.d_ll_steps); hipFree(b.d_xmean); hipFree(b.d_tmp);
@@ -114,7 +133,9 @@ static void set_keys(Bank& b, std::vector<FilterScal>& h, uint64_t seed) {
         h[f].anc_ident_s[0] = cur; h[f].anc_ident_s[1] = cur;
     }
     b.n_predict = 0;
+    b.step_base = 0;
     for (int f = 0; f < b.F; ++f) {
+        h[f].step_base = 0;
         const uint64_t s = seed + (uint64_t)f;
         h[f].k0 = (uint32_t)s;
         h[f].k1 = (uint32_t)(s >> 32);

@@ -29,7 +29,9 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
         std::vector<FilterScal> h;
         CHK(scal_download(b, h));
         b.run_resamples = 0;
-        for (int f = 0; f < b.F; ++f) { h[f].ll_total = 0.0; b.run_resamples -= h[f].resample_count; }
+        // the device adds step_base to every Philox step argument: the launches of a run carry relative steps 0, 1, ...
+        b.step_base = b.n_predict;
+        for (int f = 0; f < b.F; ++f) { h[f].ll_total = 0.0; h[f].step_base = b.step_base; b.run_resamples -= h[f].resample_count; }
         CHK(scal_upload(b, h));
     }
     const double Ts = b.cfg.model.Ts;
@@ -95,7 +97,7 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
 
     auto res_args = [&](int64_t k, bool fast) {
         ResArgs ra{};
-        ra.parity = head_slot(k); ra.step = b.n_predict; ra.M = (int32_t)b.N; ra.anc_out = b.d_anc;
+        ra.parity = head_slot(k); ra.step = rel_step(b); ra.M = (int32_t)b.N; ra.anc_out = b.d_anc;
         ra.accumulate = 1; ra.want_xmean = want_xm; ra.u_from_scal = 1;
         ra.ll_steps = ll_steps ? b.d_ll_steps : nullptr;
         ra.xmean = xmean ? b.d_xmean : nullptr;
@@ -107,9 +109,9 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
         StepArgs st{};
         st.u = b.nu > 0 ? b.d_U + k * b.nu : nullptr;
         st.t_prop = tk(k);
-        st.step = b.n_predict;
+        st.step = rel_step(b);
         st.parity = b.parity;
-        st.need_e2 = ne2; st.K = K; st.k = k; st.next_step = b.n_predict + 1; st.want_xmean = want_xm; st.accumulate = merged ? 1 : 0;
+        st.need_e2 = ne2; st.K = K; st.k = k; st.next_step = rel_step(b) + 1; st.want_xmean = want_xm; st.accumulate = merged ? 1 : 0;
         if (rbm) { st.rb_pred = b.d_rbseq + (size_t)(2 * k + 1) * b.F; st.rb_corr = b.d_rbseq + (size_t)(2 * k + 2) * b.F; }
         const bool weight = (k + 1 < T);
         if (weight) { st.y = b.d_Y + (k + 1) * b.ny; st.t_meas = tk(k + 1); st.has_y = has_y(k + 1) ? 1 : 0; }
@@ -127,11 +129,11 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
         const bool weight = (k + 1 < T);
         if (fast && !merged) {   // split schedule: the sums of the current weights in bound form, as a streaming launch
             ProfScope ps(b, LLPF_PROF_NORMALISE);
-            HIPC(launch_norm(d, ra.parity, want_xm, ne2, b.n_predict, 0, 1, k, b.stream));
+            HIPC(launch_norm(d, ra.parity, want_xm, ne2, rel_step(b), 0, 1, k, b.stream));
         }
         if (!fast) {
             ProfScope ps(b, LLPF_PROF_NORMALISE);
-            HIPC(launch_norm(d, ra.parity, want_xm, 1, b.n_predict, only_fb, 0, k, b.stream));
+            HIPC(launch_norm(d, ra.parity, want_xm, 1, rel_step(b), only_fb, 0, k, b.stream));
         }
         if (unfused) {
             {
@@ -170,16 +172,55 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
         return LLPF_OK;
     };
 
-    HIPC(hipEventRecord(b.ev_run0, b.stream));
-    {   // weighting of the first correct! (exp-sums against the bound, quanta, tile sums: no separate normalise pass)
+    auto first_weighting = [&]() -> int {
+        // weighting of the first correct! (exp-sums against the bound, quanta, tile sums: no separate normalise pass)
+        b.cur = cur0; b.qcur = qcur0; b.parity = par0; b.n_predict = np0; b.t_index = ti0;      // the state at entry
         BankDev d = b.dev();
         StepArgs a{};
         a.u = b.nu > 0 ? b.d_U : nullptr; a.y = b.d_Y; a.t_prop = tk(0); a.t_meas = tk(0); a.step = 0; a.has_y = has_y(0) ? 1 : 0;
-        a.parity = par0; a.need_e2 = ne2; a.K = K; a.k = 0; a.next_step = np0; a.want_xmean = want_xm; a.accumulate = merged ? 1 : 0;
+        a.parity = par0; a.need_e2 = ne2; a.K = K; a.k = 0; a.next_step = 0; a.want_xmean = want_xm; a.accumulate = merged ? 1 : 0;
         if (rbm) a.rb_corr = b.d_rbseq;
         ProfScope ps(b, LLPF_PROF_PROPAGATE);
         HIPC(launch_step(d, MODE_WEIGHT, a, b.stream));
+        return LLPF_OK;
+    };
+    // the asynchronous loop as a captured graph, replayed when nothing a launch argument depends on has changed
+    static const char* graph_env = getenv("LLPF_GRAPH");
+    const bool use_graph = !hist && !b.profiling && !dbg_env && !(graph_env && atoi(graph_env) == 0);
+    hipGraphExec_t gexec = nullptr;
+    if (use_graph) {
+        Bank::RunGraph key{};
+        key.T = T; key.t_index0 = t_index0; key.par0 = par0; key.cur0 = cur0; key.qcur0 = qcur0;
+        key.flags = (merged ? 1 : 0) | (unfused ? 2 : 0) | (want_xm ? 4 : 0) | (ll_steps ? 8 : 0) | ((abl_env ? atoi(abl_env) : 0) << 8);
+        key.np_parity = (int)(np0 & 1u);
+        key.dU = b.d_U; key.dY = b.d_Y; key.dll = ll_steps ? b.d_ll_steps : nullptr; key.dxm = xmean ? b.d_xmean : nullptr; key.drb = b.d_rbseq;
+        key.yhash = 1469598103934665603ULL;
+        for (int64_t k = 0; k < T; ++k) key.yhash = (key.yhash ^ (uint64_t)(has_y(k) ? 1 : 2)) * 1099511628211ULL;
+        // a run shape is captured the second time it is seen (capture + instantiation of ~T nodes costs several ms:
+        // one-off shapes are simply enqueued)
+        Bank::RunGraph* slot = nullptr;
+        for (auto& g : b.graphs) if (g.same(key)) { slot = &g; gexec = g.exec; break; }
+        if (!slot) {
+            if (b.graphs.size() >= 4) { if (b.graphs.front().exec) hipGraphExecDestroy(b.graphs.front().exec); b.graphs.erase(b.graphs.begin()); }
+            key.exec = nullptr;
+            b.graphs.push_back(key);
+        } else if (!gexec) {
+            hipGraph_t graph = nullptr;
+            HIPC(hipStreamBeginCapture(b.stream, hipStreamCaptureModeThreadLocal));
+            int rc = first_weighting();
+            for (int64_t k = 0; rc == LLPF_OK && k < T; ++k) rc = launch_timestep(k, true, 0);
+            const hipError_t ee = hipStreamEndCapture(b.stream, &graph);
+            if (rc != LLPF_OK) { if (graph) hipGraphDestroy(graph); return rc; }
+            if (ee != hipSuccess) return fail(LLPF_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ee));
+            const hipError_t ei = hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0);
+            hipGraphDestroy(graph);
+            if (ei != hipSuccess) return fail(LLPF_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ei));
+            slot->exec = gexec;
+        }
     }
+    HIPC(hipEventRecord(b.ev_run0, b.stream));
+    if (gexec) HIPC(hipGraphLaunch(gexec, b.stream));
+    else CHK(first_weighting());
     if (hist) {
         // step-synchronous form: the normalised state between correct! and predict! is copied out
         // (forward_trajectory history, reference src/filtering.jl:357-359).  Same arithmetic as the asynchronous
@@ -195,7 +236,7 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
             CHK(poll_fallback(b, fl, kf));
             if (!fl.empty()) {
                 CHK(clear_slot_sums(b, ra.parity, fl));
-                HIPC(launch_norm(d, ra.parity, want_xm, 1, b.n_predict, 1, 0, k, b.stream));
+                HIPC(launch_norm(d, ra.parity, want_xm, 1, rel_step(b), 1, 0, k, b.stream));
                 ra.fast_head = 0; ra.only_fallback = 1;
                 HIPC(launch_resample(d, ra, b.stream));
                 ra.only_fallback = 0;
@@ -224,8 +265,10 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
         }
     } else {
         int64_t k0 = 0;
+        bool replayed = gexec != nullptr;       // the graph holds all T timesteps; after a failed bound test the rest is enqueued
         while (k0 < T) {
-            for (int64_t k = k0; k < T; ++k) CHK(launch_timestep(k, true, 0));
+            if (!replayed) for (int64_t k = k0; k < T; ++k) CHK(launch_timestep(k, true, 0));
+            replayed = false;
             std::vector<int> fl;
             int64_t kf;
             CHK(poll_fallback(b, fl, kf));

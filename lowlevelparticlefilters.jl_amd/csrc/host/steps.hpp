@@ -13,7 +13,7 @@ static int bank_correct(Bank& b, const double* u, const double* y, double t, dou
         BankDev d = b.dev();
         StepArgs a{};
         a.u = b.d_uy; a.y = b.d_uy + MAXD; a.t_prop = t; a.t_meas = t; a.step = 0; a.has_y = has_y ? 1 : 0;
-        a.parity = slot; a.need_e2 = 1; a.K = llpf_qbits(b.N); a.k = 0; a.next_step = b.n_predict; a.accumulate = 1;
+        a.parity = slot; a.need_e2 = 1; a.K = llpf_qbits(b.N); a.k = 0; a.next_step = rel_step(b); a.accumulate = 1;
         if (is_rb(b) && has_y) { CHK(rb_upload_single(b, true)); a.rb_corr = b.d_rb; }
         HIPC(launch_step(d, MODE_WEIGHT, a, b.stream));     // weights + exp-sums against the bound + quanta
     }
@@ -28,7 +28,7 @@ static int bank_correct(Bank& b, const double* u, const double* y, double t, dou
     CHK(poll_fallback(b, fl, kf));
     if (!fl.empty()) {   // bound test failed: exact-max normalisation of the same weights
         CHK(clear_slot_sums(b, slot, fl));
-        HIPC(launch_norm(d, slot, 0, 1, b.n_predict, 1, 0, 0, b.stream));
+        HIPC(launch_norm(d, slot, 0, 1, rel_step(b), 1, 0, 0, b.stream));
         ra.fast_head = 0; ra.only_fallback = 1;
         HIPC(launch_resample(d, ra, b.stream));
         CHK(clear_fallback(b, fl));
@@ -46,11 +46,11 @@ static int bank_predict(Bank& b, const double* u, double t) {
     HIPC(hipMemcpyAsync(b.d_uy, hbuf, sizeof(hbuf), hipMemcpyHostToDevice, b.stream));
     BankDev d = b.dev();
     ResArgs ra{};
-    ra.mode = RES_RESAMPLE; ra.parity = (b.parity + ACC_NSLOT - 1) % ACC_NSLOT; ra.step = b.n_predict; ra.M = (int32_t)b.N;
+    ra.mode = RES_RESAMPLE; ra.parity = (b.parity + ACC_NSLOT - 1) % ACC_NSLOT; ra.step = rel_step(b); ra.M = (int32_t)b.N;
     ra.anc_out = b.d_anc; ra.k = 0;
     HIPC(launch_resample(d, ra, b.stream));
     StepArgs a{};
-    a.u = b.d_uy; a.y = nullptr; a.t_prop = t; a.t_meas = t; a.step = b.n_predict; a.has_y = 0; a.parity = b.parity;
+    a.u = b.d_uy; a.y = nullptr; a.t_prop = t; a.t_meas = t; a.step = rel_step(b); a.has_y = 0; a.parity = b.parity;
     a.K = llpf_qbits(b.N); a.k = 0;
     if (is_rb(b)) { CHK(rb_upload_single(b, false)); a.rb_pred = b.d_rb + b.F; }
     HIPC(launch_step(d, MODE_PROP, a, b.stream));

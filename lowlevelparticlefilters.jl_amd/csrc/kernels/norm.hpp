@@ -90,7 +90,7 @@ __global__ __launch_bounds__(BLOCK) void k_norm(BankDev b, int K, int parity, ui
         if (NEED_E2) acc_add_u128(acc, ACC_E2(parity), e2);
         if (tile == 0) {   // the single uniform a systematic resample of this step consumes (reference: rand(), resample.jl:23)
             FilterScal* sc = b.scal + f;
-            sc->u_slot[parity] = llpf_uniform_step(step, LLPF_STREAM_RESAMPLE, sc->k0, sc->k1);
+            sc->u_slot[parity] = llpf_uniform_step(sc->step_base + step, LLPF_STREAM_RESAMPLE, sc->k0, sc->k1);
             sc->e2v_slot[parity] = NEED_E2 ? 1 : 0;
             sc->xm_parts = b.P2;
         }

@@ -275,7 +275,7 @@ DEV void res_counts(const BankDev& b, const ResArgs& a, int f, int tile, const R
     uint32_t cnt[NORM_IPT];
     if (STRATEGY == LLPF_RESAMPLE_SYSTEMATIC) {
         ThrSys th;
-        const double U = a.Uexp ? a.Uexp[0] : (a.u_from_scal ? sc->u_slot[a.parity] : llpf_uniform_step(a.step, LLPF_STREAM_RESAMPLE, sc->k0, sc->k1));
+        const double U = a.Uexp ? a.Uexp[0] : (a.u_from_scal ? sc->u_slot[a.parity] : llpf_uniform_step(sc->step_base + a.step, LLPF_STREAM_RESAMPLE, sc->k0, sc->k1));
         th.M = M; th.Md = (double)M; th.step = 1.0 / (double)M;
         th.delta = 1e-9 + th.Md * 1e-13;
         th.r = U * binsN / (double)N;                  // r = rand()*bins[end]/N  (resample.jl:23)
@@ -288,7 +288,7 @@ DEV void res_counts(const BankDev& b, const ResArgs& a, int f, int tile, const R
         c_start = a.only_bins ? 0 : th.count((double)h.prefix * invTd);
     } else {
         ThrStrat th;
-        th.M = M; th.Md = (double)M; th.step = a.step; th.k0 = sc->k0; th.k1 = sc->k1; th.Uexp = a.Uexp;
+        th.M = M; th.Md = (double)M; th.step = sc->step_base + a.step; th.k0 = sc->k0; th.k1 = sc->k1; th.Uexp = a.Uexp;
         th.delta = 1e-9 + th.Md * 1e-13;
         th.binsN = binsN;
 #pragma unroll

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(BLOCK) void k_resid_expand(BankDev b, ResArgs a) {
     const double invTd = 1.0 / Td;
     const uint64_t* __restrict__ pr = rt + b.P2;
     for (int64_t m = m0 + threadIdx.x; m < m1; m += BLOCK) {
-        const double u = a.Uexp ? a.Uexp[m] : llpf_uniform_idx((uint32_t)m, a.step, LLPF_STREAM_STRATIFY, sc->k0, sc->k1);
+        const double u = a.Uexp ? a.Uexp[m] : llpf_uniform_idx((uint32_t)m, sc->step_base + a.step, LLPF_STREAM_STRATIFY, sc->k0, sc->k1);
         int64_t src = -1;
         if (totr != 0) {
             int lo = 0, hi = b.P2;                      // first tile t with u < bins(end of t)

@@ -40,6 +40,7 @@ struct PropCtx {
     double* __restrict__ xn;
     double* w;
     uint32_t k0, k1;
+    uint32_t pstep;        // Philox step of this predict! (step_base + st.step)
     int ablate;
     double off;            // bound of the new weights (offset of their exp-sums)
     uint64_t* qnext;       // quanta of the new weights
@@ -52,7 +53,7 @@ struct PropCtx {
 #pragma unroll
         for (int d = 0; d < NX; ++d) xp[d] = ld_off(xc + (size_t)d * Ns, so);
         if constexpr (Model::RB) {     // Rao-Blackwellized model: own noise structure, and correct! updates xl before the store
-            model.rb_propagate(xp, o, st.step, k0, k1, st.rb_pred + blockIdx.y, xs);
+            model.rb_propagate(xp, o, pstep, k0, k1, st.rb_pred + blockIdx.y, xs);
             double wr = wprev;
             if (WEIGHT) {
                 if (st.has_y) wr = wr + model.rb_weight(xs, y, st.rb_corr + blockIdx.y, o == 0);
@@ -67,11 +68,11 @@ struct PropCtx {
 #ifdef LLPF_DEVTOOLS   /* ablation switches for performance experiments (results invalid); not in production builds */
         if (!(ablate & 4)) model.dynamics(xp, fx);
         else { for (int d = 0; d < NX; ++d) fx[d] = xp[d]; }
-        if (!(ablate & 1)) llpf_normals(o, st.step, LLPF_STREAM_DYNAMICS, k0, k1, NX, xi);
+        if (!(ablate & 1)) llpf_normals(o, pstep, LLPF_STREAM_DYNAMICS, k0, k1, NX, xi);
         else { for (int d = 0; d < NX; ++d) xi[d] = 0.25 * (double)(o & 7); }
 #else
         model.dynamics(xp, fx);
-        llpf_normals(o, st.step, LLPF_STREAM_DYNAMICS, k0, k1, NX, xi);
+        llpf_normals(o, pstep, LLPF_STREAM_DYNAMICS, k0, k1, NX, xi);
 #endif
         gauss_sample<NX>(md->df, xi, nz);
 #pragma unroll
@@ -150,13 +151,13 @@ __global__ __launch_bounds__(BLOCK) void k_resprop(BankDev b, const ModelD* __re
     double y[NY];
 #pragma unroll
     for (int k = 0; k < NY; ++k) y[k] = (WEIGHT && st.has_y) ? st.y[k] : 0.0;
-    const uint32_t key0 = sc->k0, key1 = sc->k1;
+    const uint32_t key0 = sc->k0, key1 = sc->k1, sb = sc->step_base;
     const double c0_pre = md->dg.c0;                   // fetched with the other loads: the bound below must not wait for it
     const ResHead h = res_head<SRC_FILTER>(b, a, f, tile, sh, true, stop_flag, fb_flag);
     if (h.status) return;
     LLPF_STAMP(1);
     PropCtx<Model, NX, NY, WEIGHT> pc{b, model, md, st, y, b.xcur + (size_t)f * NX * Ns, b.xnext + (size_t)f * NX * Ns,
-                                      b.w + (size_t)f * Ns, key0, key1, a.ablate, 0.0, b.quanta_next + (size_t)f * Ns};
+                                      b.w + (size_t)f * Ns, key0, key1, sb + st.step, a.ablate, 0.0, b.quanta_next + (size_t)f * Ns};
     int32_t* anc = b.anc + (size_t)f * Ns;
     double bmax = -LLPF_INF;
     bool bad = false;
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(BLOCK) void k_resprop(BankDev b, const ModelD* __re
             if (ACC) sc->xm_parts = b.P2;
             sc->off_slot[st.parity] = pc.off;
             sc->e2v_slot[st.parity] = st.need_e2;
-            sc->u_slot[st.parity] = llpf_uniform_step(st.next_step, LLPF_STREAM_RESAMPLE, sc->k0, sc->k1);
+            sc->u_slot[st.parity] = llpf_uniform_step(sb + st.next_step, LLPF_STREAM_RESAMPLE, sc->k0, sc->k1);
         }
     }
     __syncthreads();

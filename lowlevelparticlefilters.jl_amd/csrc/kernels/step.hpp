@@ -16,7 +16,7 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
     const int do_res = (MODE != MODE_WEIGHT && MODE != MODE_AUX) ? sc->do_resample : 0;
     const int uniform = sc->uniform, pend = sc->norm_pending;
     const double m = sc->m, l = sc->l, wconst = sc->wconst;
-    const uint32_t k0 = sc->k0, k1 = sc->k1;
+    const uint32_t k0 = sc->k0, k1 = sc->k1, sb = sc->step_base;
     const int64_t Ns = b.Ns, N = b.N;
     const double* __restrict__ xc = b.xcur + (size_t)f * NX * Ns;
     double* __restrict__ xn = b.xnext + (size_t)f * NX * Ns;
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
 #pragma unroll
             for (int p = 0; p < STEP_PPT; ++p) {
                 if constexpr (Model::RB) {
-                    model.rb_propagate(xp[p], (uint32_t)(i0 + p), a.step, k0, k1, a.rb_pred + f, xs[p]);
+                    model.rb_propagate(xp[p], (uint32_t)(i0 + p), sb + a.step, k0, k1, a.rb_pred + f, xs[p]);
                     continue;
                 }
                 double fx[NX], xi[NX], nz[NX];
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
 #pragma unroll
                     for (int d = 0; d < NX; ++d) xs[p][d] = fx[d];
                 } else {
-                    llpf_normals((uint32_t)(i0 + p), a.step, LLPF_STREAM_DYNAMICS, k0, k1, NX, xi);
+                    llpf_normals((uint32_t)(i0 + p), sb + a.step, LLPF_STREAM_DYNAMICS, k0, k1, NX, xi);
                     gauss_sample<NX>(md->df, xi, nz);
 #pragma unroll
                     for (int d = 0; d < NX; ++d) xs[p][d] = fx[d] + nz[d];
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
                 if (a.accumulate) scw->xm_parts = b.P1;
                 scw->off_slot[a.parity] = off;
                 scw->e2v_slot[a.parity] = a.need_e2;
-                scw->u_slot[a.parity] = llpf_uniform_step(a.next_step, LLPF_STREAM_RESAMPLE, k0, k1);
+                scw->u_slot[a.parity] = llpf_uniform_step(sb + a.next_step, LLPF_STREAM_RESAMPLE, k0, k1);
             }
         }
     }

@@ -655,3 +655,28 @@ def test_error_paths_of_the_newer_entry_points():
     qt.qt[S.QT_NAMES.index("eps")] = 0.0
     with pytest.raises(_capi.LLPFError):
         _capi.FilterHandle(_cfg(qt, 100, kind=S.ADVANCED_PARTICLE_FILTER))
+
+
+@pytest.mark.parametrize("thr", [0.1, 1.0])
+def test_repeated_runs_replay_a_captured_graph(thr):
+    """loglik called again and again with the same shapes (an optimisation / MCMC loop): the second call captures the
+    run loop into a hipGraph, later calls replay it.  Every pass must equal the oracle's pass (fresh noise each time:
+    the Philox step base moves, the captured relative steps do not), including a pass whose outlier measurement makes
+    a bound test fail in the middle of a replay, and a change of data with the same shape."""
+    model = M.lg_test_model(0.1)
+    _, U, Y = M.simulate_lg(model, 50, seed=9)
+    Yo = Y.copy()
+    Yo[31] += 12.0
+    cfg = _cfg(model, 3000, thr=thr, seed=17)
+    g = _capi.FilterHandle(cfg)
+    o = ob.OracleFilter(cfg, ob.ORDER_DEVICE)
+    n_exact = 0
+    for p, Yp in enumerate([Y, Y, Y, Yo, Yo, Y, Yo]):
+        g.reset(); o.reset()
+        rg = g.run(U, Yp, 1.0, ll_steps=True)
+        e0 = o.exact_steps()
+        ro = o.run(U, Yp, 1.0, ll_steps=True)
+        n_exact += o.exact_steps() - e0
+        assert np.array_equal(rg["ll_steps"].view(np.uint64), ro["ll_steps"].view(np.uint64)), p
+        _compare_state(g, o)
+    assert n_exact >= 3

@@ -33,5 +33,25 @@ int main() {
     time("empty, grid 1954 x 256", [&] { hipLaunchKernelGGL(k_empty, dim3(1954), dim3(256), 0, s, 0); }, 3000);
     time("one dependent 8-B load+store per block, 977", [&] { hipLaunchKernelGGL(k_dep, dim3(977), dim3(256), 0, s, a, b); }, 3000);
     time("stream 8 MB read + 8 MB write (1e6 doubles)", [&] { hipLaunchKernelGGL(k_touch, dim3((n / 2 + 255) / 256), dim3(256), 0, s, a, b, n); }, 3000);
+    // the same chains captured once into a hipGraph and replayed: does a graph shorten the dependent-launch gap?
+    auto time_graph = [&](const char* name, auto fn, int chain, int reps) {
+        hipGraph_t g; hipGraphExec_t ge;
+        hipStreamBeginCapture(s, hipStreamCaptureModeGlobal);
+        for (int i = 0; i < chain; ++i) fn();
+        hipStreamEndCapture(s, &g);
+        hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+        hipGraphLaunch(ge, s);
+        hipStreamSynchronize(s);
+        hipEventRecord(e0, s);
+        for (int i = 0; i < reps; ++i) hipGraphLaunch(ge, s);
+        hipEventRecord(e1, s);
+        hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("graph: %-37s %8.2f us per launch\n", name, 1e3 * ms / (reps * chain));
+        hipGraphExecDestroy(ge); hipGraphDestroy(g);
+    };
+    time_graph("empty, grid 977 x 256", [&] { hipLaunchKernelGGL(k_empty, dim3(977), dim3(256), 0, s, 0); }, 1000, 5);
+    time_graph("one dependent load+store per block, 977", [&] { hipLaunchKernelGGL(k_dep, dim3(977), dim3(256), 0, s, a, b); }, 1000, 5);
+    time_graph("stream 8 MB read + 8 MB write", [&] { hipLaunchKernelGGL(k_touch, dim3((n / 2 + 255) / 256), dim3(256), 0, s, a, b, n); }, 1000, 5);
     return 0;
 }
