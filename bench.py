@@ -142,6 +142,8 @@ def main_bank(args, rank, world, dev):
         r = bank.run(U, Y, 1.0)
         return allreduce_logliks(r["ll"], owned, F, device)
 
+    for _ in range(2):                 # setup, untimed: hipGraph capture of the run shape (see main())
+        one_pass()
     for _ in range(args.warmup):
         one_pass()
     if world > 1:
@@ -253,6 +255,10 @@ def main():
             dist.all_reduce(ll_dev)          # the global log-likelihood: the only collective of the path
         return r["ll"]
 
+    # setup, untimed: the engine captures a run shape into a hipGraph the second time it sees it; two passes
+    # here keep that one-off capture (~10 ms) out of the warm-up accounting and of the timed region
+    for _ in range(2):
+        one_pass()
     for _ in range(args.warmup):
         one_pass()
     if world > 1:
