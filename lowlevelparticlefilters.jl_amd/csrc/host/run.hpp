@@ -118,6 +118,20 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
         else { st.y = nullptr; st.t_meas = tk(k); st.has_y = 0; }
         return st;
     };
+    // History outputs are staged on the device (one row per timestep, written between the head and the propagate of the
+    // balanced form, no host round trip per step) and copied out in bulk at the end; beyond 16 GB of history the
+    // step-synchronous loop below copies row by row instead.
+    const size_t hist_rows = (size_t)T * b.N;
+    const size_t hist_doubles = (x_hist ? hist_rows * b.nx : 0) + (w_hist ? hist_rows : 0) + (we_hist ? hist_rows : 0);
+    const bool hist_dev = hist && hist_doubles * sizeof(double) <= ((size_t)16 << 30);
+    double *dx_hist = nullptr, *dw_hist = nullptr, *dwe_hist = nullptr;
+    if (hist_dev) {
+        CHK(ensure(&b.d_hist, &b.cap_hist, hist_doubles));
+        double* p = b.d_hist;
+        if (x_hist) { dx_hist = p; p += hist_rows * b.nx; }
+        if (w_hist) { dw_hist = p; p += hist_rows; }
+        if (we_hist) { dwe_hist = p; p += hist_rows; }
+    }
     // one timestep in the given form; `fast`: the head consumes the bound-offset sums of the previous weighting,
     // otherwise the exact-max sums of a k_norm launched just before (redo of a failed step, or weighted means)
     auto launch_timestep = [&](int64_t k, bool fast, int only_fb) -> int {
@@ -140,6 +154,11 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
                 ra.mode = RES_FINALIZE | RES_RESAMPLE;
                 ProfScope ps(b, LLPF_PROF_RESAMPLE);
                 HIPC(launch_resample(d, ra, b.stream));
+            }
+            if (hist_dev) {   // x[:,t] .= particles(pf); w[:,t] .= weights(pf); we[:,t] .= expweights(pf)  (filtering.jl:357-359)
+                ProfScope ps(b, LLPF_PROF_OTHER);
+                if (dx_hist) HIPC(launch_soa2aos(d, b.d_x[b.cur], dx_hist + (size_t)k * b.N * b.nx, b.stream));
+                if (dw_hist || dwe_hist) HIPC(launch_materialize(d, dw_hist ? dw_hist + (size_t)k * b.N : nullptr, dwe_hist ? dwe_hist + (size_t)k * b.N : nullptr, b.stream));
             }
             ProfScope ps(b, LLPF_PROF_PROPAGATE);
             st.only_fallback = only_fb;
@@ -221,7 +240,7 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
     HIPC(hipEventRecord(b.ev_run0, b.stream));
     if (gexec) HIPC(hipGraphLaunch(gexec, b.stream));
     else CHK(first_weighting());
-    if (hist) {
+    if (hist && !hist_dev) {
         // step-synchronous form: the normalised state between correct! and predict! is copied out
         // (forward_trajectory history, reference src/filtering.jl:357-359).  Same arithmetic as the asynchronous
         // loop below (bound-offset form, exact redo when its test fails); not a timed path.
@@ -289,6 +308,11 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
         HIPC(launch_post_predict(d, b.stream));
     }
     HIPC(hipEventRecord(b.ev_run1, b.stream));
+    if (hist_dev) {
+        if (x_hist) HIPC(hipMemcpyAsync(x_hist, dx_hist, sizeof(double) * hist_rows * b.nx, hipMemcpyDeviceToHost, b.stream));
+        if (w_hist) HIPC(hipMemcpyAsync(w_hist, dw_hist, sizeof(double) * hist_rows, hipMemcpyDeviceToHost, b.stream));
+        if (we_hist) HIPC(hipMemcpyAsync(we_hist, dwe_hist, sizeof(double) * hist_rows, hipMemcpyDeviceToHost, b.stream));
+    }
     if (ll_steps) HIPC(hipMemcpyAsync(ll_steps, b.d_ll_steps, sizeof(double) * T * b.F, hipMemcpyDeviceToHost, b.stream));
     if (xmean) HIPC(hipMemcpyAsync(xmean, b.d_xmean, sizeof(double) * T * b.F * b.nx, hipMemcpyDeviceToHost, b.stream));
     std::vector<FilterScal> h;
