@@ -33,7 +33,7 @@ extern "C" {
 #endif
 
 #define LLPF_VERSION_MAJOR 0
-#define LLPF_VERSION_MINOR 2
+#define LLPF_VERSION_MINOR 3
 #define LLPF_MAX_DIM 8
 
 /* status codes */
@@ -68,8 +68,27 @@ enum {
      *   y   = Gn xn + Cl xl + e,          e  ~ measurement_density (R2)
      * state x = [xn; xl] (nx = nxn + nxl <= 4); A = [Fn An; 0 Al], B = [Bn; Bl], C = [Gn Cl];
      * initial_density = d0n (dimension nxn), linear_initial = d0l (the inner KalmanFilter's d0). */
-    LLPF_MODEL_RB_LINEAR       = 2
+    LLPF_MODEL_RB_LINEAR       = 2,
+    /* Rao-Blackwellized particle filter whose coupling matrix depends on the nonlinear state (reference src/rbpf.jl:163-283
+     * with `An` a function of x: the "singleR" shortcut :176/:247 is off, every particle carries its own covariance R and
+     * runs its own Riccati recursion — BASELINE config C5):
+     *   xn' = f_n(xn, u) + An(xn) xl + wn,   An(xn) = An[0] + sum_k xn[k] An[1+k]      (llpf_rb_coupling below)
+     *   xl' = Al xl + Bl u + wl,             y = g(xn) + Cl xl + e
+     * The x arrays of the filter hold xn only: nx = nxn <= 4; f_n / g are the linear-Gaussian descriptors A, B, C of this
+     * struct sized for nxn (rb.fn_kind 0) or the quad-tank RK4 dynamics / measurement (rb.fn_kind 1, nxn = 4, ny = 2).
+     * nxl = rb.nxl <= 8, ny <= 2; dynamics_density = R1n (must be Gaussian), linear_noise = R1l, linear_initial = d0l. */
+    LLPF_MODEL_RB_BILINEAR     = 3
 };
+
+/* linear substate and state-dependent coupling of LLPF_MODEL_RB_BILINEAR (ignored by the other models) */
+typedef struct llpf_rb_coupling {
+    int32_t nxl;                              /* number of linear states (1..8) */
+    int32_t fn_kind;                          /* 0: f_n = A xn + B u, g = C xn;  1: quad-tank RK4 f_n, g (qt, supersample) */
+    double  Al[LLPF_MAX_DIM * LLPF_MAX_DIM];  /* nxl x nxl row-major: kf.A */
+    double  Bl[LLPF_MAX_DIM * LLPF_MAX_DIM];  /* nxl x nu  row-major: kf.B */
+    double  Cl[LLPF_MAX_DIM * LLPF_MAX_DIM];  /* ny  x nxl row-major: kf.C (must not be zero) */
+    double  An[5][32];                        /* An[0]: constant term; An[1+k]: multiplies xn[k]; each nxn x nxl row-major */
+} llpf_rb_coupling;
 
 /* quadtank constant slots in llpf_model.qt[] */
 enum { LLPF_QT_K1 = 0, LLPF_QT_K2, LLPF_QT_G, LLPF_QT_A1, LLPF_QT_A2, LLPF_QT_A3, LLPF_QT_A4,
@@ -93,6 +112,7 @@ typedef struct llpf_model {
     llpf_gaussian initial_density;            /* d0  (RB: d0n, dimension nxn) */
     llpf_gaussian linear_noise;               /* RB only: N(0, R1l), dimension nx - nxn (kf.R1) */
     llpf_gaussian linear_initial;             /* RB only: d0l, dimension nx - nxn (kf.d0)       */
+    llpf_rb_coupling rb;                      /* LLPF_MODEL_RB_BILINEAR only */
 } llpf_model;
 
 enum { LLPF_RESAMPLE_SYSTEMATIC = 0, LLPF_RESAMPLE_STRATIFIED = 1, LLPF_RESAMPLE_RESIDUAL = 2 };   /* reference src/LowLevelParticleFilters.jl:43-46 */
@@ -182,6 +202,9 @@ int  llpf_aux_run(llpf_filter* f, const double* U, const double* Y, int64_t T, i
  * filter's untouched x, R), llpf_predict = predict! (:163-232), llpf_run = forward_trajectory / loglik.  Particles
  * are [xn; xl].  An != 0 needs nxn == 1 (the right division by Nt, :212, is implemented for a scalar). */
 int  llpf_rb_get_covariance(llpf_filter* f, double* R /* nxl*nxl row-major: x[1].R */);
+/* LLPF_MODEL_RB_BILINEAR: the per-particle Kalman state (fields xl, R of every RBParticle, reference src/rbpf.jl:1-5);
+ * xl [N][nxl], R [N][nxl][nxl] row-major, either may be NULL.  llpf_get_particles returns the xn part. */
+int  llpf_rb_get_linear_state(llpf_filter* f, double* xl, double* R);
 
 /* ---- particle smoother ---------------------------------------------------------------------------------------
  * xb, ll = smooth(pf, xf, wf, wef, ll, M, u, y, p) — reference src/smoothing.jl:116-143: forward-filtering backward

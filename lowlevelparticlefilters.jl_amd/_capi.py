@@ -30,6 +30,7 @@ SYMBOLS = {
     "llpf_run": [_vp, _dp, _dp, C.c_int64, C.c_double, _dp, C.POINTER(S.RunOutputs)],
     "llpf_smooth": [_vp, C.c_int64, _dp, C.c_int64, _dp, _dp, _dp, _dp, _ip],
     "llpf_rb_get_covariance": [_vp, _dp],
+    "llpf_rb_get_linear_state": [_vp, _dp, _dp],
     "llpf_aux_correct": [_vp, _dp],
     "llpf_aux_predict": [_vp, _dp, _dp, C.c_double],
     "llpf_aux_update": [_vp, _dp, _dp, C.c_double, _dp],
@@ -220,6 +221,14 @@ class FilterHandle:
         a = np.zeros((nl, nl))
         check(self.L.llpf_rb_get_covariance(self.h, dptr(a)))
         return a
+
+    def rb_linear_state(self):
+        """per-particle Kalman state of LLPF_MODEL_RB_BILINEAR: xl [N, nxl], R [N, nxl, nxl] (fields of RBParticle)."""
+        nl = self.cfg.model.rb.nxl
+        xl = np.zeros((self.N, nl))
+        R = np.zeros((self.N, nl, nl))
+        check(self.L.llpf_rb_get_linear_state(self.h, dptr(xl), dptr(R)))
+        return xl, R
 
     def smooth(self, M, U, xf, wf, wef):
         """xb [T, M, nx], idx [T, M]: smooth(pf, xf, wf, wef, ll, M, u, y) — reference src/smoothing.jl:116-143."""

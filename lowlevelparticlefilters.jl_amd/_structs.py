@@ -7,7 +7,7 @@ import numpy as np
 MAX_DIM = 8
 
 COV_SCAL, COV_DIAG, COV_FULL = 0, 1, 2
-MODEL_LINEAR_GAUSSIAN, MODEL_QUADTANK_RK4, MODEL_RB_LINEAR = 0, 1, 2
+MODEL_LINEAR_GAUSSIAN, MODEL_QUADTANK_RK4, MODEL_RB_LINEAR, MODEL_RB_BILINEAR = 0, 1, 2, 3
 RESAMPLE_SYSTEMATIC, RESAMPLE_STRATIFIED, RESAMPLE_RESIDUAL = 0, 1, 2
 PARTICLE_FILTER, ADVANCED_PARTICLE_FILTER = 0, 1
 
@@ -21,6 +21,12 @@ class Gaussian(C.Structure):
                 ("mu", C.c_double * MAX_DIM), ("cov", C.c_double * (MAX_DIM * MAX_DIM))]
 
 
+class RBCoupling(C.Structure):
+    _fields_ = [("nxl", C.c_int32), ("fn_kind", C.c_int32),
+                ("Al", C.c_double * 64), ("Bl", C.c_double * 64), ("Cl", C.c_double * 64),
+                ("An", (C.c_double * 32) * 5)]
+
+
 class Model(C.Structure):
     _fields_ = [("model_id", C.c_int32), ("nx", C.c_int32), ("nu", C.c_int32), ("ny", C.c_int32),
                 ("A", C.c_double * 64), ("B", C.c_double * 64), ("C", C.c_double * 64),
@@ -28,7 +34,8 @@ class Model(C.Structure):
                 ("supersample", C.c_int32), ("nxn", C.c_int32),
                 ("Ts", C.c_double),
                 ("dynamics_density", Gaussian), ("measurement_density", Gaussian),
-                ("initial_density", Gaussian), ("linear_noise", Gaussian), ("linear_initial", Gaussian)]
+                ("initial_density", Gaussian), ("linear_noise", Gaussian), ("linear_initial", Gaussian),
+                ("rb", RBCoupling)]
 
 
 class Config(C.Structure):
@@ -160,6 +167,69 @@ def make_rb_model(Fn, Bn, An, Al, Bl, Gn, Cl, R1n, R1l, R2, d0n, d0l, Ts=1.0):
         for c in range(nx):
             m.C[r * nx + c] = Cm[r, c]
     m.supersample = 1
+    m.Ts = float(Ts)
+    m.dynamics_density, m.measurement_density, m.initial_density = R1n, R2, d0n
+    m.linear_noise = make_gaussian(np.zeros(nl), np.atleast_2d(np.asarray(R1l, dtype=np.float64)), COV_FULL)
+    m.linear_initial = d0l
+    if R1n.dim != nn or d0n.dim != nn or R2.dim != ny or d0l.dim != nl:
+        raise ValueError("density dimensions do not match the RB model")
+    return m
+
+
+def make_rb_bilinear_model(An, Al, Bl, Cl, R1n, R1l, R2, d0n, d0l, Fn=None, Bn=None, Gn=None, quadtank=None,
+                           Ts=1.0, supersample=2):
+    """Rao-Blackwellized model whose coupling depends on the nonlinear state (reference src/rbpf.jl:92-98 with `An` a
+    function of x): xn' = f_n(xn, u) + An(xn) xl + wn, An(xn) = An[0] + sum_k xn[k] An[1+k]; xl' = Al xl + Bl u + wl;
+    y = g(xn) + Cl xl + e.  f_n / g: linear (Fn, Bn, Gn) or the quad-tank (quadtank = dict of constants, nxn = 4).
+    An: array [1 + nxn, nxn, nxl].  R1n, R2, d0n, d0l are Gaussian structs; R1l a matrix."""
+    An = np.asarray(An, dtype=np.float64)
+    nn, nl = An.shape[1], An.shape[2]
+    if An.shape[0] != nn + 1 or nn > 4 or nl > 8:
+        raise ValueError("An must be [1 + nxn, nxn, nxl] with nxn <= 4, nxl <= 8")
+    Al = np.asarray(Al, dtype=np.float64).reshape(nl, nl)
+    Cl = np.asarray(Cl, dtype=np.float64).reshape(-1, nl)
+    ny = Cl.shape[0]
+    m = Model()
+    m.model_id = MODEL_RB_BILINEAR
+    if quadtank is not None:
+        if nn != 4 or ny != 2:
+            raise ValueError("the quad-tank nonlinear part has 4 states and 2 outputs")
+        nu = 2
+        vals = dict(QUADTANK_DEFAULTS)
+        vals.update(quadtank)
+        for i, name in enumerate(QT_NAMES):
+            m.qt[i] = float(vals[name])
+        m.rb.fn_kind = 1
+    else:
+        Fn = np.asarray(Fn, dtype=np.float64).reshape(nn, nn)
+        Gn = np.asarray(Gn, dtype=np.float64).reshape(ny, nn)
+        Bn = np.zeros((nn, 0)) if Bn is None else np.asarray(Bn, dtype=np.float64).reshape(nn, -1)
+        nu = Bn.shape[1]
+        for r in range(nn):
+            for c in range(nn):
+                m.A[r * nn + c] = Fn[r, c]
+            for c in range(nu):
+                m.B[r * nu + c] = Bn[r, c]
+        for r in range(ny):
+            for c in range(nn):
+                m.C[r * nn + c] = Gn[r, c]
+        m.rb.fn_kind = 0
+    Bl = np.zeros((nl, nu)) if Bl is None else np.asarray(Bl, dtype=np.float64).reshape(nl, nu)
+    m.nx, m.nu, m.ny, m.nxn = nn, nu, ny, nn
+    m.rb.nxl = nl
+    for r in range(nl):
+        for c in range(nl):
+            m.rb.Al[r * nl + c] = Al[r, c]
+        for c in range(nu):
+            m.rb.Bl[r * nu + c] = Bl[r, c]
+    for r in range(ny):
+        for c in range(nl):
+            m.rb.Cl[r * nl + c] = Cl[r, c]
+    for k in range(nn + 1):
+        for r in range(nn):
+            for c in range(nl):
+                m.rb.An[k][r * nl + c] = An[k, r, c]
+    m.supersample = int(supersample)
     m.Ts = float(Ts)
     m.dynamics_density, m.measurement_density, m.initial_density = R1n, R2, d0n
     m.linear_noise = make_gaussian(np.zeros(nl), np.atleast_2d(np.asarray(R1l, dtype=np.float64)), COV_FULL)

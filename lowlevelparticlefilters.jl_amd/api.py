@@ -21,6 +21,7 @@ from . import _capi
 from . import _structs as S
 
 __all__ = [
+    "StateAffineCoupling",
     "MvNormal", "ResampleSystematic", "ResampleStratified",
     "LinearDynamics", "LinearMeasurement", "QuadTankDynamics", "QuadTankMeasurement", "GaussianLikelihood",
     "ResampleResidual", "weighted_cov", "mode_trajectory", "KalmanFilter", "RBMeasurementModel", "RBPF", "smooth", "smoothed_mean", "smoothed_cov", "smoothed_trajs", "ParticleFilter", "AdvancedParticleFilter", "AuxiliaryParticleFilter", "FilterBank", "ParticleFilteringSolution",
@@ -237,28 +238,54 @@ class RBMeasurementModel:
         self.measurement, self.R2, self.ny = measurement, R2, int(ny)
 
 
+class StateAffineCoupling:
+    """An as a function of the state (reference src/rbpf.jl:108: "`An` may be a matrix or a function of x, u, p, t that
+    returns a matrix"), in the descriptor form the GPU can run: An(xn) = An0 + sum_k xn[k] Ank[k]."""
+
+    def __init__(self, An0, Ank):
+        self.An0 = np.atleast_2d(np.asarray(An0, dtype=np.float64))
+        self.Ank = np.asarray(Ank, dtype=np.float64).reshape((self.An0.shape[0],) + self.An0.shape)
+
+    def __call__(self, x, u=None, p=None, t=0.0):
+        xn = np.asarray(getattr(x, "xn", x), dtype=np.float64)[: self.An0.shape[0]]
+        return self.An0 + np.tensordot(xn, self.Ank, axes=(0, 0))
+
+
 class RBPF(_AbstractParticleFilter):
     """RBPF(N, kf, dynamics, nl_measurement_model, R1n, d0n; An, nu, Ts, rng, resample_threshold) — the
-    Rao-Blackwellized ("marginalized") particle filter of reference src/rbpf.jl:63-144 with constant matrices:
-    dynamics = LinearDynamics(Fn, Bn) of the nonlinear substate, An the coupling matrix or None."""
+    Rao-Blackwellized ("marginalized") particle filter of reference src/rbpf.jl:63-144.  With constant matrices
+    (dynamics = LinearDynamics(Fn, Bn) of the nonlinear substate, An a matrix or None) one covariance serves all
+    particles; with An = StateAffineCoupling(...) every particle carries its own Kalman filter (the reference's
+    !singleR branches, :176/:247), and dynamics / nl_measurement_model.measurement may also be the quad-tank
+    descriptors."""
     kind = S.PARTICLE_FILTER
 
     def __init__(self, N, kf, dynamics, nl_measurement_model, R1n, d0n, *, An=None, nu=-1, Ts=1.0, p=None, rng=None,
                  resample_threshold=0.1, names=None, device=0):
         as_g = lambda d: d.struct() if isinstance(d, MvNormal) else d
         as_cov = lambda d, n: d if not isinstance(d, (np.ndarray, list)) else MvNormal(np.zeros(n), np.atleast_2d(np.asarray(d, float)))
-        nn = np.atleast_2d(np.asarray(dynamics.A, float)).shape[0]
+        nn = 4 if isinstance(dynamics, QuadTankDynamics) else np.atleast_2d(np.asarray(dynamics.A, float)).shape[0]
         R1n = as_cov(R1n, nn)
         R2 = as_cov(nl_measurement_model.R2, nl_measurement_model.ny)
         mm = nl_measurement_model.measurement
-        Gn = np.zeros((nl_measurement_model.ny, nn)) if mm is None else mm.C
+        Gn = np.zeros((nl_measurement_model.ny, nn)) if mm is None else getattr(mm, "C", None)
         self.kf, self.dynamics, self.nl_measurement_model, self.An, self.R1n, self.d0n = kf, dynamics, nl_measurement_model, An, R1n, d0n
         self.resample_threshold = float(resample_threshold)
         self.resampling_strategy = ResampleSystematic            # resampling_strategy(pf::RBPF), src/rbpf.jl:306
         self.rng = 0 if rng is None else int(rng)
         self.p, self.Ts, self.names, self.threads = p, float(Ts), names, False
         self.measurement_likelihood = None
-        self._model = S.make_rb_model(dynamics.A, dynamics.B, An, kf.A, kf.B, Gn, kf.C, as_g(R1n), kf.R1, as_g(R2), as_g(d0n), as_g(kf.d0), Ts)
+        self.per_particle_covariance = isinstance(An, StateAffineCoupling)
+        if self.per_particle_covariance:
+            Ast = np.concatenate([An.An0[None], An.Ank], axis=0)
+            if isinstance(dynamics, QuadTankDynamics):
+                self._model = S.make_rb_bilinear_model(Ast, kf.A, kf.B, kf.C, as_g(R1n), kf.R1, as_g(R2), as_g(d0n), as_g(kf.d0),
+                                                       quadtank=dynamics.consts, Ts=Ts, supersample=dynamics.supersample)
+            else:
+                self._model = S.make_rb_bilinear_model(Ast, kf.A, kf.B, kf.C, as_g(R1n), kf.R1, as_g(R2), as_g(d0n), as_g(kf.d0),
+                                                       Fn=dynamics.A, Bn=dynamics.B, Gn=Gn, Ts=Ts)
+        else:
+            self._model = S.make_rb_model(dynamics.A, dynamics.B, An, kf.A, kf.B, Gn, kf.C, as_g(R1n), kf.R1, as_g(R2), as_g(d0n), as_g(kf.d0), Ts)
         self.nx, self.nu, self.ny = self._model.nx, self._model.nu, self._model.ny
         self._cfg = S.make_config(self._model, N, self.kind, S.RESAMPLE_SYSTEMATIC, resample_threshold, self.rng, device)
         self._h = _capi.FilterHandle(self._cfg)
@@ -267,7 +294,17 @@ class RBPF(_AbstractParticleFilter):
     @property
     def covariance(self):
         """x[1].R: the covariance of the linear substate (shared by all particles for constant matrices)."""
+        if self.per_particle_covariance:
+            return self._h.rb_linear_state()[1][0]
         return self._h.rb_covariance()
+
+    def linear_state(self):
+        """(xl [N, nxl], R [N, nxl, nxl]): the fields xl, R of every RBParticle (reference src/rbpf.jl:1-5)."""
+        if not self.per_particle_covariance:
+            nn = self._model.nxn
+            xl = self._h.particles()[:, nn:]
+            return xl, np.broadcast_to(self._h.rb_covariance(), (self.N,) + self._h.rb_covariance().shape).copy()
+        return self._h.rb_linear_state()
 
 
 class AuxiliaryParticleFilter:
@@ -461,6 +498,8 @@ def mean_trajectory(pf, u=None, y=None, p=None):
 
 # accessors — reference src/PFtypes.jl:296-334
 def particles(pf):
+    if getattr(pf, "per_particle_covariance", False):       # RBParticle indexes like [xn; xl] (reference src/rbpf.jl:24-30)
+        return np.concatenate([pf._h.particles(), pf._h.rb_linear_state()[0]], axis=1)
     return pf._h.particles()
 
 

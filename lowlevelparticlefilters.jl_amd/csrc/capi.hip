@@ -159,6 +159,23 @@ int llpf_rb_get_covariance(llpf_filter* f, double* R) {
     return LLPF_OK;
 }
 
+int llpf_rb_get_linear_state(llpf_filter* f, double* xl, double* R) {
+    NEEDF(f);
+    Bank& b = f->bank;
+    if (!is_rbfull(b)) return fail(LLPF_ERR_ARG, "not a filter with per-particle covariance (LLPF_MODEL_RB_BILINEAR)");
+    CHK(use_device(b));
+    const int nn = b.nx, nl = b.cfg.model.rb.nxl, np = LLPF_RBF_NP(nl);
+    std::vector<double> rows((size_t)(nl + np) * b.Ns);
+    HIPC(hipMemcpyAsync(rows.data(), b.d_x[b.cur] + (size_t)nn * b.Ns, sizeof(double) * rows.size(), hipMemcpyDeviceToHost, b.stream));
+    HIPC(hipStreamSynchronize(b.stream));
+    for (int64_t i = 0; i < b.N; ++i) {
+        if (xl) for (int d = 0; d < nl; ++d) xl[i * nl + d] = rows[(size_t)d * b.Ns + i];
+        if (R) for (int r = 0; r < nl; ++r) for (int c = 0; c < nl; ++c)
+            R[(i * nl + r) * nl + c] = rows[(size_t)(nl + llpf_rbf_idx(r, c)) * b.Ns + i];
+    }
+    return LLPF_OK;
+}
+
 int llpf_smooth(llpf_filter* f, int64_t M, const double* U, int64_t T, const double* xf, const double* wf,
                 const double* wef, double* xb, int64_t* idx) {
     NEEDF(f);

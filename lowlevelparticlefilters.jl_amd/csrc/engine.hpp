@@ -29,6 +29,7 @@
 #include "shared/llpf_detmath.h"
 #include "shared/llpf_fixed.h"
 #include "shared/llpf_philox.h"
+#include "shared/llpf_rbfull.h"
 
 namespace llpf {
 
@@ -89,6 +90,7 @@ struct ModelD {
     int32_t rb_zeroC, rb_zeroAn;   // iszero(C), iszero(An)  (reference src/rbpf.jl:175,244)
     double Ts;
     GaussD df, dg, d0;
+    llpf_rbf_par rbf;              // LLPF_MODEL_RB_BILINEAR: linear substate and coupling (csrc/shared/llpf_rbfull.h)
 };
 
 struct FilterScal {
@@ -216,6 +218,7 @@ struct ResArgs {
 
 // launchers (kernels.hip)
 hipError_t launch_init(const BankDev& b, uint32_t step, int init_anc, hipStream_t s);
+hipError_t launch_rbfull_init(const BankDev& b, hipStream_t s);   // LLPF_MODEL_RB_BILINEAR: xl, R of reset!
 hipError_t launch_wmean(const BankDev& b, double* out /* [F][nx] */, hipStream_t s);
 hipError_t launch_step(const BankDev& b, int mode, const StepArgs& a, hipStream_t s);
 hipError_t launch_max(const BankDev& b, int parity, hipStream_t s);           // maxima of the raw w into acc
@@ -251,5 +254,7 @@ hipError_t launch_selftest_math(int which, const double* in, double* out, int64_
 hipError_t launch_selftest_normals(uint32_t k0, uint32_t k1, uint32_t step, uint32_t stream, int nd,
                                    double* out, int64_t n, hipStream_t s);
 bool step_supported(int model_id, int nx, int ny);
+bool rbfull_supported(int fn_kind, int nn, int nl, int ny);
+int rbfull_rows(int nn, int nl);   // rows of the particle plane: xn, xl, packed R
 
 }  // namespace llpf

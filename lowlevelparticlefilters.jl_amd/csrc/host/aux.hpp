@@ -96,7 +96,7 @@ static int bank_aux_correct(Bank& b, double* ll_out /* [F] or null */, const Aux
 
 // Single-call predict!(pf::AuxiliaryParticleFilter, u, y1, p, t): synchronous.  d_u / d_y1 are device pointers.
 static int aux_predict_dev(Bank& b, const double* d_u, const double* d_y1, bool has_y1, double t, int want_xm) {
-    if (is_rb(b)) return fail(LLPF_ERR_ARG, "the auxiliary filter is not defined for the Rao-Blackwellized model");
+    if (is_rb(b) || is_rbfull(b)) return fail(LLPF_ERR_ARG, "the auxiliary filter is not defined for the Rao-Blackwellized model");
     if (b.cfg.resampling_strategy == LLPF_RESAMPLE_RESIDUAL) return fail(LLPF_ERR_ARG, "the auxiliary filter supports systematic and stratified resampling");
     if (b.aux_pending) CHK(bank_aux_correct(b, nullptr, AuxOuts{}, 0));   // contract: predict! works on normalised weights
     CHK(aux_ensure_lam(b));

@@ -7,6 +7,7 @@ struct Bank {
     int F = 0;
     int64_t N = 0, Ns = 0;
     int nx = 0, nu = 0, ny = 0, P1 = 0, P2 = 0;
+    int xrows = 0;                   // rows of a particle plane: nx, or xn + xl + packed R for LLPF_MODEL_RB_BILINEAR
     int device = 0;
     hipStream_t stream = nullptr;
     ModelD* d_models = nullptr;
@@ -84,7 +85,8 @@ struct Bank {
         b.xcur = d_x[cur]; b.xnext = d_x[cur ^ 1];
         b.w = d_w; b.anc = d_anc; b.acc = d_acc; b.quanta = d_quanta[qcur]; b.quanta_next = d_quanta[qcur ^ 1]; b.tileq = d_tileq;
         b.bank_flag = d_flag; b.xmpart = d_xmpart; b.lam = d_lam; b.rtile = d_rtile;
-        b.anc_slot = (int32_t)(n_predict & 1u); b.pad0 = 0;
+        b.anc_slot = (int32_t)(n_predict & 1u);
+        b.pad0 = (cfg.model.model_id == LLPF_MODEL_RB_BILINEAR) ? (cfg.model.rb.nxl | (cfg.model.rb.fn_kind << 8)) : 0;
         return b;
     }
 };
@@ -173,6 +175,7 @@ static void prof_collect(Bank& b) {
     b.pending.clear();
 }
 
+static bool is_rbfull(const Bank& b) { return b.cfg.model.model_id == LLPF_MODEL_RB_BILINEAR; }
 static int bank_init_particles(Bank& b, bool is_reset) {
     b.aux_pending = false; b.we_is_lambda = false;
     for (size_t f = 0; f < b.rb.size(); ++f) {              // reset!(pf::RBPF): R = copy(pf.kf.d0.Sigma), src/rbpf.jl:152 (pf.kf itself is not reset)
@@ -206,6 +209,7 @@ static int bank_init_particles(Bank& b, bool is_reset) {
     HIPC(hipMemsetAsync(b.d_flag, 0, sizeof(uint32_t) * 4, b.stream));
     b.parity = 0;
     HIPC(launch_init(d, b.n_reset, is_reset ? 0 : 1, b.stream));
+    if (is_rbfull(b)) HIPC(launch_rbfull_init(d, b.stream));
     b.n_reset++;
     b.t_index = is_reset ? 1 : 0;
     HIPC(hipStreamSynchronize(b.stream));
@@ -222,6 +226,11 @@ static int bank_create(const llpf_config* cfg, const llpf_model* models, int F, 
     if (m0.nx < 1 || m0.nx > MAXD || m0.ny < 1 || m0.ny > MAXD || m0.nu < 0 || m0.nu > MAXD) return fail(LLPF_ERR_ARG, "bad dimensions");
     if (!step_supported(m0.model_id, m0.nx, m0.ny))
         return fail(LLPF_ERR_ARG, "no kernel instantiated for this model/dimension (linear-Gaussian nx,ny in 1..4; quad-tank 4/2)");
+    if (m0.model_id == LLPF_MODEL_RB_BILINEAR) {
+        if (F != 1) return fail(LLPF_ERR_ARG, "LLPF_MODEL_RB_BILINEAR: single filters only (no banks)");
+        if (!rbfull_supported(m0.rb.fn_kind, m0.nx, m0.rb.nxl, m0.ny))
+            return fail(LLPF_ERR_ARG, "LLPF_MODEL_RB_BILINEAR: instantiated shapes (nxn, nxl, ny) are (1,2,1), (2,2,2), (4,8,2); quad-tank: (4,8,2)");
+    }
     if (cfg->resampling_strategy != LLPF_RESAMPLE_SYSTEMATIC && cfg->resampling_strategy != LLPF_RESAMPLE_STRATIFIED &&
         cfg->resampling_strategy != LLPF_RESAMPLE_RESIDUAL)
         return fail(LLPF_ERR_ARG, "resampling_strategy must be systematic, stratified or residual");
@@ -237,6 +246,7 @@ static int bank_create(const llpf_config* cfg, const llpf_model* models, int F, 
     b.N = cfg->n_particles;
     b.Ns = (b.N + TILE - 1) / TILE * TILE;
     b.nx = m0.nx; b.nu = m0.nu; b.ny = m0.ny;
+    b.xrows = (m0.model_id == LLPF_MODEL_RB_BILINEAR) ? rbfull_rows(m0.nx, m0.rb.nxl) : b.nx;
     b.P1 = (int)(b.Ns / STEP_TILE);
     b.P2 = (int)(b.Ns / TILE);
     b.device = cfg->device;
@@ -255,8 +265,8 @@ static int bank_create(const llpf_config* cfg, const llpf_model* models, int F, 
     const size_t FN = (size_t)F * b.Ns;
     HIPC(hipMalloc(&b.d_models, sizeof(ModelD) * F));
     HIPC(hipMalloc(&b.d_scal, sizeof(FilterScal) * F));
-    HIPC(hipMalloc(&b.d_x[0], sizeof(double) * FN * b.nx));
-    HIPC(hipMalloc(&b.d_x[1], sizeof(double) * FN * b.nx));
+    HIPC(hipMalloc(&b.d_x[0], sizeof(double) * FN * b.xrows));
+    HIPC(hipMalloc(&b.d_x[1], sizeof(double) * FN * b.xrows));
     HIPC(hipMalloc(&b.d_w, sizeof(double) * FN));
     HIPC(hipMalloc(&b.d_anc, sizeof(int32_t) * FN));
     HIPC(hipMalloc(&b.d_acc, sizeof(uint64_t) * (size_t)F * ACC_WORDS));
@@ -281,8 +291,8 @@ static int bank_create(const llpf_config* cfg, const llpf_model* models, int F, 
     HIPC(hipMemsetAsync(b.d_rtile, 0, sizeof(uint64_t) * (size_t)F * 2 * b.P2, b.stream));
     HIPC(hipMalloc(&b.d_uy, sizeof(double) * 4 * MAXD));
     HIPC(hipMalloc(&b.d_tmp, sizeof(double) * (size_t)F * b.N * (b.nx > 1 ? b.nx : 1) + 64));
-    HIPC(hipMemsetAsync(b.d_x[0], 0, sizeof(double) * FN * b.nx, b.stream));
-    HIPC(hipMemsetAsync(b.d_x[1], 0, sizeof(double) * FN * b.nx, b.stream));
+    HIPC(hipMemsetAsync(b.d_x[0], 0, sizeof(double) * FN * b.xrows, b.stream));
+    HIPC(hipMemsetAsync(b.d_x[1], 0, sizeof(double) * FN * b.xrows, b.stream));
     HIPC(hipMemsetAsync(b.d_anc, 0, sizeof(int32_t) * FN, b.stream));
     HIPC(hipMemsetAsync(b.d_scal, 0, sizeof(FilterScal) * F, b.stream));
     HIPC(hipMemsetAsync(b.d_acc, 0, sizeof(uint64_t) * (size_t)F * ACC_WORDS, b.stream));

@@ -58,6 +58,7 @@ static int gauss_prepare(const llpf_gaussian* g, GaussD* d) {
     return 0;
 }
 
+static void gauss_cov_dense(const llpf_gaussian* g, double* S);
 static int model_prepare(const llpf_model* m, ModelD* d) {
     memset(d, 0, sizeof(*d));
     d->model_id = m->model_id;
@@ -99,6 +100,36 @@ static int model_prepare(const llpf_model* m, ModelD* d) {
         return 0;
     }
     if (d->df.dim != m->nx || d->d0.dim != m->nx || d->dg.dim != m->ny) return -4;
+    if (m->model_id == LLPF_MODEL_RB_BILINEAR) {
+        // per-particle Kalman substate: constants of csrc/shared/llpf_rbfull.h (x arrays hold xn: nx = nxn)
+        const int nn = m->nx, nl = m->rb.nxl, ny = m->ny, nu = m->nu;
+        if (nl < 1 || nl > LLPF_RBF_MAXL || nn > LLPF_RBF_MAXN || ny > LLPF_RBF_MAXY) return -5;
+        if (m->linear_noise.dim != nl || m->linear_initial.dim != nl) return -4;
+        if (m->rb.fn_kind == 1 && (nn != 4 || ny != 2 || nu != 2 || !(m->qt[LLPF_QT_EPS] > 1e-200))) return -9;
+        if (m->rb.fn_kind != 0 && m->rb.fn_kind != 1) return -9;
+        GaussD tmp;
+        if (gauss_prepare(&m->linear_noise, &tmp)) return -7;
+        if (gauss_prepare(&m->linear_initial, &tmp)) return -8;
+        llpf_rbf_par& q = d->rbf;
+        q.nn = nn; q.nl = nl; q.ny = ny; q.nu = nu;
+        bool zeroC = true;
+        for (int r = 0; r < nl; ++r) for (int c = 0; c < nl; ++c) q.Al[r * nl + c] = m->rb.Al[r * nl + c];
+        for (int r = 0; r < nl; ++r) for (int c = 0; c < nu; ++c) q.Bl[r * nu + c] = m->rb.Bl[r * nu + c];
+        for (int r = 0; r < ny; ++r) for (int c = 0; c < nl; ++c) { q.Cl[r * nl + c] = m->rb.Cl[r * nl + c]; if (q.Cl[r * nl + c] != 0.0) zeroC = false; }
+        if (zeroC) return -6;                              // C == 0 takes the reference's other branch (:274-276): use LLPF_MODEL_RB_LINEAR
+        for (int k = 0; k <= nn; ++k) for (int i = 0; i < nn * nl; ++i) q.An[k][i] = m->rb.An[k][i];
+        double S[64];
+        gauss_cov_dense(&m->linear_noise, S);
+        for (int r = 0; r < nl; ++r) for (int c = 0; c <= r; ++c) q.R1l[llpf_rbf_idx(r, c)] = S[r * nl + c];
+        gauss_cov_dense(&m->linear_initial, S);
+        for (int r = 0; r < nl; ++r) for (int c = 0; c <= r; ++c) q.R0[llpf_rbf_idx(r, c)] = S[r * nl + c];
+        for (int r = 0; r < nl; ++r) q.xl0[r] = m->linear_initial.mu[r];
+        gauss_cov_dense(&m->dynamics_density, S);
+        for (int i = 0; i < nn * nn; ++i) q.R1n[i] = S[i];
+        gauss_cov_dense(&m->measurement_density, S);
+        for (int i = 0; i < ny * ny; ++i) q.R2[i] = S[i];
+        q.c0y = -((double)ny * llpf_log(6.283185307179586)) / 2.0;
+    }
     return 0;
 }
 

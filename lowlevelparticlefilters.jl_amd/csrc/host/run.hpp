@@ -51,7 +51,8 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
     // residual resampling produces unsorted ancestors (copies first, multinomial draws after): always the balanced form
     const bool residual = b.cfg.resampling_strategy == LLPF_RESAMPLE_RESIDUAL;
     const bool rbm = is_rb(b);
-    const bool unfused = hist || residual || (unf_env ? atoi(unf_env) != 0 : heavy_dynamics);
+    const bool rbfull = is_rbfull(b);     // per-particle covariance: its own step kernel, balanced form, exp-sums by k_norm
+    const bool unfused = rbfull || hist || residual || (unf_env ? atoi(unf_env) != 0 : heavy_dynamics);
     if (rbm) {
         // the whole gain schedule of the run (data independent): corr_0, pred_0, corr_1, pred_1, ..., [F] each
         const size_t need = (size_t)(2 * T + 1) * b.F;
@@ -78,7 +79,7 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
     // its registers for the propagate and runs at higher occupancy: best when many filters saturate the SIMDs).
     // Measured on MI355X: C2 single filter 29.4 vs 30.2 us, bank 128 x 1e5: 4.3e10 vs 5.0e10 particle-steps/s.
     const char* sch_env = getenv("LLPF_SCHEDULE");       // "merged" | "split" override
-    const bool merged = hist || (sch_env ? (strcmp(sch_env, "merged") == 0) : ((int64_t)b.F * b.Ns <= ((int64_t)3 << 20)));
+    const bool merged = !rbfull && (hist || (sch_env ? (strcmp(sch_env, "merged") == 0) : ((int64_t)b.F * b.Ns <= ((int64_t)3 << 20))));
     static const char* abl_env = getenv("LLPF_ABLATE");
     static const char* dbg_env = getenv("LLPF_DEBUG_TIMING");
 

@@ -6,7 +6,7 @@ static int bank_smooth(Bank& b, int64_t M, const double* U, int64_t T, const dou
                        const double* wef, double* xb, int64_t* idx) {
     CHK(use_device(b));
     if (b.F != 1) return fail(LLPF_ERR_ARG, "smooth needs a single filter");
-    if (is_rb(b)) return fail(LLPF_ERR_ARG, "smooth is not defined for the Rao-Blackwellized model");
+    if (is_rb(b) || is_rbfull(b)) return fail(LLPF_ERR_ARG, "smooth is not defined for the Rao-Blackwellized model");
     if (M < 1 || M > b.N) return fail(LLPF_ERR_ARG, "M must be in 1..N (reference src/smoothing.jl:121)");
     if (T < 1 || !xf || !wf || !wef || !xb) return fail(LLPF_ERR_ARG, "bad arguments");
     if (b.nu > 0 && !U) return fail(LLPF_ERR_ARG, "U is null");

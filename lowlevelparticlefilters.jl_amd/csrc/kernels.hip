@@ -23,6 +23,7 @@ namespace llpf {
 #include "kernels/init.hpp"
 #include "kernels/accum.hpp"
 #include "kernels/step.hpp"
+#include "kernels/rbfull.hpp"
 #include "kernels/norm.hpp"
 #include "kernels/resample.hpp"
 #include "kernels/residual.hpp"
@@ -36,7 +37,46 @@ namespace llpf {
 // ------------------------------------------------------------------------------------------------
 static inline dim3 grid1(int64_t n, int F) { return dim3((unsigned)((n + BLOCK - 1) / BLOCK), (unsigned)F, 1); }
 
+// LLPF_MODEL_RB_BILINEAR: the instantiated shapes (nxn, nxl, ny); fn_kind 1 = quad-tank nonlinear part
+bool rbfull_supported(int fn_kind, int nn, int nl, int ny) {
+    if (fn_kind == 1) return nn == 4 && nl == 8 && ny == 2;
+    if (fn_kind != 0) return false;
+    return (nn == 1 && nl == 2 && ny == 1) || (nn == 2 && nl == 2 && ny == 2) || (nn == 4 && nl == 8 && ny == 2);
+}
+int rbfull_rows(int nn, int nl) { return nn + nl + LLPF_RBF_NP(nl); }
+
+template <class Model, int NN, int NL, int NY>
+static hipError_t launch_rbfull_t(const BankDev& b, int mode, const StepArgs& a, hipStream_t s) {
+    dim3 g((unsigned)(b.Ns / BLOCK), (unsigned)b.F, 1);
+    switch (mode) {
+        case MODE_WEIGHT: hipLaunchKernelGGL((k_rbfull<Model, NN, NL, NY, MODE_WEIGHT>), g, dim3(BLOCK), 0, s, b, b.models, b.scal, a); break;
+        case MODE_PROP: hipLaunchKernelGGL((k_rbfull<Model, NN, NL, NY, MODE_PROP>), g, dim3(BLOCK), 0, s, b, b.models, b.scal, a); break;
+        case MODE_PROP_WEIGHT: hipLaunchKernelGGL((k_rbfull<Model, NN, NL, NY, MODE_PROP_WEIGHT>), g, dim3(BLOCK), 0, s, b, b.models, b.scal, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+// BankDev::pad0 carries the shape of this model: nxl | fn_kind << 8
+static hipError_t launch_rbfull(const BankDev& b, int mode, const StepArgs& a, hipStream_t s) {
+    const int nl = b.pad0 & 0xff, fk = (b.pad0 >> 8) & 0xff;
+    if (fk == 1 && b.nx == 4 && nl == 8 && b.ny == 2) return launch_rbfull_t<QuadTank<4, 2>, 4, 8, 2>(b, mode, a, s);
+    if (fk == 0 && b.nx == 4 && nl == 8 && b.ny == 2) return launch_rbfull_t<LinGauss<4, 2>, 4, 8, 2>(b, mode, a, s);
+    if (fk == 0 && b.nx == 2 && nl == 2 && b.ny == 2) return launch_rbfull_t<LinGauss<2, 2>, 2, 2, 2>(b, mode, a, s);
+    if (fk == 0 && b.nx == 1 && nl == 2 && b.ny == 1) return launch_rbfull_t<LinGauss<1, 1>, 1, 2, 1>(b, mode, a, s);
+    return hipErrorInvalidValue;
+}
+hipError_t launch_rbfull_init(const BankDev& b, hipStream_t s) {
+    const int nl = b.pad0 & 0xff;
+    dim3 g = grid1(b.Ns, b.F);
+    if (b.nx == 4 && nl == 8) hipLaunchKernelGGL((k_rbfull_init<4, 8>), g, dim3(BLOCK), 0, s, b, b.models);
+    else if (b.nx == 2 && nl == 2) hipLaunchKernelGGL((k_rbfull_init<2, 2>), g, dim3(BLOCK), 0, s, b, b.models);
+    else if (b.nx == 1 && nl == 2) hipLaunchKernelGGL((k_rbfull_init<1, 2>), g, dim3(BLOCK), 0, s, b, b.models);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
 bool step_supported(int model_id, int nx, int ny) {
+    if (model_id == LLPF_MODEL_RB_BILINEAR) return nx >= 1 && nx <= 4 && ny >= 1 && ny <= 2;   // shape checked by rbfull_supported
     if (model_id == LLPF_MODEL_QUADTANK_RK4) return nx == 4 && ny == 2;
     if (model_id == LLPF_MODEL_RB_LINEAR) return nx >= 2 && nx <= 4 && ny >= 1 && ny <= 4;
     if (model_id == LLPF_MODEL_LINEAR_GAUSSIAN) return nx >= 1 && nx <= 4 && ny >= 1 && ny <= 4;
@@ -93,6 +133,7 @@ static hipError_t launch_step_rb_ny(const BankDev& b, int mode, const StepArgs& 
 
 hipError_t launch_step(const BankDev& b, int mode, const StepArgs& a, hipStream_t s) {
     const int model_id = b.model_id;
+    if (model_id == LLPF_MODEL_RB_BILINEAR) return launch_rbfull(b, mode, a, s);
     if (model_id == LLPF_MODEL_QUADTANK_RK4) return launch_step_t<QuadTank<4, 2>, 4, 2>(b, mode, a, s);
     if (model_id == LLPF_MODEL_RB_LINEAR) {
         switch (b.nx) {

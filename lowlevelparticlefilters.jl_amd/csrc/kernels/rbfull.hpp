@@ -1,0 +1,124 @@
+// kernels/rbfull.hpp — k_rbfull: propagate + weight of the Rao-Blackwellized filter with per-particle covariance
+// (LLPF_MODEL_RB_BILINEAR, reference src/rbpf.jl:163-283 with singleR off).  Part of kernels.hip (one translation unit, namespace llpf).
+// ------------------------------------------------------------------------------------------------
+// Particle plane layout of this model (single filter): rows 0..NN-1 of x are xn, rows NN..NN+NL-1 the Kalman mean xl,
+// the following NL(NL+1)/2 rows the packed lower triangle of the Kalman covariance R: one ancestor gather moves the
+// whole RBParticle (src/rbpf.jl:1-5, :182 `xi = s.xprev[j[i]]`).  One particle per thread; all matrices in registers
+// (csrc/shared/llpf_rbfull.h, shared with the oracle).  The exp-sums of the new weights are left to a k_norm launch in
+// bound form: S_i = C R_i C' + R2 >= R2, so max(w_prev) + c0(R2) bounds every new weight.
+// ------------------------------------------------------------------------------------------------
+constexpr double RBF_BOUND_SLACK = 0x1p-20;   // keeps exp(w - bound) <= 1 when a particle's C R C' rounds to zero
+
+template <class Model, int NN, int NL, int NY, int MODE>
+__global__ __launch_bounds__(BLOCK) void k_rbfull(BankDev b, const ModelD* __restrict__ models,
+                                                   const FilterScal* scal, StepArgs a) {
+    static_assert(MODE == MODE_WEIGHT || MODE == MODE_PROP || MODE == MODE_PROP_WEIGHT, "no auxiliary form");
+    constexpr int NP = LLPF_RBF_NP(NL), ROWS = NN + NL + NP;
+    __shared__ double sm_max[BLOCK / 64];
+    const int f = blockIdx.y;
+    const ModelD* md = models + f;
+    const FilterScal* sc = scal + f;
+    if (run_is_stopped(b, a.k)) return;
+    if (a.only_fallback ? !sc->fallback : (sc->fallback != 0)) return;
+    const int do_res = (MODE != MODE_WEIGHT) ? sc->do_resample : 0;
+    const int uniform = sc->uniform, pend = sc->norm_pending;
+    const double m = sc->m, l = sc->l, wconst = sc->wconst;
+    const uint32_t k0 = sc->k0, k1 = sc->k1, sb = sc->step_base;
+    const int64_t Ns = b.Ns, N = b.N;
+    const double* __restrict__ xc = b.xcur + (size_t)f * ROWS * Ns;
+    double* __restrict__ xo = (MODE == MODE_WEIGHT) ? const_cast<double*>(xc) : b.xnext + (size_t)f * ROWS * Ns;
+    double* w = b.w + (size_t)f * Ns;
+    const llpf_rbf_par* par = &md->rbf;
+
+    Model model;
+    model.prepare(md, a.u, a.t_prop);
+
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const int64_t src = do_res ? (int64_t)b.anc[(size_t)f * Ns + i] : i;
+    double xn[NN], xl[NL], R[NP];
+#pragma unroll
+    for (int d = 0; d < NN; ++d) xn[d] = xc[(size_t)d * Ns + src];
+#pragma unroll
+    for (int d = 0; d < NL; ++d) xl[d] = xc[(size_t)(NN + d) * Ns + src];
+#pragma unroll
+    for (int d = 0; d < NP; ++d) R[d] = xc[(size_t)(NN + NL + d) * Ns + src];
+
+    if (MODE != MODE_WEIGHT) {
+        double fi[NN], xi[NN], nz[NN], xn1[NN], xl1[NL], R1[NP];
+        model.dynamics(xn, fi);
+        llpf_normals((uint32_t)i, sb + a.step, LLPF_STREAM_DYNAMICS, k0, k1, NN, xi);
+        gauss_sample<NN>(md->df, xi, nz);
+        llpf_rbf_predict(par, NN, NL, b.nu, xn, xl, R, a.u, fi, nz, xn1, xl1, R1);
+#pragma unroll
+        for (int d = 0; d < NN; ++d) xn[d] = xn1[d];
+#pragma unroll
+        for (int d = 0; d < NL; ++d) xl[d] = xl1[d];
+#pragma unroll
+        for (int d = 0; d < NP; ++d) R[d] = R1[d];
+    }
+
+    double bmax = -LLPF_INF;
+    bool bad = false;
+    double off = 0.0;
+    if (MODE != MODE_PROP) {
+        const double wmx = do_res ? b.log1N : (uniform ? wconst : sc->wmax);
+        off = a.has_y ? (wmx + md->dg.c0) + RBF_BOUND_SLACK : wmx;
+        double wv;
+        if (do_res) wv = b.log1N;                                 // reset_weights!
+        else if (uniform) wv = wconst;
+        else { const double wr = w[i]; wv = pend ? (wr - m) - l : wr; }
+        if (a.has_y) {
+            double y[NY], yn[NY];
+#pragma unroll
+            for (int k = 0; k < NY; ++k) y[k] = a.y[k];
+            model.measurement(xn, yn);
+            wv = wv + llpf_rbf_correct(par, NL, NY, y, yn, xl, R);   // w[i] += ll, src/rbpf.jl:272
+        }
+        if (i >= N) wv = -LLPF_INF;                                // padding lanes carry zero weight
+        w[i] = wv;
+        bad = wv != wv;
+        bmax = wv;
+    }
+    if (MODE != MODE_WEIGHT || a.has_y) {
+#pragma unroll
+        for (int d = 0; d < NN; ++d) xo[(size_t)d * Ns + i] = xn[d];
+#pragma unroll
+        for (int d = 0; d < NL; ++d) xo[(size_t)(NN + d) * Ns + i] = xl[d];
+#pragma unroll
+        for (int d = 0; d < NP; ++d) xo[(size_t)(NN + NL + d) * Ns + i] = R[d];
+    }
+    if (MODE != MODE_PROP) {
+        const double r = block_max(bmax, sm_max);
+        const int anybad = __syncthreads_or(bad ? 1 : 0);
+        if (threadIdx.x == 0) {
+            acc_max(b.acc + (size_t)f * ACC_WORDS, a.parity, r, anybad != 0);
+            if (blockIdx.x == 0) {
+                FilterScal* scw = b.scal + f;
+                scw->off_slot[a.parity] = off;
+                scw->e2v_slot[a.parity] = a.need_e2;
+                scw->u_slot[a.parity] = llpf_uniform_step(sb + a.next_step, LLPF_STREAM_RESAMPLE, k0, k1);
+            }
+        }
+    }
+    if (MODE != MODE_WEIGHT && blockIdx.x == 0 && threadIdx.x == 0) {
+        FilterScal* scw = b.scal + f;
+        scw->anc_ident_s[b.anc_slot ^ 1] = do_res ? 0 : 1;
+        scw->last_resampled = do_res;
+        scw->resample_count += do_res;
+    }
+}
+
+// reset!(pf::RBPF), src/rbpf.jl:146-160: xl = copy(kf.d0.mu), R = copy(kf.d0.Sigma) for every particle (xn ~ d0n by k_init)
+template <int NN, int NL>
+__global__ __launch_bounds__(BLOCK) void k_rbfull_init(BankDev b, const ModelD* __restrict__ models) {
+    constexpr int NP = LLPF_RBF_NP(NL), ROWS = NN + NL + NP;
+    const int f = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= b.Ns) return;
+    const llpf_rbf_par* par = &models[f].rbf;
+    double* xc = b.xcur + (size_t)f * ROWS * b.Ns;
+#pragma unroll
+    for (int d = 0; d < NL; ++d) xc[(size_t)(NN + d) * b.Ns + i] = par->xl0[d];
+#pragma unroll
+    for (int d = 0; d < NP; ++d) xc[(size_t)(NN + NL + d) * b.Ns + i] = par->R0[d];
+}

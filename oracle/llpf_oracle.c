@@ -19,6 +19,14 @@
 
 #define MAXD LLPF_MAX_DIM
 #include "../lowlevelparticlefilters.jl_amd/csrc/shared/llpf_rbkf.h"
+#include "../lowlevelparticlefilters.jl_amd/csrc/shared/llpf_rbfull.h"     /* llpf_rbf_*: device order */
+#define RBF_(name) llpf_rbfr_##name                                           /* llpf_rbfr_*: the same recursion with libm */
+#define RBF_SQRT(x) sqrt(x)
+#define RBF_LOG(x) log(x)
+#include "../lowlevelparticlefilters.jl_amd/csrc/shared/llpf_rbfull_body.h"
+#undef RBF_
+#undef RBF_SQRT
+#undef RBF_LOG
 
 /* Optional OpenMP over the per-particle loops (weighting, propagation, noise, elementwise exp): an upper bound for
  * what the reference could reach with its `threads=true` option (src/PFtypes.jl:226-259 @threads :static); the
@@ -207,9 +215,14 @@ void orc_rk4_scalar_decay(double x0, double Ts0, int supersample, double* out) {
     *out = x;
 }
 
+/* LLPF_MODEL_RB_BILINEAR: f_n / g are the linear descriptors (fn_kind 0) or the quad-tank (fn_kind 1) over xn */
+static int model_is_linear(const llpf_model* m) {
+    return m->model_id == LLPF_MODEL_LINEAR_GAUSSIAN || (m->model_id == LLPF_MODEL_RB_BILINEAR && m->rb.fn_kind == 0);
+}
+
 /* dynamics(x,u,p,t) without noise */
 void orc_dynamics(const llpf_model* m, const double* x, const double* u, double t, double* out) {
-    if (m->model_id == LLPF_MODEL_LINEAR_GAUSSIAN) {          /* A*x .+ B*u, examples/example_lineargaussian.jl:28 */
+    if (model_is_linear(m)) {          /* A*x .+ B*u, examples/example_lineargaussian.jl:28 */
         for (int r = 0; r < m->nx; ++r) {
             double ax = m->A[r * m->nx + 0] * x[0];
             for (int c = 1; c < m->nx; ++c) ax = ax + m->A[r * m->nx + c] * x[c];
@@ -228,7 +241,7 @@ void orc_dynamics(const llpf_model* m, const double* x, const double* u, double 
 /* measurement(x,u,p,t) */
 void orc_measurement(const llpf_model* m, const double* x, const double* u, double t, double* out) {
     (void)u; (void)t;
-    if (m->model_id == LLPF_MODEL_LINEAR_GAUSSIAN) {          /* C*x, examples/example_lineargaussian.jl:29 */
+    if (model_is_linear(m)) {                                 /* C*x, examples/example_lineargaussian.jl:29 */
         for (int r = 0; r < m->ny; ++r) {
             double cx = m->C[r * m->nx + 0] * x[0];
             for (int c = 1; c < m->nx; ++c) cx = cx + m->C[r * m->nx + c] * x[c];
@@ -583,6 +596,13 @@ struct orc_filter {
         gaussd dS;                    /* N(0, S) of the last measurement update */
         double K[16], L[16];
     } rb;
+    /* RBPF with state-dependent coupling: every particle has its own Kalman state (src/rbpf.jl:1-5) */
+    struct {
+        int on, nn, nl, np;
+        llpf_rbf_par par;
+        double *xl, *xlprev;          /* N x nl */
+        double *R, *Rprev;            /* N x np: packed lower triangles */
+    } rbf;
     /* AuxiliaryParticleFilter (src/filtering.jl:170-217) */
     double* lam;                /* lambda of the last aux predict! (the reference keeps it in `we`) */
     int aux_pending;            /* w holds lambda - log N of an aux predict!, not yet normalised */
@@ -773,6 +793,94 @@ static void rb_propagate(orc_filter* f, const double* u, const double* xi, int r
 /* shared covariance of the linear substate (x[1].R) */
 void orc_rb_get_R(const orc_filter* f, double* R) { for (int i = 0; i < f->rb.nl * f->rb.nl; ++i) R[i] = f->rb.R[i]; }
 
+/* ------------------------------------------------------------------------------------------
+ * RBPF whose An is a function of the nonlinear state — src/rbpf.jl:163-283 with singleR false (:176, :247): the
+ * loops below are the reference's per-particle branches; the Kalman algebra is csrc/shared/llpf_rbfull_body.h
+ * (shared with the HIP kernel; instantiated with libm for the reference order).
+ * ---------------------------------------------------------------------------------------- */
+static int rbf_setup(orc_filter* f, int order) {
+    const llpf_model* m = &f->cfg.model;
+    const int nn = m->nx, nl = m->rb.nxl, ny = m->ny, nu = m->nu;
+    if (nl < 1 || nl > LLPF_RBF_MAXL || nn > LLPF_RBF_MAXN || ny > LLPF_RBF_MAXY) return -1;
+    if (m->linear_noise.dim != nl || m->linear_initial.dim != nl) return -1;
+    llpf_rbf_par* q = &f->rbf.par;
+    memset(q, 0, sizeof(*q));
+    q->nn = nn; q->nl = nl; q->ny = ny; q->nu = nu;
+    int zeroC = 1;
+    for (int r = 0; r < nl; ++r) for (int c = 0; c < nl; ++c) q->Al[r * nl + c] = m->rb.Al[r * nl + c];
+    for (int r = 0; r < nl; ++r) for (int c = 0; c < nu; ++c) q->Bl[r * nu + c] = m->rb.Bl[r * nu + c];
+    for (int r = 0; r < ny; ++r) for (int c = 0; c < nl; ++c) { q->Cl[r * nl + c] = m->rb.Cl[r * nl + c]; if (q->Cl[r * nl + c] != 0.0) zeroC = 0; }
+    if (zeroC) return -1;
+    for (int k = 0; k <= nn; ++k) for (int i = 0; i < nn * nl; ++i) q->An[k][i] = m->rb.An[k][i];
+    double S[64];
+    gauss_cov_full(&m->linear_noise, S);
+    for (int r = 0; r < nl; ++r) for (int c = 0; c <= r; ++c) q->R1l[llpf_rbf_idx(r, c)] = S[r * nl + c];
+    gauss_cov_full(&m->linear_initial, S);
+    for (int r = 0; r < nl; ++r) for (int c = 0; c <= r; ++c) q->R0[llpf_rbf_idx(r, c)] = S[r * nl + c];
+    for (int r = 0; r < nl; ++r) q->xl0[r] = m->linear_initial.mu[r];
+    gauss_cov_full(&m->dynamics_density, S);
+    for (int i = 0; i < nn * nn; ++i) q->R1n[i] = S[i];
+    gauss_cov_full(&m->measurement_density, S);
+    for (int i = 0; i < ny * ny; ++i) q->R2[i] = S[i];
+    q->c0y = (order == ORC_ORDER_DEVICE) ? -((double)ny * llpf_log(6.283185307179586)) / 2.0
+                                         : -((double)ny * log(6.283185307179586)) / 2.0;
+    f->rbf.on = 1; f->rbf.nn = nn; f->rbf.nl = nl; f->rbf.np = LLPF_RBF_NP(nl);
+    size_t N = (size_t)f->N;
+    f->rbf.xl = (double*)calloc(N * nl, 8); f->rbf.xlprev = (double*)calloc(N * nl, 8);
+    f->rbf.R = (double*)calloc(N * f->rbf.np, 8); f->rbf.Rprev = (double*)calloc(N * f->rbf.np, 8);
+    return 0;
+}
+/* reset!(pf::RBPF) — src/rbpf.jl:146-160: xl = copy(kf.d0.mu), R = copy(kf.d0.Sigma) */
+static void rbf_reset(orc_filter* f) {
+    const int nl = f->rbf.nl, np = f->rbf.np;
+    for (int64_t i = 0; i < f->N; ++i) {
+        for (int d = 0; d < nl; ++d) { f->rbf.xl[i * nl + d] = f->rbf.par.xl0[d]; f->rbf.xlprev[i * nl + d] = f->rbf.par.xl0[d]; }
+        for (int d = 0; d < np; ++d) { f->rbf.R[i * np + d] = f->rbf.par.R0[d]; f->rbf.Rprev[i * np + d] = f->rbf.par.R0[d]; }
+    }
+}
+/* correct!(pf::RBPF, u, y, p, t) — src/rbpf.jl:252-280, !zeroC && !singleR: every particle runs correct!(kf, u, y - yn) */
+static void rbf_correct(orc_filter* f, const double* u, const double* y, double t) {
+    const int nn = f->rbf.nn, nl = f->rbf.nl, np = f->rbf.np, ny = f->ny;
+    const int dev = f->order == ORC_ORDER_DEVICE;
+    ORC_PAR
+    for (int64_t i = 0; i < f->N; ++i) {
+        double yn[LLPF_RBF_MAXY];
+        orc_measurement(&f->cfg.model, f->x + i * nn, u, t, yn);
+        const double ll = dev ? llpf_rbf_correct(&f->rbf.par, nl, ny, y, yn, f->rbf.xl + i * nl, f->rbf.R + i * np)
+                              : llpf_rbfr_correct(&f->rbf.par, nl, ny, y, yn, f->rbf.xl + i * nl, f->rbf.R + i * np);
+        f->w[i] += ll;
+    }
+    memcpy(f->xprev, f->x, sizeof(double) * (size_t)f->N * nn);           /* copyto!(s.xprev, s.x), :282 */
+    memcpy(f->rbf.xlprev, f->rbf.xl, sizeof(double) * (size_t)f->N * nl);
+    memcpy(f->rbf.Rprev, f->rbf.R, sizeof(double) * (size_t)f->N * np);
+}
+/* the propagation loop of predict!(pf::RBPF, ...) — src/rbpf.jl:180-224, !zeroAn && !singleR */
+static void rbf_propagate(orc_filter* f, const double* u, double t, const double* xi, int res) {
+    const int nn = f->rbf.nn, nl = f->rbf.nl, np = f->rbf.np, nu = f->nu;
+    const int dev = f->order == ORC_ORDER_DEVICE;
+    ORC_PAR
+    for (int64_t i = 0; i < f->N; ++i) {
+        const int64_t a = res ? f->j[i] : i;                              /* xi = s.xprev[j[i]], :182 */
+        double fi[LLPF_RBF_MAXN], nz[LLPF_RBF_MAXN];
+        orc_dynamics(&f->cfg.model, f->xprev + a * nn, u, t, fi);
+        gauss_sample(&f->df, xi + i * nn, nz);                            /* rand(pf.rng, pf.R1n), :217 */
+        if (dev) llpf_rbf_predict(&f->rbf.par, nn, nl, nu, f->xprev + a * nn, f->rbf.xlprev + a * nl, f->rbf.Rprev + a * np, u, fi, nz,
+                                  f->x + i * nn, f->rbf.xl + i * nl, f->rbf.R + i * np);
+        else llpf_rbfr_predict(&f->rbf.par, nn, nl, nu, f->xprev + a * nn, f->rbf.xlprev + a * nl, f->rbf.Rprev + a * np, u, fi, nz,
+                               f->x + i * nn, f->rbf.xl + i * nl, f->rbf.R + i * np);
+    }
+    memcpy(f->rbf.xlprev, f->rbf.xl, sizeof(double) * (size_t)f->N * nl);  /* copyto!(s.xprev, s.x), :227 */
+    memcpy(f->rbf.Rprev, f->rbf.R, sizeof(double) * (size_t)f->N * np);
+}
+/* per-particle Kalman state: xl [N][nl], R [N][nl][nl] (either may be NULL) */
+void orc_rb_get_linear_state(const orc_filter* f, double* xl, double* R) {
+    const int nl = f->rbf.nl, np = f->rbf.np;
+    for (int64_t i = 0; i < f->N; ++i) {
+        if (xl) for (int d = 0; d < nl; ++d) xl[i * nl + d] = f->rbf.xl[i * nl + d];
+        if (R) for (int r = 0; r < nl; ++r) for (int c = 0; c < nl; ++c) R[(i * nl + r) * nl + c] = f->rbf.R[i * np + llpf_rbf_idx(r, c)];
+    }
+}
+
 orc_filter* orc_create(const llpf_config* cfg, int order) {
     orc_filter* f = (orc_filter*)calloc(1, sizeof(orc_filter));
     f->cfg = *cfg;
@@ -783,6 +891,7 @@ orc_filter* orc_create(const llpf_config* cfg, int order) {
         gauss_prepare(&cfg->model.measurement_density, &f->dg, order) ||
         gauss_prepare(&cfg->model.initial_density, &f->d0, order)) { free(f); return NULL; }
     if (cfg->model.model_id == LLPF_MODEL_RB_LINEAR && rb_setup(f, order)) { free(f); return NULL; }
+    if (cfg->model.model_id == LLPF_MODEL_RB_BILINEAR && rbf_setup(f, order)) { free(f); return NULL; }
     size_t N = (size_t)f->N;
     f->x = (double*)calloc(N * f->nx, 8); f->xprev = (double*)calloc(N * f->nx, 8);
     f->w = (double*)calloc(N, 8); f->we = (double*)calloc(N, 8);
@@ -794,6 +903,7 @@ orc_filter* orc_create(const llpf_config* cfg, int order) {
     gen_normals(f, f->n_reset, LLPF_STREAM_INIT, f->xi_buf);
     f->n_reset++;
     init_particles(f, f->xi_buf);
+    if (f->rbf.on) rbf_reset(f);
     fill_uniform_weights(f, order == ORC_ORDER_DEVICE ? llpf_log(1.0 / (double)f->N) : log(1.0 / (double)f->N));
     for (int64_t i = 0; i < f->N; ++i) f->j[i] = i;
     f->t = 0;
@@ -803,6 +913,7 @@ orc_filter* orc_create(const llpf_config* cfg, int order) {
 void orc_destroy(orc_filter* f) {
     if (!f) return;
     free(f->x); free(f->xprev); free(f->w); free(f->we); free(f->bins); free(f->e); free(f->j);
+    free(f->rbf.xl); free(f->rbf.xlprev); free(f->rbf.R); free(f->rbf.Rprev);
     free(f->xi_buf); free(f->U_buf); free(f->lam); free(f);
 }
 
@@ -811,6 +922,7 @@ void orc_seed(orc_filter* f, uint64_t seed) { set_key(f, seed); }
 /* reset!(pf) — src/filtering.jl:4-14 */
 void orc_reset_explicit(orc_filter* f, const double* xi) {
     init_particles(f, xi);
+    if (f->rbf.on) rbf_reset(f);
     f->aux_pending = 0;
     fill_uniform_weights(f, f->order == ORC_ORDER_DEVICE ? -llpf_log((double)f->N) : -log((double)f->N));
     f->t = 1;
@@ -852,6 +964,12 @@ static double filter_logsumexp(orc_filter* f, double off, int bound) {
 double orc_correct(orc_filter* f, const double* u, const double* y, double t) {
     const int has_y = (y != NULL && y[0] == y[0]);
     const double off = has_y ? f->wmax + f->dg.c0 : f->wmax;   /* device order: upper bound of the new weights */
+    if (f->rbf.on && has_y) {
+        /* S_i = C R_i C' + R2 >= R2: the peak of N(0, R2) bounds every increment (+ the slack the kernel uses) */
+        rbf_correct(f, u, y, t);
+        f->aux_pending = 0;
+        return filter_logsumexp(f, (f->wmax + f->dg.c0) + 0x1p-20, 1);
+    }
     if (f->rb.on && has_y) {
         rb_correct(f, y);
         f->aux_pending = 0;
@@ -931,14 +1049,15 @@ void orc_predict_explicit(orc_filter* f, const double* u, double t, const double
     int64_t N = f->N;
     int nx = f->nx;
     int res = orc_shouldresample(f);
-    if (f->rb.on) {                                           /* predict!(pf::RBPF, ...) — src/rbpf.jl:163-232 */
+    if (f->rb.on || f->rbf.on) {                              /* predict!(pf::RBPF, ...) — src/rbpf.jl:163-232 */
         if (res) {
             if (f->order == ORC_ORDER_DEVICE && f->dn_valid) filter_resample_dev(f, U);
             else orc_resample(f->cfg.resampling_strategy, f->we, N, N, U, f->j, f->bins, f->order);
         } else {
             for (int64_t i = 0; i < N; ++i) f->j[i] = i;
         }
-        rb_propagate(f, u, xi, res);
+        if (f->rbf.on) rbf_propagate(f, u, t, xi, res);
+        else rb_propagate(f, u, xi, res);
         if (res) {
             fill_uniform_weights(f, f->order == ORC_ORDER_DEVICE ? llpf_log(1.0 / (double)N) : log(1.0 / (double)N));
             f->maxw = 0.0;

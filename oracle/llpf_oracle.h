@@ -68,6 +68,8 @@ int    orc_smooth(orc_filter* f, int64_t M, const double* U, int64_t T, const do
 
 /* RBPF (model_id LLPF_MODEL_RB_LINEAR): the covariance shared by all particles, nxl x nxl row-major */
 void   orc_rb_get_R(const orc_filter* f, double* R);
+/* RBPF with per-particle covariance (LLPF_MODEL_RB_BILINEAR): xl [N][nxl], R [N][nxl][nxl]; either may be NULL */
+void   orc_rb_get_linear_state(const orc_filter* f, double* xl, double* R);
 
 int64_t orc_num_particles(const orc_filter* f);
 int64_t orc_index(const orc_filter* f);

@@ -49,6 +49,7 @@ def load():
     lib.orc_draw_one_categorical.argtypes = [_dp, _dp, C.c_int64, C.c_double, C.c_int]
     lib.orc_smooth.argtypes = [C.c_void_p, C.c_int64, _dp, C.c_int64, _dp, _dp, _dp, _dp, _ip]
     lib.orc_rb_get_R.argtypes = [C.c_void_p, _dp]
+    lib.orc_rb_get_linear_state.argtypes = [C.c_void_p, _dp, _dp]
     lib.orc_num_particles.restype = C.c_int64
     lib.orc_num_particles.argtypes = [C.c_void_p]
     lib.orc_index.restype = C.c_int64
@@ -233,6 +234,14 @@ class OracleFilter:
         a = np.zeros((nl, nl))
         self.L.orc_rb_get_R(self.h, dptr(a))
         return a
+
+    def rb_linear_state(self):
+        """per-particle Kalman state of LLPF_MODEL_RB_BILINEAR: xl [N, nxl], R [N, nxl, nxl]"""
+        nl = self.cfg.model.rb.nxl
+        xl = np.zeros((self.N, nl))
+        R = np.zeros((self.N, nl, nl))
+        self.L.orc_rb_get_linear_state(self.h, dptr(xl), dptr(R))
+        return xl, R
 
     def particles(self):
         a = np.empty((self.N, self.nx))

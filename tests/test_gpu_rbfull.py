@@ -1,0 +1,120 @@
+"""GPU parity of the Rao-Blackwellized particle filter with per-particle covariance (LLPF_MODEL_RB_BILINEAR: An a
+function of the nonlinear state, reference src/rbpf.jl:163-283 with singleR off; BASELINE config C5)."""
+import numpy as np
+import pytest
+
+import llpf_amd
+from llpf_amd import _capi, _structs as S
+import oracle_binding as ob
+import rbfull_models as M
+from gpu_common import TOL_LL_STEP, cfg_of as _cfg, compare_state as _compare_state
+
+pytestmark = pytest.mark.gpu
+
+
+def _same_bits(a, b):
+    return np.array_equal(np.ascontiguousarray(a).view(np.uint64), np.ascontiguousarray(b).view(np.uint64))
+
+
+def _compare_linear_state(g, o):
+    xg, Rg = g.rb_linear_state()
+    xo, Ro = o.rb_linear_state()
+    assert _same_bits(xg, xo), "Kalman means differ"
+    assert _same_bits(Rg, Ro), "Kalman covariances differ"
+
+
+CASES = {
+    "lin_1_2_1": lambda: M.linear_case(1, 2, 1, seed=1)[0],
+    "lin_2_2_2": lambda: M.linear_case(2, 2, 2, seed=1)[0],
+    "lin_4_8_2": lambda: M.linear_case(4, 8, 2, seed=1)[0],
+    "quadtank_4_8_2": lambda: M.quadtank_case(),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+@pytest.mark.parametrize("strategy", [S.RESAMPLE_SYSTEMATIC, S.RESAMPLE_STRATIFIED, S.RESAMPLE_RESIDUAL])
+def test_rbfull_bit_exact(name, strategy):
+    """Whole trajectories (per-step ll, history of xn, the final xn / xl / R of every particle, ancestors) bit-identical
+    to the device-order oracle and within tolerance of the reference-order one; then single steps."""
+    if strategy != S.RESAMPLE_SYSTEMATIC and name not in ("lin_2_2_2", "quadtank_4_8_2"):
+        pytest.skip("other strategies on two shapes")
+    model = CASES[name]()
+    N, T = 3000, 40
+    U, Y = M.simulate_io(model, T)
+    Y[7] = np.nan                                              # a missing measurement: weights pass through
+    cfg = _cfg(model, N, strategy, 0.5, seed=5)
+    g = _capi.FilterHandle(cfg); o = ob.OracleFilter(cfg, ob.ORDER_DEVICE); r = ob.OracleFilter(cfg, ob.ORDER_REFERENCE)
+    _compare_state(g, o); _compare_linear_state(g, o)
+    for h in (g, o, r):
+        h.reset()
+    _compare_state(g, o); _compare_linear_state(g, o)
+    rg = g.run(U, Y, 0.0, ll_steps=True, history=True); ro = o.run(U, Y, 0.0, ll_steps=True, history=True)
+    rr = r.run(U, Y, 0.0, ll_steps=True)
+    assert o.resample_count() > 3
+    assert _same_bits(rg["ll_steps"], ro["ll_steps"])
+    for key in ("x", "w", "we"):
+        assert _same_bits(rg[key], ro[key]), key
+    _compare_state(g, o); _compare_linear_state(g, o)
+    assert np.max(np.abs(rg["ll_steps"] - rr["ll_steps"])) <= TOL_LL_STEP
+    # the asynchronous loop (no history)
+    g2 = _capi.FilterHandle(cfg); g2.reset()
+    r2 = g2.run(U, Y, 0.0, ll_steps=True, xmean=True)
+    assert _same_bits(r2["ll_steps"], ro["ll_steps"])
+    _compare_linear_state(g2, o)
+    # single steps
+    g3 = _capi.FilterHandle(cfg); o3 = ob.OracleFilter(cfg, ob.ORDER_DEVICE)
+    g3.reset(); o3.reset()
+    for k in range(10):
+        assert g3.update(U[k], Y[k], k * 1.0) == o3.update(U[k], Y[k], k * 1.0)
+        _compare_state(g3, o3); _compare_linear_state(g3, o3)
+
+
+def test_rbfull_large_and_repeated_runs():
+    """N = 2e5 (the size of BASELINE config C5), quad-tank coupling: log-likelihood per step bit-identical to the
+    device-order oracle; a second and third run of the same handle (captured graph) reproduce a fresh handle's results
+    for their own noise."""
+    model = M.quadtank_case()
+    N, T = 200_000, 12
+    U, Y = M.simulate_io(model, T)
+    cfg = _cfg(model, N, S.RESAMPLE_SYSTEMATIC, 0.5, seed=9)
+    g = _capi.FilterHandle(cfg); o = ob.OracleFilter(cfg, ob.ORDER_DEVICE)
+    ob.set_threads(8)
+    try:
+        g.reset(); o.reset()
+        rg = g.run(U, Y, 0.0, ll_steps=True); ro = o.run(U, Y, 0.0, ll_steps=True)
+        assert _same_bits(rg["ll_steps"], ro["ll_steps"])
+        _compare_linear_state(g, o)
+        for _ in range(2):
+            g.reset(); o.reset()
+            rg = g.run(U, Y, 0.0, ll_steps=True); ro = o.run(U, Y, 0.0, ll_steps=True)
+            assert _same_bits(rg["ll_steps"], ro["ll_steps"])
+    finally:
+        ob.set_threads(1)
+
+
+def test_rbfull_api_and_errors():
+    """RBPF(...; An = StateAffineCoupling(...)) through the reference-shaped API; unsupported combinations fail loudly."""
+    model, mats = M.linear_case(2, 2, 2, seed=1)
+    U, Y = M.simulate_io(model, 30)
+    mv = lambda gs: llpf_amd.MvNormal(S.gaussian_mean(gs), S.gaussian_cov_matrix(gs))
+    kf = llpf_amd.KalmanFilter(mats["Al"], mats["Bl"], mats["Cl"], 0, mats["R1l"], S.gaussian_cov_matrix(model.measurement_density),
+                               mv(model.linear_initial))
+    mm = llpf_amd.RBMeasurementModel(llpf_amd.LinearMeasurement(mats["Gn"]), S.gaussian_cov_matrix(model.measurement_density), 2)
+    An = llpf_amd.StateAffineCoupling(mats["An"][0], mats["An"][1:])
+    pf = llpf_amd.RBPF(2000, kf, llpf_amd.LinearDynamics(mats["Fn"], mats["Bn"]), mm, S.gaussian_cov_matrix(model.dynamics_density),
+                       mv(model.initial_density), An=An, nu=1, rng=5, resample_threshold=0.5)
+    o = ob.OracleFilter(_cfg(model, 2000, S.RESAMPLE_SYSTEMATIC, 0.5, seed=5), ob.ORDER_DEVICE)
+    o.reset()
+    sol = llpf_amd.forward_trajectory(pf, U, Y)
+    assert sol.ll == o.run(U, Y, 0.0)["ll"]
+    assert llpf_amd.particles(pf).shape == (2000, 4)
+    xl, R = pf.linear_state()
+    assert xl.shape == (2000, 2) and R.shape == (2000, 2, 2) and pf.covariance.shape == (2, 2)
+    assert np.max(np.abs(R - R[0])) > 1e-6
+    with pytest.raises(_capi.LLPFError):
+        llpf_amd.smooth(pf, 10, U, Y)
+    with pytest.raises(_capi.LLPFError):                       # banks of this model are not provided
+        _capi.BankHandle(_cfg(model, 1000), [model, model])
+    bad, _ = M.linear_case(2, 4, 2, seed=1)                    # a shape without an instantiated kernel
+    with pytest.raises(_capi.LLPFError):
+        _capi.FilterHandle(_cfg(bad, 1000))
