@@ -54,6 +54,15 @@ def build_workload(name, n_particles, T):
         U = np.zeros((T, 0))
         kind, thr = S.PARTICLE_FILTER, 0.1
         label = "RBPF (test/test_rbpf.jl:5-31 system: 1 nonlinear + 1 linear state, An = 0.5), N=%d, T=%d, threshold 0.1" % (n_particles, T)
+    elif name == "rbpf_full":
+        import rbfull_models as RM
+        # BASELINE config C5: quad-tank levels (4 nonlinear states, RK4 x 2) + 8 linear states with a state-dependent
+        # coupling An(xn): the reference's singleR shortcut (src/rbpf.jl:176,247) is off, one 8x8 Riccati recursion per particle
+        model = RM.quadtank_case()
+        U, Y = RM.simulate_io(model, T, seed=3)
+        kind, thr = S.PARTICLE_FILTER, 0.1
+        label = ("C5: RBPF, quad-tank (4 nonlinear states) + 8 linear states, An(xn) state dependent => per-particle 8x8 covariance, "
+                 "N=%d, T=%d, threshold 0.1" % (n_particles, T))
     elif name == "aux":
         model = M.lg_test_model()
         _, U, Y = M.simulate_lg(model, T, seed=1)
@@ -209,7 +218,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="lg", choices=["lg", "quadtank", "aux", "bank", "rbpf"])
+    ap.add_argument("--workload", default="lg", choices=["lg", "quadtank", "aux", "bank", "rbpf", "rbpf_full"])
     ap.add_argument("--filters-per-gpu", type=int, default=128, help="bank workload (BASELINE config C4): filters per GPU")
     ap.add_argument("--particles", type=int, default=1000000)
     ap.add_argument("--T", type=int, default=None)
@@ -233,6 +242,9 @@ def main():
         return main_bank(args, rank, world, dev)
     from llpf_amd import _capi, _structs as S
     T = args.T if args.T else (2000 if args.workload == "quadtank" else 1000)
+    rbfull = args.workload == "rbpf_full"
+    if rbfull and args.particles == 1000000:
+        args.particles = 200000                      # BASELINE config C5 is quoted at N = 2e5
     model, U, Y, kind, thr, label = build_workload(args.workload, args.particles, T)
     if args.threshold is not None:
         thr = args.threshold
@@ -323,6 +335,15 @@ def main():
             b_step = b_model = 16 * nx + 20
         else:
             b_step = b_model = 16 * nx + (20 if not n_cls[1] else 12)
+        if rbfull:
+            # the particle plane of this model has rows = xn + xl + packed lower triangle of R (4 + 8 + 36 = 48):
+            # k_rbfull reads ancestor 4 + gathers 8 rows + writes 8 rows + writes w 8; whole timestep adds the k_norm /
+            # k_resample traffic of SURVEY 8(d): B_alg = 16 rows + 40
+            rows = nx + model.rb.nxl + model.rb.nxl * (model.rb.nxl + 1) // 2
+            b_step = b_model = 16 * rows + 12
+            b_alg = 16 * rows + 40
+            names[0] = "k_rbfull(gather RBParticle + Riccati time update + Kalman measurement update + weight)"
+            kernel_us = {names[i]: (1e3 * ms_cls[i] / n_cls[i] if n_cls[i] else None) for i in range(4)}
         timestep_s = dt / (args.steps * T)
         if one_launch:
             # the timed region itself is bracketed by HIP events on the engine stream (llpf_last_run_ms): T launches of
@@ -336,13 +357,21 @@ def main():
             method = ("hipEvent pairs around every launch on the engine stream, %d profiled passes after the timed region "
                       "(each pair adds ~2-3 us to the launch it brackets)" % max(1, min(args.steps, 3)))
         achieved = N * b_step / step_s / 1e9
-        roof = {"bound": "hbm", "kernel": "k_resprop" if fused else "k_step<MODE_PROP_WEIGHT>", "achieved": achieved, "peak": 8000.0,
+        roof = {"bound": "hbm", "kernel": "k_rbfull<MODE_PROP_WEIGHT>" if rbfull else ("k_resprop" if fused else "k_step<MODE_PROP_WEIGHT>"), "achieved": achieved, "peak": 8000.0,
                 "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
                 "bytes_per_launch": N * b_step, "kernel_model_bytes": N * b_model, "avg_launch_us": step_s * 1e6,
                 "launches_per_timestep": sum(n_cls[:3]) / float(n_cls[0]),
                 "method": method,
                 "whole_timestep": {"algorithmic_bytes": N * b_alg, "us": timestep_s * 1e6,
                                    "achieved": N * b_alg / timestep_s / 1e9, "frac": N * b_alg / timestep_s / 8e12}}
+        if rbfull:
+            # fp64 work of one particle-step counted from csrc/shared/llpf_rbfull_body.h at (nxn, nxl, ny) = (4, 8, 2):
+            # time update ~2120 fma (An(xn) 128, An R 256, Nt 80, per row of Al R: 64 + 32 + solves 20 + 16, lower triangle of
+            # Al R Al' - L Nt L' 432, means 150), measurement update ~400 fma (C R 128, S 32, K 48, R - K C R 144, ...),
+            # RK4 x 2 of the quad-tank ~730 flop
+            flop = 2.0 * 2520 + 730.0
+            roof["compute"] = {"fp64_flop_per_particle_step": flop, "achieved_tflops": N * flop / step_s / 1e12,
+                               "peak_tflops": 78.6, "frac": N * flop / step_s / 78.6e12}
         if args.workload == "quadtank":
             # this timestep is arithmetic, not traffic: RK4 x 2 sub-steps = 8 right-hand sides with 4 fp64 sqrt each.
             # fp64 flops per particle-step counted from the ISA of k_step<QuadTank, PROP_WEIGHT> (fma = 2, mul/add = 1;
@@ -370,7 +399,7 @@ def main():
                "device_ms_per_step": dev_ms / args.steps, "kernel_us": kernel_us, "loglik": ll,
                "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
-            per = 2.5e7 if args.workload == "lg" else 4.5e6        # measured 1-core rates, to size a ~10 s sample
+            per = 2.5e7 if args.workload == "lg" else (5e5 if rbfull else 4.5e6)   # measured 1-core rates, to size a ~10 s sample
             cs = args.cpu_steps if args.cpu_steps else max(2, min(T, int(10 * per / N)))
             pf2 = _capi.FilterHandle(cfg)          # a fresh handle: same Philox counters as a fresh oracle (first reset!)
             pf2.reset()

@@ -9,7 +9,7 @@
 module LLPFAmd
 
 using LinearAlgebra
-export GPUParticleFilter, GPUAuxiliaryParticleFilter, LinearGaussianModel, QuadTankModel, RBLinearModel, GaussianSpec, smooth,
+export GPUParticleFilter, GPUAuxiliaryParticleFilter, LinearGaussianModel, QuadTankModel, RBLinearModel, RBBilinearModel, linear_state, GaussianSpec, smooth,
        reset!, predict!, correct!, update!, loglik, forward_trajectory, particles, weights, expweights,
        num_particles, index, effective_particles, shouldresample, weighted_mean
 
@@ -23,6 +23,12 @@ struct CGaussian
     mu::NTuple{8,Float64}
     cov::NTuple{64,Float64}
 end
+struct CRBCoupling                                              # llpf_rb_coupling (LLPF_MODEL_RB_BILINEAR only; zeroed otherwise)
+    nxl::Int32; fn_kind::Int32
+    Al::NTuple{64,Float64}; Bl::NTuple{64,Float64}; Cl::NTuple{64,Float64}
+    An::NTuple{160,Float64}                                   # An[0] constant term, An[1+k] multiplies xn[k]; 5 x (nxn x nxl, row-major, 32 slots)
+end
+const NOCOUPLING = CRBCoupling(0, 0, ntuple(_ -> 0.0, 64), ntuple(_ -> 0.0, 64), ntuple(_ -> 0.0, 64), ntuple(_ -> 0.0, 160))
 struct CModel
     model_id::Int32; nx::Int32; nu::Int32; ny::Int32
     A::NTuple{64,Float64}; B::NTuple{64,Float64}; C::NTuple{64,Float64}
@@ -30,7 +36,8 @@ struct CModel
     supersample::Int32; nxn::Int32
     Ts::Float64
     df::CGaussian; dg::CGaussian; d0::CGaussian
-    linear_noise::CGaussian; linear_initial::CGaussian      # LLPF_MODEL_RB_LINEAR only (zeroed otherwise)
+    linear_noise::CGaussian; linear_initial::CGaussian      # Rao-Blackwellized models only (zeroed otherwise)
+    rb::CRBCoupling
 end
 struct CConfig
     struct_size::UInt32; filter_kind::Int32
@@ -76,11 +83,11 @@ QuadTankModel(; supersample = 2) = QuadTankModel(
 function cmodel(m::LinearGaussianModel, df, dg, d0, Ts)
     nx = size(m.A, 1); nu = size(m.B, 2); ny = size(m.C, 1)
     CModel(0, nx, nu, ny, pad(rowmajor(m.A), 64), pad(rowmajor(m.B), 64), pad(rowmajor(m.C), 64),
-           ntuple(_ -> 0.0, 16), 1, 0, Ts, cgauss(df), cgauss(dg), cgauss(d0), NOGAUSS, NOGAUSS)
+           ntuple(_ -> 0.0, 16), 1, 0, Ts, cgauss(df), cgauss(dg), cgauss(d0), NOGAUSS, NOGAUSS, NOCOUPLING)
 end
 cmodel(m::QuadTankModel, df, dg, d0, Ts) =
     CModel(1, 4, 2, 2, ntuple(_ -> 0.0, 64), ntuple(_ -> 0.0, 64), ntuple(_ -> 0.0, 64), m.consts,
-           m.supersample, 0, Ts, cgauss(df), cgauss(dg), cgauss(d0), NOGAUSS, NOGAUSS)
+           m.supersample, 0, Ts, cgauss(df), cgauss(dg), cgauss(d0), NOGAUSS, NOGAUSS, NOCOUPLING)
 # RBPF: df = R1n, dg = R2, d0 = d0n (all of the nonlinear substate's dimension); A = [Fn An; 0 Al], B = [Bn; Bl], C = [Gn Cl]
 function cmodel(m::RBLinearModel, df, dg, d0, Ts)
     nn = size(m.Fn, 1); nl = size(m.Al, 1); nu = size(m.Bn, 2); ny = size(m.Gn, 1)
@@ -88,7 +95,24 @@ function cmodel(m::RBLinearModel, df, dg, d0, Ts)
     Cl = m.Cl === nothing ? zeros(ny, nl) : m.Cl
     A = [m.Fn An; zeros(nl, nn) m.Al]; B = [m.Bn; m.Bl]; C = [m.Gn Cl]
     CModel(2, nn + nl, nu, ny, pad(rowmajor(A), 64), pad(rowmajor(B), 64), pad(rowmajor(C), 64), ntuple(_ -> 0.0, 16),
-           1, nn, Ts, cgauss(df), cgauss(dg), cgauss(d0), cgauss(GaussianSpec(zeros(nl), Matrix{Float64}(m.R1l))), cgauss(m.d0l))
+           1, nn, Ts, cgauss(df), cgauss(dg), cgauss(d0), cgauss(GaussianSpec(zeros(nl), Matrix{Float64}(m.R1l))), cgauss(m.d0l), NOCOUPLING)
+end
+
+"""Rao-Blackwellized model whose coupling depends on the nonlinear state (reference src/rbpf.jl:108: `An` a function of
+x): An(xn) = An0 + sum_k xn[k] Ank[k]; every particle carries its own Kalman covariance (the reference's !singleR branches,
+:176/:247).  `fn` is a LinearGaussianModel (Fn, Bn, Gn over xn) or a QuadTankModel (xn = the four levels)."""
+struct RBBilinearModel; fn; An0; Ank::Vector; Al; Bl; Cl; R1l; d0l::GaussianSpec; end
+function cmodel(m::RBBilinearModel, df, dg, d0, Ts)
+    nn, nl = size(m.An0); ny = size(m.Cl, 1)
+    an = zeros(160)
+    an[1:nn*nl] = rowmajor(m.An0)
+    for k in 1:nn; an[32k+1:32k+nn*nl] = rowmajor(m.Ank[k]); end
+    quad = m.fn isa QuadTankModel
+    base = quad ? cmodel(m.fn, df, dg, d0, Ts) : cmodel(m.fn, df, dg, d0, Ts)       # A, B, C (or qt, supersample) over xn
+    nu = base.nu
+    rb = CRBCoupling(nl, quad ? 1 : 0, pad(rowmajor(m.Al), 64), pad(nu > 0 ? rowmajor(m.Bl) : Float64[], 64), pad(rowmajor(m.Cl), 64), Tuple(an))
+    CModel(3, nn, nu, ny, base.A, base.B, base.C, base.qt, base.supersample, nn, Ts, cgauss(df), cgauss(dg), cgauss(d0),
+           cgauss(GaussianSpec(zeros(nl), Matrix{Float64}(m.R1l))), cgauss(m.d0l), rb)
 end
 
 check(rc) = rc == 0 || error("llpf status $rc: " * unsafe_string(ccall((:llpf_last_error, LIB), Cstring, ())))
@@ -242,6 +266,12 @@ function getvec(sym, pf, n)
     check(ccall((sym, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), pf.h, out)); out
 end
 particles(pf::GPUParticleFilter) = reshape(getvec(:llpf_get_particles, pf, pf.N * pf.nx), pf.nx, pf.N)
+"(xl [nxl x N], R [nxl x nxl x N]): fields xl, R of every RBParticle (src/rbpf.jl:1-5) of a filter built from an RBBilinearModel"
+function linear_state(pf::GPUParticleFilter, nxl::Integer)
+    xl = Matrix{Float64}(undef, nxl, pf.N); R = Array{Float64}(undef, nxl, nxl, pf.N)      # symmetric: row- and column-major agree
+    check(ccall((:llpf_rb_get_linear_state, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), pf.h, xl, R))
+    xl, R
+end
 weights(pf::GPUParticleFilter) = getvec(:llpf_get_weights, pf, pf.N)
 expweights(pf::GPUParticleFilter) = getvec(:llpf_get_expweights, pf, pf.N)
 weighted_mean(pf::GPUParticleFilter) = getvec(:llpf_weighted_mean, pf, pf.nx)

@@ -19,6 +19,7 @@ python tools/bench_bank.py --thr 1.0 > $OUT/bench_c4_bank_128x1e5_thr1.json 2>> 
 python bench.py --workload bank --steps 2 > $OUT/bench_c4_bank_workload.json 2>> $OUT/bench_c2.err
 python bench.py --workload aux > $OUT/bench_aux.json 2>> $OUT/bench_c2.err
 python bench.py --workload rbpf > $OUT/bench_rbpf.json 2>> $OUT/bench_c2.err
+python bench.py --workload rbpf_full > $OUT/bench_c5_rbpf_full.json 2>> $OUT/bench_c2.err
 python tools/bench_smooth.py > $OUT/bench_ffbs_smoother.json 2>> $OUT/bench_c2.err
 python tools/bench_smooth.py --particles 1000 --T 200 --M 100 --cpu-M 100 >> $OUT/bench_ffbs_smoother.json 2>> $OUT/bench_c2.err
 tools/ab/schedules.sh > $OUT/schedules_ab.txt 2>&1
@@ -28,13 +29,17 @@ rocprofv3 --kernel-trace -d $OUT/kt_bank -o kt -- python $ROOT/tools/bench_bank.
 rocprofv3 --kernel-trace -d $OUT/kt_qt -o kt -- python $ROOT/bench.py --workload quadtank --steps 2 --no-cpu-baseline > $OUT/kt_qt.log 2>&1
 rocprofv3 --kernel-trace -d $OUT/kt_aux -o kt -- python $ROOT/bench.py --workload aux --no-cpu-baseline > $OUT/kt_aux.log 2>&1
 rocprofv3 --kernel-trace -d $OUT/kt_rbpf -o kt -- python $ROOT/bench.py --workload rbpf --no-cpu-baseline > $OUT/kt_rbpf.log 2>&1
+rocprofv3 --kernel-trace -d $OUT/kt_rbpf_full -o kt -- python $ROOT/bench.py --workload rbpf_full --no-cpu-baseline > $OUT/kt_rbpf_full.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch_c5 -o p -- python $ROOT/bench.py --workload rbpf_full --steps 1 --warmup 0 --T 200 --no-cpu-baseline > $OUT/pmc_fetch_c5.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write_c5 -o p -- python $ROOT/bench.py --workload rbpf_full --steps 1 --warmup 0 --T 200 --no-cpu-baseline > $OUT/pmc_write_c5.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o p -- python $ROOT/bench.py --steps 1 --warmup 0 --T 200 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o p -- python $ROOT/bench.py --steps 1 --warmup 0 --T 200 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_ANY -d $OUT/pmc_sq -o p -- python $ROOT/bench.py --steps 1 --warmup 0 --T 200 --no-cpu-baseline > $OUT/pmc_sq.log 2>&1
 cd $ROOT
 python tools/rocprof_summary.py $(find $OUT/kt -name "*.db" | head -1) > $OUT/kernel_stats.txt
 python tools/rocprof_summary.py $(find $OUT/kt_bank -name "*.db" | head -1) > $OUT/kernel_stats_bank.txt
-for w in qt aux rbpf; do python tools/rocprof_summary.py $(find $OUT/kt_$w -name "*.db" | head -1) > $OUT/kernel_stats_$w.txt; done
+for w in qt aux rbpf rbpf_full; do python tools/rocprof_summary.py $(find $OUT/kt_$w -name "*.db" | head -1) > $OUT/kernel_stats_$w.txt; done
 python tools/rocprof_pmc_summary.py $OUT/pmc_traffic.txt $(find $OUT/pmc_fetch -name "*.db" | head -1) $(find $OUT/pmc_write -name "*.db" | head -1) $(find $OUT/pmc_sq -name "*.db" | head -1)
-rm -rf $OUT/kt $OUT/kt_bank $OUT/kt_qt $OUT/kt_aux $OUT/kt_rbpf $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/*.log
+python tools/rocprof_pmc_summary.py $OUT/pmc_traffic_c5.txt $(find $OUT/pmc_fetch_c5 -name "*.db" | head -1) $(find $OUT/pmc_write_c5 -name "*.db" | head -1)
+rm -rf $OUT/kt_rbpf_full $OUT/pmc_fetch_c5 $OUT/pmc_write_c5 $OUT/kt $OUT/kt_bank $OUT/kt_qt $OUT/kt_aux $OUT/kt_rbpf $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/*.log
 ls -la $OUT
