@@ -366,10 +366,10 @@ def main():
                                    "achieved": N * b_alg / timestep_s / 1e9, "frac": N * b_alg / timestep_s / 8e12}}
         if rbfull:
             # fp64 work of one particle-step counted from csrc/shared/llpf_rbfull_body.h at (nxn, nxl, ny) = (4, 8, 2):
-            # time update ~2120 fma (An(xn) 128, An R 256, Nt 80, per row of Al R: 64 + 32 + solves 20 + 16, lower triangle of
-            # Al R Al' - L Nt L' 432, means 150), measurement update ~400 fma (C R 128, S 32, K 48, R - K C R 144, ...),
+            # time update ~1910 fma (An(xn) 128, An R 256, Nt 80, per row: Al R 64 + Al (An R)' 32 + solve 6, lower triangle of
+            # Al R Al' - W W' 36 x 12, means 150), measurement update ~400 fma (C R 128, S 32, K 48, R - K C R 144, ...),
             # RK4 x 2 of the quad-tank ~730 flop
-            flop = 2.0 * 2520 + 730.0
+            flop = 2.0 * 2310 + 730.0
             roof["compute"] = {"fp64_flop_per_particle_step": flop, "achieved_tflops": N * flop / step_s / 1e12,
                                "peak_tflops": 78.6, "frac": N * flop / step_s / 78.6e12}
         if args.workload == "quadtank":
