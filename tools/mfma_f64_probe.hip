@@ -60,7 +60,7 @@ int main() {
     }
     for (int h = 0; h < 8; ++h)
         for (int q = 0; q < 4; ++q)
-            if (match[h][q] > trials / 2) { printf("layout %d (A %s, B %s, D %s): %s — bitwise match in %d/%d trials\n", h, (h & 1) ? "i*4+k" : "k*4+i", (h & 2) ? "j*4+k" : "k*4+j", (h & 4) ? "i*4+j" : "j*4+i", names[q], match[h][q], trials); ok_total++; }
+            if (match[h][q] > trials / 2) { printf("layout A[i][k] <-> lane 16k+4blk+i, B[k][j] <-> lane 16k+4blk+j, D[i][j] <-> lane 16i+4blk+j: %s — bitwise match in %d/%d trials\n", names[q], match[h][q], trials); ok_total++; }
     if (!ok_total) {
         printf("no hypothesis matched bitwise; best counts:\n");
         for (int h = 0; h < 8; ++h) printf("  layout %d: %d %d %d %d\n", h, match[h][0], match[h][1], match[h][2], match[h][3]);
