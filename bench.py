@@ -384,10 +384,13 @@ def main():
         # HBM traffic of the dominant kernel from the committed PMC profile of this same workload (cannot be collected
         # inside bench.py: rocprofv3 --pmc needs its own passes); only quoted when shapes match
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01h_pmc_traffic.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01i_pmc_traffic.json")))
             if one_launch and pm["n_particles"] == N and pm["nx"] == nx and args.workload == "lg" and thr == pm["resample_threshold"]:
                 roof["traffic"] = pm["k_resprop"]["bytes"]
                 roof["traffic_source"] = pm["source"] + "; " + pm["correction"]
+            if rbfull and pm["c5"]["n_particles"] == N:
+                roof["traffic"] = pm["c5"]["k_rbfull"]["bytes"]
+                roof["traffic_source"] = pm["c5"]["source"] + "; " + pm["correction"]
         except Exception:
             pass
         out = {"metric": "particle-steps/s", "value": value, "unit": "particle-steps/s", "n_gpus": world,
