@@ -74,7 +74,7 @@ enum {
      * runs its own Riccati recursion — BASELINE config C5):
      *   xn' = f_n(xn, u) + An(xn) xl + wn,   An(xn) = An[0] + sum_k xn[k] An[1+k]      (llpf_rb_coupling below)
      *   xl' = Al xl + Bl u + wl,             y = g(xn) + Cl xl + e
-     * The x arrays of the filter hold xn only: nx = nxn <= 4; f_n / g are the linear-Gaussian descriptors A, B, C of this
+     * llpf_model.nx = nxn <= 4 (what f_n, g and the densities df, d0 see); f_n / g are the linear-Gaussian descriptors A, B, C of this
      * struct sized for nxn (rb.fn_kind 0) or the quad-tank RK4 dynamics / measurement (rb.fn_kind 1, nxn = 4, ny = 2).
      * nxl = rb.nxl <= 8, ny <= 2; dynamics_density = R1n (must be Gaussian), linear_noise = R1l, linear_initial = d0l. */
     LLPF_MODEL_RB_BILINEAR     = 3
@@ -203,7 +203,9 @@ int  llpf_aux_run(llpf_filter* f, const double* U, const double* Y, int64_t T, i
  * are [xn; xl].  An != 0 needs nxn == 1 (the right division by Nt, :212, is implemented for a scalar). */
 int  llpf_rb_get_covariance(llpf_filter* f, double* R /* nxl*nxl row-major: x[1].R */);
 /* LLPF_MODEL_RB_BILINEAR: the per-particle Kalman state (fields xl, R of every RBParticle, reference src/rbpf.jl:1-5);
- * xl [N][nxl], R [N][nxl][nxl] row-major, either may be NULL.  llpf_get_particles returns the xn part. */
+ * xl [N][nxl], R [N][nxl][nxl] row-major, either may be NULL.  For this model the particle of llpf_get_particles /
+ * llpf_set_particles / llpf_weighted_mean and of the x_hist / xmean outputs of llpf_run is [xn; xl] (nxn + nxl values: an
+ * RBParticle indexes like that vector, :24-30). */
 int  llpf_rb_get_linear_state(llpf_filter* f, double* xl, double* R);
 
 /* ---- particle smoother ---------------------------------------------------------------------------------------

@@ -142,6 +142,8 @@ class FilterHandle:
         check(self.L.llpf_create(C.byref(cfg), C.byref(self.h)))
         self.N = int(cfg.n_particles)
         self.nx, self.nu, self.ny = cfg.model.nx, cfg.model.nu, cfg.model.ny
+        if cfg.model.model_id == S.MODEL_RB_BILINEAR:      # particles, history and means are [xn; xl] (RBParticle, reference src/rbpf.jl:24-30)
+            self.nx = cfg.model.nx + cfg.model.rb.nxl
 
     def close(self):
         if getattr(self, "h", None):

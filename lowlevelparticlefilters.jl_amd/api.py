@@ -287,6 +287,8 @@ class RBPF(_AbstractParticleFilter):
         else:
             self._model = S.make_rb_model(dynamics.A, dynamics.B, An, kf.A, kf.B, Gn, kf.C, as_g(R1n), kf.R1, as_g(R2), as_g(d0n), as_g(kf.d0), Ts)
         self.nx, self.nu, self.ny = self._model.nx, self._model.nu, self._model.ny
+        if self.per_particle_covariance:
+            self.nx = self._model.nx + self._model.rb.nxl      # particles are [xn; xl]
         self._cfg = S.make_config(self._model, N, self.kind, S.RESAMPLE_SYSTEMATIC, resample_threshold, self.rng, device)
         self._h = _capi.FilterHandle(self._cfg)
         self.N = int(N)
@@ -498,8 +500,6 @@ def mean_trajectory(pf, u=None, y=None, p=None):
 
 # accessors — reference src/PFtypes.jl:296-334
 def particles(pf):
-    if getattr(pf, "per_particle_covariance", False):       # RBParticle indexes like [xn; xl] (reference src/rbpf.jl:24-30)
-        return np.concatenate([pf._h.particles(), pf._h.rb_linear_state()[0]], axis=1)
     return pf._h.particles()
 
 

@@ -216,8 +216,8 @@ int llpf_set_particles(llpf_filter* f, const double* src) {
     NEEDF(f);
     Bank& b = f->bank;
     CHK(use_device(b));
-    HIPC(hipMemcpyAsync(b.d_tmp, src, sizeof(double) * b.N * b.nx, hipMemcpyHostToDevice, b.stream));
-    HIPC(launch_aos2soa(b.dev(), b.d_tmp, b.d_x[b.cur], b.stream));
+    HIPC(hipMemcpyAsync(b.d_tmp, src, sizeof(double) * b.N * b.nxp, hipMemcpyHostToDevice, b.stream));
+    HIPC(launch_aos2soa(b.devp(), b.d_tmp, b.d_x[b.cur], b.stream));
     HIPC(hipStreamSynchronize(b.stream));
     return LLPF_OK;
 }
@@ -272,8 +272,8 @@ int llpf_weighted_mean(llpf_filter* f, double* xh) {
     NEEDF(f);
     Bank& b = f->bank;
     CHK(use_device(b));
-    HIPC(launch_wmean(b.dev(), b.d_tmp, b.stream));
-    HIPC(hipMemcpyAsync(xh, b.d_tmp, sizeof(double) * b.nx, hipMemcpyDeviceToHost, b.stream));
+    CHK(bank_wmean(b, b.d_tmp));
+    HIPC(hipMemcpyAsync(xh, b.d_tmp, sizeof(double) * b.nxp, hipMemcpyDeviceToHost, b.stream));
     HIPC(hipStreamSynchronize(b.stream));
     return LLPF_OK;
 }

@@ -2,9 +2,9 @@
 // ---- accessors ----------------------------------------------------------------------------------
 static int bank_get_particles(Bank& b, double* dst) {
     CHK(use_device(b));
-    BankDev d = b.dev();
+    BankDev d = b.devp();
     HIPC(launch_soa2aos(d, b.d_x[b.cur], b.d_tmp, b.stream));
-    HIPC(hipMemcpyAsync(dst, b.d_tmp, sizeof(double) * (size_t)b.F * b.N * b.nx, hipMemcpyDeviceToHost, b.stream));
+    HIPC(hipMemcpyAsync(dst, b.d_tmp, sizeof(double) * (size_t)b.F * b.N * b.nxp, hipMemcpyDeviceToHost, b.stream));
     HIPC(hipStreamSynchronize(b.stream));
     return LLPF_OK;
 }

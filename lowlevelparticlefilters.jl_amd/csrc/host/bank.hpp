@@ -8,6 +8,7 @@ struct Bank {
     int64_t N = 0, Ns = 0;
     int nx = 0, nu = 0, ny = 0, P1 = 0, P2 = 0;
     int xrows = 0;                   // rows of a particle plane: nx, or xn + xl + packed R for LLPF_MODEL_RB_BILINEAR
+    int nxp = 0;                     // dimension of a particle as the accessors see it: nx, or nxn + nxl for LLPF_MODEL_RB_BILINEAR (RBParticle indexes like [xn; xl])
     int device = 0;
     hipStream_t stream = nullptr;
     ModelD* d_models = nullptr;
@@ -89,6 +90,8 @@ struct Bank {
         b.pad0 = (cfg.model.model_id == LLPF_MODEL_RB_BILINEAR) ? (cfg.model.rb.nxl | (cfg.model.rb.fn_kind << 8)) : 0;
         return b;
     }
+    // for the layout conversions of the accessors: the first nxp rows of the plane are the particle [xn; xl]
+    BankDev devp() const { BankDev b = dev(); b.nx = nxp; return b; }
 };
 
 // Philox step argument of a launch issued now (relative to the base the device adds)
@@ -247,6 +250,7 @@ static int bank_create(const llpf_config* cfg, const llpf_model* models, int F, 
     b.Ns = (b.N + TILE - 1) / TILE * TILE;
     b.nx = m0.nx; b.nu = m0.nu; b.ny = m0.ny;
     b.xrows = (m0.model_id == LLPF_MODEL_RB_BILINEAR) ? rbfull_rows(m0.nx, m0.rb.nxl) : b.nx;
+    b.nxp = (m0.model_id == LLPF_MODEL_RB_BILINEAR) ? m0.nx + m0.rb.nxl : b.nx;
     b.P1 = (int)(b.Ns / STEP_TILE);
     b.P2 = (int)(b.Ns / TILE);
     b.device = cfg->device;
@@ -290,7 +294,7 @@ static int bank_create(const llpf_config* cfg, const llpf_model* models, int F, 
     }
     HIPC(hipMemsetAsync(b.d_rtile, 0, sizeof(uint64_t) * (size_t)F * 2 * b.P2, b.stream));
     HIPC(hipMalloc(&b.d_uy, sizeof(double) * 4 * MAXD));
-    HIPC(hipMalloc(&b.d_tmp, sizeof(double) * (size_t)F * b.N * (b.nx > 1 ? b.nx : 1) + 64));
+    HIPC(hipMalloc(&b.d_tmp, sizeof(double) * (size_t)F * b.N * (b.nxp > 1 ? b.nxp : 1) + 64));
     HIPC(hipMemsetAsync(b.d_x[0], 0, sizeof(double) * FN * b.xrows, b.stream));
     HIPC(hipMemsetAsync(b.d_x[1], 0, sizeof(double) * FN * b.xrows, b.stream));
     HIPC(hipMemsetAsync(b.d_anc, 0, sizeof(int32_t) * FN, b.stream));
@@ -310,6 +314,16 @@ static int bank_create(const llpf_config* cfg, const llpf_model* models, int F, 
     set_keys(b, h, cfg->seed);
     CHK(scal_upload(b, h));
     return bank_init_particles(b, false);
+}
+
+// weighted_mean of the particle as the accessors see it (nxp values per filter), MAXD rows per launch
+static int bank_wmean(Bank& b, double* d_out) {
+    for (int r0 = 0; r0 < b.nxp; r0 += MAXD) {
+        BankDev d = b.dev();
+        if (b.nxp != b.nx) { d.xcur = b.d_x[b.cur] + (size_t)r0 * b.Ns; d.nx = std::min(MAXD, b.nxp - r0); }   // single filter
+        HIPC(launch_wmean(d, d_out + r0, b.stream));
+    }
+    return LLPF_OK;
 }
 
 static int check_status(Bank& b, std::vector<FilterScal>& h) {

@@ -24,7 +24,7 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
     if (b.nu > 0) HIPC(hipMemcpyAsync(b.d_U, U, sizeof(double) * T * b.nu, hipMemcpyHostToDevice, b.stream));
     HIPC(hipMemcpyAsync(b.d_Y, Y, sizeof(double) * T * b.ny, hipMemcpyHostToDevice, b.stream));
     if (ll_steps) CHK(ensure(&b.d_ll_steps, &b.cap_ll, (size_t)T * b.F));
-    if (xmean) CHK(ensure(&b.d_xmean, &b.cap_xm, (size_t)T * b.F * b.nx));
+    if (xmean) CHK(ensure(&b.d_xmean, &b.cap_xm, (size_t)T * b.F * b.nxp));
     {   // zero the running log-likelihood and remember the resample counter
         std::vector<FilterScal> h;
         CHK(scal_download(b, h));
@@ -35,7 +35,10 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
         CHK(scal_upload(b, h));
     }
     const double Ts = b.cfg.model.Ts;
-    const int want_xm = xmean ? 1 : 0;
+    // weighted means come out of the normalise / weighting kernels (partial sums over the nx rows they read anyway); the
+    // model with per-particle covariance takes them from a k_wmean launch per step over its [xn; xl] rows instead
+    const int want_xm = (xmean && !is_rbfull(b)) ? 1 : 0;
+    const bool xm_launch = xmean && is_rbfull(b);
     const int K = llpf_qbits(b.N);
     const int ne2 = need_e2(b);
     const bool hist = x_hist || w_hist || we_hist;
@@ -101,7 +104,7 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
         ra.parity = head_slot(k); ra.step = rel_step(b); ra.M = (int32_t)b.N; ra.anc_out = b.d_anc;
         ra.accumulate = 1; ra.want_xmean = want_xm; ra.u_from_scal = 1;
         ra.ll_steps = ll_steps ? b.d_ll_steps : nullptr;
-        ra.xmean = xmean ? b.d_xmean : nullptr;
+        ra.xmean = want_xm ? b.d_xmean : nullptr;
         ra.k = k; ra.row = k; ra.fast_head = fast ? 1 : 0;
         ra.ablate = abl_env ? atoi(abl_env) : 0;
         return ra;
@@ -123,13 +126,13 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
     // balanced form, no host round trip per step) and copied out in bulk at the end; beyond 16 GB of history the
     // step-synchronous loop below copies row by row instead.
     const size_t hist_rows = (size_t)T * b.N;
-    const size_t hist_doubles = (x_hist ? hist_rows * b.nx : 0) + (w_hist ? hist_rows : 0) + (we_hist ? hist_rows : 0);
+    const size_t hist_doubles = (x_hist ? hist_rows * b.nxp : 0) + (w_hist ? hist_rows : 0) + (we_hist ? hist_rows : 0);
     const bool hist_dev = hist && hist_doubles * sizeof(double) <= ((size_t)16 << 30);
     double *dx_hist = nullptr, *dw_hist = nullptr, *dwe_hist = nullptr;
     if (hist_dev) {
         CHK(ensure(&b.d_hist, &b.cap_hist, hist_doubles));
         double* p = b.d_hist;
-        if (x_hist) { dx_hist = p; p += hist_rows * b.nx; }
+        if (x_hist) { dx_hist = p; p += hist_rows * b.nxp; }
         if (w_hist) { dw_hist = p; p += hist_rows; }
         if (we_hist) { dwe_hist = p; p += hist_rows; }
     }
@@ -156,9 +159,10 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
                 ProfScope ps(b, LLPF_PROF_RESAMPLE);
                 HIPC(launch_resample(d, ra, b.stream));
             }
+            if (xm_launch) { ProfScope ps(b, LLPF_PROF_OTHER); CHK(bank_wmean(b, b.d_xmean + (size_t)k * b.nxp)); }
             if (hist_dev) {   // x[:,t] .= particles(pf); w[:,t] .= weights(pf); we[:,t] .= expweights(pf)  (filtering.jl:357-359)
                 ProfScope ps(b, LLPF_PROF_OTHER);
-                if (dx_hist) HIPC(launch_soa2aos(d, b.d_x[b.cur], dx_hist + (size_t)k * b.N * b.nx, b.stream));
+                if (dx_hist) HIPC(launch_soa2aos(b.devp(), b.d_x[b.cur], dx_hist + (size_t)k * b.N * b.nxp, b.stream));
                 if (dw_hist || dwe_hist) HIPC(launch_materialize(d, dw_hist ? dw_hist + (size_t)k * b.N : nullptr, dwe_hist ? dwe_hist + (size_t)k * b.N : nullptr, b.stream));
             }
             ProfScope ps(b, LLPF_PROF_PROPAGATE);
@@ -211,7 +215,7 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
     if (use_graph) {
         Bank::RunGraph key{};
         key.T = T; key.t_index0 = t_index0; key.par0 = par0; key.cur0 = cur0; key.qcur0 = qcur0;
-        key.flags = (merged ? 1 : 0) | (unfused ? 2 : 0) | (want_xm ? 4 : 0) | (ll_steps ? 8 : 0) | ((abl_env ? atoi(abl_env) : 0) << 8);
+        key.flags = (merged ? 1 : 0) | (unfused ? 2 : 0) | (want_xm ? 4 : 0) | (ll_steps ? 8 : 0) | (xm_launch ? 16 : 0) | ((abl_env ? atoi(abl_env) : 0) << 8);
         key.np_parity = (int)(np0 & 1u);
         key.dU = b.d_U; key.dY = b.d_Y; key.dll = ll_steps ? b.d_ll_steps : nullptr; key.dxm = xmean ? b.d_xmean : nullptr; key.drb = b.d_rbseq;
         key.yhash = 1469598103934665603ULL;
@@ -262,9 +266,10 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
                 ra.only_fallback = 0;
                 CHK(clear_fallback(b, fl));
             }
+            if (xm_launch) CHK(bank_wmean(b, b.d_xmean + (size_t)k * b.nxp));
             if (x_hist) {
-                HIPC(launch_soa2aos(d, b.d_x[b.cur], b.d_tmp, b.stream));
-                HIPC(hipMemcpyAsync(x_hist + (size_t)k * b.N * b.nx, b.d_tmp, sizeof(double) * b.N * b.nx, hipMemcpyDeviceToHost, b.stream));
+                HIPC(launch_soa2aos(b.devp(), b.d_x[b.cur], b.d_tmp, b.stream));
+                HIPC(hipMemcpyAsync(x_hist + (size_t)k * b.N * b.nxp, b.d_tmp, sizeof(double) * b.N * b.nxp, hipMemcpyDeviceToHost, b.stream));
                 HIPC(hipStreamSynchronize(b.stream));
             }
             if (w_hist) {
@@ -310,12 +315,12 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
     }
     HIPC(hipEventRecord(b.ev_run1, b.stream));
     if (hist_dev) {
-        if (x_hist) HIPC(hipMemcpyAsync(x_hist, dx_hist, sizeof(double) * hist_rows * b.nx, hipMemcpyDeviceToHost, b.stream));
+        if (x_hist) HIPC(hipMemcpyAsync(x_hist, dx_hist, sizeof(double) * hist_rows * b.nxp, hipMemcpyDeviceToHost, b.stream));
         if (w_hist) HIPC(hipMemcpyAsync(w_hist, dw_hist, sizeof(double) * hist_rows, hipMemcpyDeviceToHost, b.stream));
         if (we_hist) HIPC(hipMemcpyAsync(we_hist, dwe_hist, sizeof(double) * hist_rows, hipMemcpyDeviceToHost, b.stream));
     }
     if (ll_steps) HIPC(hipMemcpyAsync(ll_steps, b.d_ll_steps, sizeof(double) * T * b.F, hipMemcpyDeviceToHost, b.stream));
-    if (xmean) HIPC(hipMemcpyAsync(xmean, b.d_xmean, sizeof(double) * T * b.F * b.nx, hipMemcpyDeviceToHost, b.stream));
+    if (xmean) HIPC(hipMemcpyAsync(xmean, b.d_xmean, sizeof(double) * T * b.F * b.nxp, hipMemcpyDeviceToHost, b.stream));
     std::vector<FilterScal> h;
     CHK(scal_download(b, h));
     float ms = 0.f;

@@ -1317,10 +1317,24 @@ int orc_smooth(orc_filter* f, int64_t M, const double* U, int64_t T, const doubl
 }
 
 /* weighted_mean(x, we) — src/filtering.jl:541-549 */
+/* dimension of a particle as the accessors see it: an RBParticle with its own covariance indexes like [xn; xl] (src/rbpf.jl:24-30) */
+static int particle_dim(const orc_filter* f) { return f->rbf.on ? f->nx + f->rbf.nl : f->nx; }
+int orc_particle_dim(const orc_filter* f) { return particle_dim(f); }
+static void copy_particles(const orc_filter* f, double* dst) {
+    if (!f->rbf.on) { memcpy(dst, f->x, 8 * (size_t)f->N * f->nx); return; }
+    const int nn = f->nx, nl = f->rbf.nl, np = nn + nl;
+    for (int64_t i = 0; i < f->N; ++i) {
+        for (int d = 0; d < nn; ++d) dst[i * np + d] = f->x[i * nn + d];
+        for (int d = 0; d < nl; ++d) dst[i * np + nn + d] = f->rbf.xl[i * nl + d];
+    }
+}
 void orc_weighted_mean(const orc_filter* f, double* xh) {
-    for (int d = 0; d < f->nx; ++d) xh[d] = 0.0;
-    for (int64_t i = 0; i < f->N; ++i)
-        for (int d = 0; d < f->nx; ++d) xh[d] += f->x[i * f->nx + d] * f->we[i];
+    const int np = particle_dim(f), nn = f->nx;
+    for (int d = 0; d < np; ++d) xh[d] = 0.0;
+    for (int64_t i = 0; i < f->N; ++i) {
+        for (int d = 0; d < nn; ++d) xh[d] += f->x[i * nn + d] * f->we[i];
+        for (int d = nn; d < np; ++d) xh[d] += f->rbf.xl[i * f->rbf.nl + (d - nn)] * f->we[i];
+    }
 }
 
 /* the loop of forward_trajectory (src/filtering.jl:351-363, t_index0 = 0 after reset!) and of
@@ -1336,8 +1350,8 @@ double orc_run(orc_filter* f, const double* U, const double* Y, int64_t T, doubl
         double lli = orc_correct(f, u, y, ti);
         ll += lli;
         if (ll_steps) ll_steps[k] = lli;
-        if (xmean) orc_weighted_mean(f, xmean + k * f->nx);
-        if (x_hist) memcpy(x_hist + (size_t)k * N * f->nx, f->x, 8 * N * f->nx);
+        if (xmean) orc_weighted_mean(f, xmean + k * particle_dim(f));
+        if (x_hist) copy_particles(f, x_hist + (size_t)k * N * particle_dim(f));
         if (w_hist) memcpy(w_hist + (size_t)k * N, f->w, 8 * N);
         if (we_hist) memcpy(we_hist + (size_t)k * N, f->we, 8 * N);
         orc_predict(f, u, ti);
@@ -1347,12 +1361,20 @@ double orc_run(orc_filter* f, const double* U, const double* Y, int64_t T, doubl
 
 int64_t orc_num_particles(const orc_filter* f) { return f->N; }
 int64_t orc_index(const orc_filter* f) { return f->t; }
-void orc_get_particles(const orc_filter* f, double* dst) { memcpy(dst, f->x, 8 * (size_t)f->N * f->nx); }
+void orc_get_particles(const orc_filter* f, double* dst) { copy_particles(f, dst); }
 void orc_get_weights(const orc_filter* f, double* dst) { memcpy(dst, f->w, 8 * (size_t)f->N); }
 void orc_get_expweights(const orc_filter* f, double* dst) { memcpy(dst, f->we, 8 * (size_t)f->N); }
 void orc_get_ancestors(const orc_filter* f, int64_t* dst) { memcpy(dst, f->j, 8 * (size_t)f->N); }
 void orc_get_bins(const orc_filter* f, double* dst) { memcpy(dst, f->bins, 8 * (size_t)f->N); }
 void orc_set_particles(orc_filter* f, const double* src) {
+    if (f->rbf.on) {
+        const int nn = f->nx, nl = f->rbf.nl, np = nn + nl;
+        for (int64_t i = 0; i < f->N; ++i) {
+            for (int d = 0; d < nn; ++d) { f->x[i * nn + d] = src[i * np + d]; f->xprev[i * nn + d] = src[i * np + d]; }
+            for (int d = 0; d < nl; ++d) { f->rbf.xl[i * nl + d] = src[i * np + nn + d]; f->rbf.xlprev[i * nl + d] = src[i * np + nn + d]; }
+        }
+        return;
+    }
     memcpy(f->x, src, 8 * (size_t)f->N * f->nx);
     memcpy(f->xprev, src, 8 * (size_t)f->N * f->nx);
 }

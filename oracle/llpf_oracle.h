@@ -70,6 +70,7 @@ int    orc_smooth(orc_filter* f, int64_t M, const double* U, int64_t T, const do
 void   orc_rb_get_R(const orc_filter* f, double* R);
 /* RBPF with per-particle covariance (LLPF_MODEL_RB_BILINEAR): xl [N][nxl], R [N][nxl][nxl]; either may be NULL */
 void   orc_rb_get_linear_state(const orc_filter* f, double* xl, double* R);
+int    orc_particle_dim(const orc_filter* f);   /* nx, or nxn + nxl for LLPF_MODEL_RB_BILINEAR: particles / history / means are [xn; xl] */
 
 int64_t orc_num_particles(const orc_filter* f);
 int64_t orc_index(const orc_filter* f);

@@ -143,6 +143,8 @@ class OracleFilter:
             raise ValueError("orc_create failed (bad covariance?)")
         self.N = cfg.n_particles
         self.nx, self.nu, self.ny = cfg.model.nx, cfg.model.nu, cfg.model.ny
+        if cfg.model.model_id == S.MODEL_RB_BILINEAR:      # particles, history and means are [xn; xl] (RBParticle, reference src/rbpf.jl:24-30)
+            self.nx = cfg.model.nx + cfg.model.rb.nxl
 
     def __del__(self):
         if getattr(self, "h", None):

@@ -61,6 +61,12 @@ def test_rbfull_bit_exact(name, strategy):
     r2 = g2.run(U, Y, 0.0, ll_steps=True, xmean=True)
     assert _same_bits(r2["ll_steps"], ro["ll_steps"])
     _compare_linear_state(g2, o)
+    # particles / history / means are [xn; xl]; the weighted mean is a block-tree sum (tolerance, never fed back)
+    nn, nl = model.nx, model.rb.nxl
+    assert rg["x"].shape == (T, N, nn + nl) and r2["xmean"].shape == (T, nn + nl)
+    assert np.allclose(r2["xmean"], np.einsum("tnd,tn->td", ro["x"], ro["we"]), rtol=1e-11, atol=1e-13)
+    assert _same_bits(g.particles()[:, nn:], g.rb_linear_state()[0])
+    assert np.allclose(g.weighted_mean(), o.weighted_mean(), rtol=1e-11, atol=1e-13)
     # single steps
     g3 = _capi.FilterHandle(cfg); o3 = ob.OracleFilter(cfg, ob.ORDER_DEVICE)
     g3.reset(); o3.reset()
@@ -107,7 +113,11 @@ def test_rbfull_api_and_errors():
     o.reset()
     sol = llpf_amd.forward_trajectory(pf, U, Y)
     assert sol.ll == o.run(U, Y, 0.0)["ll"]
-    assert llpf_amd.particles(pf).shape == (2000, 4)
+    assert llpf_amd.particles(pf).shape == (2000, 4) and sol.x.shape == (30, 2000, 4)
+    assert llpf_amd.mean_trajectory(sol).shape == (30, 4)        # weighted means of [xn; xl]: the linear-state estimate
+    x0 = llpf_amd.particles(pf)
+    pf._h.set_particles(x0 * 0.5)                                # both parts of the RBParticle are installed
+    assert np.array_equal(llpf_amd.particles(pf), x0 * 0.5) and np.array_equal(pf.linear_state()[0], x0[:, 2:] * 0.5)
     xl, R = pf.linear_state()
     assert xl.shape == (2000, 2) and R.shape == (2000, 2, 2) and pf.covariance.shape == (2, 2)
     assert np.max(np.abs(R - R[0])) > 1e-6

@@ -28,7 +28,8 @@ def test_constant_coupling_equals_shared_covariance_recursion():
         assert np.max(np.abs(R - R[0])) == 0.0                       # data independent: every particle ends with the same R
         assert np.max(np.abs(R[0] - b.rb_R())) < 1e-14
         xb = b.particles()
-        assert np.max(np.abs(a.particles()[:, 0] - xb[:, 0])) < 1e-12 and np.max(np.abs(xl - xb[:, 1:])) < 1e-12
+        assert a.particles().shape == xb.shape == (400, 3)            # an RBParticle indexes like [xn; xl] in both forms
+        assert np.max(np.abs(a.particles() - xb)) < 1e-12 and np.max(np.abs(xl - xb[:, 1:])) < 1e-12
 
 
 def test_all_linear_matches_kalman_filter():
@@ -100,3 +101,20 @@ def test_single_steps_and_missing_measurement():
         assert a.update(U[k], Y[k], (1.0 + k) * 1.0) == ll_steps[k]
     assert np.array_equal(a.particles(), b.particles())
     assert np.array_equal(a.rb_linear_state()[1], b.rb_linear_state()[1])
+
+
+def test_particles_history_and_means_are_xn_xl():
+    """particles(pf), the x history of forward_trajectory and weighted_mean carry [xn; xl] (RBParticle, src/rbpf.jl:24-30);
+    set_particles installs both parts."""
+    m, _ = M.linear_case(2, 2, 2, seed=6)
+    U, Y = M.simulate_io(m, 8)
+    o = ob.OracleFilter(_cfg(m, 200), ob.ORDER_REFERENCE)
+    o.reset()
+    r = o.run(U, Y, 0.0, xmean=True, history=True)
+    assert r["x"].shape == (8, 200, 4) and r["xmean"].shape == (8, 4)
+    assert np.allclose(r["xmean"], np.einsum("tnd,tn->td", r["x"], r["we"]), rtol=1e-12, atol=1e-14)
+    x = o.particles()
+    assert np.array_equal(x[:, 2:], o.rb_linear_state()[0])
+    o.set_particles(x + 1.0)
+    assert np.array_equal(o.particles(), x + 1.0) and np.array_equal(o.rb_linear_state()[0], x[:, 2:] + 1.0)
+    assert np.allclose(o.weighted_mean(), (o.particles() * o.expweights()[:, None]).sum(0))
