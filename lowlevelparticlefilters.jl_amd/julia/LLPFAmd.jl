@@ -132,7 +132,8 @@ function GPUParticleFilter(N::Integer, model, df::GaussianSpec, dg::GaussianSpec
                       resample_threshold, UInt64(seed), cm))
     h = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:llpf_create, LIB), Cint, (Ref{CConfig}, Ref{Ptr{Cvoid}}), cfg, h))
-    pf = GPUParticleFilter(h[], N, cm.nx, cm.nu, cm.ny, Ts, resample_threshold)
+    nxp = cm.model_id == 3 ? cm.nx + cm.rb.nxl : cm.nx         # RBBilinearModel: particles, history and means are [xn; xl]
+    pf = GPUParticleFilter(h[], N, nxp, cm.nu, cm.ny, Ts, resample_threshold)
     finalizer(p -> ccall((:llpf_destroy, LIB), Cint, (Ptr{Cvoid},), p.h), pf)
     pf
 end
