@@ -144,7 +144,7 @@ def main_bank(args, rank, world, dev):
     _, U, Y = M.simulate_lg(M.lg_test_model(0.1), T, seed=1)
     cfg = S.make_config(models[0], N, S.PARTICLE_FILTER, S.RESAMPLE_SYSTEMATIC, thr, 5 + 100000 * rank, dev)
     bank = _capi.BankHandle(cfg, models)
-    device = torch.device("cuda", dev)
+    device = args.coll_device
 
     def one_pass():
         bank.reset()
@@ -225,6 +225,9 @@ def main():
     ap.add_argument("--threshold", type=float, default=None, help="resample_threshold override")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=None, help="timesteps of the CPU baseline sample")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL) is the measured path; gloo only exercises the multi-rank logic on a box with fewer GPUs than "
+                         "ranks (collectives on CPU tensors, ranks share devices)")
     args = ap.parse_args()
 
     import torch
@@ -233,10 +236,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    dev = local_rank if world > 1 else 0
+    dev = 0
+    if world > 1 and args.dist_backend == "nccl":
+        dev = local_rank
+        torch.cuda.set_device(dev)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev))
+    elif world > 1:
+        dev = local_rank % torch.cuda.device_count()
+        torch.cuda.set_device(dev)
+        dist.init_process_group(backend="gloo")
+    args.coll_device = torch.device("cuda", dev) if args.dist_backend == "nccl" else torch.device("cpu")
 
     if args.workload == "bank":
         return main_bank(args, rank, world, dev)
@@ -252,7 +261,7 @@ def main():
     N = args.particles
     cfg = S.make_config(model, N, kind, S.RESAMPLE_SYSTEMATIC, thr, 1000 + rank, dev)
     pf = _capi.FilterHandle(cfg)
-    ll_dev = torch.zeros(1, dtype=torch.float64, device="cuda:%d" % dev)
+    ll_dev = torch.zeros(1, dtype=torch.float64, device=args.coll_device)
 
     aux = args.workload == "aux"
 
@@ -286,7 +295,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda:%d" % dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=args.coll_device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     resamples = pf.resample_count()
