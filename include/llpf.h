@@ -252,7 +252,7 @@ int  llpf_resample_uniforms(int32_t strategy, int64_t m, uint64_t seed, uint32_t
 /* n_filters filters that share N, model_id, dimensions, strategy and threshold but have their own
  * model parameters and RNG key (seed + filter index): the `map(svec) do s ... loglik(pfs,u,y)`
  * sweep of the reference (test/runtests.jl:412-417, src/smoothing.jl:335-347), batched into
- * single launches over (tile, filter). */
+ * single launches over (tile, filter).  models == NULL: every filter uses base->model (Monte-Carlo replicas). */
 int  llpf_bank_create(const llpf_config* base, const llpf_model* models, int32_t n_filters, llpf_bank** out);
 int  llpf_bank_destroy(llpf_bank* b);
 int  llpf_bank_reset(llpf_bank* b);
@@ -260,6 +260,11 @@ int  llpf_bank_seed(llpf_bank* b, uint64_t seed);
 /* as llpf_run, shared U / Y, ll_total has n_filters entries; ll_steps (optional) is [T * n_filters] */
 int  llpf_bank_run(llpf_bank* b, const double* U, const double* Y, int64_t T, double t_index0,
                    double* ll_total, double* ll_steps);
+/* as llpf_bank_run with inputs of its own for every filter: U [n_filters][T][nu], Y [n_filters][T][ny] (e.g. the independent
+ * Monte-Carlo runs of the reference's benchmark loop, examples/example_lineargaussian.jl:282-316, as one bank); xmean
+ * (optional) is [T][n_filters][nx], the weighted mean after every correct!.  Missing measurements must coincide. */
+int  llpf_bank_run_multi(llpf_bank* b, const double* U, const double* Y, int64_t T, double t_index0,
+                         double* ll_total, double* ll_steps, double* xmean);
 /* as llpf_aux_run for every filter of the bank (the ML sweep over AuxiliaryParticleFilters, test/runtests.jl:419-423) */
 int  llpf_bank_aux_run(llpf_bank* b, const double* U, const double* Y, int64_t T, int32_t mode,
                        double* ll_total, double* ll_steps);

@@ -59,6 +59,7 @@ SYMBOLS = {
     "llpf_bank_reset": [_vp],
     "llpf_bank_seed": [_vp, C.c_uint64],
     "llpf_bank_run": [_vp, _dp, _dp, C.c_int64, C.c_double, _dp, _dp],
+    "llpf_bank_run_multi": [_vp, _dp, _dp, C.c_int64, C.c_double, _dp, _dp, _dp],
     "llpf_set_profiling": [_vp, C.c_int32],
     "llpf_get_profile": [_vp, _dp, _ip],
     "llpf_bank_set_profiling": [_vp, C.c_int32],
@@ -371,16 +372,24 @@ class FilterHandle:
 class BankHandle:
     """RAII wrapper of an `llpf_bank*` (many independent filters on one device)."""
 
-    def __init__(self, base_cfg, models):
+    def __init__(self, base_cfg, models=None, n_filters=None):
+        """models: one llpf_model per filter, or None with n_filters: every filter uses base_cfg.model (Monte-Carlo replicas)."""
         self.L = lib()
-        self.F = len(models)
-        arr = (S.Model * self.F)(*models)
-        self._models = arr
         self.cfg = base_cfg
         self.h = _vp()
-        check(self.L.llpf_bank_create(C.byref(base_cfg), arr, self.F, C.byref(self.h)))
+        if models is None:
+            self.F = int(n_filters)
+            self._models = None
+            check(self.L.llpf_bank_create(C.byref(base_cfg), None, self.F, C.byref(self.h)))
+            m0 = base_cfg.model
+        else:
+            self.F = len(models)
+            arr = (S.Model * self.F)(*models)
+            self._models = arr
+            check(self.L.llpf_bank_create(C.byref(base_cfg), arr, self.F, C.byref(self.h)))
+            m0 = models[0]
         self.N = int(base_cfg.n_particles)
-        self.nx, self.nu, self.ny = models[0].nx, models[0].nu, models[0].ny
+        self.nx, self.nu, self.ny = m0.nx, m0.nu, m0.ny
 
     def close(self):
         if getattr(self, "h", None):
@@ -407,6 +416,17 @@ class BankHandle:
         lls = np.zeros((T, self.F)) if ll_steps else None
         check(self.L.llpf_bank_run(self.h, dptr(U), dptr(Y), T, float(t_index0), dptr(ll), dptr(lls)))
         return {"ll": ll, "ll_steps": lls}
+
+    def run_multi(self, U, Y, t_index0=0.0, ll_steps=False, xmean=False):
+        """every filter runs on inputs of its own: U [F, T, nu], Y [F, T, ny]; xmean -> [T, F, nx] weighted means after correct!"""
+        Y = f64(Y).reshape(self.F, -1, self.ny)
+        T = Y.shape[1]
+        U = f64(U).reshape(self.F, T, self.nu) if self.nu else None
+        ll = np.zeros(self.F)
+        lls = np.zeros((T, self.F)) if ll_steps else None
+        xm = np.zeros((T, self.F, self.nx)) if xmean else None
+        check(self.L.llpf_bank_run_multi(self.h, dptr(U), dptr(Y), T, float(t_index0), dptr(ll), dptr(lls), dptr(xm)))
+        return {"ll": ll, "ll_steps": lls, "xmean": xm}
 
     def run_aux(self, U, Y, mode=1, ll_steps=False):
         Y = f64(Y).reshape(-1, self.ny)

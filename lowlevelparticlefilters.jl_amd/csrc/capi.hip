@@ -296,7 +296,7 @@ int llpf_get_profile(llpf_filter* f, double* ms, int64_t* n) { NEEDF(f); return 
 int llpf_bank_create(const llpf_config* base, const llpf_model* models, int32_t n_filters, llpf_bank** out) {
     if (!out) return fail(LLPF_ERR_ARG, "null out pointer");
     *out = nullptr;
-    if (!models) return fail(LLPF_ERR_ARG, "null models");
+    // models == NULL: every filter uses base->model (Monte-Carlo replicas; seeds differ: seed + k)
     llpf_bank* b = new (std::nothrow) llpf_bank();
     if (!b) return fail(LLPF_ERR_ALLOC, "out of host memory");
     int rc = bank_create(base, models, n_filters, b->bank);
@@ -316,6 +316,11 @@ int llpf_bank_run(llpf_bank* b, const double* U, const double* Y, int64_t T, dou
                   double* ll_total, double* ll_steps) {
     NEEDF(b);
     return bank_run(b->bank, U, Y, T, t_index0, ll_total, ll_steps, nullptr, nullptr, nullptr, nullptr);
+}
+int llpf_bank_run_multi(llpf_bank* b, const double* U, const double* Y, int64_t T, double t_index0,
+                        double* ll_total, double* ll_steps, double* xmean) {
+    NEEDF(b);
+    return bank_run(b->bank, U, Y, T, t_index0, ll_total, ll_steps, xmean, nullptr, nullptr, nullptr, true);
 }
 int llpf_bank_set_profiling(llpf_bank* b, int32_t on) { NEEDF(b); return set_prof(b->bank, on); }
 int llpf_bank_get_profile(llpf_bank* b, double* ms, int64_t* n) { NEEDF(b); return get_prof(b->bank, ms, n); }

@@ -184,6 +184,8 @@ struct StepArgs {
     int32_t aux;           // second half of the AuxiliaryParticleFilter predict! (k_resprop<AUX>): 1 = y1 missing, 2 = y1 present
     const RBStep* rb_corr; // LLPF_MODEL_RB_LINEAR: [F] parameters of the weighting (correct!) of this launch
     const RBStep* rb_pred; // LLPF_MODEL_RB_LINEAR: [F] parameters of the propagate (predict!) of this launch
+    int32_t u_stride;      // doubles between the u / y of consecutive filters of a bank; 0: all filters share one u / y
+    int32_t y_stride;
 };
 
 enum { RES_FINALIZE = 1, RES_RESAMPLE = 2 };
@@ -227,6 +229,8 @@ hipError_t launch_max(const BankDev& b, int parity, hipStream_t s);           //
 hipError_t launch_norm(const BankDev& b, int parity, int want_xmean, int need_e2, uint32_t step, int only_fallback, int bound, int64_t kstep, hipStream_t s);
 hipError_t launch_ess(const BankDev& b, hipStream_t s);   // on-demand sum e^2 / ESS of the current weights (accessor path)
 hipError_t launch_post_predict(const BankDev& b, hipStream_t s);
+// failed bound test: zero the exp-sums of `slot` (mode 0) / clear the flags (mode 1) of the filters that asked for the exact form
+hipError_t launch_fb_clear(const BankDev& b, int slot, int mode, hipStream_t s);
 hipError_t launch_resample(const BankDev& b, const ResArgs& a, hipStream_t s);
 // fused finalize + resample + propagate [+ weight]: one launch for predict!(u_k) and the weighting of correct!(u_{k+1}, y_{k+1})
 hipError_t launch_resprop(const BankDev& b, const ResArgs& a, const StepArgs& st, int weight, hipStream_t s);

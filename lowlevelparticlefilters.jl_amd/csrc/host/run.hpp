@@ -10,19 +10,40 @@ static int ensure(double** p, size_t* cap, size_t n) {
     return LLPF_OK;
 }
 
+// `multi`: every filter of the bank has its own inputs, U [F][T][nu] and Y [F][T][ny] (the Monte-Carlo loops of the
+// reference's own benchmark, examples/example_lineargaussian.jl:282-316, as one bank); missing measurements must coincide.
 static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double t_index0,
                     double* ll_total /* [F] */, double* ll_steps /* [T][F] */, double* xmean /* [T][F][nx] */,
-                    double* x_hist, double* w_hist, double* we_hist) {
+                    double* x_hist, double* w_hist, double* we_hist, bool multi = false) {
     CHK(use_device(b));
     if (T < 1) return fail(LLPF_ERR_ARG, "T must be >= 1");
     if (!Y) return fail(LLPF_ERR_ARG, "Y is null");
     if (b.nu > 0 && !U) return fail(LLPF_ERR_ARG, "U is null");
     if ((x_hist || w_hist || we_hist) && b.F != 1) return fail(LLPF_ERR_ARG, "history outputs need a single filter");
     b.aux_pending = false; b.we_is_lambda = false;
-    CHK(ensure(&b.d_U, &b.capU, (size_t)T * (b.nu > 0 ? b.nu : 1)));
-    CHK(ensure(&b.d_Y, &b.capY, (size_t)T * b.ny));
-    if (b.nu > 0) HIPC(hipMemcpyAsync(b.d_U, U, sizeof(double) * T * b.nu, hipMemcpyHostToDevice, b.stream));
-    HIPC(hipMemcpyAsync(b.d_Y, Y, sizeof(double) * T * b.ny, hipMemcpyHostToDevice, b.stream));
+    const int FM = multi ? b.F : 1;                      // input sets on the device, laid out [T][FM][nu | ny]
+    CHK(ensure(&b.d_U, &b.capU, (size_t)T * FM * (b.nu > 0 ? b.nu : 1)));
+    CHK(ensure(&b.d_Y, &b.capY, (size_t)T * FM * b.ny));
+    std::vector<double> stageU, stageY;
+    if (multi) {
+        if (is_rb(b)) return fail(LLPF_ERR_ARG, "per-filter inputs are not provided for the Rao-Blackwellized model");
+        stageY.resize((size_t)T * FM * b.ny);
+        for (int f = 0; f < FM; ++f)
+            for (int64_t k = 0; k < T; ++k) {
+                const double* src = Y + ((size_t)f * T + k) * b.ny;
+                if ((src[0] != src[0]) != (Y[(size_t)k * b.ny] != Y[(size_t)k * b.ny])) return fail(LLPF_ERR_ARG, "missing measurements must coincide across the filters of a bank");
+                for (int i = 0; i < b.ny; ++i) stageY[((size_t)k * FM + f) * b.ny + i] = src[i];
+            }
+        if (b.nu > 0) {
+            stageU.resize((size_t)T * FM * b.nu);
+            for (int f = 0; f < FM; ++f)
+                for (int64_t k = 0; k < T; ++k)
+                    for (int i = 0; i < b.nu; ++i) stageU[((size_t)k * FM + f) * b.nu + i] = U[((size_t)f * T + k) * b.nu + i];
+        }
+    }
+    if (b.nu > 0) HIPC(hipMemcpyAsync(b.d_U, multi ? stageU.data() : U, sizeof(double) * T * FM * b.nu, hipMemcpyHostToDevice, b.stream));
+    HIPC(hipMemcpyAsync(b.d_Y, multi ? stageY.data() : Y, sizeof(double) * T * FM * b.ny, hipMemcpyHostToDevice, b.stream));
+    if (multi) HIPC(hipStreamSynchronize(b.stream));     // the staging vectors are pageable host memory
     if (ll_steps) CHK(ensure(&b.d_ll_steps, &b.cap_ll, (size_t)T * b.F));
     if (xmean) CHK(ensure(&b.d_xmean, &b.cap_xm, (size_t)T * b.F * b.nxp));
     {   // zero the running log-likelihood and remember the resample counter
@@ -111,14 +132,15 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
     };
     auto step_args = [&](int64_t k) {
         StepArgs st{};
-        st.u = b.nu > 0 ? b.d_U + k * b.nu : nullptr;
+        st.u = b.nu > 0 ? b.d_U + k * FM * b.nu : nullptr;
+        st.u_stride = multi ? b.nu : 0; st.y_stride = multi ? b.ny : 0;
         st.t_prop = tk(k);
         st.step = rel_step(b);
         st.parity = b.parity;
         st.need_e2 = ne2; st.K = K; st.k = k; st.next_step = rel_step(b) + 1; st.want_xmean = want_xm; st.accumulate = merged ? 1 : 0;
         if (rbm) { st.rb_pred = b.d_rbseq + (size_t)(2 * k + 1) * b.F; st.rb_corr = b.d_rbseq + (size_t)(2 * k + 2) * b.F; }
         const bool weight = (k + 1 < T);
-        if (weight) { st.y = b.d_Y + (k + 1) * b.ny; st.t_meas = tk(k + 1); st.has_y = has_y(k + 1) ? 1 : 0; }
+        if (weight) { st.y = b.d_Y + (k + 1) * FM * b.ny; st.t_meas = tk(k + 1); st.has_y = has_y(k + 1) ? 1 : 0; }
         else { st.y = nullptr; st.t_meas = tk(k); st.has_y = 0; }
         return st;
     };
@@ -201,7 +223,7 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
         b.cur = cur0; b.qcur = qcur0; b.parity = par0; b.n_predict = np0; b.t_index = ti0;      // the state at entry
         BankDev d = b.dev();
         StepArgs a{};
-        a.u = b.nu > 0 ? b.d_U : nullptr; a.y = b.d_Y; a.t_prop = tk(0); a.t_meas = tk(0); a.step = 0; a.has_y = has_y(0) ? 1 : 0;
+        a.u = b.nu > 0 ? b.d_U : nullptr; a.y = b.d_Y; a.u_stride = multi ? b.nu : 0; a.y_stride = multi ? b.ny : 0; a.t_prop = tk(0); a.t_meas = tk(0); a.step = 0; a.has_y = has_y(0) ? 1 : 0;
         a.parity = par0; a.need_e2 = ne2; a.K = K; a.k = 0; a.next_step = 0; a.want_xmean = want_xm; a.accumulate = merged ? 1 : 0;
         if (rbm) a.rb_corr = b.d_rbseq;
         ProfScope ps(b, LLPF_PROF_PROPAGATE);
@@ -215,7 +237,7 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
     if (use_graph) {
         Bank::RunGraph key{};
         key.T = T; key.t_index0 = t_index0; key.par0 = par0; key.cur0 = cur0; key.qcur0 = qcur0;
-        key.flags = (merged ? 1 : 0) | (unfused ? 2 : 0) | (want_xm ? 4 : 0) | (ll_steps ? 8 : 0) | (xm_launch ? 16 : 0) | ((abl_env ? atoi(abl_env) : 0) << 8);
+        key.flags = (merged ? 1 : 0) | (unfused ? 2 : 0) | (want_xm ? 4 : 0) | (ll_steps ? 8 : 0) | (xm_launch ? 16 : 0) | (multi ? 32 : 0) | ((abl_env ? atoi(abl_env) : 0) << 8);
         key.np_parity = (int)(np0 & 1u);
         key.dU = b.d_U; key.dY = b.d_Y; key.dll = ll_steps ? b.d_ll_steps : nullptr; key.dxm = xmean ? b.d_xmean : nullptr; key.drb = b.d_rbseq;
         key.yhash = 1469598103934665603ULL;
@@ -291,18 +313,24 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
     } else {
         int64_t k0 = 0;
         bool replayed = gexec != nullptr;       // the graph holds all T timesteps; after a failed bound test the rest is enqueued
+        // Optimistic enqueue: all remaining timesteps at once, one poll at the end.  Every launch after a failed bound
+        // test is a no-op, so when tests fail often (banks of many small filters: some filter fails at most steps) the
+        // batch shrinks to a quarter on a failure and doubles again on a clean batch.
+        int64_t batch = T;
         while (k0 < T) {
-            if (!replayed) for (int64_t k = k0; k < T; ++k) CHK(launch_timestep(k, true, 0));
+            const int64_t k1 = replayed ? T : std::min(T, k0 + batch);
+            if (!replayed) for (int64_t k = k0; k < k1; ++k) CHK(launch_timestep(k, true, 0));
             replayed = false;
             std::vector<int> fl;
             int64_t kf;
             CHK(poll_fallback(b, fl, kf));
-            if (fl.empty()) break;
+            if (fl.empty()) { k0 = k1; batch = std::min(T, batch * 2); continue; }
             // step kf of the flagged filters: exact-max normalisation of the same weights, then the step again
             CHK(clear_slot_sums(b, head_slot(kf), fl));
             CHK(launch_timestep(kf, false, 1));
             CHK(clear_fallback(b, fl));
             k0 = kf + 1;
+            batch = std::max<int64_t>(1, std::min(batch, T) / 4);
         }
     }
     at_step(T);

@@ -147,3 +147,20 @@ __global__ void k_post_predict(BankDev b) {
     }
     sc->do_resample = 0;
 }
+
+// host side of a failed bound test, for the filters whose `fallback` flag is set: mode 0 zeroes the exp-sum words of
+// accumulator slot `slot` (the exact-form k_norm accumulates them afresh), mode 1 clears the flags and the run's stop word
+__global__ void k_fb_clear(BankDev b, int slot, int mode) {
+    const int f = blockIdx.x;
+    FilterScal* sc = b.scal + f;
+    if (!sc->fallback) return;
+    if (mode == 0) {
+        uint64_t* acc = b.acc + (size_t)f * ACC_WORDS;
+        const int words[7] = {ACC_S(slot), ACC_S(slot) + 1, ACC_S(slot) + 2, ACC_E2(slot), ACC_E2(slot) + 1, ACC_E2(slot) + 2, ACC_BAD(slot)};
+        for (int i = threadIdx.x; i < 7 * NSHARD * ACC_STRIDE; i += blockDim.x)
+            acc[(size_t)words[i / (NSHARD * ACC_STRIDE)] * NSHARD * ACC_STRIDE + (i % (NSHARD * ACC_STRIDE))] = 0;
+    } else if (threadIdx.x == 0) {
+        sc->fallback = 0;
+    }
+}
+__global__ void k_fb_clear_flag(BankDev b) { if (threadIdx.x < 4) b.bank_flag[threadIdx.x] = 0; }

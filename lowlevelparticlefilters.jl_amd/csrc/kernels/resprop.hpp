@@ -147,10 +147,11 @@ __global__ __launch_bounds__(BLOCK) void k_resprop(BankDev b, const ModelD* __re
 #define LLPF_STAMP(i) if (a.dbg && threadIdx.x == 0 && f == 0) a.dbg[(size_t)tile * 8 + (i)] = wall_clock64()
     LLPF_STAMP(0);
     Model model;                                       // particle-independent terms: their loads overlap the head's
-    model.prepare(md, st.u, st.t_prop);
+    model.prepare(md, st.u + (size_t)f * st.u_stride, st.t_prop);
     double y[NY];
+    const double* yf = st.y + (size_t)f * st.y_stride;
 #pragma unroll
-    for (int k = 0; k < NY; ++k) y[k] = (WEIGHT && st.has_y) ? st.y[k] : 0.0;
+    for (int k = 0; k < NY; ++k) y[k] = (WEIGHT && st.has_y) ? yf[k] : 0.0;
     const uint32_t key0 = sc->k0, key1 = sc->k1, sb = sc->step_base;
     const double c0_pre = md->dg.c0;                   // fetched with the other loads: the bound below must not wait for it
     const ResHead h = res_head<SRC_FILTER>(b, a, f, tile, sh, true, stop_flag, fb_flag);

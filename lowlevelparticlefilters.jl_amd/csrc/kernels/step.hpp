@@ -25,11 +25,12 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
 
 
     Model model;
-    model.prepare(md, a.u, a.t_prop);
+    model.prepare(md, a.u + (size_t)f * a.u_stride, a.t_prop);
     double y[NY];
     if (MODE != MODE_PROP) {
+        const double* yf = a.y + (size_t)f * a.y_stride;
 #pragma unroll
-        for (int k = 0; k < NY; ++k) y[k] = a.has_y ? a.y[k] : 0.0;
+        for (int k = 0; k < NY; ++k) y[k] = a.has_y ? yf[k] : 0.0;
     }
 
     double bmax = -LLPF_INF;

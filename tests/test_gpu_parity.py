@@ -339,6 +339,31 @@ def test_bank_equals_individual_filters():
         assert np.array_equal(rg["ll_steps"].view(np.uint64), rb["ll_steps"][:, k].copy().view(np.uint64))
 
 
+@pytest.mark.parametrize("thr,N", [(0.1, 3000), (1.0, 700), (0.5, 100000)])
+def test_bank_with_inputs_of_its_own_per_filter(thr, N):
+    """llpf_bank_run_multi: filter k of the bank, run on (U[k], Y[k]), is bit-identical to a single filter with seed s + k
+    run on the same data — log-likelihood per step and the weighted means (fused, balanced and split schedules by size);
+    a missing measurement common to all filters; mismatching missing measurements are rejected."""
+    F, T = 6, 40
+    models = [M.lg_test_model(0.1) for _ in range(F)]
+    data = [M.simulate_lg(models[0], T, seed=20 + k) for k in range(F)]
+    U = np.stack([d[1] for d in data]); Y = np.stack([d[2] for d in data])
+    Y[:, 9] = np.nan
+    bank = _capi.BankHandle(_cfg(models[0], N, thr=thr, seed=300), models) if thr != 1.0 else _capi.BankHandle(_cfg(models[0], N, thr=thr, seed=300), None, F)
+    bank.reset()
+    rb = bank.run_multi(U, Y, 0.0, ll_steps=True, xmean=True)
+    for k in range(F):
+        g = _capi.FilterHandle(_cfg(models[k], N, thr=thr, seed=300 + k))
+        g.reset()
+        rg = g.run(U[k], Y[k], 0.0, ll_steps=True, xmean=True)
+        assert rg["ll"] == rb["ll"][k]
+        assert np.array_equal(rg["ll_steps"].view(np.uint64), rb["ll_steps"][:, k].copy().view(np.uint64))
+        assert np.allclose(rg["xmean"], rb["xmean"][:, k], rtol=1e-11, atol=1e-13)
+    Y[2, 5] = np.nan
+    with pytest.raises(_capi.LLPFError):
+        bank.run_multi(U, Y, 0.0)
+
+
 def test_python_api_mirror_smoke():
     """The mirrored reference API (names of src/LowLevelParticleFilters.jl:3) end to end."""
     rng = np.random.default_rng(0)
