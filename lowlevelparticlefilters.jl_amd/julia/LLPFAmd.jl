@@ -9,7 +9,7 @@
 module LLPFAmd
 
 using LinearAlgebra
-export GPUParticleFilter, GPUAuxiliaryParticleFilter, LinearGaussianModel, QuadTankModel, RBLinearModel, RBBilinearModel, linear_state, GaussianSpec, smooth,
+export GPUFilterBank, loglik_multi, GPUParticleFilter, GPUAuxiliaryParticleFilter, LinearGaussianModel, QuadTankModel, RBLinearModel, RBBilinearModel, linear_state, GaussianSpec, smooth,
        reset!, predict!, correct!, update!, loglik, forward_trajectory, particles, weights, expweights,
        num_particles, index, effective_particles, shouldresample, weighted_mean
 
@@ -281,6 +281,42 @@ function effective_particles(pf::GPUParticleFilter)
 end
 function shouldresample(pf::GPUParticleFilter)
     r = Ref{Int32}(0); check(ccall((:llpf_shouldresample, LIB), Cint, (Ptr{Cvoid}, Ref{Int32}), pf.h, r)); r[] != 0
+end
+
+# ---- banks of independent filters (parameter sweeps, Monte-Carlo replicas) ---------------------------------------
+"`map(svec) do s; pfs = ParticleFilter(...); loglik(pfs, u, y); end` (reference test/runtests.jl:412-417) as one device job"
+mutable struct GPUFilterBank
+    h::Ptr{Cvoid}
+    F::Int; N::Int; nx::Int; nu::Int; ny::Int
+end
+function GPUFilterBank(N::Integer, models::Vector, dfs::Vector{GaussianSpec}, dg::GaussianSpec, d0::GaussianSpec;
+                       resample_threshold = 0.1, seed = 0, Ts = 1.0, device = 0)
+    cms = [cmodel(models[k], dfs[k], dg, d0, Float64(Ts)) for k in eachindex(models)]
+    cfg = Ref(CConfig(UInt32(sizeof(CConfig)), 0, N, 0, device, resample_threshold, UInt64(seed), cms[1]))
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:llpf_bank_create, LIB), Cint, (Ref{CConfig}, Ptr{CModel}, Int32, Ref{Ptr{Cvoid}}), cfg, cms, length(cms), h))
+    b = GPUFilterBank(h[], length(cms), N, cms[1].nx, cms[1].nu, cms[1].ny)
+    finalizer(x -> ccall((:llpf_bank_destroy, LIB), Cint, (Ptr{Cvoid},), x.h), b)
+    b
+end
+"log-likelihood of every filter of the bank on shared data u, y (vectors of vectors)"
+function loglik(b::GPUFilterBank, u, y)
+    T = length(y)
+    U = b.nu > 0 ? collect(reduce(hcat, u)) : zeros(0, T); Y = collect(reduce(hcat, y))    # column-major nu x T = row-major T x nu
+    ll = zeros(b.F)
+    check(ccall((:llpf_bank_reset, LIB), Cint, (Ptr{Cvoid},), b.h))
+    check(ccall((:llpf_bank_run, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64, Float64, Ptr{Float64}, Ptr{Float64}),
+                b.h, U, Y, T, 1.0, ll, C_NULL))
+    ll
+end
+"as loglik, every filter on data of its own: U nu x T x F, Y ny x T x F (column-major = the ABI's [F][T][n])"
+function loglik_multi(b::GPUFilterBank, U::Array{Float64,3}, Y::Array{Float64,3})
+    T = size(Y, 2)
+    ll = zeros(b.F); xm = zeros(b.nx, b.F, T)
+    check(ccall((:llpf_bank_reset, LIB), Cint, (Ptr{Cvoid},), b.h))
+    check(ccall((:llpf_bank_run_multi, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64, Float64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                b.h, U, Y, T, 1.0, ll, C_NULL, xm))
+    ll, xm
 end
 
 end # module
