@@ -11,6 +11,7 @@ struct Bank {
     int nxp = 0;                     // dimension of a particle as the accessors see it: nx, or nxn + nxl for LLPF_MODEL_RB_BILINEAR (RBParticle indexes like [xn; xl])
     int device = 0;
     hipStream_t stream = nullptr;
+    void* d_pool = nullptr;          // the one allocation the members below (up to d_tmp) point into
     ModelD* d_models = nullptr;
     FilterScal* d_scal = nullptr;
     double* d_x[2] = {nullptr, nullptr};
@@ -110,9 +111,9 @@ static void free_bank(Bank& b) {
     if (b.stream) hipStreamSynchronize(b.stream);
     for (auto& g : b.graphs) if (g.exec) hipGraphExecDestroy(g.exec);
     b.graphs.clear();
-    hipFree(b.d_models); hipFree(b.d_scal); hipFree(b.d_x[0]); hipFree(b.d_x[1]); hipFree(b.d_w);
-    hipFree(b.d_anc); hipFree(b.d_acc); hipFree(b.d_quanta[0]); hipFree(b.d_quanta[1]); hipFree(b.d_tileq); hipFree(b.d_flag); hipFree(b.d_xmpart); hipFree(b.d_lam); hipFree(b.d_rtile); hipFree(b.d_rb); hipFree(b.d_rbseq); hipFree(b.d_hist); hipFree(b.d_uy); hipFree(b.d_U); hipFree(b.d_Y);
-    hipFree(b.d_ll_steps); hipFree(b.d_xmean); hipFree(b.d_tmp);
+    hipFree(b.d_pool);               // models, scal, x, w, anc, acc, quanta, tileq, flag, xmpart, rtile, rb, uy, tmp
+    hipFree(b.d_lam); hipFree(b.d_rbseq); hipFree(b.d_hist); hipFree(b.d_U); hipFree(b.d_Y);
+    hipFree(b.d_ll_steps); hipFree(b.d_xmean);
     for (auto e : b.ev_pool) hipEventDestroy(e);
     for (auto& e : b.pending) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     if (b.ev_run0) hipEventDestroy(b.ev_run0);
@@ -267,22 +268,34 @@ static int bank_create(const llpf_config* cfg, const llpf_model* models, int F, 
     HIPC(hipSetDevice(b.device));
     HIPC(hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking));
     const size_t FN = (size_t)F * b.Ns;
-    HIPC(hipMalloc(&b.d_models, sizeof(ModelD) * F));
-    HIPC(hipMalloc(&b.d_scal, sizeof(FilterScal) * F));
-    HIPC(hipMalloc(&b.d_x[0], sizeof(double) * FN * b.xrows));
-    HIPC(hipMalloc(&b.d_x[1], sizeof(double) * FN * b.xrows));
-    HIPC(hipMalloc(&b.d_w, sizeof(double) * FN));
-    HIPC(hipMalloc(&b.d_anc, sizeof(int32_t) * FN));
-    HIPC(hipMalloc(&b.d_acc, sizeof(uint64_t) * (size_t)F * ACC_WORDS));
-    HIPC(hipMalloc(&b.d_quanta[0], sizeof(uint64_t) * FN));
-    HIPC(hipMalloc(&b.d_quanta[1], sizeof(uint64_t) * FN));
-    HIPC(hipMalloc(&b.d_tileq, sizeof(uint64_t) * (size_t)ACC_NSLOT * F * b.P2));
-    HIPC(hipMalloc(&b.d_flag, sizeof(uint32_t) * 4));
-    HIPC(hipMalloc(&b.d_xmpart, sizeof(double) * (size_t)F * b.P1 * MAXD));
-    HIPC(hipMalloc(&b.d_rtile, sizeof(uint64_t) * (size_t)F * 2 * b.P2));
+    {   // one device allocation for everything whose size is known here (a filter is often built per Monte-Carlo run or per
+        // parameter candidate: 17 hipMalloc + as many memsets and hipFree cost more than a short run), zero-filled once
+        size_t off = 0;
+        auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+        const size_t o_models = take(sizeof(ModelD) * F), o_scal = take(sizeof(FilterScal) * F);
+        const size_t o_x0 = take(sizeof(double) * FN * b.xrows), o_x1 = take(sizeof(double) * FN * b.xrows);
+        const size_t o_w = take(sizeof(double) * FN), o_anc = take(sizeof(int32_t) * FN);
+        const size_t o_acc = take(sizeof(uint64_t) * (size_t)F * ACC_WORDS);
+        const size_t o_q0 = take(sizeof(uint64_t) * FN), o_q1 = take(sizeof(uint64_t) * FN);
+        const size_t o_tileq = take(sizeof(uint64_t) * (size_t)ACC_NSLOT * F * b.P2), o_flag = take(sizeof(uint32_t) * 4);
+        const size_t o_xmpart = take(sizeof(double) * (size_t)F * b.P1 * MAXD), o_rtile = take(sizeof(uint64_t) * (size_t)F * 2 * b.P2);
+        const size_t o_rb = take(m0.model_id == LLPF_MODEL_RB_LINEAR ? sizeof(RBStep) * 2 * (size_t)F : 0);
+        const size_t o_uy = take(sizeof(double) * 4 * MAXD);
+        const size_t o_tmp = take(sizeof(double) * (size_t)F * b.N * (b.nxp > 1 ? b.nxp : 1) + 64);
+        HIPC(hipMalloc(&b.d_pool, off));
+        HIPC(hipMemsetAsync(b.d_pool, 0, off, b.stream));
+        char* base = static_cast<char*>(b.d_pool);
+        b.d_models = reinterpret_cast<ModelD*>(base + o_models); b.d_scal = reinterpret_cast<FilterScal*>(base + o_scal);
+        b.d_x[0] = reinterpret_cast<double*>(base + o_x0); b.d_x[1] = reinterpret_cast<double*>(base + o_x1);
+        b.d_w = reinterpret_cast<double*>(base + o_w); b.d_anc = reinterpret_cast<int32_t*>(base + o_anc);
+        b.d_acc = reinterpret_cast<uint64_t*>(base + o_acc);
+        b.d_quanta[0] = reinterpret_cast<uint64_t*>(base + o_q0); b.d_quanta[1] = reinterpret_cast<uint64_t*>(base + o_q1);
+        b.d_tileq = reinterpret_cast<uint64_t*>(base + o_tileq); b.d_flag = reinterpret_cast<uint32_t*>(base + o_flag);
+        b.d_xmpart = reinterpret_cast<double*>(base + o_xmpart); b.d_rtile = reinterpret_cast<uint64_t*>(base + o_rtile);
+        if (m0.model_id == LLPF_MODEL_RB_LINEAR) b.d_rb = reinterpret_cast<RBStep*>(base + o_rb);
+        b.d_uy = reinterpret_cast<double*>(base + o_uy); b.d_tmp = reinterpret_cast<double*>(base + o_tmp);
+    }
     if (m0.model_id == LLPF_MODEL_RB_LINEAR) {
-        HIPC(hipMalloc(&b.d_rb, sizeof(RBStep) * 2 * (size_t)F));
-        HIPC(hipMemsetAsync(b.d_rb, 0, sizeof(RBStep) * 2 * (size_t)F, b.stream));
         b.rb.resize(F);
         for (int f = 0; f < F; ++f) {                       // the inner KalmanFilter object: kf.x = d0.mu, kf.R = d0.Sigma
             double S0[16];
@@ -292,19 +305,6 @@ static int bank_create(const llpf_config* cfg, const llpf_model* models, int F, 
             for (int i = 0; i < nl; ++i) b.rb[f].kfx[i] = b.hmodels[f].linear_initial.mu[i];
         }
     }
-    HIPC(hipMemsetAsync(b.d_rtile, 0, sizeof(uint64_t) * (size_t)F * 2 * b.P2, b.stream));
-    HIPC(hipMalloc(&b.d_uy, sizeof(double) * 4 * MAXD));
-    HIPC(hipMalloc(&b.d_tmp, sizeof(double) * (size_t)F * b.N * (b.nxp > 1 ? b.nxp : 1) + 64));
-    HIPC(hipMemsetAsync(b.d_x[0], 0, sizeof(double) * FN * b.xrows, b.stream));
-    HIPC(hipMemsetAsync(b.d_x[1], 0, sizeof(double) * FN * b.xrows, b.stream));
-    HIPC(hipMemsetAsync(b.d_anc, 0, sizeof(int32_t) * FN, b.stream));
-    HIPC(hipMemsetAsync(b.d_scal, 0, sizeof(FilterScal) * F, b.stream));
-    HIPC(hipMemsetAsync(b.d_acc, 0, sizeof(uint64_t) * (size_t)F * ACC_WORDS, b.stream));
-    HIPC(hipMemsetAsync(b.d_quanta[0], 0, sizeof(uint64_t) * FN, b.stream));
-    HIPC(hipMemsetAsync(b.d_quanta[1], 0, sizeof(uint64_t) * FN, b.stream));
-    HIPC(hipMemsetAsync(b.d_tileq, 0, sizeof(uint64_t) * (size_t)ACC_NSLOT * F * b.P2, b.stream));
-    HIPC(hipMemsetAsync(b.d_flag, 0, sizeof(uint32_t) * 4, b.stream));
-    HIPC(hipMemsetAsync(b.d_xmpart, 0, sizeof(double) * (size_t)F * b.P1 * MAXD, b.stream));
     HIPC(hipMemcpyAsync(b.d_models, hm.data(), sizeof(ModelD) * F, hipMemcpyHostToDevice, b.stream));
     HIPC(hipStreamSynchronize(b.stream));
     HIPC(hipEventCreate(&b.ev_run0));
