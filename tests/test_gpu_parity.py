@@ -339,6 +339,30 @@ def test_bank_equals_individual_filters():
         assert np.array_equal(rg["ll_steps"].view(np.uint64), rb["ll_steps"][:, k].copy().view(np.uint64))
 
 
+def test_bank_at_the_c4_share_of_one_gpu():
+    """BASELINE config C4 at the size of one GPU's share (128 filters x N = 1e5, the split schedule): three filters of the
+    bank are bit-identical to single filters with seed s + k, every log-likelihood is finite, and a second run of the same
+    shape (replayed from the captured graph) reproduces a fresh bank's numbers for its own noise."""
+    F, N, T = 128, 100000, 40
+    svec = 10.0 ** np.linspace(-2, 0, F)
+    models = [M.lg_test_model(s) for s in svec]
+    _, U, Y = M.simulate_lg(M.lg_test_model(0.1), T)
+    bank = _capi.BankHandle(_cfg(models[0], N, thr=0.1, seed=900), models)
+    bank.reset()
+    rb = bank.run(U, Y, 1.0, ll_steps=True)
+    assert np.all(np.isfinite(rb["ll"])) and bank.resample_count() > 0
+    for k in (0, 61, 127):
+        g = _capi.FilterHandle(_cfg(models[k], N, thr=0.1, seed=900 + k))
+        g.reset()
+        rg = g.run(U, Y, 1.0, ll_steps=True)
+        assert np.array_equal(rg["ll_steps"].view(np.uint64), rb["ll_steps"][:, k].copy().view(np.uint64))
+    bank.reset(); r2 = bank.run(U, Y, 1.0)
+    bank.reset(); r3 = bank.run(U, Y, 1.0)
+    fresh = _capi.BankHandle(_cfg(models[0], N, thr=0.1, seed=900), models)
+    fresh.reset(); fresh.run(U, Y, 1.0); fresh.reset(); f2 = fresh.run(U, Y, 1.0); fresh.reset(); f3 = fresh.run(U, Y, 1.0)
+    assert np.array_equal(r2["ll"], f2["ll"]) and np.array_equal(r3["ll"], f3["ll"])
+
+
 @pytest.mark.parametrize("thr,N", [(0.1, 3000), (1.0, 700), (0.5, 100000)])
 def test_bank_with_inputs_of_its_own_per_filter(thr, N):
     """llpf_bank_run_multi: filter k of the bank, run on (U[k], Y[k]), is bit-identical to a single filter with seed s + k
