@@ -127,6 +127,8 @@ struct FilterScal {
     int32_t pad2;
     int32_t e2_valid;    // sum e^2 / ESS are known for the current (finalized) weights (skipped when resample_threshold == 1)
     int32_t e2v_slot[ACC_NSLOT]; // sum e^2 was accumulated into accumulator slot p
+    int32_t exact_slot[ACC_NSLOT]; // the sums of slot p are in exact-max form although a bound was available: a filter of ONE tile whose
+    int32_t pad4;                //   bound test failed redoes its sums inside the producing kernel (no host round trip)
 };
 
 // arguments common to the step-path kernels

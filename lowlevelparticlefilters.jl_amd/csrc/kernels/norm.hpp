@@ -57,6 +57,63 @@ __global__ __launch_bounds__(BLOCK) void k_norm(BankDev b, int K, int parity, ui
             }
         }
     }
+    int exact = 0;
+    if (bound && gridDim.x == 1) {
+        // one-tile filter in the split schedule: the coming head's bound test is made here; if it fails the sums are
+        // redone at once against the true maximum (what the host would otherwise ask for in a separate launch)
+        __shared__ double sm_m[BLOCK / 64];
+        const llpf_u128 sw = wave_sum_u128(S);
+        const uint64_t bw = wave_sum_u64(bad);
+        if ((threadIdx.x & 63) == 0) { sm_u[threadIdx.x >> 6][0] = sw.lo; sm_u[threadIdx.x >> 6][1] = sw.hi; sm_u[threadIdx.x >> 6][5] = bw; }
+        __syncthreads();
+        llpf_u128 tot = {sm_u[0][0], sm_u[0][1]};
+        uint64_t tb = sm_u[0][5];
+        for (int k = 1; k < BLOCK / 64; ++k) { const llpf_u128 t1 = {sm_u[k][0], sm_u[k][1]}; tot = llpf_u128_add(tot, t1); tb += sm_u[k][5]; }
+        __syncthreads();
+        if (tb || tot.hi < ((uint64_t)1 << 22)) {
+            exact = 1;
+            double mx = -LLPF_INF;
+            bool anynan = false;
+#pragma unroll
+            for (int k = 0; k < NORM_IPT / 2; ++k) {
+                mx = llpf_fmax(mx, wv[k].x); mx = llpf_fmax(mx, wv[k].y);
+                anynan = anynan || (wv[k].x != wv[k].x) || (wv[k].y != wv[k].y);
+            }
+            mx = block_max(mx, sm_m);
+            if (__syncthreads_or(anynan ? 1 : 0)) mx = llpf_u2d(0x7ff8000000000000ULL);
+            S.lo = 0; S.hi = 0; E2.lo = 0; E2.hi = 0; Q = 0; bad = 0;
+#pragma unroll
+            for (int d = 0; d < NX; ++d) xm[d] = 0.0;
+#pragma unroll
+            for (int k = 0; k < NORM_IPT / 2; ++k) {
+                const int64_t i0 = (int64_t)tile * TILE + (int64_t)k * (BLOCK * 2) + threadIdx.x * 2;
+                const double e0 = llpf_exp_le0(wv[k].x - mx);
+                const double e1 = llpf_exp_le0(wv[k].y - mx);
+                bad += (e0 != e0) ? 1u : 0u;
+                bad += (e1 != e1) ? 1u : 0u;
+                S = llpf_u128_add(S, llpf_fix96_unit(e0));
+                S = llpf_u128_add(S, llpf_fix96_unit(e1));
+                if (NEED_E2) {
+                    E2 = llpf_u128_add(E2, llpf_fix96_unit(e0 * e0));
+                    E2 = llpf_u128_add(E2, llpf_fix96_unit(e1 * e1));
+                }
+                ulonglong2 qv;
+                qv.x = llpf_q64_unit(e0, K);
+                qv.y = llpf_q64_unit(e1, K);
+                *reinterpret_cast<ulonglong2*>(b.quanta + (size_t)f * b.Ns + i0) = qv;
+                Q += qv.x;
+                Q += qv.y;
+                if (XMEAN) {
+#pragma unroll
+                    for (int d = 0; d < NX; ++d) {
+                        const double2 xv = *reinterpret_cast<const double2*>(xc + (size_t)d * b.Ns + i0);
+                        xm[d] = xm[d] + xv.x * e0;
+                        xm[d] = xm[d] + xv.y * e1;
+                    }
+                }
+            }
+        }
+    }
     S = wave_sum_u128(S);
     if (NEED_E2) E2 = wave_sum_u128(E2);
     Q = wave_sum_u64(Q);
@@ -92,6 +149,7 @@ __global__ __launch_bounds__(BLOCK) void k_norm(BankDev b, int K, int parity, ui
             FilterScal* sc = b.scal + f;
             sc->u_slot[parity] = llpf_uniform_step(sc->step_base + step, LLPF_STREAM_RESAMPLE, sc->k0, sc->k1);
             sc->e2v_slot[parity] = NEED_E2 ? 1 : 0;
+            sc->exact_slot[parity] = exact;
             sc->xm_parts = b.P2;
         }
         if (bd) atomicAdd(reinterpret_cast<unsigned long long*>(acc_slot(acc, ACC_BAD(parity), blockIdx.x & (NSHARD - 1))), (unsigned long long)bd);

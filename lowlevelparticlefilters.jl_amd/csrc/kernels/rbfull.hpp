@@ -95,6 +95,7 @@ __global__ __launch_bounds__(BLOCK) void k_rbfull(BankDev b, const ModelD* __res
             if (blockIdx.x == 0) {
                 FilterScal* scw = b.scal + f;
                 scw->off_slot[a.parity] = off;
+                scw->exact_slot[a.parity] = 0;
                 scw->e2v_slot[a.parity] = a.need_e2;
                 scw->u_slot[a.parity] = llpf_uniform_step(sb + a.next_step, LLPF_STREAM_RESAMPLE, k0, k1);
             }

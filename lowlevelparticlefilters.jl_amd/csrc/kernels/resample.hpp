@@ -93,6 +93,7 @@ DEV ResHead res_head(const BankDev& b, const ResArgs& a, int f, int tile, ResSha
     // scalars of the previous launch that are needed after the barrier below: fetched now, with the other loads
     const double off_pre = sc->off_slot[a.parity];
     const int e2v_pre = sc->e2v_slot[a.parity];
+    const int exact_pre = sc->exact_slot[a.parity];
     const int status_pre = sc->status;
 
     // loads.  wave 0: lane group g (8 lanes = 8 shards) fetches word g of this slot's accumulator set
@@ -137,7 +138,7 @@ DEV ResHead res_head(const BankDev& b, const ResArgs& a, int f, int tile, ResSha
         else { for (int p = threadIdx.x; p < b.P2; p += BLOCK) tqc[p] = 0; }      // finalize-only launch: one block
     }
     if (fin) {
-        h.fast = a.fast_head;
+        h.fast = a.fast_head && !exact_pre;            // a one-tile filter may have redone its sums in exact form already
         h.mtrue = max_unkey(sh.accw[0]);
         const llpf_u128 s128 = acc_combine_u128(sh.accw[1], sh.accw[2], sh.accw[3]);
         const llpf_u128 e128 = acc_combine_u128(sh.accw[4], sh.accw[5], sh.accw[6]);

@@ -123,7 +123,8 @@ struct TileSum {
 };
 static_assert(TILE == 1024, "TileSum assumes 1024-particle tiles");
 
-template <class Model, int NX, int NY, bool WEIGHT, bool ACC, bool AUX = false>
+// ONE: the filter is a single tile (launched only when P2 == 1): a failed bound test is redone inside this kernel
+template <class Model, int NX, int NY, bool WEIGHT, bool ACC, bool AUX = false, bool ONE = false>
 __global__ __launch_bounds__(BLOCK) void k_resprop(BankDev b, const ModelD* __restrict__ models, ResArgs a, StepArgs st) {
     __shared__ ResShared sh;
     __shared__ double sm_max[BLOCK / 64];
@@ -247,6 +248,41 @@ __global__ __launch_bounds__(BLOCK) void k_resprop(BankDev b, const ModelD* __re
         const double r = block_max(bmax, sm_max);
         const int anybad = __syncthreads_or(bad ? 1 : 0);
         if (threadIdx.x == 0) acc_max(b.acc + (size_t)f * ACC_WORDS, st.parity, r, anybad != 0);
+        int exact = 0;
+        if constexpr (ACC && ONE) {
+            // This block is the whole filter (one tile): make the bound test of the coming head here and, if it fails,
+            // redo the sums in exact-max form at once (same arithmetic as k_norm's exact form; the head is told through
+            // exact_slot).  Banks of many small filters otherwise pay a host round trip at nearly every timestep.
+            const llpf_u128 sw = wave_sum_u128(wacc.S);
+            if ((threadIdx.x & 63) == 0) { sm_acc[threadIdx.x >> 6][0] = sw.lo; sm_acc[threadIdx.x >> 6][1] = sw.hi; }
+            __syncthreads();
+            llpf_u128 tot = {sm_acc[0][0], sm_acc[0][1]};
+            for (int k = 1; k < BLOCK / 64; ++k) { const llpf_u128 t1 = {sm_acc[k][0], sm_acc[k][1]}; tot = llpf_u128_add(tot, t1); }
+            __syncthreads();
+            if (anybad || tot.hi < ((uint64_t)1 << 22)) {
+                exact = 1;
+                const double mx = anybad ? llpf_u2d(0x7ff8000000000000ULL) : r;
+                wacc.init();
+                ts.init();
+                if (threadIdx.x < 8) sh_tq[threadIdx.x] = 0;
+#pragma unroll
+                for (int d = 0; d < NX; ++d) xm[d] = 0.0;
+                __syncthreads();
+#pragma unroll 1
+                for (uint32_t o = (uint32_t)first + threadIdx.x; o < ulast; o += BLOCK) {
+                    const double wv = ld_off(pc.w, o << 3);
+                    double e;
+                    const uint64_t q = wacc.add(wv, mx, st.K, st.need_e2 != 0, &e);
+                    st_off(pc.qnext, o << 3, q);
+                    ts.add(o, q, sh_tq, tq_next, tbase);
+                    if (st.want_xmean) {
+#pragma unroll
+                        for (int d = 0; d < NX; ++d) xm[d] = xm[d] + ld_off(pc.xn + (size_t)d * Ns, o << 3) * e;
+                    }
+                }
+                ts.flush(sh_tq, tq_next, tbase);
+            }
+        }
         if (ACC) {
             wacc.flush(b.acc + (size_t)f * ACC_WORDS, st.parity, st.need_e2 != 0, sm_acc);
             __syncthreads();
@@ -262,6 +298,7 @@ __global__ __launch_bounds__(BLOCK) void k_resprop(BankDev b, const ModelD* __re
             }
             if (ACC) sc->xm_parts = b.P2;
             sc->off_slot[st.parity] = pc.off;
+            sc->exact_slot[st.parity] = exact;
             sc->e2v_slot[st.parity] = st.need_e2;
             sc->u_slot[st.parity] = llpf_uniform_step(sb + st.next_step, LLPF_STREAM_RESAMPLE, sc->k0, sc->k1);
         }
