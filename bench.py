@@ -203,6 +203,13 @@ def main_bank(args, rank, world, dev):
                             "method": "hipEvent pairs around every launch on the engine stream, one profiled pass after the timed region",
                             "whole_timestep": {"algorithmic_bytes": Fl * N * b_alg, "us": timestep_s * 1e6,
                                                "achieved": Fl * N * b_alg / timestep_s / 1e9, "frac": Fl * N * b_alg / timestep_s / 8e12}}}
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01i_pmc_traffic.json")))
+            if pm["c4"]["filters"] == Fl and pm["c4"]["n_particles"] == N:
+                out["roofline"]["traffic"] = pm["c4"]["k_resprop"]["bytes"]
+                out["roofline"]["traffic_source"] = pm["c4"]["source"] + "; " + pm["correction"]
+        except Exception:
+            pass
         if world == 1 and not args.no_cpu_baseline:
             cs = args.cpu_steps if args.cpu_steps else 1000
             out.update(cpu_baseline(models[len(models) // 2], U, Y, S.PARTICLE_FILTER, thr, N, min(cs, T), 77, None))
@@ -397,6 +404,9 @@ def main():
             if one_launch and pm["n_particles"] == N and pm["nx"] == nx and args.workload == "lg" and thr == pm["resample_threshold"]:
                 roof["traffic"] = pm["k_resprop"]["bytes"]
                 roof["traffic_source"] = pm["source"] + "; " + pm["correction"]
+            if args.workload == "quadtank" and pm["c3"]["n_particles"] == N and not fused:
+                roof["traffic"] = pm["c3"]["k_step"]["bytes"]
+                roof["traffic_source"] = pm["c3"]["source"] + "; " + pm["correction"] + "; " + pm["c3"]["k_step"]["note"]
             if rbfull and pm["c5"]["n_particles"] == N:
                 roof["traffic"] = pm["c5"]["k_rbfull"]["bytes"]
                 roof["traffic_source"] = pm["c5"]["source"] + "; " + pm["correction"]

@@ -33,6 +33,9 @@ rocprofv3 --kernel-trace -d $OUT/kt_rbpf -o kt -- python $ROOT/bench.py --worklo
 rocprofv3 --kernel-trace -d $OUT/kt_rbpf_full -o kt -- python $ROOT/bench.py --workload rbpf_full --no-cpu-baseline > $OUT/kt_rbpf_full.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch_c5 -o p -- python $ROOT/bench.py --workload rbpf_full --steps 1 --warmup 0 --T 200 --no-cpu-baseline > $OUT/pmc_fetch_c5.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write_c5 -o p -- python $ROOT/bench.py --workload rbpf_full --steps 1 --warmup 0 --T 200 --no-cpu-baseline > $OUT/pmc_write_c5.log 2>&1
+for w in quadtank bank; do for c in FETCH_SIZE WRITE_SIZE; do
+rocprofv3 --pmc $c -d $OUT/pmc_${c}_$w -o p -- python $ROOT/bench.py --workload $w --steps 1 --warmup 0 --T 100 --no-cpu-baseline > $OUT/pmc_${c}_$w.log 2>&1
+done; done
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o p -- python $ROOT/bench.py --steps 1 --warmup 0 --T 200 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o p -- python $ROOT/bench.py --steps 1 --warmup 0 --T 200 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_ANY -d $OUT/pmc_sq -o p -- python $ROOT/bench.py --steps 1 --warmup 0 --T 200 --no-cpu-baseline > $OUT/pmc_sq.log 2>&1
@@ -42,5 +45,6 @@ python tools/rocprof_summary.py $(find $OUT/kt_bank -name "*.db" | head -1) > $O
 for w in qt aux rbpf rbpf_full; do python tools/rocprof_summary.py $(find $OUT/kt_$w -name "*.db" | head -1) > $OUT/kernel_stats_$w.txt; done
 python tools/rocprof_pmc_summary.py $OUT/pmc_traffic.txt $(find $OUT/pmc_fetch -name "*.db" | head -1) $(find $OUT/pmc_write -name "*.db" | head -1) $(find $OUT/pmc_sq -name "*.db" | head -1)
 python tools/rocprof_pmc_summary.py $OUT/pmc_traffic_c5.txt $(find $OUT/pmc_fetch_c5 -name "*.db" | head -1) $(find $OUT/pmc_write_c5 -name "*.db" | head -1)
+for w in quadtank bank; do python tools/rocprof_pmc_summary.py $OUT/pmc_traffic_$w.txt $(find $OUT/pmc_FETCH_SIZE_$w -name "*.db" | head -1) $(find $OUT/pmc_WRITE_SIZE_$w -name "*.db" | head -1); rm -rf $OUT/pmc_FETCH_SIZE_$w $OUT/pmc_WRITE_SIZE_$w; done
 rm -rf $OUT/kt_rbpf_full $OUT/pmc_fetch_c5 $OUT/pmc_write_c5 $OUT/kt $OUT/kt_bank $OUT/kt_qt $OUT/kt_aux $OUT/kt_rbpf $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/*.log
 ls -la $OUT
