@@ -220,12 +220,39 @@ def main_bank(args, rank, world, dev):
         dist.destroy_process_group()
 
 
+def main_reference_mc(args, rank, world):
+    """The reference's own published benchmark (run_test(), examples/example_lineargaussian.jl:282-316) through
+    tools/bench_mc.py, in this file's output contract: one step = the whole benchmark (8.4e6 particle-steps); vs_baseline =
+    value / the faster of the two published figures (docs/src/benchmark.md:48, 7.37e6 particle-steps/s, unstated CPU).
+    Single GPU (the published benchmark is a single-process loop)."""
+    import subprocess
+    if world > 1:
+        raise SystemExit("the reference_mc workload is a single-GPU benchmark")
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_mc.py"), "--repeat", str(max(1, args.steps))]
+    if args.no_cpu_baseline:
+        cmd.append("--no-cpu-baseline")
+    r = json.loads(subprocess.check_output(cmd, stderr=subprocess.DEVNULL).decode().strip().splitlines()[-1])
+    out = {"metric": "particle-steps/s", "value": r["value"], "unit": "particle-steps/s", "n_gpus": 1, "steps": r["repetitions"],
+           "warmup": 1, "ms_per_step": 1e3 * r["seconds_mean"], "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": r["vs_published_docs"], "dtype": "f64", "data": "synthetic",
+           "config": {"workload": r["workload"], "propagated_particles": r["propagated_particles"], "filter_launches": r["filter_launches"],
+                      "timed": r["timed"], "published_reference": r["published_reference"], "note": r["note"]},
+           "seconds_breakdown_last_repetition": r["seconds_breakdown_last_repetition"],
+           "roofline": {"bound": "hbm", "kernel": "k_resprop (banks of 2..2000 filters of 10..1000 particles)", "achieved": None, "peak": 8000.0,
+                        "unit": "GB/s", "frac": None, "traffic": None,
+                        "note": "launch- and host-bound at these sizes (0.05 s of 0.15 s on the device): no roofline figure is meaningful; see the C2 / C4 lines"}}
+    if "cpu_baseline" in r:
+        out["cpu_baseline"] = r["cpu_baseline"]
+        out["speedup_vs_cpu_baseline"] = r["speedup_vs_cpu_baseline"]
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="lg", choices=["lg", "quadtank", "aux", "bank", "rbpf", "rbpf_full"])
+    ap.add_argument("--workload", default="lg", choices=["lg", "quadtank", "aux", "bank", "rbpf", "rbpf_full", "reference_mc"])
     ap.add_argument("--filters-per-gpu", type=int, default=128, help="bank workload (BASELINE config C4): filters per GPU")
     ap.add_argument("--particles", type=int, default=1000000)
     ap.add_argument("--T", type=int, default=None)
@@ -256,6 +283,8 @@ def main():
 
     if args.workload == "bank":
         return main_bank(args, rank, world, dev)
+    if args.workload == "reference_mc":
+        return main_reference_mc(args, rank, world)
     from llpf_amd import _capi, _structs as S
     T = args.T if args.T else (2000 if args.workload == "quadtank" else 1000)
     rbfull = args.workload == "rbpf_full"
