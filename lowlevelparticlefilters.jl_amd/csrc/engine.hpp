@@ -231,6 +231,7 @@ hipError_t launch_max(const BankDev& b, int parity, hipStream_t s);           //
 hipError_t launch_norm(const BankDev& b, int parity, int want_xmean, int need_e2, uint32_t step, int only_fallback, int bound, int64_t kstep, hipStream_t s);
 hipError_t launch_ess(const BankDev& b, hipStream_t s);   // on-demand sum e^2 / ESS of the current weights (accessor path)
 hipError_t launch_post_predict(const BankDev& b, hipStream_t s);
+hipError_t launch_replicate_models(ModelD* models, int F, hipStream_t s);   // models[1..F) <- models[0]
 // failed bound test: zero the exp-sums of `slot` (mode 0) / clear the flags (mode 1) of the filters that asked for the exact form
 hipError_t launch_fb_clear(const BankDev& b, int slot, int mode, hipStream_t s);
 hipError_t launch_resample(const BankDev& b, const ResArgs& a, hipStream_t s);

@@ -255,9 +255,13 @@ static int bank_create(const llpf_config* cfg, const llpf_model* models, int F, 
     b.P1 = (int)(b.Ns / STEP_TILE);
     b.P2 = (int)(b.Ns / TILE);
     b.device = cfg->device;
-    std::vector<ModelD> hm(F);
-    b.hmodels.resize(F);
-    for (int f = 0; f < F; ++f) {
+    // replicas (models == NULL): one descriptor is prepared and uploaded, the device copies it F times (a bank of
+    // thousands of Monte-Carlo replicas otherwise spends its construction on host copies of identical 8 KB structs)
+    const bool replicas = (models == nullptr) && m0.model_id != LLPF_MODEL_RB_LINEAR;
+    const int FH = replicas ? 1 : F;
+    std::vector<ModelD> hm(FH);
+    b.hmodels.resize(FH);
+    for (int f = 0; f < FH; ++f) {
         const llpf_model& mf = models ? models[f] : cfg->model;
         b.hmodels[f] = mf;
         if (mf.model_id != m0.model_id || mf.nx != m0.nx || mf.nu != m0.nu || mf.ny != m0.ny)
@@ -305,7 +309,8 @@ static int bank_create(const llpf_config* cfg, const llpf_model* models, int F, 
             for (int i = 0; i < nl; ++i) b.rb[f].kfx[i] = b.hmodels[f].linear_initial.mu[i];
         }
     }
-    HIPC(hipMemcpyAsync(b.d_models, hm.data(), sizeof(ModelD) * F, hipMemcpyHostToDevice, b.stream));
+    HIPC(hipMemcpyAsync(b.d_models, hm.data(), sizeof(ModelD) * FH, hipMemcpyHostToDevice, b.stream));
+    if (FH < F) HIPC(launch_replicate_models(b.d_models, F, b.stream));
     HIPC(hipStreamSynchronize(b.stream));
     HIPC(hipEventCreate(&b.ev_run0));
     HIPC(hipEventCreate(&b.ev_run1));

@@ -180,6 +180,10 @@ hipError_t launch_ess(const BankDev& b, hipStream_t s) {
     return hipGetLastError();
 }
 
+hipError_t launch_replicate_models(ModelD* models, int F, hipStream_t s) {
+    if (F > 1) hipLaunchKernelGGL(k_replicate_models, dim3((unsigned)(F - 1)), dim3(256), 0, s, models);
+    return hipGetLastError();
+}
 hipError_t launch_fb_clear(const BankDev& b, int slot, int mode, hipStream_t s) {
     hipLaunchKernelGGL(k_fb_clear, dim3((unsigned)b.F), dim3(64), 0, s, b, slot, mode);
     if (mode == 1) hipLaunchKernelGGL(k_fb_clear_flag, dim3(1), dim3(64), 0, s, b);     // after every filter's flag: same stream

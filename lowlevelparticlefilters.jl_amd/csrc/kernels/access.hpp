@@ -86,3 +86,10 @@ __global__ __launch_bounds__(BLOCK) void k_wmean(BankDev b, double* out) {
             out[(size_t)f * b.nx + d] = a;
         }
 }
+
+// bank of replicas: model descriptor 0 copied to the F - 1 others
+__global__ void k_replicate_models(ModelD* models) {
+    const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(models);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(models + 1 + blockIdx.x);
+    for (int i = threadIdx.x; i < (int)(sizeof(ModelD) / 4); i += blockDim.x) dst[i] = src[i];
+}
