@@ -363,6 +363,23 @@ def test_bank_at_the_c4_share_of_one_gpu():
     assert np.array_equal(r2["ll"], f2["ll"]) and np.array_equal(r3["ll"], f3["ll"])
 
 
+def test_replica_bank_equals_bank_with_explicit_models():
+    """llpf_bank_create(models = NULL): one descriptor replicated on the device gives the same filters as F explicit
+    copies (quad-tank and linear-Gaussian models)."""
+    qt = M.quadtank_model()
+    U, Y = M.quadtank_data(30, seed=2)
+    cfg = _cfg(qt, 3000, thr=0.5, kind=S.ADVANCED_PARTICLE_FILTER, seed=5)
+    a = _capi.BankHandle(cfg, None, 3); b = _capi.BankHandle(cfg, [qt] * 3)
+    a.reset(); b.reset()
+    assert np.array_equal(a.run(U, Y, 1.0)["ll"], b.run(U, Y, 1.0)["ll"])
+    lg = M.lg_test_model(0.1)
+    _, U2, Y2 = M.simulate_lg(lg, 30)
+    cfg2 = _cfg(lg, 800, thr=0.1, seed=5)
+    a = _capi.BankHandle(cfg2, None, 700); b = _capi.BankHandle(cfg2, [lg] * 700)
+    a.reset(); b.reset()
+    assert np.array_equal(a.run(U2, Y2, 1.0)["ll"], b.run(U2, Y2, 1.0)["ll"])
+
+
 @pytest.mark.parametrize("thr,N", [(0.1, 3000), (1.0, 700), (0.5, 100000)])
 def test_bank_with_inputs_of_its_own_per_filter(thr, N):
     """llpf_bank_run_multi: filter k of the bank, run on (U[k], Y[k]), is bit-identical to a single filter with seed s + k
