@@ -8,9 +8,12 @@ Default workload = BASELINE.json configs[1]: 2-D linear-Gaussian ParticleFilter 
 system, test/runtests.jl:255-266), N = 1e6, T = 1000, systematic resampling at every step
 (resample_threshold = 1.0, so the scan/expansion kernel runs in all T steps).
 
-N > 1 GPUs: one process per GPU (torch.distributed, backend nccl = RCCL); every rank runs its own
-independent filter instance (different Philox key) and the only collective is an all-reduce of the
-log-likelihoods after each pass — weak scaling.
+N > 1 GPUs (`--gpus N`): one process per GPU.  Under `python -m torch.distributed.run` the ranks come from the
+environment (RANK / LOCAL_RANK / WORLD_SIZE, which must equal --gpus); started as plain `python bench.py --gpus N`
+this file re-executes itself under torch.distributed.run with N ranks.  The default workload for N > 1 is BASELINE
+config C4: a sweep of independent filters (128 x N=1e5 per GPU) sharded over the ranks through the C ABI
+(llpf_mbank_create_rank), whose only exchange — the all-reduce of the per-filter log-likelihood vector — is an
+RCCL call inside the library on the communicator built from an id rank 0 hands out (weak scaling).
 """
 import argparse
 import json
@@ -127,58 +130,108 @@ def cpu_baseline(model, U, Y, kind, thr, n_particles, budget_steps, seed, ll_gpu
 
 def main_bank(args, rank, world, dev):
     """BASELINE config C4: a sweep of independent linear-Gaussian filters (dynamics-noise level s_k, reference
-    test/runtests.jl:412-417), filters sharded round-robin over ranks (filter k -> rank k mod world), 128 x N=1e5 per
-    GPU by default, shared u / y; the only collective is the all-reduce of the per-filter log-likelihood vector."""
+    test/runtests.jl:412-417), filter k on rank k mod world, 128 x N=1e5 per GPU by default, shared u / y, through the
+    C ABI's llpf_mbank_* handle.  The only collective is the all-reduce of the per-filter log-likelihood vector: RCCL inside
+    the library (communicator from llpf_mbank_unique_id + llpf_mbank_create_rank); with --dist-backend gloo (ranks sharing
+    a GPU: RCCL refuses that) the handle leaves the exchange to this file, which uses torch.distributed."""
     import torch
     import torch.distributed as dist
     import models as M
     from llpf_amd import _capi, _structs as S
-    from llpf_amd.distributed import shard_indices, allreduce_logliks
     T = args.T if args.T else 1000
     N = args.particles if args.particles != 1000000 else 100000
     thr = 0.1 if args.threshold is None else args.threshold
     F = args.filters_per_gpu * world
     svec = 10.0 ** np.linspace(-2, 0, F)
-    owned = shard_indices(F, rank, world)
-    models = [M.lg_test_model(svec[k]) for k in owned]
+    models = [M.lg_test_model(s) for s in svec]
     _, U, Y = M.simulate_lg(M.lg_test_model(0.1), T, seed=1)
-    cfg = S.make_config(models[0], N, S.PARTICLE_FILTER, S.RESAMPLE_SYSTEMATIC, thr, 5 + 100000 * rank, dev)
-    bank = _capi.BankHandle(cfg, models)
+    cfg = S.make_config(models[0], N, S.PARTICLE_FILTER, S.RESAMPLE_SYSTEMATIC, thr, 5, dev)
     device = args.coll_device
+    collective = "none (one shard)"
+    external = False
+    if world == 1:
+        bank = _capi.MBankHandle(cfg, models, devices=[dev])
+    elif args.dist_backend == "nccl":
+        ids = [_capi.mbank_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        ok, err = 1, ""
+        try:
+            bank = _capi.MBankHandle(cfg, models, rank=rank, world=world, unique_id=ids[0])
+            collective = "RCCL ncclAllReduce(fp64, sum) of the log-likelihood vector inside libllpf_hip.so (llpf_mbank_run)"
+        except _capi.LLPFError as e:       # reported, never silent: the line says which collective ran
+            ok, err = 0, str(e)
+        flag = torch.tensor([ok], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            bank = _capi.MBankHandle(cfg, models, rank=rank, world=world, unique_id=None)
+            external = True
+            collective = "torch.distributed all_reduce (RCCL) of the vector llpf_mbank_run returned; in-library communicator failed: " + err
+    else:
+        bank = _capi.MBankHandle(cfg, models, rank=rank, world=world, unique_id=None)
+        external = True
+        collective = "torch.distributed all_reduce (gloo, CPU tensors): ranks share a GPU"
+    info = bank.info()
 
     def one_pass():
         bank.reset()
         r = bank.run(U, Y, 1.0)
-        return allreduce_logliks(r["ll"], owned, F, device)
+        if external:
+            full = torch.as_tensor(r["ll"], device=device)
+            dist.all_reduce(full)
+            ll = full.cpu().numpy()
+            return ll, float(ll.sum())
+        return r["ll"], r["ll_sum"]
 
     for _ in range(2):                 # setup, untimed: hipGraph capture of the run shape (see main())
         one_pass()
     for _ in range(args.warmup):
         one_pass()
+    # the same per-GPU share on ONE GPU with the others idle: the reference point for the scaling of this line
+    solo = None
+    if world > 1:
+        dist.barrier()
+        if rank == 0:
+            sb = _capi.MBankHandle(cfg, models[: args.filters_per_gpu], devices=[dev])
+            for _ in range(2):
+                sb.reset(); sb.run(U, Y, 1.0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(max(1, min(args.steps, 3))):
+                sb.reset(); sb.run(U, Y, 1.0)
+            torch.cuda.synchronize()
+            solo = max(1, min(args.steps, 3)) * args.filters_per_gpu * N * T / (time.perf_counter() - t0)
+            sb.close()
+        dist.barrier()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    dev_ms = 0.0
+    dev_ms = coll_ms = 0.0
     for _ in range(args.steps):
         ll_all, ll_sum = one_pass()
-        dev_ms += bank.last_run_ms()
+        i = bank.info()
+        dev_ms += i["last_run_ms"]
+        coll_ms += i["last_collective_ms"]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    ranks_seen = [{"rank": rank, "device": dev, "filters": info["n_local_filters"], "seconds": dt}]
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        gathered = [None] * world
+        dist.all_gather_object(gathered, ranks_seen[0])
+        ranks_seen = gathered
     if rank == 0:
         bank.set_profiling(True)
         bank.reset()
         bank.run(U, Y, 1.0)
-        ms_cls, n_cls = bank.profile()
+        ms_cls, n_cls = bank.profile(0)
         bank.set_profiling(False)
         nx = 2
-        Fl = len(owned)
+        Fl = info["n_local_filters"]
         value = args.steps * F * N * T / dt
         timestep_s = dt / (args.steps * T)
         # split schedule (DESIGN.md 4): k_resprop moves 16nx+20 B per particle (read quanta 8, gather + store x 16nx,
@@ -193,23 +246,28 @@ def main_bank(args, rank, world, dev):
                "config": {"workload": "C4: sweep of %d linear-Gaussian ParticleFilters x N=%d, T=%d, threshold %g, %d per GPU" % (F, N, T, thr, args.filters_per_gpu),
                           "filters": F, "particles": N, "timesteps": T, "nx": nx, "resample_threshold": thr,
                           "resamples_per_pass_rank0": int(bank.resample_count()),
-                          "parallelism": "filters sharded round-robin over %d GPU(s), all-reduce of the log-likelihood vector" % world},
-               "device_ms_per_step": dev_ms / args.steps,
+                          "parallelism": "filter k on rank k mod %d (llpf_mbank_*), one all-reduce of the log-likelihood vector per pass" % world,
+                          "collective": collective},
+               "ranks_seen": sorted(r["rank"] for r in ranks_seen), "rank_devices": {str(r["rank"]): r["device"] for r in ranks_seen},
+               "rank_seconds": {str(r["rank"]): r["seconds"] for r in ranks_seen},
+               "device_ms_per_step": dev_ms / args.steps, "collective_ms_per_step": coll_ms / args.steps,
                "kernel_us": {"k_resprop": 1e3 * ms_cls[0] / n_cls[0], "k_norm": (1e3 * ms_cls[1] / n_cls[1]) if n_cls[1] else None},
                "argmax_sigma": float(svec[int(np.argmax(ll_all))]), "loglik_sum": ll_sum,
                "roofline": {"bound": "hbm", "kernel": "k_resprop", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                             "frac": achieved / 8000.0, "traffic": None, "bytes_per_launch": Fl * N * b_step,
                             "avg_launch_us": step_s * 1e6,
-                            "method": "hipEvent pairs around every launch on the engine stream, one profiled pass after the timed region",
+                            "method": "hipEvent pairs around every launch on the engine stream of rank 0, one profiled pass after the timed region",
                             "whole_timestep": {"algorithmic_bytes": Fl * N * b_alg, "us": timestep_s * 1e6,
                                                "achieved": Fl * N * b_alg / timestep_s / 1e9, "frac": Fl * N * b_alg / timestep_s / 8e12}}}
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01i_pmc_traffic.json")))
-            if pm["c4"]["filters"] == Fl and pm["c4"]["n_particles"] == N:
-                out["roofline"]["traffic"] = pm["c4"]["k_resprop"]["bytes"]
-                out["roofline"]["traffic_source"] = pm["c4"]["source"] + "; " + pm["correction"]
-        except Exception:
-            pass
+        if solo is not None:
+            out["one_gpu_same_share"] = {"value": solo, "unit": "particle-steps/s", "n_gpus": 1,
+                                         "note": "rank 0 alone on its per-GPU share (%d filters) while the other ranks wait: aggregate / (n_gpus x this) "
+                                                 "is the weak-scaling efficiency of this workload" % args.filters_per_gpu,
+                                         "efficiency": value / (world * solo)}
+        pm = load_pmc()
+        if pm and pm.get("c4") and pm["c4"]["filters"] == Fl and pm["c4"]["n_particles"] == N:
+            out["roofline"]["traffic"] = pm["c4"]["k_resprop"]["bytes"]
+            out["roofline"]["traffic_source"] = pm["c4"]["source"] + "; " + pm["correction"]
         if world == 1 and not args.no_cpu_baseline:
             cs = args.cpu_steps if args.cpu_steps else 1000
             out.update(cpu_baseline(models[len(models) // 2], U, Y, S.PARTICLE_FILTER, thr, N, min(cs, T), 77, None))
@@ -247,12 +305,78 @@ def main_reference_mc(args, rank, world):
     print(json.dumps(out))
 
 
+def engine_source_hash():
+    """sha256 (16 hex digits) over the engine's sources: a committed PMC summary is only quoted for the build it was taken from."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "lowlevelparticlefilters.jl_amd", "csrc")
+    files = []
+    for d, _, fs in os.walk(csrc):
+        files += [os.path.join(d, f) for f in fs if f.endswith((".hip", ".hpp", ".h"))]
+    for f in sorted(files):
+        h.update(os.path.relpath(f, csrc).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_pmc():
+    """The newest profiles/r*_pmc_traffic.json whose `engine_source_hash` matches the sources of this build, else None
+    (rocprofv3 --pmc needs passes of its own, so bench.py cannot collect HBM traffic inside its timed run; a summary taken
+    from another build of the kernels is not quoted)."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            pm = json.load(open(f))
+        except Exception:
+            continue
+        if pm.get("engine_source_hash") == engine_source_hash():
+            pm["file"] = os.path.relpath(f, ROOT)
+            return pm
+    return None
+
+
+def self_spawn(args, argv):
+    """`python bench.py --gpus N` outside a launcher: re-execute under torch.distributed.run with N ranks on this node."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+def main_spawn_check(rank, local_rank, world, backend):
+    """--spawn-check: every rank reports in and rank 0 prints what it saw; no GPU work (the CPU test of the launcher logic)."""
+    import torch
+    import torch.distributed as dist
+    me = {"rank": rank, "local_rank": local_rank, "pid": os.getpid(), "cuda_devices": torch.cuda.device_count()}
+    seen = [me]
+    if world > 1:
+        dist.init_process_group(backend="gloo")
+        seen = [None] * world
+        dist.all_gather_object(seen, me)
+    if rank == 0:
+        print(json.dumps({"spawn_check": True, "n_gpus": world, "ranks_seen": sorted(r["rank"] for r in seen),
+                          "distinct_processes": len({r["pid"] for r in seen}), "ranks": seen}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="lg", choices=["lg", "quadtank", "aux", "bank", "rbpf", "rbpf_full", "reference_mc"])
+    ap.add_argument("--workload", default=None, choices=["lg", "quadtank", "aux", "bank", "rbpf", "rbpf_full", "reference_mc"],
+                    help="default: lg (BASELINE config C2) on one GPU, bank (BASELINE config C4, the sharded sweep) on several")
+    ap.add_argument("--spawn-check", action="store_true", help="only start the ranks and report them (no GPU work)")
     ap.add_argument("--filters-per-gpu", type=int, default=128, help="bank workload (BASELINE config C4): filters per GPU")
     ap.add_argument("--particles", type=int, default=1000000)
     ap.add_argument("--T", type=int, default=None)
@@ -263,13 +387,24 @@ def main():
                     help="nccl (= RCCL) is the measured path; gloo only exercises the multi-rank logic on a box with fewer GPUs than "
                          "ranks (collectives on CPU tensors, ranks share devices)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_spawn(args, sys.argv[1:]))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks; they must agree" % (args.gpus, world))
+    if args.workload is None:
+        args.workload = "lg" if world == 1 else "bank"
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.spawn_check:
+        return main_spawn_check(rank, local_rank, world, args.dist_backend)
 
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     dev = 0
     if world > 1 and args.dist_backend == "nccl":
         dev = local_rank
@@ -426,21 +561,24 @@ def main():
                                "peak_tflops": 78.6, "frac": N * flop / step_s / 78.6e12,
                                "note": "k_step is instruction-issue bound (about 700 fp64 + 500 other VALU instructions per particle); "
                                        "the HBM figures above are reported as the contract asks but do not bound this workload"}
-        # HBM traffic of the dominant kernel from the committed PMC profile of this same workload (cannot be collected
-        # inside bench.py: rocprofv3 --pmc needs its own passes); only quoted when shapes match
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01i_pmc_traffic.json")))
-            if one_launch and pm["n_particles"] == N and pm["nx"] == nx and args.workload == "lg" and thr == pm["resample_threshold"]:
-                roof["traffic"] = pm["k_resprop"]["bytes"]
-                roof["traffic_source"] = pm["source"] + "; " + pm["correction"]
-            if args.workload == "quadtank" and pm["c3"]["n_particles"] == N and not fused:
-                roof["traffic"] = pm["c3"]["k_step"]["bytes"]
-                roof["traffic_source"] = pm["c3"]["source"] + "; " + pm["correction"] + "; " + pm["c3"]["k_step"]["note"]
-            if rbfull and pm["c5"]["n_particles"] == N:
-                roof["traffic"] = pm["c5"]["k_rbfull"]["bytes"]
-                roof["traffic_source"] = pm["c5"]["source"] + "; " + pm["correction"]
-        except Exception:
-            pass
+        # HBM traffic of the dominant kernel from the committed PMC summary of this same workload AND build (cannot be
+        # collected inside bench.py: rocprofv3 --pmc needs its own passes); quoted only when shapes and source hash match
+        pm = load_pmc()
+        if pm is None:
+            roof["traffic_source"] = "no profiles/r*_pmc_traffic.json matches this build's engine_source_hash %s: not quoted" % engine_source_hash()
+        else:
+            try:
+                if one_launch and pm["n_particles"] == N and pm["nx"] == nx and args.workload == "lg" and thr == pm["resample_threshold"]:
+                    roof["traffic"] = pm["k_resprop"]["bytes"]
+                    roof["traffic_source"] = pm["file"] + ": " + pm["source"] + "; " + pm["correction"]
+                if args.workload == "quadtank" and pm["c3"]["n_particles"] == N:
+                    roof["traffic"] = pm["c3"][roof["kernel"].split("<")[0]]["bytes"]
+                    roof["traffic_source"] = pm["file"] + ": " + pm["c3"]["source"] + "; " + pm["correction"]
+                if rbfull and pm["c5"]["n_particles"] == N:
+                    roof["traffic"] = pm["c5"]["k_rbfull"]["bytes"]
+                    roof["traffic_source"] = pm["file"] + ": " + pm["c5"]["source"] + "; " + pm["correction"]
+            except KeyError:
+                pass
         out = {"metric": "particle-steps/s", "value": value, "unit": "particle-steps/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",

@@ -33,7 +33,7 @@ extern "C" {
 #endif
 
 #define LLPF_VERSION_MAJOR 0
-#define LLPF_VERSION_MINOR 3
+#define LLPF_VERSION_MINOR 4
 #define LLPF_MAX_DIM 8
 
 /* status codes */
@@ -268,6 +268,57 @@ int  llpf_bank_run_multi(llpf_bank* b, const double* U, const double* Y, int64_t
 /* as llpf_aux_run for every filter of the bank (the ML sweep over AuxiliaryParticleFilters, test/runtests.jl:419-423) */
 int  llpf_bank_aux_run(llpf_bank* b, const double* U, const double* Y, int64_t T, int32_t mode,
                        double* ll_total, double* ll_steps);
+
+/* ---- sweeps sharded over the GPUs of one node (multi-GPU banks) ------------------------------
+ * The same sweep as llpf_bank_*, with filter k on shard k mod n_shards (one shard = one GPU, one stream): the reference's
+ * one-filter-per-thread layout (src/smoothing.jl:335-347, test/runtests.jl:412-417) with GPUs for threads.  Filters never
+ * interact; the only exchange of the path is the all-reduce (sum) of the per-filter log-likelihood vector after a run —
+ * every shard contributes its own slots and zeros — done with RCCL over xGMI on device buffers.  Filter k's RNG key is
+ * seed + k wherever it lives, and a slot has exactly one non-zero contribution, so a sharded sweep returns the bits of
+ * the unsharded llpf_bank_run.
+ *   llpf_mbank_create       one process drives n_devices GPUs (one host thread per GPU inside the calls); communicator from
+ *                           ncclCommInitAll.  n_devices == 1: no communicator, no RCCL call (llpf_bank_* behind another
+ *                           handle).  A device listed twice: shards share that GPU and the vectors are summed on the host
+ *                           (RCCL refuses two ranks on one device) — for testing the sharding on a one-GPU box.
+ *   llpf_mbank_unique_id /  one process per GPU (torchrun, MPI, Julia Distributed): rank 0 obtains an id (ncclGetUniqueId),
+ *   llpf_mbank_create_rank  the host distributes its 128 bytes, every rank r of `world` creates its shard on base->device
+ *                           (ncclCommInitRank).  id == NULL with world > 1: no communicator; llpf_mbank_run then returns
+ *                           this rank's slots (zeros elsewhere) and the caller owns the exchange.
+ * `models` is NULL (replicas of base->model) or holds all n_filters descriptors, in every process.
+ * librccl is loaded on first use (dlopen); LLPF_ERR_HIP with the loader's / RCCL's message if that fails. */
+#define LLPF_MBANK_ID_BYTES 128
+typedef struct llpf_mbank llpf_mbank;     /* opaque: shards + communicator */
+int  llpf_mbank_create(const llpf_config* base, const llpf_model* models, int32_t n_filters,
+                       const int32_t* devices, int32_t n_devices, llpf_mbank** out);
+int  llpf_mbank_unique_id(uint8_t* id /* LLPF_MBANK_ID_BYTES */);
+int  llpf_mbank_create_rank(const llpf_config* base, const llpf_model* models, int32_t n_filters,
+                            int32_t rank, int32_t world, const uint8_t* id /* LLPF_MBANK_ID_BYTES or NULL */, llpf_mbank** out);
+int  llpf_mbank_destroy(llpf_mbank* m);
+int  llpf_mbank_reset(llpf_mbank* m);
+int  llpf_mbank_seed(llpf_mbank* m, uint64_t seed);
+/* as llpf_bank_run on every shard, then the exchange: ll_total [n_filters] holds every filter's log-likelihood in every
+ * process, *ll_sum their sum in index order (the global log-likelihood of the sweep); either may be NULL */
+int  llpf_mbank_run(llpf_mbank* m, const double* U, const double* Y, int64_t T, double t_index0,
+                    double* ll_total, double* ll_sum);
+/* as llpf_bank_aux_run on every shard (mode as llpf_aux_run), then the same exchange */
+int  llpf_mbank_aux_run(llpf_mbank* m, const double* U, const double* Y, int64_t T, int32_t mode,
+                        double* ll_total, double* ll_sum);
+enum { LLPF_MBANK_COLL_NONE = 0, LLPF_MBANK_COLL_RCCL = 1, LLPF_MBANK_COLL_HOST = 2, LLPF_MBANK_COLL_EXTERNAL = 3 };
+typedef struct llpf_mbank_info_t {
+    int32_t n_filters;            /* of the whole sweep                                                  */
+    int32_t n_shards;             /* of the whole sweep (all processes)                                  */
+    int32_t n_local_shards;       /* shards this handle drives                                           */
+    int32_t first_local_shard;    /* global index of the first of them (= rank with one process per GPU) */
+    int32_t n_local_filters;
+    int32_t collective;           /* LLPF_MBANK_COLL_*: how the log-likelihood vector is exchanged       */
+    double  last_run_ms;          /* device time of the last run: slowest local shard (hipEvents)        */
+    double  last_collective_ms;   /* host time of the last exchange                                      */
+    int64_t resample_count;       /* resampling predict! calls of the last run, summed over local filters */
+} llpf_mbank_info_t;
+int  llpf_mbank_info(llpf_mbank* m, llpf_mbank_info_t* info);
+int  llpf_mbank_local_devices(llpf_mbank* m, int32_t* devices /* n_local_shards */);
+int  llpf_mbank_set_profiling(llpf_mbank* m, int32_t on);
+int  llpf_mbank_get_profile(llpf_mbank* m, int32_t local_shard, double* ms, int64_t* launches);
 
 /* ---- measurement ------------------------------------------------------------------------ */
 /* when enabled, every kernel launch of llpf_run / llpf_bank_run is bracketed by hipEvents on the

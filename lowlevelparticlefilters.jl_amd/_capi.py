@@ -60,6 +60,18 @@ SYMBOLS = {
     "llpf_bank_seed": [_vp, C.c_uint64],
     "llpf_bank_run": [_vp, _dp, _dp, C.c_int64, C.c_double, _dp, _dp],
     "llpf_bank_run_multi": [_vp, _dp, _dp, C.c_int64, C.c_double, _dp, _dp, _dp],
+    "llpf_mbank_create": [C.POINTER(S.Config), C.POINTER(S.Model), C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.POINTER(_vp)],
+    "llpf_mbank_unique_id": [C.POINTER(C.c_uint8)],
+    "llpf_mbank_create_rank": [C.POINTER(S.Config), C.POINTER(S.Model), C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_uint8), C.POINTER(_vp)],
+    "llpf_mbank_destroy": [_vp],
+    "llpf_mbank_reset": [_vp],
+    "llpf_mbank_seed": [_vp, C.c_uint64],
+    "llpf_mbank_run": [_vp, _dp, _dp, C.c_int64, C.c_double, _dp, _dp],
+    "llpf_mbank_aux_run": [_vp, _dp, _dp, C.c_int64, C.c_int32, _dp, _dp],
+    "llpf_mbank_info": [_vp, C.POINTER(S.MBankInfo)],
+    "llpf_mbank_local_devices": [_vp, C.POINTER(C.c_int32)],
+    "llpf_mbank_set_profiling": [_vp, C.c_int32],
+    "llpf_mbank_get_profile": [_vp, C.c_int32, _dp, _ip],
     "llpf_set_profiling": [_vp, C.c_int32],
     "llpf_get_profile": [_vp, _dp, _ip],
     "llpf_bank_set_profiling": [_vp, C.c_int32],
@@ -454,6 +466,114 @@ class BankHandle:
         ms = np.zeros(PROF_CLASSES)
         n = np.zeros(PROF_CLASSES, dtype=np.int64)
         check(self.L.llpf_bank_get_profile(self.h, dptr(ms), iptr(n)))
+        return ms, n
+
+MBANK_ID_BYTES = 128
+MBANK_COLL = {0: "none", 1: "rccl", 2: "host", 3: "external"}
+
+
+def mbank_unique_id():
+    """ncclGetUniqueId through the C ABI (rank 0 of a one-process-per-GPU job; the host distributes the bytes)."""
+    buf = (C.c_uint8 * MBANK_ID_BYTES)()
+    check(lib().llpf_mbank_unique_id(buf))
+    return bytes(buf)
+
+
+class MBankHandle:
+    """RAII wrapper of an `llpf_mbank*`: a sweep of independent filters sharded over GPUs, filter k on shard k mod n_shards;
+    the exchange of the log-likelihood vector (RCCL) happens inside run().
+
+    devices=[...]             : this process drives all listed GPUs (llpf_mbank_create)
+    rank=, world=, unique_id= : one process per GPU (llpf_mbank_create_rank); unique_id None with world > 1 leaves the
+                                exchange to the caller (run() then returns this rank's slots, zeros elsewhere)"""
+
+    def __init__(self, base_cfg, models=None, n_filters=None, devices=None, rank=None, world=None, unique_id=None):
+        self.L = lib()
+        self.cfg = base_cfg
+        self.h = _vp()
+        if models is None:
+            self.F = int(n_filters)
+            arr = None
+            m0 = base_cfg.model
+        else:
+            self.F = len(models)
+            arr = (S.Model * self.F)(*models)
+            m0 = models[0]
+        self._models = arr
+        if rank is None:
+            devs = list(devices if devices is not None else [base_cfg.device])
+            darr = (C.c_int32 * len(devs))(*devs)
+            check(self.L.llpf_mbank_create(C.byref(base_cfg), arr, self.F, darr, len(devs), C.byref(self.h)))
+        else:
+            idp = None
+            if unique_id is not None:
+                if len(unique_id) != MBANK_ID_BYTES:
+                    raise ValueError("unique_id must have %d bytes" % MBANK_ID_BYTES)
+                idp = (C.c_uint8 * MBANK_ID_BYTES)(*unique_id)
+            check(self.L.llpf_mbank_create_rank(C.byref(base_cfg), arr, self.F, int(rank), int(world), idp, C.byref(self.h)))
+        self.N = int(base_cfg.n_particles)
+        self.nx, self.nu, self.ny = m0.nx, m0.nu, m0.ny
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.llpf_mbank_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        check(self.L.llpf_mbank_reset(self.h))
+
+    def seed(self, s):
+        check(self.L.llpf_mbank_seed(self.h, int(s) & 0xFFFFFFFFFFFFFFFF))
+
+    def _io(self, U, Y):
+        Y = f64(Y).reshape(-1, self.ny)
+        T = Y.shape[0]
+        U = f64(U).reshape(T, self.nu) if self.nu else None
+        return U, Y, T
+
+    def run(self, U, Y, t_index0=0.0):
+        U, Y, T = self._io(U, Y)
+        ll = np.zeros(self.F)
+        tot = C.c_double(0)
+        check(self.L.llpf_mbank_run(self.h, dptr(U), dptr(Y), T, float(t_index0), dptr(ll), C.byref(tot)))
+        return {"ll": ll, "ll_sum": tot.value}
+
+    def run_aux(self, U, Y, mode=1):
+        U, Y, T = self._io(U, Y)
+        ll = np.zeros(self.F)
+        tot = C.c_double(0)
+        check(self.L.llpf_mbank_aux_run(self.h, dptr(U), dptr(Y), T, int(mode), dptr(ll), C.byref(tot)))
+        return {"ll": ll, "ll_sum": tot.value}
+
+    def info(self):
+        i = S.MBankInfo()
+        check(self.L.llpf_mbank_info(self.h, C.byref(i)))
+        d = {k: getattr(i, k) for k, _ in S.MBankInfo._fields_}
+        d["collective"] = MBANK_COLL.get(d["collective"], d["collective"])
+        devs = (C.c_int32 * max(1, i.n_local_shards))()
+        check(self.L.llpf_mbank_local_devices(self.h, devs))
+        d["local_devices"] = list(devs)[: i.n_local_shards]
+        return d
+
+    def last_run_ms(self):
+        return self.info()["last_run_ms"]
+
+    def resample_count(self):
+        return self.info()["resample_count"]
+
+    def set_profiling(self, on):
+        check(self.L.llpf_mbank_set_profiling(self.h, 1 if on else 0))
+
+    def profile(self, local_shard=0):
+        ms = np.zeros(PROF_CLASSES)
+        n = np.zeros(PROF_CLASSES, dtype=np.int64)
+        check(self.L.llpf_mbank_get_profile(self.h, int(local_shard), dptr(ms), iptr(n)))
         return ms, n
 
 

@@ -53,6 +53,12 @@ class RunOutputs(C.Structure):
                 ("we_hist", C.POINTER(C.c_double))]
 
 
+class MBankInfo(C.Structure):
+    _fields_ = [("n_filters", C.c_int32), ("n_shards", C.c_int32), ("n_local_shards", C.c_int32),
+                ("first_local_shard", C.c_int32), ("n_local_filters", C.c_int32), ("collective", C.c_int32),
+                ("last_run_ms", C.c_double), ("last_collective_ms", C.c_double), ("resample_count", C.c_int64)]
+
+
 def make_gaussian(mu, cov, kind=None):
     """N(mu, cov).  cov: python float -> ScalMat(sigma^2 = cov); 1-D array -> PDiagMat(diag = cov);
     2-D array -> PDMat(cov).  `kind` forces a storage kind (e.g. a diagonal 2-D matrix as FULL)."""

@@ -47,6 +47,7 @@ static int fail(int code, const std::string& msg) {
 #include "host/aux.hpp"
 #include "host/smooth.hpp"
 #include "host/access.hpp"
+#include "host/mbank.hpp"
 
 // ------------------------------------------------------------------------------------------------
 // C ABI
@@ -326,6 +327,138 @@ int llpf_bank_set_profiling(llpf_bank* b, int32_t on) { NEEDF(b); return set_pro
 int llpf_bank_get_profile(llpf_bank* b, double* ms, int64_t* n) { NEEDF(b); return get_prof(b->bank, ms, n); }
 int llpf_bank_resample_count(llpf_bank* b, int64_t* n) { NEEDF(b); if (n) *n = b->bank.run_resamples; return LLPF_OK; }
 int llpf_bank_last_run_ms(llpf_bank* b, double* ms) { NEEDF(b); if (ms) *ms = b->bank.last_run_ms; return LLPF_OK; }
+
+
+// ---- sweeps sharded over the GPUs of a node (host/mbank.hpp) ---------------------------------------
+static int mbank_env_collective(bool distinct, int n_shards_total) {
+    if (n_shards_total == 1) { const char* e = getenv("LLPF_MBANK_FORCE_RCCL"); return (e && atoi(e)) ? MBANK_COLL_RCCL : MBANK_COLL_NONE; }
+    return distinct ? MBANK_COLL_RCCL : MBANK_COLL_HOST;
+}
+int llpf_mbank_create(const llpf_config* base, const llpf_model* models, int32_t n_filters, const int32_t* devices,
+                      int32_t n_devices, llpf_mbank** out) {
+    if (!out) return fail(LLPF_ERR_ARG, "null out pointer");
+    *out = nullptr;
+    if (!devices || n_devices < 1) return fail(LLPF_ERR_ARG, "empty device list");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(LLPF_ERR_NO_DEVICE, "no HIP device visible; this engine has no CPU fallback");
+    bool distinct = true;
+    for (int i = 0; i < n_devices; ++i) {
+        if (devices[i] < 0 || devices[i] >= ndev) return fail(LLPF_ERR_ARG, "device ordinal out of range");
+        for (int j = 0; j < i; ++j) if (devices[j] == devices[i]) distinct = false;
+    }
+    llpf_mbank* m = new (std::nothrow) llpf_mbank();
+    if (!m) return fail(LLPF_ERR_ALLOC, "out of host memory");
+    int rc = mbank_build(m, base, models, n_filters, devices, n_devices, 0, n_devices);
+    if (rc == LLPF_OK) {
+        m->collective = mbank_env_collective(distinct, n_devices);
+        if (m->collective == MBANK_COLL_RCCL) {
+            rccl_dl::Api* R = rccl_dl::api();
+            if (!R->handle) rc = fail(LLPF_ERR_HIP, R->err);
+            else {
+                std::vector<rccl_dl::comm_t> comms((size_t)n_devices, nullptr);
+                std::vector<int> devs(devices, devices + n_devices);
+                (void)hipGetLastError();      // RCCL reads the runtime's sticky last-error after its own launches: start clean
+                rccl_dl::result_t r = R->CommInitAll(comms.data(), n_devices, devs.data());
+                if (r != rccl_dl::Success) rc = fail(LLPF_ERR_HIP, std::string("ncclCommInitAll: ") + R->GetErrorString(r));
+                else for (int i = 0; i < n_devices; ++i) m->shards[i]->comm = comms[i];
+            }
+        }
+    }
+    if (rc != LLPF_OK) { const std::string keep = g_err; mbank_free(m); g_err = keep; return rc; }
+    *out = m;
+    return LLPF_OK;
+}
+int llpf_mbank_unique_id(uint8_t* id) {
+    if (!id) return fail(LLPF_ERR_ARG, "null id");
+    rccl_dl::Api* R = rccl_dl::api();
+    if (!R->handle) return fail(LLPF_ERR_HIP, R->err);
+    rccl_dl::unique_id u;
+    RCCLC(R->GetUniqueId(&u));
+    memcpy(id, u.internal, LLPF_MBANK_ID_BYTES);
+    return LLPF_OK;
+}
+int llpf_mbank_create_rank(const llpf_config* base, const llpf_model* models, int32_t n_filters, int32_t rank, int32_t world,
+                           const uint8_t* id, llpf_mbank** out) {
+    if (!out) return fail(LLPF_ERR_ARG, "null out pointer");
+    *out = nullptr;
+    if (!base) return fail(LLPF_ERR_ARG, "null config");
+    if (world < 1 || rank < 0 || rank >= world) return fail(LLPF_ERR_ARG, "rank / world out of range");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(LLPF_ERR_NO_DEVICE, "no HIP device visible; this engine has no CPU fallback");
+    llpf_mbank* m = new (std::nothrow) llpf_mbank();
+    if (!m) return fail(LLPF_ERR_ALLOC, "out of host memory");
+    const int32_t dev = base->device;
+    int rc = mbank_build(m, base, models, n_filters, &dev, 1, rank, world);
+    if (rc == LLPF_OK) {
+        m->collective = id ? MBANK_COLL_RCCL : (world > 1 ? MBANK_COLL_EXTERNAL : mbank_env_collective(true, 1));
+        if (m->collective == MBANK_COLL_RCCL) {
+            rccl_dl::Api* R = rccl_dl::api();
+            if (!R->handle) rc = fail(LLPF_ERR_HIP, R->err);
+            else {
+                rccl_dl::unique_id u;
+                if (id) memcpy(u.internal, id, LLPF_MBANK_ID_BYTES);
+                else { rccl_dl::result_t r0 = R->GetUniqueId(&u); if (r0 != rccl_dl::Success) rc = fail(LLPF_ERR_HIP, std::string("ncclGetUniqueId: ") + R->GetErrorString(r0)); }
+                if (rc == LLPF_OK) {
+                    hipSetDevice(dev);
+                    (void)hipGetLastError();
+                    rccl_dl::result_t r = R->CommInitRank(&m->shards[0]->comm, world, u, rank);
+                    if (r != rccl_dl::Success) rc = fail(LLPF_ERR_HIP, std::string("ncclCommInitRank: ") + R->GetErrorString(r));
+                }
+            }
+        }
+    }
+    if (rc != LLPF_OK) { const std::string keep = g_err; mbank_free(m); g_err = keep; return rc; }
+    *out = m;
+    return LLPF_OK;
+}
+int llpf_mbank_destroy(llpf_mbank* m) { mbank_free(m); return LLPF_OK; }
+int llpf_mbank_reset(llpf_mbank* m) {
+    NEEDF(m);
+    return mbank_foreach(*m, [&](int s) -> int { Bank& b = m->shards[s]->bank; CHK(use_device(b)); return bank_init_particles(b, true); });
+}
+int llpf_mbank_seed(llpf_mbank* m, uint64_t seed) {
+    NEEDF(m);
+    return mbank_foreach(*m, [&](int s) -> int { return bank_seed(m->shards[s]->bank, seed); });
+}
+int llpf_mbank_run(llpf_mbank* m, const double* U, const double* Y, int64_t T, double t_index0, double* ll_total, double* ll_sum) {
+    NEEDF(m);
+    return mbank_run(*m, U, Y, T, t_index0, ll_total, ll_sum, false, 0);
+}
+int llpf_mbank_aux_run(llpf_mbank* m, const double* U, const double* Y, int64_t T, int32_t mode, double* ll_total, double* ll_sum) {
+    NEEDF(m);
+    return mbank_run(*m, U, Y, T, 0.0, ll_total, ll_sum, true, mode);
+}
+int llpf_mbank_info(llpf_mbank* m, llpf_mbank_info_t* info) {
+    NEEDF(m);
+    if (!info) return fail(LLPF_ERR_ARG, "null info");
+    info->n_filters = m->n_filters;
+    info->n_shards = m->n_shards_total;
+    info->n_local_shards = (int32_t)m->shards.size();
+    info->first_local_shard = m->first_shard;
+    info->collective = m->collective;
+    info->n_local_filters = 0;
+    for (auto& sp : m->shards) info->n_local_filters += (int32_t)sp->owned.size();
+    info->last_run_ms = m->last_run_ms;
+    info->last_collective_ms = m->last_coll_ms;
+    info->resample_count = 0;
+    for (auto& sp : m->shards) info->resample_count += sp->bank.run_resamples;
+    return LLPF_OK;
+}
+int llpf_mbank_local_devices(llpf_mbank* m, int32_t* devices) {
+    NEEDF(m);
+    for (size_t s = 0; s < m->shards.size(); ++s) devices[s] = m->shards[s]->device;
+    return LLPF_OK;
+}
+int llpf_mbank_set_profiling(llpf_mbank* m, int32_t on) {
+    NEEDF(m);
+    for (auto& sp : m->shards) set_prof(sp->bank, on);
+    return LLPF_OK;
+}
+int llpf_mbank_get_profile(llpf_mbank* m, int32_t local_shard, double* ms, int64_t* n) {
+    NEEDF(m);
+    if (local_shard < 0 || local_shard >= (int32_t)m->shards.size()) return fail(LLPF_ERR_ARG, "local shard out of range");
+    return get_prof(m->shards[local_shard]->bank, ms, n);
+}
 
 // ---- array primitives ------------------------------------------------------------------------------
 // a scratch single-filter context with a dummy 1-D model, used for weights-only operations

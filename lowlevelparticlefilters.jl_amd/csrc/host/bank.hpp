@@ -45,6 +45,8 @@ struct Bank {
     size_t cap_ll = 0, cap_xm = 0;
     double* d_tmp = nullptr;         // F*N*max(nx,1) doubles (also reinterpreted as int64 / double staging)
     uint64_t seed = 0;
+    uint64_t key_off = 0, key_stride = 1;   // filter f of this bank is filter key_off + f * key_stride of a sharded sweep (llpf_mbank): its
+                                            // Philox key is seed + that global index, so results do not depend on the sharding
     uint32_t n_reset = 0, n_predict = 0;
     uint32_t step_base = 0;           // value of FilterScal::step_base on the device: kernels add it to the step arguments
     // Captured run loops (hipGraph): a chain of T dependent launches replays ~1 us per launch faster than it enqueues
@@ -144,7 +146,7 @@ static void set_keys(Bank& b, std::vector<FilterScal>& h, uint64_t seed) {
     b.step_base = 0;
     for (int f = 0; f < b.F; ++f) {
         h[f].step_base = 0;
-        const uint64_t s = seed + (uint64_t)f;
+        const uint64_t s = seed + b.key_off + (uint64_t)f * b.key_stride;
         h[f].k0 = (uint32_t)s;
         h[f].k1 = (uint32_t)(s >> 32);
     }
@@ -220,7 +222,7 @@ static int bank_init_particles(Bank& b, bool is_reset) {
     return LLPF_OK;
 }
 
-static int bank_create(const llpf_config* cfg, const llpf_model* models, int F, Bank& b) {
+static int bank_create(const llpf_config* cfg, const llpf_model* models, int F, Bank& b, uint64_t key_off = 0, uint64_t key_stride = 1) {
     if (!cfg) return fail(LLPF_ERR_ARG, "null config");
     if (cfg->struct_size != sizeof(llpf_config)) return fail(LLPF_ERR_ARG, "llpf_config.struct_size mismatch (ABI)");
     if (F < 1) return fail(LLPF_ERR_ARG, "n_filters must be >= 1");
@@ -246,6 +248,7 @@ static int bank_create(const llpf_config* cfg, const llpf_model* models, int F, 
 
     b.cfg = *cfg;
     b.cfg.model = m0;
+    b.key_off = key_off; b.key_stride = key_stride;
     b.F = F;
     b.N = cfg->n_particles;
     b.Ns = (b.N + TILE - 1) / TILE * TILE;

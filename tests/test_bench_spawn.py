@@ -1,0 +1,36 @@
+"""bench.py's launcher logic on CPU: `--gpus N` without a launcher starts N ranks itself; a launcher whose WORLD_SIZE
+disagrees with --gpus is an error (a scaling run must never silently measure one GPU)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _env(**kw):
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(kw)
+    return env
+
+
+def test_gpus_flag_spawns_that_many_ranks():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--spawn-check"],
+                         env=_env(), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["n_gpus"] == 2 and r["ranks_seen"] == [0, 1] and r["distinct_processes"] == 2
+
+
+def test_world_size_must_agree_with_gpus():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--spawn-check"],
+                         env=_env(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "must agree" in out.stderr
+
+
+def test_single_rank_spawn_check():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--spawn-check"], env=_env(), capture_output=True, text=True, timeout=120)
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    assert r["n_gpus"] == 1 and r["ranks_seen"] == [0]
