@@ -1,6 +1,12 @@
-"""The Julia wrapper cannot be executed in this image; this keeps its C-struct mirrors honest: the byte size of every
-`struct C...` of julia/LLPFAmd.jl (computed from its field declarations) must equal the size of the ctypes mirror of the
-same struct of include/llpf.h (lowlevelparticlefilters.jl_amd/_structs.py), and the model ids / strategy codes must agree."""
+"""The Julia wrapper cannot be executed in this image (no julia binary); these checks keep it honest statically:
+  * every `struct C...` of julia/LLPFAmd.jl mirrors the C struct of include/llpf.h field by field: same field names in the
+    same order, same byte OFFSET of every field and same total size as the ctypes mirror (_structs.py, itself pinned to
+    the header by the compiled example and tests/test_capi_symbols.py);
+  * the filter type is a subtype of the reference's AbstractParticleFilter and every verb the wrapper defines for it is
+    a method of the REFERENCE'S function (imported from LowLevelParticleFilters, or written LowLevelParticleFilters.f),
+    never a new function of the same name;
+  * every ccall names a symbol of the header and passes as many arguments as the C prototype has;
+  * model ids / strategy codes agree with the header; the constructor takes the reference's keywords."""
 import ctypes as C
 import os
 import re
@@ -9,8 +15,9 @@ from llpf_amd import _structs as S
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 JL = os.path.join(ROOT, "lowlevelparticlefilters.jl_amd", "julia", "LLPFAmd.jl")
+HDR = os.path.join(ROOT, "include", "llpf.h")
 
-PRIM = {"Int32": (4, 4), "UInt32": (4, 4), "Int64": (8, 8), "UInt64": (8, 8), "Float64": (8, 8), "Cint": (4, 4)}
+PRIM = {"Int32": (4, 4), "UInt32": (4, 4), "Int64": (8, 8), "UInt64": (8, 8), "Float64": (8, 8), "Cint": (4, 4), "UInt8": (1, 1)}
 
 
 def _parse_structs(text):
@@ -21,7 +28,8 @@ def _parse_structs(text):
         for decl in re.split(r"[;\n]", body):
             decl = decl.strip()
             if "::" in decl:
-                fields.append(decl.split("::", 1)[1].strip())
+                name, typ = decl.split("::", 1)
+                fields.append((name.strip(), typ.strip()))
         out[m.group(1)] = fields
     return out
 
@@ -36,34 +44,130 @@ def _size_align(t, structs):
         s, a = _size_align(m.group(2), structs)
         return s * int(m.group(1)), a
     off, al = 0, 1
-    for f in structs[t]:
+    for _, f in structs[t]:
         s, a = _size_align(f, structs)
         off = (off + a - 1) // a * a + s
         al = max(al, a)
     return (off + al - 1) // al * al, al
 
 
-def test_julia_struct_sizes_match_the_c_abi():
+def _offsets(name, structs):
+    off, res = 0, []
+    for fname, t in structs[name]:
+        s, a = _size_align(t, structs)
+        off = (off + a - 1) // a * a
+        res.append((fname, off, s))
+        off += s
+    return res
+
+
+PAIRS = {"CGaussian": S.Gaussian, "CRBCoupling": S.RBCoupling, "CModel": S.Model, "CConfig": S.Config,
+         "CRunOutputs": S.RunOutputs, "CMBankInfo": S.MBankInfo}
+
+
+def test_julia_struct_layouts_match_the_c_abi_field_by_field():
     structs = _parse_structs(open(JL).read())
-    pairs = {"CGaussian": S.Gaussian, "CRBCoupling": S.RBCoupling, "CModel": S.Model, "CConfig": S.Config, "CRunOutputs": S.RunOutputs}
-    for name, ct in pairs.items():
+    for name, ct in PAIRS.items():
         assert name in structs, name
+        jl = _offsets(name, structs)
+        cf = [(f[0], getattr(ct, f[0]).offset, getattr(ct, f[0]).size) for f in ct._fields_]
+        assert [f[0] for f in jl] == [f[0] for f in cf], (name, "field names / order", jl, cf)
+        assert jl == cf, (name, "offsets / sizes", jl, cf)
         assert _size_align(name, structs)[0] == C.sizeof(ct), (name, _size_align(name, structs)[0], C.sizeof(ct))
 
 
-def test_julia_model_ids_match_the_header():
+def test_ctypes_mirror_field_names_follow_the_header():
+    """the ctypes structs the Julia mirrors are compared with carry the header's own field names, in order"""
+    hdr = re.sub(r"/\*.*?\*/", "", open(HDR).read(), flags=re.S)
+    for cname, ct in (("llpf_gaussian", S.Gaussian), ("llpf_rb_coupling", S.RBCoupling), ("llpf_model", S.Model), ("llpf_config", S.Config),
+                      ("llpf_run_outputs", S.RunOutputs), ("llpf_mbank_info_t", S.MBankInfo)):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), hdr, re.S).group(1)
+        names = []
+        for d in body.split(";"):
+            if d.strip():                      # "<type> a, b[..], *c": drop the type word and the array bounds
+                rest = re.match(r"\s*(?:const\s+)?\w+[\s*]+(.*)$", re.sub(r"\[[^\]]*\]", "", d.strip()), re.S).group(1)
+                names += [n.strip().lstrip("*") for n in rest.split(",")]
+        assert names == [f[0] for f in ct._fields_], (cname, names)
+
+
+def test_filter_type_subtypes_the_reference_and_verbs_are_the_references_functions():
     jl = open(JL).read()
-    hdr = open(os.path.join(ROOT, "include", "llpf.h")).read()
+    assert re.search(r"mutable struct GPUParticleFilter\{[^}]*\} <: AbstractParticleFilter", jl)
+    assert re.search(r"struct GPUAuxiliaryParticleFilter\{[^}]*\} <: AbstractParticleFilter", jl)
+    imp = re.search(r"^import LowLevelParticleFilters:(.*?)\n\n", jl, re.S | re.M).group(1)
+    imported = set(re.findall(r"[\w!]+", imp))
+    assert "AbstractParticleFilter" in imported and "ParticleFilteringSolution" in imported
+    verbs = ["reset!", "predict!", "correct!", "update!", "forward_trajectory", "loglik", "smooth", "particles", "weights", "expweights",
+             "state", "num_particles", "index", "particletype", "parameters", "effective_particles", "shouldresample", "weighted_mean",
+             "dynamics", "measurement", "dynamics_density", "measurement_density", "initial_density", "resample_threshold",
+             "resampling_strategy", "sample_state"]
+    for v in verbs:
+        assert v in imported, "verb %s is not imported from LowLevelParticleFilters: a definition would shadow, not extend" % v
+        assert re.search(r"^(function )?%s\((pf|a|::)[^)]*::(GPF|GAPF)" % re.escape(v), jl, re.M) or \
+            re.search(r":%s\b" % re.escape(v), jl), "no method of %s for the GPU filter" % v
+    # nothing the wrapper exports collides with a name the reference exports (both can be `using`-ed together)
+    ref_exports = {"ParticleFilter", "AuxiliaryParticleFilter", "AdvancedParticleFilter", "RBPF", "reset!", "predict!", "correct!", "update!",
+                   "forward_trajectory", "loglik", "smooth", "particles", "weights", "expweights", "state", "index", "num_particles",
+                   "effective_particles", "shouldresample", "weighted_mean", "mean_trajectory", "mode_trajectory", "simulate"}
+    exported = set(re.findall(r"[\w!]+", re.search(r"^export (.*?)\n\n", jl, re.S | re.M).group(1)))
+    assert not (exported & ref_exports), exported & ref_exports
+    # forward_trajectory returns the reference's solution type, built with its 7-argument constructor (src/solutions.jl:345)
+    assert len(re.findall(r"ParticleFilteringSolution\((pf|a), u, y, svec_history\(x, Val\(NX\)\), w, we, ll\)", jl)) == 2
+    # constructor: the reference's positional arguments and keywords (src/PFtypes.jl:21-36, 65-75)
+    ctor = re.search(r"function GPUParticleFilter\(N::Integer, dynamics, measurement, dynamics_density, measurement_density, initial_density;(.*?)\)\n", jl, re.S).group(1)
+    for kw in ("resample_threshold = 0.1", "resampling_strategy::Type{<:ResamplingStrategy} = ResampleSystematic", "p = NullParameters()", "Ts = 1.0", "rng"):
+        assert kw in ctor, kw
+    assert "resample_threshold = 0.5" in re.search(r"function GPUAdvancedParticleFilter\((.*?)\)\n", jl, re.S).group(1)
+    for T, code in (("ResampleSystematic", 0), ("ResampleStratified", 1), ("ResampleResidual", 2)):
+        assert re.search(r"strategy_code\(::Type\{%s\}\) = Int32\(%d\)" % (T, code), jl)
+    # a missing measurement maps to NULL / a NaN row in every entry that takes y
+    assert jl.count("ismissingy(") >= 6 and "pointer(Vector{Float64}(" not in jl
+
+
+def test_julia_model_ids_strategies_and_ccalls_match_the_header():
+    jl = open(JL).read()
+    hdr = open(HDR).read()
     ids = dict(re.findall(r"(LLPF_MODEL_\w+)\s*=\s*(\d+)", hdr))
     assert ids == {"LLPF_MODEL_LINEAR_GAUSSIAN": "0", "LLPF_MODEL_QUADTANK_RK4": "1", "LLPF_MODEL_RB_LINEAR": "2", "LLPF_MODEL_RB_BILINEAR": "3"}
     # the wrapper builds CModel(<id>, ...) literally: one constructor call per model kind
-    assert re.search(r"cmodel\(m::LinearGaussianModel.*?CModel\(0,", jl, re.S)
-    assert re.search(r"cmodel\(m::QuadTankModel.*?CModel\(1,", jl, re.S)
+    assert re.search(r"cmodel\(f::LinearDynamics.*?CModel\(0,", jl, re.S)
+    assert re.search(r"cmodel\(f::QuadTankDynamics.*?CModel\(1,", jl, re.S)
     assert re.search(r"cmodel\(m::RBLinearModel.*?CModel\(2,", jl, re.S)
     assert re.search(r"cmodel\(m::RBBilinearModel.*?CModel\(3,", jl, re.S)
-    # every ccall names a symbol the header declares
-    declared = set(re.findall(r"\b(llpf_\w+)\s*\(", hdr))
-    for sym in set(re.findall(r"ccall\(\(:(llpf_\w+), LIB\)", jl)):
-        assert sym in declared, sym
+    strat = dict(re.findall(r"(LLPF_RESAMPLE_\w+)\s*=\s*(\d+)", hdr))
+    assert strat == {"LLPF_RESAMPLE_SYSTEMATIC": "0", "LLPF_RESAMPLE_STRATIFIED": "1", "LLPF_RESAMPLE_RESIDUAL": "2"}
+    # every ccall names a symbol the header declares, with the prototype's number of arguments
+    clean = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(?:int|const char\*)\s+(llpf_\w+)\s*\((.*?)\)\s*;", clean, re.S):
+        args = m.group(2).strip()
+        protos[m.group(1)] = 0 if args in ("", "void") else len(args.split(","))
+    seen = set()
+    for m in re.finditer(r"ccall\(\(:(llpf_\w+), LIB\),\s*\w+,\s*\(", jl):
+        sym = m.group(1)
+        assert sym in protos, sym
+        i, depth, n, cur = m.end(), 1, 0, ""        # walk the argument-type tuple to its closing parenthesis
+        while depth:
+            ch = jl[i]
+            i += 1
+            if ch in "({":
+                depth += 1
+            elif ch in ")}":
+                depth -= 1
+                if depth == 0:
+                    break
+            if ch == "," and depth == 1:
+                n += 1 if cur.strip() else 0
+                cur = ""
+            else:
+                cur += ch
+        n += 1 if cur.strip() else 0
+        assert n == protos[sym], (sym, n, protos[sym])
+        seen.add(sym)
     for sym in set(re.findall(r"getvec\(:(llpf_\w+)", jl)):
-        assert sym in declared, sym
+        assert sym in protos and protos[sym] == 2, sym
+        seen.add(sym)
+    for need in ("llpf_create", "llpf_destroy", "llpf_reset", "llpf_correct", "llpf_predict", "llpf_update", "llpf_run", "llpf_aux_run",
+                 "llpf_smooth", "llpf_bank_create", "llpf_bank_run", "llpf_mbank_create", "llpf_mbank_create_rank", "llpf_mbank_unique_id",
+                 "llpf_mbank_run", "llpf_mbank_destroy", "llpf_get_ancestors", "llpf_get_bins", "llpf_maxw"):
+        assert need in seen, need
