@@ -171,3 +171,14 @@ def test_julia_model_ids_strategies_and_ccalls_match_the_header():
                  "llpf_smooth", "llpf_bank_create", "llpf_bank_run", "llpf_mbank_create", "llpf_mbank_create_rank", "llpf_mbank_unique_id",
                  "llpf_mbank_run", "llpf_mbank_destroy", "llpf_get_ancestors", "llpf_get_bins", "llpf_maxw"):
         assert need in seen, need
+
+
+def test_integration_md_example_is_the_wrappers_own_method():
+    """the `correct!` method INTEGRATION.md shows is, line for line, the one in julia/LLPFAmd.jl"""
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = re.search(r"The one-call example.*?```julia\n(.*?)```", md, re.S).group(1)
+    jl = open(JL).read()
+    lines = [re.sub(r"\s+#.*$", "", l).rstrip() for l in block.splitlines() if l.strip()]
+    assert len(lines) >= 8
+    for l in lines:
+        assert l in jl, l
