@@ -335,6 +335,9 @@ int  llpf_resample_count(llpf_filter* f, int64_t* n);
 int  llpf_bank_resample_count(llpf_bank* b, int64_t* n);
 /* elapsed device milliseconds of the last llpf_run / llpf_bank_run (hipEvents on the handle's stream) */
 int  llpf_last_run_ms(llpf_filter* f, double* ms);
+/* how the last llpf_run drove its fused timesteps: launches of the fused predict! kernel (a persistent multi-step launch counts
+ * once) and the number of timesteps that ran inside persistent launches (0: one launch per timestep) */
+int  llpf_last_run_stats(llpf_filter* f, int64_t* fused_launches, int64_t* persistent_timesteps);
 int  llpf_bank_last_run_ms(llpf_bank* b, double* ms);
 
 /* ---- misc -------------------------------------------------------------------------------- */

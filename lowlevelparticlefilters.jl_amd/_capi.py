@@ -79,6 +79,7 @@ SYMBOLS = {
     "llpf_resample_count": [_vp, _ip],
     "llpf_bank_resample_count": [_vp, _ip],
     "llpf_last_run_ms": [_vp, _dp],
+    "llpf_last_run_stats": [_vp, _ip, _ip],
     "llpf_bank_last_run_ms": [_vp, _dp],
     "llpf_last_error": [],
     "llpf_version": [C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
@@ -112,6 +113,8 @@ def lib():
             raise ImportError("libllpf_hip.so not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
         L = C.CDLL(LIB_PATH)
         for name, args in SYMBOLS.items():
+            if os.environ.get("LLPF_LIB") and not hasattr(L, name):
+                continue             # A/B run against an older build of the engine (tools/ab): newer entry points are simply absent
             fn = getattr(L, name)
             fn.argtypes = args
             fn.restype = C.c_char_p if name == "llpf_last_error" else C.c_int
@@ -370,6 +373,11 @@ class FilterHandle:
         v = C.c_double(0)
         check(self.L.llpf_last_run_ms(self.h, C.byref(v)))
         return v.value
+
+    def last_run_stats(self):
+        a, b = C.c_int64(0), C.c_int64(0)
+        check(self.L.llpf_last_run_stats(self.h, C.byref(a), C.byref(b)))
+        return {"fused_launches": a.value, "persistent_timesteps": b.value}
 
     def set_profiling(self, on):
         check(self.L.llpf_set_profiling(self.h, 1 if on else 0))

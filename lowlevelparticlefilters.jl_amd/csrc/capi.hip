@@ -279,6 +279,12 @@ int llpf_weighted_mean(llpf_filter* f, double* xh) {
     return LLPF_OK;
 }
 int llpf_resample_count(llpf_filter* f, int64_t* n) { NEEDF(f); if (n) *n = f->bank.run_resamples; return LLPF_OK; }
+int llpf_last_run_stats(llpf_filter* f, int64_t* fused_launches, int64_t* persistent_timesteps) {
+    NEEDF(f);
+    if (fused_launches) *fused_launches = f->bank.last_run_launches;
+    if (persistent_timesteps) *persistent_timesteps = f->bank.last_run_persistent_steps;
+    return LLPF_OK;
+}
 int llpf_last_run_ms(llpf_filter* f, double* ms) { NEEDF(f); if (ms) *ms = f->bank.last_run_ms; return LLPF_OK; }
 
 static int set_prof(Bank& b, int on) {

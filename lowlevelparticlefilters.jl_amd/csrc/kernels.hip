@@ -28,6 +28,7 @@ namespace llpf {
 #include "kernels/resample.hpp"
 #include "kernels/residual.hpp"
 #include "kernels/resprop.hpp"
+#include "kernels/persist.hpp"
 #include "kernels/access.hpp"
 #include "kernels/smooth.hpp"
 #include "kernels/selftest.hpp"
@@ -277,6 +278,55 @@ hipError_t launch_resprop(const BankDev& b, const ResArgs& a0, const StepArgs& s
         default: return hipErrorInvalidValue;
     }
 }
+
+// ---- persistent multi-step launch (kernels/persist.hpp): linear-Gaussian single filters whose tiles are all co-resident ----
+template <class Model, int NX, int NY>
+static hipError_t launch_persist_t(const BankDev& b, const PersistArgsHost& h, hipStream_t s, int* capacity) {
+    auto fn = k_persist<Model, NX, NY>;
+    if (capacity) {
+        int per_cu = 0, dev = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, BLOCK, 0);
+        if (e != hipSuccess) return e;
+        hipDeviceProp_t prop;
+        if ((e = hipGetDevice(&dev)) != hipSuccess || (e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return e;
+        *capacity = per_cu * prop.multiProcessorCount;
+        return hipSuccess;
+    }
+    PersistArgs pa;
+    pa.k_begin = h.k_begin; pa.k_end = h.k_end; pa.t_index0 = h.t_index0; pa.Ts = h.Ts; pa.U = h.U; pa.Y = h.Y;
+    pa.x0 = h.x0; pa.x1 = h.x1; pa.q0 = h.q0; pa.q1 = h.q1; pa.cur0 = h.cur0; pa.qcur0 = h.qcur0; pa.par0 = h.par0;
+    pa.step0 = h.step0; pa.np0 = h.np0; pa.need_e2 = h.need_e2; pa.K = llpf_qbits(b.N); pa.ll_steps = h.ll_steps;
+    pa.bar = h.bar; pa.gq = reinterpret_cast<uint64_t*>(h.bar + BAR_WORDS); pa.ablate = h.ablate; pa.dbg_step = h.dbg_step; pa.dbg = h.dbg;
+    BankDev bd = b;
+    const ModelD* models = b.models;
+    void* args[] = {&bd, &models, &pa};
+    hipError_t e0 = hipMemsetAsync(pa.gq, 0, sizeof(uint64_t) * GQ_WORDS64, s);      // group sums start from zero; the barrier counters persist
+    if (e0 != hipSuccess) return e0;
+    return hipLaunchCooperativeKernel(reinterpret_cast<const void*>(fn), dim3((unsigned)b.P2, 1, 1), dim3(BLOCK), args, 0, s);
+}
+template <int NX>
+static hipError_t launch_persist_ny(const BankDev& b, const PersistArgsHost& h, hipStream_t s, int* capacity) {
+    switch (b.ny) {
+        case 1: return launch_persist_t<LinGauss<NX, 1>, NX, 1>(b, h, s, capacity);
+        case 2: return launch_persist_t<LinGauss<NX, 2>, NX, 2>(b, h, s, capacity);
+        case 3: return launch_persist_t<LinGauss<NX, 3>, NX, 3>(b, h, s, capacity);
+        case 4: return launch_persist_t<LinGauss<NX, 4>, NX, 4>(b, h, s, capacity);
+        default: return hipErrorInvalidValue;
+    }
+}
+static hipError_t launch_persist_any(const BankDev& b, const PersistArgsHost& h, hipStream_t s, int* capacity) {
+    if (b.model_id != LLPF_MODEL_LINEAR_GAUSSIAN || b.F != 1) return hipErrorInvalidValue;
+    switch (b.nx) {
+        case 1: return launch_persist_ny<1>(b, h, s, capacity);
+        case 2: return launch_persist_ny<2>(b, h, s, capacity);
+        case 3: return launch_persist_ny<3>(b, h, s, capacity);
+        case 4: return launch_persist_ny<4>(b, h, s, capacity);
+        default: return hipErrorInvalidValue;
+    }
+}
+hipError_t launch_persist(const BankDev& b, const PersistArgsHost& h, hipStream_t s) { return launch_persist_any(b, h, s, nullptr); }
+hipError_t persist_capacity(const BankDev& b, int* blocks) { PersistArgsHost h{}; return launch_persist_any(b, h, nullptr, blocks); }
+int persist_bar_words() { return BAR_WORDS + 2 * GQ_WORDS64; }
 
 template <class Model, int NX, int NY>
 static hipError_t launch_smooth_fx_t(const BankDev& b, const SmoothArgs& a, hipStream_t s) {

@@ -76,12 +76,18 @@ struct LinGauss {   // f = A x .+ B u ; g = C x   (reference examples/example_li
         md = m;
         const int nu = m->nu;
         has_u = nu > 0 && u != nullptr;
+        // the input row first, as independent loads (no wait between them), then B u in the reference's order
+        double ur[MAXD];
+#pragma unroll
+        for (int c = 0; c < MAXD; ++c) ur[c] = (has_u && c < nu) ? u[c] : 0.0;
 #pragma unroll
         for (int r = 0; r < NX; ++r) {
             double acc = 0.0;
             if (has_u) {
-                acc = m->B[r * nu + 0] * u[0];
-                for (int c = 1; c < nu; ++c) acc = acc + m->B[r * nu + c] * u[c];
+                acc = m->B[r * nu + 0] * ur[0];
+#pragma unroll
+                for (int c = 1; c < MAXD; ++c)
+                    if (c < nu) acc = acc + m->B[r * nu + c] * ur[c];
             }
             bu[r] = acc;
         }

@@ -50,6 +50,38 @@ struct ThrStrat { // stratified: u_i = (i0 + rand()) / M * bins[N]  (resample.jl
     }
 };
 
+// ---- memory access policy ---------------------------------------------------------------------------------------
+// COH = false: ordinary loads / stores (visible to the next LAUNCH: the kernel boundary writes the L2s back).
+// COH = true : agent-scope relaxed atomics (global_load/store ... sc1): coherent at the memory side, i.e. across the eight
+//              XCDs' L2s INSIDE one launch — what the persistent multi-step kernel (kernels/persist.hpp) needs for every
+//              datum one block writes and another block reads after the grid barrier.  (tools/grid_barrier.hip: no stale
+//              reads, 5 TB/s; __threadfence() instead costs ~30 us per step: a full L2 write-back per block.)
+template <bool COH>
+struct Mem {
+    template <class T> static DEV T ld(const T* p) {
+        if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else return *p;
+    }
+    template <class T> static DEV void st(T* p, T v) {
+        if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *p = v;
+    }
+    template <class T> static DEV T ld_off(const T* base, uint32_t byte_off) {
+        return ld(reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off));
+    }
+    template <class T> static DEV void st_off(T* base, uint32_t byte_off, T v) {
+        st(reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off), v);
+    }
+};
+// block-uniform values a persistent kernel carries from one timestep to the next in registers (an ordinary launch reads
+// them from FilterScal, where tile 0 of the previous launch published them)
+struct StepCarry {
+    double off;        // offset (bound) the previous weighting phase used for its exp-sums   (FilterScal::off_slot)
+    int32_t e2v;       // it accumulated sum e^2                                                (FilterScal::e2v_slot)
+    int32_t status;    // sticky status                                                          (FilterScal::status)
+    const uint64_t* gq; // sums of the tile sums over groups of 32 tiles, one 128-B line each (nullptr: read every tile sum)
+};
+
 // ---- shared machinery of the resample kernels -----------------------------------------------------------------
 struct ResShared {                 // LDS scratch
     uint64_t red[BLOCK / 64][4];
@@ -64,6 +96,7 @@ struct ResHead {                   // block-uniform results of res_head()
     double stot, e2;               // sum e_i (all particles), sum e_i^2 (-1: not accumulated)
     uint64_t prefix, tot;          // exclusive prefix of this tile's quanta, total of all quanta
     int dr, status, uniform, fast;
+    int has_u; double u_sys;       // systematic offset of this step supplied by the caller (persistent kernel)
 };
 enum { RES_STATUS_FALLBACK = 100, RES_STATUS_SKIP = 101 };   // SKIP: this launch is a no-op for the filter   // internal: bound test failed, the host redoes this step in exact form
 
@@ -80,33 +113,67 @@ DEV double head_log(const ResHead& h) { return h.fast ? llpf_log(h.stot) : llpf_
 // Tile 0 publishes the scalars of logsumexp! / effective_particles / shouldresample for later kernels.
 // `defer_skip`: the caller fetched the run's stop flag and the filter's fallback flag without waiting for them; the
 // launch-is-a-no-op test is made here after the barrier, so that those two loads overlap all the others.
-template <int SRC>
+struct NoOverlap { DEV void operator()() const {} };
+// `overlap`: work of the caller that needs nothing from memory the head waits for (particle-independent model terms: their
+// own scalar loads); it runs after the head's vector loads are issued and before the first of them is consumed
+template <int SRC, bool COH = false, class Overlap = NoOverlap>
 DEV ResHead res_head(const BankDev& b, const ResArgs& a, int f, int tile, ResShared& sh,
-                     bool defer_skip = false, uint32_t stop_flag = 0, int fb_flag = 0) {
+                     bool defer_skip = false, uint32_t stop_flag = 0, int fb_flag = 0, const StepCarry* carry = nullptr,
+                     Overlap&& overlap = NoOverlap()) {
     FilterScal* sc = b.scal + f;
     uint64_t* acc = b.acc + (size_t)f * ACC_WORDS;
     const int lane = threadIdx.x & 63, wvid = threadIdx.x >> 6;
     const double Nd = (double)b.N;
     ResHead h;
+    h.has_u = 0; h.u_sys = 0.0;
     const bool fin = (a.mode & RES_FINALIZE) != 0;
     const bool unif0 = (SRC == SRC_FILTER) && !fin && sc->uniform;
     // scalars of the previous launch that are needed after the barrier below: fetched now, with the other loads
-    const double off_pre = sc->off_slot[a.parity];
-    const int e2v_pre = sc->e2v_slot[a.parity];
-    const int exact_pre = sc->exact_slot[a.parity];
-    const int status_pre = sc->status;
+    const double off_pre = carry ? carry->off : sc->off_slot[a.parity];
+    const int e2v_pre = carry ? carry->e2v : sc->e2v_slot[a.parity];
+    const int exact_pre = carry ? 0 : sc->exact_slot[a.parity];
+    const int status_pre = carry ? carry->status : sc->status;
 
     // loads.  wave 0: lane group g (8 lanes = 8 shards) fetches word g of this slot's accumulator set
     uint64_t accv = 0;
     const int grp = threadIdx.x / NSHARD, shard = threadIdx.x % NSHARD;
-    if (fin && threadIdx.x < 64) accv = *acc_slot(acc, acc_word_of_group(grp, a.parity), shard);
+    if (fin && threadIdx.x < 64) accv = Mem<COH>::ld(acc_slot(acc, acc_word_of_group(grp, a.parity), shard));
     uint64_t pre = 0, all = 0;
-    if ((a.mode & RES_RESAMPLE) && !unif0) {
-        const uint64_t* __restrict__ tq = tileq_slot(b, a.parity, f);
-        for (int p = threadIdx.x; p < b.P2; p += BLOCK) {
-            const uint64_t q = tq[p];
-            all += q;
-            if (p < tile) pre += q;
+    const bool want_tq = (a.mode & RES_RESAMPLE) && !unif0;
+    const bool tq_small = b.P2 <= 4 * BLOCK;   // up to 1024 tiles: four INDEPENDENT loads per thread (a loop waits for every one in turn)
+    const uint64_t* __restrict__ tq = tileq_slot(b, a.parity, f);
+    uint64_t tqv[4] = {0, 0, 0, 0};
+    const uint64_t* gq = carry ? carry->gq : nullptr;
+    if (want_tq && gq) {
+        // two-level form: 32 group sums + the <= 31 tile sums before this tile inside its own group: one load per lane of
+        // wave 0 instead of P2 loads per block (P2 blocks reading all P2 tile sums is a P2^2 burst on 8 KB of memory)
+        const int t = (int)threadIdx.x, G = (b.P2 + 31) >> 5, gs = (tile >> 5) << 5;
+        if (t < G) tqv[0] = Mem<COH>::ld(gq + (size_t)t * 16);
+        else if (t >= 32 && t < 64 && gs + (t - 32) < b.P2) tqv[0] = Mem<COH>::ld(tq + gs + (t - 32));
+    } else if (want_tq && tq_small) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int p = (int)threadIdx.x + j * BLOCK; tqv[j] = Mem<COH>::ld(tq + (p < b.P2 ? p : 0)); }
+    }
+    overlap();
+    if (want_tq && gq) {
+        const int t = (int)threadIdx.x;
+        if (t < 32) { all = tqv[0]; pre = (t < (tile >> 5)) ? tqv[0] : 0; }
+        else if (t < 64) pre = ((t - 32) < (tile & 31)) ? tqv[0] : 0;
+    } else if (want_tq) {
+        if (tq_small) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int p = (int)threadIdx.x + j * BLOCK;
+                const uint64_t q = p < b.P2 ? tqv[j] : 0;
+                all += q;
+                if (p < tile) pre += q;
+            }
+        } else {
+            for (int p = threadIdx.x; p < b.P2; p += BLOCK) {
+                const uint64_t q = Mem<COH>::ld(tq + p);
+                all += q;
+                if (p < tile) pre += q;
+            }
         }
     }
     if (fin && wvid == 0) {
@@ -132,9 +199,9 @@ DEV ResHead res_head(const BankDev& b, const ResArgs& a, int f, int tile, ResSha
     if (fin) {
         // clear the slot after next (its last reader finished two launches ago): accumulator words and tile sums
         const int clr = (a.parity + 2) % ACC_NSLOT;
-        if (tile == 0 && threadIdx.x >= 64 && threadIdx.x < 128) *acc_slot(acc, acc_word_of_group(grp - 8, clr), shard) = 0;
+        if (tile == 0 && threadIdx.x >= 64 && threadIdx.x < 128) Mem<COH>::st(acc_slot(acc, acc_word_of_group(grp - 8, clr), shard), (uint64_t)0);
         uint64_t* tqc = tileq_slot(b, clr, f);
-        if (gridDim.x == (unsigned)b.P2) { if (threadIdx.x == 0) tqc[tile] = 0; }
+        if (gridDim.x == (unsigned)b.P2) { if (threadIdx.x == 0) Mem<COH>::st(tqc + tile, (uint64_t)0); }
         else { for (int p = threadIdx.x; p < b.P2; p += BLOCK) tqc[p] = 0; }      // finalize-only launch: one block
     }
     if (fin) {
@@ -276,7 +343,7 @@ DEV void res_counts(const BankDev& b, const ResArgs& a, int f, int tile, const R
     uint32_t cnt[NORM_IPT];
     if (STRATEGY == LLPF_RESAMPLE_SYSTEMATIC) {
         ThrSys th;
-        const double U = a.Uexp ? a.Uexp[0] : (a.u_from_scal ? sc->u_slot[a.parity] : llpf_uniform_step(sc->step_base + a.step, LLPF_STREAM_RESAMPLE, sc->k0, sc->k1));
+        const double U = h.has_u ? h.u_sys : (a.Uexp ? a.Uexp[0] : (a.u_from_scal ? sc->u_slot[a.parity] : llpf_uniform_step(sc->step_base + a.step, LLPF_STREAM_RESAMPLE, sc->k0, sc->k1)));
         th.M = M; th.Md = (double)M; th.step = 1.0 / (double)M;
         th.delta = 1e-9 + th.Md * 1e-13;
         th.r = U * binsN / (double)N;                  // r = rand()*bins[end]/N  (resample.jl:23)

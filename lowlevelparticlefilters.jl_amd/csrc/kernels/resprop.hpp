@@ -29,7 +29,7 @@ struct NoModel {
     DEV void measurement(const double*, double*) const {}
 };
 
-template <class Model, int NX, int NY, bool WEIGHT>
+template <class Model, int NX, int NY, bool WEIGHT, bool COH = false>
 struct PropCtx {
     const BankDev& b;
     const Model& model;
@@ -51,7 +51,7 @@ struct PropCtx {
         const uint32_t so = src << 3, oo = o << 3;
         double xp[NX], fx[NX], xi[NX], nz[NX];
 #pragma unroll
-        for (int d = 0; d < NX; ++d) xp[d] = ld_off(xc + (size_t)d * Ns, so);
+        for (int d = 0; d < NX; ++d) xp[d] = Mem<COH>::ld_off(xc + (size_t)d * Ns, so);
         if constexpr (Model::RB) {     // Rao-Blackwellized model: own noise structure, and correct! updates xl before the store
             model.rb_propagate(xp, o, pstep, k0, k1, st.rb_pred + blockIdx.y, xs);
             double wr = wprev;
@@ -59,10 +59,10 @@ struct PropCtx {
                 if (st.has_y) wr = wr + model.rb_weight(xs, y, st.rb_corr + blockIdx.y, o == 0);
                 if (o >= (uint32_t)b.N) wr = -LLPF_INF;
                 bad = bad || (wr != wr);
-                st_off(w, oo, wr);
+                Mem<COH>::st_off(w, oo, wr);
             }
 #pragma unroll
-            for (int d = 0; d < NX; ++d) st_off(xn + (size_t)d * Ns, oo, xs[d]);
+            for (int d = 0; d < NX; ++d) Mem<COH>::st_off(xn + (size_t)d * Ns, oo, xs[d]);
             return wr;
         }
 #ifdef LLPF_DEVTOOLS   /* ablation switches for performance experiments (results invalid); not in production builds */
@@ -78,7 +78,7 @@ struct PropCtx {
 #pragma unroll
         for (int d = 0; d < NX; ++d) {
             xs[d] = fx[d] + nz[d];
-            st_off(xn + (size_t)d * Ns, oo, xs[d]);
+            Mem<COH>::st_off(xn + (size_t)d * Ns, oo, xs[d]);
         }
         double wv = wprev;
         if (WEIGHT) {
@@ -95,7 +95,7 @@ struct PropCtx {
             }
             if (o >= (uint32_t)b.N) wv = -LLPF_INF;
             bad = bad || (wv != wv);
-            st_off(w, oo, wv);
+            Mem<COH>::st_off(w, oo, wv);
         }
         return wv;
     }
@@ -106,12 +106,16 @@ struct PropCtx {
 struct TileSum {
     int32_t tcur;
     uint64_t run;
-    DEV void init() { tcur = -1; run = 0; }
+    uint64_t* gq;       // group sums (32 tiles per group, 16 u64 apart) kept by the persistent kernel, or nullptr
+    DEV void init(uint64_t* g = nullptr) { tcur = -1; run = 0; gq = g; }
     DEV void flush(uint64_t* sh_tq, uint64_t* tq_global, int32_t tbase) {
         if (run) {
             const int32_t idx = tcur - tbase;
             if (idx >= 0 && idx < 8) atomicAdd(reinterpret_cast<unsigned long long*>(sh_tq + idx), (unsigned long long)run);
-            else atomicAdd(reinterpret_cast<unsigned long long*>(tq_global + tcur), (unsigned long long)run);
+            else {
+                atomicAdd(reinterpret_cast<unsigned long long*>(tq_global + tcur), (unsigned long long)run);
+                if (gq) atomicAdd(reinterpret_cast<unsigned long long*>(gq + (size_t)(tcur >> 5) * 16), (unsigned long long)run);
+            }
         }
         run = 0;
     }
@@ -131,12 +135,17 @@ __global__ __launch_bounds__(BLOCK) void k_resprop(BankDev b, const ModelD* __re
     __shared__ uint64_t sm_acc[BLOCK / 64][5];
     __shared__ uint64_t sh_tq[8];
     __shared__ double sm_x[BLOCK / 64][MAXD];
+    // Wave priority by phase: the head / counts / tail phases are short and latency-bound (loads, LDS, barriers, atomics), the
+    // output loop is long and issue-bound.  The waves of a CU's four blocks are otherwise served oldest first, so the
+    // youngest block's head is starved by the older blocks' loops and the SIMD ends the launch with that block's loop alone
+    // (in-kernel stamps, tools/dbg/timing_report.py).  Same-box A/B: C2 27.0 -> 26.4 us per timestep.
+    __builtin_amdgcn_s_setprio(3);
     const int f = blockIdx.y;
     const int tile = blockIdx.x;
     const int64_t Ns = b.Ns;
     const ModelD* md = models + f;
     FilterScal* sc = b.scal + f;
-    const uint32_t stop_flag = *b.bank_flag;           // tested in res_head, after all other loads are in flight
+    const uint32_t stop_flag = *b.bank_flag;     // tested in res_head, after all other loads are in flight
     const int fb_flag = sc->fallback;
     if (threadIdx.x < 8) sh_tq[threadIdx.x] = 0;
     const uint64_t* __restrict__ qsrc = b.quanta + (size_t)f * Ns;
@@ -147,15 +156,18 @@ __global__ __launch_bounds__(BLOCK) void k_resprop(BankDev b, const ModelD* __re
     const int anc_ident_prev = sc->anc_ident_s[b.anc_slot];   // this launch writes the other entry
 #define LLPF_STAMP(i) if (a.dbg && threadIdx.x == 0 && f == 0) a.dbg[(size_t)tile * 8 + (i)] = wall_clock64()
     LLPF_STAMP(0);
-    Model model;                                       // particle-independent terms: their loads overlap the head's
-    model.prepare(md, st.u + (size_t)f * st.u_stride, st.t_prop);
+    Model model;
     double y[NY];
-    const double* yf = st.y + (size_t)f * st.y_stride;
-#pragma unroll
-    for (int k = 0; k < NY; ++k) y[k] = (WEIGHT && st.has_y) ? yf[k] : 0.0;
     const uint32_t key0 = sc->k0, key1 = sc->k1, sb = sc->step_base;
     const double c0_pre = md->dg.c0;                   // fetched with the other loads: the bound below must not wait for it
-    const ResHead h = res_head<SRC_FILTER>(b, a, f, tile, sh, true, stop_flag, fb_flag);
+    // particle-independent terms (B u, the measurement row): their loads run while the head's vector loads are in flight
+    auto prepare = [&]() {
+        model.prepare(md, st.u + (size_t)f * st.u_stride, st.t_prop);
+        const double* yf = st.y + (size_t)f * st.y_stride;
+#pragma unroll
+        for (int k = 0; k < NY; ++k) y[k] = (WEIGHT && st.has_y) ? yf[k] : 0.0;
+    };
+    const ResHead h = res_head<SRC_FILTER, false>(b, a, f, tile, sh, true, stop_flag, fb_flag, nullptr, prepare);
     if (h.status) return;
     LLPF_STAMP(1);
     PropCtx<Model, NX, NY, WEIGHT> pc{b, model, md, st, y, b.xcur + (size_t)f * NX * Ns, b.xnext + (size_t)f * NX * Ns,
@@ -210,6 +222,7 @@ __global__ __launch_bounds__(BLOCK) void k_resprop(BankDev b, const ModelD* __re
     LLPF_STAMP(2);
     if (a.dbg && threadIdx.x == 0 && f == 0) a.dbg[(size_t)tile * 8 + 5] = (uint64_t)(last - first);
     const uint32_t tile0 = (uint32_t)tile * TILE, ulast = (uint32_t)last, ucend = (uint32_t)c_end;
+    __builtin_amdgcn_s_setprio(0);
 #pragma unroll 1
     for (uint32_t o = (uint32_t)first + threadIdx.x; o < ulast; o += BLOCK) {
         uint32_t src = o;
@@ -243,6 +256,7 @@ __global__ __launch_bounds__(BLOCK) void k_resprop(BankDev b, const ModelD* __re
         }
     }
     if (WEIGHT && ACC) ts.flush(sh_tq, tq_next, tbase);
+    __builtin_amdgcn_s_setprio(3);
     LLPF_STAMP(3);
     if (WEIGHT) {
         const double r = block_max(bmax, sm_max);
