@@ -31,17 +31,30 @@ struct Api {
     result_t (*GroupStart)() = nullptr;
     result_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(result_t) = nullptr;
-    std::string err;
+    std::string err, path;
 };
 static Api* api() {
     static Api a;
     static bool tried = false;
     if (tried) return &a;
     tried = true;
-    // a copy the process already holds (e.g. the one PyTorch ships) is reused; otherwise ROCm's
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char* n : names) { a.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL); if (a.handle) break; }
-    if (!a.handle) for (const char* n : names) { a.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (a.handle) break; }
+    // RCCL must sit on the SAME HIP runtime as this library: streams and device pointers of one libamdhip64 mean nothing to
+    // another, and a process can hold two of them (PyTorch wheels bundle their own next to their own librccl).  So: find the
+    // file the runtime this library is bound to was loaded from, and take the librccl of that directory; only then the names.
+    std::vector<std::string> names;
+    Dl_info info;
+    if (dladdr(reinterpret_cast<const void*>(&hipGetDeviceCount), &info) && info.dli_fname) {
+        std::string dir(info.dli_fname);
+        const size_t slash = dir.rfind('/');
+        if (slash != std::string::npos) {
+            dir.resize(slash + 1);
+            names.push_back(dir + "librccl.so.1");
+            names.push_back(dir + "librccl.so");
+        }
+    }
+    names.push_back("librccl.so.1");
+    names.push_back("librccl.so");
+    for (const std::string& n : names) { a.handle = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND); if (a.handle) { a.path = n; break; } }
     if (!a.handle) { a.err = std::string("librccl not loadable: ") + dlerror(); return &a; }
 #define LLPF_SYM(field, name) a.field = reinterpret_cast<decltype(a.field)>(dlsym(a.handle, name)); if (!a.field) { a.err = std::string("librccl lacks ") + name; a.handle = nullptr; return &a; }
     LLPF_SYM(GetUniqueId, "ncclGetUniqueId") LLPF_SYM(CommInitRank, "ncclCommInitRank") LLPF_SYM(CommInitAll, "ncclCommInitAll")
