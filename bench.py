@@ -596,6 +596,13 @@ def main():
             del pf2
             out.update(cpu_baseline(model, U, Y, kind, thr, N, min(cs, T - 1), 1000 + rank, ll_gpu, aux))
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+            if args.workload == "lg":
+                # ancestor mismatches against the reference order at full size, teacher forced (tests/gpu_common.py)
+                from gpu_common import teacher_forced_ancestor_mismatches
+                tf = teacher_forced_ancestor_mismatches(cfg, U, Y, min(50, T - 1))
+                tf["note"] = ("before every predict! the reference-order oracle's state is installed in the engine; both resample and propagate "
+                              "with the same Philox draws; %d x %d ancestor decisions compared" % (tf["resampling_steps"], N))
+                out["accuracy"]["ancestor_mismatches_vs_reference_order"] = tf
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

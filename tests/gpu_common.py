@@ -24,3 +24,42 @@ def compare_state(g, o, exact=True, we_rtol=0.0):
     else:
         np.testing.assert_allclose(xg, xo, rtol=1e-12, atol=1e-12)
         np.testing.assert_allclose(eg, eo, rtol=we_rtol, atol=1e-300)
+
+
+def teacher_forced_ancestor_mismatches(cfg, U, Y, steps, t_index0=1.0):
+    """ancestor mismatches of the engine against the REFERENCE-ORDER oracle (serial fp64 cumsum, two-pointer search:
+    src/resample.jl:17-36) at full size.  A particle filter is chaotic in its ancestry, so the two are compared step by step from the
+    SAME state: before every predict! the reference-order state (particles, normalised log-weights) is installed in the engine
+    (llpf_set_particles / llpf_set_weights), both sides run predict!(u_k) with the same Philox draws, the ancestor vectors and the
+    propagated particles are compared, and the oracle alone carries the recursion on (correct! with y_{k+1}).
+    Returns dict(steps, resampling_steps, mismatches_total, mismatches_per_step_max, steps_with_mismatch, particles_equal_on_matching_ancestors)."""
+    import oracle_binding as ob
+    from llpf_amd import _capi
+    g = _capi.FilterHandle(cfg)
+    r = ob.OracleFilter(cfg, ob.ORDER_REFERENCE)
+    g.reset(); r.reset()
+    Ts = cfg.model.Ts
+    tot = worst = nsteps = nres = 0
+    same_x = True
+    for k in range(steps):
+        t = (t_index0 + k) * Ts
+        u = U[k] if U is not None and len(U) else None
+        r.correct(u, Y[k], t)
+        g.set_particles(r.particles())
+        g.set_weights(r.weights())
+        g.predict(u, t)
+        r.predict(u, t)
+        if not r.last_resampled():
+            assert not g.last_resampled()
+            continue
+        nres += 1
+        jg, jr = g.ancestors(), r.ancestors()
+        diff = jg != jr
+        m = int(np.sum(diff))
+        tot += m
+        worst = max(worst, m)
+        nsteps += 1 if m else 0
+        xg, xr = g.particles(), r.particles()
+        same_x = same_x and bool(np.array_equal(xg[~diff], xr[~diff]))
+    return {"steps": int(steps), "resampling_steps": int(nres), "mismatches_total": int(tot), "mismatches_per_step_max": int(worst),
+            "steps_with_mismatch": int(nsteps), "particles_equal_on_matching_ancestors": same_x}

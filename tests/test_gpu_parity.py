@@ -750,3 +750,83 @@ def test_repeated_runs_replay_a_captured_graph(thr):
         assert np.array_equal(rg["ll_steps"].view(np.uint64), ro["ll_steps"].view(np.uint64)), p
         _compare_state(g, o)
     assert n_exact >= 3
+
+
+# ---- parity evidence at the BASELINE sizes themselves (oracle with OpenMP over the per-particle loops) -----------------
+def test_c2_full_size_leading_steps_bit_identical_to_the_device_order_oracle():
+    """BASELINE config C2 (N = 1e6, resampling at every step): per-step log-likelihoods of the first 20 timesteps, the particles,
+    the log-weights and the ancestors after them — bit for bit the device-order oracle's"""
+    model = M.lg_test_model()
+    _, U, Y = M.simulate_lg(model, 20, seed=1)
+    cfg = _cfg(model, 1000000, thr=1.0, seed=1000)
+    ob.set_threads(16)
+    try:
+        o = ob.OracleFilter(cfg, ob.ORDER_DEVICE)
+        o.reset()
+        ro = o.run(U, Y, 1.0, ll_steps=True)
+    finally:
+        ob.set_threads(1)
+    g = _capi.FilterHandle(cfg)
+    g.reset()
+    rg = g.run(U, Y, 1.0, ll_steps=True)
+    assert np.array_equal(rg["ll_steps"].view(np.uint64), ro["ll_steps"].view(np.uint64))
+    assert g.resample_count() == o.resample_count() == 20
+    _compare_state(g, o)
+
+
+def test_c2_full_size_ancestor_mismatches_against_the_reference_order():
+    """the count SURVEY 8(d) asks for: the engine's exact fixed-point bins against the reference's serial fp64 cumulative sum at
+    N = 1e6, 50 teacher-forced resampling steps.  A threshold within ~1e-13 of a bin edge may fall on the other side: at most a
+    handful of the 5e7 ancestor decisions differ, and every output whose ancestor agrees has bit-identical particles."""
+    from gpu_common import teacher_forced_ancestor_mismatches
+    model = M.lg_test_model()
+    _, U, Y = M.simulate_lg(model, 50, seed=1)
+    r = teacher_forced_ancestor_mismatches(_cfg(model, 1000000, thr=1.0, seed=1000), U, Y, 50)
+    print("teacher-forced ancestor mismatches at N = 1e6:", r)
+    assert r["resampling_steps"] == 50
+    assert r["mismatches_total"] <= 50 and r["mismatches_per_step_max"] <= 8, r
+    assert r["particles_equal_on_matching_ancestors"]
+
+
+def test_c4_share_bank_against_the_oracle():
+    """three filters of one GPU's share of BASELINE config C4 (128 filters x N = 1e5, noise-level sweep) against the device-order
+    ORACLE (not against single HIP filters): per-step log-likelihoods bit-identical"""
+    F, N, T = 128, 100000, 40
+    svec = 10.0 ** np.linspace(-2, 0, F)
+    models = [M.lg_test_model(s) for s in svec]
+    _, U, Y = M.simulate_lg(M.lg_test_model(0.1), T)
+    bank = _capi.BankHandle(_cfg(models[0], N, thr=0.1, seed=900), models)
+    bank.reset()
+    rb = bank.run(U, Y, 1.0, ll_steps=True)
+    ob.set_threads(16)
+    try:
+        for k in (0, 61, 127):
+            o = ob.OracleFilter(_cfg(models[k], N, thr=0.1, seed=900 + k), ob.ORDER_DEVICE)
+            o.reset()
+            ro = o.run(U, Y, 1.0, ll_steps=True)
+            assert np.array_equal(ro["ll_steps"].view(np.uint64), rb["ll_steps"][:, k].copy().view(np.uint64)), k
+    finally:
+        ob.set_threads(1)
+
+
+def test_c3_full_size_full_length():
+    """BASELINE config C3 as specified: quad-tank AdvancedParticleFilter, N = 1e6, T = 2000 (through the t > 500 switch), threshold
+    0.5.  The first 8 timesteps are the device-order oracle's bit for bit; the whole run is finite, resamples at every step and
+    tracks the measured levels."""
+    model = M.quadtank_model()
+    U, Y = M.quadtank_data(2000)
+    cfg = _cfg(model, 1000000, thr=0.5, kind=S.ADVANCED_PARTICLE_FILTER, seed=5)
+    g = _capi.FilterHandle(cfg)
+    g.reset()
+    r = g.run(U, Y, 0.0, ll_steps=True, xmean=True)
+    assert np.all(np.isfinite(r["ll_steps"])) and np.all(np.isfinite(r["xmean"]))
+    assert g.resample_count() == 2000 and g.index() == 2001
+    assert np.max(np.abs(r["xmean"][50:, :2] - Y[50:])) < 0.1
+    ob.set_threads(16)
+    try:
+        o = ob.OracleFilter(cfg, ob.ORDER_DEVICE)
+        o.reset()
+        ro = o.run(U[:8], Y[:8], 0.0, ll_steps=True)
+    finally:
+        ob.set_threads(1)
+    assert np.array_equal(r["ll_steps"][:8].view(np.uint64), ro["ll_steps"].view(np.uint64))
