@@ -77,7 +77,9 @@ enum {
      * llpf_model.nx = nxn <= 4 (what f_n, g and the densities df, d0 see); f_n / g are the linear-Gaussian descriptors A, B, C of this
      * struct sized for nxn (rb.fn_kind 0) or the quad-tank RK4 dynamics / measurement (rb.fn_kind 1, nxn = 4, ny = 2).
      * nxl = rb.nxl <= 8, ny <= 2; dynamics_density = R1n (must be Gaussian), linear_noise = R1l, linear_initial = d0l. */
-    LLPF_MODEL_RB_BILINEAR     = 3
+    LLPF_MODEL_RB_BILINEAR     = 3,
+    /* ids >= LLPF_MODEL_USER_BASE: models compiled at run time from device source, llpf_model_compile() below */
+    LLPF_MODEL_USER_BASE       = 1000
 };
 
 /* linear substate and state-dependent coupling of LLPF_MODEL_RB_BILINEAR (ignored by the other models) */
@@ -217,6 +219,27 @@ int  llpf_rb_get_linear_state(llpf_filter* f, double* xl, double* R);
  * xb is [T*M*nx] (time-major), idx (optional) [T*M] the 0-based particle index behind every sample.  M <= N. */
 int  llpf_smooth(llpf_filter* f, int64_t M, const double* U, int64_t T, const double* xf, const double* wf,
                  const double* wef, double* xb, int64_t* idx);
+
+/* ---- user-supplied models ------------------------------------------------------------------------------------------
+ * The reference's filters take arbitrary callables dynamics(x,u,p,t) / measurement(x,u,p,t) (src/PFtypes.jl:59-63, 189-193,
+ * 226-289).  A Julia closure cannot cross this boundary, device code can: `device_src` is HIP C++ that defines
+ *     struct UserModel {
+ *         static constexpr bool RB = false;
+ *         DEV void prepare(const ModelD* m, const double* u, double t);   // once per thread: particle-independent terms.  The
+ *                                              // parameter block p is the llpf_model of the filter as the device sees it:
+ *                                              // m->A[64], m->B[64], m->C[64], m->qt[16], m->Ts, m->supersample, m->nu
+ *         DEV void dynamics(const double* x, double* out) const;          // x+ = f(x, u, p, t), noise-free (nx values)
+ *         DEV void measurement(const double* x, double* out) const;       // y  = g(x, u, p, t)            (ny values)
+ *     };
+ * (DEV = __device__ __forceinline__; the engine's deterministic math — llpf_exp, llpf_log, llpf_sqrt_pos, ... of
+ * csrc/shared/llpf_detmath.h — is in scope, and the source is compiled with -ffp-contract=off like the engine.)  The snippet is
+ * compiled with hiprtc for the visible device into the engine's own step kernel; *model_id (>= LLPF_MODEL_USER_BASE) then goes
+ * into llpf_model.model_id with the same nx, ny.  Process noise, measurement likelihood and initial density remain the Gaussian
+ * descriptors of llpf_model (an AdvancedParticleFilter whose dynamics add their own Gaussian noise and whose
+ * measurement_likelihood is a Gaussian around `measurement`).  Such filters and banks run the balanced two-launch timestep;
+ * the auxiliary verbs work, the smoother and the Rao-Blackwellized forms are not provided for them.
+ * On failure the compiler log is in llpf_last_error(). */
+int  llpf_model_compile(const char* device_src, int32_t nx, int32_t ny, int32_t* model_id);
 
 /* ---- accessors (reference src/PFtypes.jl:296-334) --------------------------------------- */
 int  llpf_num_particles(const llpf_filter* f, int64_t* n);                /* num_particles(pf) */

@@ -72,6 +72,7 @@ SYMBOLS = {
     "llpf_mbank_local_devices": [_vp, C.POINTER(C.c_int32)],
     "llpf_mbank_set_profiling": [_vp, C.c_int32],
     "llpf_mbank_get_profile": [_vp, C.c_int32, _dp, _ip],
+    "llpf_model_compile": [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32)],
     "llpf_set_profiling": [_vp, C.c_int32],
     "llpf_get_profile": [_vp, _dp, _ip],
     "llpf_bank_set_profiling": [_vp, C.c_int32],
@@ -583,6 +584,14 @@ class MBankHandle:
         n = np.zeros(PROF_CLASSES, dtype=np.int64)
         check(self.L.llpf_mbank_get_profile(self.h, int(local_shard), dptr(ms), iptr(n)))
         return ms, n
+
+
+def model_compile(device_src, nx, ny):
+    """llpf_model_compile: JIT a user model (HIP source defining `struct UserModel`, include/llpf.h); returns the model id
+    to put into llpf_model.model_id"""
+    mid = C.c_int32(-1)
+    check(lib().llpf_model_compile(device_src.encode("utf-8"), int(nx), int(ny), C.byref(mid)))
+    return mid.value
 
 
 # array primitives -----------------------------------------------------------------------------------

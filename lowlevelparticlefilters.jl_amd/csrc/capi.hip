@@ -299,6 +299,22 @@ static int get_prof(Bank& b, double* ms, int64_t* n) {
 int llpf_set_profiling(llpf_filter* f, int32_t on) { NEEDF(f); return set_prof(f->bank, on); }
 int llpf_get_profile(llpf_filter* f, double* ms, int64_t* n) { NEEDF(f); return get_prof(f->bank, ms, n); }
 
+// ---- user-supplied models (kernels/jit.hpp) -----------------------------------------------------------
+int llpf_model_compile(const char* device_src, int32_t nx, int32_t ny, int32_t* model_id) {
+    if (!model_id) return fail(LLPF_ERR_ARG, "null output");
+    *model_id = -1;
+    int ndev = 0;
+    // (LLPF_JIT_COMPILE_ONLY=1: the build check on a box without a GPU — hiprtc cross-compiles for gfx950; nothing can run)
+    const char* co = getenv("LLPF_JIT_COMPILE_ONLY");
+    if ((hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) && !(co && atoi(co)))
+        return fail(LLPF_ERR_NO_DEVICE, "no HIP device visible; this engine has no CPU fallback");
+    std::string err;
+    const int id = jit_compile_user_model(device_src, nx, ny, err);
+    if (id < 0) return fail(LLPF_ERR_ARG, err);
+    *model_id = id;
+    return LLPF_OK;
+}
+
 // ---- banks ---------------------------------------------------------------------------------------
 int llpf_bank_create(const llpf_config* base, const llpf_model* models, int32_t n_filters, llpf_bank** out) {
     if (!out) return fail(LLPF_ERR_ARG, "null out pointer");

@@ -24,6 +24,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string>
 
 #include "../../include/llpf.h"
 #include "shared/llpf_detmath.h"
@@ -190,6 +191,7 @@ struct StepArgs {
     int32_t y_stride;
 };
 
+// ---- end of the part the run-time compiled user-model kernels see (tools/gen_jit_prelude.py cuts here) ----
 enum { RES_FINALIZE = 1, RES_RESAMPLE = 2 };
 
 // arguments of the resample(+finalize) kernel
@@ -281,6 +283,8 @@ hipError_t launch_selftest_math(int which, const double* in, double* out, int64_
 hipError_t launch_selftest_normals(uint32_t k0, uint32_t k1, uint32_t step, uint32_t stream, int nd,
                                    double* out, int64_t n, hipStream_t s);
 bool step_supported(int model_id, int nx, int ny);
+// user models compiled at run time (host/jit in kernels.hip): returns a model id >= LLPF_MODEL_USER_BASE, or -1 with `err` set
+int jit_compile_user_model(const char* device_src, int nx, int ny, std::string& err);
 bool rbfull_supported(int fn_kind, int nn, int nl, int ny);
 int rbfull_rows(int nn, int nl);   // rows of the particle plane: xn, xl, packed R
 

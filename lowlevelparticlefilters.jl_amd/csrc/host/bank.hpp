@@ -258,7 +258,7 @@ static int bank_create(const llpf_config* cfg, const llpf_model* models, int F, 
     b.nx = m0.nx; b.nu = m0.nu; b.ny = m0.ny;
     b.xrows = (m0.model_id == LLPF_MODEL_RB_BILINEAR) ? rbfull_rows(m0.nx, m0.rb.nxl) : b.nx;
     b.nxp = (m0.model_id == LLPF_MODEL_RB_BILINEAR) ? m0.nx + m0.rb.nxl : b.nx;
-    b.P1 = (int)(b.Ns / STEP_TILE);
+    b.P1 = (int)(b.Ns / BLOCK);          // entries of the per-block weighted-mean partials of one filter (finest block granularity)
     b.P2 = (int)(b.Ns / TILE);
     b.device = cfg->device;
     // replicas (models == NULL): one descriptor is prepared and uploaded, the device copies it F times (a bank of

@@ -76,7 +76,8 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
     const bool residual = b.cfg.resampling_strategy == LLPF_RESAMPLE_RESIDUAL;
     const bool rbm = is_rb(b);
     const bool rbfull = is_rbfull(b);     // per-particle covariance: its own step kernel, balanced form, exp-sums by k_norm
-    const bool unfused = rbfull || hist || residual || (unf_env ? atoi(unf_env) != 0 : heavy_dynamics);
+    const bool user_model = b.cfg.model.model_id >= LLPF_MODEL_USER_BASE;   // run-time compiled model: only its k_step exists
+    const bool unfused = user_model || rbfull || hist || residual || (unf_env ? atoi(unf_env) != 0 : heavy_dynamics);
     if (rbm) {
         // the whole gain schedule of the run (data independent): corr_0, pred_0, corr_1, pred_1, ..., [F] each
         const size_t need = (size_t)(2 * T + 1) * b.F;

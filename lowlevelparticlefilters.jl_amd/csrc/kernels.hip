@@ -12,7 +12,13 @@
 //   three        auxiliary filter: k_step<MODE_AUX> + k_resprop<AUX> + finalize
 // All particle data is fp64 structure-of-arrays; wave64; 256-thread workgroups; grid = (tiles, filters).
 // Compiled with -ffp-contract=off: the arithmetic is the same IEEE sequence as oracle/llpf_oracle.c (device order).
+#include <hip/hiprtc.h>
+
+#include <mutex>
+#include <vector>
+
 #include "engine.hpp"
+#include "jit_prelude.inc"
 
 namespace llpf {
 
@@ -32,6 +38,7 @@ namespace llpf {
 #include "kernels/access.hpp"
 #include "kernels/smooth.hpp"
 #include "kernels/selftest.hpp"
+#include "kernels/jit.hpp"
 
 // ------------------------------------------------------------------------------------------------
 // launchers
@@ -77,6 +84,7 @@ hipError_t launch_rbfull_init(const BankDev& b, hipStream_t s) {
 }
 
 bool step_supported(int model_id, int nx, int ny) {
+    if (model_id >= LLPF_MODEL_USER_BASE) return jit_supported(model_id, nx, ny);
     if (model_id == LLPF_MODEL_RB_BILINEAR) return nx >= 1 && nx <= 4 && ny >= 1 && ny <= 2;   // shape checked by rbfull_supported
     if (model_id == LLPF_MODEL_QUADTANK_RK4) return nx == 4 && ny == 2;
     if (model_id == LLPF_MODEL_RB_LINEAR) return nx >= 2 && nx <= 4 && ny >= 1 && ny <= 4;
@@ -96,14 +104,17 @@ hipError_t launch_init(const BankDev& b, uint32_t step, int init_anc, hipStream_
     return hipGetLastError();
 }
 
-template <class Model, int NX, int NY>
+#ifndef LLPF_QT_PPT
+#define LLPF_QT_PPT 2
+#endif
+template <class Model, int NX, int NY, int PPT = STEP_PPT>
 static hipError_t launch_step_t(const BankDev& b, int mode, const StepArgs& a, hipStream_t s) {
-    dim3 g((unsigned)b.P1, (unsigned)b.F, 1);
+    dim3 g((unsigned)(b.Ns / (BLOCK * PPT * STEP_ITERS)), (unsigned)b.F, 1);
     switch (mode) {
-        case MODE_WEIGHT: hipLaunchKernelGGL((k_step<Model, NX, NY, MODE_WEIGHT>), g, dim3(BLOCK), 0, s, b, b.models, b.scal, a); break;
-        case MODE_PROP: hipLaunchKernelGGL((k_step<Model, NX, NY, MODE_PROP>), g, dim3(BLOCK), 0, s, b, b.models, b.scal, a); break;
-        case MODE_PROP_WEIGHT: hipLaunchKernelGGL((k_step<Model, NX, NY, MODE_PROP_WEIGHT>), g, dim3(BLOCK), 0, s, b, b.models, b.scal, a); break;
-        case MODE_AUX: hipLaunchKernelGGL((k_step<Model, NX, NY, MODE_AUX>), g, dim3(BLOCK), 0, s, b, b.models, b.scal, a); break;
+        case MODE_WEIGHT: hipLaunchKernelGGL((k_step<Model, NX, NY, MODE_WEIGHT, PPT>), g, dim3(BLOCK), 0, s, b, b.models, b.scal, a); break;
+        case MODE_PROP: hipLaunchKernelGGL((k_step<Model, NX, NY, MODE_PROP, PPT>), g, dim3(BLOCK), 0, s, b, b.models, b.scal, a); break;
+        case MODE_PROP_WEIGHT: hipLaunchKernelGGL((k_step<Model, NX, NY, MODE_PROP_WEIGHT, PPT>), g, dim3(BLOCK), 0, s, b, b.models, b.scal, a); break;
+        case MODE_AUX: hipLaunchKernelGGL((k_step<Model, NX, NY, MODE_AUX, PPT>), g, dim3(BLOCK), 0, s, b, b.models, b.scal, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -134,8 +145,9 @@ static hipError_t launch_step_rb_ny(const BankDev& b, int mode, const StepArgs& 
 
 hipError_t launch_step(const BankDev& b, int mode, const StepArgs& a, hipStream_t s) {
     const int model_id = b.model_id;
+    if (model_id >= LLPF_MODEL_USER_BASE) return launch_step_user(b, mode, a, s);
     if (model_id == LLPF_MODEL_RB_BILINEAR) return launch_rbfull(b, mode, a, s);
-    if (model_id == LLPF_MODEL_QUADTANK_RK4) return launch_step_t<QuadTank<4, 2>, 4, 2>(b, mode, a, s);
+    if (model_id == LLPF_MODEL_QUADTANK_RK4) return launch_step_t<QuadTank<4, 2>, 4, 2, LLPF_QT_PPT>(b, mode, a, s);
     if (model_id == LLPF_MODEL_RB_LINEAR) {
         switch (b.nx) {
             case 2: return launch_step_rb_ny<2>(b, mode, a, s);
@@ -154,7 +166,7 @@ hipError_t launch_step(const BankDev& b, int mode, const StepArgs& a, hipStream_
 }
 
 hipError_t launch_max(const BankDev& b, int parity, hipStream_t s) {
-    hipLaunchKernelGGL(k_max, dim3((unsigned)b.P1, (unsigned)b.F, 1), dim3(BLOCK), 0, s, b, parity);
+    hipLaunchKernelGGL(k_max, dim3((unsigned)(b.Ns / STEP_TILE), (unsigned)b.F, 1), dim3(BLOCK), 0, s, b, parity);
     return hipGetLastError();
 }
 

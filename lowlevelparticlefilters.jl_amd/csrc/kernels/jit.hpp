@@ -1,0 +1,105 @@
+// kernels/jit.hpp — user-supplied models, compiled at run time (host side; part of kernels.hip, namespace llpf).
+// ------------------------------------------------------------------------------------------------
+// The reference's filters take arbitrary `dynamics` / `measurement` callables (src/PFtypes.jl:59-63, 189-193); a Julia
+// closure cannot run on the GPU, but a device-code snippet can: llpf_model_compile() takes HIP source that defines
+//     struct UserModel {                                   // the Model concept of kernels/models.hpp
+//         static constexpr bool RB = false;
+//         DEV void prepare(const ModelD* m, const double* u, double t);   // particle-independent terms; m->A, B, C, qt[16], Ts,
+//                                                                          // supersample are the model's parameter block
+//         DEV void dynamics(const double* x, double* out) const;          // f(x, u, p, t) without noise
+//         DEV void measurement(const double* x, double* out) const;       // g(x, u, p, t)
+//     };
+// appends it to the engine's own headers (jit_prelude.inc, generated at build time) and compiles k_step<UserModel, nx, ny, MODE>
+// with hiprtc (--offload-arch of the device, -ffp-contract=off like the engine itself).  Filters with such a model run the
+// balanced form: the precompiled k_resample + the compiled k_step; noise and likelihood stay the Gaussian descriptors.
+// ------------------------------------------------------------------------------------------------
+// (kernels.hip includes <hip/hiprtc.h>, <mutex>, <vector> and jit_prelude.inc before it opens the namespace)
+
+struct JitModel {
+    int nx = 0, ny = 0;
+    std::vector<char> code;
+    std::string name[4];                       // lowered names of k_step<UserModel, nx, ny, MODE, STEP_PPT>, MODE = 0..3
+    struct PerDevice { hipModule_t mod = nullptr; hipFunction_t fn[4] = {nullptr, nullptr, nullptr, nullptr}; };
+    std::vector<PerDevice> dev;                // indexed by device ordinal, loaded on first use
+};
+static std::mutex g_jit_mutex;
+static std::vector<JitModel*> g_jit_models;
+
+int jit_compile_user_model(const char* device_src, int nx, int ny, std::string& err) {
+    if (!device_src) { err = "null source"; return -1; }
+    if (nx < 1 || nx > MAXD || ny < 1 || ny > MAXD) { err = "nx, ny must be in 1..8"; return -1; }
+    std::string src(LLPF_JIT_PRELUDE);
+    src += "\nnamespace llpf {\n";
+    src += device_src;
+    src += "\n}  // namespace llpf\n";
+    hiprtcProgram prog = nullptr;
+    if (hiprtcCreateProgram(&prog, src.c_str(), "llpf_user_model.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) { err = "hiprtcCreateProgram failed"; return -1; }
+    std::string expr[4];
+    for (int mode = 0; mode < 4; ++mode) {
+        expr[mode] = "llpf::k_step<llpf::UserModel, " + std::to_string(nx) + ", " + std::to_string(ny) + ", " + std::to_string(mode) + ", " + std::to_string(STEP_PPT) + ">";
+        hiprtcAddNameExpression(prog, expr[mode].c_str());
+    }
+    int devid = 0;
+    hipDeviceProp_t prop;
+    std::string arch = "gfx950";
+    if (hipGetDevice(&devid) == hipSuccess && hipGetDeviceProperties(&prop, devid) == hipSuccess && prop.gcnArchName[0]) arch = prop.gcnArchName;
+    const std::string archopt = "--offload-arch=" + arch;
+    const char* opts[] = {archopt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-Wno-unused-value"};
+    const hiprtcResult rc = hiprtcCompileProgram(prog, (int)(sizeof(opts) / sizeof(opts[0])), opts);
+    if (rc != HIPRTC_SUCCESS) {
+        size_t n = 0;
+        hiprtcGetProgramLogSize(prog, &n);
+        std::string log(n, '\0');
+        if (n) hiprtcGetProgramLog(prog, &log[0]);
+        err = std::string("hiprtc: ") + hiprtcGetErrorString(rc) + "\n" + log;
+        hiprtcDestroyProgram(&prog);
+        return -1;
+    }
+    JitModel* jm = new JitModel();
+    jm->nx = nx; jm->ny = ny;
+    size_t sz = 0;
+    hiprtcGetCodeSize(prog, &sz);
+    jm->code.resize(sz);
+    hiprtcGetCode(prog, jm->code.data());
+    for (int mode = 0; mode < 4; ++mode) {
+        const char* low = nullptr;
+        if (hiprtcGetLoweredName(prog, expr[mode].c_str(), &low) != HIPRTC_SUCCESS || !low) { err = "hiprtcGetLoweredName failed for " + expr[mode]; delete jm; hiprtcDestroyProgram(&prog); return -1; }
+        jm->name[mode] = low;
+    }
+    hiprtcDestroyProgram(&prog);
+    std::lock_guard<std::mutex> lk(g_jit_mutex);
+    g_jit_models.push_back(jm);
+    return LLPF_MODEL_USER_BASE + (int)g_jit_models.size() - 1;
+}
+
+static JitModel* jit_model(int model_id) {
+    std::lock_guard<std::mutex> lk(g_jit_mutex);
+    const int k = model_id - LLPF_MODEL_USER_BASE;
+    return (k >= 0 && k < (int)g_jit_models.size()) ? g_jit_models[(size_t)k] : nullptr;
+}
+static bool jit_supported(int model_id, int nx, int ny) {
+    JitModel* jm = jit_model(model_id);
+    return jm && jm->nx == nx && jm->ny == ny;
+}
+static hipError_t launch_step_user(const BankDev& b, int mode, const StepArgs& a, hipStream_t s) {
+    JitModel* jm = jit_model(b.model_id);
+    if (!jm || mode < 0 || mode > 3) return hipErrorInvalidValue;
+    int devid = 0;
+    hipError_t e = hipGetDevice(&devid);
+    if (e != hipSuccess) return e;
+    hipFunction_t fn = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_jit_mutex);
+        if ((int)jm->dev.size() <= devid) jm->dev.resize((size_t)devid + 1);
+        JitModel::PerDevice& pd = jm->dev[(size_t)devid];
+        if (!pd.mod && (e = hipModuleLoadData(&pd.mod, jm->code.data())) != hipSuccess) return e;
+        if (!pd.fn[mode] && (e = hipModuleGetFunction(&pd.fn[mode], pd.mod, jm->name[mode].c_str())) != hipSuccess) return e;
+        fn = pd.fn[mode];
+    }
+    BankDev bd = b;
+    const ModelD* models = b.models;
+    const FilterScal* scal = b.scal;
+    StepArgs aa = a;
+    void* args[] = {&bd, &models, &scal, &aa};
+    return hipModuleLaunchKernel(fn, (unsigned)(b.Ns / (BLOCK * STEP_PPT * STEP_ITERS)), (unsigned)b.F, 1, BLOCK, 1, 1, 0, s, args, nullptr);
+}

@@ -2,7 +2,9 @@
 // ------------------------------------------------------------------------------------------------
 // k_step — fused propagate + weight + running max
 // ------------------------------------------------------------------------------------------------
-template <class Model, int NX, int NY, int MODE>
+// PPT particles per thread (16-B vector accesses at 2; 1 halves the registers: models whose dynamics dominate, e.g. the quad-tank's
+// RK4 with 32 square roots per particle, gain more from the doubled occupancy than they lose on 8-B accesses)
+template <class Model, int NX, int NY, int MODE, int PPT = STEP_PPT>
 __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restrict__ models,
                                                  const FilterScal* scal, StepArgs a) {
     __shared__ double sm_max[BLOCK / 64];
@@ -54,27 +56,28 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
     }
 #pragma unroll 1
     for (int it = 0; it < STEP_ITERS; ++it) {
-        const int64_t i0 = ((int64_t)blockIdx.x * STEP_ITERS + it) * (BLOCK * STEP_PPT) + (int64_t)threadIdx.x * STEP_PPT;
-        double xs[STEP_PPT][NX];
+        const int64_t i0 = ((int64_t)blockIdx.x * STEP_ITERS + it) * (BLOCK * PPT) + (int64_t)threadIdx.x * PPT;
+        double xs[PPT][NX];
         if (MODE != MODE_WEIGHT) {
-            double xp[STEP_PPT][NX];
+            double xp[PPT][NX];
             if (do_res) {
-                const int2 av = *reinterpret_cast<const int2*>(anc + i0);
+                int32_t av[PPT];
+                if constexpr (PPT == 2) { const int2 a2 = *reinterpret_cast<const int2*>(anc + i0); av[0] = a2.x; av[1] = a2.y; }
+                else av[0] = anc[i0];
 #pragma unroll
                 for (int d = 0; d < NX; ++d) {
-                    xp[0][d] = xc[(size_t)d * Ns + av.x];
-                    xp[1][d] = xc[(size_t)d * Ns + av.y];
+#pragma unroll
+                    for (int p = 0; p < PPT; ++p) xp[p][d] = xc[(size_t)d * Ns + av[p]];
                 }
             } else {
 #pragma unroll
                 for (int d = 0; d < NX; ++d) {
-                    const double2 v = *reinterpret_cast<const double2*>(xc + (size_t)d * Ns + i0);
-                    xp[0][d] = v.x;
-                    xp[1][d] = v.y;
+                    if constexpr (PPT == 2) { const double2 v = *reinterpret_cast<const double2*>(xc + (size_t)d * Ns + i0); xp[0][d] = v.x; xp[1][d] = v.y; }
+                    else xp[0][d] = *(xc + (size_t)d * Ns + i0);
                 }
             }
 #pragma unroll
-            for (int p = 0; p < STEP_PPT; ++p) {
+            for (int p = 0; p < PPT; ++p) {
                 if constexpr (Model::RB) {
                     model.rb_propagate(xp[p], (uint32_t)(i0 + p), sb + a.step, k0, k1, a.rb_pred + f, xs[p]);
                     continue;
@@ -94,37 +97,36 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
             if (!(Model::RB && MODE == MODE_PROP_WEIGHT && a.has_y)) {
 #pragma unroll
                 for (int d = 0; d < NX; ++d) {
-                    double2 v;
-                    v.x = xs[0][d];
-                    v.y = xs[1][d];
-                    *reinterpret_cast<double2*>(xn + (size_t)d * Ns + i0) = v;
+                    if constexpr (PPT == 2) { double2 v; v.x = xs[0][d]; v.y = xs[1][d]; *reinterpret_cast<double2*>(xn + (size_t)d * Ns + i0) = v; }
+                    else *(xn + (size_t)d * Ns + i0) = xs[0][d];
                 }
             }
         } else {
 #pragma unroll
             for (int d = 0; d < NX; ++d) {
-                const double2 v = *reinterpret_cast<const double2*>(xc + (size_t)d * Ns + i0);
-                xs[0][d] = v.x;
-                xs[1][d] = v.y;
+                if constexpr (PPT == 2) { const double2 v = *reinterpret_cast<const double2*>(xc + (size_t)d * Ns + i0); xs[0][d] = v.x; xs[1][d] = v.y; }
+                else xs[0][d] = *(xc + (size_t)d * Ns + i0);
             }
         }
         if (MODE != MODE_PROP) {
-            double wp[STEP_PPT];
+            double wp[PPT];
             if (do_res) {                          // reset_weights!: w = log(1/N)
-                wp[0] = b.log1N;
-                wp[1] = b.log1N;
-            } else if (uniform) {
-                wp[0] = wconst;
-                wp[1] = wconst;
-            } else {
-                const double2 wv = *reinterpret_cast<const double2*>(w + i0);
-                wp[0] = pend ? (wv.x - m) - l : wv.x;  // lazy w .-= offset ; w .-= log1p(s)
-                wp[1] = pend ? (wv.y - m) - l : wv.y;
-            }
-            double wn[STEP_PPT];
-            double lamv[STEP_PPT];
 #pragma unroll
-            for (int p = 0; p < STEP_PPT; ++p) {
+                for (int p = 0; p < PPT; ++p) wp[p] = b.log1N;
+            } else if (uniform) {
+#pragma unroll
+                for (int p = 0; p < PPT; ++p) wp[p] = wconst;
+            } else {
+                double wr[PPT];
+                if constexpr (PPT == 2) { const double2 wv = *reinterpret_cast<const double2*>(w + i0); wr[0] = wv.x; wr[1] = wv.y; }
+                else wr[0] = w[i0];
+#pragma unroll
+                for (int p = 0; p < PPT; ++p) wp[p] = pend ? (wr[p] - m) - l : wr[p];  // lazy w .-= offset ; w .-= log1p(s)
+            }
+            double wn[PPT];
+            double lamv[PPT];
+#pragma unroll
+            for (int p = 0; p < PPT; ++p) {
                 double wv = wp[p];
                 if (MODE == MODE_AUX) {            // lambda .= 0; lambda += logpdf; w .+= lambda  (filtering.jl:201-204)
                     double lam = 0.0;
@@ -153,38 +155,35 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
                 bad = bad || (wv != wv);
                 bmax = llpf_fmax(bmax, wv);
             }
-            double2 wo;
-            wo.x = wn[0];
-            wo.y = wn[1];
-            *reinterpret_cast<double2*>(w + i0) = wo;
+            if constexpr (PPT == 2) { double2 wo; wo.x = wn[0]; wo.y = wn[1]; *reinterpret_cast<double2*>(w + i0) = wo; }
+            else w[i0] = wn[0];
             if constexpr (Model::RB) {             // correct! has updated xl (Kalman measurement update)
                 if (a.has_y) {
                     double* xdst = (MODE == MODE_WEIGHT) ? const_cast<double*>(xc) : xn;
 #pragma unroll
                     for (int d = 0; d < NX; ++d) {
-                        double2 v;
-                        v.x = xs[0][d];
-                        v.y = xs[1][d];
-                        *reinterpret_cast<double2*>(xdst + (size_t)d * Ns + i0) = v;
+                        if constexpr (PPT == 2) { double2 v; v.x = xs[0][d]; v.y = xs[1][d]; *reinterpret_cast<double2*>(xdst + (size_t)d * Ns + i0) = v; }
+                        else *(xdst + (size_t)d * Ns + i0) = xs[0][d];
                     }
                 }
             }
             if (MODE == MODE_AUX) {
-                double2 lo;
-                lo.x = lamv[0];
-                lo.y = lamv[1];
-                *reinterpret_cast<double2*>(b.lam + (size_t)f * Ns + i0) = lo;
+                if constexpr (PPT == 2) { double2 lo; lo.x = lamv[0]; lo.y = lamv[1]; *reinterpret_cast<double2*>(b.lam + (size_t)f * Ns + i0) = lo; }
+                else b.lam[(size_t)f * Ns + i0] = lamv[0];
             }
             if (a.accumulate) {   // merged schedule: exp-sums, quanta and tile sums of the new weights formed here
-                ulonglong2 qv;
-                double e0, e1;
-                qv.x = wacc.add(wn[0], off, a.K, a.need_e2 != 0, &e0);
-                qv.y = wacc.add(wn[1], off, a.K, a.need_e2 != 0, &e1);
-                *reinterpret_cast<ulonglong2*>(b.quanta_next + (size_t)f * Ns + i0) = qv;
-                qsum += qv.x + qv.y;
+                uint64_t qv[PPT];
+                double ev[PPT];
+#pragma unroll
+                for (int p = 0; p < PPT; ++p) { qv[p] = wacc.add(wn[p], off, a.K, a.need_e2 != 0, &ev[p]); qsum += qv[p]; }
+                if constexpr (PPT == 2) { ulonglong2 q2; q2.x = qv[0]; q2.y = qv[1]; *reinterpret_cast<ulonglong2*>(b.quanta_next + (size_t)f * Ns + i0) = q2; }
+                else b.quanta_next[(size_t)f * Ns + i0] = qv[0];
                 if (a.want_xmean) {
 #pragma unroll
-                    for (int d = 0; d < NX; ++d) { xm[d] = xm[d] + xs[0][d] * e0; xm[d] = xm[d] + xs[1][d] * e1; }
+                    for (int d = 0; d < NX; ++d) {
+#pragma unroll
+                        for (int p = 0; p < PPT; ++p) xm[d] = xm[d] + xs[p][d] * ev[p];
+                    }
                 }
             }
         }
@@ -203,11 +202,11 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
         if (threadIdx.x == 0) {
             uint64_t q = 0;
             for (int k = 0; k < BLOCK / 64; ++k) q += sm_acc[k][0];
-            const int64_t tile = ((int64_t)blockIdx.x * STEP_TILE) / TILE;
+            const int64_t tile = ((int64_t)blockIdx.x * (BLOCK * PPT * STEP_ITERS)) / TILE;
             if (q) atomicAdd(reinterpret_cast<unsigned long long*>(tileq_slot(b, a.parity, f) + tile), (unsigned long long)q);
             if (blockIdx.x == 0) {
                 FilterScal* scw = b.scal + f;
-                if (a.accumulate) scw->xm_parts = b.P1;
+                if (a.accumulate) scw->xm_parts = (int32_t)gridDim.x;
                 scw->off_slot[a.parity] = off;
                 scw->exact_slot[a.parity] = 0;
                 scw->e2v_slot[a.parity] = a.need_e2;

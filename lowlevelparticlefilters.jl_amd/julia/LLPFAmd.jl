@@ -34,7 +34,7 @@ import LowLevelParticleFilters: AbstractParticleFilter, ParticleFilteringSolutio
 
 export GPUParticleFilter, GPUAdvancedParticleFilter, GPUAuxiliaryParticleFilter, GPURBPF, GPUFilterBank, GPUMultiBank,
        LinearDynamics, LinearMeasurement, QuadTankDynamics, QuadTankMeasurement, GaussianLikelihood,
-       RBLinearModel, RBBilinearModel, GaussianSpec, linear_state, shared_covariance, loglik_multi, mbank_unique_id,
+       RBLinearModel, RBBilinearModel, GaussianSpec, UserDynamics, UserMeasurement, linear_state, shared_covariance, loglik_multi, mbank_unique_id,
        seed!, ancestors, last_resampled
 
 const LIB = get(ENV, "LLPF_HIP_LIB", joinpath(@__DIR__, "..", "libllpf_hip.so"))
@@ -226,6 +226,38 @@ x): An(xn) = An0 + sum_k xn[k] Ank[k]; every particle carries its own Kalman cov
 :176/:247).  `fn` / `gn` are a LinearDynamics / LinearMeasurement pair over xn or the quad-tank pair (xn = the four levels)."""
 struct RBBilinearModel
     fn; gn; An0; Ank::Vector; Al; Bl; Cl; R1l; d0l
+end
+
+"""
+    UserDynamics(device_src, nx, nu, ny; host = nothing, A = zeros(0,0), B = zeros(0,0), C = zeros(0,0), qt = zeros(16), supersample = 1)
+
+A model the engine has no built-in for: HIP device source defining `struct UserModel` (prepare / dynamics / measurement, see
+include/llpf.h `llpf_model_compile`), compiled for the GPU with hiprtc when the filter is constructed.  `A, B, C, qt` fill the
+parameter block the snippet reads (`m->A`, ...).  `host` (optional) is the same dynamics as a Julia callable `(x,u,p,t)`, used
+only by host-side `simulate`.  Pair it with `UserMeasurement(host)`."""
+struct UserDynamics
+    src::String
+    nx::Int; nu::Int; ny::Int
+    host
+    A; B; C
+    qt::Vector{Float64}
+    supersample::Int
+end
+UserDynamics(src, nx, nu, ny; host = nothing, A = zeros(0, 0), B = zeros(0, 0), C = zeros(0, 0), qt = zeros(16), supersample = 1) =
+    UserDynamics(String(src), nx, nu, ny, host, A, B, C, collect(Float64, qt), supersample)
+(f::UserDynamics)(x, u, p, t) = f.host === nothing ? error("no host version of this device model was given") : f.host(x, u, p, t)
+(f::UserDynamics)(x, u, p, t, noise) = f(x, u, p, t)
+struct UserMeasurement
+    host
+end
+(g::UserMeasurement)(x, u, p, t) = g.host === nothing ? error("no host version of this device model was given") : g.host(x, u, p, t)
+(g::UserMeasurement)(x, u, p, t, noise) = g(x, u, p, t)
+function cmodel(f::UserDynamics, ::UserMeasurement, df, dg, d0, Ts)
+    id = Ref{Int32}(-1)
+    check(ccall((:llpf_model_compile, LIB), Cint, (Cstring, Int32, Int32, Ref{Int32}), f.src, f.nx, f.ny, id))
+    CModel(id[], f.nx, f.nu, f.ny, pad(isempty(f.A) ? Float64[] : rowmajor(f.A), 64), pad(isempty(f.B) ? Float64[] : rowmajor(f.B), 64),
+           pad(isempty(f.C) ? Float64[] : rowmajor(f.C), 64), pad(f.qt, 16), f.supersample, 0, Ts, cgauss(df), cgauss(dg), cgauss(d0),
+           NOGAUSS, NOGAUSS, NOCOUPLING)
 end
 
 model_dims(f::LinearDynamics, g::LinearMeasurement) = (size(f.A, 1), size(f.B, 2), size(g.C, 1))

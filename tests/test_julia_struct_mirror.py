@@ -128,7 +128,8 @@ def test_julia_model_ids_strategies_and_ccalls_match_the_header():
     jl = open(JL).read()
     hdr = open(HDR).read()
     ids = dict(re.findall(r"(LLPF_MODEL_\w+)\s*=\s*(\d+)", hdr))
-    assert ids == {"LLPF_MODEL_LINEAR_GAUSSIAN": "0", "LLPF_MODEL_QUADTANK_RK4": "1", "LLPF_MODEL_RB_LINEAR": "2", "LLPF_MODEL_RB_BILINEAR": "3"}
+    assert ids == {"LLPF_MODEL_LINEAR_GAUSSIAN": "0", "LLPF_MODEL_QUADTANK_RK4": "1", "LLPF_MODEL_RB_LINEAR": "2", "LLPF_MODEL_RB_BILINEAR": "3",
+                   "LLPF_MODEL_USER_BASE": "1000"}
     # the wrapper builds CModel(<id>, ...) literally: one constructor call per model kind
     assert re.search(r"cmodel\(f::LinearDynamics.*?CModel\(0,", jl, re.S)
     assert re.search(r"cmodel\(f::QuadTankDynamics.*?CModel\(1,", jl, re.S)
@@ -169,7 +170,7 @@ def test_julia_model_ids_strategies_and_ccalls_match_the_header():
         seen.add(sym)
     for need in ("llpf_create", "llpf_destroy", "llpf_reset", "llpf_correct", "llpf_predict", "llpf_update", "llpf_run", "llpf_aux_run",
                  "llpf_smooth", "llpf_bank_create", "llpf_bank_run", "llpf_mbank_create", "llpf_mbank_create_rank", "llpf_mbank_unique_id",
-                 "llpf_mbank_run", "llpf_mbank_destroy", "llpf_get_ancestors", "llpf_get_bins", "llpf_maxw"):
+                 "llpf_mbank_run", "llpf_mbank_destroy", "llpf_get_ancestors", "llpf_get_bins", "llpf_maxw", "llpf_model_compile"):
         assert need in seen, need
 
 

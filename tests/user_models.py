@@ -1,0 +1,74 @@
+"""Device-source snippets a USER of the C ABI would hand to llpf_model_compile (include/llpf.h): the Model concept of
+csrc/kernels/models.hpp written out for two systems.  The quad-tank one restates examples/example_quadtank.jl:8-35 through rk4 of
+src/utils.jl:220-237 with the constants taken from the parameter block (m->qt); it evaluates the same expressions in the same
+order as the engine's built-in model, so the two must agree to the bit — which is the test."""
+
+QUADTANK_SRC = r'''
+struct UserModel {
+    static constexpr bool RB = false;
+    double c1a, c1a_sw, c1b, c1u, c2a, c2b, c2u, c3a, c3u, c4a, c4u, tg, eps, tsw, u0, u1, t0, h;
+    int ss;
+    DEV void prepare(const ModelD* m, const double* u, double t) {
+        const double* q = m->qt;        // k1 k2 g A1..A4 a1..a4 gamma1 gamma2 tswitch a1factor eps
+        c1a = (-q[7]) / q[3];   c1a_sw = (-(q[7] * q[14])) / q[3];   c1b = q[9] / q[3];    c1u = (q[11] * q[0]) / q[3];
+        c2a = (-q[8]) / q[4];   c2b = q[10] / q[4];                  c2u = (q[12] * q[1]) / q[4];
+        c3a = (-q[9]) / q[5];   c3u = ((1.0 - q[12]) * q[1]) / q[5];
+        c4a = (-q[10]) / q[6];  c4u = ((1.0 - q[11]) * q[0]) / q[6];
+        tg = 2.0 * q[2];  eps = q[15];  tsw = q[13];
+        u0 = u[0];  u1 = u[1];  t0 = t;
+        ss = m->supersample < 1 ? 1 : m->supersample;
+        h = m->Ts / (double)ss;
+    }
+    DEV void rhs(const double* x, double t, double* xd) const {
+        double s[4];
+        for (int i = 0; i < 4; ++i) { const double v = tg * x[i]; s[i] = llpf_sqrt_pos((v > 0.0 ? v : 0.0) + eps); }
+        const double ca = (t > tsw) ? c1a_sw : c1a;
+        xd[0] = ca * s[0] + c1b * s[2] + c1u * u0;
+        xd[1] = c2a * s[1] + c2b * s[3] + c2u * u1;
+        xd[2] = c3a * s[2] + c3u * u1;
+        xd[3] = c4a * s[3] + c4u * u0;
+    }
+    DEV void dynamics(const double* x0, double* out) const {
+        double x[4], f1[4], f2[4], f3[4], f4[4], xt[4];
+        double t = t0;
+        for (int i = 0; i < 4; ++i) x[i] = x0[i];
+        for (int it = 0; it < ss; ++it) {
+            rhs(x, t, f1);
+            for (int i = 0; i < 4; ++i) xt[i] = x[i] + (h / 2.0) * f1[i];
+            rhs(xt, t + h / 2.0, f2);
+            for (int i = 0; i < 4; ++i) xt[i] = x[i] + (h / 2.0) * f2[i];
+            rhs(xt, t + h / 2.0, f3);
+            for (int i = 0; i < 4; ++i) xt[i] = x[i] + h * f3[i];
+            rhs(xt, t + h, f4);
+            for (int i = 0; i < 4; ++i) x[i] = x[i] + (h / 6.0) * (((f1[i] + 2.0 * f2[i]) + 2.0 * f3[i]) + f4[i]);
+            t = t + h;
+        }
+        for (int i = 0; i < 4; ++i) out[i] = x[i];
+    }
+    DEV void measurement(const double* x, double* out) const { out[0] = x[0]; out[1] = x[1]; }
+};
+'''
+
+# a model the engine has no built-in for: a pendulum with a cubic damper, Euler-discretised, measured through sin(angle)
+PENDULUM_SRC = r'''
+struct UserModel {
+    static constexpr bool RB = false;
+    double g_over_l, damp, dt, torque;
+    DEV void prepare(const ModelD* m, const double* u, double t) {
+        g_over_l = m->qt[0]; damp = m->qt[1]; dt = m->Ts; torque = (m->nu > 0 && u) ? u[0] : 0.0;
+    }
+    DEV void dynamics(const double* x, double* out) const {
+        double sn, cs;
+        const double turns = x[0] * 0.15915494309189535;            // angle / (2 pi)
+        llpf_sincos2pi(turns - llpf_rint(turns) < 0.0 ? turns - llpf_rint(turns) + 1.0 : turns - llpf_rint(turns), &sn, &cs);
+        out[0] = x[0] + dt * x[1];
+        out[1] = x[1] + dt * (torque - g_over_l * sn - damp * x[1] * x[1] * x[1]);
+    }
+    DEV void measurement(const double* x, double* out) const {
+        double sn, cs;
+        const double turns = x[0] * 0.15915494309189535;
+        llpf_sincos2pi(turns - llpf_rint(turns) < 0.0 ? turns - llpf_rint(turns) + 1.0 : turns - llpf_rint(turns), &sn, &cs);
+        out[0] = sn;
+    }
+};
+'''
