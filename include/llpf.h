@@ -189,7 +189,10 @@ int  llpf_run(llpf_filter* f, const double* U, const double* Y, int64_t T, doubl
  *                     mode 1: loglik(pf::AuxiliaryParticleFilter,u,y,p)              src/smoothing.jl:232-236
  *                     (call llpf_reset first; t_k = k * Ts; all launches are enqueued back to back unless history
  *                     outputs are requested)
- * The AuxiliaryParticleFilter{AdvancedParticleFilter} variant (filtering.jl:219-234) is not provided. */
+ * AuxiliaryParticleFilter{AdvancedParticleFilter} (filter_kind LLPF_ADVANCED_PARTICLE_FILTER; src/filtering.jl:219-234): the same
+ * verbs; its predict! uses the look-ahead weights only to choose the ancestors, then propagates AGAIN from the previous particles
+ * with noise and resets the weights (lambda is discarded, so the following correct! returns ~0, as in the reference).  Driven
+ * one step per call; llpf_aux_run loops the steps synchronously. */
 int  llpf_aux_correct(llpf_filter* f, double* ll);
 int  llpf_aux_predict(llpf_filter* f, const double* u, const double* y1, double t);
 int  llpf_aux_update(llpf_filter* f, const double* u, const double* y1, double t, double* ll);

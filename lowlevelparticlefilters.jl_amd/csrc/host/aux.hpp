@@ -94,10 +94,53 @@ static int bank_aux_correct(Bank& b, double* ll_out /* [F] or null */, const Aux
     return check_status(b, h);
 }
 
+// predict!(pf::AuxiliaryParticleFilter{<:AdvancedParticleFilter}, u, y, p, t) — reference src/filtering.jl:219-234: the look-ahead
+// weights lambda (noise-free prediction) only steer the resampling; the particles are then propagated AGAIN from xprev[j], with
+// noise, and the weights are reset (lambda is discarded: the following correct!, which is logsumexp! only, returns ~0).
+// Device: k_step<MODE_AUX> (x' = f(x) into the scratch plane, w <- w + lambda, exp-sums) -> k_resample (expnormalize! + forced
+// resample: ancestors) -> k_step<MODE_PROP> from the ORIGINAL particles -> reset_weights!.  Synchronous.
+static int aux_predict_dev_advanced(Bank& b, const double* d_u, const double* d_y1, bool has_y1, double t) {
+    CHK(aux_ensure_lam(b));
+    CHK(aux_launch_look(b, d_u, d_y1, has_y1, t, 0, 0));
+    const int slot = b.parity;
+    b.parity = (b.parity + 1) % ACC_NSLOT;
+    b.qcur ^= 1;                                  // the quanta of w + lambda are the current ones; b.cur stays: xnext holds x' and is overwritten
+    BankDev d = b.dev();
+    ResArgs ra{};
+    ra.mode = RES_FINALIZE | RES_RESAMPLE; ra.parity = slot; ra.step = rel_step(b); ra.M = (int32_t)b.N; ra.anc_out = b.d_anc;
+    ra.force = 1; ra.fast_head = 1; ra.u_from_scal = 1; ra.k = 0;
+    HIPC(launch_resample(d, ra, b.stream));
+    std::vector<int> fl;
+    int64_t kf;
+    CHK(poll_fallback(b, fl, kf));
+    if (!fl.empty()) {   // expnormalize! of w + lambda in the exact-max form
+        CHK(clear_slot_sums(b, slot, fl));
+        HIPC(launch_norm(d, slot, 0, 0, rel_step(b), 1, 0, 0, b.stream));
+        ra.fast_head = 0; ra.only_fallback = 1;
+        HIPC(launch_resample(d, ra, b.stream));
+        CHK(clear_fallback(b, fl));
+    }
+    StepArgs a{};
+    a.u = d_u; a.y = nullptr; a.t_prop = t; a.t_meas = t; a.step = rel_step(b); a.has_y = 0; a.parity = b.parity;
+    a.K = llpf_qbits(b.N); a.k = 0;
+    HIPC(launch_step(d, MODE_PROP, a, b.stream));             // propagate_particles!(pf.pf, u, j, p, t): with noise, from xprev[j]
+    HIPC(launch_post_predict(d, b.stream));                   // reset_weights!(s)
+    b.cur ^= 1;
+    b.n_predict++;
+    b.t_index++;
+    b.aux_pending = false;
+    b.we_is_lambda = false;
+    return LLPF_OK;
+}
+
 // Single-call predict!(pf::AuxiliaryParticleFilter, u, y1, p, t): synchronous.  d_u / d_y1 are device pointers.
 static int aux_predict_dev(Bank& b, const double* d_u, const double* d_y1, bool has_y1, double t, int want_xm) {
     if (is_rb(b) || is_rbfull(b)) return fail(LLPF_ERR_ARG, "the auxiliary filter is not defined for the Rao-Blackwellized model");
     if (b.cfg.resampling_strategy == LLPF_RESAMPLE_RESIDUAL) return fail(LLPF_ERR_ARG, "the auxiliary filter supports systematic and stratified resampling");
+    if (b.cfg.filter_kind == LLPF_ADVANCED_PARTICLE_FILTER) {
+        if (b.aux_pending) CHK(bank_aux_correct(b, nullptr, AuxOuts{}, 0));
+        return aux_predict_dev_advanced(b, d_u, d_y1, has_y1, t);
+    }
     if (b.aux_pending) CHK(bank_aux_correct(b, nullptr, AuxOuts{}, 0));   // contract: predict! works on normalised weights
     CHK(aux_ensure_lam(b));
     CHK(aux_launch_look(b, d_u, d_y1, has_y1, t, 0, 0));
@@ -195,14 +238,15 @@ static int bank_aux_run(Bank& b, const double* U, const double* Y, int64_t T, in
     // correct! of step 0 (synchronous: after reset! the weights are uniform and take the exact-max form).  loglik with
     // T = 1 consists of the wrapped filter's update! alone.
     if (mode == 0 || T > 1) CHK(bank_aux_correct(b, nullptr, outs, 0));
-    if (hist) {
+    const bool advanced = b.cfg.filter_kind == LLPF_ADVANCED_PARTICLE_FILTER;     // its predict! is driven synchronously (filtering.jl:219-234)
+    if (hist || advanced) {
         // step-synchronous form (history is copied out between correct! and predict!)
-        if (mode == 0 || T > 1) CHK(record(0));
+        if (hist && (mode == 0 || T > 1)) CHK(record(0));
         for (int64_t k = 0; k < n_aux; ++k) {
             CHK(aux_predict_dev(b, b.nu > 0 ? b.d_U + k * b.nu : nullptr, b.d_Y + (k + 1) * b.ny, has_y(k + 1), (double)k * Ts, want_xm));
             if (mode == 1 && k + 1 == T - 1) break;           // loglik: the last step is the wrapped filter's update!
             CHK(bank_aux_correct(b, nullptr, outs, k + 1));
-            CHK(record(k + 1));
+            if (hist) CHK(record(k + 1));
         }
     } else if (n_aux > 0) {
         // epochs: e = 3k+1 look-ahead(k), 3k+2 resample+propagate(k), 3k+3 finalize(k+1)

@@ -255,7 +255,7 @@ DEV ResHead res_head(const BankDev& b, const ResArgs& a, int f, int tile, ResSha
                 sc->norm_pending = a.keep_norm ? 0 : 1;
                 if (a.keep_norm) sc->wmax = h.mtrue;              // set_weights: w stays as installed
                 if (h.status) sc->status = h.status;
-                sc->do_resample = h.dr;
+                sc->do_resample = (h.dr || a.force) ? 1 : 0;      // `force`: the auxiliary filter resamples whatever the ESS (filtering.jl:206, 225)
                 if (a.accumulate) sc->ll_total = sc->ll_total + ll;
                 if (a.ll_steps) a.ll_steps[(size_t)a.row * b.F + f] = ll;
                 sh.dval[0] = inv;

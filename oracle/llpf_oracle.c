@@ -1120,8 +1120,8 @@ double orc_update(orc_filter* f, const double* u, const double* y, double t) {
 
 /* ------------------------------------------------------------------------------------------
  * AuxiliaryParticleFilter{ParticleFilter} — src/PFtypes.jl:38-49, src/filtering.jl:170-217, 367-384,
- * src/smoothing.jl:232-236.  (The {AdvancedParticleFilter} variant, filtering.jl:219-234, discards
- * lambda and re-propagates with noise; not restated.)
+ * src/smoothing.jl:232-236.  The {AdvancedParticleFilter} variant, filtering.jl:219-234, discards
+ * lambda and re-propagates with noise: restated inside orc_aux_predict for filter_kind LLPF_ADVANCED_PARTICLE_FILTER.
  * ---------------------------------------------------------------------------------------- */
 /* correct!(pf::AuxiliaryParticleFilter, u, y, p, t) — src/filtering.jl:170-174: the measurement update was done in
  * the predict step, only ll = logsumexp!(state) remains (so y of the very first call is never used). */
@@ -1174,6 +1174,27 @@ void orc_aux_predict(orc_filter* f, const double* u, const double* y1, double t)
     } else {
         orc_expnormalize_inplace(f->w, N);
         orc_resample(f->cfg.resampling_strategy, f->w, N, N, f->U_buf, f->j, f->bins, ORC_ORDER_REFERENCE);
+    }
+    if (f->cfg.filter_kind == LLPF_ADVANCED_PARTICLE_FILTER) {
+        /* predict!(pf::AuxiliaryParticleFilter{<:AdvancedParticleFilter}, ...) — src/filtering.jl:219-234: lambda only steered the
+         * resampling; reset_weights!(s) (:226), then propagate_particles!(pf.pf, u, j, p, t) (:228): "propagate with noise and
+         * permutation" — from the PREVIOUS particles xprev[j], the noise-free prediction in s.x is overwritten */
+        ORC_PAR
+        for (int64_t i = 0; i < N; ++i) {
+            double fx[MAXD], nz[MAXD];
+            orc_dynamics(&f->cfg.model, f->xprev + f->j[i] * nx, u, t, fx);
+            gauss_sample(&f->df, f->xi_buf + i * nx, nz);
+            for (int d = 0; d < nx; ++d) f->x[i * nx + d] = fx[d] + nz[d];
+        }
+        fill_uniform_weights(f, dev ? llpf_log(1.0 / (double)N) : log(1.0 / (double)N));
+        f->maxw = 0.0;
+        f->t += 1;                                            /* :230 */
+        memcpy(f->xprev, f->x, sizeof(double) * (size_t)N * nx);  /* :231 */
+        f->dn_valid = 0;
+        f->aux_pending = 0;
+        f->last_resampled = 1;
+        f->resample_count++;
+        return;
     }
     /* permute_with_buffer!(s.x, s.xprev, j): buf[i] = x[j[i]]; copyto!(x, buf) — src/utils.jl:81-86 */
     for (int64_t i = 0; i < N; ++i)

@@ -129,3 +129,46 @@ def test_aux_filter_async_run_with_several_outliers():
             rg = g.run_aux(U[:T], Y[:T], mode, ll_steps=True); ro = o.run_aux(U[:T], Y[:T], mode, ll_steps=True)
             assert np.array_equal(rg["ll_steps"].view(np.uint64), ro["ll_steps"].view(np.uint64)), (T, mode)
             _compare_state(g, o)
+
+
+@pytest.mark.parametrize("which", ["quadtank", "lineargaussian"])
+def test_aux_filter_over_an_advanced_filter(which):
+    """AuxiliaryParticleFilter{AdvancedParticleFilter} (src/filtering.jl:219-234): the look-ahead weights only choose the ancestors,
+    the particles are propagated again from xprev[j] with noise and the weights reset.  Single steps, forward_trajectory and loglik
+    loops: bit-identical to the device-order oracle, within tolerance of the reference order; every auxiliary correct! returns ~0."""
+    if which == "quadtank":
+        model = M.quadtank_model()
+        U, Y = M.quadtank_data(25, seed=2)
+        t0 = 490.0
+    else:
+        model = M.lg_c1_model()
+        _, U, Y = M.simulate_lg(model, 25)
+        t0 = 0.0
+    cfg = _cfg(model, 4000, S.RESAMPLE_SYSTEMATIC, 0.5, seed=13, kind=S.ADVANCED_PARTICLE_FILTER)
+    g = _capi.FilterHandle(cfg); o = ob.OracleFilter(cfg, ob.ORDER_DEVICE); r = ob.OracleFilter(cfg, ob.ORDER_REFERENCE)
+    for h in (g, o, r):
+        h.reset()
+    for k in range(10):
+        ll_g, ll_o, ll_r = g.aux_correct(), o.aux_correct(), r.aux_correct()
+        assert ll_g == ll_o and abs(ll_g - ll_r) < TOL_LL_STEP and abs(ll_g) < 1e-9            # logsumexp! of uniform weights
+        _compare_state(g, o)
+        y1 = None if k == 4 else Y[k + 1]
+        t = t0 + k * model.Ts
+        for h in (g, o, r):
+            h.aux_predict(U[k], y1, t)
+        _compare_state(g, o)
+        assert g.last_resampled() and np.all(g.weights() == np.log(1.0 / 4000))                  # reset_weights!
+        assert np.array_equal(g.ancestors(), r.ancestors())
+        np.testing.assert_allclose(g.particles(), r.particles(), rtol=1e-12, atol=1e-12)
+    # the run loops (driven synchronously for this kind)
+    for mode in (0, 1):
+        g2 = _capi.FilterHandle(cfg); o2 = ob.OracleFilter(cfg, ob.ORDER_DEVICE)
+        g2.reset(); o2.reset()
+        rg = g2.run_aux(U, Y, mode, ll_steps=True, history=(mode == 0))
+        ro = o2.run_aux(U, Y, mode, ll_steps=True, history=(mode == 0))
+        assert np.array_equal(rg["ll_steps"].view(np.uint64), ro["ll_steps"].view(np.uint64))
+        if mode == 0:
+            assert np.array_equal(rg["x"], ro["x"]) and np.array_equal(rg["we"], ro["we"])
+        else:
+            assert rg["ll_steps"][-1] != 0.0 and np.all(np.abs(rg["ll_steps"][:-1]) < 1e-9)       # only the wrapped filter's update! counts
+        _compare_state(g2, o2)
