@@ -251,7 +251,7 @@ int  llpf_get_particles(llpf_filter* f, double* dst /* N*nx */);          /* par
 int  llpf_get_weights(llpf_filter* f, double* dst /* N */);               /* weights(pf): log-weights  */
 int  llpf_get_expweights(llpf_filter* f, double* dst /* N */);            /* expweights(pf)    */
 int  llpf_get_ancestors(llpf_filter* f, int64_t* dst /* N, 0-based */);   /* state(pf).j       */
-int  llpf_get_bins(llpf_filter* f, double* dst /* N */);                  /* state(pf).bins (as used by the last resample) */
+int  llpf_get_bins(llpf_filter* f, double* dst /* N */);                  /* state(pf).bins (as used by the last resample); LLPF_ERR_ARG for ResampleResidual */
 int  llpf_set_particles(llpf_filter* f, const double* src /* N*nx */);    /* state(pf).x .= , xprev .=  */
 int  llpf_set_weights(llpf_filter* f, const double* w /* N log-weights */); /* state(pf).w .= w; we .= exp.(w) */
 int  llpf_set_index(llpf_filter* f, int64_t t);
@@ -266,8 +266,8 @@ int  llpf_maxw(llpf_filter* f, double* maxw);                             /* sta
 int  llpf_logsumexp(int32_t device, double* w, double* we, int64_t n, double* ll);
 /* j = resample(strategy, we, M) — reference src/resample.jl:12-117.  U holds the uniform draws the
  * reference takes from the global rand(): 1 value (systematic) or m values (stratified; residual: U[i] is the
- * draw of output i, read only for the outputs after the deterministic copies).  j is in/out: entries whose
- * threshold is never met keep their input value, as in the reference. */
+ * draw of output i, read only for the outputs after the deterministic copies) — the caller's U must hold that many.  j is
+ * in/out: entries whose threshold is never met keep their input value, as in the reference. */
 int  llpf_resample(int32_t device, int32_t strategy, const double* we, int64_t n, int64_t m,
                    const double* U, int64_t* j /* m, 0-based */);
 /* the uniforms the filter path draws for its resample at Philox step `step` (host evaluation of the

@@ -611,6 +611,9 @@ def resample(strategy, we, U, m=None, j0=None, device=0):
     m = n if m is None else int(m)
     j = np.zeros(m, dtype=np.int64) if j0 is None else np.ascontiguousarray(j0, dtype=np.int64).copy()
     U = f64(np.atleast_1d(U))
+    need = 1 if strategy == S.RESAMPLE_SYSTEMATIC else m
+    if U.size < need or j.size < m:
+        raise ValueError("resample: %d uniform(s) and %d ancestor slots are needed" % (need, m))
     check(lib().llpf_resample(device, strategy, dptr(we), n, m, dptr(U), iptr(j)))
     return j
 

@@ -319,8 +319,6 @@ class AuxiliaryParticleFilter:
             pf = args[0]
         else:
             pf = ParticleFilter(*args, **kwargs)
-        if isinstance(pf, AdvancedParticleFilter):
-            raise NotImplementedError("AuxiliaryParticleFilter{AdvancedParticleFilter} (reference src/filtering.jl:219-234) is not provided")
         object.__setattr__(self, "pf", pf)
 
     def __getattr__(self, name):            # getproperty forwarding, src/PFtypes.jl:101-105

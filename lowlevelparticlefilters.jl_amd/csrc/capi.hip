@@ -155,6 +155,7 @@ int llpf_bank_aux_run(llpf_bank* b, const double* U, const double* Y, int64_t T,
 int llpf_rb_get_covariance(llpf_filter* f, double* R) {
     NEEDF(f);
     if (!is_rb(f->bank)) return fail(LLPF_ERR_ARG, "not a Rao-Blackwellized filter");
+    if (!R) return fail(LLPF_ERR_ARG, "null output");
     const int nl = f->bank.nx - f->bank.cfg.model.nxn;
     for (int i = 0; i < nl * nl; ++i) R[i] = f->bank.rb[0].R[i];
     return LLPF_OK;
@@ -202,6 +203,9 @@ int llpf_get_ancestors(llpf_filter* f, int64_t* dst) {
 int llpf_get_bins(llpf_filter* f, double* dst) {
     NEEDF(f);
     Bank& b = f->bank;
+    if (!dst) return fail(LLPF_ERR_ARG, "null output");
+    if (b.cfg.resampling_strategy == LLPF_RESAMPLE_RESIDUAL)   // the reference leaves the bins of the RESIDUAL weights there (src/resample.jl:98-104)
+        return fail(LLPF_ERR_ARG, "state(pf).bins is not provided for residual resampling");
     CHK(use_device(b));
     BankDev d = b.dev();
     ResArgs ra{};
@@ -582,30 +586,40 @@ int llpf_resample_uniforms(int32_t strategy, int64_t m, uint64_t seed, uint32_t 
 int llpf_selftest_math(int32_t device, int32_t which, const double* in, double* out, int64_t n) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(LLPF_ERR_NO_DEVICE, "no HIP device visible");
+    if (!in || !out || n < 1) return fail(LLPF_ERR_ARG, "bad arguments");
     HIPC(hipSetDevice(device));
     double *di = nullptr, *dout = nullptr;
-    HIPC(hipMalloc(&di, sizeof(double) * n));
-    HIPC(hipMalloc(&dout, sizeof(double) * n));
-    HIPC(hipMemcpy(di, in, sizeof(double) * n, hipMemcpyHostToDevice));
-    HIPC(launch_selftest_math(which, di, dout, n, nullptr));
-    HIPC(hipDeviceSynchronize());
-    HIPC(hipMemcpy(out, dout, sizeof(double) * n, hipMemcpyDeviceToHost));
+    auto body = [&]() -> int {
+        HIPC(hipMalloc(&di, sizeof(double) * n));
+        HIPC(hipMalloc(&dout, sizeof(double) * n));
+        HIPC(hipMemcpy(di, in, sizeof(double) * n, hipMemcpyHostToDevice));
+        HIPC(launch_selftest_math(which, di, dout, n, nullptr));
+        HIPC(hipDeviceSynchronize());
+        HIPC(hipMemcpy(out, dout, sizeof(double) * n, hipMemcpyDeviceToHost));
+        return LLPF_OK;
+    };
+    const int rc = body();
     hipFree(di);
     hipFree(dout);
-    return LLPF_OK;
+    return rc;
 }
 int llpf_selftest_normals(int32_t device, uint64_t seed, uint32_t step, uint32_t stream, int32_t nd, double* out, int64_t n) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(LLPF_ERR_NO_DEVICE, "no HIP device visible");
     if (nd < 1 || nd > MAXD) return fail(LLPF_ERR_ARG, "nd out of range");
+    if (!out || n < 1) return fail(LLPF_ERR_ARG, "bad arguments");
     HIPC(hipSetDevice(device));
     double* dout = nullptr;
-    HIPC(hipMalloc(&dout, sizeof(double) * n * nd));
-    HIPC(launch_selftest_normals((uint32_t)seed, (uint32_t)(seed >> 32), step, stream, nd, dout, n, nullptr));
-    HIPC(hipDeviceSynchronize());
-    HIPC(hipMemcpy(out, dout, sizeof(double) * n * nd, hipMemcpyDeviceToHost));
+    auto body = [&]() -> int {
+        HIPC(hipMalloc(&dout, sizeof(double) * n * nd));
+        HIPC(launch_selftest_normals((uint32_t)seed, (uint32_t)(seed >> 32), step, stream, nd, dout, n, nullptr));
+        HIPC(hipDeviceSynchronize());
+        HIPC(hipMemcpy(out, dout, sizeof(double) * n * nd, hipMemcpyDeviceToHost));
+        return LLPF_OK;
+    };
+    const int rc = body();
     hipFree(dout);
-    return LLPF_OK;
+    return rc;
 }
 
 }  // extern "C"

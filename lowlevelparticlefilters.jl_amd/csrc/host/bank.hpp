@@ -244,6 +244,8 @@ static int bank_create(const llpf_config* cfg, const llpf_model* models, int F, 
         cfg->resampling_strategy != LLPF_RESAMPLE_RESIDUAL)
         return fail(LLPF_ERR_ARG, "resampling_strategy must be systematic, stratified or residual");
     if (!(cfg->resample_threshold >= 0.0 && cfg->resample_threshold <= 1.0)) return fail(LLPF_ERR_ARG, "resample_threshold must be in [0,1]");
+    if (cfg->filter_kind != LLPF_PARTICLE_FILTER && cfg->filter_kind != LLPF_ADVANCED_PARTICLE_FILTER)
+        return fail(LLPF_ERR_ARG, "filter_kind must be LLPF_PARTICLE_FILTER or LLPF_ADVANCED_PARTICLE_FILTER");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(LLPF_ERR_NO_DEVICE, "no HIP device visible; this engine has no CPU fallback");

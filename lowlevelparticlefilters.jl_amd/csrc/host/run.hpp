@@ -150,10 +150,16 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
     // step-synchronous loop below copies row by row instead.
     const size_t hist_rows = (size_t)T * b.N;
     const size_t hist_doubles = (x_hist ? hist_rows * b.nxp : 0) + (w_hist ? hist_rows : 0) + (we_hist ? hist_rows : 0);
-    const bool hist_dev = hist && hist_doubles * sizeof(double) <= ((size_t)16 << 30);
+    bool hist_dev = hist && hist_doubles * sizeof(double) <= ((size_t)16 << 30);
     double *dx_hist = nullptr, *dw_hist = nullptr, *dwe_hist = nullptr;
+    if (hist_dev && (b.cap_hist < hist_doubles || !b.d_hist)) {
+        // the staging buffer can be most of the device's memory: if it cannot be had, copy row by row instead of failing
+        if (b.d_hist) hipFree(b.d_hist);
+        b.d_hist = nullptr; b.cap_hist = 0;
+        if (hipMalloc(&b.d_hist, sizeof(double) * hist_doubles) == hipSuccess) b.cap_hist = hist_doubles;
+        else { (void)hipGetLastError(); b.d_hist = nullptr; hist_dev = false; }
+    }
     if (hist_dev) {
-        CHK(ensure(&b.d_hist, &b.cap_hist, hist_doubles));
         double* p = b.d_hist;
         if (x_hist) { dx_hist = p; p += hist_rows * b.nxp; }
         if (w_hist) { dw_hist = p; p += hist_rows; }
@@ -401,6 +407,12 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
         if (x_hist) HIPC(hipMemcpyAsync(x_hist, dx_hist, sizeof(double) * hist_rows * b.nxp, hipMemcpyDeviceToHost, b.stream));
         if (w_hist) HIPC(hipMemcpyAsync(w_hist, dw_hist, sizeof(double) * hist_rows, hipMemcpyDeviceToHost, b.stream));
         if (we_hist) HIPC(hipMemcpyAsync(we_hist, dwe_hist, sizeof(double) * hist_rows, hipMemcpyDeviceToHost, b.stream));
+    }
+    if (hist_dev && b.cap_hist * sizeof(double) > ((size_t)256 << 20)) {
+        // a large history staging buffer is not kept for the lifetime of the handle (other filters / banks need the memory)
+        HIPC(hipStreamSynchronize(b.stream));
+        hipFree(b.d_hist);
+        b.d_hist = nullptr; b.cap_hist = 0;
     }
     if (ll_steps) HIPC(hipMemcpyAsync(ll_steps, b.d_ll_steps, sizeof(double) * T * b.F, hipMemcpyDeviceToHost, b.stream));
     if (xmean) HIPC(hipMemcpyAsync(xmean, b.d_xmean, sizeof(double) * T * b.F * b.nxp, hipMemcpyDeviceToHost, b.stream));

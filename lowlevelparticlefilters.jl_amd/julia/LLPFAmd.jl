@@ -568,7 +568,7 @@ function shared_covariance(pf::GPF)
 end
 
 # ---- AuxiliaryParticleFilter{ParticleFilter} (reference src/PFtypes.jl:38-49) ----------------------------------------
-"GPUAuxiliaryParticleFilter(pf) / GPUAuxiliaryParticleFilter(args...; kwargs...): the same device handle driven through the auxiliary verbs"
+"GPUAuxiliaryParticleFilter(pf) / GPUAuxiliaryParticleFilter(args...; kwargs...): the same device handle driven through the auxiliary verbs\n(over a GPUParticleFilter: src/filtering.jl:195-217; over a GPUAdvancedParticleFilter: :219-234, look-ahead resampling + re-propagation)"
 struct GPUAuxiliaryParticleFilter{T<:GPUParticleFilter} <: AbstractParticleFilter
     pf::T
 end
