@@ -30,6 +30,7 @@ namespace llpf {
 #include "kernels/accum.hpp"
 #include "kernels/step.hpp"
 #include "kernels/rbfull.hpp"
+#include "kernels/rbfull_mfma.hpp"
 #include "kernels/norm.hpp"
 #include "kernels/resample.hpp"
 #include "kernels/residual.hpp"
@@ -67,6 +68,16 @@ static hipError_t launch_rbfull_t(const BankDev& b, int mode, const StepArgs& a,
 // BankDev::pad0 carries the shape of this model: nxl | fn_kind << 8
 static hipError_t launch_rbfull(const BankDev& b, int mode, const StepArgs& a, hipStream_t s) {
     const int nl = b.pad0 & 0xff, fk = (b.pad0 >> 8) & 0xff;
+    // BASELINE config C5's shape, predict! + correct! with a measurement: the matrix-unit form (kernels/rbfull_mfma.hpp), opt-in
+    // with LLPF_RBFULL_MFMA=1 — bit-identical, but measured SLOWER than the register form on the MI355X (150 vs 95 us at N = 2e5:
+    // its LDS hand-over between thread-per-particle and matrix-layout phases leaves 3 waves per CU)
+    const char* mf_env = getenv("LLPF_RBFULL_MFMA");
+    if (mode == MODE_PROP_WEIGHT && a.has_y && b.nx == 4 && nl == 8 && b.ny == 2 && mf_env && atoi(mf_env) != 0) {
+        dim3 g((unsigned)(b.Ns / 64), (unsigned)b.F, 1);
+        if (fk == 1) hipLaunchKernelGGL((k_rbfull_mfma<QuadTank<4, 2>>), g, dim3(64), 0, s, b, b.models, b.scal, a);
+        else hipLaunchKernelGGL((k_rbfull_mfma<LinGauss<4, 2>>), g, dim3(64), 0, s, b, b.models, b.scal, a);
+        return hipGetLastError();
+    }
     if (fk == 1 && b.nx == 4 && nl == 8 && b.ny == 2) return launch_rbfull_t<QuadTank<4, 2>, 4, 8, 2>(b, mode, a, s);
     if (fk == 0 && b.nx == 4 && nl == 8 && b.ny == 2) return launch_rbfull_t<LinGauss<4, 2>, 4, 8, 2>(b, mode, a, s);
     if (fk == 0 && b.nx == 2 && nl == 2 && b.ny == 2) return launch_rbfull_t<LinGauss<2, 2>, 2, 2, 2>(b, mode, a, s);

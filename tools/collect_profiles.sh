@@ -17,6 +17,9 @@ python bench.py --workload quadtank > $OUT/bench_c3_quadtank.json 2>> $OUT/bench
 python tools/bench_bank.py > $OUT/bench_c4_bank_128x1e5_one_gpu.json 2>> $OUT/bench_c2.err
 python tools/bench_bank.py --thr 1.0 > $OUT/bench_c4_bank_128x1e5_thr1.json 2>> $OUT/bench_c2.err
 python bench.py --workload bank --steps 2 > $OUT/bench_c4_bank_workload.json 2>> $OUT/bench_c2.err
+python bench.py --gpus 2 --dist-backend gloo --steps 2 --no-cpu-baseline > $OUT/bench_c4_two_ranks_one_gpu_gloo.json 2>> $OUT/bench_c2.err
+LLPF_PERSIST=1 python bench.py --no-cpu-baseline > $OUT/bench_c2_persistent.json 2>> $OUT/bench_c2.err
+tools/grid_barrier_32 2000 > $OUT/grid_barrier.txt 2>&1
 python bench.py --workload aux > $OUT/bench_aux.json 2>> $OUT/bench_c2.err
 python bench.py --workload rbpf > $OUT/bench_rbpf.json 2>> $OUT/bench_c2.err
 python bench.py --workload rbpf_full > $OUT/bench_c5_rbpf_full.json 2>> $OUT/bench_c2.err
@@ -46,5 +49,6 @@ for w in qt aux rbpf rbpf_full; do python tools/rocprof_summary.py $(find $OUT/k
 python tools/rocprof_pmc_summary.py $OUT/pmc_traffic.txt $(find $OUT/pmc_fetch -name "*.db" | head -1) $(find $OUT/pmc_write -name "*.db" | head -1) $(find $OUT/pmc_sq -name "*.db" | head -1)
 python tools/rocprof_pmc_summary.py $OUT/pmc_traffic_c5.txt $(find $OUT/pmc_fetch_c5 -name "*.db" | head -1) $(find $OUT/pmc_write_c5 -name "*.db" | head -1)
 for w in quadtank bank; do python tools/rocprof_pmc_summary.py $OUT/pmc_traffic_$w.txt $(find $OUT/pmc_FETCH_SIZE_$w -name "*.db" | head -1) $(find $OUT/pmc_WRITE_SIZE_$w -name "*.db" | head -1); rm -rf $OUT/pmc_FETCH_SIZE_$w $OUT/pmc_WRITE_SIZE_$w; done
+python tools/make_pmc_json.py $OUT $OUT/pmc_traffic.json $TAG
 rm -rf $OUT/kt_rbpf_full $OUT/pmc_fetch_c5 $OUT/pmc_write_c5 $OUT/kt $OUT/kt_bank $OUT/kt_qt $OUT/kt_aux $OUT/kt_rbpf $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/*.log
 ls -la $OUT

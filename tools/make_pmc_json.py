@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""profiles/<tag>_pmc_traffic.json from the per-kernel PMC summaries tools/collect_profiles.sh writes (rocprofv3 --pmc FETCH_SIZE /
+WRITE_SIZE in separate passes, tools/rocprof_pmc_summary.py).  The file carries the hash of the engine sources it was measured
+with: bench.py quotes `roofline.traffic` from it only when that hash matches the sources of the build it is running.
+usage: make_pmc_json.py <dir with pmc_traffic*.txt> <out.json> <tag>"""
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import engine_source_hash
+
+d, out, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+
+
+def counters(path, kernel):
+    res = {}
+    if not os.path.exists(path):
+        return res
+    for line in open(path):
+        if kernel in line:
+            m = re.search(r"(FETCH_SIZE|WRITE_SIZE)\s+dispatches=\s*(\d+)\s+avg=\s*([\d.]+)", line)
+            if m:
+                res[m.group(1)] = float(m.group(3))
+    return res
+
+
+def entry(path, kernel, model_bytes, extra=None):
+    c = counters(path, kernel)
+    if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+        return None
+    e = {"fetch_kb": c["FETCH_SIZE"], "write_kb": c["WRITE_SIZE"], "bytes": int(round((2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)),
+         "kernel_model_bytes": model_bytes}
+    if extra:
+        e.update(extra)
+    return e
+
+
+N = 1000000
+j = {"engine_source_hash": engine_source_hash(),
+     "source": "profiles/%s_pmc_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, C2 workload N=1e6, T=200)" % tag,
+     "correction": "FETCH_SIZE x 2 (MI355X_MICROARCH.md #HBM: gfx950 reports half the bytes of wide coalesced reads); WRITE_SIZE as reported; KB = 1024 B",
+     "n_particles": N, "nx": 2, "resample_threshold": 1.0}
+e = entry(os.path.join(d, "pmc_traffic.txt"), "k_resprop<llpf::LinGauss<2, 1>", 60 * N, {"algorithmic_bytes": 72 * N})
+if e:
+    j["k_resprop"] = e
+e = entry(os.path.join(d, "pmc_traffic_c5.txt"), "k_rbfull", 780 * 200000)
+if e:
+    j["c5"] = {"source": "profiles/%s_pmc_traffic_c5.txt (same recipe, workload rbpf_full N=2e5, T=200)" % tag, "k_rbfull": e, "n_particles": 200000}
+e = entry(os.path.join(d, "pmc_traffic_quadtank.txt"), "k_step<llpf::QuadTank", 84 * N)
+if e:
+    j["c3"] = {"source": "profiles/%s_pmc_traffic_quadtank.txt (same recipe, workload quadtank N=1e6, T=100)" % tag, "k_step": e, "n_particles": N}
+e1 = entry(os.path.join(d, "pmc_traffic_bank.txt"), "k_resprop<llpf::LinGauss<2, 1>", 52 * 12800000)
+e2 = entry(os.path.join(d, "pmc_traffic_bank.txt"), "k_norm", 16 * 12800000)
+if e1 and e2:
+    j["c4"] = {"source": "profiles/%s_pmc_traffic_bank.txt (same recipe, workload bank 128 x 1e5, T=100)" % tag, "k_resprop": e1, "k_norm": e2,
+               "filters": 128, "n_particles": 100000}
+json.dump(j, open(out, "w"), indent=1)
+print(json.dumps({k: (v if not isinstance(v, dict) else "...") for k, v in j.items()}))
