@@ -56,14 +56,16 @@ struct ThrStrat { // stratified: u_i = (i0 + rand()) / M * bins[N]  (resample.jl
 //              XCDs' L2s INSIDE one launch — what the persistent multi-step kernel (kernels/persist.hpp) needs for every
 //              datum one block writes and another block reads after the grid barrier.  (tools/grid_barrier.hip: no stale
 //              reads, 5 TB/s; __threadfence() instead costs ~30 us per step: a full L2 write-back per block.)
-template <bool COH>
+template <int COH>
 struct Mem {
     template <class T> static DEV T ld(const T* p) {
-        if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if constexpr (COH != 0) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else return *p;
     }
     template <class T> static DEV void st(T* p, T v) {
-        if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if constexpr (COH == 1) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else if constexpr (COH == 2) __builtin_nontemporal_store(v, p);
+        else if constexpr (COH == 3) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         else *p = v;
     }
     template <class T> static DEV T ld_off(const T* base, uint32_t byte_off) {
@@ -413,7 +415,7 @@ __global__ __launch_bounds__(BLOCK) void k_resample(BankDev b, ResArgs a) {
     if (a.only_bins) return;
     int32_t* ao = a.anc_out + (size_t)f * b.Ns;
     for (int32_t o = c_start + threadIdx.x; o < c_end; o += BLOCK)
-        ao[o] = (int32_t)((int64_t)tile * TILE + res_owner(sh.cl, o));
+        wt_store(ao + o, (int32_t)((int64_t)tile * TILE + res_owner(sh.cl, o)));
     // outputs whose threshold is >= bins[N] are never written by the reference (j keeps its previous
     // value); the previous value is only materialised here if it was the identity 1:N
     if (tile == b.P2 - 1 && SRC == SRC_FILTER && b.scal[f].anc_ident_s[b.anc_slot]) {

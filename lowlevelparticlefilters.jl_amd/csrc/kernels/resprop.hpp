@@ -29,6 +29,9 @@ struct NoModel {
     DEV void measurement(const double*, double*) const {}
 };
 
+// stores of the output loop are write-through (wt_store in reduce.hpp says why)
+#define LLPF_STCOH ((LLPF_WT && !Model::RB) ? 1 : COH)
+#define LLPF_STCOH0 ((LLPF_WT && !Model::RB) ? 1 : 0)
 template <class Model, int NX, int NY, bool WEIGHT, bool COH = false>
 struct PropCtx {
     const BankDev& b;
@@ -59,10 +62,10 @@ struct PropCtx {
                 if (st.has_y) wr = wr + model.rb_weight(xs, y, st.rb_corr + blockIdx.y, o == 0);
                 if (o >= (uint32_t)b.N) wr = -LLPF_INF;
                 bad = bad || (wr != wr);
-                Mem<COH>::st_off(w, oo, wr);
+                Mem<LLPF_STCOH>::st_off(w, oo, wr);
             }
 #pragma unroll
-            for (int d = 0; d < NX; ++d) Mem<COH>::st_off(xn + (size_t)d * Ns, oo, xs[d]);
+            for (int d = 0; d < NX; ++d) Mem<LLPF_STCOH>::st_off(xn + (size_t)d * Ns, oo, xs[d]);
             return wr;
         }
 #ifdef LLPF_DEVTOOLS   /* ablation switches for performance experiments (results invalid); not in production builds */
@@ -78,7 +81,7 @@ struct PropCtx {
 #pragma unroll
         for (int d = 0; d < NX; ++d) {
             xs[d] = fx[d] + nz[d];
-            Mem<COH>::st_off(xn + (size_t)d * Ns, oo, xs[d]);
+            Mem<LLPF_STCOH>::st_off(xn + (size_t)d * Ns, oo, xs[d]);
         }
         double wv = wprev;
         if (WEIGHT) {
@@ -95,7 +98,7 @@ struct PropCtx {
             }
             if (o >= (uint32_t)b.N) wv = -LLPF_INF;
             bad = bad || (wv != wv);
-            Mem<COH>::st_off(w, oo, wv);
+            Mem<LLPF_STCOH>::st_off(w, oo, wv);
         }
         return wv;
     }
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(BLOCK) void k_resprop(BankDev b, const ModelD* __re
             if (o < ucend) src = tile0 + (uint32_t)res_owner(sh.cl, (int32_t)o);
 #endif
             else src = anc_ident_prev ? o : (uint32_t)ld_off(anc, o << 2);
-            st_off(anc, o << 2, (int32_t)src);
+            Mem<LLPF_STCOH0>::st_off(anc, o << 2, (int32_t)src);
             if (AUX) wprev = ld_off(lamp, o << 3) - lN;               // s.w[i] = lambda[i] - log N (unresampled index, filtering.jl:209-213)
         } else if (AUX) {
             wprev = ld_off(lamp, o << 3) - lN;
@@ -247,7 +250,7 @@ __global__ __launch_bounds__(BLOCK) void k_resprop(BankDev b, const ModelD* __re
         if (WEIGHT && ACC) {
             double e;
             const uint64_t q = wacc.add(wv, pc.off, st.K, st.need_e2 != 0, &e);
-            st_off(pc.qnext, o << 3, q);
+            Mem<LLPF_STCOH0>::st_off(pc.qnext, o << 3, q);
             ts.add(o, q, sh_tq, tq_next, tbase);
             if (st.want_xmean) {
 #pragma unroll

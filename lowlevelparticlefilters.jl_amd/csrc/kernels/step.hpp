@@ -24,7 +24,7 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
     double* __restrict__ xn = b.xnext + (size_t)f * NX * Ns;
     double* w = b.w + (size_t)f * Ns;
     const int32_t* __restrict__ anc = b.anc + (size_t)f * Ns;
-
+    constexpr bool WT = (MODE != MODE_AUX) && !Model::RB;     // write-through stores where they measured faster (wt_store, reduce.hpp)
 
     Model model;
     model.prepare(md, a.u + (size_t)f * a.u_stride, a.t_prop);
@@ -97,8 +97,8 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
             if (!(Model::RB && MODE == MODE_PROP_WEIGHT && a.has_y)) {
 #pragma unroll
                 for (int d = 0; d < NX; ++d) {
-                    if constexpr (PPT == 2) { double2 v; v.x = xs[0][d]; v.y = xs[1][d]; *reinterpret_cast<double2*>(xn + (size_t)d * Ns + i0) = v; }
-                    else *(xn + (size_t)d * Ns + i0) = xs[0][d];
+                    if constexpr (PPT == 2) { double2 v; v.x = xs[0][d]; v.y = xs[1][d]; wt_store<WT>(reinterpret_cast<double2*>(xn + (size_t)d * Ns + i0), v); }
+                    else wt_store<WT>(xn + (size_t)d * Ns + i0, xs[0][d]);
                 }
             }
         } else {
@@ -155,15 +155,15 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
                 bad = bad || (wv != wv);
                 bmax = llpf_fmax(bmax, wv);
             }
-            if constexpr (PPT == 2) { double2 wo; wo.x = wn[0]; wo.y = wn[1]; *reinterpret_cast<double2*>(w + i0) = wo; }
-            else w[i0] = wn[0];
+            if constexpr (PPT == 2) { double2 wo; wo.x = wn[0]; wo.y = wn[1]; wt_store<WT>(reinterpret_cast<double2*>(w + i0), wo); }
+            else wt_store<WT>(w + i0, wn[0]);
             if constexpr (Model::RB) {             // correct! has updated xl (Kalman measurement update)
                 if (a.has_y) {
                     double* xdst = (MODE == MODE_WEIGHT) ? const_cast<double*>(xc) : xn;
 #pragma unroll
                     for (int d = 0; d < NX; ++d) {
-                        if constexpr (PPT == 2) { double2 v; v.x = xs[0][d]; v.y = xs[1][d]; *reinterpret_cast<double2*>(xdst + (size_t)d * Ns + i0) = v; }
-                        else *(xdst + (size_t)d * Ns + i0) = xs[0][d];
+                        if constexpr (PPT == 2) { double2 v; v.x = xs[0][d]; v.y = xs[1][d]; wt_store<WT>(reinterpret_cast<double2*>(xdst + (size_t)d * Ns + i0), v); }
+                        else wt_store<WT>(xdst + (size_t)d * Ns + i0, xs[0][d]);
                     }
                 }
             }
@@ -176,8 +176,8 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
                 double ev[PPT];
 #pragma unroll
                 for (int p = 0; p < PPT; ++p) { qv[p] = wacc.add(wn[p], off, a.K, a.need_e2 != 0, &ev[p]); qsum += qv[p]; }
-                if constexpr (PPT == 2) { ulonglong2 q2; q2.x = qv[0]; q2.y = qv[1]; *reinterpret_cast<ulonglong2*>(b.quanta_next + (size_t)f * Ns + i0) = q2; }
-                else b.quanta_next[(size_t)f * Ns + i0] = qv[0];
+                if constexpr (PPT == 2) { ulonglong2 q2; q2.x = qv[0]; q2.y = qv[1]; wt_store<WT>(reinterpret_cast<ulonglong2*>(b.quanta_next + (size_t)f * Ns + i0), q2); }
+                else wt_store<WT>(b.quanta_next + (size_t)f * Ns + i0, qv[0]);
                 if (a.want_xmean) {
 #pragma unroll
                     for (int d = 0; d < NX; ++d) {
