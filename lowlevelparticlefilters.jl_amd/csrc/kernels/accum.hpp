@@ -71,7 +71,7 @@ struct WeightAcc {
     DEV void flush(uint64_t* acc, int slot, bool need_e2, uint64_t (*sm)[5]) {
         llpf_u128 s = wave_sum_u128(S), e2 = {0, 0};
         if (need_e2) e2 = wave_sum_u128(E2);
-        const uint64_t bd = wave_sum_u64(bad);
+        const uint64_t bd = (uint64_t)__builtin_popcountll(__ballot(bad != 0));     // only its being non-zero is ever used
         const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
         __syncthreads();
         if (lane == 0) { sm[wv][0] = s.lo; sm[wv][1] = s.hi; sm[wv][2] = e2.lo; sm[wv][3] = e2.hi; sm[wv][4] = bd; }

@@ -50,15 +50,24 @@ DEV uint64_t readlane_u64(uint64_t v, int lane) {
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane);
     return ((uint64_t)hi << 32) | lo;
 }
-// inclusive prefix sum over the wave
+// inclusive prefix sum over the wave.  The add itself carries the DPP modifier (v_add_co_u32_dpp / v_addc_co_u32_dpp: two
+// instructions per step for 64 bits, four for 128); written through update_dpp the compiler emits a v_mov_b32_dpp per half
+// and then the add (four per step), and a 128-bit sum had to go limb-wise through three 64-bit scans.
+// Hazards inside the block are ours to keep: a VALU write of a VGPR needs 2 wait states before a DPP read of it (s_nop 0 +
+// the other half's instruction), and the block starts with s_nop 4 (a VALU write of EXEC needs 5 before DPP).
+#define LLPF_DPP_SHR(n) "row_shr:" #n " row_mask:0xf bank_mask:0xf bound_ctrl:0"
+#define LLPF_DPP_B15 "row_bcast:15 row_mask:0xa bank_mask:0xf"
+#define LLPF_DPP_B31 "row_bcast:31 row_mask:0xc bank_mask:0xf"
+#define LLPF_ADD64_DPP(C) "v_add_co_u32_dpp %0, vcc, %0, %0 " C "\n\tv_addc_co_u32_dpp %1, vcc, %1, %1, vcc " C "\n\ts_nop 0\n\t"
+#define LLPF_ADD128_DPP(C) "v_add_co_u32_dpp %0, vcc, %0, %0 " C "\n\tv_addc_co_u32_dpp %1, vcc, %1, %1, vcc " C "\n\t" \
+                           "v_addc_co_u32_dpp %2, vcc, %2, %2, vcc " C "\n\tv_addc_co_u32_dpp %3, vcc, %3, %3, vcc " C "\n\t"
 DEV uint64_t wave_scan_u64(uint64_t x) {
-    x += dpp_u64<DPP_ROW_SHR(1), 0xF, true>(0, x);
-    x += dpp_u64<DPP_ROW_SHR(2), 0xF, true>(0, x);
-    x += dpp_u64<DPP_ROW_SHR(4), 0xF, true>(0, x);
-    x += dpp_u64<DPP_ROW_SHR(8), 0xF, true>(0, x);
-    x += dpp_u64<DPP_ROW_BCAST15, 0xA, false>(0, x);
-    x += dpp_u64<DPP_ROW_BCAST31, 0xC, false>(0, x);
-    return x;
+    uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    asm("s_nop 4\n\t"
+        LLPF_ADD64_DPP(LLPF_DPP_SHR(1)) LLPF_ADD64_DPP(LLPF_DPP_SHR(2)) LLPF_ADD64_DPP(LLPF_DPP_SHR(4)) LLPF_ADD64_DPP(LLPF_DPP_SHR(8))
+        LLPF_ADD64_DPP(LLPF_DPP_B15) LLPF_ADD64_DPP(LLPF_DPP_B31)
+        : "+v"(lo), "+v"(hi) : : "vcc");
+    return ((uint64_t)hi << 32) | lo;
 }
 DEV uint32_t wave_scan_max_u32(uint32_t x) {
 #define LLPF_MAXSTEP(CTRL, RM, BC) { const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, RM, 0xF, BC); x = t > x ? t : x; }
@@ -70,16 +79,15 @@ DEV uint32_t wave_scan_max_u32(uint32_t x) {
 // total over the wave, returned uniformly to every lane
 DEV uint64_t wave_sum_u64(uint64_t v) { return readlane_u64(wave_scan_u64(v), 63); }
 DEV llpf_u128 wave_sum_u128(llpf_u128 v) {
-    // sum the three 43-bit limbs separately (no carries between lanes), recombine: exact
-    const uint64_t M43 = ((uint64_t)1 << 43) - 1;
-    const uint64_t l0 = wave_sum_u64(v.lo & M43);
-    const uint64_t l1 = wave_sum_u64(((v.lo >> 43) | (v.hi << 21)) & M43);
-    const uint64_t l2 = wave_sum_u64(v.hi >> 22);
-    llpf_u128 r = {l0, 0}, t;
-    t.lo = l1 << 43; t.hi = l1 >> 21;
-    r = llpf_u128_add(r, t);
-    t.lo = 0; t.hi = l2 << 22;
-    return llpf_u128_add(r, t);
+    uint32_t w0 = (uint32_t)v.lo, w1 = (uint32_t)(v.lo >> 32), w2 = (uint32_t)v.hi, w3 = (uint32_t)(v.hi >> 32);
+    asm("s_nop 4\n\t"
+        LLPF_ADD128_DPP(LLPF_DPP_SHR(1)) LLPF_ADD128_DPP(LLPF_DPP_SHR(2)) LLPF_ADD128_DPP(LLPF_DPP_SHR(4)) LLPF_ADD128_DPP(LLPF_DPP_SHR(8))
+        LLPF_ADD128_DPP(LLPF_DPP_B15) LLPF_ADD128_DPP(LLPF_DPP_B31)
+        : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3) : : "vcc");
+    llpf_u128 r;
+    r.lo = readlane_u64(((uint64_t)w1 << 32) | w0, 63);
+    r.hi = readlane_u64(((uint64_t)w3 << 32) | w2, 63);
+    return r;
 }
 DEV double wave_max(double v) {
     // running maximum with the same DPP sequence; out-of-row / masked lanes read the lane's own value

@@ -32,6 +32,17 @@
 LLPF_HD uint64_t llpf_d2u(double x) { uint64_t u; __builtin_memcpy(&u, &x, 8); return u; }
 LLPF_HD double   llpf_u2d(uint64_t u) { double x; __builtin_memcpy(&x, &u, 8); return x; }
 LLPF_HD double   llpf_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+/* one Horner step q*r + c with a constant c.  Same fused operation as llpf_fma; on the device it is pinned to the
+ * three-address v_fma_f64 (the compiler otherwise copies the constant into the destination for a two-address v_fmac) */
+LLPF_HD double   llpf_horner(double q, double r, double c) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(LLPF_NO_ASM_HORNER)
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(q), "v"(r), "v"(c));
+    return d;
+#else
+    return __builtin_fma(q, r, c);
+#endif
+}
 LLPF_HD double   llpf_sqrt(double a) { return __builtin_sqrt(a); }
 /* sqrt(a) for a NORMAL, finite, strictly positive a that is neither tiny nor huge (2^-700 < a < 2^700): the
  * correctly-rounded result, i.e. the same bits as llpf_sqrt.  On the device the compiler's IEEE expansion of sqrt
@@ -73,17 +84,17 @@ LLPF_HD double llpf_exp_core(double xc) {      /* xc in [-746, 709.78] or NaN */
     r = llpf_fma(-kf, LN2_LO, r);
     /* q(r) = 1/2! + r/3! + ... + r^11/13! */
     double q = 1.6059043836821613e-10;              /* 1/13! */
-    q = llpf_fma(q, r, 2.08767569878681e-09);       /* 1/12! */
-    q = llpf_fma(q, r, 2.505210838544172e-08);      /* 1/11! */
-    q = llpf_fma(q, r, 2.755731922398589e-07);      /* 1/10! */
-    q = llpf_fma(q, r, 2.7557319223985893e-06);     /* 1/9!  */
-    q = llpf_fma(q, r, 2.48015873015873e-05);       /* 1/8!  */
-    q = llpf_fma(q, r, 1.984126984126984e-04);      /* 1/7!  */
-    q = llpf_fma(q, r, 1.388888888888889e-03);      /* 1/6!  */
-    q = llpf_fma(q, r, 8.333333333333333e-03);      /* 1/5!  */
-    q = llpf_fma(q, r, 4.1666666666666664e-02);     /* 1/4!  */
-    q = llpf_fma(q, r, 1.6666666666666666e-01);     /* 1/3!  */
-    q = llpf_fma(q, r, 0.5);                        /* 1/2!  */
+    q = llpf_horner(q, r, 2.08767569878681e-09);       /* 1/12! */
+    q = llpf_horner(q, r, 2.505210838544172e-08);      /* 1/11! */
+    q = llpf_horner(q, r, 2.755731922398589e-07);      /* 1/10! */
+    q = llpf_horner(q, r, 2.7557319223985893e-06);     /* 1/9!  */
+    q = llpf_horner(q, r, 2.48015873015873e-05);       /* 1/8!  */
+    q = llpf_horner(q, r, 1.984126984126984e-04);      /* 1/7!  */
+    q = llpf_horner(q, r, 1.388888888888889e-03);      /* 1/6!  */
+    q = llpf_horner(q, r, 8.333333333333333e-03);      /* 1/5!  */
+    q = llpf_horner(q, r, 4.1666666666666664e-02);     /* 1/4!  */
+    q = llpf_horner(q, r, 1.6666666666666666e-01);     /* 1/3!  */
+    q = llpf_horner(q, r, 0.5);                        /* 1/2!  */
     double p = llpf_fma(r * r, q, r);               /* r + r^2 q(r) */
     double y = 1.0 + p;
     /* kf is an integer in [-1077, 1024] (or NaN, in which case y is NaN and the scale factors are irrelevant
