@@ -47,6 +47,8 @@ struct PropCtx {
     int ablate;
     double off;            // bound of the new weights (offset of their exp-sums)
     uint64_t* qnext;       // quanta of the new weights
+    const double* rng_lg = nullptr;   // the block's copy of the generator's tables in LDS , or nullptr: the
+    const double* rng_sc = nullptr;   //   tables in constant memory (a global load through the GOT per lookup)
     // propagate output o from source src with previous log-weight wprev; returns the new log-weight
     // Addresses are a uniform plane base (SGPRs) + a 32-bit byte offset (one VGPR): Ns * 8 < 2^32 is checked at create.
     DEV double one(uint32_t src, uint32_t o, double wprev, bool& bad, double* xs) const {
@@ -71,11 +73,12 @@ struct PropCtx {
 #ifdef LLPF_DEVTOOLS   /* ablation switches for performance experiments (results invalid); not in production builds */
         if (!(ablate & 4)) model.dynamics(xp, fx);
         else { for (int d = 0; d < NX; ++d) fx[d] = xp[d]; }
-        if (!(ablate & 1)) llpf_normals(o, pstep, LLPF_STREAM_DYNAMICS, k0, k1, NX, xi);
+        if (!(ablate & 1)) { if (rng_lg) llpf_normals_tab(o, pstep, LLPF_STREAM_DYNAMICS, k0, k1, NX, xi, rng_lg, rng_sc); else llpf_normals(o, pstep, LLPF_STREAM_DYNAMICS, k0, k1, NX, xi); }
         else { for (int d = 0; d < NX; ++d) xi[d] = 0.25 * (double)(o & 7); }
 #else
         model.dynamics(xp, fx);
-        llpf_normals(o, pstep, LLPF_STREAM_DYNAMICS, k0, k1, NX, xi);
+        if (rng_lg) llpf_normals_tab(o, pstep, LLPF_STREAM_DYNAMICS, k0, k1, NX, xi, rng_lg, rng_sc);
+        else llpf_normals(o, pstep, LLPF_STREAM_DYNAMICS, k0, k1, NX, xi);
 #endif
         gauss_sample<NX>(md->df, xi, nz);
 #pragma unroll
@@ -132,12 +135,15 @@ static_assert(TILE == 1024, "TileSum assumes 1024-particle tiles");
 
 // ONE: the filter is a single tile (launched only when P2 == 1): a failed bound test is redone inside this kernel
 template <class Model, int NX, int NY, bool WEIGHT, bool ACC, bool AUX = false, bool ONE = false>
-__global__ __launch_bounds__(BLOCK) void k_resprop(BankDev b, const ModelD* __restrict__ models, ResArgs a, StepArgs st) {
+// amdgpu_waves_per_eu(4): the ~3.8 blocks per CU of a 10^6-particle filter must be resident together (<= 128 VGPRs); the
+// larger state dimensions and the Rao-Blackwellized propagate would spill under that cap and keep the compiler's choice
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!Model::RB && NX <= 2 && NY <= 2 && !ONE) ? 4 : 1))) void k_resprop(BankDev b, const ModelD* __restrict__ models, ResArgs a, StepArgs st) {
     __shared__ ResShared sh;
     __shared__ double sm_max[BLOCK / 64];
     __shared__ uint64_t sm_acc[BLOCK / 64][5];
     __shared__ uint64_t sh_tq[8];
     __shared__ double sm_x[BLOCK / 64][MAXD];
+    __shared__ __attribute__((aligned(16))) double sh_rng_lg[2 * LLPF_RNG_LG_ENTRIES], sh_rng_sc[2 * LLPF_RNG_SC_ENTRIES];
     // Wave priority by phase: the head / counts / tail phases are short and latency-bound (loads, LDS, barriers, atomics), the
     // output loop is long and issue-bound.  The waves of a CU's four blocks are otherwise served oldest first, so the
     // youngest block's head is starved by the older blocks' loops and the SIMD ends the launch with that block's loop alone
@@ -157,6 +163,13 @@ __global__ __launch_bounds__(BLOCK) void k_resprop(BankDev b, const ModelD* __re
 #pragma unroll
     for (int k = 0; k < NORM_IPT / 2; ++k) qv[k] = *reinterpret_cast<const ulonglong2*>(qsrc + ib + 2 * k);
     const int anc_ident_prev = sc->anc_ident_s[b.anc_slot];   // this launch writes the other entry
+    // the generator's tables -> LDS (two of them per lookup as one 16-byte LDS read instead of two global loads)
+    double rt0 = 0.0, rt1 = 0.0;
+    if (!Model::RB) {
+        const int t = (int)threadIdx.x;
+        if (t < LLPF_RNG_SC_ENTRIES) { rt0 = LLPF_SIN64[t]; rt1 = LLPF_COS64[t]; }
+        else if (t < LLPF_RNG_SC_ENTRIES + LLPF_RNG_LG_ENTRIES) { rt0 = LLPF_LOG_INVC[t - LLPF_RNG_SC_ENTRIES]; rt1 = LLPF_LOG_LNC[t - LLPF_RNG_SC_ENTRIES]; }
+    }
 #define LLPF_STAMP(i) if (a.dbg && threadIdx.x == 0 && f == 0) a.dbg[(size_t)tile * 8 + (i)] = wall_clock64()
     LLPF_STAMP(0);
     Model model;
@@ -169,12 +182,18 @@ __global__ __launch_bounds__(BLOCK) void k_resprop(BankDev b, const ModelD* __re
         const double* yf = st.y + (size_t)f * st.y_stride;
 #pragma unroll
         for (int k = 0; k < NY; ++k) y[k] = (WEIGHT && st.has_y) ? yf[k] : 0.0;
+        if (!Model::RB) {      // before the head's barrier
+            const int t = (int)threadIdx.x;
+            if (t < LLPF_RNG_SC_ENTRIES) { sh_rng_sc[2 * t] = rt0; sh_rng_sc[2 * t + 1] = rt1; }
+            else if (t < LLPF_RNG_SC_ENTRIES + LLPF_RNG_LG_ENTRIES) { sh_rng_lg[2 * (t - LLPF_RNG_SC_ENTRIES)] = rt0; sh_rng_lg[2 * (t - LLPF_RNG_SC_ENTRIES) + 1] = rt1; }
+        }
     };
     const ResHead h = res_head<SRC_FILTER, false>(b, a, f, tile, sh, true, stop_flag, fb_flag, nullptr, prepare);
     if (h.status) return;
     LLPF_STAMP(1);
     PropCtx<Model, NX, NY, WEIGHT> pc{b, model, md, st, y, b.xcur + (size_t)f * NX * Ns, b.xnext + (size_t)f * NX * Ns,
-                                      b.w + (size_t)f * Ns, key0, key1, sb + st.step, a.ablate, 0.0, b.quanta_next + (size_t)f * Ns};
+                                      b.w + (size_t)f * Ns, key0, key1, sb + st.step, a.ablate, 0.0, b.quanta_next + (size_t)f * Ns,
+                                      Model::RB ? nullptr : sh_rng_lg, Model::RB ? nullptr : sh_rng_sc};
     int32_t* anc = b.anc + (size_t)f * Ns;
     double bmax = -LLPF_INF;
     bool bad = false;

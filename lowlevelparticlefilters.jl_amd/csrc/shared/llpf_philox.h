@@ -73,6 +73,35 @@ LLPF_HD void llpf_normal_pair(uint32_t idx, uint32_t step, uint32_t sub, uint32_
     *z1 = rad * sn;
 }
 
+/* the same with the four tables read from a caller's copy (lg[2 i] = 1/c_i, lg[2 i + 1] = ln c_i; sc[2 j] = sin, sc[2 j + 1] = cos):
+ * identical values, so identical results */
+LLPF_HD void llpf_normal_pair_tab(uint32_t idx, uint32_t step, uint32_t sub, uint32_t stream, uint32_t k0, uint32_t k1,
+                                  const double* lg, const double* sc, double* z0, double* z1) {
+    llpf_philox4 r = llpf_philox4x32_10(idx, step, sub, stream, k0, k1);
+    double u1 = llpf_u01_open(r.v[0], r.v[1]);
+    double u2 = llpf_u01_half(r.v[2], r.v[3]);
+    double m, dk, f;
+    const int i = llpf_log_unit_split(u1, &m, &dk);
+    const int j = llpf_sincos2pi_split(u2, &f);
+    double rad = llpf_sqrt(-2.0 * llpf_log_unit_eval(m, dk, lg[2 * i], lg[2 * i + 1]));
+    double sn, cs;
+    llpf_sincos2pi_eval(f, sc[2 * j], sc[2 * j + 1], &sn, &cs);
+    *z0 = rad * cs;
+    *z1 = rad * sn;
+}
+LLPF_HD void llpf_normals_tab(uint32_t idx, uint32_t step, uint32_t stream, uint32_t k0, uint32_t k1,
+                              int nd, double* xi, const double* lg, const double* sc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int b = 0; 2 * b < nd; ++b) {
+        double z0, z1;
+        llpf_normal_pair_tab(idx, step, (uint32_t)b, stream, k0, k1, lg, sc, &z0, &z1);
+        xi[2 * b] = z0;
+        if (2 * b + 1 < nd) xi[2 * b + 1] = z1;
+    }
+}
+
 /* nd standard normals for particle idx at a step: dims (2b, 2b+1) come from sub-block b */
 LLPF_HD void llpf_normals(uint32_t idx, uint32_t step, uint32_t stream, uint32_t k0, uint32_t k1,
                           int nd, double* xi) {
