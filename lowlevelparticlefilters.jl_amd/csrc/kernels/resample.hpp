@@ -85,7 +85,7 @@ struct StepCarry {
 };
 
 // ---- shared machinery of the resample kernels -----------------------------------------------------------------
-struct ResShared {                 // LDS scratch
+struct __attribute__((aligned(16))) ResShared {   // LDS scratch
     uint64_t red[BLOCK / 64][4];
     uint64_t accw[8];
     double dval[4];
@@ -390,6 +390,44 @@ DEV int res_owner(const uint32_t* cl, int32_t o) {
     return (int)(p4 >> 2);
 }
 static_assert(TILE == 1024, "res_owner assumes 2^10 sources per tile");
+
+// The same map as a table: own[o - c_start] = 1 + (tile-local index of the source that produces output o) for the first
+// OWN_CAP outputs of the tile (a tile produces ~TILE outputs; later ones, of tiles that hold very heavy particles, go through
+// res_owner).  Each source with a non-empty range writes its index at the range's first slot, an inclusive max-scan fills
+// the rest (indices grow with the slot).  ~55 instructions per thread and three barriers instead of a ten-probe descent
+// (~45 instructions, ten dependent LDS round trips) per OUTPUT.  own[] must be zero on entry; sh.cl complete (res_counts).
+constexpr int OWN_CAP = 2 * TILE;
+DEV void res_owner_table(const ResShared& shc, ResShared& sh, uint32_t* own, int32_t c_start) {
+    const int t = (int)threadIdx.x, lane = t & 63, wvid = t >> 6;
+    static_assert(NORM_IPT == 4 && OWN_CAP == 8 * BLOCK, "one 16-byte read of cl and two of own per thread");
+    const uint4 c4 = *reinterpret_cast<const uint4*>(shc.cl + 4 * t);
+    uint32_t prev = t ? shc.cl[4 * t - 1] : (uint32_t)c_start;
+    const uint32_t cur[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t idx = prev - (uint32_t)c_start;
+        if (cur[k] > prev && idx < (uint32_t)OWN_CAP) own[idx] = (uint32_t)(4 * t + k + 1);
+        prev = cur[k];
+    }
+    __syncthreads();
+    uint4* own4 = reinterpret_cast<uint4*>(own);
+    uint4 a = own4[2 * t], b = own4[2 * t + 1];
+    a.y = a.y > a.x ? a.y : a.x; a.z = a.z > a.y ? a.z : a.y; a.w = a.w > a.z ? a.w : a.z;
+    b.x = b.x > a.w ? b.x : a.w; b.y = b.y > b.x ? b.y : b.x; b.z = b.z > b.y ? b.z : b.y; b.w = b.w > b.z ? b.w : b.z;
+    const uint32_t incl = wave_scan_max_u32(b.w);
+    uint32_t base = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x138 /* wave_shr:1 */, 0xF, 0xF, true);
+    if (lane == 63) sh.red[wvid][3] = incl;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < BLOCK / 64 - 1; ++k) {
+        const uint32_t c = (uint32_t)sh.red[k][3];
+        if (k < wvid) base = c > base ? c : base;
+    }
+    a.x = a.x > base ? a.x : base; a.y = a.y > base ? a.y : base; a.z = a.z > base ? a.z : base; a.w = a.w > base ? a.w : base;
+    b.x = b.x > base ? b.x : base; b.y = b.y > base ? b.y : base; b.z = b.z > base ? b.z : base; b.w = b.w > base ? b.w : base;
+    own4[2 * t] = a; own4[2 * t + 1] = b;
+    __syncthreads();
+}
 
 template <int STRATEGY, int SRC>
 __global__ __launch_bounds__(BLOCK) void k_resample(BankDev b, ResArgs a) {

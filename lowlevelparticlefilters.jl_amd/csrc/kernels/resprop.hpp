@@ -32,7 +32,7 @@ struct NoModel {
 // stores of the output loop are write-through (wt_store in reduce.hpp says why)
 #define LLPF_STCOH ((LLPF_WT && !Model::RB) ? 1 : COH)
 #define LLPF_STCOH0 ((LLPF_WT && !Model::RB) ? 1 : 0)
-template <class Model, int NX, int NY, bool WEIGHT, bool COH = false>
+template <class Model, int NX, int NY, bool WEIGHT, bool COH = false, bool LTAB = false>
 struct PropCtx {
     const BankDev& b;
     const Model& model;
@@ -73,11 +73,11 @@ struct PropCtx {
 #ifdef LLPF_DEVTOOLS   /* ablation switches for performance experiments (results invalid); not in production builds */
         if (!(ablate & 4)) model.dynamics(xp, fx);
         else { for (int d = 0; d < NX; ++d) fx[d] = xp[d]; }
-        if (!(ablate & 1)) { if (rng_lg) llpf_normals_tab(o, pstep, LLPF_STREAM_DYNAMICS, k0, k1, NX, xi, rng_lg, rng_sc); else llpf_normals(o, pstep, LLPF_STREAM_DYNAMICS, k0, k1, NX, xi); }
+        if (!(ablate & 1)) { if constexpr (LTAB) llpf_normals_tab(o, pstep, LLPF_STREAM_DYNAMICS, k0, k1, NX, xi, rng_lg, rng_sc); else llpf_normals(o, pstep, LLPF_STREAM_DYNAMICS, k0, k1, NX, xi); }
         else { for (int d = 0; d < NX; ++d) xi[d] = 0.25 * (double)(o & 7); }
 #else
         model.dynamics(xp, fx);
-        if (rng_lg) llpf_normals_tab(o, pstep, LLPF_STREAM_DYNAMICS, k0, k1, NX, xi, rng_lg, rng_sc);
+        if constexpr (LTAB) llpf_normals_tab(o, pstep, LLPF_STREAM_DYNAMICS, k0, k1, NX, xi, rng_lg, rng_sc);
         else llpf_normals(o, pstep, LLPF_STREAM_DYNAMICS, k0, k1, NX, xi);
 #endif
         gauss_sample<NX>(md->df, xi, nz);
@@ -143,6 +143,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!Model::
     __shared__ uint64_t sm_acc[BLOCK / 64][5];
     __shared__ uint64_t sh_tq[8];
     __shared__ double sm_x[BLOCK / 64][MAXD];
+    constexpr bool OWN_TABLE = !Model::RB;      // the Rao-Blackwellized propagate has no registers to spare for it (occupancy 3 -> 2)
+    __shared__ __attribute__((aligned(16))) uint32_t sh_own[OWN_TABLE ? OWN_CAP : 4];
     __shared__ __attribute__((aligned(16))) double sh_rng_lg[2 * LLPF_RNG_LG_ENTRIES], sh_rng_sc[2 * LLPF_RNG_SC_ENTRIES];
     // Wave priority by phase: the head / counts / tail phases are short and latency-bound (loads, LDS, barriers, atomics), the
     // output loop is long and issue-bound.  The waves of a CU's four blocks are otherwise served oldest first, so the
@@ -163,6 +165,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!Model::
 #pragma unroll
     for (int k = 0; k < NORM_IPT / 2; ++k) qv[k] = *reinterpret_cast<const ulonglong2*>(qsrc + ib + 2 * k);
     const int anc_ident_prev = sc->anc_ident_s[b.anc_slot];   // this launch writes the other entry
+    if (OWN_TABLE) {   // owner table of the output loop: cleared here, filled after the counts (res_owner_table)
+        const uint4 z = {0u, 0u, 0u, 0u};
+        reinterpret_cast<uint4*>(sh_own)[2 * threadIdx.x] = z;
+        reinterpret_cast<uint4*>(sh_own)[2 * threadIdx.x + 1] = z;
+    }
     // the generator's tables -> LDS (two of them per lookup as one 16-byte LDS read instead of two global loads)
     double rt0 = 0.0, rt1 = 0.0;
     if (!Model::RB) {
@@ -191,7 +198,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!Model::
     const ResHead h = res_head<SRC_FILTER, false>(b, a, f, tile, sh, true, stop_flag, fb_flag, nullptr, prepare);
     if (h.status) return;
     LLPF_STAMP(1);
-    PropCtx<Model, NX, NY, WEIGHT> pc{b, model, md, st, y, b.xcur + (size_t)f * NX * Ns, b.xnext + (size_t)f * NX * Ns,
+    PropCtx<Model, NX, NY, WEIGHT, false, !Model::RB> pc{b, model, md, st, y, b.xcur + (size_t)f * NX * Ns, b.xnext + (size_t)f * NX * Ns,
                                       b.w + (size_t)f * Ns, key0, key1, sb + st.step, a.ablate, 0.0, b.quanta_next + (size_t)f * Ns,
                                       Model::RB ? nullptr : sh_rng_lg, Model::RB ? nullptr : sh_rng_sc};
     int32_t* anc = b.anc + (size_t)f * Ns;
@@ -222,6 +229,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!Model::
         else res_counts<LLPF_RESAMPLE_STRATIFIED>(b, a, f, tile, h, qv, sh, c_start, c_end);
         first = c_start;
         last = (tile == b.P2 - 1) ? (int64_t)a.M : (int64_t)c_end;
+        if (OWN_TABLE) res_owner_table(sh, sh, sh_own, c_start);
     } else {
         l = head_log(h);
         first = (int64_t)tile * TILE;
@@ -253,7 +261,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!Model::
 #ifdef LLPF_DEVTOOLS
             if (o < ucend) src = tile0 + ((a.ablate & 2) ? ((o - (uint32_t)first) & (TILE - 1)) : (uint32_t)res_owner(sh.cl, (int32_t)o));
 #else
-            if (o < ucend) src = tile0 + (uint32_t)res_owner(sh.cl, (int32_t)o);
+            if (o < ucend) {
+                const uint32_t idx = o - (uint32_t)first;
+                src = tile0 + ((OWN_TABLE && idx < (uint32_t)OWN_CAP) ? sh_own[idx] - 1u : (uint32_t)res_owner(sh.cl, (int32_t)o));
+            }
 #endif
             else src = anc_ident_prev ? o : (uint32_t)ld_off(anc, o << 2);
             Mem<LLPF_STCOH0>::st_off(anc, o << 2, (int32_t)src);
