@@ -9,8 +9,11 @@
 // ------------------------------------------------------------------------------------------------
 constexpr double RBF_BOUND_SLACK = 0x1p-20;   // keeps exp(w - bound) <= 1 when a particle's C R C' rounds to zero
 
+#ifndef LLPF_RBF_WAVES
+#define LLPF_RBF_WAVES 2
+#endif
 template <class Model, int NN, int NL, int NY, int MODE>
-__global__ __launch_bounds__(BLOCK) void k_rbfull(BankDev b, const ModelD* __restrict__ models,
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(NL >= 8 ? LLPF_RBF_WAVES : 1))) void k_rbfull(BankDev b, const ModelD* __restrict__ models,
                                                    const FilterScal* scal, StepArgs a) {
     static_assert(MODE == MODE_WEIGHT || MODE == MODE_PROP || MODE == MODE_PROP_WEIGHT, "no auxiliary form");
     constexpr int NP = LLPF_RBF_NP(NL), ROWS = NN + NL + NP;

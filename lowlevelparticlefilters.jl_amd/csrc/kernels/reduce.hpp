@@ -23,7 +23,9 @@ template <bool WT = true, class T> DEV void wt_store(T* p, T v) {
     } else if constexpr (sizeof(T) == 16) {
         llpf_u32x4 r;
         __builtin_memcpy(&r, &v, 16);
-        asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(r) : "memory");
+        // s_nop: a store of more than 64 bits needs one wait state before a VALU instruction may overwrite its data
+        // registers; the compiler keeps that hazard for its own stores but does not see into this one
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" : : "v"(p), "v"(r) : "memory");
     } else {
         __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -53,8 +55,9 @@ DEV uint64_t readlane_u64(uint64_t v, int lane) {
 // inclusive prefix sum over the wave.  The add itself carries the DPP modifier (v_add_co_u32_dpp / v_addc_co_u32_dpp: two
 // instructions per step for 64 bits, four for 128); written through update_dpp the compiler emits a v_mov_b32_dpp per half
 // and then the add (four per step), and a 128-bit sum had to go limb-wise through three 64-bit scans.
-// Hazards inside the block are ours to keep: a VALU write of a VGPR needs 2 wait states before a DPP read of it (s_nop 0 +
-// the other half's instruction), and the block starts with s_nop 4 (a VALU write of EXEC needs 5 before DPP).
+// Hazards inside the block are ours to keep (the compiler does not see into it): a VALU write of a VGPR needs 2 wait states
+// before a DPP read of it (s_nop 0 + the other half's instruction; s_nop 1 at the end for a DPP instruction of the compiler's
+// that may follow), and the block starts with s_nop 4 (a VALU write of EXEC needs 5 before DPP).
 #define LLPF_DPP_SHR(n) "row_shr:" #n " row_mask:0xf bank_mask:0xf bound_ctrl:0"
 #define LLPF_DPP_B15 "row_bcast:15 row_mask:0xa bank_mask:0xf"
 #define LLPF_DPP_B31 "row_bcast:31 row_mask:0xc bank_mask:0xf"
@@ -65,7 +68,7 @@ DEV uint64_t wave_scan_u64(uint64_t x) {
     uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
     asm("s_nop 4\n\t"
         LLPF_ADD64_DPP(LLPF_DPP_SHR(1)) LLPF_ADD64_DPP(LLPF_DPP_SHR(2)) LLPF_ADD64_DPP(LLPF_DPP_SHR(4)) LLPF_ADD64_DPP(LLPF_DPP_SHR(8))
-        LLPF_ADD64_DPP(LLPF_DPP_B15) LLPF_ADD64_DPP(LLPF_DPP_B31)
+        LLPF_ADD64_DPP(LLPF_DPP_B15) LLPF_ADD64_DPP(LLPF_DPP_B31) "s_nop 1"
         : "+v"(lo), "+v"(hi) : : "vcc");
     return ((uint64_t)hi << 32) | lo;
 }
@@ -82,7 +85,7 @@ DEV llpf_u128 wave_sum_u128(llpf_u128 v) {
     uint32_t w0 = (uint32_t)v.lo, w1 = (uint32_t)(v.lo >> 32), w2 = (uint32_t)v.hi, w3 = (uint32_t)(v.hi >> 32);
     asm("s_nop 4\n\t"
         LLPF_ADD128_DPP(LLPF_DPP_SHR(1)) LLPF_ADD128_DPP(LLPF_DPP_SHR(2)) LLPF_ADD128_DPP(LLPF_DPP_SHR(4)) LLPF_ADD128_DPP(LLPF_DPP_SHR(8))
-        LLPF_ADD128_DPP(LLPF_DPP_B15) LLPF_ADD128_DPP(LLPF_DPP_B31)
+        LLPF_ADD128_DPP(LLPF_DPP_B15) LLPF_ADD128_DPP(LLPF_DPP_B31) "s_nop 1"
         : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3) : : "vcc");
     llpf_u128 r;
     r.lo = readlane_u64(((uint64_t)w1 << 32) | w0, 63);

@@ -432,6 +432,12 @@ DEV void res_owner_table(const ResShared& shc, ResShared& sh, uint32_t* own, int
 template <int STRATEGY, int SRC>
 __global__ __launch_bounds__(BLOCK) void k_resample(BankDev b, ResArgs a) {
     __shared__ ResShared sh;
+    __shared__ __attribute__((aligned(16))) uint32_t sh_own[OWN_CAP];
+    {
+        const uint4 z = {0u, 0u, 0u, 0u};
+        reinterpret_cast<uint4*>(sh_own)[2 * threadIdx.x] = z;
+        reinterpret_cast<uint4*>(sh_own)[2 * threadIdx.x + 1] = z;
+    }
     const int f = blockIdx.y;
     const int tile = blockIdx.x;
     if (SRC == SRC_FILTER && run_is_stopped(b, a.k)) return;
@@ -452,8 +458,13 @@ __global__ __launch_bounds__(BLOCK) void k_resample(BankDev b, ResArgs a) {
     res_counts<STRATEGY>(b, a, f, tile, h, qv, sh, c_start, c_end);
     if (a.only_bins) return;
     int32_t* ao = a.anc_out + (size_t)f * b.Ns;
-    for (int32_t o = c_start + threadIdx.x; o < c_end; o += BLOCK)
-        wt_store(ao + o, (int32_t)((int64_t)tile * TILE + res_owner(sh.cl, o)));
+    const bool table = c_end - c_start >= BLOCK;       // block-uniform; a table for a handful of outputs would not pay
+    if (table) res_owner_table(sh, sh, sh_own, c_start);
+    for (int32_t o = c_start + threadIdx.x; o < c_end; o += BLOCK) {
+        const uint32_t idx = (uint32_t)(o - c_start);
+        const int own = (table && idx < (uint32_t)OWN_CAP) ? (int)sh_own[idx] - 1 : res_owner(sh.cl, o);
+        wt_store(ao + o, (int32_t)((int64_t)tile * TILE + own));
+    }
     // outputs whose threshold is >= bins[N] are never written by the reference (j keeps its previous
     // value); the previous value is only materialised here if it was the identity 1:N
     if (tile == b.P2 - 1 && SRC == SRC_FILTER && b.scal[f].anc_ident_s[b.anc_slot]) {

@@ -15,6 +15,15 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
     const FilterScal* sc = scal + f;
     if (run_is_stopped(b, a.k)) return;
     if (a.only_fallback ? !sc->fallback : (sc->fallback != 0)) return;   // redo launches take the flagged filters, all others skip them
+    // the generator's tables in LDS (one 16-byte LDS read per lookup instead of two global loads through the GOT)
+    constexpr bool LTAB = !Model::RB && MODE != MODE_WEIGHT && MODE != MODE_AUX;
+    __shared__ __attribute__((aligned(16))) double sh_rng_lg[LTAB ? 2 * LLPF_RNG_LG_ENTRIES : 2], sh_rng_sc[LTAB ? 2 * LLPF_RNG_SC_ENTRIES : 2];
+    if (LTAB) {
+        const int t = (int)threadIdx.x;
+        if (t < LLPF_RNG_SC_ENTRIES) { sh_rng_sc[2 * t] = LLPF_SIN64[t]; sh_rng_sc[2 * t + 1] = LLPF_COS64[t]; }
+        else if (t < LLPF_RNG_SC_ENTRIES + LLPF_RNG_LG_ENTRIES) { sh_rng_lg[2 * (t - LLPF_RNG_SC_ENTRIES)] = LLPF_LOG_INVC[t - LLPF_RNG_SC_ENTRIES]; sh_rng_lg[2 * (t - LLPF_RNG_SC_ENTRIES) + 1] = LLPF_LOG_LNC[t - LLPF_RNG_SC_ENTRIES]; }
+        __syncthreads();
+    }
     const int do_res = (MODE != MODE_WEIGHT && MODE != MODE_AUX) ? sc->do_resample : 0;
     const int uniform = sc->uniform, pend = sc->norm_pending;
     const double m = sc->m, l = sc->l, wconst = sc->wconst;
@@ -88,7 +97,8 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
 #pragma unroll
                     for (int d = 0; d < NX; ++d) xs[p][d] = fx[d];
                 } else {
-                    llpf_normals((uint32_t)(i0 + p), sb + a.step, LLPF_STREAM_DYNAMICS, k0, k1, NX, xi);
+                    if constexpr (LTAB) llpf_normals_tab((uint32_t)(i0 + p), sb + a.step, LLPF_STREAM_DYNAMICS, k0, k1, NX, xi, sh_rng_lg, sh_rng_sc);
+                    else llpf_normals((uint32_t)(i0 + p), sb + a.step, LLPF_STREAM_DYNAMICS, k0, k1, NX, xi);
                     gauss_sample<NX>(md->df, xi, nz);
 #pragma unroll
                     for (int d = 0; d < NX; ++d) xs[p][d] = fx[d] + nz[d];
