@@ -563,6 +563,36 @@ def test_outlier_measurements_take_the_exact_form(thr, N):
     _compare_state(g3, o)
 
 
+@pytest.mark.gpu
+def test_heavy_particles_beyond_the_owner_table():
+    """A very informative measurement leaves a handful of particles with all the weight: the tile that holds one of them
+    produces far more outputs than the fused kernel's owner table holds (2048), so the rest of its range goes through the
+    descent over the cumulative counts; tiles without surviving particles produce nothing.  Every bit must still agree."""
+    base = M.lg_test_model()
+    A = np.array(base.A[:4]).reshape(2, 2); B = np.array(base.B[:2]).reshape(2, 1); Cm = np.array([[0.0, 1.0]])
+    model = S.make_lg_model(A, B, Cm, S.make_gaussian(np.zeros(2), 0.01), S.make_gaussian(np.zeros(1), np.full(1, 1e-16)),
+                            S.make_gaussian(np.array([0.3, -0.5]), 4.0), 1.0)
+    _, U, Y = M.simulate_lg(base, 12)
+    cfg = _cfg(model, 40000, thr=1.0)
+    g = _capi.FilterHandle(cfg)
+    o = ob.OracleFilter(cfg, ob.ORDER_DEVICE)
+    g.reset(); o.reset()
+    most = 0
+    for k in range(12):
+        lg_, lo_ = g.correct(U[k], Y[k], float(k)), o.correct(U[k], Y[k], float(k))
+        assert np.float64(lg_).view(np.uint64) == np.float64(lo_).view(np.uint64)
+        g.predict(U[k], float(k)); o.predict(U[k], float(k))
+        ja = g.ancestors()
+        assert np.array_equal(ja, o.ancestors())
+        most = max(most, int(np.bincount(ja).max()))
+    assert most > 4096
+    _compare_state(g, o)
+    g2 = _capi.FilterHandle(cfg)
+    g2.reset()
+    r2 = g2.run(U, Y, 0.0, ll_steps=True)            # the fused run loop
+    _compare_state(g2, o)
+
+
 def test_bank_with_one_outlier_filter():
     """In a bank only the filter whose bound test fails is redone; the others are untouched by the redo."""
     models = [M.lg_test_model(s) for s in (0.05, 0.1, 0.2, 0.4)]
