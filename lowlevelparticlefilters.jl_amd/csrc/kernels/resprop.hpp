@@ -136,8 +136,10 @@ static_assert(TILE == 1024, "TileSum assumes 1024-particle tiles");
 // ONE: the filter is a single tile (launched only when P2 == 1): a failed bound test is redone inside this kernel
 template <class Model, int NX, int NY, bool WEIGHT, bool ACC, bool AUX = false, bool ONE = false>
 // amdgpu_waves_per_eu(4): the ~3.8 blocks per CU of a 10^6-particle filter must be resident together (<= 128 VGPRs); the
-// larger state dimensions and the Rao-Blackwellized propagate would spill under that cap and keep the compiler's choice
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!Model::RB && NX <= 2 && NY <= 2 && !ONE) ? 4 : 1))) void k_resprop(BankDev b, const ModelD* __restrict__ models, ResArgs a, StepArgs st) {
+// larger state dimensions would spill under that cap and keep the compiler's choice; the Rao-Blackwellized propagate uses
+// 130-156 VGPRs and is pinned to three waves per SIMD (<= 168): twice in this round an unrelated change pushed it past 170 and
+// cost it 28 %
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!Model::RB && NX <= 2 && NY <= 2 && !ONE) ? 4 : (Model::RB ? 3 : 1)))) void k_resprop(BankDev b, const ModelD* __restrict__ models, ResArgs a, StepArgs st) {
     __shared__ ResShared sh;
     __shared__ double sm_max[BLOCK / 64];
     __shared__ uint64_t sm_acc[BLOCK / 64][5];
