@@ -21,6 +21,18 @@ __global__ void k_selftest_math(int which, const double* __restrict__ in, double
         case 9: r = llpf_log_unit(x); break;
         case 10: llpf_sincos2pi_fast(x, &s, &c); r = s; break;
         case 11: llpf_sincos2pi_fast(x, &s, &c); r = c; break;
+        // the wave primitives written in inline assembly (kernels/reduce.hpp); n must be a multiple of 64: each group of 64
+        // consecutive elements is one wave, the operand is the bit pattern of x
+        case 13: r = (double)(uint32_t)wave_scan_u64(llpf_d2u(x)); break;
+        case 14: r = (double)(uint32_t)(wave_scan_u64(llpf_d2u(x)) >> 32); break;
+        case 15: case 16: case 17: case 18: {
+            const uint64_t u = llpf_d2u(x);
+            llpf_u128 v; v.lo = u; v.hi = (u << 29) | (u >> 35);
+            const llpf_u128 t = wave_sum_u128(v);
+            const uint32_t w[4] = {(uint32_t)t.lo, (uint32_t)(t.lo >> 32), (uint32_t)t.hi, (uint32_t)(t.hi >> 32)};
+            r = (double)w[which - 15];
+            break;
+        }
         default: r = 0.0;
     }
     out[i] = r;

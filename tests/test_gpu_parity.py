@@ -40,6 +40,25 @@ def test_device_math_bit_identical_to_host():
         assert np.array_equal(host.view(np.uint64), dev.view(np.uint64)), "primitive %d differs host/device" % which
 
 
+def test_wave_scans_written_in_assembly():
+    """kernels/reduce.hpp: 64-bit inclusive wave scan and 128-bit wave sum with the DPP modifier on the add (inline asm whose
+    hazards the compiler does not see): against numpy on random bit patterns, carries across every 32-bit boundary."""
+    rng = np.random.default_rng(5)
+    bits = rng.integers(0, 2 ** 64, size=64 * 300, dtype=np.uint64)
+    bits[:64] = np.uint64(0xFFFFFFFFFFFFFFFF)          # every add carries
+    bits[64:128] = np.uint64(0xFFFFFFFF)
+    x = bits.view(np.float64)
+    scan = np.cumsum(bits.reshape(-1, 64), axis=1, dtype=np.uint64).reshape(-1)           # wraps mod 2^64
+    lo = _capi.selftest_math(13, x); hi = _capi.selftest_math(14, x)
+    assert np.array_equal(lo.astype(np.uint64), scan & np.uint64(0xFFFFFFFF))
+    assert np.array_equal(hi.astype(np.uint64), scan >> np.uint64(32))
+    tot = [sum((int(b) | (((int(b) << 29) | (int(b) >> 35)) & (2 ** 64 - 1)) << 64) for b in grp) % 2 ** 128 for grp in bits.reshape(-1, 64)]
+    for k in range(4):
+        w = _capi.selftest_math(15 + k, x).astype(np.uint64).reshape(-1, 64)
+        want = np.array([(t >> (32 * k)) & 0xFFFFFFFF for t in tot], dtype=np.uint64)
+        assert np.array_equal(w[:, 0], want) and np.all(w == w[:, :1])
+
+
 def test_device_normals_bit_identical_to_host():
     for nd in (1, 2, 3, 4):
         host = ob.normals(12345, 17, 1, nd, 100000)
@@ -563,7 +582,6 @@ def test_outlier_measurements_take_the_exact_form(thr, N):
     _compare_state(g3, o)
 
 
-@pytest.mark.gpu
 def test_heavy_particles_beyond_the_owner_table():
     """A very informative measurement leaves a handful of particles with all the weight: the tile that holds one of them
     produces far more outputs than the fused kernel's owner table holds (2048), so the rest of its range goes through the
