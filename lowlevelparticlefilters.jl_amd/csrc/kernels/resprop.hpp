@@ -255,41 +255,53 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!Model::
     if (a.dbg && threadIdx.x == 0 && f == 0) a.dbg[(size_t)tile * 8 + 5] = (uint64_t)(last - first);
     const uint32_t tile0 = (uint32_t)tile * TILE, ulast = (uint32_t)last, ucend = (uint32_t)c_end;
     __builtin_amdgcn_s_setprio(0);
-#pragma unroll 1
-    for (uint32_t o = (uint32_t)first + threadIdx.x; o < ulast; o += BLOCK) {
-        uint32_t src = o;
-        double wprev = b.log1N;                                        // reset_weights!: w = log(1/N)
-        if (res) {
+    // tile-local source of output o (< c_end): the owner table, the descent beyond it
+    auto owner_of = [&](uint32_t o) -> uint32_t {
 #ifdef LLPF_DEVTOOLS
-            if (o < ucend) src = tile0 + ((a.ablate & 2) ? ((o - (uint32_t)first) & (TILE - 1)) : (uint32_t)res_owner(sh.cl, (int32_t)o));
-#else
-            if (o < ucend) {
-                const uint32_t idx = o - (uint32_t)first;
-                src = tile0 + ((OWN_TABLE && idx < (uint32_t)OWN_CAP) ? sh_own[idx] - 1u : (uint32_t)res_owner(sh.cl, (int32_t)o));
-            }
+        if (a.ablate & 2) return (o - (uint32_t)first) & (TILE - 1);
 #endif
-            else src = anc_ident_prev ? o : (uint32_t)ld_off(anc, o << 2);
-            Mem<LLPF_STCOH0>::st_off(anc, o << 2, (int32_t)src);
-            if (AUX) wprev = ld_off(lamp, o << 3) - lN;               // s.w[i] = lambda[i] - log N (unresampled index, filtering.jl:209-213)
-        } else if (AUX) {
-            wprev = ld_off(lamp, o << 3) - lN;
-        } else if (WEIGHT) {
-            wprev = (ld_off(pc.w, o << 3) - h.a) - l;                  // lazy w .-= offset ; w .-= log(sum)
-        }
-        double xs[NX];
-        const double wv = pc.one(src, o, wprev, bad, xs);
-        bmax = llpf_fmax(bmax, wv);
-        if (WEIGHT && ACC) {
-            double e;
-            const uint64_t q = wacc.add(wv, pc.off, st.K, st.need_e2 != 0, &e);
-            Mem<LLPF_STCOH0>::st_off(pc.qnext, o << 3, q);
-            ts.add(o, q, sh_tq, tq_next, tbase);
-            if (st.want_xmean) {
-#pragma unroll
-                for (int d = 0; d < NX; ++d) xm[d] = xm[d] + xs[d] * e;
-            }
-        }
+        const uint32_t idx = o - (uint32_t)first;
+        return (OWN_TABLE && idx < (uint32_t)OWN_CAP) ? sh_own[idx] - 1u : (uint32_t)res_owner(sh.cl, (int32_t)o);
+    };
+    // The output loop: source of output o (owner table / previous ancestor / o itself), its previous weight (log(1/N) after a
+    // resampling; lambda - log N in the auxiliary filter's second half; else the lazily normalised stored weight: w .-= offset,
+    // w .-= log(sum)), propagate [+ weight], exp-sum / quanta / tile-sum accumulation.  Written once, instantiated per value of
+    // the block-uniform resample flag where that measured faster (split-schedule and Rao-Blackwellized kernels: each version
+    // keeps only its own uniform values live; the merged single-filter kernel is 0.3 us faster with ONE loop and the flag
+    // tested inside).
+#define LLPF_OUTPUT_LOOP(RESX) \
+_Pragma("unroll 1") \
+    for (uint32_t o = (uint32_t)first + threadIdx.x; o < ulast; o += BLOCK) { \
+        uint32_t src = o; \
+        double wprev = b.log1N; \
+        if (RESX) { \
+            if (o < ucend) src = tile0 + owner_of(o); \
+            else src = anc_ident_prev ? o : (uint32_t)ld_off(anc, o << 2); \
+            Mem<LLPF_STCOH0>::st_off(anc, o << 2, (int32_t)src); \
+            if (AUX) wprev = ld_off(lamp, o << 3) - lN; \
+        } else if (AUX) { \
+            wprev = ld_off(lamp, o << 3) - lN; \
+        } else if (WEIGHT) { \
+            wprev = (ld_off(pc.w, o << 3) - h.a) - l; \
+        } \
+        double xs[NX]; \
+        const double wv = pc.one(src, o, wprev, bad, xs); \
+        bmax = llpf_fmax(bmax, wv); \
+        if (WEIGHT && ACC) { \
+            double e; \
+            const uint64_t q = wacc.add(wv, pc.off, st.K, st.need_e2 != 0, &e); \
+            Mem<LLPF_STCOH0>::st_off(pc.qnext, o << 3, q); \
+            ts.add(o, q, sh_tq, tq_next, tbase); \
+            if (st.want_xmean) { \
+_Pragma("unroll") \
+                for (int d = 0; d < NX; ++d) xm[d] = xm[d] + xs[d] * e; \
+            } \
+        } \
     }
+    if constexpr (WEIGHT && ACC && !Model::RB) { LLPF_OUTPUT_LOOP(res) }
+    else if (res) { LLPF_OUTPUT_LOOP(true) }
+    else { LLPF_OUTPUT_LOOP(false) }
+#undef LLPF_OUTPUT_LOOP
     if (WEIGHT && ACC) ts.flush(sh_tq, tq_next, tbase);
     __builtin_amdgcn_s_setprio(3);
     LLPF_STAMP(3);
