@@ -252,12 +252,12 @@ template <class Model, int NX, int NY>
 static hipError_t launch_resprop_t(const BankDev& b, const ResArgs& a, const StepArgs& st, int weight, hipStream_t s) {
     dim3 g((unsigned)b.P2, (unsigned)b.F, 1);
     const bool one = b.P2 == 1;      // one-tile filters: the variant that redoes a failed bound test in place (kernels/resprop.hpp)
-    if (st.aux && one) hipLaunchKernelGGL((k_resprop<NoModel<NX>, NX, 1, true, true, true, true>), g, dim3(BLOCK), 0, s, b, b.models, a, st);
-    else if (st.aux) hipLaunchKernelGGL((k_resprop<NoModel<NX>, NX, 1, true, true, true>), g, dim3(BLOCK), 0, s, b, b.models, a, st);
-    else if (weight && st.accumulate && one) hipLaunchKernelGGL((k_resprop<Model, NX, NY, true, true, false, true>), g, dim3(BLOCK), 0, s, b, b.models, a, st);
-    else if (weight && st.accumulate) hipLaunchKernelGGL((k_resprop<Model, NX, NY, true, true>), g, dim3(BLOCK), 0, s, b, b.models, a, st);
-    else if (weight) hipLaunchKernelGGL((k_resprop<Model, NX, NY, true, false>), g, dim3(BLOCK), 0, s, b, b.models, a, st);
-    else hipLaunchKernelGGL((k_resprop<Model, NX, NY, false, false>), g, dim3(BLOCK), 0, s, b, b.models, a, st);
+    if (st.aux && one) hipLaunchKernelGGL((k_resprop<NoModel<NX>, NX, 1, true, true, true, true>), g, dim3(BLOCK), 0, s, LLPF_HOT_ARGS(b, a), b, b.models, a, st);
+    else if (st.aux) hipLaunchKernelGGL((k_resprop<NoModel<NX>, NX, 1, true, true, true>), g, dim3(BLOCK), 0, s, LLPF_HOT_ARGS(b, a), b, b.models, a, st);
+    else if (weight && st.accumulate && one) hipLaunchKernelGGL((k_resprop<Model, NX, NY, true, true, false, true>), g, dim3(BLOCK), 0, s, LLPF_HOT_ARGS(b, a), b, b.models, a, st);
+    else if (weight && st.accumulate) hipLaunchKernelGGL((k_resprop<Model, NX, NY, true, true>), g, dim3(BLOCK), 0, s, LLPF_HOT_ARGS(b, a), b, b.models, a, st);
+    else if (weight) hipLaunchKernelGGL((k_resprop<Model, NX, NY, true, false>), g, dim3(BLOCK), 0, s, LLPF_HOT_ARGS(b, a), b, b.models, a, st);
+    else hipLaunchKernelGGL((k_resprop<Model, NX, NY, false, false>), g, dim3(BLOCK), 0, s, LLPF_HOT_ARGS(b, a), b, b.models, a, st);
     return hipGetLastError();
 }
 template <int NX>

@@ -133,13 +133,26 @@ struct TileSum {
 };
 static_assert(TILE == 1024, "TileSum assumes 1024-particle tiles");
 
+// leading scalar kernel arguments: preloaded into SGPRs by the command processor (-mllvm -amdgpu-kernarg-preload-count;
+// a struct passed by value as the FIRST argument disables the preload, which is why these are not left inside BankDev)
+#define LLPF_HOT_PARAMS uint64_t* hot_acc, uint64_t* hot_tileq, FilterScal* hot_scal, uint32_t* hot_flag, const uint64_t* hot_quanta, \
+                        int hot_F, int hot_P2, int hot_parity
+#define LLPF_HOT_ARGS(b, a) (b).acc, (b).tileq, (b).scal, (b).bank_flag, (b).quanta, (b).F, (b).P2, (a).parity
+
 // ONE: the filter is a single tile (launched only when P2 == 1): a failed bound test is redone inside this kernel
 template <class Model, int NX, int NY, bool WEIGHT, bool ACC, bool AUX = false, bool ONE = false>
 // amdgpu_waves_per_eu(4): the ~3.8 blocks per CU of a 10^6-particle filter must be resident together (<= 128 VGPRs); the
 // larger state dimensions would spill under that cap and keep the compiler's choice; the Rao-Blackwellized propagate uses
 // 130-156 VGPRs and is pinned to three waves per SIMD (<= 168): twice in this round an unrelated change pushed it past 170 and
 // cost it 28 %
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!Model::RB && NX <= 2 && NY <= 2 && !ONE) ? 4 : (Model::RB ? 3 : 1)))) void k_resprop(BankDev b, const ModelD* __restrict__ models, ResArgs a, StepArgs st) {
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!Model::RB && NX <= 2 && NY <= 2 && !ONE) ? 4 : (Model::RB ? 3 : 1)))) void k_resprop(LLPF_HOT_PARAMS, BankDev b_in, const ModelD* __restrict__ models, ResArgs a_in, StepArgs st) {
+    // what the head's first loads are addressed with arrives in SGPRs with the wave (kernarg preload) instead of through a
+    // scalar load of the argument block: one memory round trip less at the start of every launch
+    BankDev b = b_in;
+    b.acc = hot_acc; b.tileq = hot_tileq; b.scal = hot_scal; b.bank_flag = hot_flag; b.quanta = const_cast<uint64_t*>(hot_quanta);
+    b.F = hot_F; b.P2 = hot_P2;
+    ResArgs a = a_in;
+    a.parity = hot_parity;
     __shared__ ResShared sh;
     __shared__ double sm_max[BLOCK / 64];
     __shared__ uint64_t sm_acc[BLOCK / 64][5];
@@ -164,21 +177,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!Model::
     const uint64_t* __restrict__ qsrc = b.quanta + (size_t)f * Ns;
     const int64_t ib = (int64_t)tile * TILE + (int64_t)threadIdx.x * NORM_IPT;
     ulonglong2 qv[NORM_IPT / 2];
-#pragma unroll
-    for (int k = 0; k < NORM_IPT / 2; ++k) qv[k] = *reinterpret_cast<const ulonglong2*>(qsrc + ib + 2 * k);
     const int anc_ident_prev = sc->anc_ident_s[b.anc_slot];   // this launch writes the other entry
     if (OWN_TABLE) {   // owner table of the output loop: cleared here, filled after the counts (res_owner_table)
         const uint4 z = {0u, 0u, 0u, 0u};
         reinterpret_cast<uint4*>(sh_own)[2 * threadIdx.x] = z;
         reinterpret_cast<uint4*>(sh_own)[2 * threadIdx.x + 1] = z;
     }
-    // the generator's tables -> LDS (two of them per lookup as one 16-byte LDS read instead of two global loads)
     double rt0 = 0.0, rt1 = 0.0;
-    if (!Model::RB) {
-        const int t = (int)threadIdx.x;
-        if (t < LLPF_RNG_SC_ENTRIES) { rt0 = LLPF_SIN64[t]; rt1 = LLPF_COS64[t]; }
-        else if (t < LLPF_RNG_SC_ENTRIES + LLPF_RNG_LG_ENTRIES) { rt0 = LLPF_LOG_INVC[t - LLPF_RNG_SC_ENTRIES]; rt1 = LLPF_LOG_LNC[t - LLPF_RNG_SC_ENTRIES]; }
-    }
 #define LLPF_STAMP(i) if (a.dbg && threadIdx.x == 0 && f == 0) a.dbg[(size_t)tile * 8 + (i)] = wall_clock64()
     LLPF_STAMP(0);
     Model model;
@@ -191,14 +196,24 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!Model::
         const double* yf = st.y + (size_t)f * st.y_stride;
 #pragma unroll
         for (int k = 0; k < NY; ++k) y[k] = (WEIGHT && st.has_y) ? yf[k] : 0.0;
-        if (!Model::RB) {      // before the head's barrier
+        // Issued LAST, after everything the head itself waits for (accumulator words, tile sums: a few KB): the tile's quanta
+        // are 8 MB over the whole launch, all blocks start at once, and loads return in order — issued first they kept every
+        // head waiting 2.5 us for a burst that is only needed by the counts.  Likewise the generator's tables (for the loop).
+#pragma unroll
+        for (int k = 0; k < NORM_IPT / 2; ++k) qv[k] = *reinterpret_cast<const ulonglong2*>(qsrc + ib + 2 * k);
+        if (!Model::RB) {
             const int t = (int)threadIdx.x;
-            if (t < LLPF_RNG_SC_ENTRIES) { sh_rng_sc[2 * t] = rt0; sh_rng_sc[2 * t + 1] = rt1; }
-            else if (t < LLPF_RNG_SC_ENTRIES + LLPF_RNG_LG_ENTRIES) { sh_rng_lg[2 * (t - LLPF_RNG_SC_ENTRIES)] = rt0; sh_rng_lg[2 * (t - LLPF_RNG_SC_ENTRIES) + 1] = rt1; }
+            if (t < LLPF_RNG_SC_ENTRIES) { rt0 = LLPF_SIN64[t]; rt1 = LLPF_COS64[t]; }
+            else if (t < LLPF_RNG_SC_ENTRIES + LLPF_RNG_LG_ENTRIES) { rt0 = LLPF_LOG_INVC[t - LLPF_RNG_SC_ENTRIES]; rt1 = LLPF_LOG_LNC[t - LLPF_RNG_SC_ENTRIES]; }
         }
     };
     const ResHead h = res_head<SRC_FILTER, false>(b, a, f, tile, sh, true, stop_flag, fb_flag, nullptr, prepare);
     if (h.status) return;
+    if (!Model::RB) {      // the generator's tables -> LDS (one 16-byte LDS read per lookup instead of two global loads); the
+        const int t = (int)threadIdx.x;     // barriers of the counts / the one below come before the loop reads them
+        if (t < LLPF_RNG_SC_ENTRIES) { sh_rng_sc[2 * t] = rt0; sh_rng_sc[2 * t + 1] = rt1; }
+        else if (t < LLPF_RNG_SC_ENTRIES + LLPF_RNG_LG_ENTRIES) { sh_rng_lg[2 * (t - LLPF_RNG_SC_ENTRIES)] = rt0; sh_rng_lg[2 * (t - LLPF_RNG_SC_ENTRIES) + 1] = rt1; }
+    }
     LLPF_STAMP(1);
     PropCtx<Model, NX, NY, WEIGHT, false, !Model::RB> pc{b, model, md, st, y, b.xcur + (size_t)f * NX * Ns, b.xnext + (size_t)f * NX * Ns,
                                       b.w + (size_t)f * Ns, key0, key1, sb + st.step, a.ablate, 0.0, b.quanta_next + (size_t)f * Ns,
@@ -236,6 +251,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!Model::
         l = head_log(h);
         first = (int64_t)tile * TILE;
         last = first + TILE;
+        if (!Model::RB) __syncthreads();      // generator tables in LDS
     }
     {   // bound of the weights produced below: max of the previous (normalised) weights + the density's peak
         const double wmx = res ? b.log1N : (h.mtrue - h.a) - l;
