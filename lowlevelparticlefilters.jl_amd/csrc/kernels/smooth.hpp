@@ -80,6 +80,9 @@ __global__ __launch_bounds__(BLOCK) void k_smooth_draw(BankDev b, const ModelD* 
         for (int k = 0; k < 4; ++k)
             if (n0 + k < N && (double)(excl + c[k]) * invTd < s) ++count;
         carry += all;
+        // bins are non-decreasing (fl and the multiplication by 1/total are monotone): once the running total is not below s
+        // no later bin is, and the rest of the sweep would count nothing — on average half of it
+        if (!((double)carry * invTd < s)) break;
     }
     count = wave_sum_u64(count);
     __syncthreads();
