@@ -165,7 +165,7 @@ def main_bank(args, rank, world, dev):
         if int(flag.item()) == 0:
             bank = _capi.MBankHandle(cfg, models, rank=rank, world=world, unique_id=None)
             external = True
-            collective = "torch.distributed all_reduce (RCCL) of the vector llpf_mbank_run returned; in-library communicator failed: " + err
+            collective = "torch.distributed all_reduce (gloo) of the vector llpf_mbank_run returned; in-library communicator failed: " + err
     else:
         bank = _capi.MBankHandle(cfg, models, rank=rank, world=world, unique_id=None)
         external = True
@@ -247,7 +247,7 @@ def main_bank(args, rank, world, dev):
                           "filters": F, "particles": N, "timesteps": T, "nx": nx, "resample_threshold": thr,
                           "resamples_per_pass_rank0": int(bank.resample_count()),
                           "parallelism": "filter k on rank k mod %d (llpf_mbank_*), one all-reduce of the log-likelihood vector per pass" % world,
-                          "collective": collective},
+                          "collective": collective, "control_plane": "torch.distributed gloo (rendezvous, barriers, timing reduction)"},
                "ranks_seen": sorted(r["rank"] for r in ranks_seen), "rank_devices": {str(r["rank"]): r["device"] for r in ranks_seen},
                "rank_seconds": {str(r["rank"]): r["seconds"] for r in ranks_seen},
                "device_ms_per_step": dev_ms / args.steps, "collective_ms_per_step": coll_ms / args.steps,
@@ -384,8 +384,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=None, help="timesteps of the CPU baseline sample")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
-                    help="nccl (= RCCL) is the measured path; gloo only exercises the multi-rank logic on a box with fewer GPUs than "
-                         "ranks (collectives on CPU tensors, ranks share devices)")
+                    help="nccl (= RCCL, the measured path): one rank per GPU, the log-likelihood all-reduce over RCCL INSIDE the library; "
+                         "gloo: that exchange through torch.distributed on CPU tensors, ranks may share devices (exercises the multi-rank "
+                         "logic on a box with fewer GPUs than ranks).  Rendezvous, barriers and the timing reduction use gloo in both")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
@@ -406,15 +407,15 @@ def main():
     import torch.distributed as dist
 
     dev = 0
-    if world > 1 and args.dist_backend == "nccl":
-        dev = local_rank
+    if world > 1:
+        # one rank per GPU (nccl) / ranks folded onto the GPUs there are (gloo)
+        dev = local_rank if args.dist_backend == "nccl" else local_rank % torch.cuda.device_count()
         torch.cuda.set_device(dev)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev))
-    elif world > 1:
-        dev = local_rank % torch.cuda.device_count()
-        torch.cuda.set_device(dev)
+        # Control plane (unique-id broadcast, barriers, the max over ranks of the elapsed time) on gloo in BOTH modes.  The data
+        # path's collective is RCCL inside libllpf_hip.so, bound to /opt/rocm's runtime; the torch wheel bundles a second RCCL
+        # and HIP runtime, and with gloo here that second RCCL is never initialised in this process.
         dist.init_process_group(backend="gloo")
-    args.coll_device = torch.device("cuda", dev) if args.dist_backend == "nccl" else torch.device("cpu")
+    args.coll_device = torch.device("cpu")
 
     if args.workload == "bank":
         return main_bank(args, rank, world, dev)
