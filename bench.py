@@ -16,6 +16,7 @@ config C4: a sweep of independent filters (128 x N=1e5 per GPU) sharded over the
 RCCL call inside the library on the communicator built from an id rank 0 hands out (weak scaling).
 """
 import argparse
+import threading
 import json
 import os
 import sys
@@ -154,18 +155,40 @@ def main_bank(args, rank, world, dev):
     elif args.dist_backend == "nccl":
         ids = [_capi.mbank_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
+        # The communicator and its first all-reduce are made under a watchdog: this path has never run on more than one GPU
+        # (none was available to the build), and a rendezvous that hangs must cost the scaling run a line that says so, not the run.
+        box = {}
+
+        def make_and_try():
+            try:
+                h = _capi.MBankHandle(cfg, models, rank=rank, world=world, unique_id=ids[0])
+                h.reset()
+                h.run(U[:2], Y[:2], 1.0)
+                box["bank"] = h
+            except Exception as e:              # reported, never silent: the line says which collective ran
+                box["err"] = "%s: %s" % (type(e).__name__, e)
+
+        th = threading.Thread(target=make_and_try, daemon=True)
+        th.start()
+        th.join(timeout=args.rccl_timeout)
         ok, err = 1, ""
-        try:
-            bank = _capi.MBankHandle(cfg, models, rank=rank, world=world, unique_id=ids[0])
-            collective = "RCCL ncclAllReduce(fp64, sum) of the log-likelihood vector inside libllpf_hip.so (llpf_mbank_run)"
-        except _capi.LLPFError as e:       # reported, never silent: the line says which collective ran
-            ok, err = 0, str(e)
+        if th.is_alive():
+            ok, err = 0, "no answer from ncclCommInitRank / the first ncclAllReduce within %g s on rank %d" % (args.rccl_timeout, rank)
+            args.stuck_thread = True
+        elif "err" in box:
+            ok, err = 0, box["err"]
         flag = torch.tensor([ok], dtype=torch.int32, device=device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
-            bank = _capi.MBankHandle(cfg, models, rank=rank, world=world, unique_id=None)
+        if int(flag.item()) == 1:
+            bank = box["bank"]
+            collective = "RCCL ncclAllReduce(fp64, sum) of the log-likelihood vector inside libllpf_hip.so (llpf_mbank_run)"
+        else:
+            errs = [None] * world
+            dist.all_gather_object(errs, err)
+            bank = _capi.MBankHandle(cfg, models, rank=rank, world=world, unique_id=None)     # a working handle of a peer is left alone
             external = True
-            collective = "torch.distributed all_reduce (gloo) of the vector llpf_mbank_run returned; in-library communicator failed: " + err
+            collective = ("torch.distributed all_reduce (gloo) of the vector llpf_mbank_run returned; in-library communicator failed: "
+                          + "; ".join(sorted({e for e in errs if e})))
     else:
         bank = _capi.MBankHandle(cfg, models, rank=rank, world=world, unique_id=None)
         external = True
@@ -276,6 +299,9 @@ def main_bank(args, rank, world, dev):
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if getattr(args, "stuck_thread", False):      # a thread is still inside RCCL: do not let interpreter shutdown wait for it
+        sys.stdout.flush()
+        os._exit(0)
 
 
 def main_reference_mc(args, rank, world):
@@ -383,6 +409,9 @@ def main():
     ap.add_argument("--threshold", type=float, default=None, help="resample_threshold override")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=None, help="timesteps of the CPU baseline sample")
+    ap.add_argument("--rccl-timeout", type=float, default=120.0,
+                    help="N > 1: seconds the in-library RCCL communicator and its first all-reduce may take before the run falls back "
+                         "to exchanging the log-likelihood vector through torch.distributed (and says so in config.collective)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, the measured path): one rank per GPU, the log-likelihood all-reduce over RCCL INSIDE the library; "
                          "gloo: that exchange through torch.distributed on CPU tensors, ranks may share devices (exercises the multi-rank "
@@ -409,7 +438,8 @@ def main():
     dev = 0
     if world > 1:
         # one rank per GPU (nccl) / ranks folded onto the GPUs there are (gloo)
-        dev = local_rank if args.dist_backend == "nccl" else local_rank % torch.cuda.device_count()
+        fold = args.dist_backend != "nccl" or os.environ.get("LLPF_BENCH_FOLD_DEVICES")   # the env var: to watch the nccl mode's
+        dev = local_rank % torch.cuda.device_count() if fold else local_rank                  # fallback on a box with too few GPUs
         torch.cuda.set_device(dev)
         # Control plane (unique-id broadcast, barriers, the max over ranks of the elapsed time) on gloo in BOTH modes.  The data
         # path's collective is RCCL inside libllpf_hip.so, bound to /opt/rocm's runtime; the torch wheel bundles a second RCCL
