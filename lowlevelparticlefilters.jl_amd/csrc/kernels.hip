@@ -56,11 +56,11 @@ int rbfull_rows(int nn, int nl) { return nn + nl + LLPF_RBF_NP(nl); }
 
 template <class Model, int NN, int NL, int NY>
 static hipError_t launch_rbfull_t(const BankDev& b, int mode, const StepArgs& a, hipStream_t s) {
-    dim3 g((unsigned)(b.Ns / BLOCK), (unsigned)b.F, 1);
+    dim3 g((unsigned)(b.Ns / RBF_BLOCK), (unsigned)b.F, 1);
     switch (mode) {
-        case MODE_WEIGHT: hipLaunchKernelGGL((k_rbfull<Model, NN, NL, NY, MODE_WEIGHT>), g, dim3(BLOCK), 0, s, b, b.models, b.scal, a); break;
-        case MODE_PROP: hipLaunchKernelGGL((k_rbfull<Model, NN, NL, NY, MODE_PROP>), g, dim3(BLOCK), 0, s, b, b.models, b.scal, a); break;
-        case MODE_PROP_WEIGHT: hipLaunchKernelGGL((k_rbfull<Model, NN, NL, NY, MODE_PROP_WEIGHT>), g, dim3(BLOCK), 0, s, b, b.models, b.scal, a); break;
+        case MODE_WEIGHT: hipLaunchKernelGGL((k_rbfull<Model, NN, NL, NY, MODE_WEIGHT>), g, dim3(RBF_BLOCK), 0, s, b, b.models, b.scal, a); break;
+        case MODE_PROP: hipLaunchKernelGGL((k_rbfull<Model, NN, NL, NY, MODE_PROP>), g, dim3(RBF_BLOCK), 0, s, b, b.models, b.scal, a); break;
+        case MODE_PROP_WEIGHT: hipLaunchKernelGGL((k_rbfull<Model, NN, NL, NY, MODE_PROP_WEIGHT>), g, dim3(RBF_BLOCK), 0, s, b, b.models, b.scal, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

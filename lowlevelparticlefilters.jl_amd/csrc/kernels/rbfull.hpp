@@ -12,12 +12,14 @@ constexpr double RBF_BOUND_SLACK = 0x1p-20;   // keeps exp(w - bound) <= 1 when 
 #ifndef LLPF_RBF_WAVES
 #define LLPF_RBF_WAVES 2
 #endif
+// One wave per workgroup: a particle costs ~6000 instructions here and N = 2e5 is 3.06 waves per SIMD, so the launch ends with the
+// SIMDs that got a fourth wave; single-wave groups let the dispatcher hand a wave to whichever SIMD frees a slot.
+constexpr int RBF_BLOCK = 64;
 template <class Model, int NN, int NL, int NY, int MODE>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(NL >= 8 ? LLPF_RBF_WAVES : 1))) void k_rbfull(BankDev b, const ModelD* __restrict__ models,
+__global__ __launch_bounds__(RBF_BLOCK) __attribute__((amdgpu_waves_per_eu(NL >= 8 ? LLPF_RBF_WAVES : 1))) void k_rbfull(BankDev b, const ModelD* __restrict__ models,
                                                    const FilterScal* scal, StepArgs a) {
     static_assert(MODE == MODE_WEIGHT || MODE == MODE_PROP || MODE == MODE_PROP_WEIGHT, "no auxiliary form");
     constexpr int NP = LLPF_RBF_NP(NL), ROWS = NN + NL + NP;
-    __shared__ double sm_max[BLOCK / 64];
     const int f = blockIdx.y;
     const ModelD* md = models + f;
     const FilterScal* sc = scal + f;
@@ -36,7 +38,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(NL >= 8 ?
     Model model;
     model.prepare(md, a.u, a.t_prop);
 
-    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * RBF_BLOCK + threadIdx.x;
     const int64_t src = do_res ? (int64_t)b.anc[(size_t)f * Ns + i] : i;
     double xn[NN], xl[NL], R[NP];
 #pragma unroll
@@ -91,8 +93,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(NL >= 8 ?
         for (int d = 0; d < NP; ++d) xo[(size_t)(NN + NL + d) * Ns + i] = R[d];
     }
     if (MODE != MODE_PROP) {
-        const double r = block_max(bmax, sm_max);
-        const int anybad = __syncthreads_or(bad ? 1 : 0);
+        const double r = wave_max(bmax);                        // the workgroup is one wave
+        const int anybad = __ballot(bad) != 0 ? 1 : 0;
         if (threadIdx.x == 0) {
             acc_max(b.acc + (size_t)f * ACC_WORDS, a.parity, r, anybad != 0);
             if (blockIdx.x == 0) {
