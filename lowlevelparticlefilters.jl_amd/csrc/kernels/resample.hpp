@@ -131,10 +131,10 @@ DEV ResHead res_head(const BankDev& b, const ResArgs& a, int f, int tile, ResSha
     const bool fin = (a.mode & RES_FINALIZE) != 0;
     const bool unif0 = (SRC == SRC_FILTER) && !fin && sc->uniform;
     // scalars of the previous launch that are needed after the barrier below: fetched now, with the other loads
-    const double off_pre = carry ? carry->off : sc->off_slot[a.parity];
-    const int e2v_pre = carry ? carry->e2v : sc->e2v_slot[a.parity];
-    const int exact_pre = carry ? 0 : sc->exact_slot[a.parity];
-    const int status_pre = carry ? carry->status : sc->status;
+    double off_pre = carry ? carry->off : sc->off_slot[a.parity];
+    int e2v_pre = carry ? carry->e2v : sc->e2v_slot[a.parity];
+    int exact_pre = carry ? 0 : sc->exact_slot[a.parity];
+    int status_pre = carry ? carry->status : sc->status;
 
     // loads.  wave 0: lane group g (8 lanes = 8 shards) fetches word g of this slot's accumulator set
     uint64_t accv = 0;
@@ -189,6 +189,18 @@ DEV ResHead res_head(const BankDev& b, const ResArgs& a, int f, int tile, ResSha
     all = wave_sum_u64(all);
     if (lane == 0) { sh.red[wvid][0] = pre; sh.red[wvid][1] = all; }
     __syncthreads();
+    if (SRC == SRC_FILTER && !carry) {
+        // FilterScal is written by these kernels, so the scalars fetched above are vector loads made uniform with
+        // v_readfirstlane — placed by the compiler right behind the loads, with a wait, BEFORE the accumulator and tile-sum
+        // loads are issued.  The asm pins their first use here, behind the barrier.
+        uint32_t ol = (uint32_t)llpf_d2u(off_pre), oh = (uint32_t)(llpf_d2u(off_pre) >> 32);
+        asm volatile("" : "+v"(ol), "+v"(oh), "+v"(e2v_pre), "+v"(exact_pre), "+v"(status_pre), "+v"(stop_flag), "+v"(fb_flag));
+        ol = __builtin_amdgcn_readfirstlane(ol); oh = __builtin_amdgcn_readfirstlane(oh);
+        off_pre = llpf_u2d(((uint64_t)oh << 32) | ol);
+        e2v_pre = __builtin_amdgcn_readfirstlane(e2v_pre); exact_pre = __builtin_amdgcn_readfirstlane(exact_pre);
+        status_pre = __builtin_amdgcn_readfirstlane(status_pre);
+        stop_flag = __builtin_amdgcn_readfirstlane(stop_flag); fb_flag = __builtin_amdgcn_readfirstlane(fb_flag);
+    }
     h.status = 0;
     h.s = 0.0;
     if (defer_skip) {

@@ -153,6 +153,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!Model::
     b.F = hot_F; b.P2 = hot_P2;
     ResArgs a = a_in;
     a.parity = hot_parity;
+    a.mode = RES_FINALIZE | RES_RESAMPLE;        // what launch_resprop always passes: known here, the head's first loads then wait for no scalar load of the argument block
     __shared__ ResShared sh;
     __shared__ double sm_max[BLOCK / 64];
     __shared__ uint64_t sm_acc[BLOCK / 64][5];
@@ -177,18 +178,24 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!Model::
     const uint64_t* __restrict__ qsrc = b.quanta + (size_t)f * Ns;
     const int64_t ib = (int64_t)tile * TILE + (int64_t)threadIdx.x * NORM_IPT;
     ulonglong2 qv[NORM_IPT / 2];
-    const int anc_ident_prev = sc->anc_ident_s[b.anc_slot];   // this launch writes the other entry
+    int anc_ident_v = sc->anc_ident_s[b.anc_slot];            // this launch writes the other entry
     if (OWN_TABLE) {   // owner table of the output loop: cleared here, filled after the counts (res_owner_table)
         const uint4 z = {0u, 0u, 0u, 0u};
         reinterpret_cast<uint4*>(sh_own)[2 * threadIdx.x] = z;
         reinterpret_cast<uint4*>(sh_own)[2 * threadIdx.x + 1] = z;
     }
     double rt0 = 0.0, rt1 = 0.0;
+// phase stamps (tools/dbg/timing_c2.sh): compiled in with DEVTOOLS=1 only — the test of a.dbg at the kernel's first instruction made
+// every block wait for a scalar load of the argument block before it could request anything else
+#ifdef LLPF_DEVTOOLS
 #define LLPF_STAMP(i) if (a.dbg && threadIdx.x == 0 && f == 0) a.dbg[(size_t)tile * 8 + (i)] = wall_clock64()
+#else
+#define LLPF_STAMP(i) ((void)0)
+#endif
     LLPF_STAMP(0);
     Model model;
     double y[NY];
-    const uint32_t key0 = sc->k0, key1 = sc->k1, sb = sc->step_base;
+    uint32_t key0_v = sc->k0, key1_v = sc->k1, sb_v = sc->step_base;
     const double c0_pre = md->dg.c0;                   // fetched with the other loads: the bound below must not wait for it
     // particle-independent terms (B u, the measurement row): their loads run while the head's vector loads are in flight
     auto prepare = [&]() {
@@ -209,6 +216,14 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!Model::
     };
     const ResHead h = res_head<SRC_FILTER, false>(b, a, f, tile, sh, true, stop_flag, fb_flag, nullptr, prepare);
     if (h.status) return;
+    // Values of FilterScal fetched above with the head's loads but wanted only from here on.  FilterScal is written by this
+    // kernel, so they are vector loads made uniform with v_readfirstlane — which the compiler otherwise places right behind the
+    // loads, with a vmcnt wait BEFORE the head's own loads are issued (a second, serialized memory round trip at the start of
+    // every block).  The asm pins the first use behind the head's barrier.
+    asm volatile("" : "+v"(key0_v), "+v"(key1_v), "+v"(sb_v), "+v"(anc_ident_v));
+    const uint32_t key0 = __builtin_amdgcn_readfirstlane(key0_v), key1 = __builtin_amdgcn_readfirstlane(key1_v);
+    const uint32_t sb = __builtin_amdgcn_readfirstlane(sb_v);
+    const int anc_ident_prev = __builtin_amdgcn_readfirstlane(anc_ident_v);
     if (!Model::RB) {      // the generator's tables -> LDS (one 16-byte LDS read per lookup instead of two global loads); the
         const int t = (int)threadIdx.x;     // barriers of the counts / the one below come before the loop reads them
         if (t < LLPF_RNG_SC_ENTRIES) { sh_rng_sc[2 * t] = rt0; sh_rng_sc[2 * t + 1] = rt1; }
@@ -268,7 +283,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!Model::
     const double* lamp = AUX ? b.lam + (size_t)f * Ns : nullptr;
     const int32_t tbase = (int32_t)(first >> 10);
     LLPF_STAMP(2);
+#ifdef LLPF_DEVTOOLS
     if (a.dbg && threadIdx.x == 0 && f == 0) a.dbg[(size_t)tile * 8 + 5] = (uint64_t)(last - first);
+#endif
     const uint32_t tile0 = (uint32_t)tile * TILE, ulast = (uint32_t)last, ucend = (uint32_t)c_end;
     __builtin_amdgcn_s_setprio(0);
     // tile-local source of output o (< c_end): the owner table, the descent beyond it
