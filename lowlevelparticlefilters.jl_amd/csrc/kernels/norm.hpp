@@ -9,19 +9,23 @@ __global__ __launch_bounds__(BLOCK) void k_norm(BankDev b, int K, int parity, ui
     __shared__ double sm_x[BLOCK / 64][MAXD];
     const int f = blockIdx.y;
     const int tile = blockIdx.x;
-    if (only_fallback && !b.scal[f].fallback) return;
-    if (bound && run_is_stopped(b, kstep)) return;
-    if (bound && b.scal[f].fallback) return;
     uint64_t* acc = b.acc + (size_t)f * ACC_WORDS;
     const double* __restrict__ w = b.w + (size_t)f * b.Ns;
     const double* __restrict__ xc = b.xcur + (size_t)f * NX * b.Ns;
 
+    // flags and weights are requested together and the flags tested afterwards (tested first, each was a memory round trip
+    // of its own before the weights were even asked for)
+    const int fb_flag = b.scal[f].fallback;
+    const uint32_t stop_flag = bound ? *b.bank_flag : 0u;
     double2 wv[NORM_IPT / 2];
 #pragma unroll
     for (int k = 0; k < NORM_IPT / 2; ++k) {
         const int64_t i0 = (int64_t)tile * TILE + (int64_t)k * (BLOCK * 2) + threadIdx.x * 2;
         wv[k] = *reinterpret_cast<const double2*>(w + i0);
     }
+    if (only_fallback && !fb_flag) return;
+    if (bound && stop_flag != 0 && (int64_t)(stop_flag - 1) < kstep) return;      // run_is_stopped
+    if (bound && fb_flag) return;
     const double m = bound ? b.scal[f].off_slot[parity] : acc_read_max_wave(acc, parity);
 
     llpf_u128 S = {0, 0}, E2 = {0, 0};

@@ -452,16 +452,21 @@ __global__ __launch_bounds__(BLOCK) void k_resample(BankDev b, ResArgs a) {
     }
     const int f = blockIdx.y;
     const int tile = blockIdx.x;
-    if (SRC == SRC_FILTER && run_is_stopped(b, a.k)) return;
-    if (SRC == SRC_FILTER && (a.only_fallback ? !b.scal[f].fallback : (b.scal[f].fallback != 0))) return;
+    // the stop / fallback flags are requested with the head's loads and tested behind its barrier (res_head, defer_skip):
+    // tested first they were two memory round trips before anything else was asked for; the tile's quanta are requested last
+    const uint32_t stop_flag = (SRC == SRC_FILTER) ? *b.bank_flag : 0u;
+    const int fb_flag = (SRC == SRC_FILTER) ? b.scal[f].fallback : 0;
     const uint64_t* __restrict__ qsrc = b.quanta + (size_t)f * b.Ns;
     const int64_t ib = (int64_t)tile * TILE + (int64_t)threadIdx.x * NORM_IPT;
     ulonglong2 qv[NORM_IPT / 2];
-    if (a.mode & RES_RESAMPLE) {
+    auto load_quanta = [&]() {
+        if (a.mode & RES_RESAMPLE) {
 #pragma unroll
-        for (int k = 0; k < NORM_IPT / 2; ++k) qv[k] = *reinterpret_cast<const ulonglong2*>(qsrc + ib + 2 * k);
-    }
-    const ResHead h = res_head<SRC>(b, a, f, tile, sh);
+            for (int k = 0; k < NORM_IPT / 2; ++k) qv[k] = *reinterpret_cast<const ulonglong2*>(qsrc + ib + 2 * k);
+        }
+    };
+    const ResHead h = res_head<SRC>(b, a, f, tile, sh, SRC == SRC_FILTER, stop_flag, fb_flag, nullptr, load_quanta);
+    if (h.status == RES_STATUS_SKIP) return;
     if (!(a.mode & RES_RESAMPLE)) return;
     if (h.status) return;
     if (!a.force && !h.dr) return;

@@ -13,21 +13,31 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
     const int f = blockIdx.y;
     const ModelD* md = models + f;
     const FilterScal* sc = scal + f;
-    if (run_is_stopped(b, a.k)) return;
-    if (a.only_fallback ? !sc->fallback : (sc->fallback != 0)) return;   // redo launches take the flagged filters, all others skip them
+    // Everything the prologue reads is REQUESTED first and tested afterwards: tested one by one (stop flag, fallback flag, tables,
+    // scalars) each was a memory round trip of its own at the start of every block.
+    const uint32_t stop_flag = *b.bank_flag;
+    const int fb_flag = sc->fallback;
     // the generator's tables in LDS (one 16-byte LDS read per lookup instead of two global loads through the GOT)
     constexpr bool LTAB = !Model::RB && MODE != MODE_WEIGHT && MODE != MODE_AUX;
     __shared__ __attribute__((aligned(16))) double sh_rng_lg[LTAB ? 2 * LLPF_RNG_LG_ENTRIES : 2], sh_rng_sc[LTAB ? 2 * LLPF_RNG_SC_ENTRIES : 2];
+    double rt0 = 0.0, rt1 = 0.0;
     if (LTAB) {
         const int t = (int)threadIdx.x;
-        if (t < LLPF_RNG_SC_ENTRIES) { sh_rng_sc[2 * t] = LLPF_SIN64[t]; sh_rng_sc[2 * t + 1] = LLPF_COS64[t]; }
-        else if (t < LLPF_RNG_SC_ENTRIES + LLPF_RNG_LG_ENTRIES) { sh_rng_lg[2 * (t - LLPF_RNG_SC_ENTRIES)] = LLPF_LOG_INVC[t - LLPF_RNG_SC_ENTRIES]; sh_rng_lg[2 * (t - LLPF_RNG_SC_ENTRIES) + 1] = LLPF_LOG_LNC[t - LLPF_RNG_SC_ENTRIES]; }
-        __syncthreads();
+        if (t < LLPF_RNG_SC_ENTRIES) { rt0 = LLPF_SIN64[t]; rt1 = LLPF_COS64[t]; }
+        else if (t < LLPF_RNG_SC_ENTRIES + LLPF_RNG_LG_ENTRIES) { rt0 = LLPF_LOG_INVC[t - LLPF_RNG_SC_ENTRIES]; rt1 = LLPF_LOG_LNC[t - LLPF_RNG_SC_ENTRIES]; }
     }
     const int do_res = (MODE != MODE_WEIGHT && MODE != MODE_AUX) ? sc->do_resample : 0;
     const int uniform = sc->uniform, pend = sc->norm_pending;
     const double m = sc->m, l = sc->l, wconst = sc->wconst;
     const uint32_t k0 = sc->k0, k1 = sc->k1, sb = sc->step_base;
+    if (stop_flag != 0 && (int64_t)(stop_flag - 1) < a.k) return;          // run_is_stopped
+    if (a.only_fallback ? !fb_flag : (fb_flag != 0)) return;   // redo launches take the flagged filters, all others skip them
+    if (LTAB) {
+        const int t = (int)threadIdx.x;
+        if (t < LLPF_RNG_SC_ENTRIES) { sh_rng_sc[2 * t] = rt0; sh_rng_sc[2 * t + 1] = rt1; }
+        else if (t < LLPF_RNG_SC_ENTRIES + LLPF_RNG_LG_ENTRIES) { sh_rng_lg[2 * (t - LLPF_RNG_SC_ENTRIES)] = rt0; sh_rng_lg[2 * (t - LLPF_RNG_SC_ENTRIES) + 1] = rt1; }
+        __syncthreads();
+    }
     const int64_t Ns = b.Ns, N = b.N;
     const double* __restrict__ xc = b.xcur + (size_t)f * NX * Ns;
     double* __restrict__ xn = b.xnext + (size_t)f * NX * Ns;
