@@ -1,4 +1,5 @@
 #!/bin/bash
+# (needs an engine built with `make -C lowlevelparticlefilters.jl_amd/csrc DEVTOOLS=1`: the stamps are not in production builds)
 # per-phase wall-clock stamps of ONE fused launch (timestep $1, default 500) of the default bench workload
 K=${1:-500}
 mkdir -p gpurun_out
