@@ -30,6 +30,12 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
     const int uniform = sc->uniform, pend = sc->norm_pending;
     const double m = sc->m, l = sc->l, wconst = sc->wconst;
     const uint32_t k0 = sc->k0, k1 = sc->k1, sb = sc->step_base;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // one batch: every scalar above is wanted HERE, so their loads are issued back to back and waited for once (left to the
+    // compiler they trickle in behind the branches below, a scalar-cache round trip each)
+    asm volatile("" : : "s"(stop_flag), "s"(fb_flag), "s"(do_res), "s"(uniform), "s"(pend), "s"(m), "s"(l), "s"(wconst), "s"(k0), "s"(k1), "s"(sb),
+                 "s"(b.Ns), "s"(b.N), "s"(a.k), "s"(a.only_fallback), "s"(a.has_y), "s"(a.step));
+#endif
     if (stop_flag != 0 && (int64_t)(stop_flag - 1) < a.k) return;          // run_is_stopped
     if (a.only_fallback ? !fb_flag : (fb_flag != 0)) return;   // redo launches take the flagged filters, all others skip them
     if (LTAB) {
