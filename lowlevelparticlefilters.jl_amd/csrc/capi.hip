@@ -472,6 +472,7 @@ int llpf_mbank_info(llpf_mbank* m, llpf_mbank_info_t* info) {
 }
 int llpf_mbank_local_devices(llpf_mbank* m, int32_t* devices) {
     NEEDF(m);
+    if (!devices) return fail(LLPF_ERR_ARG, "devices is NULL");
     for (size_t s = 0; s < m->shards.size(); ++s) devices[s] = m->shards[s]->device;
     return LLPF_OK;
 }

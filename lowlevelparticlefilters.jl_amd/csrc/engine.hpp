@@ -83,10 +83,12 @@ struct RBStep {
     double kfx[MAXD];          // kf.x as the reference leaves it in every particle when C == 0
 };
 
+enum { QTC_1A = 0, QTC_1A_SW, QTC_1B, QTC_1U, QTC_2A, QTC_2B, QTC_2U, QTC_3A, QTC_3U, QTC_4A, QTC_4U, QTC_TG, QTC_H, QTC_H2, QTC_H6, QTC_COUNT };
 struct ModelD {
     int32_t model_id, nx, nu, ny;
     double A[MAXD * MAXD], B[MAXD * MAXD], C[MAXD * MAXD];
     double qt[LLPF_QT_COUNT];
+    double qtc[QTC_COUNT];         // quad-tank: coefficients of the right-hand side and the RK4 step sizes, formed once on the host (host/densities.hpp)
     int32_t supersample, nxn;      // nxn: LLPF_MODEL_RB_LINEAR, number of nonlinear states (A = [Fn An; 0 Al], B = [Bn; Bl], C = [Gn Cl])
     int32_t rb_zeroC, rb_zeroAn;   // iszero(C), iszero(An)  (reference src/rbpf.jl:175,244)
     double Ts;

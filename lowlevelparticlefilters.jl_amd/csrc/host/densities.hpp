@@ -69,6 +69,32 @@ static int model_prepare(const llpf_model* m, ModelD* d) {
     memcpy(d->qt, m->qt, sizeof(d->qt));
     d->supersample = m->supersample;
     d->Ts = m->Ts;
+    {   // quad-tank: the particle-independent coefficients, divided once here instead of by every thread of every launch — the
+        // same IEEE operations in the order QuadTank::prepare used to evaluate them (examples/example_quadtank.jl:19-27)
+        const double* q = m->qt;
+        const double k1 = q[LLPF_QT_K1], k2 = q[LLPF_QT_K2], g = q[LLPF_QT_G];
+        const double A1 = q[LLPF_QT_A1], A2 = q[LLPF_QT_A2], A3 = q[LLPF_QT_A3], A4 = q[LLPF_QT_A4];
+        const double a1 = q[LLPF_QT_a1], a2 = q[LLPF_QT_a2], a3 = q[LLPF_QT_a3], a4 = q[LLPF_QT_a4];
+        const double g1 = q[LLPF_QT_GAMMA1], g2 = q[LLPF_QT_GAMMA2];
+        double* c = d->qtc;
+        c[QTC_1A] = (-a1) / A1;
+        c[QTC_1A_SW] = (-(a1 * q[LLPF_QT_A1FACTOR])) / A1;
+        c[QTC_1B] = a3 / A1;
+        c[QTC_1U] = (g1 * k1) / A1;
+        c[QTC_2A] = (-a2) / A2;
+        c[QTC_2B] = a4 / A2;
+        c[QTC_2U] = (g2 * k2) / A2;
+        c[QTC_3A] = (-a3) / A3;
+        c[QTC_3U] = ((1.0 - g2) * k2) / A3;
+        c[QTC_4A] = (-a4) / A4;
+        c[QTC_4U] = ((1.0 - g1) * k1) / A4;
+        c[QTC_TG] = 2.0 * g;
+        const int ss = m->supersample < 1 ? 1 : m->supersample;
+        const double h = m->Ts / (double)ss;
+        c[QTC_H] = h;
+        c[QTC_H2] = h / 2.0;
+        c[QTC_H6] = h / 6.0;
+    }
     // the quad-tank right-hand side takes sqrt(max(x,0) + eps) with the special-case-free llpf_sqrt_pos
     if (m->model_id == LLPF_MODEL_QUADTANK_RK4 && !(m->qt[LLPF_QT_EPS] > 1e-200)) return -9;
     if (gauss_prepare(&m->dynamics_density, &d->df)) return -1;

@@ -14,6 +14,7 @@
 // same bits (tests/test_gpu_mbank.py).
 #include <dlfcn.h>
 
+#include <mutex>
 #include <thread>
 
 namespace rccl_dl {
@@ -33,11 +34,14 @@ struct Api {
     const char* (*GetErrorString)(result_t) = nullptr;
     std::string err, path;
 };
-static Api* api() {
+static void load(Api& a);
+static Api* api() {            // loaded once, also when two host threads build their first multi-GPU bank at the same time
     static Api a;
-    static bool tried = false;
-    if (tried) return &a;
-    tried = true;
+    static std::once_flag once;
+    std::call_once(once, [] { load(a); });
+    return &a;
+}
+static void load(Api& a) {
     // RCCL must sit on the SAME HIP runtime as this library: streams and device pointers of one libamdhip64 mean nothing to
     // another, and a process can hold two of them (PyTorch wheels bundle their own next to their own librccl).  So: find the
     // file the runtime this library is bound to was loaded from, and take the librccl of that directory; only then the names.
@@ -55,13 +59,12 @@ static Api* api() {
     names.push_back("librccl.so.1");
     names.push_back("librccl.so");
     for (const std::string& n : names) { a.handle = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND); if (a.handle) { a.path = n; break; } }
-    if (!a.handle) { a.err = std::string("librccl not loadable: ") + dlerror(); return &a; }
-#define LLPF_SYM(field, name) a.field = reinterpret_cast<decltype(a.field)>(dlsym(a.handle, name)); if (!a.field) { a.err = std::string("librccl lacks ") + name; a.handle = nullptr; return &a; }
+    if (!a.handle) { a.err = std::string("librccl not loadable: ") + dlerror(); return; }
+#define LLPF_SYM(field, name) a.field = reinterpret_cast<decltype(a.field)>(dlsym(a.handle, name)); if (!a.field) { a.err = std::string("librccl lacks ") + name; a.handle = nullptr; return; }
     LLPF_SYM(GetUniqueId, "ncclGetUniqueId") LLPF_SYM(CommInitRank, "ncclCommInitRank") LLPF_SYM(CommInitAll, "ncclCommInitAll")
     LLPF_SYM(CommDestroy, "ncclCommDestroy") LLPF_SYM(AllReduce, "ncclAllReduce") LLPF_SYM(GroupStart, "ncclGroupStart")
     LLPF_SYM(GroupEnd, "ncclGroupEnd") LLPF_SYM(GetErrorString, "ncclGetErrorString")
 #undef LLPF_SYM
-    return &a;
 }
 }  // namespace rccl_dl
 

@@ -30,12 +30,13 @@ namespace llpf {
 #include "kernels/accum.hpp"
 #include "kernels/step.hpp"
 #include "kernels/rbfull.hpp"
-#include "kernels/rbfull_mfma.hpp"
 #include "kernels/norm.hpp"
 #include "kernels/resample.hpp"
 #include "kernels/residual.hpp"
 #include "kernels/resprop.hpp"
-#include "kernels/persist.hpp"
+#ifdef LLPF_DEVTOOLS
+#include "kernels/persist.hpp"      // experiment kept for reference: measured slower than the graph of per-timestep launches
+#endif
 #include "kernels/access.hpp"
 #include "kernels/smooth.hpp"
 #include "kernels/selftest.hpp"
@@ -68,16 +69,6 @@ static hipError_t launch_rbfull_t(const BankDev& b, int mode, const StepArgs& a,
 // BankDev::pad0 carries the shape of this model: nxl | fn_kind << 8
 static hipError_t launch_rbfull(const BankDev& b, int mode, const StepArgs& a, hipStream_t s) {
     const int nl = b.pad0 & 0xff, fk = (b.pad0 >> 8) & 0xff;
-    // BASELINE config C5's shape, predict! + correct! with a measurement: the matrix-unit form (kernels/rbfull_mfma.hpp), opt-in
-    // with LLPF_RBFULL_MFMA=1 — bit-identical, but measured SLOWER than the register form on the MI355X (150 vs 95 us at N = 2e5:
-    // its LDS hand-over between thread-per-particle and matrix-layout phases leaves 3 waves per CU)
-    const char* mf_env = getenv("LLPF_RBFULL_MFMA");
-    if (mode == MODE_PROP_WEIGHT && a.has_y && b.nx == 4 && nl == 8 && b.ny == 2 && mf_env && atoi(mf_env) != 0) {
-        dim3 g((unsigned)(b.Ns / 64), (unsigned)b.F, 1);
-        if (fk == 1) hipLaunchKernelGGL((k_rbfull_mfma<QuadTank<4, 2>>), g, dim3(64), 0, s, b, b.models, b.scal, a);
-        else hipLaunchKernelGGL((k_rbfull_mfma<LinGauss<4, 2>>), g, dim3(64), 0, s, b, b.models, b.scal, a);
-        return hipGetLastError();
-    }
     if (fk == 1 && b.nx == 4 && nl == 8 && b.ny == 2) return launch_rbfull_t<QuadTank<4, 2>, 4, 8, 2>(b, mode, a, s);
     if (fk == 0 && b.nx == 4 && nl == 8 && b.ny == 2) return launch_rbfull_t<LinGauss<4, 2>, 4, 8, 2>(b, mode, a, s);
     if (fk == 0 && b.nx == 2 && nl == 2 && b.ny == 2) return launch_rbfull_t<LinGauss<2, 2>, 2, 2, 2>(b, mode, a, s);
@@ -284,6 +275,8 @@ hipError_t launch_resprop(const BankDev& b, const ResArgs& a0, const StepArgs& s
     ResArgs a = a0;
     a.K = llpf_qbits(b.N);
     a.mode = RES_FINALIZE | RES_RESAMPLE;
+    // a run-time compiled model has no fused kernel: only the auxiliary second half (which propagates nothing: NoModel) may come here
+    if (b.model_id >= LLPF_MODEL_USER_BASE && !st.aux) return hipErrorInvalidValue;
     if (b.model_id == LLPF_MODEL_QUADTANK_RK4) return launch_resprop_t<QuadTank<4, 2>, 4, 2>(b, a, st, weight, s);
     if (b.model_id == LLPF_MODEL_RB_LINEAR) {
         switch (b.nx) {
@@ -302,6 +295,7 @@ hipError_t launch_resprop(const BankDev& b, const ResArgs& a0, const StepArgs& s
     }
 }
 
+#ifdef LLPF_DEVTOOLS
 // ---- persistent multi-step launch (kernels/persist.hpp): linear-Gaussian single filters whose tiles are all co-resident ----
 template <class Model, int NX, int NY>
 static hipError_t launch_persist_t(const BankDev& b, const PersistArgsHost& h, hipStream_t s, int* capacity) {
@@ -312,7 +306,7 @@ static hipError_t launch_persist_t(const BankDev& b, const PersistArgsHost& h, h
         if (e != hipSuccess) return e;
         hipDeviceProp_t prop;
         if ((e = hipGetDevice(&dev)) != hipSuccess || (e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return e;
-        *capacity = per_cu * prop.multiProcessorCount;
+        *capacity = std::min(per_cu * prop.multiProcessorCount, GQ_GROUPS * 32);   // the two-level tile prefix holds GQ_GROUPS groups of 32 tiles
         return hipSuccess;
     }
     PersistArgs pa;
@@ -350,6 +344,11 @@ static hipError_t launch_persist_any(const BankDev& b, const PersistArgsHost& h,
 hipError_t launch_persist(const BankDev& b, const PersistArgsHost& h, hipStream_t s) { return launch_persist_any(b, h, s, nullptr); }
 hipError_t persist_capacity(const BankDev& b, int* blocks) { PersistArgsHost h{}; return launch_persist_any(b, h, nullptr, blocks); }
 int persist_bar_words() { return BAR_WORDS + 2 * GQ_WORDS64; }
+#else   // product build: the persistent form is not compiled in (it measured slower; DEVTOOLS=1 builds it for experiments)
+hipError_t launch_persist(const BankDev&, const PersistArgsHost&, hipStream_t) { return hipErrorNotSupported; }
+hipError_t persist_capacity(const BankDev&, int* blocks) { *blocks = 0; return hipSuccess; }
+int persist_bar_words() { return 64; }
+#endif
 
 template <class Model, int NX, int NY>
 static hipError_t launch_smooth_fx_t(const BankDev& b, const SmoothArgs& a, hipStream_t s) {
@@ -367,6 +366,7 @@ static hipError_t launch_smooth_fx_ny(const BankDev& b, const SmoothArgs& a, hip
     }
 }
 hipError_t launch_smooth_fx(const BankDev& b, const SmoothArgs& a, hipStream_t s) {
+    if (b.model_id >= LLPF_MODEL_USER_BASE) return hipErrorInvalidValue;     // no smoother kernel is compiled for user models
     if (b.model_id == LLPF_MODEL_QUADTANK_RK4) return launch_smooth_fx_t<QuadTank<4, 2>, 4, 2>(b, a, s);
     switch (b.nx) {
         case 1: return launch_smooth_fx_ny<1>(b, a, s);

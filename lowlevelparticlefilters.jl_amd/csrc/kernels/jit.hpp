@@ -17,6 +17,7 @@
 
 struct JitModel {
     int nx = 0, ny = 0;
+    std::string src;                           // the snippet: a second llpf_model_compile of the same (source, nx, ny) returns the same id
     std::vector<char> code;
     std::string name[4];                       // lowered names of k_step<UserModel, nx, ny, MODE, STEP_PPT>, MODE = 0..3
     struct PerDevice { hipModule_t mod = nullptr; hipFunction_t fn[4] = {nullptr, nullptr, nullptr, nullptr}; };
@@ -27,7 +28,14 @@ static std::vector<JitModel*> g_jit_models;
 
 int jit_compile_user_model(const char* device_src, int nx, int ny, std::string& err) {
     if (!device_src) { err = "null source"; return -1; }
-    if (nx < 1 || nx > MAXD || ny < 1 || ny > MAXD) { err = "nx, ny must be in 1..8"; return -1; }
+    // the kernels around the compiled k_step (k_init, k_norm with the weighted mean, k_resample, the auxiliary second half) are
+    // precompiled for 1..4 state and measurement dimensions
+    if (nx < 1 || nx > 4 || ny < 1 || ny > 4) { err = "user models: nx and ny must be in 1..4"; return -1; }
+    {   // parameter sweeps and PMMH loops rebuild filters with the same snippet: compile once
+        std::lock_guard<std::mutex> lk(g_jit_mutex);
+        for (size_t k = 0; k < g_jit_models.size(); ++k)
+            if (g_jit_models[k]->nx == nx && g_jit_models[k]->ny == ny && g_jit_models[k]->src == device_src) return LLPF_MODEL_USER_BASE + (int)k;
+    }
     std::string src(LLPF_JIT_PRELUDE);
     src += "\nnamespace llpf {\n";
     src += device_src;
@@ -56,7 +64,7 @@ int jit_compile_user_model(const char* device_src, int nx, int ny, std::string& 
         return -1;
     }
     JitModel* jm = new JitModel();
-    jm->nx = nx; jm->ny = ny;
+    jm->nx = nx; jm->ny = ny; jm->src = device_src;
     size_t sz = 0;
     hiprtcGetCodeSize(prog, &sz);
     jm->code.resize(sz);

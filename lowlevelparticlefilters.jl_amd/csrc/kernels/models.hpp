@@ -249,33 +249,23 @@ struct QuadTank {   // reference examples/example_quadtank.jl:8-35 with rk4 of s
     static_assert(NX == 4 && NY == 2, "quad-tank is 4 states / 2 outputs");
     // coefficients in the reference's evaluation order: (-a/A), (a/A), (gamma k / A)
     double c1a, c1a_sw, c1b, c1u, c2a, c2b, c2u, c3a, c3u, c4a, c4u;
-    double tg, eps, tsw, u0, u1, t0, Ts;
+    double tg, eps, tsw, u0, u1, t0, Ts, Ts2, Ts6;
     int ss;
     DEV void prepare(const ModelD* m, const double* __restrict__ u, double t) {
-        const double* q = m->qt;
-        const double k1 = q[LLPF_QT_K1], k2 = q[LLPF_QT_K2], g = q[LLPF_QT_G];
-        const double A1 = q[LLPF_QT_A1], A2 = q[LLPF_QT_A2], A3 = q[LLPF_QT_A3], A4 = q[LLPF_QT_A4];
-        const double a1 = q[LLPF_QT_a1], a2 = q[LLPF_QT_a2], a3 = q[LLPF_QT_a3], a4 = q[LLPF_QT_a4];
-        const double g1 = q[LLPF_QT_GAMMA1], g2 = q[LLPF_QT_GAMMA2];
-        c1a = (-a1) / A1;
-        c1a_sw = (-(a1 * q[LLPF_QT_A1FACTOR])) / A1;
-        c1b = a3 / A1;
-        c1u = (g1 * k1) / A1;
-        c2a = (-a2) / A2;
-        c2b = a4 / A2;
-        c2u = (g2 * k2) / A2;
-        c3a = (-a3) / A3;
-        c3u = ((1.0 - g2) * k2) / A3;
-        c4a = (-a4) / A4;
-        c4u = ((1.0 - g1) * k1) / A4;
-        tg = 2.0 * g;
-        eps = q[LLPF_QT_EPS];
-        tsw = q[LLPF_QT_TSWITCH];
+        // the eleven quotients (-a/A, a/A, gamma k / A) and the step sizes come from the host (ModelD::qtc, host/densities.hpp):
+        // an fp64 division is a ~30-instruction expansion, and these were particle-independent
+        const double* c = m->qtc;
+        c1a = c[QTC_1A]; c1a_sw = c[QTC_1A_SW]; c1b = c[QTC_1B]; c1u = c[QTC_1U];
+        c2a = c[QTC_2A]; c2b = c[QTC_2B]; c2u = c[QTC_2U];
+        c3a = c[QTC_3A]; c3u = c[QTC_3U]; c4a = c[QTC_4A]; c4u = c[QTC_4U];
+        tg = c[QTC_TG];
+        eps = m->qt[LLPF_QT_EPS];
+        tsw = m->qt[LLPF_QT_TSWITCH];
         u0 = u[0];
         u1 = u[1];
         t0 = t;
         ss = m->supersample < 1 ? 1 : m->supersample;
-        Ts = m->Ts / (double)ss;
+        Ts = c[QTC_H]; Ts2 = c[QTC_H2]; Ts6 = c[QTC_H6];
     }
     DEV void rhs(const double* h, double t, double* xd) const {
         double s[4];
@@ -298,16 +288,16 @@ struct QuadTank {   // reference examples/example_quadtank.jl:8-35 with rk4 of s
         for (int it = 0; it < ss; ++it) {
             rhs(x, t, f1);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) xt[i] = x[i] + (Ts / 2.0) * f1[i];
-            rhs(xt, t + Ts / 2.0, f2);
+            for (int i = 0; i < 4; ++i) xt[i] = x[i] + Ts2 * f1[i];
+            rhs(xt, t + Ts2, f2);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) xt[i] = x[i] + (Ts / 2.0) * f2[i];
-            rhs(xt, t + Ts / 2.0, f3);
+            for (int i = 0; i < 4; ++i) xt[i] = x[i] + Ts2 * f2[i];
+            rhs(xt, t + Ts2, f3);
 #pragma unroll
             for (int i = 0; i < 4; ++i) xt[i] = x[i] + Ts * f3[i];
             rhs(xt, t + Ts, f4);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) x[i] = x[i] + (Ts / 6.0) * (((f1[i] + 2.0 * f2[i]) + 2.0 * f3[i]) + f4[i]);
+            for (int i = 0; i < 4; ++i) x[i] = x[i] + Ts6 * (((f1[i] + 2.0 * f2[i]) + 2.0 * f3[i]) + f4[i]);
             t = t + Ts;
         }
 #pragma unroll

@@ -40,13 +40,17 @@ __global__ __launch_bounds__(RBF_BLOCK) __attribute__((amdgpu_waves_per_eu(NL >=
 
     const int64_t i = (int64_t)blockIdx.x * RBF_BLOCK + threadIdx.x;
     const int64_t src = do_res ? (int64_t)b.anc[(size_t)f * Ns + i] : i;
+    // one 32-bit byte offset per thread against uniform plane bases (48 planes: 64-bit addresses would hold 96 registers)
+    const uint32_t so = (uint32_t)src * 8u, io = (uint32_t)i * 8u;
+    auto ld = [&](int row, uint32_t off) { return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(xc + (size_t)row * Ns) + off); };
+    auto st = [&](int row, double v) { *reinterpret_cast<double*>(reinterpret_cast<char*>(xo + (size_t)row * Ns) + io) = v; };
     double xn[NN], xl[NL], R[NP];
 #pragma unroll
-    for (int d = 0; d < NN; ++d) xn[d] = xc[(size_t)d * Ns + src];
+    for (int d = 0; d < NN; ++d) xn[d] = ld(d, so);
 #pragma unroll
-    for (int d = 0; d < NL; ++d) xl[d] = xc[(size_t)(NN + d) * Ns + src];
+    for (int d = 0; d < NL; ++d) xl[d] = ld(NN + d, so);
 #pragma unroll
-    for (int d = 0; d < NP; ++d) R[d] = xc[(size_t)(NN + NL + d) * Ns + src];
+    for (int d = 0; d < NP; ++d) R[d] = ld(NN + NL + d, so);
 
     if (MODE != MODE_WEIGHT) {
         double fi[NN], xi[NN], nz[NN], xn1[NN], xl1[NL], R1[NP];
@@ -86,11 +90,11 @@ __global__ __launch_bounds__(RBF_BLOCK) __attribute__((amdgpu_waves_per_eu(NL >=
     }
     if (MODE != MODE_WEIGHT || a.has_y) {
 #pragma unroll
-        for (int d = 0; d < NN; ++d) xo[(size_t)d * Ns + i] = xn[d];
+        for (int d = 0; d < NN; ++d) st(d, xn[d]);
 #pragma unroll
-        for (int d = 0; d < NL; ++d) xo[(size_t)(NN + d) * Ns + i] = xl[d];
+        for (int d = 0; d < NL; ++d) st(NN + d, xl[d]);
 #pragma unroll
-        for (int d = 0; d < NP; ++d) xo[(size_t)(NN + NL + d) * Ns + i] = R[d];
+        for (int d = 0; d < NP; ++d) st(NN + NL + d, R[d]);
     }
     if (MODE != MODE_PROP) {
         const double r = wave_max(bmax);                        // the workgroup is one wave

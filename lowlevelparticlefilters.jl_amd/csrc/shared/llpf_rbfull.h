@@ -3,10 +3,9 @@
  * particle carries its own covariance R; LLPF_MODEL_RB_BILINEAR, BASELINE config C5).
  *
  * Shared by the HIP kernel (kernels/rbfull.hpp: one particle per thread, every loop below unrolls because the dimensions
- * are literal constants at the call site) and by the oracle, so that both run the same IEEE sequence.  The body
- * (llpf_rbfull_body.h) is a macro template over the square root / logarithm: this header instantiates it with the
- * deterministic device-order functions (prefix llpf_rbf_); the oracle instantiates it a second time with libm for its
- * reference order (prefix llpf_rbfr_).
+ * are literal constants at the call site) and by the oracle's DEVICE order, so that both run the same IEEE sequence.  The
+ * oracle's reference order does not use this file: it restates the reference's formulas literally (oracle/llpf_oracle.c,
+ * rbfr_predict / rbfr_correct), so the two orders check each other to rounding.
  *
  * The covariance is stored as its packed lower triangle, entry (r,c), c <= r, at r(r+1)/2 + c: 36 numbers for nxl = 8. */
 #ifndef LLPF_RBFULL_H
@@ -45,9 +44,27 @@ LLPF_HD int llpf_rbf_idx(int r, int c) { return r >= c ? r * (r + 1) / 2 + c : c
 #define RBF_(name) llpf_rbf_##name
 #define RBF_SQRT(x) llpf_sqrt(x)
 #define RBF_LOG(x) llpf_log(x)
+#if defined(__HIP_DEVICE_COMPILE__)
+/* Device: the parameters are read through the CONSTANT address space (scalar loads, whatever the compiler can or cannot prove
+ * about the pointer), and at a stage boundary the pointer re-emerges from an empty asm that also reads `dep`: loads through it
+ * can neither be hoisted above the point where `dep` is computed nor merged with earlier loads (llpf_rbfull_body.h, "Stages"). */
+typedef const __attribute__((address_space(4))) llpf_rbf_par* llpf_rbf_cptr;
+#define RBF_CPTR(p) ((llpf_rbf_cptr)(p))
+#define RBF_STAGE(ptr, dep) do { const double rbf_dep_ = (dep); asm volatile("" : "+s"(ptr) : "v"(rbf_dep_)); } while (0)
+/* no instruction may be scheduled across this point (keeps two panels of the time update from being live together) */
+#define RBF_FENCE(dep) __builtin_amdgcn_sched_barrier(0)
+#else
+typedef const llpf_rbf_par* llpf_rbf_cptr;
+#define RBF_CPTR(p) (p)
+#define RBF_STAGE(ptr, dep) ((void)0)
+#define RBF_FENCE(dep) ((void)0)
+#endif
 #include "llpf_rbfull_body.h"
 #undef RBF_
 #undef RBF_SQRT
 #undef RBF_LOG
+#undef RBF_STAGE
+#undef RBF_FENCE
+#undef RBF_CPTR
 
 #endif /* LLPF_RBFULL_H */

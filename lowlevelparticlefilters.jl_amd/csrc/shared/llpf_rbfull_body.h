@@ -1,172 +1,234 @@
-/* llpf_rbfull_body.h — macro template, included by llpf_rbfull.h (and once more by the oracle) with
+/* llpf_rbfull_body.h — macro template, included by llpf_rbfull.h with
  *   RBF_(name)   function-name prefix
  *   RBF_SQRT(x)  square root      RBF_LOG(x)  natural logarithm
- * All accumulations run over the summation index in increasing order with explicit fused multiply-adds. */
+ *   RBF_STAGE(ptr, dep)  device only: the parameter pointer becomes opaque to the compiler at this point and the point is
+ *                        tied to the value `dep` — see "Stages" below; nothing on the host.
+ * All accumulations run over the summation index in increasing order with explicit fused multiply-adds.
+ *
+ * The recursion in the form computed here (round 3).  The reference writes the time update of the linear substate as
+ *     Nt = An R An' + R1n ;  L = (Al R An') / Nt ;  R1 = Al R Al' + R1l - L Nt L' ;  xl1 = Al xl + Bl u + L (z - An xl)
+ * (src/rbpf.jl:206-221).  With Nt = Lc Lc' and V = (An R)' Lc^-T this is, term by term,
+ *     L Nt L' = Al (V V') Al'          L d = Al V (Lc^-1 d)
+ * so that
+ *     R~  = R - V V'                   x~l = xl + V (Lc^-1 (z - An xl))         "condition on the pseudo-measurement z"
+ *     R1  = Al R~ Al' + R1l            xl1 = Al x~l + Bl u                      "ordinary Kalman time update"
+ * — the same quantities (Schoen, Gustafsson, Nordlund 2005, eq. 22-24 group them this way), 250 multiply-adds fewer per particle
+ * than forming Al R An' and W W', and — the reason for the change — every step works IN PLACE on one covariance: the live set
+ * of a particle is R + one 4 x 8 panel (~90 doubles) instead of R, R1, An R, W and An at once (~200), which is what let the
+ * kernel keep one wave per SIMD only (kernels/rbfull.hpp).  The reference-order oracle keeps the reference's literal formulas
+ * (oracle/llpf_oracle.c: rbfr_*), so the two forms check each other to rounding.
+ *
+ * Stages.  The constant matrices are uniform: on the device they are scalar loads into SGPRs, of which a wave has ~100 — 50
+ * doubles, against ~330 here.  Left alone the compiler hoists all of those loads to the top of the (fully unrolled) body and
+ * spills the SGPRs into VGPR lanes: a third of the old kernel's instructions were v_readlane / v_writelane.  RBF_STAGE pins the
+ * loads of a stage behind the value that ends the stage before it, and the stages are cut so that none needs more than ~40
+ * doubles of constants: a row of An(xn) at a time (40), the upper half of Al, then the lower half (32 each). */
 
-/* An(xn) = An[0] + sum_k xn[k] An[1+k]                       (pf.An as a function of the state, src/rbpf.jl:208) */
+/* row r of An(xn) = An[0] + sum_k xn[k] An[1+k]              (pf.An as a function of the state, src/rbpf.jl:208) */
+LLPF_HD void RBF_(coupling_row)(llpf_rbf_cptr p, const int nn, const int nl, const int r, const double* xn, double* a) {
+    LLPF_UNROLL
+    for (int c = 0; c < nl; ++c) a[c] = p->An[0][r * nl + c];
+    LLPF_UNROLL
+    for (int k = 0; k < nn; ++k) {
+        LLPF_UNROLL
+        for (int c = 0; c < nl; ++c) a[c] = llpf_fma(xn[k], p->An[1 + k][r * nl + c], a[c]);
+    }
+}
 LLPF_HD void RBF_(coupling)(const llpf_rbf_par* p, const int nn, const int nl, const double* xn, double* An) {
     LLPF_UNROLL
-    for (int r = 0; r < nn; ++r) {
-        LLPF_UNROLL
-        for (int c = 0; c < nl; ++c) {
-            double a = p->An[0][r * nl + c];
-            LLPF_UNROLL
-            for (int k = 0; k < nn; ++k) a = llpf_fma(xn[k], p->An[1 + k][r * nl + c], a);
-            An[r * nl + c] = a;
-        }
-    }
+    for (int r = 0; r < nn; ++r) RBF_(coupling_row)(RBF_CPTR(p), nn, nl, r, xn, An + r * nl);
 }
 
 /* Loop nests below run the inner (summation) index OUTERMOST over a set of independent accumulators: every accumulator
  * still sums its products in increasing index order (so results do not depend on the nesting), but consecutive
- * instructions are independent — a wave that runs alone on its SIMD (440 registers) otherwise waits out the latency of
- * each dependent fma. */
+ * instructions are independent. */
 
-/* Time update of one particle — src/rbpf.jl:206-221 (An != 0 branch, !singleR):
- *   Nt = An R An' + R1n ; L = (Al R An') / Nt ; R1 = Al R Al' + R1l - L Nt L'
- *   Axl = An xl ; z = Axl + nz ; xn1 = fi + z ; xl1 = Al xl + Bl u + L (z - Axl)
- * fi = f_n(xn, u, p, t) and nz ~ R1n come from the caller.  With Nt = Lc Lc' (Cholesky, reciprocal diagonal) the gain
- * is never formed: W = (Al R An') Lc^-T gives L Nt L' = W W' and L d = W (Lc^-1 d) — the same quantities as the
- * reference's generic `/`, 200 multiply-adds fewer per particle.  (Al R An') is taken as Al (An R)'.
- * R, R1: packed lower triangles (may not alias). */
+/* rows [r0, r1) of M = Al X for a symmetric X held as a packed lower triangle */
+#define RBF_PANEL(M, r0, r1)                                                                                         \
+    LLPF_UNROLL                                                                                                      \
+    for (int r = (r0); r < (r1); ++r) {                                                                              \
+        LLPF_UNROLL                                                                                                  \
+        for (int c = 0; c < nl; ++c) M[(r - (r0)) * nl + c] = pp->Al[r * nl] * Rt[llpf_rbf_idx(0, c)];              \
+    }                                                                                                                \
+    LLPF_UNROLL                                                                                                      \
+    for (int q = 1; q < nl; ++q) {                                                                                   \
+        LLPF_UNROLL                                                                                                  \
+        for (int r = (r0); r < (r1); ++r) {                                                                          \
+            LLPF_UNROLL                                                                                              \
+            for (int c = 0; c < nl; ++c)                                                                             \
+                M[(r - (r0)) * nl + c] = llpf_fma(pp->Al[r * nl + q], Rt[llpf_rbf_idx(q, c)], M[(r - (r0)) * nl + c]); \
+        }                                                                                                            \
+    }
+/* rows [r0, r1) of Al x~l + Bl u */
+#define RBF_MEAN(r0, r1)                                                                                             \
+    LLPF_UNROLL                                                                                                      \
+    for (int r = (r0); r < (r1); ++r) xl1[r] = pp->Al[r * nl] * xt[0];                                               \
+    LLPF_UNROLL                                                                                                      \
+    for (int c = 1; c < nl; ++c) {                                                                                   \
+        LLPF_UNROLL                                                                                                  \
+        for (int r = (r0); r < (r1); ++r) xl1[r] = llpf_fma(pp->Al[r * nl + c], xt[c], xl1[r]);                      \
+    }                                                                                                                \
+    if (nu > 0) {                                                                                                    \
+        LLPF_UNROLL                                                                                                  \
+        for (int r = (r0); r < (r1); ++r) {                                                                          \
+            double b2 = pp->Bl[r * nu] * u[0];                                                                       \
+            for (int c = 1; c < nu; ++c) b2 = llpf_fma(pp->Bl[r * nu + c], u[c], b2);                                \
+            xl1[r] = xl1[r] + b2;                                                                                    \
+        }                                                                                                            \
+    }
+
+/* Time update of one particle — src/rbpf.jl:206-221 (An != 0 branch, !singleR), in the form of the header comment.
+ * fi = f_n(xn, u, p, t) and nz ~ R1n come from the caller.  R, R1: packed lower triangles (may alias: R is copied first). */
 LLPF_HD void RBF_(predict)(const llpf_rbf_par* p, const int nn, const int nl, const int nu, const double* xn,
                            const double* xl, const double* R, const double* u, const double* fi, const double* nz,
                            double* xn1, double* xl1, double* R1) {
-    double AnR[LLPF_RBF_MAXN * LLPF_RBF_MAXL];
-    double Lc[LLPF_RBF_MAXN * LLPF_RBF_MAXN], invd[LLPF_RBF_MAXN], v[LLPF_RBF_MAXN];
-    double W[LLPF_RBF_MAXL * LLPF_RBF_MAXN];
-    {
-        double An[LLPF_RBF_MAXN * LLPF_RBF_MAXL], Nt[LLPF_RBF_MAXN * LLPF_RBF_MAXN], dz[LLPF_RBF_MAXN], ax[LLPF_RBF_MAXN];
-        RBF_(coupling)(p, nn, nl, xn, An);
+    llpf_rbf_cptr pp = RBF_CPTR(p);
+    double Rt[LLPF_RBF_NP(LLPF_RBF_MAXL)];                       /* R, then R~ */
+    double AnR[LLPF_RBF_MAXN * LLPF_RBF_MAXL];                   /* An R; column c becomes row c of V */
+    double Nt[LLPF_RBF_MAXN * LLPF_RBF_MAXN], Lc[LLPF_RBF_MAXN * LLPF_RBF_MAXN], invd[LLPF_RBF_MAXN];
+    double ax[LLPF_RBF_MAXN], v[LLPF_RBF_MAXN], xt[LLPF_RBF_MAXL];
+    const int np = LLPF_RBF_NP(nl);
+    LLPF_UNROLL
+    for (int d = 0; d < np; ++d) Rt[d] = R[d];
+    LLPF_UNROLL
+    for (int r = 0; r < nn; ++r) {                              /* one row of An(xn) at a time */
+        double a[LLPF_RBF_MAXL];
+        RBF_STAGE(pp, r == 0 ? Rt[0] : Nt[(r - 1) * nn + (r - 1)]);
+        RBF_(coupling_row)(pp, nn, nl, r, xn, a);
+        ax[r] = a[0] * xl[0];                                    /* (An xl)[r] */
         LLPF_UNROLL
-        for (int r = 0; r < nn; ++r) ax[r] = An[r * nl] * xl[0];   /* z = An xl + nz ; xn1 = fi + z ; dz = z - An xl */
+        for (int c = 1; c < nl; ++c) ax[r] = llpf_fma(a[c], xl[c], ax[r]);
         LLPF_UNROLL
-        for (int c = 1; c < nl; ++c) {
-            LLPF_UNROLL
-            for (int r = 0; r < nn; ++r) ax[r] = llpf_fma(An[r * nl + c], xl[c], ax[r]);
-        }
-        LLPF_UNROLL
-        for (int r = 0; r < nn; ++r) {
-            const double z = ax[r] + nz[r];
-            xn1[r] = fi[r] + z;
-            dz[r] = z - ax[r];
-        }
-        LLPF_UNROLL
-        for (int r = 0; r < nn; ++r) {                          /* AnR = An R */
-            LLPF_UNROLL
-            for (int c = 0; c < nl; ++c) AnR[r * nl + c] = An[r * nl] * R[llpf_rbf_idx(0, c)];
-        }
+        for (int c = 0; c < nl; ++c) AnR[r * nl + c] = a[0] * Rt[llpf_rbf_idx(0, c)];      /* (An R)[r, :] */
         LLPF_UNROLL
         for (int q = 1; q < nl; ++q) {
             LLPF_UNROLL
-            for (int r = 0; r < nn; ++r) {
-                LLPF_UNROLL
-                for (int c = 0; c < nl; ++c) AnR[r * nl + c] = llpf_fma(An[r * nl + q], R[llpf_rbf_idx(q, c)], AnR[r * nl + c]);
-            }
+            for (int c = 0; c < nl; ++c) AnR[r * nl + c] = llpf_fma(a[q], Rt[llpf_rbf_idx(q, c)], AnR[r * nl + c]);
         }
         LLPF_UNROLL
-        for (int i = 0; i < nn; ++i) {                          /* Nt = AnR An' + R1n (lower triangle) */
-            LLPF_UNROLL
-            for (int j = 0; j <= i; ++j) Nt[i * nn + j] = AnR[i * nl] * An[j * nl];
-        }
+        for (int j = 0; j <= r; ++j) Nt[r * nn + j] = a[0] * AnR[j * nl];                  /* Nt[r, j] = An[r, :] . (An R)[j, :] */
         LLPF_UNROLL
         for (int c = 1; c < nl; ++c) {
             LLPF_UNROLL
-            for (int i = 0; i < nn; ++i) {
-                LLPF_UNROLL
-                for (int j = 0; j <= i; ++j) Nt[i * nn + j] = llpf_fma(AnR[i * nl + c], An[j * nl + c], Nt[i * nn + j]);
-            }
+            for (int j = 0; j <= r; ++j) Nt[r * nn + j] = llpf_fma(a[c], AnR[j * nl + c], Nt[r * nn + j]);
         }
         LLPF_UNROLL
-        for (int i = 0; i < nn; ++i) {
-            LLPF_UNROLL
-            for (int j = 0; j <= i; ++j) Nt[i * nn + j] = Nt[i * nn + j] + p->R1n[i * nn + j];
-        }
-        LLPF_UNROLL
-        for (int i = 0; i < nn; ++i) {                          /* Nt = Lc Lc' */
-            LLPF_UNROLL
-            for (int j = 0; j <= i; ++j) {
-                double acc = Nt[i * nn + j];
-                LLPF_UNROLL
-                for (int k = 0; k < j; ++k) acc = llpf_fma(-Lc[i * nn + k], Lc[j * nn + k], acc);
-                if (i == j) {
-                    const double d = RBF_SQRT(acc);             /* not positive definite: NaN, caught as a degenerate weight */
-                    Lc[i * nn + i] = d;
-                    invd[i] = 1.0 / d;
-                } else {
-                    Lc[i * nn + j] = acc * invd[j];
-                }
-            }
-        }
-        LLPF_UNROLL
-        for (int i = 0; i < nn; ++i) {                          /* Lc v = dz */
-            double acc = dz[i];
-            LLPF_UNROLL
-            for (int q = 0; q < i; ++q) acc = llpf_fma(-Lc[i * nn + q], v[q], acc);
-            v[i] = acc * invd[i];
-        }
+        for (int j = 0; j <= r; ++j) Nt[r * nn + j] = Nt[r * nn + j] + pp->R1n[r * nn + j];
     }
-    {                                                           /* Al xl + Bl u for all rows */
+    LLPF_UNROLL
+    for (int i = 0; i < nn; ++i) {                              /* Nt = Lc Lc' */
         LLPF_UNROLL
-        for (int r = 0; r < nl; ++r) xl1[r] = p->Al[r * nl] * xl[0];
-        LLPF_UNROLL
-        for (int c = 1; c < nl; ++c) {
+        for (int j = 0; j <= i; ++j) {
+            double acc = Nt[i * nn + j];
             LLPF_UNROLL
-            for (int r = 0; r < nl; ++r) xl1[r] = llpf_fma(p->Al[r * nl + c], xl[c], xl1[r]);
-        }
-        if (nu > 0) {
-            LLPF_UNROLL
-            for (int r = 0; r < nl; ++r) {
-                double b2 = p->Bl[r * nu] * u[0];
-                for (int c = 1; c < nu; ++c) b2 = llpf_fma(p->Bl[r * nu + c], u[c], b2);
-                xl1[r] = xl1[r] + b2;
+            for (int k = 0; k < j; ++k) acc = llpf_fma(-Lc[i * nn + k], Lc[j * nn + k], acc);
+            if (i == j) {
+                const double d = RBF_SQRT(acc);                 /* not positive definite: NaN, caught as a degenerate weight */
+                Lc[i * nn + i] = d;
+                invd[i] = 1.0 / d;
+            } else {
+                Lc[i * nn + j] = acc * invd[j];
             }
         }
     }
     LLPF_UNROLL
-    for (int r = 0; r < nl; ++r) {
-        double ARr[LLPF_RBF_MAXL], g[LLPF_RBF_MAXN], acc[LLPF_RBF_MAXL];
+    for (int i = 0; i < nn; ++i) {                              /* z = An xl + nz ; xn1 = fi + z ; Lc v = z - An xl */
+        const double z = ax[i] + nz[i];
+        xn1[i] = fi[i] + z;
+        double acc = z - ax[i];
         LLPF_UNROLL
-        for (int i = 0; i < nn; ++i) g[i] = p->Al[r * nl] * AnR[i * nl];    /* row r of Al (An R)' */
+        for (int q = 0; q < i; ++q) acc = llpf_fma(-Lc[i * nn + q], v[q], acc);
+        v[i] = acc * invd[i];
+    }
+    LLPF_UNROLL
+    for (int i = 0; i < nn; ++i) {                              /* Lc V' = An R, in place: V[c, i] at AnR[i, c] */
         LLPF_UNROLL
-        for (int c = 0; c < nl; ++c) ARr[c] = p->Al[r * nl] * R[llpf_rbf_idx(0, c)];   /* row r of Al R */
-        LLPF_UNROLL
-        for (int q = 1; q < nl; ++q) {
+        for (int c = 0; c < nl; ++c) {
+            double acc = AnR[i * nl + c];
             LLPF_UNROLL
-            for (int i = 0; i < nn; ++i) g[i] = llpf_fma(p->Al[r * nl + q], AnR[i * nl + q], g[i]);
-            LLPF_UNROLL
-            for (int c = 0; c < nl; ++c) ARr[c] = llpf_fma(p->Al[r * nl + q], R[llpf_rbf_idx(q, c)], ARr[c]);
-        }
-        LLPF_UNROLL
-        for (int i = 0; i < nn; ++i) {                          /* Lc w = g : row r of W */
-            double a = g[i];
-            LLPF_UNROLL
-            for (int q = 0; q < i; ++q) a = llpf_fma(-Lc[i * nn + q], W[r * nn + q], a);
-            W[r * nn + i] = a * invd[i];
-        }
-        LLPF_UNROLL
-        for (int c = 0; c <= r; ++c) acc[c] = ARr[0] * p->Al[c * nl];       /* (Al R Al')[r, 0..r] */
-        LLPF_UNROLL
-        for (int q = 1; q < nl; ++q) {
-            LLPF_UNROLL
-            for (int c = 0; c <= r; ++c) acc[c] = llpf_fma(ARr[q], p->Al[c * nl + q], acc[c]);
-        }
-        LLPF_UNROLL
-        for (int c = 0; c <= r; ++c) {                          /* R1[r,c] = (Al R Al')[r,c] + R1l[r,c] - (W W')[r,c] */
-            const double a = acc[c] + p->R1l[llpf_rbf_idx(r, c)];
-            double s = W[r * nn] * W[c * nn];
-            LLPF_UNROLL
-            for (int j = 1; j < nn; ++j) s = llpf_fma(W[r * nn + j], W[c * nn + j], s);
-            R1[llpf_rbf_idx(r, c)] = a - s;
-        }
-        {                                                       /* xl1 = (Al xl + Bl u) + W (Lc^-1 dz) */
-            double s = W[r * nn] * v[0];
-            LLPF_UNROLL
-            for (int j = 1; j < nn; ++j) s = llpf_fma(W[r * nn + j], v[j], s);
-            xl1[r] = xl1[r] + s;
+            for (int q = 0; q < i; ++q) acc = llpf_fma(-Lc[i * nn + q], AnR[q * nl + c], acc);
+            AnR[i * nl + c] = acc * invd[i];
         }
     }
+    LLPF_UNROLL
+    for (int c = 0; c < nl; ++c) {                              /* x~l = xl + V v */
+        double s = AnR[c] * v[0];
+        LLPF_UNROLL
+        for (int j = 1; j < nn; ++j) s = llpf_fma(AnR[j * nl + c], v[j], s);
+        xt[c] = xl[c] + s;
+    }
+    LLPF_UNROLL
+    for (int j = 0; j < nn; ++j) {                              /* R~ = R - V V' */
+        LLPF_UNROLL
+        for (int r = 0; r < nl; ++r) {
+            LLPF_UNROLL
+            for (int c = 0; c <= r; ++c) Rt[llpf_rbf_idx(r, c)] = llpf_fma(-AnR[j * nl + r], AnR[j * nl + c], Rt[llpf_rbf_idx(r, c)]);
+        }
+    }
+    {                                                           /* xl1 = Al x~l + Bl u ; R1 = Al R~ Al' + R1l : by halves of Al */
+        const int ht = (nl + 1) / 2;
+        double M[((LLPF_RBF_MAXL + 1) / 2) * LLPF_RBF_MAXL];
+        RBF_STAGE(pp, Rt[np - 1]);
+        RBF_MEAN(0, ht)
+        if (ht < nl) {
+            RBF_STAGE(pp, xl1[ht - 1]);
+            RBF_MEAN(ht, nl)
+        }
+        RBF_STAGE(pp, xl1[nl - 1]);
+        RBF_PANEL(M, 0, ht)                                     /* M = Al[0:ht, :] R~ */
+        LLPF_UNROLL
+        for (int r = 0; r < ht; ++r) {                          /* upper-left block: R1[r, c] = M[r, :] . Al[c, :] */
+            LLPF_UNROLL
+            for (int c = 0; c <= r; ++c) R1[llpf_rbf_idx(r, c)] = M[r * nl] * pp->Al[c * nl];
+        }
+        LLPF_UNROLL
+        for (int q = 1; q < nl; ++q) {
+            LLPF_UNROLL
+            for (int r = 0; r < ht; ++r) {
+                LLPF_UNROLL
+                for (int c = 0; c <= r; ++c) R1[llpf_rbf_idx(r, c)] = llpf_fma(M[r * nl + q], pp->Al[c * nl + q], R1[llpf_rbf_idx(r, c)]);
+            }
+        }
+        if (ht < nl) {
+            RBF_STAGE(pp, R1[llpf_rbf_idx(ht - 1, ht - 1)]);
+            LLPF_UNROLL
+            for (int r = ht; r < nl; ++r) {                     /* lower-left block: R1[r, c] = Al[r, :] . M[c, :]  (R~ is symmetric) */
+                LLPF_UNROLL
+                for (int c = 0; c < ht; ++c) R1[llpf_rbf_idx(r, c)] = pp->Al[r * nl] * M[c * nl];
+            }
+            LLPF_UNROLL
+            for (int q = 1; q < nl; ++q) {
+                LLPF_UNROLL
+                for (int r = ht; r < nl; ++r) {
+                    LLPF_UNROLL
+                    for (int c = 0; c < ht; ++c) R1[llpf_rbf_idx(r, c)] = llpf_fma(pp->Al[r * nl + q], M[c * nl + q], R1[llpf_rbf_idx(r, c)]);
+                }
+            }
+            RBF_FENCE(R1[llpf_rbf_idx(nl - 1, ht - 1)]);
+            RBF_PANEL(M, ht, nl)                                /* M = Al[ht:nl, :] R~ */
+            RBF_FENCE(M[(nl - ht) * nl - 1]);
+            LLPF_UNROLL
+            for (int r = ht; r < nl; ++r) {                     /* lower-right block */
+                LLPF_UNROLL
+                for (int c = ht; c <= r; ++c) R1[llpf_rbf_idx(r, c)] = M[(r - ht) * nl] * pp->Al[c * nl];
+            }
+            LLPF_UNROLL
+            for (int q = 1; q < nl; ++q) {
+                LLPF_UNROLL
+                for (int r = ht; r < nl; ++r) {
+                    LLPF_UNROLL
+                    for (int c = ht; c <= r; ++c)
+                        R1[llpf_rbf_idx(r, c)] = llpf_fma(M[(r - ht) * nl + q], pp->Al[c * nl + q], R1[llpf_rbf_idx(r, c)]);
+                }
+            }
+        }
+        RBF_STAGE(pp, R1[np - 1]);
+        LLPF_UNROLL
+        for (int d = 0; d < np; ++d) R1[d] = R1[d] + pp->R1l[d];
+    }
 }
+#undef RBF_PANEL
+#undef RBF_MEAN
 
 /* Measurement update of one particle — src/rbpf.jl:259-263 -> correct!(kf, u, y - yn, p, t), src/filtering.jl:100-128:
  *   e = (y - yn) - C xl ; S = symmetrize(C R C') + R2 ; K = (R C') / chol(S) ; xl += K e ;
@@ -174,39 +236,41 @@ LLPF_HD void RBF_(predict)(const llpf_rbf_par* p, const int nn, const int nl, co
  * xl and R (packed lower triangle) are updated in place. */
 LLPF_HD double RBF_(correct)(const llpf_rbf_par* p, const int nl, const int ny, const double* y, const double* yn,
                              double* xl, double* R) {
+    llpf_rbf_cptr pp = RBF_CPTR(p);
     double e[LLPF_RBF_MAXY], CR[LLPF_RBF_MAXY * LLPF_RBF_MAXL], raw[LLPF_RBF_MAXY * LLPF_RBF_MAXY];
     double Lc[LLPF_RBF_MAXY * LLPF_RBF_MAXY], invd[LLPF_RBF_MAXY], K[LLPF_RBF_MAXL * LLPF_RBF_MAXY];
+    RBF_STAGE(pp, R[0]);
     LLPF_UNROLL
     for (int i = 0; i < ny; ++i) {
-        double a = p->Cl[i * nl] * xl[0];
+        double a = pp->Cl[i * nl] * xl[0];
         LLPF_UNROLL
-        for (int c = 1; c < nl; ++c) a = llpf_fma(p->Cl[i * nl + c], xl[c], a);
+        for (int c = 1; c < nl; ++c) a = llpf_fma(pp->Cl[i * nl + c], xl[c], a);
         e[i] = (y[i] - yn[i]) - a;
     }
     LLPF_UNROLL
     for (int i = 0; i < ny; ++i) {                              /* CR = C R  (its transpose is R C') */
         LLPF_UNROLL
-        for (int c = 0; c < nl; ++c) CR[i * nl + c] = p->Cl[i * nl] * R[llpf_rbf_idx(0, c)];
+        for (int c = 0; c < nl; ++c) CR[i * nl + c] = pp->Cl[i * nl] * R[llpf_rbf_idx(0, c)];
     }
     LLPF_UNROLL
     for (int q = 1; q < nl; ++q) {
         LLPF_UNROLL
         for (int i = 0; i < ny; ++i) {
             LLPF_UNROLL
-            for (int c = 0; c < nl; ++c) CR[i * nl + c] = llpf_fma(p->Cl[i * nl + q], R[llpf_rbf_idx(q, c)], CR[i * nl + c]);
+            for (int c = 0; c < nl; ++c) CR[i * nl + c] = llpf_fma(pp->Cl[i * nl + q], R[llpf_rbf_idx(q, c)], CR[i * nl + c]);
         }
     }
     LLPF_UNROLL
     for (int i = 0; i < ny; ++i) {
         LLPF_UNROLL
-        for (int j = 0; j < ny; ++j) raw[i * ny + j] = CR[i * nl] * p->Cl[j * nl];
+        for (int j = 0; j < ny; ++j) raw[i * ny + j] = CR[i * nl] * pp->Cl[j * nl];
     }
     LLPF_UNROLL
     for (int c = 1; c < nl; ++c) {
         LLPF_UNROLL
         for (int i = 0; i < ny; ++i) {
             LLPF_UNROLL
-            for (int j = 0; j < ny; ++j) raw[i * ny + j] = llpf_fma(CR[i * nl + c], p->Cl[j * nl + c], raw[i * ny + j]);
+            for (int j = 0; j < ny; ++j) raw[i * ny + j] = llpf_fma(CR[i * nl + c], pp->Cl[j * nl + c], raw[i * ny + j]);
         }
     }
     double ldet = 0.0;
@@ -214,7 +278,7 @@ LLPF_HD double RBF_(correct)(const llpf_rbf_par* p, const int nl, const int ny, 
     for (int i = 0; i < ny; ++i) {                              /* S = 0.5 (raw + raw') + R2 = Lc Lc' */
         LLPF_UNROLL
         for (int j = 0; j <= i; ++j) {
-            double acc = 0.5 * (raw[i * ny + j] + raw[j * ny + i]) + p->R2[i * ny + j];
+            double acc = 0.5 * (raw[i * ny + j] + raw[j * ny + i]) + pp->R2[i * ny + j];
             LLPF_UNROLL
             for (int k = 0; k < j; ++k) acc = llpf_fma(-Lc[i * ny + k], Lc[j * ny + k], acc);
             if (i == j) {
@@ -277,5 +341,5 @@ LLPF_HD double RBF_(correct)(const llpf_rbf_par* p, const int nl, const int ny, 
             R[llpf_rbf_idx(r, c)] = 0.5 * (a + b2);
         }
     }
-    return (p->c0y - ldet) - 0.5 * quad;
+    return (pp->c0y - ldet) - 0.5 * quad;
 }

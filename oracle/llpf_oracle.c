@@ -19,14 +19,7 @@
 
 #define MAXD LLPF_MAX_DIM
 #include "../lowlevelparticlefilters.jl_amd/csrc/shared/llpf_rbkf.h"
-#include "../lowlevelparticlefilters.jl_amd/csrc/shared/llpf_rbfull.h"     /* llpf_rbf_*: device order */
-#define RBF_(name) llpf_rbfr_##name                                           /* llpf_rbfr_*: the same recursion with libm */
-#define RBF_SQRT(x) sqrt(x)
-#define RBF_LOG(x) log(x)
-#include "../lowlevelparticlefilters.jl_amd/csrc/shared/llpf_rbfull_body.h"
-#undef RBF_
-#undef RBF_SQRT
-#undef RBF_LOG
+#include "../lowlevelparticlefilters.jl_amd/csrc/shared/llpf_rbfull.h"     /* llpf_rbf_*: device order only; the reference order is rbfr_* below */
 
 /* Optional OpenMP over the per-particle loops (weighting, propagation, noise, elementwise exp): an upper bound for
  * what the reference could reach with its `threads=true` option (src/PFtypes.jl:226-259 @threads :static); the
@@ -795,9 +788,163 @@ void orc_rb_get_R(const orc_filter* f, double* R) { for (int i = 0; i < f->rb.nl
 
 /* ------------------------------------------------------------------------------------------
  * RBPF whose An is a function of the nonlinear state — src/rbpf.jl:163-283 with singleR false (:176, :247): the
- * loops below are the reference's per-particle branches; the Kalman algebra is csrc/shared/llpf_rbfull_body.h
- * (shared with the HIP kernel; instantiated with libm for the reference order).
+ * loops below are the reference's per-particle branches.  Kalman algebra per particle:
+ *   device order    csrc/shared/llpf_rbfull_body.h (shared with the HIP kernel: fused multiply-adds, packed triangles,
+ *                   the time update regrouped as "condition on z, then propagate" — see that file's header);
+ *   reference order rbfr_predict / rbfr_correct below: the reference's formulas as written, on full matrices, plain
+ *                   multiply and add in increasing index order, libm — nothing shared with the device order, so the
+ *                   two check each other to rounding (tests/test_oracle_rbfull.py, tests/test_gpu_rbfull.py).
+ * The particle's covariance is STORED as its lower triangle in both orders (the reference keeps the full matrix, whose
+ * two triangles differ by rounding after `Al*R*Al' + R1l - L*Nt*L'`: acknowledged deviation, ~1e-17 relative).
  * ---------------------------------------------------------------------------------------- */
+#define RBM LLPF_RBF_MAXL
+/* C[m x n] = A[m x k] B[k x n], row-major with explicit leading dimensions; sums in increasing index order */
+static void rbfr_mm(const double* A, int lda, const double* B, int ldb, double* C, int ldc, int m, int k, int n) {
+    for (int i = 0; i < m; ++i) for (int j = 0; j < n; ++j) {
+        double acc = 0.0;
+        for (int q = 0; q < k; ++q) acc += A[i * lda + q] * B[q * ldb + j];
+        C[i * ldc + j] = acc;
+    }
+}
+/* C[m x n] = A[m x k] B'[k x n] with B given as n x k */
+static void rbfr_mmt(const double* A, int lda, const double* B, int ldb, double* C, int ldc, int m, int k, int n) {
+    for (int i = 0; i < m; ++i) for (int j = 0; j < n; ++j) {
+        double acc = 0.0;
+        for (int q = 0; q < k; ++q) acc += A[i * lda + q] * B[j * ldb + q];
+        C[i * ldc + j] = acc;
+    }
+}
+/* X = G / N for a square N (n x n), G m x n: Julia's generic right division, (N' \ G')' through an LU factorization
+ * with partial pivoting of N' (LinearAlgebra: `/` -> `\` -> lu for a dense square matrix that is not triangular). */
+static void rbfr_rdiv(const double* G, int m, const double* Nm, int n, double* X) {
+    double LU[LLPF_RBF_MAXN * LLPF_RBF_MAXN];
+    int piv[LLPF_RBF_MAXN];
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) LU[i * n + j] = Nm[j * n + i];     /* N' */
+    for (int k = 0; k < n; ++k) {
+        int pr = k;
+        double best = fabs(LU[k * n + k]);
+        for (int i = k + 1; i < n; ++i) if (fabs(LU[i * n + k]) > best) { best = fabs(LU[i * n + k]); pr = i; }
+        piv[k] = pr;
+        if (pr != k) for (int j = 0; j < n; ++j) { const double tmp = LU[k * n + j]; LU[k * n + j] = LU[pr * n + j]; LU[pr * n + j] = tmp; }
+        const double inv = 1.0 / LU[k * n + k];
+        for (int i = k + 1; i < n; ++i) LU[i * n + k] *= inv;
+        for (int i = k + 1; i < n; ++i) for (int j = k + 1; j < n; ++j) LU[i * n + j] -= LU[i * n + k] * LU[k * n + j];
+    }
+    for (int r = 0; r < m; ++r) {                               /* column r of G': solve N' x = G[r, :]' */
+        double b[LLPF_RBF_MAXN];
+        for (int i = 0; i < n; ++i) b[i] = G[r * n + i];
+        for (int k = 0; k < n; ++k) if (piv[k] != k) { const double tmp = b[k]; b[k] = b[piv[k]]; b[piv[k]] = tmp; }
+        for (int i = 0; i < n; ++i) for (int q = 0; q < i; ++q) b[i] -= LU[i * n + q] * b[q];
+        for (int i = n - 1; i >= 0; --i) { for (int q = i + 1; q < n; ++q) b[i] -= LU[i * n + q] * b[q]; b[i] /= LU[i * n + i]; }
+        for (int i = 0; i < n; ++i) X[r * n + i] = b[i];
+    }
+}
+static void rbfr_unpack(const double* Rp, int nl, double* R) {
+    for (int r = 0; r < nl; ++r) for (int c = 0; c < nl; ++c) R[r * RBM + c] = Rp[llpf_rbf_idx(r, c)];
+}
+/* predict!(pf::RBPF), the !zeroAn && !singleR branch as written — src/rbpf.jl:206-221 */
+static void rbfr_predict(const llpf_rbf_par* p, int nn, int nl, int nu, const double* xn, const double* xl, const double* Rp,
+                         const double* u, const double* fi, const double* nz, double* xn1, double* xl1, double* R1p) {
+    double R[RBM * RBM], An[LLPF_RBF_MAXN * RBM], AnR[LLPF_RBF_MAXN * RBM], Nt[LLPF_RBF_MAXN * LLPF_RBF_MAXN];
+    double AlR[RBM * RBM], G[RBM * LLPF_RBF_MAXN], L[RBM * LLPF_RBF_MAXN], LN[RBM * LLPF_RBF_MAXN], T1[RBM * RBM], T2[RBM * RBM];
+    rbfr_unpack(Rp, nl, R);
+    for (int r = 0; r < nn; ++r) for (int c = 0; c < nl; ++c) {   /* An = get_mat(pf.An, xi.xn, u, p, t), :208 */
+        double a = p->An[0][r * nl + c];
+        for (int k = 0; k < nn; ++k) a += xn[k] * p->An[1 + k][r * nl + c];
+        An[r * RBM + c] = a;
+    }
+    rbfr_mm(An, RBM, R, RBM, AnR, RBM, nn, nl, nl);             /* Nt = An*R*An' + pf.R1n.Σ, :209 */
+    rbfr_mmt(AnR, RBM, An, RBM, Nt, nn, nn, nl, nn);
+    for (int i = 0; i < nn * nn; ++i) Nt[i] += p->R1n[i];
+    rbfr_mm(p->Al, nl, R, RBM, AlR, RBM, nl, nl, nl);           /* L = Al*R*An' / Nt, :210 */
+    rbfr_mmt(AlR, RBM, An, RBM, G, nn, nl, nl, nn);
+    rbfr_rdiv(G, nl, Nt, nn, L);
+    rbfr_mmt(AlR, RBM, p->Al, nl, T1, RBM, nl, nl, nl);         /* R1 = Al*R*Al' + R1l - L*Nt*L', :211 */
+    rbfr_mm(L, nn, Nt, nn, LN, nn, nl, nn, nn);
+    rbfr_mmt(LN, nn, L, nn, T2, RBM, nl, nn, nl);
+    for (int r = 0; r < nl; ++r) for (int c = 0; c <= r; ++c)
+        R1p[llpf_rbf_idx(r, c)] = (T1[r * RBM + c] + p->R1l[llpf_rbf_idx(r, c)]) - T2[r * RBM + c];
+    double dz[LLPF_RBF_MAXN];
+    for (int r = 0; r < nn; ++r) {                              /* Axl = An*xi.xl ; z = Axl + rand(R1n) ; xn1 = fi + z, :213-215 */
+        double a = 0.0;
+        for (int c = 0; c < nl; ++c) a += An[r * RBM + c] * xl[c];
+        const double z = a + nz[r];
+        xn1[r] = fi[r] + z;
+        dz[r] = z - a;
+    }
+    for (int r = 0; r < nl; ++r) {                              /* xl1 = Al*xi.xl + Bl*u + L*(z - Axl), :217 */
+        double a = 0.0, b = 0.0, c2 = 0.0;
+        for (int c = 0; c < nl; ++c) a += p->Al[r * nl + c] * xl[c];
+        for (int c = 0; c < nu; ++c) b += p->Bl[r * nu + c] * u[c];
+        for (int c = 0; c < nn; ++c) c2 += L[r * nn + c] * dz[c];
+        xl1[r] = (a + b) + c2;
+    }
+}
+/* correct!(kf, u, y - yn, p, t) for one particle — src/rbpf.jl:259-263 -> src/filtering.jl:100-128 as written */
+static double rbfr_correct(const llpf_rbf_par* p, int nl, int ny, const double* y, const double* yn, double* xl, double* Rp) {
+    double R[RBM * RBM], CR[LLPF_RBF_MAXY * RBM], S[LLPF_RBF_MAXY * LLPF_RBF_MAXY], U[LLPF_RBF_MAXY * LLPF_RBF_MAXY];
+    double RCt[RBM * LLPF_RBF_MAXY], K[RBM * LLPF_RBF_MAXY], IKC[RBM * RBM], Rn[RBM * RBM], e[LLPF_RBF_MAXY];
+    rbfr_unpack(Rp, nl, R);
+    for (int i = 0; i < ny; ++i) {                              /* e = y .- Ct*x */
+        double a = 0.0;
+        for (int c = 0; c < nl; ++c) a += p->Cl[i * nl + c] * xl[c];
+        e[i] = (y[i] - yn[i]) - a;
+    }
+    rbfr_mm(p->Cl, nl, R, RBM, CR, RBM, ny, nl, nl);            /* S = symmetrize(Ct*R*Ct') .+ R2 */
+    rbfr_mmt(CR, RBM, p->Cl, nl, S, ny, ny, nl, ny);
+    for (int i = 0; i < ny; ++i) for (int j = i + 1; j < ny; ++j) { S[i * ny + j] = 0.5 * (S[i * ny + j] + S[j * ny + i]); S[j * ny + i] = S[i * ny + j]; }
+    for (int i = 0; i < ny * ny; ++i) S[i] += p->R2[i];
+    double ldet = 0.0;
+    for (int j = 0; j < ny; ++j) {                              /* cholesky(Symmetric(S)): S = U'U, column by column */
+        for (int i = 0; i <= j; ++i) {
+            double acc = S[i * ny + j];
+            for (int k = 0; k < i; ++k) acc -= U[k * ny + i] * U[k * ny + j];
+            U[i * ny + j] = (i == j) ? sqrt(acc) : acc / U[i * ny + i];
+        }
+        ldet += log(U[j * ny + j]);
+    }
+    ldet = 2.0 * ldet;                                          /* logdet(::Cholesky) */
+    rbfr_mmt(R, RBM, p->Cl, nl, RCt, ny, nl, nl, ny);           /* K = (R*Ct')/S_chol : k U'U = row  ->  (k U') U = row */
+    for (int r = 0; r < nl; ++r) {
+        double t[LLPF_RBF_MAXY] = {0.0};
+        for (int i = 0; i < ny; ++i) {                          /* t U = row */
+            double acc = RCt[r * ny + i];
+            for (int q = 0; q < i; ++q) acc -= t[q] * U[q * ny + i];
+            t[i] = acc / U[i * ny + i];
+        }
+        for (int i = ny - 1; i >= 0; --i) {                     /* k U' = t */
+            double acc = t[i];
+            for (int q = i + 1; q < ny; ++q) acc -= K[r * ny + q] * U[i * ny + q];
+            K[r * ny + i] = acc / U[i * ny + i];
+        }
+    }
+    for (int r = 0; r < nl; ++r) {                              /* kf.x += K*e */
+        double a = 0.0;
+        for (int i = 0; i < ny; ++i) a += K[r * ny + i] * e[i];
+        xl[r] += a;
+    }
+    for (int r = 0; r < nl; ++r) for (int c = 0; c < nl; ++c) { /* kf.R = symmetrize((I - K*Ct)*R) */
+        double a = 0.0;
+        for (int i = 0; i < ny; ++i) a += K[r * ny + i] * p->Cl[i * nl + c];
+        IKC[r * RBM + c] = (r == c ? 1.0 : 0.0) - a;
+    }
+    rbfr_mm(IKC, RBM, R, RBM, Rn, RBM, nl, nl, nl);
+    for (int r = 0; r < nl; ++r) for (int c = 0; c <= r; ++c)
+        Rp[llpf_rbf_idx(r, c)] = (r == c) ? Rn[r * RBM + r] : 0.5 * (Rn[c * RBM + r] + Rn[r * RBM + c]);
+    double quad = 0.0;                                          /* extended_logpdf: mvnormal_c0 - invquad/2, src/utils.jl:252-257 */
+    {
+        double z[LLPF_RBF_MAXY];
+        for (int i = 0; i < ny; ++i) {                          /* U' z = e */
+            double acc = e[i];
+            for (int q = 0; q < i; ++q) acc -= U[q * ny + i] * z[q];
+            z[i] = acc / U[i * ny + i];
+            quad += z[i] * z[i];
+        }
+    }
+    return -((double)ny * log(6.283185307179586) + ldet) / 2.0 - quad / 2.0;
+}
+#undef RBM
+
 static int rbf_setup(orc_filter* f, int order) {
     const llpf_model* m = &f->cfg.model;
     const int nn = m->nx, nl = m->rb.nxl, ny = m->ny, nu = m->nu;
@@ -847,7 +994,7 @@ static void rbf_correct(orc_filter* f, const double* u, const double* y, double 
         double yn[LLPF_RBF_MAXY];
         orc_measurement(&f->cfg.model, f->x + i * nn, u, t, yn);
         const double ll = dev ? llpf_rbf_correct(&f->rbf.par, nl, ny, y, yn, f->rbf.xl + i * nl, f->rbf.R + i * np)
-                              : llpf_rbfr_correct(&f->rbf.par, nl, ny, y, yn, f->rbf.xl + i * nl, f->rbf.R + i * np);
+                              : rbfr_correct(&f->rbf.par, nl, ny, y, yn, f->rbf.xl + i * nl, f->rbf.R + i * np);
         f->w[i] += ll;
     }
     memcpy(f->xprev, f->x, sizeof(double) * (size_t)f->N * nn);           /* copyto!(s.xprev, s.x), :282 */
@@ -866,7 +1013,7 @@ static void rbf_propagate(orc_filter* f, const double* u, double t, const double
         gauss_sample(&f->df, xi + i * nn, nz);                            /* rand(pf.rng, pf.R1n), :217 */
         if (dev) llpf_rbf_predict(&f->rbf.par, nn, nl, nu, f->xprev + a * nn, f->rbf.xlprev + a * nl, f->rbf.Rprev + a * np, u, fi, nz,
                                   f->x + i * nn, f->rbf.xl + i * nl, f->rbf.R + i * np);
-        else llpf_rbfr_predict(&f->rbf.par, nn, nl, nu, f->xprev + a * nn, f->rbf.xlprev + a * nl, f->rbf.Rprev + a * np, u, fi, nz,
+        else rbfr_predict(&f->rbf.par, nn, nl, nu, f->xprev + a * nn, f->rbf.xlprev + a * nl, f->rbf.Rprev + a * np, u, fi, nz,
                                f->x + i * nn, f->rbf.xl + i * nl, f->rbf.R + i * np);
     }
     memcpy(f->rbf.xlprev, f->rbf.xl, sizeof(double) * (size_t)f->N * nl);  /* copyto!(s.xprev, s.x), :227 */

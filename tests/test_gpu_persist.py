@@ -14,6 +14,17 @@ from llpf_amd import _capi, _structs as S
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, scope="module")
+def _needs_a_devtools_build():
+    """The persistent form is an experiment that measured slower: the product library is built without it
+    (csrc/Makefile, DEVTOOLS=1 compiles it in), and then LLPF_PERSIST=1 changes nothing."""
+    model = M.lg_test_model()
+    _, U, Y = M.simulate_lg(model, 8)
+    r = _run(cfg_of(model, 2000, S.RESAMPLE_SYSTEMATIC, 1.0), U, Y, True)
+    if r[0][1]["persistent_timesteps"] == 0:
+        pytest.skip("library built without DEVTOOLS=1: the persistent multi-step kernel is not compiled in")
+
+
 def _run(cfg, U, Y, persist, passes=1, t0=1.0, ll_steps=True):
     os.environ["LLPF_PERSIST"] = "1" if persist else "0"
     try:

@@ -128,34 +128,3 @@ def test_rbfull_api_and_errors():
     bad, _ = M.linear_case(2, 4, 2, seed=1)                    # a shape without an instantiated kernel
     with pytest.raises(_capi.LLPFError):
         _capi.FilterHandle(_cfg(bad, 1000))
-
-
-@pytest.mark.parametrize("name", ["lin_4_8_2", "quadtank_4_8_2"])
-def test_matrix_unit_form_is_bit_identical(name):
-    """k_rbfull_mfma (csrc/kernels/rbfull_mfma.hpp, opt-in with LLPF_RBFULL_MFMA=1): the 8x8 / 4x8 / 2x8 contractions of the
-    per-particle Kalman recursion on v_mfma_f64_4x4x4 reproduce the register form — and the oracle — bit for bit (trajectory with
-    a missing measurement, every particle's xn, xl, R, the ancestors), also at the size of BASELINE config C5"""
-    import os
-    model = CASES[name]()
-    for N, T in ((3000, 30), (200000, 8)):
-        U, Y = M.simulate_io(model, T)
-        Y[5] = np.nan
-        cfg = _cfg(model, N, S.RESAMPLE_SYSTEMATIC, 0.5, seed=9)
-        res = {}
-        for flag in ("1", "0"):
-            os.environ["LLPF_RBFULL_MFMA"] = flag
-            try:
-                g = _capi.FilterHandle(cfg)
-                g.reset()
-                r = g.run(U, Y, 0.0, ll_steps=True)
-                res[flag] = (r["ll_steps"], g.particles(), g.rb_linear_state(), g.ancestors())
-            finally:
-                del os.environ["LLPF_RBFULL_MFMA"]
-        assert _same_bits(res["1"][0], res["0"][0]) and _same_bits(res["1"][1], res["0"][1])
-        assert _same_bits(res["1"][2][0], res["0"][2][0]) and _same_bits(res["1"][2][1], res["0"][2][1])
-        assert np.array_equal(res["1"][3], res["0"][3])
-        if N <= 3000:
-            o = ob.OracleFilter(cfg, ob.ORDER_DEVICE)
-            o.reset()
-            ro = o.run(U, Y, 0.0, ll_steps=True)
-            assert _same_bits(res["1"][0], ro["ll_steps"]) and _same_bits(res["1"][2][1], o.rb_linear_state()[1])
