@@ -1,0 +1,56 @@
+// k_rbfull.hip — the Rao-Blackwellized filter with per-particle covariance (kernels/rbfull.hpp) and its launchers
+// One of the engine's device translation units (kernels.hip has the map); split so that they build in parallel.
+
+#include "engine.hpp"
+
+namespace llpf {
+
+#define DEV __device__ __forceinline__
+
+#include "kernels/reduce.hpp"
+#include "kernels/models.hpp"
+#include "kernels/accum.hpp"
+#include "kernels/rbfull.hpp"
+
+static inline dim3 grid1(int64_t n, int F) { return dim3((unsigned)((n + BLOCK - 1) / BLOCK), (unsigned)F, 1); }
+
+// LLPF_MODEL_RB_BILINEAR: the instantiated shapes (nxn, nxl, ny); fn_kind 1 = quad-tank nonlinear part
+bool rbfull_supported(int fn_kind, int nn, int nl, int ny) {
+    if (fn_kind == 1) return nn == 4 && nl == 8 && ny == 2;
+    if (fn_kind != 0) return false;
+    return (nn == 1 && nl == 2 && ny == 1) || (nn == 2 && nl == 2 && ny == 2) || (nn == 4 && nl == 8 && ny == 2);
+}
+int rbfull_rows(int nn, int nl) { return nn + nl + LLPF_RBF_NP(nl); }
+
+template <class Model, int NN, int NL, int NY>
+static hipError_t launch_rbfull_t(const BankDev& b, int mode, const StepArgs& a, hipStream_t s) {
+    dim3 g((unsigned)(b.Ns / RBF_BLOCK), (unsigned)b.F, 1);
+    switch (mode) {
+        case MODE_WEIGHT: hipLaunchKernelGGL((k_rbfull<Model, NN, NL, NY, MODE_WEIGHT>), g, dim3(RBF_BLOCK), 0, s, b, b.models, b.scal, a); break;
+        case MODE_PROP: hipLaunchKernelGGL((k_rbfull<Model, NN, NL, NY, MODE_PROP>), g, dim3(RBF_BLOCK), 0, s, b, b.models, b.scal, a); break;
+        case MODE_PROP_WEIGHT: hipLaunchKernelGGL((k_rbfull<Model, NN, NL, NY, MODE_PROP_WEIGHT>), g, dim3(RBF_BLOCK), 0, s, b, b.models, b.scal, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+// BankDev::pad0 carries the shape of this model: nxl | fn_kind << 8
+hipError_t launch_rbfull(const BankDev& b, int mode, const StepArgs& a, hipStream_t s) {
+    const int nl = b.pad0 & 0xff, fk = (b.pad0 >> 8) & 0xff;
+    if (fk == 1 && b.nx == 4 && nl == 8 && b.ny == 2) return launch_rbfull_t<QuadTank<4, 2>, 4, 8, 2>(b, mode, a, s);
+    if (fk == 0 && b.nx == 4 && nl == 8 && b.ny == 2) return launch_rbfull_t<LinGauss<4, 2>, 4, 8, 2>(b, mode, a, s);
+    if (fk == 0 && b.nx == 2 && nl == 2 && b.ny == 2) return launch_rbfull_t<LinGauss<2, 2>, 2, 2, 2>(b, mode, a, s);
+    if (fk == 0 && b.nx == 1 && nl == 2 && b.ny == 1) return launch_rbfull_t<LinGauss<1, 1>, 1, 2, 1>(b, mode, a, s);
+    return hipErrorInvalidValue;
+}
+hipError_t launch_rbfull_init(const BankDev& b, hipStream_t s) {
+    const int nl = b.pad0 & 0xff;
+    dim3 g = grid1(b.Ns, b.F);
+    if (b.nx == 4 && nl == 8) hipLaunchKernelGGL((k_rbfull_init<4, 8>), g, dim3(BLOCK), 0, s, b, b.models);
+    else if (b.nx == 2 && nl == 2) hipLaunchKernelGGL((k_rbfull_init<2, 2>), g, dim3(BLOCK), 0, s, b, b.models);
+    else if (b.nx == 1 && nl == 2) hipLaunchKernelGGL((k_rbfull_init<1, 2>), g, dim3(BLOCK), 0, s, b, b.models);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+
+}  // namespace llpf

@@ -226,3 +226,26 @@ __global__ void k_fb_clear(BankDev b, int slot, int mode) {
     }
 }
 __global__ void k_fb_clear_flag(BankDev b) { if (threadIdx.x < 4) b.bank_flag[threadIdx.x] = 0; }
+
+// per-tile sums of the quanta of plain values (standalone resample(we))
+__global__ __launch_bounds__(BLOCK) void k_qpart(BankDev b, int K) {
+    __shared__ uint64_t sm_w[BLOCK / 64];
+    const int f = blockIdx.y, tile = blockIdx.x;
+    const double* __restrict__ w = b.w + (size_t)f * b.Ns;
+    uint64_t Q = 0;
+#pragma unroll
+    for (int k = 0; k < NORM_IPT; ++k) {
+        const int64_t i = (int64_t)tile * TILE + (int64_t)k * BLOCK + threadIdx.x;
+        const uint64_t q = (i < b.N) ? llpf_q64_unit(w[i], K) : 0;
+        b.quanta[(size_t)f * b.Ns + i] = q;
+        Q += q;
+    }
+    Q = wave_sum_u64(Q);
+    if ((threadIdx.x & 63) == 0) sm_w[threadIdx.x >> 6] = Q;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t q = 0;
+        for (int k = 0; k < BLOCK / 64; ++k) q += sm_w[k];
+        tileq_slot(b, 0, f)[tile] = q;      // scratch bank of the standalone resample(we): slot 0
+    }
+}
