@@ -7,6 +7,7 @@
 // (csrc/shared/llpf_rbfull.h, shared with the oracle).  The exp-sums of the new weights are left to a k_norm launch in
 // bound form: S_i = C R_i C' + R2 >= R2, so max(w_prev) + c0(R2) bounds every new weight.
 // ------------------------------------------------------------------------------------------------
+#define RBF_KCPTR(p) ((llpf_rbf_cptr)(p))
 constexpr double RBF_BOUND_SLACK = 0x1p-20;   // keeps exp(w - bound) <= 1 when a particle's C R C' rounds to zero
 
 #ifndef LLPF_RBF_WAVES
@@ -37,13 +38,21 @@ __global__ __launch_bounds__(RBF_BLOCK) __attribute__((amdgpu_waves_per_eu(NL >=
 
     Model model;
     model.prepare(md, a.u, a.t_prop);
+    // Bl u is particle-independent and nu a run-time number: formed once per wave, read back by the time update from LDS
+    // (as a branch inside the unrolled body it cut the body into blocks that each kept their constants' SGPRs alive)
+    __shared__ double sh_blu[LLPF_RBF_MAXL];
+    if (MODE != MODE_WEIGHT) {
+        if (threadIdx.x < NL) sh_blu[threadIdx.x] = llpf_rbf_blu_row(RBF_KCPTR(par), b.nu, (int)threadIdx.x, a.u);
+        __syncthreads();
+    }
 
     const int64_t i = (int64_t)blockIdx.x * RBF_BLOCK + threadIdx.x;
     const int64_t src = do_res ? (int64_t)b.anc[(size_t)f * Ns + i] : i;
-    // one 32-bit byte offset per thread against uniform plane bases (48 planes: 64-bit addresses would hold 96 registers)
-    const uint32_t so = (uint32_t)src * 8u, io = (uint32_t)i * 8u;
-    auto ld = [&](int row, uint32_t off) { return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(xc + (size_t)row * Ns) + off); };
-    auto st = [&](int row, double v) { *reinterpret_cast<double*>(reinterpret_cast<char*>(xo + (size_t)row * Ns) + io) = v; };
+    // 32-bit byte offsets from ONE uniform base per buffer (48 planes: 64-bit addresses would hold 96 registers and cost two
+    // instructions each); the launcher checks that a filter's planes span less than 4 GB
+    const uint32_t stride = (uint32_t)Ns * 8u, so = (uint32_t)src * 8u, io = (uint32_t)i * 8u;
+    auto ld = [&](int row, uint32_t off) { return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(xc) + (off + (uint32_t)row * stride)); };
+    auto st = [&](int row, double v) { *reinterpret_cast<double*>(reinterpret_cast<char*>(xo) + (io + (uint32_t)row * stride)) = v; };
     double xn[NN], xl[NL], R[NP];
 #pragma unroll
     for (int d = 0; d < NN; ++d) xn[d] = ld(d, so);
@@ -57,7 +66,7 @@ __global__ __launch_bounds__(RBF_BLOCK) __attribute__((amdgpu_waves_per_eu(NL >=
         model.dynamics(xn, fi);
         llpf_normals((uint32_t)i, sb + a.step, LLPF_STREAM_DYNAMICS, k0, k1, NN, xi);
         gauss_sample<NN>(md->df, xi, nz);
-        llpf_rbf_predict(par, NN, NL, b.nu, xn, xl, R, a.u, fi, nz, xn1, xl1, R1);
+        llpf_rbf_predict(par, NN, NL, b.nu, xn, xl, R, a.u, sh_blu, fi, nz, xn1, xl1, R1);
 #pragma unroll
         for (int d = 0; d < NN; ++d) xn[d] = xn1[d];
 #pragma unroll

@@ -22,7 +22,7 @@
  * doubles, against ~330 here.  Left alone the compiler hoists all of those loads to the top of the (fully unrolled) body and
  * spills the SGPRs into VGPR lanes: a third of the old kernel's instructions were v_readlane / v_writelane.  RBF_STAGE pins the
  * loads of a stage behind the value that ends the stage before it, and the stages are cut so that none needs more than ~40
- * doubles of constants: a row of An(xn) at a time (40), the upper half of Al, then the lower half (32 each). */
+ * doubles of constants: a row of one coupling matrix (8) or a pair of rows of Al (16) at a time. */
 
 /* row r of An(xn) = An[0] + sum_k xn[k] An[1+k]              (pf.An as a function of the state, src/rbpf.jl:208) */
 LLPF_HD void RBF_(coupling_row)(llpf_rbf_cptr p, const int nn, const int nl, const int r, const double* xn, double* a) {
@@ -30,6 +30,7 @@ LLPF_HD void RBF_(coupling_row)(llpf_rbf_cptr p, const int nn, const int nl, con
     for (int c = 0; c < nl; ++c) a[c] = p->An[0][r * nl + c];
     LLPF_UNROLL
     for (int k = 0; k < nn; ++k) {
+        RBF_SUBSTAGE(p, a[nl - 1]);
         LLPF_UNROLL
         for (int c = 0; c < nl; ++c) a[c] = llpf_fma(xn[k], p->An[1 + k][r * nl + c], a[c]);
     }
@@ -43,12 +44,12 @@ LLPF_HD void RBF_(coupling)(const llpf_rbf_par* p, const int nn, const int nl, c
  * still sums its products in increasing index order (so results do not depend on the nesting), but consecutive
  * instructions are independent. */
 
-/* rows [r0, r1) of M = Al X for a symmetric X held as a packed lower triangle */
-#define RBF_PANEL(M, r0, r1)                                                                                         \
+/* rows [r0, r1) of M = Al X for a symmetric X held as a packed lower triangle; M row r is stored at row r - m0 */
+#define RBF_PANEL(M, m0, r0, r1)                                                                                     \
     LLPF_UNROLL                                                                                                      \
     for (int r = (r0); r < (r1); ++r) {                                                                              \
         LLPF_UNROLL                                                                                                  \
-        for (int c = 0; c < nl; ++c) M[(r - (r0)) * nl + c] = pp->Al[r * nl] * Rt[llpf_rbf_idx(0, c)];              \
+        for (int c = 0; c < nl; ++c) M[(r - (m0)) * nl + c] = pp->Al[r * nl] * Rt[llpf_rbf_idx(0, c)];              \
     }                                                                                                                \
     LLPF_UNROLL                                                                                                      \
     for (int q = 1; q < nl; ++q) {                                                                                   \
@@ -56,9 +57,17 @@ LLPF_HD void RBF_(coupling)(const llpf_rbf_par* p, const int nn, const int nl, c
         for (int r = (r0); r < (r1); ++r) {                                                                          \
             LLPF_UNROLL                                                                                              \
             for (int c = 0; c < nl; ++c)                                                                             \
-                M[(r - (r0)) * nl + c] = llpf_fma(pp->Al[r * nl + q], Rt[llpf_rbf_idx(q, c)], M[(r - (r0)) * nl + c]); \
+                M[(r - (m0)) * nl + c] = llpf_fma(pp->Al[r * nl + q], Rt[llpf_rbf_idx(q, c)], M[(r - (m0)) * nl + c]); \
         }                                                                                                            \
     }
+/* (Bl u)[r] — particle-independent; the device computes it once per wave (kernels/rbfull.hpp) and the body reads it back, so
+ * that the body stays one straight-line block (nu is a run-time number) */
+LLPF_HD double RBF_(blu_row)(llpf_rbf_cptr p, const int nu, const int r, const double* u) {
+    if (nu <= 0) return -0.0;                                    /* x + (-0.0) == x for every x, signed zeros included */
+    double b2 = p->Bl[r * nu] * u[0];
+    for (int c = 1; c < nu; ++c) b2 = llpf_fma(p->Bl[r * nu + c], u[c], b2);
+    return b2;
+}
 /* rows [r0, r1) of Al x~l + Bl u */
 #define RBF_MEAN(r0, r1)                                                                                             \
     LLPF_UNROLL                                                                                                      \
@@ -68,21 +77,49 @@ LLPF_HD void RBF_(coupling)(const llpf_rbf_par* p, const int nn, const int nl, c
         LLPF_UNROLL                                                                                                  \
         for (int r = (r0); r < (r1); ++r) xl1[r] = llpf_fma(pp->Al[r * nl + c], xt[c], xl1[r]);                      \
     }                                                                                                                \
-    if (nu > 0) {                                                                                                    \
+    LLPF_UNROLL                                                                                                      \
+    for (int r = (r0); r < (r1); ++r) xl1[r] = xl1[r] + RBF_BLU(pp, nu, r, u, blu);
+/* columns [c0, c1) of a block of R1 = M Al': R1[r, c] = M[r - m0, :] . Al[c, :] for rows max(c, rlo) <= r < rhi */
+#define RBF_OUT_COLS(M, m0, c0, c1, rlo, rhi)                                                                        \
+    LLPF_UNROLL                                                                                                      \
+    for (int c = (c0); c < (c1); ++c) {                                                                              \
         LLPF_UNROLL                                                                                                  \
-        for (int r = (r0); r < (r1); ++r) {                                                                          \
-            double b2 = pp->Bl[r * nu] * u[0];                                                                       \
-            for (int c = 1; c < nu; ++c) b2 = llpf_fma(pp->Bl[r * nu + c], u[c], b2);                                \
-            xl1[r] = xl1[r] + b2;                                                                                    \
+        for (int r = (c > (rlo) ? c : (rlo)); r < (rhi); ++r) R1[llpf_rbf_idx(r, c)] = M[(r - (m0)) * nl] * pp->Al[c * nl]; \
+    }                                                                                                                \
+    LLPF_UNROLL                                                                                                      \
+    for (int q = 1; q < nl; ++q) {                                                                                   \
+        LLPF_UNROLL                                                                                                  \
+        for (int c = (c0); c < (c1); ++c) {                                                                          \
+            LLPF_UNROLL                                                                                              \
+            for (int r = (c > (rlo) ? c : (rlo)); r < (rhi); ++r)                                                    \
+                R1[llpf_rbf_idx(r, c)] = llpf_fma(M[(r - (m0)) * nl + q], pp->Al[c * nl + q], R1[llpf_rbf_idx(r, c)]); \
         }                                                                                                            \
     }
+/* rows [r0, r1) of the lower-left block of R1 = Al M' (R~ is symmetric): R1[r, c] = Al[r, :] . M[c, :] for c < ht */
+#define RBF_OUT_ROWS(M, r0, r1)                                                                                      \
+    LLPF_UNROLL                                                                                                      \
+    for (int r = (r0); r < (r1); ++r) {                                                                              \
+        LLPF_UNROLL                                                                                                  \
+        for (int c = 0; c < ht; ++c) R1[llpf_rbf_idx(r, c)] = pp->Al[r * nl] * M[c * nl];                            \
+    }                                                                                                                \
+    LLPF_UNROLL                                                                                                      \
+    for (int q = 1; q < nl; ++q) {                                                                                   \
+        LLPF_UNROLL                                                                                                  \
+        for (int r = (r0); r < (r1); ++r) {                                                                          \
+            LLPF_UNROLL                                                                                              \
+            for (int c = 0; c < ht; ++c) R1[llpf_rbf_idx(r, c)] = llpf_fma(pp->Al[r * nl + q], M[c * nl + q], R1[llpf_rbf_idx(r, c)]); \
+        }                                                                                                            \
+    }
+#define RBF_MIN(a, b) ((a) < (b) ? (a) : (b))
 
 /* Time update of one particle — src/rbpf.jl:206-221 (An != 0 branch, !singleR), in the form of the header comment.
- * fi = f_n(xn, u, p, t) and nz ~ R1n come from the caller.  R, R1: packed lower triangles (may alias: R is copied first). */
+ * fi = f_n(xn, u, p, t) and nz ~ R1n come from the caller.  R, R1: packed lower triangles (may alias: R is copied first).
+ * blu: device only, Bl u as precomputed with blu_row (the host evaluates blu_row in place and ignores it). */
 LLPF_HD void RBF_(predict)(const llpf_rbf_par* p, const int nn, const int nl, const int nu, const double* xn,
-                           const double* xl, const double* R, const double* u, const double* fi, const double* nz,
-                           double* xn1, double* xl1, double* R1) {
+                           const double* xl, const double* R, const double* u, const double* blu, const double* fi,
+                           const double* nz, double* xn1, double* xl1, double* R1) {
     llpf_rbf_cptr pp = RBF_CPTR(p);
+    (void)blu;
     double Rt[LLPF_RBF_NP(LLPF_RBF_MAXL)];                       /* R, then R~ */
     double AnR[LLPF_RBF_MAXN * LLPF_RBF_MAXL];                   /* An R; column c becomes row c of V */
     double Nt[LLPF_RBF_MAXN * LLPF_RBF_MAXN], Lc[LLPF_RBF_MAXN * LLPF_RBF_MAXN], invd[LLPF_RBF_MAXN];
@@ -114,6 +151,9 @@ LLPF_HD void RBF_(predict)(const llpf_rbf_par* p, const int nn, const int nl, co
         }
         LLPF_UNROLL
         for (int j = 0; j <= r; ++j) Nt[r * nn + j] = Nt[r * nn + j] + pp->R1n[r * nn + j];
+        RBF_DONE(AnR, r * nl, r * nl + nl);
+        RBF_DONE(Nt, r * nn, r * nn + r + 1);
+        RBF_DONE(ax, r, r + 1);
     }
     LLPF_UNROLL
     for (int i = 0; i < nn; ++i) {                              /* Nt = Lc Lc' */
@@ -165,70 +205,66 @@ LLPF_HD void RBF_(predict)(const llpf_rbf_par* p, const int nn, const int nl, co
             for (int c = 0; c <= r; ++c) Rt[llpf_rbf_idx(r, c)] = llpf_fma(-AnR[j * nl + r], AnR[j * nl + c], Rt[llpf_rbf_idx(r, c)]);
         }
     }
-    {                                                           /* xl1 = Al x~l + Bl u ; R1 = Al R~ Al' + R1l : by halves of Al */
+    {   /* xl1 = Al x~l + Bl u ; R1 = Al R~ Al' + R1l.  The covariance goes by halves of Al (upper-left block from the upper
+         * panel M = Al[0:ht] R~, lower-left block from the same panel against the lower rows of Al, then the lower panel and
+         * the lower-right block), and every piece by pairs of rows of Al: 16 constants per stage. */
         const int ht = (nl + 1) / 2;
         double M[((LLPF_RBF_MAXL + 1) / 2) * LLPF_RBF_MAXL];
-        RBF_STAGE(pp, Rt[np - 1]);
-        RBF_MEAN(0, ht)
-        if (ht < nl) {
-            RBF_STAGE(pp, xl1[ht - 1]);
-            RBF_MEAN(ht, nl)
-        }
-        RBF_STAGE(pp, xl1[nl - 1]);
-        RBF_PANEL(M, 0, ht)                                     /* M = Al[0:ht, :] R~ */
         LLPF_UNROLL
-        for (int r = 0; r < ht; ++r) {                          /* upper-left block: R1[r, c] = M[r, :] . Al[c, :] */
-            LLPF_UNROLL
-            for (int c = 0; c <= r; ++c) R1[llpf_rbf_idx(r, c)] = M[r * nl] * pp->Al[c * nl];
+        for (int r0 = 0; r0 < nl; r0 += 2) {
+            RBF_STAGE(pp, r0 == 0 ? Rt[np - 1] : xl1[r0 - 1]);
+            RBF_MEAN(r0, RBF_MIN(r0 + 2, nl))
+            RBF_DONE(xl1, r0, RBF_MIN(r0 + 2, nl));
         }
         LLPF_UNROLL
-        for (int q = 1; q < nl; ++q) {
-            LLPF_UNROLL
-            for (int r = 0; r < ht; ++r) {
-                LLPF_UNROLL
-                for (int c = 0; c <= r; ++c) R1[llpf_rbf_idx(r, c)] = llpf_fma(M[r * nl + q], pp->Al[c * nl + q], R1[llpf_rbf_idx(r, c)]);
-            }
+        for (int r0 = 0; r0 < ht; r0 += 2) {                    /* M = Al[0:ht, :] R~ */
+            RBF_STAGE(pp, r0 == 0 ? xl1[nl - 1] : M[r0 * nl - 1]);
+            RBF_PANEL(M, 0, r0, RBF_MIN(r0 + 2, ht))
+            RBF_DONE(M, r0 * nl, RBF_MIN(r0 + 2, ht) * nl);
+        }
+        LLPF_UNROLL
+        for (int c0 = 0; c0 < ht; c0 += 2) {                    /* upper-left block */
+            RBF_STAGE(pp, c0 == 0 ? M[ht * nl - 1] : R1[llpf_rbf_idx(ht - 1, c0 - 1)]);
+            RBF_OUT_COLS(M, 0, c0, RBF_MIN(c0 + 2, ht), 0, ht)
+            RBF_DONE(R1, 0, LLPF_RBF_NP(ht));
         }
         if (ht < nl) {
-            RBF_STAGE(pp, R1[llpf_rbf_idx(ht - 1, ht - 1)]);
             LLPF_UNROLL
-            for (int r = ht; r < nl; ++r) {                     /* lower-left block: R1[r, c] = Al[r, :] . M[c, :]  (R~ is symmetric) */
+            for (int r0 = ht; r0 < nl; r0 += 2) {               /* lower-left block */
+                RBF_STAGE(pp, r0 == ht ? R1[llpf_rbf_idx(ht - 1, ht - 1)] : R1[llpf_rbf_idx(r0 - 1, ht - 1)]);
+                RBF_OUT_ROWS(M, r0, RBF_MIN(r0 + 2, nl))
                 LLPF_UNROLL
-                for (int c = 0; c < ht; ++c) R1[llpf_rbf_idx(r, c)] = pp->Al[r * nl] * M[c * nl];
-            }
-            LLPF_UNROLL
-            for (int q = 1; q < nl; ++q) {
-                LLPF_UNROLL
-                for (int r = ht; r < nl; ++r) {
-                    LLPF_UNROLL
-                    for (int c = 0; c < ht; ++c) R1[llpf_rbf_idx(r, c)] = llpf_fma(pp->Al[r * nl + q], M[c * nl + q], R1[llpf_rbf_idx(r, c)]);
-                }
+                for (int r = r0; r < RBF_MIN(r0 + 2, nl); ++r) RBF_DONE(R1, llpf_rbf_idx(r, 0), llpf_rbf_idx(r, 0) + ht);
             }
             RBF_FENCE(R1[llpf_rbf_idx(nl - 1, ht - 1)]);
-            RBF_PANEL(M, ht, nl)                                /* M = Al[ht:nl, :] R~ */
+            LLPF_UNROLL
+            for (int r0 = ht; r0 < nl; r0 += 2) {               /* M = Al[ht:nl, :] R~ */
+                RBF_STAGE(pp, r0 == ht ? R1[llpf_rbf_idx(nl - 1, ht - 1)] : M[(r0 - ht) * nl - 1]);
+                RBF_PANEL(M, ht, r0, RBF_MIN(r0 + 2, nl))
+                RBF_DONE(M, (r0 - ht) * nl, (RBF_MIN(r0 + 2, nl) - ht) * nl);
+            }
             RBF_FENCE(M[(nl - ht) * nl - 1]);
             LLPF_UNROLL
-            for (int r = ht; r < nl; ++r) {                     /* lower-right block */
-                LLPF_UNROLL
-                for (int c = ht; c <= r; ++c) R1[llpf_rbf_idx(r, c)] = M[(r - ht) * nl] * pp->Al[c * nl];
-            }
-            LLPF_UNROLL
-            for (int q = 1; q < nl; ++q) {
-                LLPF_UNROLL
-                for (int r = ht; r < nl; ++r) {
-                    LLPF_UNROLL
-                    for (int c = ht; c <= r; ++c)
-                        R1[llpf_rbf_idx(r, c)] = llpf_fma(M[(r - ht) * nl + q], pp->Al[c * nl + q], R1[llpf_rbf_idx(r, c)]);
-                }
+            for (int c0 = ht; c0 < nl; c0 += 2) {               /* lower-right block */
+                RBF_STAGE(pp, c0 == ht ? M[(nl - ht) * nl - 1] : R1[llpf_rbf_idx(nl - 1, c0 - 1)]);
+                RBF_OUT_COLS(M, ht, c0, RBF_MIN(c0 + 2, nl), ht, nl)
+                RBF_DONE(R1, LLPF_RBF_NP(ht), np);
             }
         }
-        RBF_STAGE(pp, R1[np - 1]);
         LLPF_UNROLL
-        for (int d = 0; d < np; ++d) R1[d] = R1[d] + pp->R1l[d];
+        for (int d0 = 0; d0 < np; d0 += 12) {
+            RBF_STAGE(pp, d0 == 0 ? R1[np - 1] : R1[d0 - 1]);
+            LLPF_UNROLL
+            for (int d = d0; d < RBF_MIN(d0 + 12, np); ++d) R1[d] = R1[d] + pp->R1l[d];
+            RBF_DONE(R1, d0, RBF_MIN(d0 + 12, np));
+        }
     }
 }
 #undef RBF_PANEL
 #undef RBF_MEAN
+#undef RBF_OUT_COLS
+#undef RBF_OUT_ROWS
+#undef RBF_MIN
 
 /* Measurement update of one particle — src/rbpf.jl:259-263 -> correct!(kf, u, y - yn, p, t), src/filtering.jl:100-128:
  *   e = (y - yn) - C xl ; S = symmetrize(C R C') + R2 ; K = (R C') / chol(S) ; xl += K e ;

@@ -1011,7 +1011,7 @@ static void rbf_propagate(orc_filter* f, const double* u, double t, const double
         double fi[LLPF_RBF_MAXN], nz[LLPF_RBF_MAXN];
         orc_dynamics(&f->cfg.model, f->xprev + a * nn, u, t, fi);
         gauss_sample(&f->df, xi + i * nn, nz);                            /* rand(pf.rng, pf.R1n), :217 */
-        if (dev) llpf_rbf_predict(&f->rbf.par, nn, nl, nu, f->xprev + a * nn, f->rbf.xlprev + a * nl, f->rbf.Rprev + a * np, u, fi, nz,
+        if (dev) llpf_rbf_predict(&f->rbf.par, nn, nl, nu, f->xprev + a * nn, f->rbf.xlprev + a * nl, f->rbf.Rprev + a * np, u, NULL, fi, nz,
                                   f->x + i * nn, f->rbf.xl + i * nl, f->rbf.R + i * np);
         else rbfr_predict(&f->rbf.par, nn, nl, nu, f->xprev + a * nn, f->rbf.xlprev + a * nl, f->rbf.Rprev + a * np, u, fi, nz,
                                f->x + i * nn, f->rbf.xl + i * nl, f->rbf.R + i * np);
