@@ -104,7 +104,7 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
     // its registers for the propagate and runs at higher occupancy: best when many filters saturate the SIMDs).
     // Measured on MI355X: C2 single filter 29.4 vs 30.2 us, bank 128 x 1e5: 4.3e10 vs 5.0e10 particle-steps/s.
     const char* sch_env = getenv("LLPF_SCHEDULE");       // "merged" | "split" override
-    const bool merged = !rbfull && (hist || (sch_env ? (strcmp(sch_env, "merged") == 0) : ((int64_t)b.F * b.Ns <= ((int64_t)3 << 20))));
+    const bool merged = (hist || (sch_env ? (strcmp(sch_env, "merged") == 0) : ((int64_t)b.F * b.Ns <= ((int64_t)3 << 20))));
     static const char* abl_env = getenv("LLPF_ABLATE");
     static const char* dbg_env = getenv("LLPF_DEBUG_TIMING");
 

@@ -13,14 +13,13 @@ static int bank_correct(Bank& b, const double* u, const double* y, double t, dou
         BankDev d = b.dev();
         StepArgs a{};
         a.u = b.d_uy; a.y = b.d_uy + MAXD; a.t_prop = t; a.t_meas = t; a.step = 0; a.has_y = has_y ? 1 : 0;
-        a.parity = slot; a.need_e2 = 1; a.K = llpf_qbits(b.N); a.k = 0; a.next_step = rel_step(b); a.accumulate = is_rbfull(b) ? 0 : 1;
+        a.parity = slot; a.need_e2 = 1; a.K = llpf_qbits(b.N); a.k = 0; a.next_step = rel_step(b); a.accumulate = 1;
         if (is_rb(b) && has_y) { CHK(rb_upload_single(b, true)); a.rb_corr = b.d_rb; }
         HIPC(launch_step(d, MODE_WEIGHT, a, b.stream));     // weights + exp-sums against the bound + quanta
     }
     b.qcur ^= 1;
     b.parity = (b.parity + 1) % ACC_NSLOT;
     BankDev d = b.dev();
-    if (is_rbfull(b)) HIPC(launch_norm(d, slot, 0, 1, rel_step(b), 0, 1, 0, b.stream));   // its weighting kernel leaves the exp-sums to k_norm (bound form)
     ResArgs ra{};
     ra.mode = RES_FINALIZE; ra.parity = slot; ra.M = (int32_t)b.N; ra.fast_head = 1; ra.k = 0;
     HIPC(launch_resample(d, ra, b.stream));

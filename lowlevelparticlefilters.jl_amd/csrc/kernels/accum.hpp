@@ -67,6 +67,17 @@ struct WeightAcc {
         if (need_e2) E2 = llpf_u128_add(E2, llpf_fix96_unit(e * e));
         return llpf_q64_unit(e, K);
     }
+    // the same for a workgroup that is one wave (k_rbfull)
+    DEV void flush_wave(uint64_t* acc, int slot, bool need_e2) {
+        llpf_u128 s = wave_sum_u128(S), e2 = {0, 0};
+        if (need_e2) e2 = wave_sum_u128(E2);
+        const uint64_t bd = (uint64_t)__builtin_popcountll(__ballot(bad != 0));
+        if (threadIdx.x == 0) {
+            acc_add_u128(acc, ACC_S(slot), s);
+            if (need_e2) acc_add_u128(acc, ACC_E2(slot), e2);
+            if (bd) atomicAdd(reinterpret_cast<unsigned long long*>(acc_slot(acc, ACC_BAD(slot), blockIdx.x & (NSHARD - 1))), (unsigned long long)bd);
+        }
+    }
     // block-wide totals into the sharded accumulators of `slot`; sm: [BLOCK/64][5] u64 of LDS
     DEV void flush(uint64_t* acc, int slot, bool need_e2, uint64_t (*sm)[5]) {
         llpf_u128 s = wave_sum_u128(S), e2 = {0, 0};

@@ -4,8 +4,8 @@
 // Particle plane layout of this model (single filter): rows 0..NN-1 of x are xn, rows NN..NN+NL-1 the Kalman mean xl,
 // the following NL(NL+1)/2 rows the packed lower triangle of the Kalman covariance R: one ancestor gather moves the
 // whole RBParticle (src/rbpf.jl:1-5, :182 `xi = s.xprev[j[i]]`).  One particle per thread; all matrices in registers
-// (csrc/shared/llpf_rbfull.h, shared with the oracle).  The exp-sums of the new weights are left to a k_norm launch in
-// bound form: S_i = C R_i C' + R2 >= R2, so max(w_prev) + c0(R2) bounds every new weight.
+// (csrc/shared/llpf_rbfull.h, shared with the oracle).  S_i = C R_i C' + R2 >= R2, so max(w_prev) + c0(R2) bounds every new
+// weight: the exp-sums against that bound are formed here (merged schedule, StepArgs::accumulate) or by a k_norm launch.
 // ------------------------------------------------------------------------------------------------
 #define RBF_KCPTR(p) ((llpf_rbf_cptr)(p))
 constexpr double RBF_BOUND_SLACK = 0x1p-20;   // keeps exp(w - bound) <= 1 when a particle's C R C' rounds to zero
@@ -78,7 +78,10 @@ __global__ __launch_bounds__(RBF_BLOCK) __attribute__((amdgpu_waves_per_eu(NL >=
     double bmax = -LLPF_INF;
     bool bad = false;
     double off = 0.0;
+    WeightAcc wacc;
+    uint64_t qsum = 0;
     if (MODE != MODE_PROP) {
+        wacc.init();
         const double wmx = do_res ? b.log1N : (uniform ? wconst : sc->wmax);
         off = a.has_y ? (wmx + md->dg.c0) + RBF_BOUND_SLACK : wmx;
         double wv;
@@ -96,6 +99,10 @@ __global__ __launch_bounds__(RBF_BLOCK) __attribute__((amdgpu_waves_per_eu(NL >=
         w[i] = wv;
         bad = wv != wv;
         bmax = wv;
+        if (a.accumulate) {     // merged schedule: exp-sums, quantum and tile sum of the new weight formed here (otherwise by k_norm)
+            qsum = wacc.add(wv, off, a.K, a.need_e2 != 0);
+            b.quanta_next[(size_t)f * Ns + i] = qsum;
+        }
     }
     if (MODE != MODE_WEIGHT || a.has_y) {
 #pragma unroll
@@ -108,7 +115,12 @@ __global__ __launch_bounds__(RBF_BLOCK) __attribute__((amdgpu_waves_per_eu(NL >=
     if (MODE != MODE_PROP) {
         const double r = wave_max(bmax);                        // the workgroup is one wave
         const int anybad = __ballot(bad) != 0 ? 1 : 0;
+        if (a.accumulate) {
+            wacc.flush_wave(b.acc + (size_t)f * ACC_WORDS, a.parity, a.need_e2 != 0);
+            qsum = wave_sum_u64(qsum);     // the wave's 64 particles lie in one 1024-particle tile
+        }
         if (threadIdx.x == 0) {
+            if (a.accumulate && qsum) atomicAdd(reinterpret_cast<unsigned long long*>(tileq_slot(b, a.parity, f) + (i / TILE)), (unsigned long long)qsum);
             acc_max(b.acc + (size_t)f * ACC_WORDS, a.parity, r, anybad != 0);
             if (blockIdx.x == 0) {
                 FilterScal* scw = b.scal + f;

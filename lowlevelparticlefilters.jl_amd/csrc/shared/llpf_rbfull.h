@@ -50,17 +50,18 @@ LLPF_HD int llpf_rbf_idx(int r, int c) { return r >= c ? r * (r + 1) / 2 + c : c
  * can neither be hoisted above the point where `dep` is computed nor merged with earlier loads (llpf_rbfull_body.h, "Stages"). */
 typedef const __attribute__((address_space(4))) llpf_rbf_par* llpf_rbf_cptr;
 #define RBF_CPTR(p) ((llpf_rbf_cptr)(p))
+#ifndef LLPF_RBF_NO_AHEAD
+/* ... one stage AHEAD: a stage reads through the pointer made opaque at the start of the stage before it, so its scalar loads
+ * can be in flight while that stage computes (a lone s_load waits ~200 cycles, and there are ~45 stages) */
+#define RBF_STAGE(ptr, dep) do { const double rbf_dep_ = (dep); ptr = ptr##_nx; asm volatile("" : "+s"(ptr##_nx) : "v"(rbf_dep_)); } while (0)
+#else
 #define RBF_STAGE(ptr, dep) do { const double rbf_dep_ = (dep); asm volatile("" : "+s"(ptr) : "v"(rbf_dep_)); } while (0)
+#endif
 #define RBF_BLU(pp, nu, r, u, blu) ((blu)[r])
 /* every element of arr[i0, i1) is computed before the next stage begins: the stage's own `dep` orders only the chain that
  * value hangs on, and the compiler postponed the other rows of a stage to the end of the body — with every stage's pointer
  * and constants still alive in SGPRs */
 #define RBF_DONE(arr, i0, i1) do { LLPF_UNROLL for (int rbf_i_ = (i0); rbf_i_ < (i1); ++rbf_i_) asm volatile("" : : "v"((arr)[rbf_i_])); } while (0)
-#ifdef LLPF_RBF_SUBSTAGE
-#define RBF_SUBSTAGE(ptr, dep) RBF_STAGE(ptr, dep)
-#else
-#define RBF_SUBSTAGE(ptr, dep) ((void)0)
-#endif
 /* no instruction may be scheduled across this point (keeps two panels of the time update from being live together) */
 #define RBF_FENCE(dep) __builtin_amdgcn_sched_barrier(0)
 #else
@@ -68,7 +69,6 @@ typedef const llpf_rbf_par* llpf_rbf_cptr;
 #define RBF_CPTR(p) (p)
 #define RBF_STAGE(ptr, dep) ((void)0)
 #define RBF_FENCE(dep) ((void)0)
-#define RBF_SUBSTAGE(ptr, dep) ((void)0)
 #define RBF_DONE(arr, i0, i1) ((void)0)
 #define RBF_BLU(pp, nu, r, u, blu) RBF_(blu_row)(pp, nu, r, u)
 #endif
@@ -78,7 +78,6 @@ typedef const llpf_rbf_par* llpf_rbf_cptr;
 #undef RBF_LOG
 #undef RBF_STAGE
 #undef RBF_FENCE
-#undef RBF_SUBSTAGE
 #undef RBF_BLU
 #undef RBF_DONE
 #undef RBF_CPTR

@@ -30,7 +30,6 @@ LLPF_HD void RBF_(coupling_row)(llpf_rbf_cptr p, const int nn, const int nl, con
     for (int c = 0; c < nl; ++c) a[c] = p->An[0][r * nl + c];
     LLPF_UNROLL
     for (int k = 0; k < nn; ++k) {
-        RBF_SUBSTAGE(p, a[nl - 1]);
         LLPF_UNROLL
         for (int c = 0; c < nl; ++c) a[c] = llpf_fma(xn[k], p->An[1 + k][r * nl + c], a[c]);
     }
@@ -118,8 +117,8 @@ LLPF_HD double RBF_(blu_row)(llpf_rbf_cptr p, const int nu, const int r, const d
 LLPF_HD void RBF_(predict)(const llpf_rbf_par* p, const int nn, const int nl, const int nu, const double* xn,
                            const double* xl, const double* R, const double* u, const double* blu, const double* fi,
                            const double* nz, double* xn1, double* xl1, double* R1) {
-    llpf_rbf_cptr pp = RBF_CPTR(p);
-    (void)blu;
+    llpf_rbf_cptr pp = RBF_CPTR(p), pp_nx = RBF_CPTR(p);
+    (void)blu; (void)pp_nx;
     double Rt[LLPF_RBF_NP(LLPF_RBF_MAXL)];                       /* R, then R~ */
     double AnR[LLPF_RBF_MAXN * LLPF_RBF_MAXL];                   /* An R; column c becomes row c of V */
     double Nt[LLPF_RBF_MAXN * LLPF_RBF_MAXN], Lc[LLPF_RBF_MAXN * LLPF_RBF_MAXN], invd[LLPF_RBF_MAXN];
@@ -272,7 +271,8 @@ LLPF_HD void RBF_(predict)(const llpf_rbf_par* p, const int nn, const int nl, co
  * xl and R (packed lower triangle) are updated in place. */
 LLPF_HD double RBF_(correct)(const llpf_rbf_par* p, const int nl, const int ny, const double* y, const double* yn,
                              double* xl, double* R) {
-    llpf_rbf_cptr pp = RBF_CPTR(p);
+    llpf_rbf_cptr pp = RBF_CPTR(p), pp_nx = RBF_CPTR(p);
+    (void)pp_nx;
     double e[LLPF_RBF_MAXY], CR[LLPF_RBF_MAXY * LLPF_RBF_MAXL], raw[LLPF_RBF_MAXY * LLPF_RBF_MAXY];
     double Lc[LLPF_RBF_MAXY * LLPF_RBF_MAXY], invd[LLPF_RBF_MAXY], K[LLPF_RBF_MAXL * LLPF_RBF_MAXY];
     RBF_STAGE(pp, R[0]);
