@@ -24,28 +24,34 @@ __global__ __launch_bounds__(RBF_BLOCK) __attribute__((amdgpu_waves_per_eu(NL >=
     const int f = blockIdx.y;
     const ModelD* md = models + f;
     const FilterScal* sc = scal + f;
-    if (run_is_stopped(b, a.k)) return;
-    if (a.only_fallback ? !sc->fallback : (sc->fallback != 0)) return;
+#if defined(LLPF_RBF_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+    RBF_STAMP(0);
+    { uint32_t hw_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_)); g_rbf_dbg[(size_t)blockIdx.x * 16 + 13] = hw_; }
+#endif
+    // everything the prologue reads is REQUESTED first and tested afterwards (as in k_step): tested one by one, the stop flag, the
+    // fallback flag and the scalars were eight scalar-cache round trips in a row in front of the gather
+    const uint32_t stop_flag = *b.bank_flag;
+    const int fb_flag = sc->fallback;
     const int do_res = (MODE != MODE_WEIGHT) ? sc->do_resample : 0;
     const int uniform = sc->uniform, pend = sc->norm_pending;
-    const double m = sc->m, l = sc->l, wconst = sc->wconst;
+    const double m = sc->m, l = sc->l, wconst = sc->wconst, wmax_prev = sc->wmax;
     const uint32_t k0 = sc->k0, k1 = sc->k1, sb = sc->step_base;
     const int64_t Ns = b.Ns, N = b.N;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : : "s"(stop_flag), "s"(fb_flag), "s"(do_res), "s"(uniform), "s"(pend), "s"(m), "s"(l), "s"(wconst), "s"(wmax_prev), "s"(k0), "s"(k1),
+                 "s"(sb), "s"(Ns), "s"(N), "s"(a.k), "s"(a.only_fallback), "s"(a.has_y), "s"(a.step));
+    asm volatile("" : : "s"(b.nu), "s"(b.log1N), "s"(b.anc_slot), "s"(b.F), "s"(a.next_step), "s"(a.parity), "s"(a.K), "s"(a.need_e2), "s"(a.accumulate),
+                 "s"(a.t_prop), "s"(b.anc), "s"(b.xcur), "s"(b.xnext), "s"(b.w), "s"(b.quanta_next), "s"(b.acc), "s"(b.tileq), "s"(a.u), "s"(a.y));
+#endif
+    if (stop_flag != 0 && (int64_t)(stop_flag - 1) < a.k) return;          // run_is_stopped
+    if (a.only_fallback ? !fb_flag : (fb_flag != 0)) return;
     const double* __restrict__ xc = b.xcur + (size_t)f * ROWS * Ns;
     double* __restrict__ xo = (MODE == MODE_WEIGHT) ? const_cast<double*>(xc) : b.xnext + (size_t)f * ROWS * Ns;
     double* w = b.w + (size_t)f * Ns;
     const llpf_rbf_par* par = &md->rbf;
 
-    Model model;
-    model.prepare(md, a.u, a.t_prop);
-    // Bl u is particle-independent and nu a run-time number: formed once per wave, read back by the time update from LDS
-    // (as a branch inside the unrolled body it cut the body into blocks that each kept their constants' SGPRs alive)
-    __shared__ double sh_blu[LLPF_RBF_MAXL];
-    if (MODE != MODE_WEIGHT) {
-        if (threadIdx.x < NL) sh_blu[threadIdx.x] = llpf_rbf_blu_row(RBF_KCPTR(par), b.nu, (int)threadIdx.x, a.u);
-        __syncthreads();
-    }
-
+    // The gather first: its HBM latency (~2 us) is what everything below waits for, so the particle-independent work of the
+    // prologue is placed behind the loads' issue, not in front of it.
     const int64_t i = (int64_t)blockIdx.x * RBF_BLOCK + threadIdx.x;
     const int64_t src = do_res ? (int64_t)b.anc[(size_t)f * Ns + i] : i;
     // 32-bit byte offsets from ONE uniform base per buffer (48 planes: 64-bit addresses would hold 96 registers and cost two
@@ -61,11 +67,28 @@ __global__ __launch_bounds__(RBF_BLOCK) __attribute__((amdgpu_waves_per_eu(NL >=
 #pragma unroll
     for (int d = 0; d < NP; ++d) R[d] = ld(NN + NL + d, so);
 
+    Model model;
+    model.prepare(md, a.u, a.t_prop);
+    // Bl u is particle-independent and nu a run-time number: formed once per wave, read back by the time update from LDS
+    // (as a branch inside the unrolled body it cut the body into blocks that each kept their constants' SGPRs alive)
+    __shared__ double sh_blu[LLPF_RBF_MAXL];
+    if (MODE != MODE_WEIGHT) {
+#pragma unroll
+        for (int r = 0; r < NL; ++r) {      // uniform addresses only: the parameter pointer must stay scalar (RBF_STAGE takes it in SGPRs)
+            const double v = llpf_rbf_blu_row(RBF_KCPTR(par), b.nu, r, a.u);
+            if (threadIdx.x == 0) sh_blu[r] = v;
+        }
+        __syncthreads();
+    }
+
     if (MODE != MODE_WEIGHT) {
         double fi[NN], xi[NN], nz[NN], xn1[NN], xl1[NL], R1[NP];
         model.dynamics(xn, fi);
         llpf_normals((uint32_t)i, sb + a.step, LLPF_STREAM_DYNAMICS, k0, k1, NN, xi);
         gauss_sample<NN>(md->df, xi, nz);
+#if defined(LLPF_RBF_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : : "v"(fi[NN - 1]), "v"(nz[NN - 1]));      // RK4 and the generator are done before stamp 1
+#endif
         llpf_rbf_predict(par, NN, NL, b.nu, xn, xl, R, a.u, sh_blu, fi, nz, xn1, xl1, R1);
 #pragma unroll
         for (int d = 0; d < NN; ++d) xn[d] = xn1[d];
@@ -82,7 +105,7 @@ __global__ __launch_bounds__(RBF_BLOCK) __attribute__((amdgpu_waves_per_eu(NL >=
     uint64_t qsum = 0;
     if (MODE != MODE_PROP) {
         wacc.init();
-        const double wmx = do_res ? b.log1N : (uniform ? wconst : sc->wmax);
+        const double wmx = do_res ? b.log1N : (uniform ? wconst : wmax_prev);
         off = a.has_y ? (wmx + md->dg.c0) + RBF_BOUND_SLACK : wmx;
         double wv;
         if (do_res) wv = b.log1N;                                 // reset_weights!
@@ -94,6 +117,10 @@ __global__ __launch_bounds__(RBF_BLOCK) __attribute__((amdgpu_waves_per_eu(NL >=
             for (int k = 0; k < NY; ++k) y[k] = a.y[k];
             model.measurement(xn, yn);
             wv = wv + llpf_rbf_correct(par, NL, NY, y, yn, xl, R);   // w[i] += ll, src/rbpf.jl:272
+#if defined(LLPF_RBF_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" : : "v"(wv));
+            RBF_STAMP(11);
+#endif
         }
         if (i >= N) wv = -LLPF_INF;                                // padding lanes carry zero weight
         w[i] = wv;
@@ -131,6 +158,9 @@ __global__ __launch_bounds__(RBF_BLOCK) __attribute__((amdgpu_waves_per_eu(NL >=
             }
         }
     }
+#if defined(LLPF_RBF_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+    RBF_STAMP(12);
+#endif
     if (MODE != MODE_WEIGHT && blockIdx.x == 0 && threadIdx.x == 0) {
         FilterScal* scw = b.scal + f;
         scw->anc_ident_s[b.anc_slot ^ 1] = do_res ? 0 : 1;

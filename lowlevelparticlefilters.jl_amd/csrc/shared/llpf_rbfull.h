@@ -42,6 +42,9 @@ typedef struct llpf_rbf_par {
 LLPF_HD int llpf_rbf_idx(int r, int c) { return r >= c ? r * (r + 1) / 2 + c : c * (c + 1) / 2 + r; }
 
 #define RBF_(name) llpf_rbf_##name
+#ifndef RBF_STAMP
+#define RBF_STAMP(k) ((void)0)      /* tools/rbfull_probe.hip defines it: cycle stamps at the stage boundaries */
+#endif
 #define RBF_SQRT(x) llpf_sqrt(x)
 #define RBF_LOG(x) llpf_log(x)
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -50,13 +53,7 @@ LLPF_HD int llpf_rbf_idx(int r, int c) { return r >= c ? r * (r + 1) / 2 + c : c
  * can neither be hoisted above the point where `dep` is computed nor merged with earlier loads (llpf_rbfull_body.h, "Stages"). */
 typedef const __attribute__((address_space(4))) llpf_rbf_par* llpf_rbf_cptr;
 #define RBF_CPTR(p) ((llpf_rbf_cptr)(p))
-#ifndef LLPF_RBF_NO_AHEAD
-/* ... one stage AHEAD: a stage reads through the pointer made opaque at the start of the stage before it, so its scalar loads
- * can be in flight while that stage computes (a lone s_load waits ~200 cycles, and there are ~45 stages) */
-#define RBF_STAGE(ptr, dep) do { const double rbf_dep_ = (dep); ptr = ptr##_nx; asm volatile("" : "+s"(ptr##_nx) : "v"(rbf_dep_)); } while (0)
-#else
 #define RBF_STAGE(ptr, dep) do { const double rbf_dep_ = (dep); asm volatile("" : "+s"(ptr) : "v"(rbf_dep_)); } while (0)
-#endif
 #define RBF_BLU(pp, nu, r, u, blu) ((blu)[r])
 /* every element of arr[i0, i1) is computed before the next stage begins: the stage's own `dep` orders only the chain that
  * value hangs on, and the compiler postponed the other rows of a stage to the end of the body — with every stage's pointer

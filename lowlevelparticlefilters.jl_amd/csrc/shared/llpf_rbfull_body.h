@@ -110,6 +110,9 @@ LLPF_HD double RBF_(blu_row)(llpf_rbf_cptr p, const int nu, const int r, const d
         }                                                                                                            \
     }
 #define RBF_MIN(a, b) ((a) < (b) ? (a) : (b))
+#ifndef RBF_RPS
+#define RBF_RPS 2      /* rows of Al per stage */
+#endif
 
 /* Time update of one particle — src/rbpf.jl:206-221 (An != 0 branch, !singleR), in the form of the header comment.
  * fi = f_n(xn, u, p, t) and nz ~ R1n come from the caller.  R, R1: packed lower triangles (may alias: R is copied first).
@@ -117,8 +120,8 @@ LLPF_HD double RBF_(blu_row)(llpf_rbf_cptr p, const int nu, const int r, const d
 LLPF_HD void RBF_(predict)(const llpf_rbf_par* p, const int nn, const int nl, const int nu, const double* xn,
                            const double* xl, const double* R, const double* u, const double* blu, const double* fi,
                            const double* nz, double* xn1, double* xl1, double* R1) {
-    llpf_rbf_cptr pp = RBF_CPTR(p), pp_nx = RBF_CPTR(p);
-    (void)blu; (void)pp_nx;
+    llpf_rbf_cptr pp = RBF_CPTR(p);
+    (void)blu;
     double Rt[LLPF_RBF_NP(LLPF_RBF_MAXL)];                       /* R, then R~ */
     double AnR[LLPF_RBF_MAXN * LLPF_RBF_MAXL];                   /* An R; column c becomes row c of V */
     double Nt[LLPF_RBF_MAXN * LLPF_RBF_MAXN], Lc[LLPF_RBF_MAXN * LLPF_RBF_MAXN], invd[LLPF_RBF_MAXN];
@@ -126,6 +129,7 @@ LLPF_HD void RBF_(predict)(const llpf_rbf_par* p, const int nn, const int nl, co
     const int np = LLPF_RBF_NP(nl);
     LLPF_UNROLL
     for (int d = 0; d < np; ++d) Rt[d] = R[d];
+    RBF_STAMP(1);
     LLPF_UNROLL
     for (int r = 0; r < nn; ++r) {                              /* one row of An(xn) at a time */
         double a[LLPF_RBF_MAXL];
@@ -154,6 +158,7 @@ LLPF_HD void RBF_(predict)(const llpf_rbf_par* p, const int nn, const int nl, co
         RBF_DONE(Nt, r * nn, r * nn + r + 1);
         RBF_DONE(ax, r, r + 1);
     }
+    RBF_STAMP(2);
     LLPF_UNROLL
     for (int i = 0; i < nn; ++i) {                              /* Nt = Lc Lc' */
         LLPF_UNROLL
@@ -204,49 +209,54 @@ LLPF_HD void RBF_(predict)(const llpf_rbf_par* p, const int nn, const int nl, co
             for (int c = 0; c <= r; ++c) Rt[llpf_rbf_idx(r, c)] = llpf_fma(-AnR[j * nl + r], AnR[j * nl + c], Rt[llpf_rbf_idx(r, c)]);
         }
     }
+    RBF_STAMP(3);
     {   /* xl1 = Al x~l + Bl u ; R1 = Al R~ Al' + R1l.  The covariance goes by halves of Al (upper-left block from the upper
          * panel M = Al[0:ht] R~, lower-left block from the same panel against the lower rows of Al, then the lower panel and
          * the lower-right block), and every piece by pairs of rows of Al: 16 constants per stage. */
         const int ht = (nl + 1) / 2;
         double M[((LLPF_RBF_MAXL + 1) / 2) * LLPF_RBF_MAXL];
         LLPF_UNROLL
-        for (int r0 = 0; r0 < nl; r0 += 2) {
+        for (int r0 = 0; r0 < nl; r0 += RBF_RPS) {
             RBF_STAGE(pp, r0 == 0 ? Rt[np - 1] : xl1[r0 - 1]);
-            RBF_MEAN(r0, RBF_MIN(r0 + 2, nl))
-            RBF_DONE(xl1, r0, RBF_MIN(r0 + 2, nl));
+            RBF_MEAN(r0, RBF_MIN(r0 + RBF_RPS, nl))
+            RBF_DONE(xl1, r0, RBF_MIN(r0 + RBF_RPS, nl));
         }
+        RBF_STAMP(4);
         LLPF_UNROLL
-        for (int r0 = 0; r0 < ht; r0 += 2) {                    /* M = Al[0:ht, :] R~ */
+        for (int r0 = 0; r0 < ht; r0 += RBF_RPS) {                    /* M = Al[0:ht, :] R~ */
             RBF_STAGE(pp, r0 == 0 ? xl1[nl - 1] : M[r0 * nl - 1]);
-            RBF_PANEL(M, 0, r0, RBF_MIN(r0 + 2, ht))
-            RBF_DONE(M, r0 * nl, RBF_MIN(r0 + 2, ht) * nl);
+            RBF_PANEL(M, 0, r0, RBF_MIN(r0 + RBF_RPS, ht))
+            RBF_DONE(M, r0 * nl, RBF_MIN(r0 + RBF_RPS, ht) * nl);
         }
         LLPF_UNROLL
-        for (int c0 = 0; c0 < ht; c0 += 2) {                    /* upper-left block */
+        for (int c0 = 0; c0 < ht; c0 += RBF_RPS) {                    /* upper-left block */
             RBF_STAGE(pp, c0 == 0 ? M[ht * nl - 1] : R1[llpf_rbf_idx(ht - 1, c0 - 1)]);
-            RBF_OUT_COLS(M, 0, c0, RBF_MIN(c0 + 2, ht), 0, ht)
+            RBF_OUT_COLS(M, 0, c0, RBF_MIN(c0 + RBF_RPS, ht), 0, ht)
             RBF_DONE(R1, 0, LLPF_RBF_NP(ht));
         }
+        RBF_STAMP(5);
         if (ht < nl) {
             LLPF_UNROLL
-            for (int r0 = ht; r0 < nl; r0 += 2) {               /* lower-left block */
+            for (int r0 = ht; r0 < nl; r0 += RBF_RPS) {               /* lower-left block */
                 RBF_STAGE(pp, r0 == ht ? R1[llpf_rbf_idx(ht - 1, ht - 1)] : R1[llpf_rbf_idx(r0 - 1, ht - 1)]);
-                RBF_OUT_ROWS(M, r0, RBF_MIN(r0 + 2, nl))
+                RBF_OUT_ROWS(M, r0, RBF_MIN(r0 + RBF_RPS, nl))
                 LLPF_UNROLL
-                for (int r = r0; r < RBF_MIN(r0 + 2, nl); ++r) RBF_DONE(R1, llpf_rbf_idx(r, 0), llpf_rbf_idx(r, 0) + ht);
+                for (int r = r0; r < RBF_MIN(r0 + RBF_RPS, nl); ++r) RBF_DONE(R1, llpf_rbf_idx(r, 0), llpf_rbf_idx(r, 0) + ht);
             }
             RBF_FENCE(R1[llpf_rbf_idx(nl - 1, ht - 1)]);
+            RBF_STAMP(6);
             LLPF_UNROLL
-            for (int r0 = ht; r0 < nl; r0 += 2) {               /* M = Al[ht:nl, :] R~ */
+            for (int r0 = ht; r0 < nl; r0 += RBF_RPS) {               /* M = Al[ht:nl, :] R~ */
                 RBF_STAGE(pp, r0 == ht ? R1[llpf_rbf_idx(nl - 1, ht - 1)] : M[(r0 - ht) * nl - 1]);
-                RBF_PANEL(M, ht, r0, RBF_MIN(r0 + 2, nl))
-                RBF_DONE(M, (r0 - ht) * nl, (RBF_MIN(r0 + 2, nl) - ht) * nl);
+                RBF_PANEL(M, ht, r0, RBF_MIN(r0 + RBF_RPS, nl))
+                RBF_DONE(M, (r0 - ht) * nl, (RBF_MIN(r0 + RBF_RPS, nl) - ht) * nl);
             }
             RBF_FENCE(M[(nl - ht) * nl - 1]);
+            RBF_STAMP(7);
             LLPF_UNROLL
-            for (int c0 = ht; c0 < nl; c0 += 2) {               /* lower-right block */
+            for (int c0 = ht; c0 < nl; c0 += RBF_RPS) {               /* lower-right block */
                 RBF_STAGE(pp, c0 == ht ? M[(nl - ht) * nl - 1] : R1[llpf_rbf_idx(nl - 1, c0 - 1)]);
-                RBF_OUT_COLS(M, ht, c0, RBF_MIN(c0 + 2, nl), ht, nl)
+                RBF_OUT_COLS(M, ht, c0, RBF_MIN(c0 + RBF_RPS, nl), ht, nl)
                 RBF_DONE(R1, LLPF_RBF_NP(ht), np);
             }
         }
@@ -257,6 +267,7 @@ LLPF_HD void RBF_(predict)(const llpf_rbf_par* p, const int nn, const int nl, co
             for (int d = d0; d < RBF_MIN(d0 + 12, np); ++d) R1[d] = R1[d] + pp->R1l[d];
             RBF_DONE(R1, d0, RBF_MIN(d0 + 12, np));
         }
+        RBF_STAMP(8);
     }
 }
 #undef RBF_PANEL
@@ -271,11 +282,11 @@ LLPF_HD void RBF_(predict)(const llpf_rbf_par* p, const int nn, const int nl, co
  * xl and R (packed lower triangle) are updated in place. */
 LLPF_HD double RBF_(correct)(const llpf_rbf_par* p, const int nl, const int ny, const double* y, const double* yn,
                              double* xl, double* R) {
-    llpf_rbf_cptr pp = RBF_CPTR(p), pp_nx = RBF_CPTR(p);
-    (void)pp_nx;
+    llpf_rbf_cptr pp = RBF_CPTR(p);
     double e[LLPF_RBF_MAXY], CR[LLPF_RBF_MAXY * LLPF_RBF_MAXL], raw[LLPF_RBF_MAXY * LLPF_RBF_MAXY];
     double Lc[LLPF_RBF_MAXY * LLPF_RBF_MAXY], invd[LLPF_RBF_MAXY], K[LLPF_RBF_MAXL * LLPF_RBF_MAXY];
     RBF_STAGE(pp, R[0]);
+    RBF_STAMP(9);
     LLPF_UNROLL
     for (int i = 0; i < ny; ++i) {
         double a = pp->Cl[i * nl] * xl[0];
@@ -339,6 +350,7 @@ LLPF_HD double RBF_(correct)(const llpf_rbf_par* p, const int nl, const int ny, 
             quad = llpf_fma(z[i], z[i], quad);
         }
     }
+    RBF_STAMP(10);
     LLPF_UNROLL
     for (int r = 0; r < nl; ++r) {                              /* row r of K solves k S = (R C')[r,:] */
         double t[LLPF_RBF_MAXY];
