@@ -295,6 +295,8 @@ def main_bank(args, rank, world, dev):
             cs = args.cpu_steps if args.cpu_steps else 1000
             out.update(cpu_baseline(models[len(models) // 2], U, Y, S.PARTICLE_FILTER, thr, N, min(cs, T), 77, None))
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+        if world == 1 and args.workload == "lg" and not args.no_other_configs and not args.no_cpu_baseline and args.particles == 1000000 and not args.T:
+            out["other_configs"] = other_configs()
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
@@ -329,6 +331,23 @@ def main_reference_mc(args, rank, world):
         out["cpu_baseline"] = r["cpu_baseline"]
         out["speedup_vs_cpu_baseline"] = r["speedup_vs_cpu_baseline"]
     print(json.dumps(out))
+
+
+def other_configs():
+    """The default line also carries the other single-GPU BASELINE configs, each from a short run of this same script (2 timed
+    passes, no CPU baseline) with its own roofline block: C3 quad-tank (N = 1e6, T = 2000), one GPU's share of C4 (128 filters x
+    1e5), C5 RBPF with per-particle covariance (N = 2e5).  Their full lines (with the CPU baseline) are `--workload ...`."""
+    import subprocess
+    res = {}
+    for key, wl in (("C3_quadtank", "quadtank"), ("C4_share_128x1e5", "bank"), ("C5_rbpf_full", "rbpf_full")):
+        try:
+            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", wl, "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                               capture_output=True, text=True, timeout=300)
+            d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+            res[key] = {k: d.get(k) for k in ("metric", "value", "unit", "steps", "ms_per_step", "dtype", "config", "kernel_us", "roofline") if k in d}
+        except Exception as e:      # a failed side run must not cost the headline line
+            res[key] = {"error": repr(e)[:300]}
+    return res
 
 
 def engine_source_hash():
@@ -408,6 +427,8 @@ def main():
     ap.add_argument("--T", type=int, default=None)
     ap.add_argument("--threshold", type=float, default=None, help="resample_threshold override")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="default C2 line only: skip the short runs of the other BASELINE configs (C3, one GPU's share of C4, C5) that it carries as `other_configs`")
     ap.add_argument("--cpu-steps", type=int, default=None, help="timesteps of the CPU baseline sample")
     ap.add_argument("--rccl-timeout", type=float, default=120.0,
                     help="N > 1: seconds the in-library RCCL communicator and its first all-reduce may take before the run falls back "
@@ -551,7 +572,7 @@ def main():
             # k_rbfull reads ancestor 4 + gathers 8 rows + writes 8 rows + writes w 8; whole timestep adds the k_norm /
             # k_resample traffic of SURVEY 8(d): B_alg = 16 rows + 40
             rows = nx + model.rb.nxl + model.rb.nxl * (model.rb.nxl + 1) // 2
-            b_step = b_model = 16 * rows + 12
+            b_step = b_model = 16 * rows + 12 + (8 if not n_cls[1] else 0)      # + its quanta when it forms the exp-sums itself
             b_alg = 16 * rows + 40
             names[0] = "k_rbfull(gather RBParticle + Riccati time update + Kalman measurement update + weight)"
             kernel_us = {names[i]: (1e3 * ms_cls[i] / n_cls[i] if n_cls[i] else None) for i in range(4)}
@@ -577,10 +598,10 @@ def main():
                                    "achieved": N * b_alg / timestep_s / 1e9, "frac": N * b_alg / timestep_s / 8e12}}
         if rbfull:
             # fp64 work of one particle-step counted from csrc/shared/llpf_rbfull_body.h at (nxn, nxl, ny) = (4, 8, 2):
-            # time update ~1910 fma (An(xn) 128, An R 256, Nt 80, per row: Al R 64 + Al (An R)' 32 + solve 6, lower triangle of
-            # Al R Al' - W W' 36 x 12, means 150), measurement update ~400 fma (C R 128, S 32, K 48, R - K C R 144, ...),
+            # time update ~1700 fma (An(xn) 128, An xl 32, An R 256, Nt 80, Cholesky + V 110, x~l 32, R~ = R - V V' 144, Al x~l + Bl u 80,
+            # two panels Al R~ 512, the three blocks of M Al' 288, R1l 36), measurement update ~420 fma (C R 128, S 32, K 48, R - K C R 144, ...),
             # RK4 x 2 of the quad-tank ~730 flop
-            flop = 2.0 * 2310 + 730.0
+            flop = 2.0 * 2120 + 730.0
             roof["compute"] = {"fp64_flop_per_particle_step": flop, "achieved_tflops": N * flop / step_s / 1e12,
                                "peak_tflops": 78.6, "frac": N * flop / step_s / 78.6e12}
         if args.workload == "quadtank":
@@ -631,9 +652,12 @@ def main():
                 # ancestor mismatches against the reference order at full size, teacher forced (tests/gpu_common.py)
                 from gpu_common import teacher_forced_ancestor_mismatches
                 tf = teacher_forced_ancestor_mismatches(cfg, U, Y, min(50, T - 1))
-                tf["note"] = ("before every predict! the reference-order oracle's state is installed in the engine; both resample and propagate "
-                              "with the same Philox draws; %d x %d ancestor decisions compared" % (tf["resampling_steps"], N))
+                tf["note"] = ("before every correct! and every predict! the reference-order oracle's state is installed in the engine; both take the "
+                              "step with the same measurement / Philox draws; %d x %d ancestor decisions and %d log-likelihood increments compared "
+                              "(tolerance: |dll| <= 1e-10, exp-weights rel <= 1e-12)" % (tf["resampling_steps"], N, tf["correct_steps"]))
                 out["accuracy"]["ancestor_mismatches_vs_reference_order"] = tf
+        if world == 1 and args.workload == "lg" and not args.no_other_configs and not args.no_cpu_baseline and args.particles == 1000000 and not args.T:
+            out["other_configs"] = other_configs()
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

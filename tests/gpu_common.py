@@ -27,26 +27,38 @@ def compare_state(g, o, exact=True, we_rtol=0.0):
 
 
 def teacher_forced_ancestor_mismatches(cfg, U, Y, steps, t_index0=1.0):
-    """ancestor mismatches of the engine against the REFERENCE-ORDER oracle (serial fp64 cumsum, two-pointer search:
-    src/resample.jl:17-36) at full size.  A particle filter is chaotic in its ancestry, so the two are compared step by step from the
-    SAME state: before every predict! the reference-order state (particles, normalised log-weights) is installed in the engine
-    (llpf_set_particles / llpf_set_weights), both sides run predict!(u_k) with the same Philox draws, the ancestor vectors and the
-    propagated particles are compared, and the oracle alone carries the recursion on (correct! with y_{k+1}).
-    Returns dict(steps, resampling_steps, mismatches_total, mismatches_per_step_max, steps_with_mismatch, particles_equal_on_matching_ancestors)."""
+    """the engine against the REFERENCE-ORDER oracle (libm exp, pairwise sum, serial fp64 cumsum, two-pointer search:
+    src/utils.jl:18-27, src/resample.jl:17-36) at full size.  A particle filter is chaotic in its ancestry, so the two are compared
+    step by step from the SAME state: the reference-order state (particles, log-weights) is installed in the engine
+    (llpf_set_particles / llpf_set_weights) before every correct! and again before every predict!; both sides then take that step
+    with the same measurement / the same Philox draws, and the oracle alone carries the recursion on.  Compared: the log-likelihood
+    increment and the normalised exp-weights of every correct! (the stated fp64 tolerance: |dll| <= 1e-10, rel <= 1e-12), the
+    ancestor vectors of every resampling predict!, and the propagated particles of every output whose ancestor agrees.
+    Returns dict(steps, resampling_steps, mismatches_total, mismatches_per_step_max, steps_with_mismatch,
+    particles_equal_on_matching_ancestors, correct_steps, ll_abs_err_max, expweights_rel_err_max)."""
     import oracle_binding as ob
     from llpf_amd import _capi
     g = _capi.FilterHandle(cfg)
     r = ob.OracleFilter(cfg, ob.ORDER_REFERENCE)
     g.reset(); r.reset()
     Ts = cfg.model.Ts
-    tot = worst = nsteps = nres = 0
+    tot = worst = nsteps = nres = ncorr = 0
     same_x = True
+    dll = dwe = 0.0
     for k in range(steps):
         t = (t_index0 + k) * Ts
         u = U[k] if U is not None and len(U) else None
-        r.correct(u, Y[k], t)
-        g.set_particles(r.particles())
+        g.set_particles(r.particles())              # correct! from the same state on both sides
         g.set_weights(r.weights())
+        ll_g = g.correct(u, Y[k], t)
+        ll_r = r.correct(u, Y[k], t)
+        if not np.any(np.isnan(Y[k])):
+            ncorr += 1
+            dll = max(dll, abs(ll_g - ll_r))
+            eg, er = g.expweights(), r.expweights()
+            nz = er > 1e-290
+            dwe = max(dwe, float(np.max(np.abs(eg[nz] - er[nz]) / er[nz])))
+        g.set_weights(r.weights())                  # predict! from the same state (particles are unchanged by correct!)
         g.predict(u, t)
         r.predict(u, t)
         if not r.last_resampled():
@@ -62,4 +74,5 @@ def teacher_forced_ancestor_mismatches(cfg, U, Y, steps, t_index0=1.0):
         xg, xr = g.particles(), r.particles()
         same_x = same_x and bool(np.array_equal(xg[~diff], xr[~diff]))
     return {"steps": int(steps), "resampling_steps": int(nres), "mismatches_total": int(tot), "mismatches_per_step_max": int(worst),
-            "steps_with_mismatch": int(nsteps), "particles_equal_on_matching_ancestors": same_x}
+            "steps_with_mismatch": int(nsteps), "particles_equal_on_matching_ancestors": same_x,
+            "correct_steps": int(ncorr), "ll_abs_err_max": float(dll), "expweights_rel_err_max": float(dwe)}

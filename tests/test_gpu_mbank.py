@@ -72,6 +72,44 @@ def test_shards_sharing_the_device_return_the_unsharded_bits(F, shards):
     assert _same_bits(mr.run(U, Y, 1.0)["ll"], br.run(U, Y, 1.0)["ll"])
 
 
+def test_c4_as_stated_1024_filters_over_8_shards():
+    """BASELINE config C4 at its stated shape — 1024 independent linear-Gaussian filters x N = 1e5 over EIGHT shards (folded onto
+    the one device of this box: the host-summed exchange) — returns the bits of the unsharded 1024-filter bank, and three of its
+    filters (first, middle, the last: shard 7, Philox key seed + 1023) the device-order ORACLE's.  Reference layout: one filter
+    per parameter value, `map(svec) do s ... loglik(pfs, u, y) end` (test/runtests.jl:412-417)."""
+    import oracle_binding as ob
+    F, N, T = 1024, 100000, 10
+    svec = 10.0 ** np.linspace(-2, 0, F)
+    models = [M.lg_test_model(s) for s in svec]
+    _, U, Y = M.simulate_lg(M.lg_test_model(0.1), T)
+    cfg = S.make_config(models[0], N, S.PARTICLE_FILTER, S.RESAMPLE_SYSTEMATIC, 0.1, 4000, 0)
+    mb = _capi.MBankHandle(cfg, models, devices=[0] * 8)
+    info = mb.info()
+    assert info["n_shards"] == 8 and info["n_local_filters"] == F and info["collective"] == "host"
+    mb.reset()
+    rm = mb.run(U, Y, 1.0)
+    del mb
+    b = _capi.BankHandle(cfg, models)
+    b.reset()
+    rb = b.run(U, Y, 1.0)
+    del b
+    assert rm["ll"].shape == (F,) and _same_bits(rm["ll"], rb["ll"])
+    acc = 0.0
+    for v in rb["ll"]:                 # the library sums in index order (numpy's pairwise sum rounds differently at F = 1024)
+        acc += float(v)
+    assert rm["ll_sum"] == acc
+    ob.set_threads(16)
+    try:
+        for k in (0, 511, 1023):
+            ck = S.make_config(models[k], N, S.PARTICLE_FILTER, S.RESAMPLE_SYSTEMATIC, 0.1, 4000 + k, 0)
+            o = ob.OracleFilter(ck, ob.ORDER_DEVICE)
+            o.reset()
+            ro = o.run(U, Y, 1.0)
+            assert _same_bits(np.array([ro["ll"]]), np.array([rm["ll"][k]])), k
+    finally:
+        ob.set_threads(1)
+
+
 def test_reseeding_and_aux_runs_shard_too():
     cfg, models, U, Y = _sweep(F=6)
     b = _capi.BankHandle(cfg, models)

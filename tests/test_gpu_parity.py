@@ -834,6 +834,8 @@ def test_c2_full_size_ancestor_mismatches_against_the_reference_order():
     assert r["resampling_steps"] == 50
     assert r["mismatches_total"] <= 50 and r["mismatches_per_step_max"] <= 8, r
     assert r["particles_equal_on_matching_ancestors"]
+    # the stated fp64 tolerance at the BASELINE size: every correct! from the reference order's own state
+    assert r["correct_steps"] == 50 and r["ll_abs_err_max"] <= 1e-10 and r["expweights_rel_err_max"] <= 1e-12, r
 
 
 def test_c4_share_bank_against_the_oracle():

@@ -22,7 +22,7 @@ def counters(path, kernel):
     for line in open(path):
         if kernel in line:
             m = re.search(r"(FETCH_SIZE|WRITE_SIZE)\s+dispatches=\s*(\d+)\s+avg=\s*([\d.]+)", line)
-            if m:
+            if m and m.group(1) not in res:          # the first row that names the kernel
                 res[m.group(1)] = float(m.group(3))
     return res
 
@@ -46,7 +46,8 @@ j = {"engine_source_hash": engine_source_hash(),
 e = entry(os.path.join(d, "pmc_traffic.txt"), "k_resprop<llpf::LinGauss<2, 1>", 60 * N, {"algorithmic_bytes": 72 * N})
 if e:
     j["k_resprop"] = e
-e = entry(os.path.join(d, "pmc_traffic_c5.txt"), "k_rbfull", 780 * 200000)
+# "k_rbfull<": the template kernel, not k_rbfull_init (whose later row a bare substring match would return: round 2's summary did)
+e = entry(os.path.join(d, "pmc_traffic_c5.txt"), "k_rbfull<", 788 * 200000)
 if e:
     j["c5"] = {"source": "profiles/%s_pmc_traffic_c5.txt (same recipe, workload rbpf_full N=2e5, T=200)" % tag, "k_rbfull": e, "n_particles": 200000}
 e = entry(os.path.join(d, "pmc_traffic_quadtank.txt"), "k_step<llpf::QuadTank", 84 * N)
