@@ -308,3 +308,10 @@ struct QuadTank {   // reference examples/example_quadtank.jl:8-35 with rk4 of s
         out[1] = x[1];
     }
 };
+
+// Is f(x) expensive enough to be computed once per distinct ancestor of a block and handed to the outputs that share it
+// (k_step)?  Yes unless the model says otherwise: run-time compiled user models and the quad-tank's RK4 are; a matrix-vector
+// product is not.
+template <class Model> struct share_dynamics { static constexpr bool value = true; };
+template <int NX, int NY> struct share_dynamics<LinGauss<NX, NY>> { static constexpr bool value = false; };
+template <int NX, int NY> struct share_dynamics<RBLin<NX, NY>> { static constexpr bool value = false; };

@@ -10,6 +10,10 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
     __shared__ double sm_max[BLOCK / 64];
     __shared__ uint64_t sm_acc[BLOCK / 64][5];
     __shared__ double sm_x[BLOCK / 64][MAXD];
+    // dynamics shared between the outputs of one ancestor (below): models whose f is worth a table
+    constexpr bool SHARE = share_dynamics<Model>::value && !Model::RB && MODE != MODE_WEIGHT && MODE != MODE_AUX;
+    __shared__ int32_t sh_prev[SHARE ? BLOCK : 1], sh_run[SHARE ? BLOCK : 1], sh_wcnt[BLOCK / 64];
+    __shared__ double sh_fx[SHARE ? BLOCK : 1][NX];
     const int f = blockIdx.y;
     const ModelD* md = models + f;
     const FilterScal* sc = scal + f;
@@ -85,14 +89,64 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
         double xs[PPT][NX];
         if (MODE != MODE_WEIGHT) {
             double xp[PPT][NX];
+            double fsh[PPT][NX];          // f(x[ancestor]) taken from the block's table when the dynamics were shared
+            bool shared = false;          // block-uniform
             if (do_res) {
                 int32_t av[PPT];
                 if constexpr (PPT == 2) { const int2 a2 = *reinterpret_cast<const int2*>(anc + i0); av[0] = a2.x; av[1] = a2.y; }
                 else av[0] = anc[i0];
+                if constexpr (SHARE) {
+                    // x' = f(x[j]) + noise: outputs with the same ancestor share f(x[j]).  The ancestors of systematic / stratified /
+                    // (the copies of) residual resampling are sorted, so the block's distinct ancestors are the starts of its runs:
+                    // they are listed, the first D threads evaluate the dynamics once each, and every output reads its run's value
+                    // back — the same bits, D evaluations instead of BLOCK * PPT.  With a peaked likelihood (quad-tank, BASELINE C3:
+                    // ESS ~ 1e-3 N at every step) D is 1-3 per block and three of the four waves skip the RK4 altogether.
+                    const int t = (int)threadIdx.x;
+                    sh_prev[t] = av[PPT - 1];
+                    __syncthreads();
+                    const int32_t prev = t ? sh_prev[t - 1] : -1;
+                    int nw[PPT], c = 0;
+                    nw[0] = av[0] != prev ? 1 : 0;
 #pragma unroll
-                for (int d = 0; d < NX; ++d) {
+                    for (int p = 1; p < PPT; ++p) nw[p] = av[p] != av[p - 1] ? 1 : 0;
 #pragma unroll
-                    for (int p = 0; p < PPT; ++p) xp[p][d] = xc[(size_t)d * Ns + av[p]];
+                    for (int p = 0; p < PPT; ++p) c += nw[p];
+                    const int incl = (int)wave_scan_u64((uint64_t)c);
+                    if ((t & 63) == 63) sh_wcnt[t >> 6] = incl;
+                    __syncthreads();
+                    int base = 0, D = 0;
+#pragma unroll
+                    for (int k = 0; k < BLOCK / 64; ++k) { const int v = sh_wcnt[k]; base += (k < (t >> 6)) ? v : 0; D += v; }
+                    if (D <= BLOCK) {
+                        int rr = base + incl - c, run[PPT];
+#pragma unroll
+                        for (int p = 0; p < PPT; ++p) { rr += nw[p]; run[p] = rr - 1; if (nw[p]) sh_run[rr - 1] = av[p]; }
+                        __syncthreads();
+                        const int kq = t;       // (rotating the evaluating wave with the block index measured no different)
+                        if (kq < D) {
+                            const int32_t aj = sh_run[kq];
+                            double xq[NX], fq[NX];
+#pragma unroll
+                            for (int d = 0; d < NX; ++d) xq[d] = xc[(size_t)d * Ns + aj];
+                            model.dynamics(xq, fq);
+#pragma unroll
+                            for (int d = 0; d < NX; ++d) sh_fx[kq][d] = fq[d];
+                        }
+                        __syncthreads();
+#pragma unroll
+                        for (int p = 0; p < PPT; ++p) {
+#pragma unroll
+                            for (int d = 0; d < NX; ++d) fsh[p][d] = sh_fx[run[p]][d];
+                        }
+                        shared = true;
+                    }
+                }
+                if (!shared) {
+#pragma unroll
+                    for (int d = 0; d < NX; ++d) {
+#pragma unroll
+                        for (int p = 0; p < PPT; ++p) xp[p][d] = xc[(size_t)d * Ns + av[p]];
+                    }
                 }
             } else {
 #pragma unroll
@@ -108,7 +162,12 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
                     continue;
                 }
                 double fx[NX], xi[NX], nz[NX];
-                model.dynamics(xp[p], fx);
+                if (shared) {
+#pragma unroll
+                    for (int d = 0; d < NX; ++d) fx[d] = fsh[p][d];
+                } else {
+                    model.dynamics(xp[p], fx);
+                }
                 if (MODE == MODE_AUX) {            // propagate_particles!(pf, u, p, t, nothing): no noise
 #pragma unroll
                     for (int d = 0; d < NX; ++d) xs[p][d] = fx[d];
