@@ -164,6 +164,8 @@ struct BankDev {
     uint64_t* rtile;     // [F][2][P2] residual resampling: per-tile copy counts / residual sums, then their inclusive prefixes
     int32_t anc_slot;    // n_predict & 1: index of the current FilterScal::anc_ident_s entry
     int32_t pad0;
+    int32_t xrows;       // rows of one filter's particle plane: nx, or xn + xl + packed R for LLPF_MODEL_RB_BILINEAR (the stride between
+    int32_t pad1;        //   the filters of a bank in xcur / xnext; kernels that know the model use their own constant)
 };
 
 // MODE_AUX: first half of the AuxiliaryParticleFilter predict! (reference src/filtering.jl:195-205): noise-free

@@ -94,6 +94,7 @@ struct Bank {
         b.bank_flag = d_flag; b.xmpart = d_xmpart; b.lam = d_lam; b.rtile = d_rtile;
         b.anc_slot = (int32_t)(n_predict & 1u);
         b.pad0 = (cfg.model.model_id == LLPF_MODEL_RB_BILINEAR) ? (cfg.model.rb.nxl | (cfg.model.rb.fn_kind << 8)) : 0;
+        b.xrows = xrows; b.pad1 = 0;
         return b;
     }
     // for the layout conversions of the accessors: the first nxp rows of the plane are the particle [xn; xl]
@@ -236,7 +237,8 @@ static int bank_create(const llpf_config* cfg, const llpf_model* models, int F, 
     if (!step_supported(m0.model_id, m0.nx, m0.ny))
         return fail(LLPF_ERR_ARG, "no kernel instantiated for this model/dimension (linear-Gaussian nx,ny in 1..4; quad-tank 4/2)");
     if (m0.model_id == LLPF_MODEL_RB_BILINEAR) {
-        if (F != 1) return fail(LLPF_ERR_ARG, "LLPF_MODEL_RB_BILINEAR: single filters only (no banks)");
+        if ((uint64_t)rbfull_rows(m0.nx, m0.rb.nxl) * (uint64_t)((cfg->n_particles + TILE - 1) / TILE * TILE) * 8u >= ((uint64_t)1 << 32))
+            return fail(LLPF_ERR_ARG, "LLPF_MODEL_RB_BILINEAR: the planes of one filter (rows x particles x 8 bytes) must span less than 4 GB");
         if (!rbfull_supported(m0.rb.fn_kind, m0.nx, m0.rb.nxl, m0.ny))
             return fail(LLPF_ERR_ARG, "LLPF_MODEL_RB_BILINEAR: instantiated shapes (nxn, nxl, ny) are (1,2,1), (2,2,2), (4,8,2); quad-tank: (4,8,2)");
     }

@@ -60,6 +60,7 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
     // model with per-particle covariance takes them from a k_wmean launch per step over its [xn; xl] rows instead
     const int want_xm = (xmean && !is_rbfull(b)) ? 1 : 0;
     const bool xm_launch = xmean && is_rbfull(b);
+    if (xm_launch && b.F != 1) return fail(LLPF_ERR_ARG, "weighted means of a BANK of filters with per-particle covariance are not provided (run without xmean)");
     const int K = llpf_qbits(b.N);
     const int ne2 = need_e2(b);
     const bool hist = x_hist || w_hist || we_hist;

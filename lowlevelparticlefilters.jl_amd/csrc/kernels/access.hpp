@@ -39,14 +39,14 @@ __global__ __launch_bounds__(BLOCK) void k_soa2aos(BankDev b, const double* __re
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= b.N) return;
     for (int d = 0; d < b.nx; ++d)
-        dst[((size_t)f * b.N + i) * b.nx + d] = xsrc[((size_t)f * b.nx + d) * b.Ns + i];
+        dst[((size_t)f * b.N + i) * b.nx + d] = xsrc[((size_t)f * b.xrows + d) * b.Ns + i];
 }
 __global__ __launch_bounds__(BLOCK) void k_aos2soa(BankDev b, const double* __restrict__ src, double* xdst) {
     const int f = blockIdx.y;
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= b.Ns) return;
     for (int d = 0; d < b.nx; ++d)
-        xdst[((size_t)f * b.nx + d) * b.Ns + i] = (i < b.N) ? src[((size_t)f * b.N + i) * b.nx + d] : 0.0;
+        xdst[((size_t)f * b.xrows + d) * b.Ns + i] = (i < b.N) ? src[((size_t)f * b.N + i) * b.nx + d] : 0.0;
 }
 __global__ __launch_bounds__(BLOCK) void k_anc64(BankDev b, int64_t* dst) {
     const int f = blockIdx.y;
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(BLOCK) void k_wmean(BankDev b, double* out) {
     __shared__ double sm_x[BLOCK / 64][MAXD];
     const int f = blockIdx.x;
     const FilterScal* sc = b.scal + f;
-    const double* __restrict__ xc = b.xcur + (size_t)f * b.nx * b.Ns;
+    const double* __restrict__ xc = b.xcur + (size_t)f * b.xrows * b.Ns;
     double acc[MAXD];
 #pragma unroll
     for (int d = 0; d < MAXD; ++d) acc[d] = 0.0;

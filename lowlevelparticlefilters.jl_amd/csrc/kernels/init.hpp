@@ -12,7 +12,7 @@ __global__ __launch_bounds__(BLOCK) void k_init(BankDev b, const ModelD* __restr
     double xi[NX], x0[NX];
     llpf_normals((uint32_t)i, step, LLPF_STREAM_INIT, scal[f].k0, scal[f].k1, NX, xi);
     gauss_sample<NX>(md->d0, xi, x0);
-    double* xc = b.xcur + (size_t)f * NX * b.Ns;
+    double* xc = b.xcur + (size_t)f * b.xrows * b.Ns;      // NX rows are drawn; a Rao-Blackwellized particle has more (k_rbfull_init)
 #pragma unroll
     for (int d = 0; d < NX; ++d) xc[(size_t)d * b.Ns + i] = x0[d];
     b.w[(size_t)f * b.Ns + i] = -LLPF_INF;

@@ -67,15 +67,16 @@ __global__ __launch_bounds__(RBF_BLOCK) __attribute__((amdgpu_waves_per_eu(NL >=
 #pragma unroll
     for (int d = 0; d < NP; ++d) R[d] = ld(NN + NL + d, so);
 
+    const double* uf = a.u + (size_t)f * a.u_stride;       // banks on data of their own (llpf_bank_run_multi): filter f's row
     Model model;
-    model.prepare(md, a.u, a.t_prop);
+    model.prepare(md, uf, a.t_prop);
     // Bl u is particle-independent and nu a run-time number: formed once per wave, read back by the time update from LDS
     // (as a branch inside the unrolled body it cut the body into blocks that each kept their constants' SGPRs alive)
     __shared__ double sh_blu[LLPF_RBF_MAXL];
     if (MODE != MODE_WEIGHT) {
 #pragma unroll
         for (int r = 0; r < NL; ++r) {      // uniform addresses only: the parameter pointer must stay scalar (RBF_STAGE takes it in SGPRs)
-            const double v = llpf_rbf_blu_row(RBF_KCPTR(par), b.nu, r, a.u);
+            const double v = llpf_rbf_blu_row(RBF_KCPTR(par), b.nu, r, uf);
             if (threadIdx.x == 0) sh_blu[r] = v;
         }
         __syncthreads();
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(RBF_BLOCK) __attribute__((amdgpu_waves_per_eu(NL >=
 #if defined(LLPF_RBF_TIMING) && defined(__HIP_DEVICE_COMPILE__)
         asm volatile("" : : "v"(fi[NN - 1]), "v"(nz[NN - 1]));      // RK4 and the generator are done before stamp 1
 #endif
-        llpf_rbf_predict(par, NN, NL, b.nu, xn, xl, R, a.u, sh_blu, fi, nz, xn1, xl1, R1);
+        llpf_rbf_predict(par, NN, NL, b.nu, xn, xl, R, uf, sh_blu, fi, nz, xn1, xl1, R1);
 #pragma unroll
         for (int d = 0; d < NN; ++d) xn[d] = xn1[d];
 #pragma unroll
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(RBF_BLOCK) __attribute__((amdgpu_waves_per_eu(NL >=
         if (a.has_y) {
             double y[NY], yn[NY];
 #pragma unroll
-            for (int k = 0; k < NY; ++k) y[k] = a.y[k];
+            for (int k = 0; k < NY; ++k) y[k] = a.y[(size_t)f * a.y_stride + k];
             model.measurement(xn, yn);
             wv = wv + llpf_rbf_correct(par, NL, NY, y, yn, xl, R);   // w[i] += ll, src/rbpf.jl:272
 #if defined(LLPF_RBF_TIMING) && defined(__HIP_DEVICE_COMPILE__)

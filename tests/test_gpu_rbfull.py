@@ -123,8 +123,47 @@ def test_rbfull_api_and_errors():
     assert np.max(np.abs(R - R[0])) > 1e-6
     with pytest.raises(_capi.LLPFError):
         llpf_amd.smooth(pf, 10, U, Y)
-    with pytest.raises(_capi.LLPFError):                       # banks of this model are not provided
-        _capi.BankHandle(_cfg(model, 1000), [model, model])
     bad, _ = M.linear_case(2, 4, 2, seed=1)                    # a shape without an instantiated kernel
     with pytest.raises(_capi.LLPFError):
         _capi.FilterHandle(_cfg(bad, 1000))
+
+
+@pytest.mark.parametrize("name,N,T", [("lin_2_2_2", 3000, 30), ("quadtank_4_8_2", 20000, 12)])
+def test_bank_of_rb_filters(name, N, T):
+    """A parameter sweep over Rao-Blackwellized filters — BASELINE config C4's pattern applied to C5's model (reference:
+    `map(svec) do s ... loglik(pfs, u, y) end`, test/runtests.jl:412-417, over the filters of test/test_rbpf.jl:111-166): a bank of 8
+    filters with different measurement-noise levels returns, filter by filter, the bits of 8 single filters (key seed + k) and of the
+    device-order oracle, in both schedules (exp-sums inside k_rbfull / by k_norm), also sharded over two folded devices."""
+    import os
+    base = CASES[name]()
+    U, Y = M.simulate_io(base, T)
+    Y[3] = np.nan
+    models = []
+    for k in range(8):
+        m = type(base).from_buffer_copy(bytes(base))
+        cov = np.asarray(S.gaussian_cov_matrix(base.measurement_density))
+        m.measurement_density = S.make_gaussian(np.zeros(cov.shape[0]), cov * (0.5 + 0.25 * k))
+        models.append(m)
+    cfg = _cfg(base, N, S.RESAMPLE_SYSTEMATIC, 0.5, seed=40)
+    singles = []
+    for k in range(8):
+        g = _capi.FilterHandle(_cfg(models[k], N, S.RESAMPLE_SYSTEMATIC, 0.5, seed=40 + k))
+        g.reset()
+        singles.append(g.run(U, Y, 0.0, ll_steps=True)["ll_steps"])
+    for sched in ("merged", "split"):
+        os.environ["LLPF_SCHEDULE"] = sched
+        try:
+            b = _capi.BankHandle(cfg, models)
+            b.reset()
+            rb = b.run(U, Y, 0.0, ll_steps=True)
+        finally:
+            del os.environ["LLPF_SCHEDULE"]
+        for k in range(8):
+            assert _same_bits(rb["ll_steps"][:, k].copy(), singles[k]), (sched, k)
+    for k in (0, 7):
+        o = ob.OracleFilter(_cfg(models[k], N, S.RESAMPLE_SYSTEMATIC, 0.5, seed=40 + k), ob.ORDER_DEVICE)
+        o.reset()
+        assert _same_bits(o.run(U, Y, 0.0, ll_steps=True)["ll_steps"], singles[k]), k
+    mb = _capi.MBankHandle(cfg, models, devices=[0, 0])
+    mb.reset()
+    assert _same_bits(mb.run(U, Y, 0.0)["ll"], rb["ll"])
