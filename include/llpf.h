@@ -233,14 +233,24 @@ int  llpf_smooth(llpf_filter* f, int64_t M, const double* U, int64_t T, const do
  *                                              // m->A[64], m->B[64], m->C[64], m->qt[16], m->Ts, m->supersample, m->nu
  *         DEV void dynamics(const double* x, double* out) const;          // x+ = f(x, u, p, t), noise-free (nx values)
  *         DEV void measurement(const double* x, double* out) const;       // y  = g(x, u, p, t)            (ny values)
+ *         // optional — a measurement likelihood of the model's own: the reference's measurement_likelihood(x,u,y,p,t) callable of an
+ *         // AdvancedParticleFilter (src/PFtypes.jl:226-239), or logpdf of a measurement density that is not Gaussian
+ *         // (ext/LowLevelParticleFiltersDistributionsExt.jl:80); replaces logpdf(measurement_density, y - measurement(x)):
+ *         DEV double loglik(const double* x, const double* y, double t) const;   // log p(y | x) at measurement time t
+ *         DEV double loglik_bound() const;     // an upper bound of loglik over x and y for the parameters prepare() saw (it is
+ *                                              // evaluated once, when the filter is built, with u = 0, t = 0): what the engine's
+ *                                              // bound-offset normalisation needs.  Without this member every step is normalised
+ *                                              // against the true maximum instead (same results to rounding, one host round trip
+ *                                              // per step).  A bound that does not hold is reported as LLPF_ERR_DEGENERATE.
  *     };
  * (DEV = __device__ __forceinline__; the engine's deterministic math — llpf_exp, llpf_log, llpf_sqrt_pos, ... of
  * csrc/shared/llpf_detmath.h — is in scope, and the source is compiled with -ffp-contract=off like the engine.)  The snippet is
  * compiled with hiprtc for the visible device into the engine's own step kernel; *model_id (>= LLPF_MODEL_USER_BASE) then goes
- * into llpf_model.model_id with the same nx, ny.  Process noise, measurement likelihood and initial density remain the Gaussian
- * descriptors of llpf_model (an AdvancedParticleFilter whose dynamics add their own Gaussian noise and whose
- * measurement_likelihood is a Gaussian around `measurement`).  Such filters and banks run the balanced two-launch timestep;
- * the auxiliary verbs work, the smoother and the Rao-Blackwellized forms are not provided for them.
+ * into llpf_model.model_id with the same nx, ny (1..4 each: the kernels around the compiled one are precompiled for those).  Process
+ * noise and initial density remain the Gaussian descriptors of llpf_model, and so does the measurement likelihood unless the snippet
+ * defines `loglik` (measurement_density is then unused, but must still be a valid Gaussian of dimension ny).  Such filters and banks
+ * run the balanced two-launch timestep; the auxiliary verbs work, the smoother and the Rao-Blackwellized forms are not provided for
+ * them.  Compiling the same (source, nx, ny) again returns the same id.
  * On failure the compiler log is in llpf_last_error(). */
 int  llpf_model_compile(const char* device_src, int32_t nx, int32_t ny, int32_t* model_id);
 

@@ -29,7 +29,7 @@ __all__ = [
     "particles", "weights", "expweights", "state", "num_particles", "index", "effective_particles",
     "shouldresample", "resample", "weighted_mean", "logsumexp", "simulate", "parameters",
     "dynamics", "measurement", "measurement_likelihood", "dynamics_density", "measurement_density",
-    "initial_density", "resample_threshold", "resampling_strategy",
+    "initial_density", "resample_threshold", "resampling_strategy", "UserDynamics", "UserMeasurement", "UserLikelihood",
 ]
 
 
@@ -147,7 +147,64 @@ class GaussianLikelihood:
         self.measurement_density = measurement_density
 
 
+class UserDynamics:
+    """A model the engine has no built-in for: HIP device source defining `struct UserModel` — prepare / dynamics / measurement and,
+    optionally, `loglik` + `loglik_bound` (a measurement likelihood of its own) — compiled for the GPU with hiprtc when the filter
+    is built (include/llpf.h: llpf_model_compile).  A, B, C, qt fill the parameter block the snippet reads (m->A, ..., m->qt[16]);
+    `host` (optional) is the same dynamics as a Python callable, used only by host-side simulate."""
+
+    def __init__(self, src, nx, nu, ny, A=None, B=None, C=None, qt=(), supersample=1, host=None):
+        self.src, self.nx, self.nu, self.ny = str(src), int(nx), int(nu), int(ny)
+        self.A, self.B, self.C, self.qt, self.supersample, self.host = A, B, C, list(qt), int(supersample), host
+
+    def __call__(self, x, u=None, p=None, t=0.0, noise=False):
+        if self.host is None:
+            raise TypeError("no host version of this device model was given")
+        return self.host(x, u, p, t)
+
+
+class UserMeasurement:
+    """the measurement of a UserDynamics snippet (`UserModel::measurement`); `host`: the same as a Python callable, for simulate"""
+
+    def __init__(self, host=None):
+        self.host = host
+
+    def __call__(self, x, u=None, p=None, t=0.0, noise=False):
+        if self.host is None:
+            raise TypeError("no host version of this device model was given")
+        return self.host(x, u, p, t)
+
+
+class UserLikelihood:
+    """measurement_likelihood(x, u, y, p, t) of an AdvancedParticleFilter (reference src/PFtypes.jl:226-239) as the `loglik(x, y, t)`
+    member of the paired UserDynamics snippet; its `loglik_bound()` member declares the upper bound the normalisation works
+    against (without one every step is normalised against the true maximum: one host round trip per step)."""
+
+    def __init__(self, host=None):
+        self.host = host
+
+    def __call__(self, x, u, y, p=None, t=0.0):
+        if self.host is None:
+            raise TypeError("no host version of this device likelihood was given")
+        return self.host(x, u, y, p, t)
+
+
 def _build_model(dyn, meas, df, dg, d0, Ts):
+    if isinstance(dyn, UserDynamics):
+        if not isinstance(meas, UserMeasurement):
+            raise TypeError("pair UserDynamics with UserMeasurement (the snippet's own measurement)")
+        m = S.Model()
+        m.model_id = _capi.model_compile(dyn.src, dyn.nx, dyn.ny)
+        m.nx, m.nu, m.ny = dyn.nx, dyn.nu, dyn.ny
+        for name, mat in (("A", dyn.A), ("B", dyn.B), ("C", dyn.C)):
+            if mat is not None:
+                for i, v in enumerate(np.asarray(mat, dtype=np.float64).reshape(-1)):
+                    getattr(m, name)[i] = v
+        for i, v in enumerate(dyn.qt):
+            m.qt[i] = float(v)
+        m.supersample, m.Ts = dyn.supersample, float(Ts)
+        m.dynamics_density, m.measurement_density, m.initial_density = df.struct(), dg.struct(), d0.struct()
+        return m
     if isinstance(dyn, LinearDynamics) and isinstance(meas, LinearMeasurement):
         return S.make_lg_model(dyn.A, dyn.B, meas.C, df.struct(), dg.struct(), d0.struct(), Ts)
     if isinstance(dyn, QuadTankDynamics) and isinstance(meas, QuadTankMeasurement):
@@ -212,9 +269,15 @@ class AdvancedParticleFilter(_AbstractParticleFilter):
     def __init__(self, N, dynamics, measurement, measurement_likelihood, dynamics_density, initial_density, *,
                  resample_threshold=0.5, resampling_strategy=ResampleSystematic, rng=None, p=None,
                  threads=False, Ts=1.0, nu=-1, ny=-1, device=0):
-        if not isinstance(measurement_likelihood, GaussianLikelihood):
-            raise TypeError("measurement_likelihood must be a GaussianLikelihood descriptor")
-        self._setup(N, dynamics, measurement, dynamics_density, measurement_likelihood.measurement_density,
+        if isinstance(measurement_likelihood, UserLikelihood):
+            if not isinstance(dynamics, UserDynamics):
+                raise TypeError("a UserLikelihood is the loglik member of a UserDynamics snippet")
+            dgs = MvNormal(np.zeros(dynamics.ny), 1.0)       # the descriptor's Gaussian is not used by such a model (its bound replaces the peak)
+        elif isinstance(measurement_likelihood, GaussianLikelihood):
+            dgs = measurement_likelihood.measurement_density
+        else:
+            raise TypeError("measurement_likelihood must be a GaussianLikelihood or a UserLikelihood descriptor")
+        self._setup(N, dynamics, measurement, dynamics_density, dgs,
                     initial_density, resample_threshold, resampling_strategy, rng, p, threads, Ts, nu, ny, device)
         self.measurement_likelihood = measurement_likelihood
 

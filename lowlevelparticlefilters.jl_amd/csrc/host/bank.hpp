@@ -323,6 +323,8 @@ static int bank_create(const llpf_config* cfg, const llpf_model* models, int F, 
     }
     HIPC(hipMemcpyAsync(b.d_models, hm.data(), sizeof(ModelD) * FH, hipMemcpyHostToDevice, b.stream));
     if (FH < F) HIPC(launch_replicate_models(b.d_models, F, b.stream));
+    // a run-time compiled model with a likelihood of its own declares the bound the normalisation works against (d_uy is zero-filled)
+    if (m0.model_id >= LLPF_MODEL_USER_BASE) HIPC(launch_user_bound(m0.model_id, b.d_models, F, b.d_uy, b.stream));
     HIPC(hipStreamSynchronize(b.stream));
     HIPC(hipEventCreate(&b.ev_run0));
     HIPC(hipEventCreate(&b.ev_run1));

@@ -19,8 +19,8 @@ struct JitModel {
     int nx = 0, ny = 0;
     std::string src;                           // the snippet: a second llpf_model_compile of the same (source, nx, ny) returns the same id
     std::vector<char> code;
-    std::string name[4];                       // lowered names of k_step<UserModel, nx, ny, MODE, STEP_PPT>, MODE = 0..3
-    struct PerDevice { hipModule_t mod = nullptr; hipFunction_t fn[4] = {nullptr, nullptr, nullptr, nullptr}; };
+    std::string name[5];                       // lowered names of k_step<UserModel, nx, ny, MODE, STEP_PPT>, MODE = 0..3; [4]: k_user_bound<UserModel>
+    struct PerDevice { hipModule_t mod = nullptr; hipFunction_t fn[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; };
     std::vector<PerDevice> dev;                // indexed by device ordinal, loaded on first use
 };
 static std::mutex g_jit_mutex;
@@ -42,11 +42,11 @@ int jit_compile_user_model(const char* device_src, int nx, int ny, std::string& 
     src += "\n}  // namespace llpf\n";
     hiprtcProgram prog = nullptr;
     if (hiprtcCreateProgram(&prog, src.c_str(), "llpf_user_model.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) { err = "hiprtcCreateProgram failed"; return -1; }
-    std::string expr[4];
-    for (int mode = 0; mode < 4; ++mode) {
+    std::string expr[5];
+    for (int mode = 0; mode < 4; ++mode)
         expr[mode] = "llpf::k_step<llpf::UserModel, " + std::to_string(nx) + ", " + std::to_string(ny) + ", " + std::to_string(mode) + ", " + std::to_string(STEP_PPT) + ">";
-        hiprtcAddNameExpression(prog, expr[mode].c_str());
-    }
+    expr[4] = "llpf::k_user_bound<llpf::UserModel>";
+    for (int mode = 0; mode < 5; ++mode) hiprtcAddNameExpression(prog, expr[mode].c_str());
     int devid = 0;
     hipDeviceProp_t prop;
     std::string arch = "gfx950";
@@ -69,7 +69,7 @@ int jit_compile_user_model(const char* device_src, int nx, int ny, std::string& 
     hiprtcGetCodeSize(prog, &sz);
     jm->code.resize(sz);
     hiprtcGetCode(prog, jm->code.data());
-    for (int mode = 0; mode < 4; ++mode) {
+    for (int mode = 0; mode < 5; ++mode) {
         const char* low = nullptr;
         if (hiprtcGetLoweredName(prog, expr[mode].c_str(), &low) != HIPRTC_SUCCESS || !low) { err = "hiprtcGetLoweredName failed for " + expr[mode]; delete jm; hiprtcDestroyProgram(&prog); return -1; }
         jm->name[mode] = low;
@@ -89,21 +89,34 @@ static bool jit_supported(int model_id, int nx, int ny) {
     JitModel* jm = jit_model(model_id);
     return jm && jm->nx == nx && jm->ny == ny;
 }
-static hipError_t launch_step_user(const BankDev& b, int mode, const StepArgs& a, hipStream_t s) {
-    JitModel* jm = jit_model(b.model_id);
-    if (!jm || mode < 0 || mode > 3) return hipErrorInvalidValue;
+static hipError_t jit_function(JitModel* jm, int which, hipFunction_t* fn) {      // this device's handle of kernel `which`
     int devid = 0;
     hipError_t e = hipGetDevice(&devid);
     if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lk(g_jit_mutex);
+    if ((int)jm->dev.size() <= devid) jm->dev.resize((size_t)devid + 1);
+    JitModel::PerDevice& pd = jm->dev[(size_t)devid];
+    if (!pd.mod && (e = hipModuleLoadData(&pd.mod, jm->code.data())) != hipSuccess) return e;
+    if (!pd.fn[which] && (e = hipModuleGetFunction(&pd.fn[which], pd.mod, jm->name[which].c_str())) != hipSuccess) return e;
+    *fn = pd.fn[which];
+    return hipSuccess;
+}
+// a user model with a likelihood of its own: its upper bound into every filter's descriptor (see k_user_bound); a no-op kernel otherwise
+hipError_t launch_user_bound(int model_id, ModelD* models, int F, const double* zero_u, hipStream_t s) {
+    JitModel* jm = jit_model(model_id);
+    if (!jm) return hipErrorInvalidValue;
     hipFunction_t fn = nullptr;
-    {
-        std::lock_guard<std::mutex> lk(g_jit_mutex);
-        if ((int)jm->dev.size() <= devid) jm->dev.resize((size_t)devid + 1);
-        JitModel::PerDevice& pd = jm->dev[(size_t)devid];
-        if (!pd.mod && (e = hipModuleLoadData(&pd.mod, jm->code.data())) != hipSuccess) return e;
-        if (!pd.fn[mode] && (e = hipModuleGetFunction(&pd.fn[mode], pd.mod, jm->name[mode].c_str())) != hipSuccess) return e;
-        fn = pd.fn[mode];
-    }
+    hipError_t e = jit_function(jm, 4, &fn);
+    if (e != hipSuccess) return e;
+    void* args[] = {&models, &zero_u};
+    return hipModuleLaunchKernel(fn, (unsigned)F, 1, 1, 64, 1, 1, 0, s, args, nullptr);
+}
+static hipError_t launch_step_user(const BankDev& b, int mode, const StepArgs& a, hipStream_t s) {
+    JitModel* jm = jit_model(b.model_id);
+    if (!jm || mode < 0 || mode > 3) return hipErrorInvalidValue;
+    hipFunction_t fn = nullptr;
+    hipError_t e = jit_function(jm, mode, &fn);
+    if (e != hipSuccess) return e;
     BankDev bd = b;
     const ModelD* models = b.models;
     const FilterScal* scal = b.scal;

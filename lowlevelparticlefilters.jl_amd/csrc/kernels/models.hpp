@@ -315,3 +315,18 @@ struct QuadTank {   // reference examples/example_quadtank.jl:8-35 with rk4 of s
 template <class Model> struct share_dynamics { static constexpr bool value = true; };
 template <int NX, int NY> struct share_dynamics<LinGauss<NX, NY>> { static constexpr bool value = false; };
 template <int NX, int NY> struct share_dynamics<RBLin<NX, NY>> { static constexpr bool value = false; };
+
+// Optional hooks of a model (run-time compiled user models, kernels/jit.hpp):
+//   DEV double loglik(const double* x, const double* y, double t) const   log p(y | x) — the reference's measurement_likelihood(x, u, y, p, t)
+//                                                                          (src/PFtypes.jl:226-239) or logpdf of ANY measurement density
+//                                                                          (ext/LowLevelParticleFiltersDistributionsExt.jl:80); replaces the
+//                                                                          Gaussian logpdf(dg, y - g(x)) of the descriptor
+//   DEV double loglik_bound() const                                        an upper bound of loglik over x and y for these parameters (what the
+//                                                                          bound-offset normalisation needs); without it every
+//                                                                          step is normalised in the exact-max form
+// detected here without <type_traits> (hiprtc has no system headers)
+template <class M, class = void> struct has_loglik { static constexpr bool value = false; };
+template <class M> struct has_loglik<M, decltype((void)&M::loglik)> { static constexpr bool value = true; };
+template <class M, class = void> struct has_loglik_bound { static constexpr bool value = false; };
+template <class M> struct has_loglik_bound<M, decltype((void)&M::loglik_bound)> { static constexpr bool value = true; };
+constexpr double LLPF_NO_BOUND = 1e300;   // "bound" of a likelihood that declares none: every bound test fails, every step takes the exact form

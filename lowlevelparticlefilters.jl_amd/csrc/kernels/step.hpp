@@ -216,17 +216,23 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
                 if (MODE == MODE_AUX) {            // lambda .= 0; lambda += logpdf; w .+= lambda  (filtering.jl:201-204)
                     double lam = 0.0;
                     if (a.has_y) {
-                        double g[NY], v[NY];
-                        model.measurement(xs[p], g);
+                        if constexpr (has_loglik<Model>::value) {
+                            lam = lam + model.loglik(xs[p], y, a.t_meas);
+                        } else {
+                            double g[NY], v[NY];
+                            model.measurement(xs[p], g);
 #pragma unroll
-                        for (int k = 0; k < NY; ++k) v[k] = y[k] - g[k];
-                        lam = lam + gauss_logpdf<NY>(md->dg, v);
+                            for (int k = 0; k < NY; ++k) v[k] = y[k] - g[k];
+                            lam = lam + gauss_logpdf<NY>(md->dg, v);
+                        }
                     }
                     lamv[p] = lam;
                     wv = wv + lam;
                 } else if (a.has_y) {
                     if constexpr (Model::RB) {
                         wv = wv + model.rb_weight(xs[p], y, a.rb_corr + f, i0 + p == 0);
+                    } else if constexpr (has_loglik<Model>::value) {
+                        wv = wv + model.loglik(xs[p], y, a.t_meas);         // user measurement_likelihood; its bound sits in md->dg.c0 (k_user_bound)
                     } else {
                         double g[NY], v[NY];
                         model.measurement(xs[p], g);
@@ -305,6 +311,26 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
         scw->anc_ident_s[b.anc_slot ^ 1] = do_res ? 0 : 1;
         scw->last_resampled = do_res;
         scw->resample_count += do_res;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_user_bound — a model with its own likelihood: the upper bound the normalisation works against replaces the peak of the
+// (unused) Gaussian descriptor, per filter, with the filter's own parameters (launched once when the bank is built)
+// ------------------------------------------------------------------------------------------------
+template <class Model>
+__global__ void k_user_bound(ModelD* models, const double* zero_u) {
+    if constexpr (has_loglik<Model>::value) {
+        ModelD* md = models + blockIdx.x;
+        if (threadIdx.x == 0) {
+            if constexpr (has_loglik_bound<Model>::value) {
+                Model model;
+                model.prepare(md, zero_u, 0.0);
+                md->dg.c0 = model.loglik_bound();
+            } else {
+                md->dg.c0 = LLPF_NO_BOUND;
+            }
+        }
     }
 }
 

@@ -66,6 +66,7 @@ LLPF_HD double   llpf_sqrt_pos(double a) { return __builtin_sqrt(a); }
 #endif
 LLPF_HD double   llpf_rint(double a) { return __builtin_rint(a); }
 LLPF_HD double   llpf_fmax(double a, double b) { return a > b ? a : b; }
+LLPF_HD double   llpf_fabs(double a) { return __builtin_fabs(a); }
 
 #define LLPF_INF (__builtin_inf())
 

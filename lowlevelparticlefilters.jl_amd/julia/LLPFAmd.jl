@@ -34,7 +34,7 @@ import LowLevelParticleFilters: AbstractParticleFilter, ParticleFilteringSolutio
 
 export GPUParticleFilter, GPUAdvancedParticleFilter, GPUAuxiliaryParticleFilter, GPURBPF, GPUFilterBank, GPUMultiBank,
        LinearDynamics, LinearMeasurement, QuadTankDynamics, QuadTankMeasurement, GaussianLikelihood,
-       RBLinearModel, RBBilinearModel, GaussianSpec, UserDynamics, UserMeasurement, linear_state, shared_covariance, loglik_multi, mbank_unique_id,
+       RBLinearModel, RBBilinearModel, GaussianSpec, UserDynamics, UserMeasurement, UserLikelihood, linear_state, shared_covariance, loglik_multi, mbank_unique_id,
        seed!, ancestors, last_resampled
 
 const LIB = get(ENV, "LLPF_HIP_LIB", joinpath(@__DIR__, "..", "libllpf_hip.so"))
@@ -252,6 +252,19 @@ struct UserMeasurement
 end
 (g::UserMeasurement)(x, u, p, t) = g.host === nothing ? error("no host version of this device model was given") : g.host(x, u, p, t)
 (g::UserMeasurement)(x, u, p, t, noise) = g(x, u, p, t)
+"""
+    UserLikelihood(host = nothing)
+
+`measurement_likelihood(x,u,y,p,t)` of an `AdvancedParticleFilter` (reference src/PFtypes.jl:226-239) — or `logpdf` of a measurement
+density that is not Gaussian (ext/LowLevelParticleFiltersDistributionsExt.jl:80) — as the `loglik(x, y, t)` member of the paired
+`UserDynamics` snippet.  Its `loglik_bound()` member declares the upper bound of the log-density the normalisation works against;
+a snippet without one is normalised against the true maximum at every step (one host round trip per step).  `host`: the same
+likelihood as a Julia callable `(x,u,y,p,t)`, for host-side use."""
+struct UserLikelihood
+    host
+end
+UserLikelihood() = UserLikelihood(nothing)
+(l::UserLikelihood)(x, u, y, p, t) = l.host === nothing ? error("no host version of this device likelihood was given") : l.host(x, u, y, p, t)
 function cmodel(f::UserDynamics, ::UserMeasurement, df, dg, d0, Ts)
     id = Ref{Int32}(-1)
     check(ccall((:llpf_model_compile, LIB), Cint, (Cstring, Int32, Int32, Ref{Int32}), f.src, f.nx, f.ny, id))
@@ -358,6 +371,17 @@ function GPUAdvancedParticleFilter(N::Integer, dynamics, measurement, measuremen
                                    resampling_strategy::Type{<:ResamplingStrategy} = ResampleSystematic,
                                    p = NullParameters(), Ts = 1.0, seed = 0, device = 0, rng = Xoshiro(), kwargs...)
     dg = measurement_likelihood.dg
+    cm = cmodel(dynamics, measurement, dynamics_density, dg, initial_density, Float64(Ts))
+    create_filter(N, cm, true, Float64(resample_threshold), resampling_strategy, seed, device, dynamics, measurement,
+                  measurement_likelihood, dynamics_density, dg, initial_density, p, rng)
+end
+
+# a likelihood of the user's own: the descriptor's Gaussian is not used by such a model (k_user_bound puts the declared bound in its place)
+function GPUAdvancedParticleFilter(N::Integer, dynamics::UserDynamics, measurement::UserMeasurement, measurement_likelihood::UserLikelihood,
+                                   dynamics_density, initial_density; resample_threshold = 0.5,
+                                   resampling_strategy::Type{<:ResamplingStrategy} = ResampleSystematic,
+                                   p = NullParameters(), Ts = 1.0, seed = 0, device = 0, rng = Xoshiro(), kwargs...)
+    dg = GaussianSpec(zeros(dynamics.ny), 1.0)
     cm = cmodel(dynamics, measurement, dynamics_density, dg, initial_density, Float64(Ts))
     create_filter(N, cm, true, Float64(resample_threshold), resampling_strategy, seed, device, dynamics, measurement,
                   measurement_likelihood, dynamics_density, dg, initial_density, p, rng)

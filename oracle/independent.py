@@ -57,6 +57,31 @@ class Gaussian:
         return self.mu + np.atleast_2d(xi) @ self.L.T
 
 
+class Laplace:
+    """independent Laplace components of scale b: a measurement density other than a Gaussian (the reference weights with
+    logpdf of any Distribution, ext/LowLevelParticleFiltersDistributionsExt.jl:80, or with a measurement_likelihood callable,
+    src/PFtypes.jl:226-239)"""
+
+    def __init__(self, b):
+        self.b = float(b)
+
+    def logpdf(self, v):
+        v = np.atleast_2d(v)
+        return -np.sum(np.abs(v), axis=1) / self.b - v.shape[1] * math.log(2.0 * self.b)
+
+
+class StudentT:
+    """independent Student-t components, nu degrees of freedom, scale sigma"""
+
+    def __init__(self, nu, sigma):
+        self.nu, self.sigma = float(nu), float(sigma)
+        self.c1 = math.lgamma((self.nu + 1.0) / 2.0) - math.lgamma(self.nu / 2.0) - 0.5 * math.log(self.nu * math.pi) - math.log(self.sigma)
+
+    def logpdf(self, v):
+        v = np.atleast_2d(v)
+        return np.sum(self.c1 - (self.nu + 1.0) / 2.0 * np.log1p((v / self.sigma) ** 2 / self.nu), axis=1)
+
+
 # ---- models -------------------------------------------------------------------------------------------------------------------
 class LinearModel:
     """dynamics A x + B u, measurement C x (examples/example_lineargaussian.jl:28-29)"""

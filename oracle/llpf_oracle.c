@@ -566,6 +566,11 @@ struct orc_filter {
     int64_t N;
     int nx, nu, ny;
     gaussd df, dg, d0;
+    /* a measurement likelihood other than the Gaussian descriptor (orc_set_user_loglik): the counterpart, in this checker, of
+     * the reference's measurement_likelihood(x,u,y,p,t) callable (src/PFtypes.jl:226-239) / of a non-Gaussian measurement
+     * density (ext/LowLevelParticleFiltersDistributionsExt.jl:80) */
+    int user_ll_kind;
+    double user_par[4], user_c, user_bound;
     double *x, *xprev;          /* N*nx, AoS like Vector{SVector} */
     double *w, *we, *bins, *e;  /* e: exp(w_raw - m) of the last normalisation (device order) */
     int64_t* j;
@@ -1105,12 +1110,52 @@ static double filter_logsumexp(orc_filter* f, double off, int bound) {
     return ll;
 }
 
+/* ---- user likelihoods (test-side counterparts of the device snippets in tests/user_models.py) -----------------------------------
+ * kind 1  Laplace, independent components, scale b = par[0]:      ll = -(sum_k |v_k|) / b - ny log(2 b)
+ * kind 2  Student-t, independent components, nu = par[0], sigma = par[1], c1 = par[2] (the per-component log-normaliser
+ *         lgamma((nu+1)/2) - lgamma(nu/2) - log(nu pi)/2 - log sigma, formed by the caller):
+ *                                                                 ll = sum_k ( c1 - (nu+1)/2 log1p((v_k/sigma)^2 / nu) )
+ * v = y - g(x).  Device order: the deterministic log / log1p of llpf_detmath.h, as the device snippet; reference order: libm. */
+int orc_set_user_loglik(orc_filter* f, int kind, const double* par, int npar) {
+    if (!f || kind < 0 || kind > 2 || npar > 4) return -1;
+    f->user_ll_kind = kind;
+    for (int i = 0; i < 4; ++i) f->user_par[i] = (par && i < npar) ? par[i] : 0.0;
+    const int dev = f->order == ORC_ORDER_DEVICE;
+    if (kind == 1) {
+        f->user_c = (double)f->ny * (dev ? llpf_log(2.0 * f->user_par[0]) : log(2.0 * f->user_par[0]));
+        f->user_bound = -f->user_c;
+    } else if (kind == 2) {
+        f->user_c = (f->user_par[0] + 1.0) / 2.0;
+        double b = 0.0;
+        for (int k = 0; k < f->ny; ++k) b = b + f->user_par[2];
+        f->user_bound = b;
+    }
+    return 0;
+}
+static double meas_bound(const orc_filter* f) { return f->user_ll_kind ? f->user_bound : f->dg.c0; }
+static double meas_loglik(const orc_filter* f, const double* v) {
+    if (!f->user_ll_kind) return gauss_logpdf(&f->dg, v);
+    const int dev = f->order == ORC_ORDER_DEVICE;
+    if (f->user_ll_kind == 1) {
+        double s = fabs(v[0]);
+        for (int k = 1; k < f->ny; ++k) s = s + fabs(v[k]);
+        return (-(s / f->user_par[0])) - f->user_c;
+    }
+    double ll = 0.0;
+    for (int k = 0; k < f->ny; ++k) {
+        const double z = v[k] / f->user_par[1];
+        const double q = (z * z) / f->user_par[0];
+        ll = ll + (f->user_par[2] - f->user_c * (dev ? llpf_log1p_nonneg(q) : log1p(q)));
+    }
+    return ll;
+}
+
 /* correct!(pf,u,y,p,t) — src/filtering.jl:164-168; measurement_equation! src/PFtypes.jl:107-120 (PF),
  * :226-239 (Advanced: w[i] += measurement_likelihood(x[i],u,y,p,t), which for the built-in models is
  * logpdf(dg, y - g(x))) */
 double orc_correct(orc_filter* f, const double* u, const double* y, double t) {
     const int has_y = (y != NULL && y[0] == y[0]);
-    const double off = has_y ? f->wmax + f->dg.c0 : f->wmax;   /* device order: upper bound of the new weights */
+    const double off = has_y ? f->wmax + meas_bound(f) : f->wmax;   /* device order: upper bound of the new weights */
     if (f->rbf.on && has_y) {
         /* S_i = C R_i C' + R2 >= R2: the peak of N(0, R2) bounds every increment (+ the slack the kernel uses) */
         rbf_correct(f, u, y, t);
@@ -1128,7 +1173,7 @@ double orc_correct(orc_filter* f, const double* u, const double* y, double t) {
             double g[MAXD], v[MAXD];
             orc_measurement(&f->cfg.model, f->x + i * f->nx, u, t, g);
             for (int k = 0; k < f->ny; ++k) v[k] = y[k] - g[k];
-            f->w[i] += gauss_logpdf(&f->dg, v);
+            f->w[i] += meas_loglik(f, v);
         }
     }
     f->aux_pending = 0;
@@ -1306,14 +1351,14 @@ void orc_aux_predict(orc_filter* f, const double* u, const double* y1, double t)
             double g[MAXD], v[MAXD];
             orc_measurement(&f->cfg.model, f->x + i * nx, u, t, g);
             for (int k = 0; k < f->ny; ++k) v[k] = y1[k] - g[k];
-            lam += gauss_logpdf(&f->dg, v);
+            lam += meas_loglik(f, v);
         }
         f->lam[i] = lam;
         f->w[i] += lam;                                        /* s.w .+= lambda, :204 */
     }
     /* expnormalize!(s.w) (w used as buffer, :205) ; j = resample(strategy, s.w, s.j, s.bins), :206 */
     if (dev) {
-        const double off = has_y ? f->wmax + f->dg.c0 : f->wmax;
+        const double off = has_y ? f->wmax + meas_bound(f) : f->wmax;
         dev_norm_bound(f->w, f->e, N, off, &f->dn);
         if (!f->dn.fast) f->n_exact_steps++;
         f->dn_valid = 1;
@@ -1363,7 +1408,7 @@ void orc_aux_predict(orc_filter* f, const double* u, const double* y1, double t)
     memcpy(f->xprev, f->x, sizeof(double) * (size_t)N * nx);  /* :216 */
     f->dn_valid = 0;
     f->aux_pending = 1;
-    f->aux_off = (has_y ? f->dg.c0 : 0.0) - lN;
+    f->aux_off = (has_y ? meas_bound(f) : 0.0) - lN;
     f->wmax = f->aux_off;                                      /* an upper bound of the current log-weights */
     f->last_resampled = 1;
     f->resample_count++;

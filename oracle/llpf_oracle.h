@@ -93,6 +93,8 @@ int64_t orc_exact_steps(const orc_filter* f);   /* device order: weightings norm
 
 /* OpenMP threads for the per-particle loops (default 1; results are independent of the count) */
 void   orc_set_threads(int n);
+/* a measurement likelihood other than the Gaussian descriptor: kind 0 none, 1 Laplace (par: b), 2 Student-t (par: nu, sigma, c1) */
+int    orc_set_user_loglik(orc_filter* f, int kind, const double* par, int npar);
 int    orc_get_threads(void);
 
 /* array primitives */

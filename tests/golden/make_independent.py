@@ -23,7 +23,7 @@ for name, case in IC.cases().items():
     np.savez_compressed(os.path.join(HERE, "indep_%s.npz" % name), U=case["U"], Y=case["Y"], **r)
     line = "%-22s resamples %2d" % (name, int(r["resamples"]))
     for tag, order in (("reference order", ob.ORDER_REFERENCE), ("device order", ob.ORDER_DEVICE)):
-        o = ob.OracleFilter(IC.config_of(case), order)
+        o = IC.oracle_of(ob, case, order)
         o.reset()
         ro = o.run(case["U"], case["Y"], case["t0"], ll_steps=True)
         line += " | %s: max|dll| %.1e max|dx| %.1e anc %s" % (tag, np.max(np.abs(ro["ll_steps"] - r["ll_steps"])),

@@ -48,6 +48,14 @@ def cases():
         out[name] = dict(model=lg, kind=S.PARTICLE_FILTER, N=400, T=60, thr=thr, strategy=strat, t0=0.0, U=U, Y=Y,
                          make=lambda thr=thr, strat=strat: ind.ParticleFilter(400, _lg_objects(lg), _gauss(lg.dynamics_density), _gauss(lg.measurement_density),
                                                                               _gauss(lg.initial_density), thr, strat == S.RESAMPLE_STRATIFIED, lg.Ts))
+    # measurement likelihoods of the user's own (run-time compiled on the engine side, tests/user_models.py): Laplace and Student-t
+    # noise on the same linear system; `user` = (oracle kind, oracle parameters, device snippet, qt parameter block of the snippet)
+    import user_models as UM
+    st = ind.StudentT(4.0, 0.7)
+    for name, dens, user in (("pf_lg_laplace", ind.Laplace(0.8), (1, [0.8], UM.LAPLACE_SRC, [0.8])),
+                             ("pf_lg_student_t", st, (2, [4.0, 0.7, st.c1], UM.STUDENT_T_SRC, [4.0, 0.7, st.c1]))):
+        out[name] = dict(model=lg, kind=S.ADVANCED_PARTICLE_FILTER, N=400, T=60, thr=0.5, strategy=S.RESAMPLE_SYSTEMATIC, t0=0.0, U=U, Y=Y, user=user,
+                         make=lambda dens=dens: ind.ParticleFilter(400, _lg_objects(lg), _gauss(lg.dynamics_density), dens, _gauss(lg.initial_density), 0.5, False, lg.Ts))
     qt = M.quadtank_model()
     Uq, Yq = M.quadtank_data(40, seed=2)
     out["pf_quadtank"] = dict(model=qt, kind=S.ADVANCED_PARTICLE_FILTER, N=300, T=40, thr=0.5, strategy=S.RESAMPLE_SYSTEMATIC, t0=485.0, U=Uq, Y=Yq,
@@ -101,3 +109,24 @@ def run_independent(ob, case):
 
 def config_of(case):
     return S.make_config(case["model"], case["N"], case["kind"], case["strategy"], case["thr"], SEED, 0)
+
+
+def oracle_of(ob, case, order):
+    """the C oracle for a case (with the case's own measurement likelihood installed)"""
+    o = ob.OracleFilter(config_of(case), order)
+    if case.get("user"):
+        o.set_user_loglik(case["user"][0], case["user"][1])
+    return o
+
+
+def engine_of(case):
+    """the HIP engine for a case: cases with a measurement likelihood of their own run a model compiled from the case's device snippet"""
+    from llpf_amd import _capi
+    if not case.get("user"):
+        return _capi.FilterHandle(config_of(case))
+    kind, par, src, qt = case["user"]
+    m = S.Model.from_buffer_copy(bytes(case["model"]))
+    m.model_id = _capi.model_compile(src, m.nx, m.ny)
+    for i, v in enumerate(qt):
+        m.qt[i] = v
+    return _capi.FilterHandle(S.make_config(m, case["N"], case["kind"], case["strategy"], case["thr"], SEED, 0))

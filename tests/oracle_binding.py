@@ -28,6 +28,7 @@ def load():
     lib.orc_create.argtypes = [C.POINTER(S.Config), C.c_int]
     lib.orc_destroy.argtypes = [C.c_void_p]
     lib.orc_seed.argtypes = [C.c_void_p, C.c_uint64]
+    lib.orc_set_user_loglik.argtypes = [C.c_void_p, C.c_int, _dp, C.c_int]
     lib.orc_reset.argtypes = [C.c_void_p]
     lib.orc_reset_explicit.argtypes = [C.c_void_p, _dp]
     lib.orc_correct.restype = C.c_double
@@ -153,6 +154,12 @@ class OracleFilter:
 
     def seed(self, s):
         self.L.orc_seed(self.h, s)
+
+    def set_user_loglik(self, kind, par):
+        """a measurement likelihood other than the Gaussian descriptor (llpf_oracle.c: 1 Laplace [b], 2 Student-t [nu, sigma, c1])"""
+        a = np.ascontiguousarray(par, dtype=np.float64)
+        if self.L.orc_set_user_loglik(self.h, int(kind), dptr(a), int(a.size)) != 0:
+            raise ValueError("orc_set_user_loglik")
 
     def reset(self, xi=None):
         if xi is None:

@@ -40,7 +40,7 @@ def test_independent_restatement_reproduces_its_frozen_outputs(name):
 @pytest.mark.parametrize("name", list(CASES))
 def test_c_oracle_agrees_with_the_independent_restatement(name, order):
     d, case = _golden(name), CASES[name]
-    o = ob.OracleFilter(IC.config_of(case), order)
+    o = IC.oracle_of(ob, case, order)
     o.reset()
     r = o.run(case["U"], case["Y"], case["t0"], ll_steps=True)
     assert np.max(np.abs(r["ll_steps"] - d["ll_steps"])) < TOL_LL
@@ -54,9 +54,8 @@ def test_c_oracle_agrees_with_the_independent_restatement(name, order):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", list(CASES))
 def test_engine_agrees_with_the_independent_restatement(name):
-    from llpf_amd import _capi
     d, case = _golden(name), CASES[name]
-    g = _capi.FilterHandle(IC.config_of(case))
+    g = IC.engine_of(case)
     g.reset()
     r = g.run(case["U"], case["Y"], case["t0"], ll_steps=True)
     assert np.max(np.abs(r["ll_steps"] - d["ll_steps"])) < TOL_LL

@@ -19,11 +19,17 @@ def test_snippets_compile_for_gfx950_without_a_device():
         a = _capi.model_compile(UM.QUADTANK_SRC, 4, 2)
         b = _capi.model_compile(UM.PENDULUM_SRC, 2, 1)
         assert a >= 1000 and b == a + 1
+        assert _capi.model_compile(UM.QUADTANK_SRC, 4, 2) == a                 # the same (source, nx, ny) again: the same id, no recompilation
+        ids = [_capi.model_compile(src, 2, 1) for src in (UM.LAPLACE_SRC, UM.STUDENT_T_SRC, UM.LAPLACE_NO_BOUND_SRC)]   # likelihood hooks
+        assert len(set(ids)) == 3 and "loglik_bound" not in UM.LAPLACE_NO_BOUND_SRC
         with pytest.raises(_capi.LLPFError) as ei:
             _capi.model_compile("struct UserModel { int broken }", 2, 1)
         assert "hiprtc" in str(ei.value)
         with pytest.raises(_capi.LLPFError):
             _capi.model_compile(UM.PENDULUM_SRC, 9, 1)
+        with pytest.raises(_capi.LLPFError) as ei:                             # the kernels around the compiled one cover 1..4 dimensions
+            _capi.model_compile(UM.PENDULUM_SRC, 5, 1)
+        assert "1..4" in str(ei.value)
     finally:
         del os.environ["LLPF_JIT_COMPILE_ONLY"]
 
@@ -96,3 +102,76 @@ def test_a_model_without_builtin_counterpart():
     assert np.isfinite(f3.run_aux(U, Y, 1)["ll"])
     with pytest.raises(_capi.LLPFError):
         f3.smooth(10, U, np.zeros((T, 20000, 2)), np.zeros((T, 20000)), np.zeros((T, 20000)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["pf_lg_laplace", "pf_lg_student_t"])
+def test_user_measurement_likelihood(name):
+    """A measurement likelihood of the user's own — the reference's measurement_likelihood(x, u, y, p, t) of an AdvancedParticleFilter
+    (src/PFtypes.jl:226-239) / logpdf of a non-Gaussian measurement density (ext/LowLevelParticleFiltersDistributionsExt.jl:80) — as a
+    `loglik` hook of a run-time compiled model with a declared upper bound: bit-identical to the device-order oracle (whose C
+    counterpart of the same density is itself held to the independent numpy restatement, tests/test_independent_oracle.py), within
+    1e-10 per step of the reference order; a bank of such filters, the auxiliary filter over it, and single steps."""
+    import independent_cases as IC
+    case = IC.cases()[name]
+    U, Y = case["U"], case["Y"]
+    g = IC.engine_of(case)
+    od, orf = IC.oracle_of(ob, case, ob.ORDER_DEVICE), IC.oracle_of(ob, case, ob.ORDER_REFERENCE)
+    for h in (g, od, orf):
+        h.reset()
+    rg, rd, rr = (h.run(U, Y, 0.0, ll_steps=True) for h in (g, od, orf))
+    assert np.array_equal(rg["ll_steps"].view(np.uint64), rd["ll_steps"].view(np.uint64))
+    assert np.array_equal(g.particles().view(np.uint64), od.particles().view(np.uint64)) and np.array_equal(g.ancestors(), od.ancestors())
+    assert np.array_equal(g.weights().view(np.uint64), od.weights().view(np.uint64))
+    assert np.max(np.abs(rg["ll_steps"] - rr["ll_steps"])) <= 1e-10 and g.resample_count() == od.resample_count() > 3
+    assert od.exact_steps() == 0                                  # the declared bound held: no step fell back to the exact form
+    # step by step
+    g.reset(); od.reset()
+    for k in range(12):
+        assert g.correct(U[k], Y[k], float(k)) == od.correct(U[k], Y[k], float(k))
+        g.predict(U[k], float(k)); od.predict(U[k], float(k))
+    assert np.array_equal(g.particles().view(np.uint64), od.particles().view(np.uint64))
+    # the auxiliary filter over it (look-ahead weights from the same likelihood)
+    g.reset(); od.reset()
+    ra, ro = g.run_aux(U, Y, 0, ll_steps=True), od.run_aux(U, Y, 0, ll_steps=True)
+    assert np.array_equal(ra["ll_steps"].view(np.uint64), ro["ll_steps"].view(np.uint64))
+
+
+@pytest.mark.gpu
+def test_user_likelihood_without_a_declared_bound_takes_the_exact_form():
+    """no `loglik_bound` in the snippet: every step is normalised against the true maximum (the exact form, one host round trip
+    each) — the results are the bounded model's to rounding, and the reference order's within tolerance"""
+    import independent_cases as IC
+    case = dict(IC.cases()["pf_lg_laplace"])
+    g1 = IC.engine_of(case)
+    case["user"] = case["user"][:2] + (UM.LAPLACE_NO_BOUND_SRC,) + case["user"][3:]
+    g0 = IC.engine_of(case)
+    orf = IC.oracle_of(ob, case, ob.ORDER_REFERENCE)
+    for h in (g0, g1, orf):
+        h.reset()
+    r0, r1, rr = (h.run(case["U"], case["Y"], 0.0, ll_steps=True) for h in (g0, g1, orf))
+    assert np.max(np.abs(r0["ll_steps"] - r1["ll_steps"])) <= 1e-12 and np.max(np.abs(r0["ll_steps"] - rr["ll_steps"])) <= 1e-10
+    assert np.array_equal(g0.ancestors(), g1.ancestors())
+
+
+@pytest.mark.gpu
+def test_user_likelihood_through_the_filter_objects():
+    """the mirror of the reference's constructor: AdvancedParticleFilter(N, dynamics, measurement, measurement_likelihood, df, d0) with
+    UserDynamics / UserMeasurement / UserLikelihood descriptors (lowlevelparticlefilters.jl_amd/api.py; julia/LLPFAmd.jl has the same)"""
+    import llpf_amd
+    import independent_cases as IC
+    case = IC.cases()["pf_lg_laplace"]
+    lg = case["model"]
+    A = np.array(lg.A[:4]).reshape(2, 2); B = np.array(lg.B[:2]).reshape(2, 1); Cm = np.array(lg.C[:2]).reshape(1, 2)
+    dyn = llpf_amd.UserDynamics(UM.LAPLACE_SRC, 2, 1, 1, A=A, B=B, C=Cm, qt=[0.8])
+    df = llpf_amd.MvNormal(np.zeros(2), S.gaussian_cov_matrix(lg.dynamics_density))
+    d0 = llpf_amd.MvNormal(np.array(lg.initial_density.mu[:2]), S.gaussian_cov_matrix(lg.initial_density))
+    pf = llpf_amd.AdvancedParticleFilter(case["N"], dyn, llpf_amd.UserMeasurement(), llpf_amd.UserLikelihood(), df, d0,
+                                         resample_threshold=case["thr"], rng=IC.SEED)
+    o = IC.oracle_of(ob, case, ob.ORDER_REFERENCE)
+    o.reset()
+    ro = o.run(case["U"], case["Y"], 0.0, ll_steps=True)
+    sol = llpf_amd.forward_trajectory(pf, case["U"], case["Y"])
+    assert abs(sol.ll - ro["ll"]) <= 1e-9
+    with pytest.raises(TypeError):
+        llpf_amd.AdvancedParticleFilter(100, llpf_amd.LinearDynamics(A, B), llpf_amd.LinearMeasurement(Cm), llpf_amd.UserLikelihood(), df, d0)

@@ -72,3 +72,97 @@ struct UserModel {
     }
 };
 '''
+
+# A linear system (A, B, C of the parameter block: the same expressions, in the same order, as the engine's built-in linear-Gaussian
+# model) with a measurement LIKELIHOOD of its own — the reference's measurement_likelihood(x, u, y, p, t) callable of an
+# AdvancedParticleFilter (src/PFtypes.jl:226-239), or a non-Gaussian measurement density of a ParticleFilter
+# (ext/LowLevelParticleFiltersDistributionsExt.jl:80).  `loglik_bound` is what lets the engine normalise against an analytic bound.
+_LINEAR_PART = r"""
+    static constexpr bool RB = false;
+    const ModelD* md;
+    double bu[NXU];
+    bool has_u;
+    DEV void prepare_linear(const ModelD* m, const double* u) {
+        md = m;
+        const int nu = m->nu;
+        has_u = nu > 0 && u != nullptr;
+        for (int r = 0; r < NXU; ++r) {
+            double acc = 0.0;
+            if (has_u) {
+                acc = m->B[r * nu + 0] * u[0];
+                for (int c = 1; c < nu; ++c) acc = acc + m->B[r * nu + c] * u[c];
+            }
+            bu[r] = acc;
+        }
+    }
+    DEV void dynamics(const double* x, double* out) const {
+        for (int r = 0; r < NXU; ++r) {
+            double ax = md->A[r * NXU + 0] * x[0];
+            for (int c = 1; c < NXU; ++c) ax = ax + md->A[r * NXU + c] * x[c];
+            out[r] = has_u ? ax + bu[r] : ax;
+        }
+    }
+    DEV void measurement(const double* x, double* out) const {
+        for (int r = 0; r < NYU; ++r) {
+            double cx = md->C[r * NXU + 0] * x[0];
+            for (int c = 1; c < NXU; ++c) cx = cx + md->C[r * NXU + c] * x[c];
+            out[r] = cx;
+        }
+    }
+"""
+
+# Laplace measurement noise, independent components, scale b = qt[0]:  log p = -(sum_k |y_k - g_k|) / b - ny log(2 b)
+LAPLACE_SRC = r"""
+struct UserModel {
+    static constexpr int NXU = 2, NYU = 1;
+""" + _LINEAR_PART + r"""
+    double b, c;
+    DEV void prepare(const ModelD* m, const double* u, double t) {
+        prepare_linear(m, u);
+        b = m->qt[0];
+        c = (double)NYU * llpf_log(2.0 * b);
+    }
+    DEV double loglik(const double* x, const double* y, double t) const {
+        double g[NYU];
+        measurement(x, g);
+        double s = llpf_fabs(y[0] - g[0]);
+        for (int k = 1; k < NYU; ++k) s = s + llpf_fabs(y[k] - g[k]);
+        return (-(s / b)) - c;
+    }
+    DEV double loglik_bound() const { return -c; }
+};
+"""
+
+# Student-t measurement noise, independent components: nu = qt[0], sigma = qt[1], c1 = qt[2] (the per-component log-normaliser,
+# lgamma((nu+1)/2) - lgamma(nu/2) - log(nu pi)/2 - log sigma, formed by the host):  log p = sum_k (c1 - (nu+1)/2 log1p((v_k/sigma)^2/nu))
+STUDENT_T_SRC = r"""
+struct UserModel {
+    static constexpr int NXU = 2, NYU = 1;
+""" + _LINEAR_PART + r"""
+    double nu_, sigma, c1, h;
+    DEV void prepare(const ModelD* m, const double* u, double t) {
+        prepare_linear(m, u);
+        nu_ = m->qt[0]; sigma = m->qt[1]; c1 = m->qt[2];
+        h = (nu_ + 1.0) / 2.0;
+    }
+    DEV double loglik(const double* x, const double* y, double t) const {
+        double g[NYU];
+        measurement(x, g);
+        double ll = 0.0;
+        for (int k = 0; k < NYU; ++k) {
+            const double z = (y[k] - g[k]) / sigma;
+            const double q = (z * z) / nu_;
+            ll = ll + (c1 - h * llpf_log1p_nonneg(q));
+        }
+        return ll;
+    }
+    DEV double loglik_bound() const {
+        double bd = 0.0;
+        for (int k = 0; k < NYU; ++k) bd = bd + c1;
+        return bd;
+    }
+};
+"""
+
+# the same Laplace likelihood WITHOUT a declared bound: every step is normalised in the exact-max form (one host round trip each)
+LAPLACE_NO_BOUND_SRC = LAPLACE_SRC.replace("    DEV double loglik_bound() const { return -c; }\n", "")
