@@ -231,6 +231,24 @@ static int bank_create(const llpf_config* cfg, const llpf_model* models, int F, 
     if (cfg->struct_size != sizeof(llpf_config)) return fail(LLPF_ERR_ARG, "llpf_config.struct_size mismatch (ABI)");
     if (F < 1) return fail(LLPF_ERR_ARG, "n_filters must be >= 1");
     const llpf_model& m0 = models ? models[0] : cfg->model;
+    if (m0.model_id == LLPF_MODEL_LINEAR_GAUSSIAN && (m0.nx > 4 || m0.ny > 4) && m0.nx >= 1 && m0.nx <= MAXD && m0.ny >= 1 && m0.ny <= MAXD) {
+        // the linear-Gaussian model above the precompiled dimensions: LinGauss<nx, ny> compiled on demand (kernels/jit.hpp), after
+        // which the bank is a bank of that run-time compiled model
+        std::string err;
+        const int id = jit_builtin_lg(m0.nx, m0.ny, err);
+        if (id < 0) return fail(LLPF_ERR_HIP, "linear-Gaussian model at nx = " + std::to_string(m0.nx) + ", ny = " + std::to_string(m0.ny) + ": " + err);
+        llpf_config c2 = *cfg;
+        c2.model.model_id = id;
+        std::vector<llpf_model> mm;
+        if (models) {
+            mm.assign(models, models + F);
+            for (int f = 0; f < F; ++f) {
+                if (mm[f].model_id != LLPF_MODEL_LINEAR_GAUSSIAN) return fail(LLPF_ERR_ARG, "all filters of a bank must share model id and dimensions");
+                mm[f].model_id = id;
+            }
+        }
+        return bank_create(&c2, models ? mm.data() : nullptr, F, b, key_off, key_stride);
+    }
     if (cfg->n_particles < 1 || cfg->n_particles > ((int64_t)1 << 29) - 2 * TILE)   // 32-bit byte offsets into a particle plane
         return fail(LLPF_ERR_ARG, "n_particles must be in 1..2^29-2048");
     if (m0.nx < 1 || m0.nx > MAXD || m0.ny < 1 || m0.ny > MAXD || m0.nu < 0 || m0.nu > MAXD) return fail(LLPF_ERR_ARG, "bad dimensions");

@@ -30,6 +30,7 @@ static hipError_t launch_resprop_t(const BankDev& b, const ResArgs& a, const Ste
 }
 template <int NX>
 static hipError_t launch_resprop_lg_ny(const BankDev& b, const ResArgs& a, const StepArgs& st, int weight, hipStream_t s) {
+    if (st.aux) return launch_resprop_t<LinGauss<NX, 1>, NX, 1>(b, a, st, weight, s);     // the auxiliary second half does not see the measurement
     switch (b.ny) {
         case 1: return launch_resprop_t<LinGauss<NX, 1>, NX, 1>(b, a, st, weight, s);
         case 2: return launch_resprop_t<LinGauss<NX, 2>, NX, 2>(b, a, st, weight, s);
@@ -47,6 +48,15 @@ static hipError_t launch_resprop_rb_ny(const BankDev& b, const ResArgs& a, const
         case 4: return launch_resprop_t<RBLin<NX, 4>, NX, 4>(b, a, st, weight, s);
         default: return hipErrorInvalidValue;
     }
+}
+// state dimensions 5..8 (models compiled on demand): only the auxiliary filter's second half comes here, which propagates nothing
+template <int NX>
+static hipError_t launch_resprop_aux_only(const BankDev& b, const ResArgs& a, const StepArgs& st, hipStream_t s) {
+    if (!st.aux) return hipErrorInvalidValue;
+    dim3 g((unsigned)b.P2, (unsigned)b.F, 1);
+    if (b.P2 == 1) hipLaunchKernelGGL((k_resprop<NoModel<NX>, NX, 1, true, true, true, true>), g, dim3(BLOCK), 0, s, LLPF_HOT_ARGS(b, a), b, b.models, a, st);
+    else hipLaunchKernelGGL((k_resprop<NoModel<NX>, NX, 1, true, true, true>), g, dim3(BLOCK), 0, s, LLPF_HOT_ARGS(b, a), b, b.models, a, st);
+    return hipGetLastError();
 }
 hipError_t launch_resprop(const BankDev& b, const ResArgs& a0, const StepArgs& st, int weight, hipStream_t s) {
     ResArgs a = a0;
@@ -68,6 +78,10 @@ hipError_t launch_resprop(const BankDev& b, const ResArgs& a0, const StepArgs& s
         case 2: return launch_resprop_lg_ny<2>(b, a, st, weight, s);
         case 3: return launch_resprop_lg_ny<3>(b, a, st, weight, s);
         case 4: return launch_resprop_lg_ny<4>(b, a, st, weight, s);
+        case 5: return launch_resprop_aux_only<5>(b, a, st, s);
+        case 6: return launch_resprop_aux_only<6>(b, a, st, s);
+        case 7: return launch_resprop_aux_only<7>(b, a, st, s);
+        case 8: return launch_resprop_aux_only<8>(b, a, st, s);
         default: return hipErrorInvalidValue;
     }
 }

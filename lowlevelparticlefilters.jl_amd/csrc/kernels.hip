@@ -41,6 +41,10 @@ hipError_t launch_init(const BankDev& b, uint32_t step, int init_anc, hipStream_
         case 2: hipLaunchKernelGGL(k_init<2>, g, dim3(BLOCK), 0, s, b, b.models, b.scal, step, init_anc); break;
         case 3: hipLaunchKernelGGL(k_init<3>, g, dim3(BLOCK), 0, s, b, b.models, b.scal, step, init_anc); break;
         case 4: hipLaunchKernelGGL(k_init<4>, g, dim3(BLOCK), 0, s, b, b.models, b.scal, step, init_anc); break;
+        case 5: hipLaunchKernelGGL(k_init<5>, g, dim3(BLOCK), 0, s, b, b.models, b.scal, step, init_anc); break;   // 5..8: models compiled on demand
+        case 6: hipLaunchKernelGGL(k_init<6>, g, dim3(BLOCK), 0, s, b, b.models, b.scal, step, init_anc); break;
+        case 7: hipLaunchKernelGGL(k_init<7>, g, dim3(BLOCK), 0, s, b, b.models, b.scal, step, init_anc); break;
+        case 8: hipLaunchKernelGGL(k_init<8>, g, dim3(BLOCK), 0, s, b, b.models, b.scal, step, init_anc); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -60,6 +64,10 @@ hipError_t launch_norm(const BankDev& b, int parity, int want_xmean, int need_e2
         case 2: launch_norm_e2<2, true>(b, parity, need_e2, step, only_fallback, bound, kstep, s); break;
         case 3: launch_norm_e2<3, true>(b, parity, need_e2, step, only_fallback, bound, kstep, s); break;
         case 4: launch_norm_e2<4, true>(b, parity, need_e2, step, only_fallback, bound, kstep, s); break;
+        case 5: launch_norm_e2<5, true>(b, parity, need_e2, step, only_fallback, bound, kstep, s); break;
+        case 6: launch_norm_e2<6, true>(b, parity, need_e2, step, only_fallback, bound, kstep, s); break;
+        case 7: launch_norm_e2<7, true>(b, parity, need_e2, step, only_fallback, bound, kstep, s); break;
+        case 8: launch_norm_e2<8, true>(b, parity, need_e2, step, only_fallback, bound, kstep, s); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -244,6 +244,7 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
                 if (i0 + p >= N) wv = -LLPF_INF;   // padding lanes carry zero weight
                 wn[p] = wv;
                 bad = bad || (wv != wv);
+                if constexpr (has_loglik<Model>::value) bad = bad || (a.has_y && wv > off);   // the user's declared bound does not hold: reported like NaN weights
                 bmax = llpf_fmax(bmax, wv);
             }
             if constexpr (PPT == 2) { double2 wo; wo.x = wn[0]; wo.y = wn[1]; wt_store<WT>(reinterpret_cast<double2*>(w + i0), wo); }

@@ -504,10 +504,46 @@ def test_invalid_run_arguments():
     g = _capi.FilterHandle(_cfg(model, 100))
     with pytest.raises(_capi.LLPFError):
         g.run(np.zeros((0, 1)), np.zeros((0, 1)), 0.0)           # empty trajectory
-    cfg = _cfg(S.make_lg_model(np.eye(5) * 0.5, None, np.eye(5), S.make_gaussian(np.zeros(5), 1.0),
-                               S.make_gaussian(np.zeros(5), 1.0), S.make_gaussian(np.zeros(5), 1.0)), 100)
-    with pytest.raises(_capi.LLPFError):
-        _capi.FilterHandle(cfg)                                  # nx = 5: no kernel instantiated
+    cfg = _cfg(S.make_lg_model(np.eye(9) * 0.5, None, np.eye(9)[:2], S.make_gaussian(np.zeros(9), 1.0),
+                               S.make_gaussian(np.zeros(2), 1.0), S.make_gaussian(np.zeros(9), 1.0)), 100) if S.MAX_DIM >= 9 else None
+    if cfg is not None:
+        with pytest.raises(_capi.LLPFError):
+            _capi.FilterHandle(cfg)                              # above LLPF_MAX_DIM
+
+
+@pytest.mark.parametrize("nx,ny,nu", [(5, 2, 1), (2, 6, 0), (8, 8, 2)])
+def test_linear_gaussian_above_the_precompiled_dimensions(nx, ny, nu):
+    """The reference is generic in the state dimension (src/PFtypes.jl:65-75); the library is precompiled for nx, ny <= 4 and
+    compiles LinGauss<nx, ny> on demand above that (kernels/jit.hpp: jit_builtin_lg): whole trajectories with weighted means,
+    single steps, the auxiliary filter and a bank are the device-order oracle's bit for bit, the reference order's within tolerance."""
+    rng = np.random.default_rng(100 + nx + ny)
+    A = 0.9 * np.linalg.qr(rng.standard_normal((nx, nx)))[0]
+    B = 0.2 * rng.standard_normal((nx, nu)) if nu else None
+    Cm = rng.standard_normal((ny, nx))
+    model = S.make_lg_model(A, B, Cm, S.make_gaussian(np.zeros(nx), 0.05), S.make_gaussian(np.zeros(ny), 0.5 + rng.random(ny)),
+                            S.make_gaussian(rng.standard_normal(nx), 1.0))
+    _, U, Y = M.simulate_lg(model, 30, seed=4)
+    Y[11] = np.nan
+    cfg = _cfg(model, 3000, thr=0.5, seed=77)
+    g, o, r = _capi.FilterHandle(cfg), ob.OracleFilter(cfg, ob.ORDER_DEVICE), ob.OracleFilter(cfg, ob.ORDER_REFERENCE)
+    for h in (g, o, r):
+        h.reset()
+    _compare_state(g, o)
+    rg, ro, rr = (h.run(U, Y, 0.0, ll_steps=True, xmean=True) for h in (g, o, r))
+    assert np.array_equal(rg["ll_steps"].view(np.uint64), ro["ll_steps"].view(np.uint64)) and o.resample_count() > 2
+    np.testing.assert_allclose(rg["xmean"], ro["xmean"], rtol=1e-12, atol=1e-13)       # a plain fp64 sum: order differs, never fed back
+    _compare_state(g, o)
+    assert np.max(np.abs(rg["ll_steps"] - rr["ll_steps"])) <= TOL_LL_STEP
+    g.reset(); o.reset()
+    for k in range(8):
+        assert g.update(U[k] if nu else None, Y[k], float(k)) == o.update(U[k] if nu else None, Y[k], float(k))
+    _compare_state(g, o)
+    g.reset(); o.reset()
+    assert np.array_equal(g.run_aux(U, Y, 1, ll_steps=True)["ll_steps"].view(np.uint64), o.run_aux(U, Y, 1, ll_steps=True)["ll_steps"].view(np.uint64))
+    b = _capi.BankHandle(cfg, [model, model, model])
+    b.reset()
+    g2 = _capi.FilterHandle(_cfg(model, 3000, thr=0.5, seed=79)); g2.reset()
+    assert np.array_equal(b.run(U, Y, 0.0, ll_steps=True)["ll_steps"][:, 2].copy().view(np.uint64), g2.run(U, Y, 0.0, ll_steps=True)["ll_steps"].view(np.uint64))
 
 
 def test_bank_shares_of_a_sharded_sweep_match_single_bank():
