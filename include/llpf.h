@@ -61,7 +61,8 @@ typedef struct llpf_gaussian {
 
 /* built-in models */
 enum {
-    LLPF_MODEL_LINEAR_GAUSSIAN = 0,  /* f = A x + B u, g = C x  (reference examples/example_lineargaussian.jl:28-29) */
+    LLPF_MODEL_LINEAR_GAUSSIAN = 0,  /* f = A x + B u, g = C x  (reference examples/example_lineargaussian.jl:28-29); nx, ny, nu in 1..8 (nu from 0):
+                                      * precompiled up to 4 (one fused launch per timestep), compiled on demand through hiprtc above (two launches) */
     LLPF_MODEL_QUADTANK_RK4    = 1,  /* quad-tank, RK4          (reference examples/example_quadtank.jl:8-35, src/utils.jl:220-237) */
     /* Rao-Blackwellized particle filter with constant matrices (reference src/rbpf.jl:63-283, "model 2" of :92-98):
      *   xn' = Fn xn + Bn u + An xl + wn,  wn ~ dynamics_density (R1n)     xl' = Al xl + Bl u + wl,  wl ~ linear_noise (R1l)
@@ -76,7 +77,9 @@ enum {
      *   xl' = Al xl + Bl u + wl,             y = g(xn) + Cl xl + e
      * llpf_model.nx = nxn <= 4 (what f_n, g and the densities df, d0 see); f_n / g are the linear-Gaussian descriptors A, B, C of this
      * struct sized for nxn (rb.fn_kind 0) or the quad-tank RK4 dynamics / measurement (rb.fn_kind 1, nxn = 4, ny = 2).
-     * nxl = rb.nxl <= 8, ny <= 2; dynamics_density = R1n (must be Gaussian), linear_noise = R1l, linear_initial = d0l. */
+     * nxl = rb.nxl <= 8, ny <= 2; dynamics_density = R1n (must be Gaussian), linear_noise = R1l, linear_initial = d0l.
+     * Shapes (nxn, nxl, ny) = (1,2,1), (2,2,2), (4,8,2) are precompiled, every other one is compiled through hiprtc when the filter is
+     * built.  Banks and multi-GPU sweeps of such filters are provided (without weighted means); the auxiliary filter and the smoother are not. */
     LLPF_MODEL_RB_BILINEAR     = 3,
     /* ids >= LLPF_MODEL_USER_BASE: models compiled at run time from device source, llpf_model_compile() below */
     LLPF_MODEL_USER_BASE       = 1000

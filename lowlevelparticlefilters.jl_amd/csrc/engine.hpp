@@ -228,6 +228,8 @@ struct ResArgs {
 
 // launchers (kernels.hip)
 hipError_t launch_init(const BankDev& b, uint32_t step, int init_anc, hipStream_t s);
+hipError_t launch_rbfull_jit(int fn_kind, int nn, int nl, int ny, const BankDev& b, int mode, const StepArgs& a, hipStream_t s);   // kernels/jit.hpp
+int jit_prepare_rbfull(int fn_kind, int nn, int nl, int ny, std::string& err);   // compiles the shape if needed (bank construction reports the log)
 int jit_builtin_lg(int nx, int ny, std::string& err);   // kernels/jit.hpp: LinGauss<nx, ny> compiled on demand (nx or ny above 4), id as a user model
 hipError_t launch_user_bound(int model_id, ModelD* models, int F, const double* zero_u, hipStream_t s);   // kernels/jit.hpp: bound of a user likelihood
 hipError_t launch_rbfull(const BankDev& b, int mode, const StepArgs& a, hipStream_t s);   // k_rbfull.hip (called by launch_step)

@@ -258,7 +258,12 @@ static int bank_create(const llpf_config* cfg, const llpf_model* models, int F, 
         if ((uint64_t)rbfull_rows(m0.nx, m0.rb.nxl) * (uint64_t)((cfg->n_particles + TILE - 1) / TILE * TILE) * 8u >= ((uint64_t)1 << 32))
             return fail(LLPF_ERR_ARG, "LLPF_MODEL_RB_BILINEAR: the planes of one filter (rows x particles x 8 bytes) must span less than 4 GB");
         if (!rbfull_supported(m0.rb.fn_kind, m0.nx, m0.rb.nxl, m0.ny))
-            return fail(LLPF_ERR_ARG, "LLPF_MODEL_RB_BILINEAR: instantiated shapes (nxn, nxl, ny) are (1,2,1), (2,2,2), (4,8,2); quad-tank: (4,8,2)");
+            return fail(LLPF_ERR_ARG, "LLPF_MODEL_RB_BILINEAR: nxn in 1..4, nxl in 1..8, ny in 1..2 (quad-tank nonlinear part: nxn = 4, ny = 2)");
+        const bool pre = (m0.rb.fn_kind == 1) ? (m0.rb.nxl == 8) : ((m0.nx == 1 && m0.rb.nxl == 2 && m0.ny == 1) || (m0.nx == 2 && m0.rb.nxl == 2 && m0.ny == 2) || (m0.nx == 4 && m0.rb.nxl == 8 && m0.ny == 2));
+        if (!pre) {     // a shape the library was not precompiled for: k_rbfull compiled on demand (kernels/jit.hpp), cached
+            std::string err;
+            if (jit_prepare_rbfull(m0.rb.fn_kind, m0.nx, m0.rb.nxl, m0.ny, err) != 0) return fail(LLPF_ERR_HIP, "LLPF_MODEL_RB_BILINEAR shape: " + err);
+        }
     }
     if (cfg->resampling_strategy != LLPF_RESAMPLE_SYSTEMATIC && cfg->resampling_strategy != LLPF_RESAMPLE_STRATIFIED &&
         cfg->resampling_strategy != LLPF_RESAMPLE_RESIDUAL)

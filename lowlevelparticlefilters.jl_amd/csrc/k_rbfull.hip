@@ -22,10 +22,15 @@ namespace llpf {
 static inline dim3 grid1(int64_t n, int F) { return dim3((unsigned)((n + BLOCK - 1) / BLOCK), (unsigned)F, 1); }
 
 // LLPF_MODEL_RB_BILINEAR: the instantiated shapes (nxn, nxl, ny); fn_kind 1 = quad-tank nonlinear part
-bool rbfull_supported(int fn_kind, int nn, int nl, int ny) {
+// precompiled: (1,2,1), (2,2,2), (4,8,2) and the quad-tank's (4,8,2); every other shape within the header's limits is compiled on demand
+static bool rbfull_precompiled(int fn_kind, int nn, int nl, int ny) {
     if (fn_kind == 1) return nn == 4 && nl == 8 && ny == 2;
-    if (fn_kind != 0) return false;
     return (nn == 1 && nl == 2 && ny == 1) || (nn == 2 && nl == 2 && ny == 2) || (nn == 4 && nl == 8 && ny == 2);
+}
+bool rbfull_supported(int fn_kind, int nn, int nl, int ny) {
+    if (nn < 1 || nn > LLPF_RBF_MAXN || nl < 1 || nl > LLPF_RBF_MAXL || ny < 1 || ny > LLPF_RBF_MAXY) return false;
+    if (fn_kind == 1) return nn == 4 && ny == 2;
+    return fn_kind == 0;
 }
 int rbfull_rows(int nn, int nl) { return nn + nl + LLPF_RBF_NP(nl); }
 
@@ -47,15 +52,14 @@ hipError_t launch_rbfull(const BankDev& b, int mode, const StepArgs& a, hipStrea
     if (fk == 0 && b.nx == 4 && nl == 8 && b.ny == 2) return launch_rbfull_t<LinGauss<4, 2>, 4, 8, 2>(b, mode, a, s);
     if (fk == 0 && b.nx == 2 && nl == 2 && b.ny == 2) return launch_rbfull_t<LinGauss<2, 2>, 2, 2, 2>(b, mode, a, s);
     if (fk == 0 && b.nx == 1 && nl == 2 && b.ny == 1) return launch_rbfull_t<LinGauss<1, 1>, 1, 2, 1>(b, mode, a, s);
-    return hipErrorInvalidValue;
+    if (!rbfull_supported(fk, b.nx, nl, b.ny) || rbfull_precompiled(fk, b.nx, nl, b.ny)) return hipErrorInvalidValue;
+    return launch_rbfull_jit(fk, b.nx, nl, b.ny, b, mode, a, s);        // compiled on demand (kernels/jit.hpp), cached per shape
 }
 hipError_t launch_rbfull_init(const BankDev& b, hipStream_t s) {
     const int nl = b.pad0 & 0xff;
     dim3 g = grid1(b.Ns, b.F);
-    if (b.nx == 4 && nl == 8) hipLaunchKernelGGL((k_rbfull_init<4, 8>), g, dim3(BLOCK), 0, s, b, b.models);
-    else if (b.nx == 2 && nl == 2) hipLaunchKernelGGL((k_rbfull_init<2, 2>), g, dim3(BLOCK), 0, s, b, b.models);
-    else if (b.nx == 1 && nl == 2) hipLaunchKernelGGL((k_rbfull_init<1, 2>), g, dim3(BLOCK), 0, s, b, b.models);
-    else return hipErrorInvalidValue;
+    if (nl < 1 || nl > LLPF_RBF_MAXL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_rbfull_init, g, dim3(BLOCK), 0, s, b, b.models);
     return hipGetLastError();
 }
 

@@ -135,3 +135,86 @@ static hipError_t launch_step_user(const BankDev& b, int mode, const StepArgs& a
     void* args[] = {&bd, &models, &scal, &aa};
     return hipModuleLaunchKernel(fn, (unsigned)(b.Ns / (BLOCK * STEP_PPT * STEP_ITERS)), (unsigned)b.F, 1, BLOCK, 1, 1, 0, s, args, nullptr);
 }
+
+// ---- k_rbfull for shapes the library was not precompiled for (kernels/rbfull.hpp is part of the prelude) -----------------------------
+struct JitRbfull {
+    int fk = 0, nn = 0, nl = 0, ny = 0;
+    std::vector<char> code;
+    std::string name[3];                       // MODE_WEIGHT, MODE_PROP, MODE_PROP_WEIGHT
+    struct PerDevice { hipModule_t mod = nullptr; hipFunction_t fn[3] = {nullptr, nullptr, nullptr}; };
+    std::vector<PerDevice> dev;
+};
+static std::vector<JitRbfull*> g_jit_rbfull;
+static JitRbfull* jit_rbfull_find(int fk, int nn, int nl, int ny) {
+    for (JitRbfull* j : g_jit_rbfull) if (j->fk == fk && j->nn == nn && j->nl == nl && j->ny == ny) return j;
+    return nullptr;
+}
+int jit_prepare_rbfull(int fk, int nn, int nl, int ny, std::string& err) {
+    {
+        std::lock_guard<std::mutex> lk(g_jit_mutex);
+        if (jit_rbfull_find(fk, nn, nl, ny)) return 0;
+    }
+    std::string src(LLPF_JIT_PRELUDE);
+    hiprtcProgram prog = nullptr;
+    if (hiprtcCreateProgram(&prog, src.c_str(), "llpf_rbfull_shape.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) { err = "hiprtcCreateProgram failed"; return -1; }
+    const std::string model = (fk == 1 ? "llpf::QuadTank<" : "llpf::LinGauss<") + std::to_string(nn) + ", " + std::to_string(ny) + ">";
+    std::string expr[3];
+    for (int mode = 0; mode < 3; ++mode) {
+        expr[mode] = "llpf::k_rbfull<" + model + ", " + std::to_string(nn) + ", " + std::to_string(nl) + ", " + std::to_string(ny) + ", " + std::to_string(mode) + ">";
+        hiprtcAddNameExpression(prog, expr[mode].c_str());
+    }
+    int devid = 0;
+    hipDeviceProp_t prop;
+    std::string arch = "gfx950";
+    if (hipGetDevice(&devid) == hipSuccess && hipGetDeviceProperties(&prop, devid) == hipSuccess && prop.gcnArchName[0]) arch = prop.gcnArchName;
+    const std::string archopt = "--offload-arch=" + arch;
+    const char* opts[] = {archopt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-Wno-unused-value"};
+    const hiprtcResult rc = hiprtcCompileProgram(prog, (int)(sizeof(opts) / sizeof(opts[0])), opts);
+    if (rc != HIPRTC_SUCCESS) {
+        size_t n = 0;
+        hiprtcGetProgramLogSize(prog, &n);
+        std::string log(n, '\0');
+        if (n) hiprtcGetProgramLog(prog, &log[0]);
+        err = std::string("hiprtc: ") + hiprtcGetErrorString(rc) + "\n" + log;
+        hiprtcDestroyProgram(&prog);
+        return -1;
+    }
+    JitRbfull* j = new JitRbfull();
+    j->fk = fk; j->nn = nn; j->nl = nl; j->ny = ny;
+    size_t sz = 0;
+    hiprtcGetCodeSize(prog, &sz);
+    j->code.resize(sz);
+    hiprtcGetCode(prog, j->code.data());
+    for (int mode = 0; mode < 3; ++mode) {
+        const char* low = nullptr;
+        if (hiprtcGetLoweredName(prog, expr[mode].c_str(), &low) != HIPRTC_SUCCESS || !low) { err = "hiprtcGetLoweredName failed for " + expr[mode]; delete j; hiprtcDestroyProgram(&prog); return -1; }
+        j->name[mode] = low;
+    }
+    hiprtcDestroyProgram(&prog);
+    std::lock_guard<std::mutex> lk(g_jit_mutex);
+    g_jit_rbfull.push_back(j);
+    return 0;
+}
+hipError_t launch_rbfull_jit(int fk, int nn, int nl, int ny, const BankDev& b, int mode, const StepArgs& a, hipStream_t s) {
+    if (mode < 0 || mode > 2) return hipErrorInvalidValue;
+    int devid = 0;
+    hipError_t e = hipGetDevice(&devid);
+    if (e != hipSuccess) return e;
+    hipFunction_t fn = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_jit_mutex);
+        JitRbfull* j = jit_rbfull_find(fk, nn, nl, ny);
+        if (!j) return hipErrorInvalidValue;            // jit_prepare_rbfull runs when the bank is built
+        if ((int)j->dev.size() <= devid) j->dev.resize((size_t)devid + 1);
+        JitRbfull::PerDevice& pd = j->dev[(size_t)devid];
+        if (!pd.mod && (e = hipModuleLoadData(&pd.mod, j->code.data())) != hipSuccess) return e;
+        if (!pd.fn[mode] && (e = hipModuleGetFunction(&pd.fn[mode], pd.mod, j->name[mode].c_str())) != hipSuccess) return e;
+        fn = pd.fn[mode];
+    }
+    BankDev bd = b;
+    const ModelD* models = b.models;
+    const FilterScal* scal = b.scal;
+    StepArgs aa = a;
+    void* args[] = {&bd, &models, &scal, &aa};
+    return hipModuleLaunchKernel(fn, (unsigned)(b.Ns / 64), (unsigned)b.F, 1, 64, 1, 1, 0, s, args, nullptr);
+}

@@ -170,17 +170,14 @@ __global__ __launch_bounds__(RBF_BLOCK) __attribute__((amdgpu_waves_per_eu(NL >=
     }
 }
 
-// reset!(pf::RBPF), src/rbpf.jl:146-160: xl = copy(kf.d0.mu), R = copy(kf.d0.Sigma) for every particle (xn ~ d0n by k_init)
-template <int NN, int NL>
+// reset!(pf::RBPF), src/rbpf.jl:146-160: xl = copy(kf.d0.mu), R = copy(kf.d0.Sigma) for every particle (xn ~ d0n by k_init); any shape
 __global__ __launch_bounds__(BLOCK) void k_rbfull_init(BankDev b, const ModelD* __restrict__ models) {
-    constexpr int NP = LLPF_RBF_NP(NL), ROWS = NN + NL + NP;
+    const int nn = b.nx, nl = b.pad0 & 0xff, np = LLPF_RBF_NP(nl);
     const int f = blockIdx.y;
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= b.Ns) return;
     const llpf_rbf_par* par = &models[f].rbf;
-    double* xc = b.xcur + (size_t)f * ROWS * b.Ns;
-#pragma unroll
-    for (int d = 0; d < NL; ++d) xc[(size_t)(NN + d) * b.Ns + i] = par->xl0[d];
-#pragma unroll
-    for (int d = 0; d < NP; ++d) xc[(size_t)(NN + NL + d) * b.Ns + i] = par->R0[d];
+    double* xc = b.xcur + (size_t)f * b.xrows * b.Ns;
+    for (int d = 0; d < nl; ++d) xc[(size_t)(nn + d) * b.Ns + i] = par->xl0[d];
+    for (int d = 0; d < np; ++d) xc[(size_t)(nn + nl + d) * b.Ns + i] = par->R0[d];
 }

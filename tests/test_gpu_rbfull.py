@@ -123,7 +123,8 @@ def test_rbfull_api_and_errors():
     assert np.max(np.abs(R - R[0])) > 1e-6
     with pytest.raises(_capi.LLPFError):
         llpf_amd.smooth(pf, 10, U, Y)
-    bad, _ = M.linear_case(2, 4, 2, seed=1)                    # a shape without an instantiated kernel
+    bad, _ = M.linear_case(2, 4, 2, seed=1)
+    bad.rb.nxl = 9                                               # above the header's limit (LLPF_RBF_MAXL)
     with pytest.raises(_capi.LLPFError):
         _capi.FilterHandle(_cfg(bad, 1000))
 
@@ -167,3 +168,25 @@ def test_bank_of_rb_filters(name, N, T):
     mb = _capi.MBankHandle(cfg, models, devices=[0, 0])
     mb.reset()
     assert _same_bits(mb.run(U, Y, 0.0)["ll"], rb["ll"])
+
+
+@pytest.mark.parametrize("shape", [(2, 4, 2), (3, 5, 1), (4, 3, 2)])
+def test_rb_shapes_compiled_on_demand(shape):
+    """(nxn, nxl, ny) beyond the precompiled (1,2,1), (2,2,2), (4,8,2): k_rbfull<LinGauss<nxn, ny>, nxn, nxl, ny> is compiled through
+    hiprtc when the filter is built (kernels/jit.hpp, cached per shape) — the reference's RBPF is generic in its dimensions
+    (src/rbpf.jl:63-144).  Trajectories, every particle's Kalman mean and covariance, single steps: the device-order oracle's bits."""
+    model, _ = M.linear_case(*shape, seed=2)
+    U, Y = M.simulate_io(model, 25)
+    cfg = _cfg(model, 2000, S.RESAMPLE_SYSTEMATIC, 0.5, seed=6)
+    g = _capi.FilterHandle(cfg); o = ob.OracleFilter(cfg, ob.ORDER_DEVICE); r = ob.OracleFilter(cfg, ob.ORDER_REFERENCE)
+    for h in (g, o, r):
+        h.reset()
+    _compare_state(g, o); _compare_linear_state(g, o)
+    rg, ro, rr = (h.run(U, Y, 0.0, ll_steps=True) for h in (g, o, r))
+    assert _same_bits(rg["ll_steps"], ro["ll_steps"]) and o.resample_count() > 1
+    _compare_state(g, o); _compare_linear_state(g, o)
+    assert np.max(np.abs(rg["ll_steps"] - rr["ll_steps"])) <= TOL_LL_STEP
+    g.reset(); o.reset()
+    for k in range(6):
+        assert g.update(U[k], Y[k], float(k)) == o.update(U[k], Y[k], float(k))
+    _compare_linear_state(g, o)
