@@ -287,6 +287,11 @@ def main_bank(args, rank, world, dev):
                                          "note": "rank 0 alone on its per-GPU share (%d filters) while the other ranks wait: aggregate / (n_gpus x this) "
                                                  "is the weak-scaling efficiency of this workload" % args.filters_per_gpu,
                                          "efficiency": value / (world * solo)}
+        # The N = 1 default line is C2 (one filter), the N > 1 default lines are C4 (a sweep): a ratio of their `value`s would mix two
+        # workloads.  Every line therefore names the one-GPU rate of ITS OWN per-GPU share, the denominator of a weak-scaling ratio.
+        out["scaling_reference"] = {"workload": "C4 share: %d filters x N=%d per GPU" % (Fl, N), "value_one_gpu": solo if solo is not None else value,
+                                    "unit": "particle-steps/s",
+                                    "how_to_use": "weak-scaling efficiency of this line = value / (n_gpus x value_one_gpu); do not divide by the N = 1 C2 line"}
         pm = load_pmc()
         if pm and pm.get("c4") and pm["c4"]["filters"] == Fl and pm["c4"]["n_particles"] == N:
             out["roofline"]["traffic"] = pm["c4"]["k_resprop"]["bytes"]
@@ -297,6 +302,11 @@ def main_bank(args, rank, world, dev):
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
         if world == 1 and args.workload == "lg" and not args.no_other_configs and not args.no_cpu_baseline and args.particles == 1000000 and not args.T:
             out["other_configs"] = other_configs()
+            c4 = out["other_configs"].get("C4_share_128x1e5", {})
+            out["scaling_reference"] = {"workload": (c4.get("config") or {}).get("workload"), "value_one_gpu": c4.get("value"), "unit": "particle-steps/s",
+                                        "how_to_use": "`bench.py --gpus N` (N > 1) runs BASELINE config C4, a sweep of independent filters, 128 per GPU — not this "
+                                                      "line's C2 single filter.  The one-GPU rate of that per-GPU share is this value: weak-scaling efficiency of an "
+                                                      "N-GPU line = its value / (N x value_one_gpu)"}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
@@ -395,6 +405,10 @@ def self_spawn(args, argv):
     return subprocess.call(cmd, env=env)
 
 
+SCALING_REFERENCE_DOC = ("every bench line carries `scaling_reference.value_one_gpu`: the one-GPU rate of the per-GPU share the N > 1 lines run "
+                         "(BASELINE config C4), so that a scaling ratio never divides a C4 sweep by the C2 single filter of the N = 1 default line")
+
+
 def main_spawn_check(rank, local_rank, world, backend):
     """--spawn-check: every rank reports in and rank 0 prints what it saw; no GPU work (the CPU test of the launcher logic)."""
     import torch
@@ -407,7 +421,8 @@ def main_spawn_check(rank, local_rank, world, backend):
         dist.all_gather_object(seen, me)
     if rank == 0:
         print(json.dumps({"spawn_check": True, "n_gpus": world, "ranks_seen": sorted(r["rank"] for r in seen),
-                          "distinct_processes": len({r["pid"] for r in seen}), "ranks": seen}))
+                          "distinct_processes": len({r["pid"] for r in seen}), "ranks": seen,
+                          "default_workload": "C4 share (bank) per GPU" if world > 1 else "C2 (lg)", "scaling_reference_doc": SCALING_REFERENCE_DOC}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -658,6 +673,11 @@ def main():
                 out["accuracy"]["ancestor_mismatches_vs_reference_order"] = tf
         if world == 1 and args.workload == "lg" and not args.no_other_configs and not args.no_cpu_baseline and args.particles == 1000000 and not args.T:
             out["other_configs"] = other_configs()
+            c4 = out["other_configs"].get("C4_share_128x1e5", {})
+            out["scaling_reference"] = {"workload": (c4.get("config") or {}).get("workload"), "value_one_gpu": c4.get("value"), "unit": "particle-steps/s",
+                                        "how_to_use": "`bench.py --gpus N` (N > 1) runs BASELINE config C4, a sweep of independent filters, 128 per GPU — not this "
+                                                      "line's C2 single filter.  The one-GPU rate of that per-GPU share is this value: weak-scaling efficiency of an "
+                                                      "N-GPU line = its value / (N x value_one_gpu)"}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -324,12 +324,21 @@ int  llpf_bank_aux_run(llpf_bank* b, const double* U, const double* Y, int64_t T
  *                           (ncclCommInitRank).  id == NULL with world > 1: no communicator; llpf_mbank_run then returns
  *                           this rank's slots (zeros elsewhere) and the caller owns the exchange.
  * `models` is NULL (replicas of base->model) or holds all n_filters descriptors, in every process.
- * librccl is loaded on first use (dlopen); LLPF_ERR_HIP with the loader's / RCCL's message if that fails. */
+ * librccl is loaded on first use (dlopen); LLPF_ERR_HIP with the loader's / RCCL's message if that fails.
+ * STATUS of the RCCL exchange: exercised with one-rank communicators only (the development boxes have one GPU); sharding, the
+ * host-summed exchange, the caller-owned exchange (id == NULL) and the partition are tested to return the unsharded sweep's bits.
+ * Until a run on two or more GPUs has confirmed the same for ncclCommInitAll / ncclCommInitRank with more than one rank, treat
+ * that mode as experimental: `id == NULL` + the caller's own all-reduce is the verified way to span processes. */
 #define LLPF_MBANK_ID_BYTES 128
 typedef struct llpf_mbank llpf_mbank;     /* opaque: shards + communicator */
 int  llpf_mbank_create(const llpf_config* base, const llpf_model* models, int32_t n_filters,
                        const int32_t* devices, int32_t n_devices, llpf_mbank** out);
 int  llpf_mbank_unique_id(uint8_t* id /* LLPF_MBANK_ID_BYTES */);
+/* which filters of a sweep shard `shard` of `n_shards` owns (k with k mod n_shards == shard, ascending) — the partition both
+ * constructors use, exposed for callers that own the exchange themselves (id == NULL) and for tests; pure host code, no device.
+ * owned may be NULL (count only); replaces the index arithmetic of `map(svec) do s ... end` spread over workers
+ * (reference test/runtests.jl:412-417, src/smoothing.jl:335-347) */
+int  llpf_mbank_partition(int32_t n_filters, int32_t shard, int32_t n_shards, int32_t* owned, int32_t* n_owned);
 int  llpf_mbank_create_rank(const llpf_config* base, const llpf_model* models, int32_t n_filters,
                             int32_t rank, int32_t world, const uint8_t* id /* LLPF_MBANK_ID_BYTES or NULL */, llpf_mbank** out);
 int  llpf_mbank_destroy(llpf_mbank* m);

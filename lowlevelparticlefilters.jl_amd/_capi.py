@@ -62,6 +62,7 @@ SYMBOLS = {
     "llpf_bank_run_multi": [_vp, _dp, _dp, C.c_int64, C.c_double, _dp, _dp, _dp],
     "llpf_mbank_create": [C.POINTER(S.Config), C.POINTER(S.Model), C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.POINTER(_vp)],
     "llpf_mbank_unique_id": [C.POINTER(C.c_uint8)],
+    "llpf_mbank_partition": [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
     "llpf_mbank_create_rank": [C.POINTER(S.Config), C.POINTER(S.Model), C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_uint8), C.POINTER(_vp)],
     "llpf_mbank_destroy": [_vp],
     "llpf_mbank_reset": [_vp],
@@ -584,6 +585,15 @@ class MBankHandle:
         n = np.zeros(PROF_CLASSES, dtype=np.int64)
         check(self.L.llpf_mbank_get_profile(self.h, int(local_shard), dptr(ms), iptr(n)))
         return ms, n
+
+
+def mbank_partition(n_filters, shard, n_shards):
+    """llpf_mbank_partition: global indices of the filters shard `shard` of `n_shards` owns (pure host code)"""
+    n = C.c_int32(0)
+    check(lib().llpf_mbank_partition(int(n_filters), int(shard), int(n_shards), None, C.byref(n)))
+    a = (C.c_int32 * max(1, n.value))()
+    check(lib().llpf_mbank_partition(int(n_filters), int(shard), int(n_shards), a, C.byref(n)))
+    return [int(a[i]) for i in range(n.value)]
 
 
 def model_compile(device_src, nx, ny):

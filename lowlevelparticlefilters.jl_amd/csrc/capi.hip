@@ -403,6 +403,15 @@ int llpf_mbank_unique_id(uint8_t* id) {
     memcpy(id, u.internal, LLPF_MBANK_ID_BYTES);
     return LLPF_OK;
 }
+// the partition llpf_mbank_create / llpf_mbank_create_rank use (mbank_owned), as an entry point of its own: pure host code, needs no device
+int llpf_mbank_partition(int32_t n_filters, int32_t shard, int32_t n_shards, int32_t* owned, int32_t* n_owned) {
+    if (n_filters < 0 || n_shards < 1 || shard < 0 || shard >= n_shards || !n_owned) return fail(LLPF_ERR_ARG, "partition: bad arguments");
+    std::vector<int> o;
+    mbank_owned(n_filters, shard, n_shards, o);
+    *n_owned = (int32_t)o.size();
+    if (owned) for (size_t i = 0; i < o.size(); ++i) owned[i] = (int32_t)o[i];
+    return LLPF_OK;
+}
 int llpf_mbank_create_rank(const llpf_config* base, const llpf_model* models, int32_t n_filters, int32_t rank, int32_t world,
                            const uint8_t* id, llpf_mbank** out) {
     if (!out) return fail(LLPF_ERR_ARG, "null out pointer");

@@ -22,6 +22,10 @@ def test_gpus_flag_spawns_that_many_ranks():
     assert out.returncode == 0, out.stderr[-2000:]
     r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert r["n_gpus"] == 2 and r["ranks_seen"] == [0, 1] and r["distinct_processes"] == 2
+    # the N > 1 default is another workload than the N = 1 default: every line names the one-GPU rate of its own share
+    assert r["default_workload"].startswith("C4") and "scaling_reference" in r["scaling_reference_doc"]
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert src.count('out["scaling_reference"]') >= 2             # set on the bank (N >= 1) lines and on the default C2 line
 
 
 def test_world_size_must_agree_with_gpus():

@@ -1,6 +1,8 @@
-"""N > 1 host logic on CPU: two processes over gloo shard a sweep of independent filters and all-reduce the
-per-filter log-likelihoods.  The per-rank compute is injected (oracle-backed stand-in here, the GPU bank in
-bench.py), so this exercises exactly the sharding + collective code the GPU path uses."""
+"""N > 1 host logic on CPU: two processes over gloo shard a sweep of independent filters with the partition of the C ABI
+(llpf_mbank_partition — the function llpf_mbank_create / llpf_mbank_create_rank use themselves, pure host code) and own the exchange
+like a caller of llpf_mbank_create_rank(..., id = NULL): every rank fills its own slots of the per-filter log-likelihood vector and
+the vectors are summed (all-reduce).  The per-rank compute is an oracle-backed stand-in (no GPU here); filter k keeps key seed + k
+wherever it lives, so the sharded sweep must return the unsharded one's bits."""
 import os
 import sys
 
@@ -9,46 +11,49 @@ import pytest
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N_FILTERS, N_PART, SEED = 5, 300, 50
 
 
-class _OracleBank:
-    """Stand-in with the BankHandle interface: filter k uses seed base + global index, like llpf_bank_create."""
+def _sweep():
+    import models as M
+    models = [M.lg_test_model(s) for s in 10.0 ** np.linspace(-2, 0, N_FILTERS)]
+    _, U, Y = M.simulate_lg(models[2], 40)
+    return models, U, Y
 
-    def __init__(self, models, owned, N, seed):
-        import oracle_binding as ob
-        from llpf_amd import _structs as S
-        self.filters = [ob.OracleFilter(S.make_config(m, N, resample_threshold=0.1, seed=seed + g), ob.ORDER_DEVICE)
-                        for m, g in zip(models, owned)]
 
-    def reset(self):
-        for f in self.filters:
-            f.reset()
-
-    def run(self, U, Y, t_index0):
-        return {"ll": np.array([f.run(U, Y, t_index0)["ll"] for f in self.filters])}
+def _shard_ll(models, U, Y, owned):
+    """what a shard computes: log-likelihood of every owned filter, key seed + global index (llpf_bank_create's rule)"""
+    import oracle_binding as ob
+    from llpf_amd import _structs as S
+    full = np.zeros(len(models))
+    for k in owned:
+        f = ob.OracleFilter(S.make_config(models[k], N_PART, resample_threshold=0.1, seed=SEED + k), ob.ORDER_DEVICE)
+        f.reset()
+        full[k] = f.run(U, Y, 1.0)["ll"]
+    return full
 
 
 def _worker(rank, world, port, q):
     for p in (ROOT, os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
+    import torch
     import torch.distributed as dist
-    import models as M
-    from llpf_amd import distributed as D
+    from llpf_amd import _capi
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    models = [M.lg_test_model(s) for s in 10.0 ** np.linspace(-2, 0, 5)]
-    _, U, Y = M.simulate_lg(models[2], 40)
-    ll, tot = D.sharded_bank_loglik(lambda ms, owned: _OracleBank(ms, owned, 300, 50), models, U, Y, rank, world)
-    q.put((rank, ll, tot))
+    models, U, Y = _sweep()
+    owned = _capi.mbank_partition(len(models), rank, world)
+    t = torch.from_numpy(_shard_ll(models, U, Y, owned))
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)           # a slot has one non-zero contribution: the sum is exact
+    q.put((rank, owned, t.numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_two_rank_sweep_matches_single_process():
-    import models as M
-    from llpf_amd import distributed as D
+    from llpf_amd import _capi
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + (os.getpid() % 500)
@@ -59,11 +64,20 @@ def test_two_rank_sweep_matches_single_process():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    models = [M.lg_test_model(s) for s in 10.0 ** np.linspace(-2, 0, 5)]
-    _, U, Y = M.simulate_lg(models[2], 40)
-    ll_ref, tot_ref = D.sharded_bank_loglik(lambda ms, owned: _OracleBank(ms, owned, 300, 50), models, U, Y, 0, 1)
-    for rank, ll, tot in res:
-        assert np.array_equal(ll, ll_ref), "rank %d" % rank      # every rank ends with the full vector
-        assert tot == tot_ref
-    assert D.shard_indices(5, 0, 2) == [0, 2, 4] and D.shard_indices(5, 1, 2) == [1, 3]
-    assert sorted(D.shard_indices(1024, 3, 8))[:3] == [3, 11, 19] and len(D.shard_indices(1024, 3, 8)) == 128
+    models, U, Y = _sweep()
+    ll_ref = _shard_ll(models, U, Y, range(len(models)))
+    seen = []
+    for rank, owned, ll in res:
+        assert np.array_equal(ll, ll_ref), "rank %d" % rank      # every rank ends with the full vector, bit for bit
+        seen += owned
+    assert sorted(seen) == list(range(N_FILTERS))
+
+
+def test_partition_of_the_abi():
+    from llpf_amd import _capi
+    assert _capi.mbank_partition(5, 0, 2) == [0, 2, 4] and _capi.mbank_partition(5, 1, 2) == [1, 3]
+    p = _capi.mbank_partition(1024, 3, 8)                       # BASELINE config C4: 128 filters per GPU
+    assert p[:3] == [3, 11, 19] and len(p) == 128 and p[-1] == 1019
+    assert _capi.mbank_partition(3, 7, 8) == [] and _capi.mbank_partition(0, 0, 1) == []
+    with pytest.raises(_capi.LLPFError):
+        _capi.mbank_partition(10, 2, 2)

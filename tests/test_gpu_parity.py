@@ -548,8 +548,7 @@ def test_linear_gaussian_above_the_precompiled_dimensions(nx, ny, nu):
 
 def test_bank_shares_of_a_sharded_sweep_match_single_bank():
     """The 8-GPU sharding of config C4 in miniature: banks built from round-robin shards of a sweep (what each rank
-    runs, lowlevelparticlefilters.jl_amd/distributed.py) reproduce the log-likelihoods of the whole bank."""
-    from llpf_amd import distributed as D
+    runs; partition: llpf_mbank_partition) reproduce the log-likelihoods of the whole bank."""
     svec = 10.0 ** np.linspace(-2, 0, 12)
     models = [M.lg_test_model(s) for s in svec]
     _, U, Y = M.simulate_lg(models[5], 60)
@@ -571,7 +570,7 @@ def test_bank_shares_of_a_sharded_sweep_match_single_bank():
     ll_whole = whole.run(U, Y, 1.0)["ll"]
     got = np.zeros(12)
     for rank in range(4):
-        own = D.shard_indices(12, rank, 4)
+        own = _capi.mbank_partition(12, rank, 4)
         b = Bank([models[k] for k in own], own)
         b.reset()
         got[own] = b.run(U, Y, 1.0)["ll"]
