@@ -300,13 +300,6 @@ def main_bank(args, rank, world, dev):
             cs = args.cpu_steps if args.cpu_steps else 1000
             out.update(cpu_baseline(models[len(models) // 2], U, Y, S.PARTICLE_FILTER, thr, N, min(cs, T), 77, None))
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
-        if world == 1 and args.workload == "lg" and not args.no_other_configs and not args.no_cpu_baseline and args.particles == 1000000 and not args.T:
-            out["other_configs"] = other_configs()
-            c4 = out["other_configs"].get("C4_share_128x1e5", {})
-            out["scaling_reference"] = {"workload": (c4.get("config") or {}).get("workload"), "value_one_gpu": c4.get("value"), "unit": "particle-steps/s",
-                                        "how_to_use": "`bench.py --gpus N` (N > 1) runs BASELINE config C4, a sweep of independent filters, 128 per GPU — not this "
-                                                      "line's C2 single filter.  The one-GPU rate of that per-GPU share is this value: weak-scaling efficiency of an "
-                                                      "N-GPU line = its value / (N x value_one_gpu)"}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -170,7 +170,8 @@ struct BankDev {
 
 // MODE_AUX: first half of the AuxiliaryParticleFilter predict! (reference src/filtering.jl:195-205): noise-free
 // propagate of every particle (no ancestors), lambda = logpdf(y1 - g(x)), w <- w_norm + lambda, exp-sums of the new w
-enum StepMode { MODE_WEIGHT = 0, MODE_PROP = 1, MODE_PROP_WEIGHT = 2, MODE_AUX = 3 };
+enum StepMode { MODE_WEIGHT = 0, MODE_PROP = 1, MODE_PROP_WEIGHT = 2, MODE_AUX = 3,
+                MODE_AUX2 = 4 };   // second half of the auxiliary predict! in balanced form (ancestors in HBM: residual resampling), k_step<NoModel>
 
 struct StepArgs {
     const double* u;       // device pointer to u of the propagate (nu doubles) or nullptr

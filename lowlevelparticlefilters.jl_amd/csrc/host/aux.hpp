@@ -136,7 +136,6 @@ static int aux_predict_dev_advanced(Bank& b, const double* d_u, const double* d_
 // Single-call predict!(pf::AuxiliaryParticleFilter, u, y1, p, t): synchronous.  d_u / d_y1 are device pointers.
 static int aux_predict_dev(Bank& b, const double* d_u, const double* d_y1, bool has_y1, double t, int want_xm) {
     if (is_rb(b) || is_rbfull(b)) return fail(LLPF_ERR_ARG, "the auxiliary filter is not defined for the Rao-Blackwellized model");
-    if (b.cfg.resampling_strategy == LLPF_RESAMPLE_RESIDUAL) return fail(LLPF_ERR_ARG, "the auxiliary filter supports systematic and stratified resampling");
     if (b.cfg.filter_kind == LLPF_ADVANCED_PARTICLE_FILTER) {
         if (b.aux_pending) CHK(bank_aux_correct(b, nullptr, AuxOuts{}, 0));
         return aux_predict_dev_advanced(b, d_u, d_y1, has_y1, t);
@@ -147,6 +146,39 @@ static int aux_predict_dev(Bank& b, const double* d_u, const double* d_y1, bool 
     b.parity = (b.parity + 1) % ACC_NSLOT;
     b.qcur ^= 1;
     b.cur ^= 1;                                   // the noise-free prediction is the source of the second half
+    if (b.cfg.resampling_strategy == LLPF_RESAMPLE_RESIDUAL) {
+        // resample(ResampleResidual, ...) (src/resample.jl:63-117) under the auxiliary filter: residual ancestors are not sorted, which
+        // the fused second half relies on; the balanced form instead — k_resample (expnormalize! of w + lambda, forced residual
+        // resample: ancestors to HBM), then k_step<NoModel, MODE_AUX2>: x = x'[j] + noise, w = lambda - log N, exp-sums
+        const int slot1 = (b.parity + ACC_NSLOT - 1) % ACC_NSLOT;
+        BankDev d = b.dev();
+        ResArgs ra{};
+        ra.mode = RES_FINALIZE | RES_RESAMPLE; ra.parity = slot1; ra.step = rel_step(b); ra.M = (int32_t)b.N; ra.anc_out = b.d_anc;
+        ra.force = 1; ra.fast_head = 1; ra.u_from_scal = 1; ra.k = 0;
+        HIPC(launch_resample(d, ra, b.stream));
+        std::vector<int> fl;
+        int64_t kf;
+        CHK(poll_fallback(b, fl, kf));
+        if (!fl.empty()) {   // expnormalize! of w + lambda in the exact-max form
+            CHK(clear_slot_sums(b, slot1, fl));
+            HIPC(launch_norm(d, slot1, 0, 0, rel_step(b), 1, 0, 0, b.stream));
+            ra.fast_head = 0; ra.only_fallback = 1;
+            HIPC(launch_resample(d, ra, b.stream));
+            CHK(clear_fallback(b, fl));
+        }
+        StepArgs st{};
+        st.t_prop = t; st.t_meas = t; st.step = rel_step(b); st.has_y = 0; st.parity = b.parity; st.need_e2 = 0; st.K = llpf_qbits(b.N);
+        st.k = 0; st.next_step = rel_step(b) + 1; st.want_xmean = want_xm; st.accumulate = 1; st.aux = has_y1 ? 2 : 1;
+        HIPC(launch_step(d, MODE_AUX2, st, b.stream));
+        b.parity = (b.parity + 1) % ACC_NSLOT;
+        b.qcur ^= 1;
+        b.cur ^= 1;
+        b.n_predict++;
+        b.t_index++;
+        b.aux_pending = true;
+        b.we_is_lambda = true;
+        return LLPF_OK;
+    }
     CHK(aux_launch_resprop(b, has_y1, t, true, 0, 0, want_xm));
     std::vector<int> fl;
     int64_t kf;
@@ -199,7 +231,7 @@ static int bank_aux_run(Bank& b, const double* U, const double* Y, int64_t T, in
     HIPC(hipMemcpyAsync(b.d_Y, Y, sizeof(double) * T * b.ny, hipMemcpyHostToDevice, b.stream));
     CHK(ensure(&b.d_ll_steps, &b.cap_ll, (size_t)T * b.F));
     if (xmean) CHK(ensure(&b.d_xmean, &b.cap_xm, (size_t)T * b.F * b.nx));
-    if (b.cfg.resampling_strategy == LLPF_RESAMPLE_RESIDUAL) return fail(LLPF_ERR_ARG, "the auxiliary filter supports systematic and stratified resampling");
+    const bool residual = b.cfg.resampling_strategy == LLPF_RESAMPLE_RESIDUAL;     // balanced form, driven step by step (aux_predict_dev)
     CHK(aux_ensure_lam(b));
     const double Ts = b.cfg.model.Ts;
     const bool hist = x_hist || w_hist || we_hist;
@@ -239,7 +271,7 @@ static int bank_aux_run(Bank& b, const double* U, const double* Y, int64_t T, in
     // T = 1 consists of the wrapped filter's update! alone.
     if (mode == 0 || T > 1) CHK(bank_aux_correct(b, nullptr, outs, 0));
     const bool advanced = b.cfg.filter_kind == LLPF_ADVANCED_PARTICLE_FILTER;     // its predict! is driven synchronously (filtering.jl:219-234)
-    if (hist || advanced) {
+    if (hist || advanced || residual) {
         // step-synchronous form (history is copied out between correct! and predict!)
         if (hist && (mode == 0 || T > 1)) CHK(record(0));
         for (int64_t k = 0; k < n_aux; ++k) {

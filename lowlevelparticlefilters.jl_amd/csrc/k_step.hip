@@ -39,7 +39,7 @@ static hipError_t launch_step_t(const BankDev& b, int mode, const StepArgs& a, h
         case MODE_PROP: hipLaunchKernelGGL((k_step<Model, NX, NY, MODE_PROP, PPT>), g, dim3(BLOCK), 0, s, b, b.models, b.scal, a); break;
         case MODE_PROP_WEIGHT: hipLaunchKernelGGL((k_step<Model, NX, NY, MODE_PROP_WEIGHT, PPT>), g, dim3(BLOCK), 0, s, b, b.models, b.scal, a); break;
         case MODE_AUX: hipLaunchKernelGGL((k_step<Model, NX, NY, MODE_AUX, PPT>), g, dim3(BLOCK), 0, s, b, b.models, b.scal, a); break;
-        default: return hipErrorInvalidValue;
+        default: return hipErrorInvalidValue;      // MODE_AUX2 is model independent: launch_step_aux2
     }
     return hipGetLastError();
 }
@@ -67,8 +67,30 @@ static hipError_t launch_step_rb_ny(const BankDev& b, int mode, const StepArgs& 
     }
 }
 
+// second half of the auxiliary predict! in balanced form: whatever the model, it propagates nothing (NoModel); lambda does not see NY
+template <int NX>
+static hipError_t launch_step_aux2_t(const BankDev& b, const StepArgs& a, hipStream_t s) {
+    dim3 g((unsigned)(b.Ns / (BLOCK * STEP_PPT * STEP_ITERS)), (unsigned)b.F, 1);
+    hipLaunchKernelGGL((k_step<NoModel<NX>, NX, 1, MODE_AUX2, STEP_PPT>), g, dim3(BLOCK), 0, s, b, b.models, b.scal, a);
+    return hipGetLastError();
+}
+static hipError_t launch_step_aux2(const BankDev& b, const StepArgs& a, hipStream_t s) {
+    switch (b.nx) {
+        case 1: return launch_step_aux2_t<1>(b, a, s);
+        case 2: return launch_step_aux2_t<2>(b, a, s);
+        case 3: return launch_step_aux2_t<3>(b, a, s);
+        case 4: return launch_step_aux2_t<4>(b, a, s);
+        case 5: return launch_step_aux2_t<5>(b, a, s);
+        case 6: return launch_step_aux2_t<6>(b, a, s);
+        case 7: return launch_step_aux2_t<7>(b, a, s);
+        case 8: return launch_step_aux2_t<8>(b, a, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
 hipError_t launch_step(const BankDev& b, int mode, const StepArgs& a, hipStream_t s) {
     const int model_id = b.model_id;
+    if (mode == MODE_AUX2) return (model_id == LLPF_MODEL_RB_LINEAR || model_id == LLPF_MODEL_RB_BILINEAR) ? hipErrorInvalidValue : launch_step_aux2(b, a, s);
     if (model_id >= LLPF_MODEL_USER_BASE) return launch_step_user(b, mode, a, s);
     if (model_id == LLPF_MODEL_RB_BILINEAR) return launch_rbfull(b, mode, a, s);
     if (model_id == LLPF_MODEL_QUADTANK_RK4) return launch_step_t<QuadTank<4, 2>, 4, 2, LLPF_QT_PPT>(b, mode, a, s);

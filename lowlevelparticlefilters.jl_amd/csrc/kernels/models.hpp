@@ -309,12 +309,25 @@ struct QuadTank {   // reference examples/example_quadtank.jl:8-35 with rk4 of s
     }
 };
 
+// placeholder model of the AuxiliaryParticleFilter's second half: the dynamics were applied by k_step<MODE_AUX>
+template <int NX>
+struct NoModel {
+    static constexpr bool RB = false;
+    DEV void prepare(const ModelD*, const double*, double) {}
+    DEV void dynamics(const double* x, double* out) const {
+#pragma unroll
+        for (int d = 0; d < NX; ++d) out[d] = x[d];
+    }
+    DEV void measurement(const double*, double*) const {}
+};
+
 // Is f(x) expensive enough to be computed once per distinct ancestor of a block and handed to the outputs that share it
 // (k_step)?  Yes unless the model says otherwise: run-time compiled user models and the quad-tank's RK4 are; a matrix-vector
 // product is not.
 template <class Model> struct share_dynamics { static constexpr bool value = true; };
 template <int NX, int NY> struct share_dynamics<LinGauss<NX, NY>> { static constexpr bool value = false; };
 template <int NX, int NY> struct share_dynamics<RBLin<NX, NY>> { static constexpr bool value = false; };
+template <int NX> struct share_dynamics<NoModel<NX>> { static constexpr bool value = false; };
 
 // Optional hooks of a model (run-time compiled user models, kernels/jit.hpp):
 //   DEV double loglik(const double* x, const double* y, double t) const   log p(y | x) — the reference's measurement_likelihood(x, u, y, p, t)

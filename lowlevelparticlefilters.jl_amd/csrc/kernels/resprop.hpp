@@ -17,18 +17,6 @@ template <class T> DEV void st_off(T* base, uint32_t byte_off, T v) {
     *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off) = v;
 }
 
-// placeholder model of the AuxiliaryParticleFilter's second half: the dynamics were applied by k_step<MODE_AUX>
-template <int NX>
-struct NoModel {
-    static constexpr bool RB = false;
-    DEV void prepare(const ModelD*, const double*, double) {}
-    DEV void dynamics(const double* x, double* out) const {
-#pragma unroll
-        for (int d = 0; d < NX; ++d) out[d] = x[d];
-    }
-    DEV void measurement(const double*, double*) const {}
-};
-
 // stores of the output loop are write-through (wt_store in reduce.hpp says why)
 #define LLPF_STCOH ((LLPF_WT && !Model::RB) ? 1 : COH)
 #define LLPF_STCOH0 ((LLPF_WT && !Model::RB) ? 1 : 0)

@@ -30,7 +30,7 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
         if (t < LLPF_RNG_SC_ENTRIES) { rt0 = LLPF_SIN64[t]; rt1 = LLPF_COS64[t]; }
         else if (t < LLPF_RNG_SC_ENTRIES + LLPF_RNG_LG_ENTRIES) { rt0 = LLPF_LOG_INVC[t - LLPF_RNG_SC_ENTRIES]; rt1 = LLPF_LOG_LNC[t - LLPF_RNG_SC_ENTRIES]; }
     }
-    const int do_res = (MODE != MODE_WEIGHT && MODE != MODE_AUX) ? sc->do_resample : 0;
+    const int do_res = (MODE == MODE_AUX2) ? 1 : ((MODE != MODE_WEIGHT && MODE != MODE_AUX) ? sc->do_resample : 0);   // AUX2: always resampled (filtering.jl:206)
     const int uniform = sc->uniform, pend = sc->norm_pending;
     const double m = sc->m, l = sc->l, wconst = sc->wconst;
     const uint32_t k0 = sc->k0, k1 = sc->k1, sb = sc->step_base;
@@ -81,6 +81,7 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
         } else {
             off = a.has_y ? wmx + md->dg.c0 : wmx;
         }
+        if (MODE == MODE_AUX2) off = ((a.aux == 2) ? md->dg.c0 : 0.0) - (-b.mlogN);    // w = lambda - log N <= c0 - log N (lambda = 0 when y1 is missing)
         wacc.init();
     }
 #pragma unroll 1
@@ -195,7 +196,12 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
         }
         if (MODE != MODE_PROP) {
             double wp[PPT];
-            if (do_res) {                          // reset_weights!: w = log(1/N)
+            if (MODE == MODE_AUX2) {               // w[i] = lambda[i] - log N, the unresampled lambda (filtering.jl:211-214)
+                const double lN = -b.mlogN;
+                const double* lamp = b.lam + (size_t)f * Ns;
+                if constexpr (PPT == 2) { const double2 lv = *reinterpret_cast<const double2*>(lamp + i0); wp[0] = lv.x - lN; wp[1] = lv.y - lN; }
+                else wp[0] = lamp[i0] - lN;
+            } else if (do_res) {                   // reset_weights!: w = log(1/N)
 #pragma unroll
                 for (int p = 0; p < PPT; ++p) wp[p] = b.log1N;
             } else if (uniform) {
@@ -228,7 +234,7 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
                     }
                     lamv[p] = lam;
                     wv = wv + lam;
-                } else if (a.has_y) {
+                } else if (MODE != MODE_AUX2 && a.has_y) {
                     if constexpr (Model::RB) {
                         wv = wv + model.rb_weight(xs[p], y, a.rb_corr + f, i0 + p == 0);
                     } else if constexpr (has_loglik<Model>::value) {
@@ -299,6 +305,7 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
             if (blockIdx.x == 0) {
                 FilterScal* scw = b.scal + f;
                 if (a.accumulate) scw->xm_parts = (int32_t)gridDim.x;
+                if (MODE == MODE_AUX2) { scw->norm_pending = 0; scw->uniform = 0; scw->wmax = off; }   // final values, bounded by off (as k_resprop<AUX>)
                 scw->off_slot[a.parity] = off;
                 scw->exact_slot[a.parity] = 0;
                 scw->e2v_slot[a.parity] = a.need_e2;

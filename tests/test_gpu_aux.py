@@ -11,7 +11,7 @@ from gpu_common import TOL_LL_STEP, cfg_of as _cfg, compare_state as _compare_st
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("strategy", [S.RESAMPLE_SYSTEMATIC, S.RESAMPLE_STRATIFIED])
+@pytest.mark.parametrize("strategy", [S.RESAMPLE_SYSTEMATIC, S.RESAMPLE_STRATIFIED, S.RESAMPLE_RESIDUAL])
 def test_aux_filter_single_steps_bit_exact(strategy):
     """correct! / predict! of the auxiliary filter step by step: ll, particles, log-weights, lambda (the reference's
     `we` after predict!), ancestors — bit-identical to the device-order oracle; a missing look-ahead measurement."""
@@ -172,3 +172,29 @@ def test_aux_filter_over_an_advanced_filter(which):
         else:
             assert rg["ll_steps"][-1] != 0.0 and np.all(np.abs(rg["ll_steps"][:-1]) < 1e-9)       # only the wrapped filter's update! counts
         _compare_state(g2, o2)
+
+
+@pytest.mark.parametrize("kind", [S.PARTICLE_FILTER, S.ADVANCED_PARTICLE_FILTER])
+def test_aux_filter_with_residual_resampling(kind):
+    """resample(ResampleResidual, ...) under the auxiliary filter (the reference's predict! resamples with whatever strategy the
+    filter has, src/filtering.jl:206, src/resample.jl:63-117): residual ancestors are not sorted, so the second half runs in the
+    balanced form (k_resample + k_step<NoModel, MODE_AUX2>; over an AdvancedParticleFilter: + the re-propagation).  Both run
+    loops, with an outlier and a missing measurement: the device-order oracle's bits, the reference order within tolerance."""
+    model = M.lg_test_model(0.1) if kind == S.PARTICLE_FILTER else M.quadtank_model()
+    if kind == S.PARTICLE_FILTER:
+        _, U, Y = M.simulate_lg(model, 40, seed=5)
+        Y = Y.copy(); Y[17] += 11.0
+    else:
+        U, Y = M.quadtank_data(40, seed=2)
+        Y = Y.copy()
+    Y[25] = np.nan
+    cfg = _cfg(model, 3000, S.RESAMPLE_RESIDUAL, 0.5, seed=35, kind=kind)
+    for mode in (0, 1):
+        g = _capi.FilterHandle(cfg); o = ob.OracleFilter(cfg, ob.ORDER_DEVICE); r = ob.OracleFilter(cfg, ob.ORDER_REFERENCE)
+        for h in (g, o, r):
+            h.reset()
+        rg, ro, rr = (h.run_aux(U, Y, mode, ll_steps=True) for h in (g, o, r))
+        assert np.array_equal(rg["ll_steps"].view(np.uint64), ro["ll_steps"].view(np.uint64)), mode
+        _compare_state(g, o)
+        assert np.max(np.abs(rg["ll_steps"] - rr["ll_steps"])) <= TOL_LL_STEP
+        assert g.resample_count() == o.resample_count() > 10

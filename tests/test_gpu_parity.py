@@ -779,16 +779,10 @@ def test_c_client_of_the_abi():
 
 def test_error_paths_of_the_newer_entry_points():
     """Invalid uses are rejected with LLPF_ERR_ARG and a message (no exception crosses the ABI, nothing is computed):
-    residual resampling or the Rao-Blackwellized model with the auxiliary verbs, smooth with M > N or an RB model,
+    the Rao-Blackwellized model with the auxiliary verbs, smooth with M > N or an RB model,
     RB model shapes the kernels do not cover, a quad-tank model with eps = 0."""
     model = M.lg_test_model(0.1)
     _, U, Y = M.simulate_lg(model, 10)
-    g = _capi.FilterHandle(_cfg(model, 500, S.RESAMPLE_RESIDUAL, 0.5))
-    g.reset()
-    with pytest.raises(_capi.LLPFError):
-        g.aux_predict(U[0], Y[1], 0.0)
-    with pytest.raises(_capi.LLPFError):
-        g.run_aux(U, Y, 1)
     g2 = _capi.FilterHandle(_cfg(model, 500))
     g2.reset()
     r = g2.run(U, Y, 0.0, history=True)

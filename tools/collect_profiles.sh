@@ -11,19 +11,16 @@ TAG=${1:-prof}
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
-python bench.py > $OUT/bench_c2.json 2> $OUT/bench_c2.err
+python bench.py --no-other-configs > $OUT/bench_c2.json 2> $OUT/bench_c2.err
 python bench.py --threshold 0.1 --no-cpu-baseline > $OUT/bench_c2_thr01.json 2>> $OUT/bench_c2.err
 python bench.py --workload quadtank > $OUT/bench_c3_quadtank.json 2>> $OUT/bench_c2.err
 python tools/bench_bank.py > $OUT/bench_c4_bank_128x1e5_one_gpu.json 2>> $OUT/bench_c2.err
 python tools/bench_bank.py --thr 1.0 > $OUT/bench_c4_bank_128x1e5_thr1.json 2>> $OUT/bench_c2.err
 python bench.py --workload bank --steps 2 > $OUT/bench_c4_bank_workload.json 2>> $OUT/bench_c2.err
 python bench.py --gpus 2 --dist-backend gloo --steps 2 --no-cpu-baseline | grep '^{' > $OUT/bench_c4_two_ranks_one_gpu_gloo.json 2>> $OUT/bench_c2.err
-LLPF_PERSIST=1 python bench.py --no-cpu-baseline > $OUT/bench_c2_persistent.json 2>> $OUT/bench_c2.err
-tools/grid_barrier_32 2000 > $OUT/grid_barrier.txt 2>&1
 python bench.py --workload aux > $OUT/bench_aux.json 2>> $OUT/bench_c2.err
 python bench.py --workload rbpf > $OUT/bench_rbpf.json 2>> $OUT/bench_c2.err
 python bench.py --workload rbpf_full > $OUT/bench_c5_rbpf_full.json 2>> $OUT/bench_c2.err
-LLPF_RBFULL_MFMA=1 python bench.py --workload rbpf_full --no-cpu-baseline > $OUT/bench_c5_mfma_form.json 2>> $OUT/bench_c2.err
 python tools/bench_smooth.py > $OUT/bench_ffbs_smoother.json 2>> $OUT/bench_c2.err
 python tools/bench_smooth.py --particles 1000 --T 200 --M 100 --cpu-M 100 >> $OUT/bench_ffbs_smoother.json 2>> $OUT/bench_c2.err
 python tools/bench_mc.py > $OUT/bench_reference_mc_run_test.json 2>> $OUT/bench_c2.err

@@ -3,7 +3,7 @@
 
     python tools/isa_census.py [kernel-name-substring]      default: the C2 fused kernel
 
-Compiles csrc/kernels.hip for gfx950 with the Makefile's flags to assembly (hipcc --cuda-device-only -S, ~3 min), cuts the
+Compiles csrc/k_resprop.hip for gfx950 with the Makefile's flags to assembly (hipcc --cuda-device-only -S, ~3 min), cuts the
 kernel out, splits it at the s_setprio markers of k_resprop (head+counts | output loop | tail) when they are present, and prints
 per region the number of vector / scalar / LDS / memory instructions and the most frequent opcodes, plus the register and scratch
 figures of the kernel.  This is the census DESIGN.md section 4 (round 2) quotes."""
@@ -19,7 +19,7 @@ def main():
     out = os.path.join(tempfile.gettempdir(), "llpf_kernels.s")
     flags = "-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -mllvm -amdgpu-kernarg-preload-count=16 --offload-arch=gfx950".split()
     subprocess.check_call(["make", "-C", CSRC, "jit_prelude.inc"], stdout=subprocess.DEVNULL)
-    subprocess.check_call(["/opt/rocm/bin/hipcc"] + flags + ["--cuda-device-only", "-S", "kernels.hip", "-o", out], cwd=CSRC,
+    subprocess.check_call(["/opt/rocm/bin/hipcc"] + flags + ["--cuda-device-only", "-S", "k_resprop.hip", "-o", out], cwd=CSRC,
                           stderr=subprocess.DEVNULL)
     lines = open(out).read().split("\n")
     start = next(i for i, l in enumerate(lines) if re.match(r"^_ZN4llpf\S*%s\S*:" % re.escape(want), l))
