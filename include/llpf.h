@@ -252,8 +252,8 @@ int  llpf_smooth(llpf_filter* f, int64_t M, const double* U, int64_t T, const do
  * into llpf_model.model_id with the same nx, ny (1..4 each: the kernels around the compiled one are precompiled for those).  Process
  * noise and initial density remain the Gaussian descriptors of llpf_model, and so does the measurement likelihood unless the snippet
  * defines `loglik` (measurement_density is then unused, but must still be a valid Gaussian of dimension ny).  Such filters and banks
- * run the balanced two-launch timestep; the auxiliary verbs work, the smoother and the Rao-Blackwellized forms are not provided for
- * them.  Compiling the same (source, nx, ny) again returns the same id.
+ * run the balanced two-launch timestep; the auxiliary verbs and the smoother work (their kernels are compiled with the snippet too), the
+ * Rao-Blackwellized forms are not provided for them.  Compiling the same (source, nx, ny) again returns the same id.
  * On failure the compiler log is in llpf_last_error(). */
 int  llpf_model_compile(const char* device_src, int32_t nx, int32_t ny, int32_t* model_id);
 

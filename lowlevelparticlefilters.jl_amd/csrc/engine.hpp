@@ -196,6 +196,19 @@ struct StepArgs {
     int32_t y_stride;
 };
 
+// FFBS smoother (reference src/smoothing.jl:116-143): one backward step t for all M trajectories
+struct SmoothArgs {
+    const double* xf_t;     // [N][nx] filter particles at time t (AoS, as forward_trajectory returns them)
+    const double* wf_t;     // [N] normalised log-weights at time t
+    const double* u;        // device pointer to u[t]
+    double t;               // time passed to the dynamics
+    double* fx;             // [nx][Ns] scratch: f(xf[n,t], u[t], p, t)
+    const double* xb_next;  // [M][nx] smoothed samples at t+1
+    double* xb_t;           // [M][nx] out
+    int64_t* idx_t;         // [M] out: index of the particle behind every sample
+    int32_t M;
+    uint32_t step;          // Philox step of the draws (= t)
+};
 // ---- end of the part the run-time compiled user-model kernels see (tools/gen_jit_prelude.py cuts here) ----
 enum { RES_FINALIZE = 1, RES_RESAMPLE = 2 };
 
@@ -232,6 +245,7 @@ hipError_t launch_init(const BankDev& b, uint32_t step, int init_anc, hipStream_
 hipError_t launch_rbfull_jit(int fn_kind, int nn, int nl, int ny, const BankDev& b, int mode, const StepArgs& a, hipStream_t s);   // kernels/jit.hpp
 int jit_prepare_rbfull(int fn_kind, int nn, int nl, int ny, std::string& err);   // compiles the shape if needed (bank construction reports the log)
 int jit_builtin_lg(int nx, int ny, std::string& err);   // kernels/jit.hpp: LinGauss<nx, ny> compiled on demand (nx or ny above 4), id as a user model
+hipError_t launch_smooth_fx_user(const BankDev& b, const SmoothArgs& a, hipStream_t s);   // kernels/jit.hpp: k_smooth_fx of a run-time compiled model
 hipError_t launch_user_bound(int model_id, ModelD* models, int F, const double* zero_u, hipStream_t s);   // kernels/jit.hpp: bound of a user likelihood
 hipError_t launch_rbfull(const BankDev& b, int mode, const StepArgs& a, hipStream_t s);   // k_rbfull.hip (called by launch_step)
 hipError_t launch_rbfull_init(const BankDev& b, hipStream_t s);   // LLPF_MODEL_RB_BILINEAR: xl, R of reset!
@@ -269,19 +283,6 @@ struct PersistArgsHost {
 hipError_t launch_persist(const BankDev& b, const PersistArgsHost& a, hipStream_t s);
 hipError_t persist_capacity(const BankDev& b, int* blocks);   // co-resident workgroups of the instance for b's dimensions
 int persist_bar_words();
-// FFBS smoother (reference src/smoothing.jl:116-143): one backward step t for all M trajectories
-struct SmoothArgs {
-    const double* xf_t;     // [N][nx] filter particles at time t (AoS, as forward_trajectory returns them)
-    const double* wf_t;     // [N] normalised log-weights at time t
-    const double* u;        // device pointer to u[t]
-    double t;               // time passed to the dynamics
-    double* fx;             // [nx][Ns] scratch: f(xf[n,t], u[t], p, t)
-    const double* xb_next;  // [M][nx] smoothed samples at t+1
-    double* xb_t;           // [M][nx] out
-    int64_t* idx_t;         // [M] out: index of the particle behind every sample
-    int32_t M;
-    uint32_t step;          // Philox step of the draws (= t)
-};
 hipError_t launch_smooth_fx(const BankDev& b, const SmoothArgs& a, hipStream_t s);
 hipError_t launch_smooth_draw(const BankDev& b, const SmoothArgs& a, hipStream_t s);
 hipError_t launch_bake_weights(const BankDev& b, hipStream_t s);   // w[] <- the normalised / uniform values it stands for (padding -Inf)

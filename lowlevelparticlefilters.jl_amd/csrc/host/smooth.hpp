@@ -4,7 +4,6 @@ extern "C" int llpf_resample(int32_t device, int32_t strategy, const double* we,
 
 static int bank_smooth(Bank& b, int64_t M, const double* U, int64_t T, const double* xf, const double* wf,
                        const double* wef, double* xb, int64_t* idx) {
-    if (b.cfg.model.model_id >= LLPF_MODEL_USER_BASE) return fail(LLPF_ERR_ARG, "the smoother is not provided for run-time compiled models");
     CHK(use_device(b));
     if (b.F != 1) return fail(LLPF_ERR_ARG, "smooth needs a single filter");
     if (is_rb(b) || is_rbfull(b)) return fail(LLPF_ERR_ARG, "smooth is not defined for the Rao-Blackwellized model");

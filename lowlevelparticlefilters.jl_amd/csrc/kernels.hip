@@ -137,7 +137,7 @@ static hipError_t launch_smooth_fx_ny(const BankDev& b, const SmoothArgs& a, hip
     }
 }
 hipError_t launch_smooth_fx(const BankDev& b, const SmoothArgs& a, hipStream_t s) {
-    if (b.model_id >= LLPF_MODEL_USER_BASE) return hipErrorInvalidValue;     // no smoother kernel is compiled for user models
+    if (b.model_id >= LLPF_MODEL_USER_BASE) return launch_smooth_fx_user(b, a, s);     // compiled with the user's dynamics (kernels/jit.hpp)
     if (b.model_id == LLPF_MODEL_QUADTANK_RK4) return launch_smooth_fx_t<QuadTank<4, 2>, 4, 2>(b, a, s);
     switch (b.nx) {
         case 1: return launch_smooth_fx_ny<1>(b, a, s);
@@ -154,6 +154,10 @@ hipError_t launch_smooth_draw(const BankDev& b, const SmoothArgs& a, hipStream_t
         case 2: hipLaunchKernelGGL((k_smooth_draw<2>), g, dim3(BLOCK), 0, s, b, b.models, a); break;
         case 3: hipLaunchKernelGGL((k_smooth_draw<3>), g, dim3(BLOCK), 0, s, b, b.models, a); break;
         case 4: hipLaunchKernelGGL((k_smooth_draw<4>), g, dim3(BLOCK), 0, s, b, b.models, a); break;
+        case 5: hipLaunchKernelGGL((k_smooth_draw<5>), g, dim3(BLOCK), 0, s, b, b.models, a); break;
+        case 6: hipLaunchKernelGGL((k_smooth_draw<6>), g, dim3(BLOCK), 0, s, b, b.models, a); break;
+        case 7: hipLaunchKernelGGL((k_smooth_draw<7>), g, dim3(BLOCK), 0, s, b, b.models, a); break;
+        case 8: hipLaunchKernelGGL((k_smooth_draw<8>), g, dim3(BLOCK), 0, s, b, b.models, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

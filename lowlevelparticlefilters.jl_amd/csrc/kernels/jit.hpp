@@ -19,8 +19,9 @@ struct JitModel {
     int nx = 0, ny = 0;
     std::string src;                           // the snippet: a second llpf_model_compile of the same (source, nx, ny) returns the same id
     std::vector<char> code;
-    std::string name[5];                       // lowered names of k_step<UserModel, nx, ny, MODE, STEP_PPT>, MODE = 0..3; [4]: k_user_bound<UserModel>
-    struct PerDevice { hipModule_t mod = nullptr; hipFunction_t fn[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; };
+    std::string name[6];                       // lowered names of k_step<UserModel, nx, ny, MODE, STEP_PPT>, MODE = 0..3; [4]: k_user_bound<UserModel>;
+                                               // [5]: k_smooth_fx<UserModel, nx, ny>
+    struct PerDevice { hipModule_t mod = nullptr; hipFunction_t fn[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; };
     std::vector<PerDevice> dev;                // indexed by device ordinal, loaded on first use
 };
 static std::mutex g_jit_mutex;
@@ -53,11 +54,12 @@ static int jit_compile_model(const char* device_src, int nx, int ny, bool intern
     src += "\n}  // namespace llpf\n";
     hiprtcProgram prog = nullptr;
     if (hiprtcCreateProgram(&prog, src.c_str(), "llpf_user_model.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) { err = "hiprtcCreateProgram failed"; return -1; }
-    std::string expr[5];
+    std::string expr[6];
     for (int mode = 0; mode < 4; ++mode)
         expr[mode] = "llpf::k_step<llpf::UserModel, " + std::to_string(nx) + ", " + std::to_string(ny) + ", " + std::to_string(mode) + ", " + std::to_string(STEP_PPT) + ">";
     expr[4] = "llpf::k_user_bound<llpf::UserModel>";
-    for (int mode = 0; mode < 5; ++mode) hiprtcAddNameExpression(prog, expr[mode].c_str());
+    expr[5] = "llpf::k_smooth_fx<llpf::UserModel, " + std::to_string(nx) + ", " + std::to_string(ny) + ">";
+    for (int mode = 0; mode < 6; ++mode) hiprtcAddNameExpression(prog, expr[mode].c_str());
     int devid = 0;
     hipDeviceProp_t prop;
     std::string arch = "gfx950";
@@ -80,7 +82,7 @@ static int jit_compile_model(const char* device_src, int nx, int ny, bool intern
     hiprtcGetCodeSize(prog, &sz);
     jm->code.resize(sz);
     hiprtcGetCode(prog, jm->code.data());
-    for (int mode = 0; mode < 5; ++mode) {
+    for (int mode = 0; mode < 6; ++mode) {
         const char* low = nullptr;
         if (hiprtcGetLoweredName(prog, expr[mode].c_str(), &low) != HIPRTC_SUCCESS || !low) { err = "hiprtcGetLoweredName failed for " + expr[mode]; delete jm; hiprtcDestroyProgram(&prog); return -1; }
         jm->name[mode] = low;
@@ -121,6 +123,18 @@ hipError_t launch_user_bound(int model_id, ModelD* models, int F, const double* 
     if (e != hipSuccess) return e;
     void* args[] = {&models, &zero_u};
     return hipModuleLaunchKernel(fn, (unsigned)F, 1, 1, 64, 1, 1, 0, s, args, nullptr);
+}
+hipError_t launch_smooth_fx_user(const BankDev& b, const SmoothArgs& a, hipStream_t s) {
+    JitModel* jm = jit_model(b.model_id);
+    if (!jm) return hipErrorInvalidValue;
+    hipFunction_t fn = nullptr;
+    hipError_t e = jit_function(jm, 5, &fn);
+    if (e != hipSuccess) return e;
+    BankDev bd = b;
+    const ModelD* models = b.models;
+    SmoothArgs aa = a;
+    void* args[] = {&bd, &models, &aa};
+    return hipModuleLaunchKernel(fn, (unsigned)((b.N + BLOCK - 1) / BLOCK), 1, 1, BLOCK, 1, 1, 0, s, args, nullptr);
 }
 static hipError_t launch_step_user(const BankDev& b, int mode, const StepArgs& a, hipStream_t s) {
     JitModel* jm = jit_model(b.model_id);

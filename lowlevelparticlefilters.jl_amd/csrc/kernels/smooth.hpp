@@ -5,19 +5,7 @@
 //   wb[n] = wf[n,t] + logpdf(df, xb[m,t+1] - fx[n])  (recomputed in each of the three sweeps: max, total of the
 //   quanta of exp(wb - max), count of bins below s = rand()*bins[end]), index = #{b : bins[b] < s}.
 // ------------------------------------------------------------------------------------------------
-template <class Model, int NX, int NY>
-__global__ __launch_bounds__(BLOCK) void k_smooth_fx(BankDev b, const ModelD* __restrict__ models, SmoothArgs a) {
-    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= b.N) return;
-    Model model;
-    model.prepare(models, a.u, a.t);
-    double xp[NX], fx[NX];
-#pragma unroll
-    for (int d = 0; d < NX; ++d) xp[d] = a.xf_t[i * NX + d];
-    model.dynamics(xp, fx);
-#pragma unroll
-    for (int d = 0; d < NX; ++d) a.fx[(size_t)d * b.Ns + i] = fx[d];
-}
+#include "smooth_fx.hpp"
 
 template <int NX>
 __global__ __launch_bounds__(BLOCK) void k_smooth_draw(BankDev b, const ModelD* __restrict__ md, SmoothArgs a) {

@@ -50,3 +50,32 @@ def test_smoother_api():
     assert xbm.shape == (2, 200) and np.mean((X.T - xbm) ** 2) < 5
     assert all(np.trace(Cv) < 2 for Cv in llpf_amd.smoothed_cov(xb))
     assert llpf_amd.smoothed_trajs(xb).shape == (2, 100, 200)
+
+
+def test_smoother_of_models_compiled_at_run_time():
+    """smooth for run-time compiled models (k_smooth_fx is compiled with the user's dynamics): the quad-tank written as a USER
+    snippet gives the built-in quad-tank's — and the oracle's — indices and samples bit for bit; a linear-Gaussian model above the
+    precompiled dimensions (nx = 5: compiled on demand) those of the oracle."""
+    import user_models as UM
+    qm = M.quadtank_model(); Uq, Yq = M.quadtank_data(25)
+    qu = S.Model.from_buffer_copy(bytes(qm)); qu.model_id = _capi.model_compile(UM.QUADTANK_SRC, 4, 2)
+    cb = _cfg(qm, 1500, S.RESAMPLE_SYSTEMATIC, 0.5, seed=9, kind=S.ADVANCED_PARTICLE_FILTER)
+    cu = _cfg(qu, 1500, S.RESAMPLE_SYSTEMATIC, 0.5, seed=9, kind=S.ADVANCED_PARTICLE_FILTER)
+    gb, gu, o = _capi.FilterHandle(cb), _capi.FilterHandle(cu), ob.OracleFilter(cb, ob.ORDER_DEVICE)
+    for h in (gb, gu, o):
+        h.reset()
+    rb, ru, ro = (h.run(Uq, Yq, 0.0, history=True) for h in (gb, gu, o))
+    xb, ib = gb.smooth(64, Uq, rb["x"], rb["w"], rb["we"]); xu, iu = gu.smooth(64, Uq, ru["x"], ru["w"], ru["we"])
+    xo, io = o.smooth(64, Uq, ro["x"], ro["w"], ro["we"])
+    assert np.array_equal(iu, ib) and np.array_equal(iu, io) and np.array_equal(xu.view(np.uint64), xo.view(np.uint64))
+    rng = np.random.default_rng(3)
+    A = 0.9 * np.linalg.qr(rng.standard_normal((5, 5)))[0]
+    model = S.make_lg_model(A, 0.2 * rng.standard_normal((5, 1)), rng.standard_normal((2, 5)), S.make_gaussian(np.zeros(5), 0.05),
+                            S.make_gaussian(np.zeros(2), 0.5), S.make_gaussian(np.zeros(5), 1.0))
+    _, U, Y = M.simulate_lg(model, 30, seed=4)
+    cfg = _cfg(model, 2000, S.RESAMPLE_SYSTEMATIC, 0.5, seed=3)
+    g, o = _capi.FilterHandle(cfg), ob.OracleFilter(cfg, ob.ORDER_DEVICE)
+    g.reset(); o.reset()
+    rg, ro = g.run(U, Y, 0.0, history=True), o.run(U, Y, 0.0, history=True)
+    xg, ig = g.smooth(100, U, rg["x"], rg["w"], rg["we"]); xo, io = o.smooth(100, U, ro["x"], ro["w"], ro["we"])
+    assert np.array_equal(ig, io) and np.array_equal(xg.view(np.uint64), xo.view(np.uint64))

@@ -100,8 +100,13 @@ def test_a_model_without_builtin_counterpart():
     assert np.array_equal(rb["ll_steps"][:, 0], f2.run(U, Y, 0.0, ll_steps=True)["ll_steps"])
     f3 = _capi.FilterHandle(cfg); f3.reset()
     assert np.isfinite(f3.run_aux(U, Y, 1)["ll"])
-    with pytest.raises(_capi.LLPFError):
-        f3.smooth(10, U, np.zeros((T, 20000, 2)), np.zeros((T, 20000)), np.zeros((T, 20000)))
+    # the smoother runs for such models too (k_smooth_fx compiled with the snippet): smoothed angle no worse than the filtered one
+    f4 = _capi.FilterHandle(S.make_config(m, 2000, S.ADVANCED_PARTICLE_FILTER, S.RESAMPLE_SYSTEMATIC, 0.5, 11, 0))
+    f4.reset()
+    r4 = f4.run(U[:60], Y[:60], 0.0, history=True, xmean=True)
+    xb, idx = f4.smooth(50, U[:60], r4["x"], r4["w"], r4["we"])
+    assert xb.shape == (60, 50, 2) and np.all(np.isfinite(xb))
+    assert np.sqrt(np.mean((xb.mean(axis=1)[10:, 0] - X[10:60, 0]) ** 2)) < 0.1
 
 
 @pytest.mark.gpu
