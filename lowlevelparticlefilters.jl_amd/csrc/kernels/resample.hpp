@@ -409,16 +409,20 @@ static_assert(TILE == 1024, "res_owner assumes 2^10 sources per tile");
 // the rest (indices grow with the slot).  ~55 instructions per thread and three barriers instead of a ten-probe descent
 // (~45 instructions, ten dependent LDS round trips) per OUTPUT.  own[] must be zero on entry; sh.cl complete (res_counts).
 constexpr int OWN_CAP = 2 * TILE;
-DEV void res_owner_table(const ResShared& shc, ResShared& sh, uint32_t* own, int32_t c_start) {
+// `wb` (default: the tile's first output) is the first output of the WINDOW of OWN_CAP outputs the table covers: a tile that holds very
+// heavy particles walks its outputs window by window (k_resample), each window's table seeded by the sources whose ranges reach into it.
+DEV void res_owner_table(const ResShared& shc, ResShared& sh, uint32_t* own, int32_t c_start, int32_t wb = -1) {
     const int t = (int)threadIdx.x, lane = t & 63, wvid = t >> 6;
     static_assert(NORM_IPT == 4 && OWN_CAP == 8 * BLOCK, "one 16-byte read of cl and two of own per thread");
+    const uint32_t w0 = (uint32_t)(wb < 0 ? c_start : wb);
     const uint4 c4 = *reinterpret_cast<const uint4*>(shc.cl + 4 * t);
     uint32_t prev = t ? shc.cl[4 * t - 1] : (uint32_t)c_start;
     const uint32_t cur[4] = {c4.x, c4.y, c4.z, c4.w};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const uint32_t idx = prev - (uint32_t)c_start;
-        if (cur[k] > prev && idx < (uint32_t)OWN_CAP) own[idx] = (uint32_t)(4 * t + k + 1);
+        const uint32_t lo = prev > w0 ? prev : w0;          // first output of this source inside the window
+        const uint32_t idx = lo - w0;
+        if (cur[k] > lo && idx < (uint32_t)OWN_CAP) own[idx] = (uint32_t)(4 * t + k + 1);
         prev = cur[k];
     }
     __syncthreads();
@@ -476,11 +480,25 @@ __global__ __launch_bounds__(BLOCK) void k_resample(BankDev b, ResArgs a) {
     if (a.only_bins) return;
     int32_t* ao = a.anc_out + (size_t)f * b.Ns;
     const bool table = c_end - c_start >= BLOCK;       // block-uniform; a table for a handful of outputs would not pay
-    if (table) res_owner_table(sh, sh, sh_own, c_start);
-    for (int32_t o = c_start + threadIdx.x; o < c_end; o += BLOCK) {
-        const uint32_t idx = (uint32_t)(o - c_start);
-        const int own = (table && idx < (uint32_t)OWN_CAP) ? (int)sh_own[idx] - 1 : res_owner(sh.cl, o);
-        wt_store(ao + o, (int32_t)((int64_t)tile * TILE + own));
+    if (table) {
+        // window by window of OWN_CAP outputs: a tile that holds very heavy particles (peaked likelihoods: BASELINE C3) owns many times
+        // TILE outputs, and beyond the first table every output used to cost a ten-probe descent (ten dependent LDS round trips)
+        for (int32_t wb = c_start; wb < c_end; wb += OWN_CAP) {
+            if (wb != c_start) {
+                __syncthreads();                           // the previous window's table has been read
+                const uint4 z = {0u, 0u, 0u, 0u};
+                reinterpret_cast<uint4*>(sh_own)[2 * threadIdx.x] = z;
+                reinterpret_cast<uint4*>(sh_own)[2 * threadIdx.x + 1] = z;
+                __syncthreads();
+            }
+            res_owner_table(sh, sh, sh_own, c_start, wb);
+            const int32_t we = (c_end - wb) < OWN_CAP ? c_end : wb + OWN_CAP;
+            for (int32_t o = wb + threadIdx.x; o < we; o += BLOCK)
+                wt_store(ao + o, (int32_t)((int64_t)tile * TILE + (int)sh_own[o - wb] - 1));
+        }
+    } else {
+        for (int32_t o = c_start + threadIdx.x; o < c_end; o += BLOCK)
+            wt_store(ao + o, (int32_t)((int64_t)tile * TILE + res_owner(sh.cl, o)));
     }
     // outputs whose threshold is >= bins[N] are never written by the reference (j keeps its previous
     // value); the previous value is only materialised here if it was the identity 1:N
