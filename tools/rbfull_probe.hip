@@ -82,6 +82,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PROBE_WAVES)
 int main(int argc, char** argv) {
     const double wps = argc > 1 ? atof(argv[1]) : 1.0;
     const int reps = argc > 2 ? atoi(argv[2]) : 20, memonly = argc > 3 ? atoi(argv[3]) : 0;
+    const int lds_bytes = argc > 4 ? atoi(argv[4]) : 0;       // dynamic LDS per (one-wave) workgroup: 20000 caps the occupancy at 2 waves per SIMD whatever the registers
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
     const int waves = (int)(prop.multiProcessorCount * 4 * wps);
@@ -126,8 +127,8 @@ int main(int argc, char** argv) {
     float best = 1e9f;
     for (int r = 0; r < reps; ++r) {
         CK(hipEventRecord(e0));
-        if (memonly) hipLaunchKernelGGL((llpf::k_probe<NN, NL, NY, true>), dim3(waves), dim3(64), 0, 0, dx, dxo, dp, Ns, du, dy);
-        else hipLaunchKernelGGL((llpf::k_probe<NN, NL, NY, false>), dim3(waves), dim3(64), 0, 0, dx, dxo, dp, Ns, du, dy);
+        if (memonly) hipLaunchKernelGGL((llpf::k_probe<NN, NL, NY, true>), dim3(waves), dim3(64), lds_bytes, 0, dx, dxo, dp, Ns, du, dy);
+        else hipLaunchKernelGGL((llpf::k_probe<NN, NL, NY, false>), dim3(waves), dim3(64), lds_bytes, 0, dx, dxo, dp, Ns, du, dy);
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
         float ms;
