@@ -3,7 +3,7 @@
 
 #if defined(LLPF_RBF_TIMING) && defined(__HIP_DEVICE_COMPILE__)
 // developer build (tools/dbg/rbf_timing.py): cycle stamps of every wave at the stage boundaries of the recursion
-#define RBF_STAMP(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)); g_rbf_dbg[(size_t)blockIdx.x * 16 + (k)] = t_; } while (0)
+#define RBF_STAMP(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)); g_rbf_dbg[(size_t)blockIdx.x * 32 + (k)] = t_; } while (0)
 #endif
 #if defined(LLPF_RBF_TIMING)
 __device__ unsigned long long* g_rbf_dbg;
@@ -72,12 +72,12 @@ static int64_t g_rbf_dbg_waves = 0;
 extern "C" __attribute__((visibility("default"))) int llpf_debug_rbf_timing_arm(int64_t waves) {
     if (g_rbf_dbg_dev) hipFree(g_rbf_dbg_dev);
     g_rbf_dbg_waves = waves;
-    if (hipMalloc(&g_rbf_dbg_dev, sizeof(unsigned long long) * 16 * (size_t)waves) != hipSuccess) return -1;
-    hipMemset(g_rbf_dbg_dev, 0, sizeof(unsigned long long) * 16 * (size_t)waves);
+    if (hipMalloc(&g_rbf_dbg_dev, sizeof(unsigned long long) * 32 * (size_t)waves) != hipSuccess) return -1;
+    hipMemset(g_rbf_dbg_dev, 0, sizeof(unsigned long long) * 32 * (size_t)waves);
     return hipMemcpyToSymbol(HIP_SYMBOL(g_rbf_dbg), &g_rbf_dbg_dev, sizeof(g_rbf_dbg_dev)) == hipSuccess ? 0 : -2;
 }
 extern "C" __attribute__((visibility("default"))) int llpf_debug_rbf_timing_read(unsigned long long* dst) {
     if (hipDeviceSynchronize() != hipSuccess) return -1;
-    return hipMemcpy(dst, g_rbf_dbg_dev, sizeof(unsigned long long) * 16 * (size_t)g_rbf_dbg_waves, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
+    return hipMemcpy(dst, g_rbf_dbg_dev, sizeof(unsigned long long) * 32 * (size_t)g_rbf_dbg_waves, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
 }
 #endif

@@ -20,6 +20,30 @@ DEV void gauss_sample(const GaussD& g, const double* xi, double* out) {
     }
 }
 
+// gauss_sample with the covariance kind tested ONCE and the (uniform) operands through scalar loads: inside the unrolled loop
+// every dimension was a branch with its loads behind it — a memory round trip per dimension (k_rbfull).  Same operations.
+typedef const __attribute__((address_space(4))) GaussD* gauss_cptr;
+template <int ND>
+DEV void gauss_sample_c(gauss_cptr g, const double* xi, double* out) {
+    const int kind = g->kind;
+    if (kind == LLPF_COV_SCAL) {
+        const double s = g->sqrtscal;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) out[i] = s * xi[i] + g->mu[i];
+    } else if (kind == LLPF_COV_DIAG) {
+#pragma unroll
+        for (int i = 0; i < ND; ++i) out[i] = g->sqrtdiag[i] * xi[i] + g->mu[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            double v = g->L[i * MAXD + 0] * xi[0];
+#pragma unroll
+            for (int j = 1; j <= i; ++j) v = v + g->L[i * MAXD + j] * xi[j];
+            out[i] = v + g->mu[i];
+        }
+    }
+}
+
 template <int ND>
 DEV double gauss_logpdf(const GaussD& g, const double* x) {
     double d[ND], q;

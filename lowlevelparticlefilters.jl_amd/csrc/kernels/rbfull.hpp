@@ -10,6 +10,25 @@
 #define RBF_KCPTR(p) ((llpf_rbf_cptr)(p))
 constexpr double RBF_BOUND_SLACK = 0x1p-20;   // keeps exp(w - bound) <= 1 when a particle's C R C' rounds to zero
 
+// Pins every word of a prepared model object in front of `dep` (an empty asm the compiler cannot see through): whatever loads
+// Model::prepare left pending are issued and waited for BEFORE the instructions that consume `dep`.
+template <class M>
+DEV void rbf_model_ready(const M& m, uint32_t& dep) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int W = (int)(sizeof(M) / 4);
+    uint32_t w[W > 0 ? W : 1];
+    __builtin_memcpy(w, &m, (size_t)W * 4);
+#pragma unroll
+    for (int k = 0; k < W; ++k) asm volatile("" : : "v"(w[k]));
+    asm volatile("" : "+v"(dep));
+#endif
+}
+
+#if defined(LLPF_RBF_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+#define RBF_TSTAMP(k, dep) do { asm volatile("" : : "v"(dep)); RBF_STAMP(k); } while (0)
+#else
+#define RBF_TSTAMP(k, dep) ((void)0)
+#endif
 #ifndef LLPF_RBF_WAVES
 #define LLPF_RBF_WAVES 2
 #endif
@@ -26,7 +45,8 @@ __global__ __launch_bounds__(RBF_BLOCK) __attribute__((amdgpu_waves_per_eu(NL >=
     const FilterScal* sc = scal + f;
 #if defined(LLPF_RBF_TIMING) && defined(__HIP_DEVICE_COMPILE__)
     RBF_STAMP(0);
-    { uint32_t hw_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_)); g_rbf_dbg[(size_t)blockIdx.x * 16 + 13] = hw_; }
+    { uint32_t hw_, xcc_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));
+      g_rbf_dbg[(size_t)blockIdx.x * 32 + 13] = hw_; g_rbf_dbg[(size_t)blockIdx.x * 32 + 14] = xcc_; }
 #endif
     // everything the prologue reads is REQUESTED first and tested afterwards (as in k_step): tested one by one, the stop flag, the
     // fallback flag and the scalars were eight scalar-cache round trips in a row in front of the gather
@@ -50,13 +70,42 @@ __global__ __launch_bounds__(RBF_BLOCK) __attribute__((amdgpu_waves_per_eu(NL >=
     double* w = b.w + (size_t)f * Ns;
     const llpf_rbf_par* par = &md->rbf;
 
-    // The gather first: its HBM latency (~2 us) is what everything below waits for, so the particle-independent work of the
-    // prologue is placed behind the loads' issue, not in front of it.
+    // Order of the requests.  Vector loads return in order, so whatever is requested AFTER the 48-plane gather can only be waited
+    // for together with all of it: the ancestor index goes first, then every particle-independent operand (generator tables, the
+    // row of Bl and u of lane r < NL, y, the model's constants), then the gather; the Gaussian's operands come through scalar
+    // loads (a counter of their own).  Behind the gather's issue: the generator and Bl u (they need nothing of it), then the
+    // dynamics (xn, the first four planes), then the recursion (R).  Before this order the RK4 waited for the whole gather and
+    // Bl u was sixteen round trips in a row: 31k of a wave's 50k cycles (tools/dbg/rbf_timing.py).
     const int64_t i = (int64_t)blockIdx.x * RBF_BLOCK + threadIdx.x;
-    const int64_t src = do_res ? (int64_t)b.anc[(size_t)f * Ns + i] : i;
+    const int t = (int)threadIdx.x;
+    int32_t anc_i = 0;
+    if (do_res) anc_i = b.anc[(size_t)f * Ns + i];
+    const double* uf = a.u + (size_t)f * a.u_stride;       // banks on data of their own (llpf_bank_run_multi): filter f's row
+    __shared__ __attribute__((aligned(16))) double sh_rng_lg[2 * LLPF_RNG_LG_ENTRIES], sh_rng_sc[2 * LLPF_RNG_SC_ENTRIES];
+    __shared__ double sh_blu[LLPF_RBF_MAXL], sh_y[LLPF_RBF_MAXY + 1], sh_w[RBF_BLOCK];      // sh_y[NY]: c0 of the measurement density
+    static_assert(RBF_BLOCK >= LLPF_RNG_SC_ENTRIES && RBF_BLOCK >= LLPF_RNG_LG_ENTRIES, "one table entry per lane");
+    double rt0 = 0.0, rt1 = 0.0, rt2 = 0.0, rt3 = 0.0, blv[8], uv[8], yv = 0.0, wv0 = 0.0;
+    const int nu = b.nu;
+    if (MODE != MODE_WEIGHT) {
+        rt0 = LLPF_SIN64[t]; rt1 = LLPF_COS64[t];
+        if (t < LLPF_RNG_LG_ENTRIES) { rt2 = LLPF_LOG_INVC[t]; rt3 = LLPF_LOG_LNC[t]; }
+        if (nu > 0 && t < NL) {      // lane r: row r of Bl (stride nu) and u; entries beyond nu are read (inside the arrays) and not used
+#pragma unroll
+            for (int c = 0; c < 8; ++c) { const int cc = c < nu ? c : 0; blv[c] = par->Bl[t * nu + cc]; uv[c] = uf[cc]; }
+        }
+    }
+    if (MODE != MODE_PROP && a.has_y && t <= NY) yv = t < NY ? a.y[(size_t)f * a.y_stride + t] : md->dg.c0;
+    if (MODE != MODE_PROP && !do_res && !uniform) wv0 = w[i];
+    Model model;
+    model.prepare(md, uf, a.t_prop);
+    RBF_TSTAMP(16, t);                 // prologue scalars back, ancestor and operands requested
+    const int64_t src = do_res ? (int64_t)anc_i : i;
     // 32-bit byte offsets from ONE uniform base per buffer (48 planes: 64-bit addresses would hold 96 registers and cost two
     // instructions each); the launcher checks that a filter's planes span less than 4 GB
-    const uint32_t stride = (uint32_t)Ns * 8u, so = (uint32_t)src * 8u, io = (uint32_t)i * 8u;
+    const uint32_t stride = (uint32_t)Ns * 8u, io = (uint32_t)i * 8u;
+    uint32_t so = (uint32_t)src * 8u;
+    rbf_model_ready(model, so);
+    RBF_TSTAMP(17, so);                // ancestor and operands back      // the gather's addresses "depend" on the model's constants: their loads are issued, and back, before it
     auto ld = [&](int row, uint32_t off) { return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(xc) + (off + (uint32_t)row * stride)); };
     auto st = [&](int row, double v) { *reinterpret_cast<double*>(reinterpret_cast<char*>(xo) + (io + (uint32_t)row * stride)) = v; };
     double xn[NN], xl[NL], R[NP];
@@ -67,26 +116,35 @@ __global__ __launch_bounds__(RBF_BLOCK) __attribute__((amdgpu_waves_per_eu(NL >=
 #pragma unroll
     for (int d = 0; d < NP; ++d) R[d] = ld(NN + NL + d, so);
 
-    const double* uf = a.u + (size_t)f * a.u_stride;       // banks on data of their own (llpf_bank_run_multi): filter f's row
-    Model model;
-    model.prepare(md, uf, a.t_prop);
-    // Bl u is particle-independent and nu a run-time number: formed once per wave, read back by the time update from LDS
-    // (as a branch inside the unrolled body it cut the body into blocks that each kept their constants' SGPRs alive)
-    __shared__ double sh_blu[LLPF_RBF_MAXL];
+    // Bl u is particle-independent and nu a run-time number: formed once per wave (lane r: row r), read back by the time update from
+    // LDS (as a branch inside the unrolled body it cut the body into blocks that each kept their constants' SGPRs alive)
     if (MODE != MODE_WEIGHT) {
+        sh_rng_sc[2 * t] = rt0; sh_rng_sc[2 * t + 1] = rt1;
+        if (t < LLPF_RNG_LG_ENTRIES) { sh_rng_lg[2 * t] = rt2; sh_rng_lg[2 * t + 1] = rt3; }
+        if (t < NL) {
+            double b2 = -0.0;                                        // llpf_rbf_blu_row: x + (-0.0) == x for every x
+            if (nu > 0) {
+                b2 = blv[0] * uv[0];
 #pragma unroll
-        for (int r = 0; r < NL; ++r) {      // uniform addresses only: the parameter pointer must stay scalar (RBF_STAGE takes it in SGPRs)
-            const double v = llpf_rbf_blu_row(RBF_KCPTR(par), b.nu, r, uf);
-            if (threadIdx.x == 0) sh_blu[r] = v;
+                for (int c = 1; c < 8; ++c) { const double t2 = llpf_fma(blv[c], uv[c], b2); b2 = c < nu ? t2 : b2; }
+            }
+            sh_blu[t] = b2;
         }
-        __syncthreads();
     }
+    if (MODE != MODE_PROP) {
+        if (a.has_y && t <= NY) sh_y[t] = yv;
+        sh_w[t] = wv0;
+    }
+    __syncthreads();
+    RBF_TSTAMP(18, t);                 // gather issued, tables in LDS
 
     if (MODE != MODE_WEIGHT) {
         double fi[NN], xi[NN], nz[NN], xn1[NN], xl1[NL], R1[NP];
+        llpf_normals_tab((uint32_t)i, sb + a.step, LLPF_STREAM_DYNAMICS, k0, k1, NN, xi, sh_rng_lg, sh_rng_sc);
+        gauss_sample_c<NN>((gauss_cptr)&md->df, xi, nz);
+        RBF_TSTAMP(19, nz[NN - 1]);        // generator done
+        RBF_TSTAMP(20, xn[NN - 1]);        // xn back
         model.dynamics(xn, fi);
-        llpf_normals((uint32_t)i, sb + a.step, LLPF_STREAM_DYNAMICS, k0, k1, NN, xi);
-        gauss_sample<NN>(md->df, xi, nz);
 #if defined(LLPF_RBF_TIMING) && defined(__HIP_DEVICE_COMPILE__)
         asm volatile("" : : "v"(fi[NN - 1]), "v"(nz[NN - 1]));      // RK4 and the generator are done before stamp 1
 #endif
@@ -107,15 +165,15 @@ __global__ __launch_bounds__(RBF_BLOCK) __attribute__((amdgpu_waves_per_eu(NL >=
     if (MODE != MODE_PROP) {
         wacc.init();
         const double wmx = do_res ? b.log1N : (uniform ? wconst : wmax_prev);
-        off = a.has_y ? (wmx + md->dg.c0) + RBF_BOUND_SLACK : wmx;
+        off = a.has_y ? (wmx + sh_y[NY]) + RBF_BOUND_SLACK : wmx;
         double wv;
         if (do_res) wv = b.log1N;                                 // reset_weights!
         else if (uniform) wv = wconst;
-        else { const double wr = w[i]; wv = pend ? (wr - m) - l : wr; }
+        else { const double wr = sh_w[t]; wv = pend ? (wr - m) - l : wr; }
         if (a.has_y) {
             double y[NY], yn[NY];
 #pragma unroll
-            for (int k = 0; k < NY; ++k) y[k] = a.y[(size_t)f * a.y_stride + k];
+            for (int k = 0; k < NY; ++k) y[k] = sh_y[k];
             model.measurement(xn, yn);
             wv = wv + llpf_rbf_correct(par, NL, NY, y, yn, xl, R);   // w[i] += ll, src/rbpf.jl:272
 #if defined(LLPF_RBF_TIMING) && defined(__HIP_DEVICE_COMPILE__)

@@ -26,9 +26,9 @@ waves = (N + 1023) // 1024 * 16
 assert L.llpf_debug_rbf_timing_arm(ctypes.c_int64(waves)) == 0
 pf.reset()
 pf.run(U, Y, 1.0)
-buf = np.zeros((waves, 16), dtype=np.uint64)
+buf = np.zeros((waves, 32), dtype=np.uint64)
 assert L.llpf_debug_rbf_timing_read(buf.ctypes.data_as(ctypes.c_void_p)) == 0
-st = buf[:, :13].astype(np.int64)
+st = buf[:, :24].astype(np.int64)
 hw = buf[:, 13].astype(np.int64)
 names = ["", "prologue, RK4, generator (gather in flight)", "coupling rows: An, An R, Nt", "Cholesky, V, x~l, R~", "Al x~l + Bl u",
          "upper panel + upper-left block", "lower-left block", "lower panel", "lower-right block + R1l", "(predict -> correct)",
@@ -40,12 +40,86 @@ for k in range(1, 13):
     print("  %-46s median %6d  p10 %6d  p90 %6d" % (names[k], np.median(d), np.percentile(d, 10), np.percentile(d, 90)))
 tot = st[:, 12] - st[:, 0]
 print("  %-46s median %6d  p10 %6d  p90 %6d" % ("whole wave", np.median(tot), np.percentile(tot, 10), np.percentile(tot, 90)))
-# HW_ID (gfx9): wave_id[3:0] simd_id[5:4] pipe[7:6] cu_id[11:8] sh_id[12] se_id[15:13] ...; the XCC comes from another register, so
-# waves of different XCDs share a key here: residency is therefore reported per (key, overlapping intervals) only as a histogram
-key = (hw >> 4) & 0xfff
-start, end = st[:, 0] - t0, st[:, 12] - t0
+# s_memtime is a per-XCD counter: the eight XCDs' values are far apart, so the waves are grouped by the gaps between their sorted
+# start stamps and every group is referred to its own first start.  (The run's last launch is the closing time update: stamps 0-9
+# and 12 are its own, 10 and 11 are left from the launch before.)
+hw = buf[:, 13].astype(np.int64)
+xcc = buf[:, 14].astype(np.int64) & 0xf          # HW_REG_XCC_ID: the XCD of the wave; s_memtime is a per-XCD counter
+grp = xcc
+simd = ((hw >> 4) & 0x3) | (((hw >> 8) & 0xf) << 2) | (((hw >> 12) & 0x1) << 6) | (((hw >> 13) & 0x7) << 7) | (xcc << 10)   # simd, cu, sh, se, xcc
+start = np.zeros(waves, dtype=np.int64)
+end = np.zeros(waves, dtype=np.int64)
+for g in range(grp.max() + 1):
+    m = grp == g
+    start[m] = st[m, 0] - st[m, 0].min()
+    end[m] = st[m, 12] - st[m, 0].min()
+print("%d clock groups (XCDs); launch span per group: %s ticks" % (grp.max() + 1, [int(end[grp == g].max()) for g in range(grp.max() + 1)]))
 span = end.max()
-print("start times: p50 %d p90 %d max %d; end times: p10 %d p50 %d max %d" % (np.median(start), np.percentile(start, 90), start.max(),
-                                                                              np.percentile(end, 10), np.median(end), end.max()))
-order = np.argsort(start)
-print("waves started in ticks [0,5%%) %d, [5,50%%) %d, [50,100%%) %d of the launch" % ((start < 0.05 * span).sum(), ((start >= 0.05 * span) & (start < 0.5 * span)).sum(), (start >= 0.5 * span).sum()))
+early = start < 4000
+print("waves that start with the launch: %d; later: %d" % (early.sum(), (~early).sum()))
+print("start of the later ones: p10 %d p50 %d p90 %d; ends: first-round p50 %d p90 %d, later p50 %d p90 %d max %d" % (
+    np.percentile(start[~early], 10), np.median(start[~early]), np.percentile(start[~early], 90), np.median(end[early]), np.percentile(end[early], 90),
+    np.median(end[~early]), np.percentile(end[~early], 90), end.max()))
+for nm, sel in (("started with the launch", early), ("started later", ~early)):
+    print("%s (%d waves)" % (nm, sel.sum()))
+    for k in range(1, 10):
+        d = (st[:, k] - st[:, k - 1])[sel]
+        print("    %-46s median %6d  p10 %6d  p90 %6d" % (names[k], np.median(d), np.percentile(d, 10), np.percentile(d, 90)))
+    d = (st[:, 12] - st[:, 9])[sel]
+    print("    %-46s median %6d  p10 %6d  p90 %6d" % ("stores, tail", np.median(d), np.percentile(d, 10), np.percentile(d, 90)))
+    print("    %-46s median %6d" % ("whole wave", np.median((st[:, 12] - st[:, 0])[sel])))
+# per SIMD: how many waves it ran and how its second-round waves fared
+ids, cnt = np.unique(simd, return_counts=True)
+print("SIMDs seen %d; waves per SIMD: %s" % (len(ids), dict(zip(*np.unique(cnt, return_counts=True)))))
+# the rounds of a SIMD (its waves share one counter whatever the clock domains are): the two waves it starts with, then the
+# one(s) that take a freed slot
+rows = []
+for sid in ids[cnt == 3]:
+    m = np.where(simd == sid)[0]
+    m = m[np.argsort(st[m, 0])]
+    z = st[m[0], 0]
+    rows.append([st[m[1], 0] - z, st[m[2], 0] - z, st[m[0], 12] - z, st[m[1], 12] - z, st[m[2], 12] - z,
+                 st[m[2], 1] - st[m[2], 0], st[m[2], 9 if False else 8] - st[m[2], 1], st[m[2], 12] - st[m[2], 8],
+                 st[m[0], 1] - st[m[0], 0], st[m[0], 8] - st[m[0], 1], st[m[0], 12] - st[m[0], 8]])
+r = np.median(np.array(rows), axis=0)
+print("SIMDs with three waves (medians, ticks from the SIMD's first start): second starts %d, third starts %d; ends %d %d %d" % tuple(r[:5]))
+print("   third wave: phase one %d, recursion (predict) %d, correct + tail %d;  first wave: %d, %d, %d" % tuple(r[5:]))
+names1 = ["scalars back; ancestor, operands requested", "ancestor and operands back", "gather issued, tables in LDS", "generator", "xn back", "RK4"]
+seq = [0, 16, 17, 18, 19, 20, 1]
+for which, idx in (("first", 0), ("third", 2)):
+    rr = []
+    for sid in ids[cnt == 3]:
+        m = np.where(simd == sid)[0]
+        m = m[np.argsort(st[m, 0])]
+        rr.append([st[m[idx], seq[k + 1]] - st[m[idx], seq[k]] for k in range(6)])
+    rr = np.median(np.array(rr), axis=0)
+    print("   phase one of the %s wave: %s" % (which, ", ".join("%s %d" % (names1[k], rr[k]) for k in range(6))))
+# which workgroups share a SIMD (the dispatcher's order): block indices of the three waves of a few SIMDs, in start order
+show = []
+for sid in ids[cnt == 3][:12]:
+    m = np.where(simd == sid)[0]
+    m = m[np.argsort(st[m, 0])]
+    show.append(tuple(int(x) for x in m))
+print("blocks of a SIMD in start order:", show)
+second = []
+for sid in ids[cnt == 3]:
+    m = np.where(simd == sid)[0]
+    m = m[np.argsort(st[m, 0])]
+    second.append((m[0], m[1], m[2]))
+second = np.array(second)
+print("first-wave block index: min %d max %d; second: min %d max %d; third: min %d max %d" % (second[:, 0].min(), second[:, 0].max(), second[:, 1].min(), second[:, 1].max(), second[:, 2].min(), second[:, 2].max()))
+print("second - first: %s" % dict(zip(*np.unique(second[:, 1] - second[:, 0], return_counts=True))))
+print("wave slot (HW_ID[3:0]) of first / second / third: %s" % [dict(zip(*np.unique(hw[second[:, k]] & 0xf, return_counts=True))) for k in range(3)])
+# absolute time line of the three waves of a SIMD (medians over the SIMDs with three waves; ticks from the SIMD's first start)
+order_s = [0, 16, 17, 18, 19, 20, 1, 2, 3, 4, 5, 6, 7, 8, 12]
+lab = ["start", "scalars", "operands", "gather issued", "generator", "xn back", "RK4", "coupling", "Chol/V/R~", "Al x", "up panel", "ll block", "lo panel", "lr block", "end"]
+tl = []
+for sid in ids[cnt == 3]:
+    m = np.where(simd == sid)[0]
+    m = m[np.argsort(st[m, 0])]
+    z = st[m[0], 0]
+    tl.append([[st[m[k], q] - z for q in order_s] for k in range(3)])
+tl = np.median(np.array(tl), axis=0)
+print("%-14s %8s %8s %8s" % ("stamp", "first", "second", "third"))
+for q in range(len(order_s)):
+    print("%-14s %8d %8d %8d" % (lab[q], tl[0, q], tl[1, q], tl[2, q]))
