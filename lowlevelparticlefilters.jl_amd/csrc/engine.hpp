@@ -298,5 +298,6 @@ bool step_supported(int model_id, int nx, int ny);
 int jit_compile_user_model(const char* device_src, int nx, int ny, std::string& err);
 bool rbfull_supported(int fn_kind, int nn, int nl, int ny);
 int rbfull_rows(int nn, int nl);   // rows of the particle plane: xn, xl, packed R
+unsigned rbfull_grid_x(const BankDev& b, int nl, int mode);   // workgroups along x of a k_rbfull launch (persistent for the 8x8 form)
 
 }  // namespace llpf

@@ -3,10 +3,13 @@
 
 #if defined(LLPF_RBF_TIMING) && defined(__HIP_DEVICE_COMPILE__)
 // developer build (tools/dbg/rbf_timing.py): cycle stamps of every wave at the stage boundaries of the recursion
-#define RBF_STAMP(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)); g_rbf_dbg[(size_t)blockIdx.x * 32 + (k)] = t_; } while (0)
+#define RBF_STAMP(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)); g_rbf_dbg[(size_t)g_rbf_row * 32 + (k)] = t_; } while (0)
 #endif
 #if defined(LLPF_RBF_TIMING)
 __device__ unsigned long long* g_rbf_dbg;
+#if defined(__HIP_DEVICE_COMPILE__)
+__shared__ unsigned int g_rbf_row;      // the batch a persistent wave has in hand: the row its stamps go to
+#endif
 #endif
 #include "engine.hpp"
 
@@ -34,9 +37,27 @@ bool rbfull_supported(int fn_kind, int nn, int nl, int ny) {
 }
 int rbfull_rows(int nn, int nl) { return nn + nl + LLPF_RBF_NP(nl); }
 
+// Workgroups (single waves) along x.  The 8x8 form is persistent (kernels/rbfull.hpp): as many waves as the device holds at once —
+// two per SIMD, eight per CU — shared among the bank's filters; every wave takes batches blockIdx.x, blockIdx.x + gridDim.x, ...
+unsigned rbfull_grid_x(const BankDev& b, int nl, int mode) {
+    const unsigned nbatch = (unsigned)(b.Ns / RBF_BLOCK);
+    if (nl < 8 || mode == MODE_WEIGHT) return nbatch;
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nbatch;
+    if (cus[dev] == 0) {
+        int n = 0;
+        cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : -1;
+    }
+    if (cus[dev] < 0) return nbatch;
+    const unsigned resident = (unsigned)cus[dev] * 4u * (unsigned)LLPF_RBF_WAVES;
+    const unsigned per_filter = resident / (unsigned)(b.F > 0 ? b.F : 1);
+    return nbatch < per_filter ? nbatch : (per_filter > 0 ? per_filter : 1u);
+}
+
 template <class Model, int NN, int NL, int NY>
 static hipError_t launch_rbfull_t(const BankDev& b, int mode, const StepArgs& a, hipStream_t s) {
-    dim3 g((unsigned)(b.Ns / RBF_BLOCK), (unsigned)b.F, 1);
+    dim3 g(rbfull_grid_x(b, NL, mode), (unsigned)b.F, 1);
     switch (mode) {
         case MODE_WEIGHT: hipLaunchKernelGGL((k_rbfull<Model, NN, NL, NY, MODE_WEIGHT>), g, dim3(RBF_BLOCK), 0, s, b, b.models, b.scal, a); break;
         case MODE_PROP: hipLaunchKernelGGL((k_rbfull<Model, NN, NL, NY, MODE_PROP>), g, dim3(RBF_BLOCK), 0, s, b, b.models, b.scal, a); break;

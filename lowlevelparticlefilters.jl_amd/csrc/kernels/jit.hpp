@@ -182,7 +182,8 @@ int jit_prepare_rbfull(int fk, int nn, int nl, int ny, std::string& err) {
     std::string arch = "gfx950";
     if (hipGetDevice(&devid) == hipSuccess && hipGetDeviceProperties(&prop, devid) == hipSuccess && prop.gcnArchName[0]) arch = prop.gcnArchName;
     const std::string archopt = "--offload-arch=" + arch;
-    const char* opts[] = {archopt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-Wno-unused-value"};
+    // -disable-machine-licm: as for k_rbfull.hip (Makefile) — hoisted out of the persistent loop, the literal constants of the body are spilled
+    const char* opts[] = {archopt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-Wno-unused-value", "-mllvm", "-disable-machine-licm"};
     const hiprtcResult rc = hiprtcCompileProgram(prog, (int)(sizeof(opts) / sizeof(opts[0])), opts);
     if (rc != HIPRTC_SUCCESS) {
         size_t n = 0;
@@ -230,5 +231,5 @@ hipError_t launch_rbfull_jit(int fk, int nn, int nl, int ny, const BankDev& b, i
     const FilterScal* scal = b.scal;
     StepArgs aa = a;
     void* args[] = {&bd, &models, &scal, &aa};
-    return hipModuleLaunchKernel(fn, (unsigned)(b.Ns / 64), (unsigned)b.F, 1, 64, 1, 1, 0, s, args, nullptr);
+    return hipModuleLaunchKernel(fn, rbfull_grid_x(b, nl, mode), (unsigned)b.F, 1, 64, 1, 1, 0, s, args, nullptr);
 }

@@ -29,24 +29,43 @@ DEV void rbf_model_ready(const M& m, uint32_t& dep) {
 #else
 #define RBF_TSTAMP(k, dep) ((void)0)
 #endif
+// element idx of an array through a 32-bit byte offset from its (uniform) base: one address register, saddr + voffset addressing
+DEV double* rbf_at(double* base, uint32_t idx) { return reinterpret_cast<double*>(reinterpret_cast<char*>(base) + (size_t)(idx * 8u)); }
+DEV uint64_t* rbf_at(uint64_t* base, uint32_t idx) { return reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(base) + (size_t)(idx * 8u)); }
+DEV const int32_t* rbf_at(const int32_t* base, uint32_t idx) { return reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(base) + (size_t)(idx * 4u)); }
 #ifndef LLPF_RBF_WAVES
 #define LLPF_RBF_WAVES 2
 #endif
-// One wave per workgroup: a particle costs ~6000 instructions here and N = 2e5 is 3.06 waves per SIMD, so the launch ends with the
-// SIMDs that got a fourth wave; single-wave groups let the dispatcher hand a wave to whichever SIMD frees a slot.
+// One wave per workgroup: a particle costs ~4000 vector instructions here, two waves fit a SIMD (226 VGPRs) and N = 2e5 is 3.06 batches
+// of 64 particles per SIMD.  The launch is PERSISTENT for the 8x8 form: at most two waves per SIMD (launch_rbfull: gridDim.x), each
+// taking batches blockIdx.x, blockIdx.x + gridDim.x, ...  While a wave runs the recursion of one batch, the covariance planes of its
+// next batch travel global -> LDS without passing through registers (global_load_lds_dword: per-lane gather addresses, 35 of the 36
+// planes = 17.5 KB of the 20 KB a wave may hold when eight share a CU's 160 KB); the remaining 13 planes (xn, xl, the last of R) are
+// requested into registers after the recursion, before the batch's stores.  Launched as one wave per batch the third wave of every
+// SIMD started its gather when the memory system was busy with the first round's stores, and the memory-bound and the issue-bound
+// phases of the launch added up (tools/dbg/rbf_timing.py: 40k + 49k of 89k cycles).
 constexpr int RBF_BLOCK = 64;
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(3))) void* rbf_lds_ptr;
+typedef const __attribute__((address_space(1))) void* rbf_glb_ptr;
+#endif
 template <class Model, int NN, int NL, int NY, int MODE>
 __global__ __launch_bounds__(RBF_BLOCK) __attribute__((amdgpu_waves_per_eu(NL >= 8 ? LLPF_RBF_WAVES : 1))) void k_rbfull(BankDev b, const ModelD* __restrict__ models,
                                                    const FilterScal* scal, StepArgs a) {
     static_assert(MODE == MODE_WEIGHT || MODE == MODE_PROP || MODE == MODE_PROP_WEIGHT, "no auxiliary form");
     constexpr int NP = LLPF_RBF_NP(NL), ROWS = NN + NL + NP;
+    constexpr bool DMA = NL >= 8 && MODE != MODE_WEIGHT;       // covariance planes through LDS (the persistent form)
+    constexpr int NPD = DMA ? NP - 1 : 0, NDIR = NP - NPD;     // planes of R through LDS / straight into registers
     const int f = blockIdx.y;
     const ModelD* md = models + f;
     const FilterScal* sc = scal + f;
+    uint32_t bb = blockIdx.x;                                   // the batch (64 particles) in hand
 #if defined(LLPF_RBF_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+    if (threadIdx.x == 0) g_rbf_row = bb;
+    __syncthreads();
     RBF_STAMP(0);
     { uint32_t hw_, xcc_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));
-      g_rbf_dbg[(size_t)blockIdx.x * 32 + 13] = hw_; g_rbf_dbg[(size_t)blockIdx.x * 32 + 14] = xcc_; }
+      g_rbf_dbg[(size_t)bb * 32 + 13] = hw_; g_rbf_dbg[(size_t)bb * 32 + 14] = xcc_; }
 #endif
     // everything the prologue reads is REQUESTED first and tested afterwards (as in k_step): tested one by one, the stop flag, the
     // fallback flag and the scalars were eight scalar-cache round trips in a row in front of the gather
@@ -68,23 +87,27 @@ __global__ __launch_bounds__(RBF_BLOCK) __attribute__((amdgpu_waves_per_eu(NL >=
     const double* __restrict__ xc = b.xcur + (size_t)f * ROWS * Ns;
     double* __restrict__ xo = (MODE == MODE_WEIGHT) ? const_cast<double*>(xc) : b.xnext + (size_t)f * ROWS * Ns;
     double* w = b.w + (size_t)f * Ns;
+    const int32_t* ancf = b.anc + (size_t)f * Ns;
     const llpf_rbf_par* par = &md->rbf;
+    const uint32_t nbatch = (uint32_t)(Ns / RBF_BLOCK), gstep = gridDim.x;
+    const bool need_w = MODE != MODE_PROP && !do_res && !uniform;
 
-    // Order of the requests.  Vector loads return in order, so whatever is requested AFTER the 48-plane gather can only be waited
-    // for together with all of it: the ancestor index goes first, then every particle-independent operand (generator tables, the
-    // row of Bl and u of lane r < NL, y, the model's constants), then the gather; the Gaussian's operands come through scalar
-    // loads (a counter of their own).  Behind the gather's issue: the generator and Bl u (they need nothing of it), then the
-    // dynamics (xn, the first four planes), then the recursion (R).  Before this order the RK4 waited for the whole gather and
-    // Bl u was sixteen round trips in a row: 31k of a wave's 50k cycles (tools/dbg/rbf_timing.py).
-    const int64_t i = (int64_t)blockIdx.x * RBF_BLOCK + threadIdx.x;
+    // Order of the requests.  Vector loads return in order, so whatever is requested AFTER a gather can only be waited for together
+    // with all of it: the ancestor index goes first, then every particle-independent operand (generator tables, the row of Bl and u
+    // of lane r < NL, y, the model's constants), then the planes; the Gaussian's operands come through scalar loads (a counter of
+    // their own).  Behind the planes' issue: the generator (it needs nothing of them), then the dynamics (xn), then the recursion (R).
     const int t = (int)threadIdx.x;
+    // 32-bit particle index and byte offsets from uniform bases: what stays in registers through the loop is one word per quantity
+    uint32_t i = bb * (uint32_t)RBF_BLOCK + (uint32_t)t;
+    uint64_t* qnf = b.quanta_next + (size_t)f * Ns;
     int32_t anc_i = 0;
-    if (do_res) anc_i = b.anc[(size_t)f * Ns + i];
+    if (do_res) anc_i = *rbf_at(ancf, i);
     const double* uf = a.u + (size_t)f * a.u_stride;       // banks on data of their own (llpf_bank_run_multi): filter f's row
     __shared__ __attribute__((aligned(16))) double sh_rng_lg[2 * LLPF_RNG_LG_ENTRIES], sh_rng_sc[2 * LLPF_RNG_SC_ENTRIES];
     __shared__ double sh_blu[LLPF_RBF_MAXL], sh_y[LLPF_RBF_MAXY + 1], sh_w[RBF_BLOCK];      // sh_y[NY]: c0 of the measurement density
+    __shared__ __attribute__((aligned(16))) uint32_t sh_R[DMA ? NPD * 128 : 4];                // plane d: 64 low words, 64 high words
     static_assert(RBF_BLOCK >= LLPF_RNG_SC_ENTRIES && RBF_BLOCK >= LLPF_RNG_LG_ENTRIES, "one table entry per lane");
-    double rt0 = 0.0, rt1 = 0.0, rt2 = 0.0, rt3 = 0.0, blv[8], uv[8], yv = 0.0, wv0 = 0.0;
+    double rt0 = 0.0, rt1 = 0.0, rt2 = 0.0, rt3 = 0.0, blv[8], uv[8], yv = 0.0, wN = 0.0;
     const int nu = b.nu;
     if (MODE != MODE_WEIGHT) {
         rt0 = LLPF_SIN64[t]; rt1 = LLPF_COS64[t];
@@ -95,26 +118,41 @@ __global__ __launch_bounds__(RBF_BLOCK) __attribute__((amdgpu_waves_per_eu(NL >=
         }
     }
     if (MODE != MODE_PROP && a.has_y && t <= NY) yv = t < NY ? a.y[(size_t)f * a.y_stride + t] : md->dg.c0;
-    if (MODE != MODE_PROP && !do_res && !uniform) wv0 = w[i];
-    Model model;
-    model.prepare(md, uf, a.t_prop);
+    if (need_w) wN = *rbf_at(w, i);
     RBF_TSTAMP(16, t);                 // prologue scalars back, ancestor and operands requested
-    const int64_t src = do_res ? (int64_t)anc_i : i;
     // 32-bit byte offsets from ONE uniform base per buffer (48 planes: 64-bit addresses would hold 96 registers and cost two
     // instructions each); the launcher checks that a filter's planes span less than 4 GB
-    const uint32_t stride = (uint32_t)Ns * 8u, io = (uint32_t)i * 8u;
-    uint32_t so = (uint32_t)src * 8u;
-    rbf_model_ready(model, so);
-    RBF_TSTAMP(17, so);                // ancestor and operands back      // the gather's addresses "depend" on the model's constants: their loads are issued, and back, before it
+    const uint32_t stride = (uint32_t)Ns * 8u;
+    uint32_t so = (do_res ? (uint32_t)anc_i : i) * 8u;
+    RBF_TSTAMP(17, so);                // ancestor and operands back
     auto ld = [&](int row, uint32_t off) { return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(xc) + (off + (uint32_t)row * stride)); };
-    auto st = [&](int row, double v) { *reinterpret_cast<double*>(reinterpret_cast<char*>(xo) + (io + (uint32_t)row * stride)) = v; };
-    double xn[NN], xl[NL], R[NP];
+    // the planes of one batch: xn, xl and the last NDIR planes of R into registers, the first NPD planes of R into LDS
+    double xn[NN], xl[NL], RN[NDIR], fi[NN], nz[NN];
+    auto request_regs = [&](uint32_t off) {
 #pragma unroll
-    for (int d = 0; d < NN; ++d) xn[d] = ld(d, so);
+        for (int d = 0; d < NN; ++d) xn[d] = ld(d, off);
 #pragma unroll
-    for (int d = 0; d < NL; ++d) xl[d] = ld(NN + d, so);
+        for (int d = 0; d < NL; ++d) xl[d] = ld(NN + d, off);
 #pragma unroll
-    for (int d = 0; d < NP; ++d) R[d] = ld(NN + NL + d, so);
+        for (int d = 0; d < NDIR; ++d) RN[d] = ld(NN + NL + NPD + d, off);
+    };
+    auto request_lds = [&](uint32_t off) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (DMA) {
+            const char* base = reinterpret_cast<const char*>(xc);
+#pragma unroll
+            for (int d = 0; d < NPD; ++d) {      // the instruction's offset moves the global AND the LDS address: the high word's LDS base is taken 4 back
+                const uint32_t o = off + (uint32_t)(NN + NL + d) * stride;
+                __builtin_amdgcn_global_load_lds((rbf_glb_ptr)(base + o), (rbf_lds_ptr)(sh_R + d * 128), 4, 0, 0);
+                __builtin_amdgcn_global_load_lds((rbf_glb_ptr)(base + o), (rbf_lds_ptr)(sh_R + d * 128 + 63), 4, 4, 0);
+            }
+        }
+#endif
+    };
+    request_regs(so);
+    double Rf[NPD > 0 ? NPD : 1];      // the first batch's LDS planes come straight into registers (half the instructions of the LDS path)
+#pragma unroll
+    for (int d = 0; d < NPD; ++d) Rf[d] = ld(NN + NL + d, so);
 
     // Bl u is particle-independent and nu a run-time number: formed once per wave (lane r: row r), read back by the time update from
     // LDS (as a branch inside the unrolled body it cut the body into blocks that each kept their constants' SGPRs alive)
@@ -131,100 +169,173 @@ __global__ __launch_bounds__(RBF_BLOCK) __attribute__((amdgpu_waves_per_eu(NL >=
             sh_blu[t] = b2;
         }
     }
-    if (MODE != MODE_PROP) {
-        if (a.has_y && t <= NY) sh_y[t] = yv;
-        sh_w[t] = wv0;
-    }
+    if (MODE != MODE_PROP && a.has_y && t <= NY) sh_y[t] = yv;
     __syncthreads();
-    RBF_TSTAMP(18, t);                 // gather issued, tables in LDS
+    RBF_TSTAMP(18, t);                 // planes requested, tables in LDS
 
-    if (MODE != MODE_WEIGHT) {
-        double fi[NN], xi[NN], nz[NN], xn1[NN], xl1[NL], R1[NP];
-        llpf_normals_tab((uint32_t)i, sb + a.step, LLPF_STREAM_DYNAMICS, k0, k1, NN, xi, sh_rng_lg, sh_rng_sc);
-        gauss_sample_c<NN>((gauss_cptr)&md->df, xi, nz);
-        RBF_TSTAMP(19, nz[NN - 1]);        // generator done
-        RBF_TSTAMP(20, xn[NN - 1]);        // xn back
-        model.dynamics(xn, fi);
-#if defined(LLPF_RBF_TIMING) && defined(__HIP_DEVICE_COMPILE__)
-        asm volatile("" : : "v"(fi[NN - 1]), "v"(nz[NN - 1]));      // RK4 and the generator are done before stamp 1
+    // The model's constants through scalar loads (their own counter: no place in the queue of the planes), where they are used: held
+    // across the loop they would sit in registers through the recursion.  The pointers pass an empty asm tied to a value of the batch
+    // in hand, so the loads can be neither hoisted out of the loop nor issued before that value exists.
+    auto prepared = [&](double dep) {
+        Model mdl;
+#if defined(__HIP_DEVICE_COMPILE__)
+        const __attribute__((address_space(4))) ModelD* mk = (const __attribute__((address_space(4))) ModelD*)md;
+        const __attribute__((address_space(4))) double* uk = (const __attribute__((address_space(4))) double*)uf;
+        asm volatile("" : "+s"(mk), "+s"(uk) : "v"(dep));
+        mdl.prepare((const ModelD*)mk, (const double*)uk, a.t_prop);
+#else
+        mdl.prepare(md, uf, a.t_prop);
 #endif
-        llpf_rbf_predict(par, NN, NL, b.nu, xn, xl, R, uf, sh_blu, fi, nz, xn1, xl1, R1);
-#pragma unroll
-        for (int d = 0; d < NN; ++d) xn[d] = xn1[d];
-#pragma unroll
-        for (int d = 0; d < NL; ++d) xl[d] = xl1[d];
-#pragma unroll
-        for (int d = 0; d < NP; ++d) R[d] = R1[d];
-    }
-
-    double bmax = -LLPF_INF;
-    bool bad = false;
-    double off = 0.0;
-    WeightAcc wacc;
-    uint64_t qsum = 0;
-    if (MODE != MODE_PROP) {
-        wacc.init();
-        const double wmx = do_res ? b.log1N : (uniform ? wconst : wmax_prev);
-        off = a.has_y ? (wmx + sh_y[NY]) + RBF_BOUND_SLACK : wmx;
-        double wv;
-        if (do_res) wv = b.log1N;                                 // reset_weights!
-        else if (uniform) wv = wconst;
-        else { const double wr = sh_w[t]; wv = pend ? (wr - m) - l : wr; }
-        if (a.has_y) {
-            double y[NY], yn[NY];
-#pragma unroll
-            for (int k = 0; k < NY; ++k) y[k] = sh_y[k];
-            model.measurement(xn, yn);
-            wv = wv + llpf_rbf_correct(par, NL, NY, y, yn, xl, R);   // w[i] += ll, src/rbpf.jl:272
+        return mdl;
+    };
+    // what does not need the covariance: the noise of particle idx, then (xn back) the dynamics
+    auto front = [&](uint32_t idx) {
+        if (MODE != MODE_WEIGHT) {
+            double xi[NN];
+            llpf_normals_tab(idx, sb + a.step, LLPF_STREAM_DYNAMICS, k0, k1, NN, xi, sh_rng_lg, sh_rng_sc);
+            gauss_sample_c<NN>((gauss_cptr)&md->df, xi, nz);
+            RBF_TSTAMP(19, nz[NN - 1]);        // generator done
+        }
+        RBF_TSTAMP(20, xn[NN - 1]);            // xn back
+        if (MODE != MODE_WEIGHT) {
+            const Model mdl = prepared(nz[0]);
+            mdl.dynamics(xn, fi);
 #if defined(LLPF_RBF_TIMING) && defined(__HIP_DEVICE_COMPILE__)
-            asm volatile("" : : "v"(wv));
-            RBF_STAMP(11);
+            asm volatile("" : : "v"(fi[NN - 1]), "v"(nz[NN - 1]));      // RK4 and the generator are done before stamp 1
 #endif
         }
-        if (i >= N) wv = -LLPF_INF;                                // padding lanes carry zero weight
-        w[i] = wv;
-        bad = wv != wv;
-        bmax = wv;
-        if (a.accumulate) {     // merged schedule: exp-sums, quantum and tile sum of the new weight formed here (otherwise by k_norm)
-            qsum = wacc.add(wv, off, a.K, a.need_e2 != 0);
-            b.quanta_next[(size_t)f * Ns + i] = qsum;
-        }
+    };
+    front(i);
+    if (DMA) {
+#pragma unroll
+        for (int d = 0; d < NPD; ++d) { sh_R[d * 128 + t] = (uint32_t)__double2loint(Rf[d]); sh_R[d * 128 + 64 + t] = (uint32_t)__double2hiint(Rf[d]); }
     }
-    if (MODE != MODE_WEIGHT || a.has_y) {
+
+    for (;;) {
+        const bool has_next = DMA && bb + gstep < nbatch;          // uniform
+        const uint32_t i_n = i + gstep * (uint32_t)RBF_BLOCK;
+        const uint32_t io = i * 8u;
+        auto st = [&](int row, double v) { *reinterpret_cast<double*>(reinterpret_cast<char*>(xo) + (io + (uint32_t)row * stride)) = v; };
+        // the next batch's ancestor: requested here, wanted after the time update
+        int32_t anc_n = 0;
+        if (has_next && do_res) anc_n = *rbf_at(ancf, i_n);
+        if (MODE != MODE_PROP) sh_w[t] = wN;
+        double R[NP];
 #pragma unroll
-        for (int d = 0; d < NN; ++d) st(d, xn[d]);
+        for (int d = 0; d < NPD; ++d) R[d] = __hiloint2double((int)sh_R[d * 128 + 64 + t], (int)sh_R[d * 128 + t]);
 #pragma unroll
-        for (int d = 0; d < NL; ++d) st(NN + d, xl[d]);
+        for (int d = 0; d < NDIR; ++d) R[NPD + d] = RN[d];
+        uint32_t so_n = (do_res ? (uint32_t)anc_n : i_n) * 8u;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (DMA && has_next) {
+            // The next batch's covariance planes start travelling while this batch's recursion runs.  The LDS planes they overwrite have
+            // just been read: the reads are pinned in front of the wait below, which holds until their data is back.
 #pragma unroll
-        for (int d = 0; d < NP; ++d) st(NN + NL + d, R[d]);
-    }
-    if (MODE != MODE_PROP) {
-        const double r = wave_max(bmax);                        // the workgroup is one wave
-        const int anybad = __ballot(bad) != 0 ? 1 : 0;
-        if (a.accumulate) {
-            wacc.flush_wave(b.acc + (size_t)f * ACC_WORDS, a.parity, a.need_e2 != 0);
-            qsum = wave_sum_u64(qsum);     // the wave's 64 particles lie in one 1024-particle tile
+            for (int d = 0; d < NPD; ++d) asm volatile("" : : "v"(R[d]));
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(so_n));
+            request_lds(so_n);
         }
-        if (threadIdx.x == 0) {
-            if (a.accumulate && qsum) atomicAdd(reinterpret_cast<unsigned long long*>(tileq_slot(b, a.parity, f) + (i / TILE)), (unsigned long long)qsum);
-            acc_max(b.acc + (size_t)f * ACC_WORDS, a.parity, r, anybad != 0);
-            if (blockIdx.x == 0) {
-                FilterScal* scw = b.scal + f;
-                scw->off_slot[a.parity] = off;
-                scw->exact_slot[a.parity] = 0;
-                scw->e2v_slot[a.parity] = a.need_e2;
-                scw->u_slot[a.parity] = llpf_uniform_step(sb + a.next_step, LLPF_STREAM_RESAMPLE, k0, k1);
+#endif
+        if (MODE != MODE_WEIGHT) {
+            double xn1[NN], xl1[NL], R1[NP];
+            llpf_rbf_predict(par, NN, NL, b.nu, xn, xl, R, uf, sh_blu, fi, nz, xn1, xl1, R1);
+#pragma unroll
+            for (int d = 0; d < NN; ++d) xn[d] = xn1[d];
+#pragma unroll
+            for (int d = 0; d < NL; ++d) xl[d] = xl1[d];
+#pragma unroll
+            for (int d = 0; d < NP; ++d) R[d] = R1[d];
+        }
+
+        double bmax = -LLPF_INF;
+        bool bad = false;
+        double off = 0.0;
+        WeightAcc wacc;
+        uint64_t qsum = 0;
+        double wv = 0.0;
+        if (MODE != MODE_PROP) {
+            wacc.init();
+            const double wmx = do_res ? b.log1N : (uniform ? wconst : wmax_prev);
+            off = a.has_y ? (wmx + sh_y[NY]) + RBF_BOUND_SLACK : wmx;
+            if (do_res) wv = b.log1N;                                 // reset_weights!
+            else if (uniform) wv = wconst;
+            else { const double wr = sh_w[t]; wv = pend ? (wr - m) - l : wr; }
+            if (a.has_y) {
+                double y[NY], yn[NY];
+#pragma unroll
+                for (int k = 0; k < NY; ++k) y[k] = sh_y[k];
+                prepared(xn[0]).measurement(xn, yn);
+                wv = wv + llpf_rbf_correct(par, NL, NY, y, yn, xl, R);   // w[i] += ll, src/rbpf.jl:272
+#if defined(LLPF_RBF_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+                asm volatile("" : : "v"(wv));
+                RBF_STAMP(11);
+#endif
+            }
+            if (i >= (uint32_t)N) wv = -LLPF_INF;                                // padding lanes carry zero weight
+        }
+        if (MODE != MODE_PROP) {
+            bad = wv != wv;
+            bmax = wv;
+            // merged schedule: exp-sums, quantum and tile sum of the new weight formed here (otherwise by k_norm)
+            if (a.accumulate) qsum = wacc.add(wv, off, a.K, a.need_e2 != 0);
+        }
+        if (MODE != MODE_PROP) {
+            *rbf_at(w, i) = wv;
+            if (a.accumulate) *rbf_at(qnf, i) = qsum;
+        }
+        if (MODE != MODE_WEIGHT || a.has_y) {
+#pragma unroll
+            for (int d = 0; d < NN; ++d) st(d, xn[d]);
+#pragma unroll
+            for (int d = 0; d < NL; ++d) st(NN + d, xl[d]);
+#pragma unroll
+            for (int d = 0; d < NP; ++d) st(NN + NL + d, R[d]);
+        }
+        // the next batch's register planes: behind this batch's stores in the queue (requested before them, their 26 registers do not
+        // fit beside the 96 being stored and the compiler spills them with a wait); its noise is generated while they travel
+        if (has_next) {
+            request_regs(so_n);
+            if (need_w) wN = *rbf_at(w, i_n);
+        }
+        if (MODE != MODE_PROP) {
+            const double r = wave_max(bmax);                        // the workgroup is one wave
+            const int anybad = __ballot(bad) != 0 ? 1 : 0;
+            if (a.accumulate) {
+                wacc.flush_wave(b.acc + (size_t)f * ACC_WORDS, a.parity, a.need_e2 != 0);
+                qsum = wave_sum_u64(qsum);     // the wave's 64 particles lie in one 1024-particle tile
+            }
+            if (threadIdx.x == 0) {
+                if (a.accumulate && qsum) atomicAdd(reinterpret_cast<unsigned long long*>(tileq_slot(b, a.parity, f) + (i / TILE)), (unsigned long long)qsum);
+                acc_max(b.acc + (size_t)f * ACC_WORDS, a.parity, r, anybad != 0);
+                if (bb == 0) {
+                    FilterScal* scw = b.scal + f;
+                    scw->off_slot[a.parity] = off;
+                    scw->exact_slot[a.parity] = 0;
+                    scw->e2v_slot[a.parity] = a.need_e2;
+                    scw->u_slot[a.parity] = llpf_uniform_step(sb + a.next_step, LLPF_STREAM_RESAMPLE, k0, k1);
+                }
             }
         }
-    }
 #if defined(LLPF_RBF_TIMING) && defined(__HIP_DEVICE_COMPILE__)
-    RBF_STAMP(12);
+        RBF_STAMP(12);
 #endif
-    if (MODE != MODE_WEIGHT && blockIdx.x == 0 && threadIdx.x == 0) {
-        FilterScal* scw = b.scal + f;
-        scw->anc_ident_s[b.anc_slot ^ 1] = do_res ? 0 : 1;
-        scw->last_resampled = do_res;
-        scw->resample_count += do_res;
+        if (MODE != MODE_WEIGHT && bb == 0 && threadIdx.x == 0) {
+            FilterScal* scw = b.scal + f;
+            scw->anc_ident_s[b.anc_slot ^ 1] = do_res ? 0 : 1;
+            scw->last_resampled = do_res;
+            scw->resample_count += do_res;
+        }
+        if (!DMA || !has_next) break;      // only the form with its covariance planes through LDS is launched with fewer waves than batches
+        bb += gstep;
+        i = i_n;
+#if defined(LLPF_RBF_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+        if (threadIdx.x == 0) g_rbf_row = bb;
+        __syncthreads();
+        RBF_STAMP(0);
+        { uint32_t hw_, xcc_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));
+          g_rbf_dbg[(size_t)bb * 32 + 13] = hw_; g_rbf_dbg[(size_t)bb * 32 + 14] = xcc_; g_rbf_dbg[(size_t)bb * 32 + 15] = 1; }
+#endif
+        front(i);                          // the next batch's noise and dynamics while this batch's stores drain
     }
 }
 

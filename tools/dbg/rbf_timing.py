@@ -71,55 +71,21 @@ for nm, sel in (("started with the launch", early), ("started later", ~early)):
 # per SIMD: how many waves it ran and how its second-round waves fared
 ids, cnt = np.unique(simd, return_counts=True)
 print("SIMDs seen %d; waves per SIMD: %s" % (len(ids), dict(zip(*np.unique(cnt, return_counts=True)))))
-# the rounds of a SIMD (its waves share one counter whatever the clock domains are): the two waves it starts with, then the
-# one(s) that take a freed slot
-rows = []
-for sid in ids[cnt == 3]:
-    m = np.where(simd == sid)[0]
-    m = m[np.argsort(st[m, 0])]
-    z = st[m[0], 0]
-    rows.append([st[m[1], 0] - z, st[m[2], 0] - z, st[m[0], 12] - z, st[m[1], 12] - z, st[m[2], 12] - z,
-                 st[m[2], 1] - st[m[2], 0], st[m[2], 9 if False else 8] - st[m[2], 1], st[m[2], 12] - st[m[2], 8],
-                 st[m[0], 1] - st[m[0], 0], st[m[0], 8] - st[m[0], 1], st[m[0], 12] - st[m[0], 8]])
-r = np.median(np.array(rows), axis=0)
-print("SIMDs with three waves (medians, ticks from the SIMD's first start): second starts %d, third starts %d; ends %d %d %d" % tuple(r[:5]))
-print("   third wave: phase one %d, recursion (predict) %d, correct + tail %d;  first wave: %d, %d, %d" % tuple(r[5:]))
-names1 = ["scalars back; ancestor, operands requested", "ancestor and operands back", "gather issued, tables in LDS", "generator", "xn back", "RK4"]
-seq = [0, 16, 17, 18, 19, 20, 1]
-for which, idx in (("first", 0), ("third", 2)):
-    rr = []
-    for sid in ids[cnt == 3]:
-        m = np.where(simd == sid)[0]
-        m = m[np.argsort(st[m, 0])]
-        rr.append([st[m[idx], seq[k + 1]] - st[m[idx], seq[k]] for k in range(6)])
-    rr = np.median(np.array(rr), axis=0)
-    print("   phase one of the %s wave: %s" % (which, ", ".join("%s %d" % (names1[k], rr[k]) for k in range(6))))
-# which workgroups share a SIMD (the dispatcher's order): block indices of the three waves of a few SIMDs, in start order
-show = []
-for sid in ids[cnt == 3][:12]:
-    m = np.where(simd == sid)[0]
-    m = m[np.argsort(st[m, 0])]
-    show.append(tuple(int(x) for x in m))
-print("blocks of a SIMD in start order:", show)
-second = []
-for sid in ids[cnt == 3]:
-    m = np.where(simd == sid)[0]
-    m = m[np.argsort(st[m, 0])]
-    second.append((m[0], m[1], m[2]))
-second = np.array(second)
-print("first-wave block index: min %d max %d; second: min %d max %d; third: min %d max %d" % (second[:, 0].min(), second[:, 0].max(), second[:, 1].min(), second[:, 1].max(), second[:, 2].min(), second[:, 2].max()))
-print("second - first: %s" % dict(zip(*np.unique(second[:, 1] - second[:, 0], return_counts=True))))
-print("wave slot (HW_ID[3:0]) of first / second / third: %s" % [dict(zip(*np.unique(hw[second[:, k]] & 0xf, return_counts=True))) for k in range(3)])
-# absolute time line of the three waves of a SIMD (medians over the SIMDs with three waves; ticks from the SIMD's first start)
+# The batches of a SIMD in start order (its waves share one counter whatever the clock domains are).  The launch is persistent:
+# a wave's second batch carries 1 in column 15 and starts at the end of its first.
+cont = buf[:, 15].astype(np.int64)
 order_s = [0, 16, 17, 18, 19, 20, 1, 2, 3, 4, 5, 6, 7, 8, 12]
-lab = ["start", "scalars", "operands", "gather issued", "generator", "xn back", "RK4", "coupling", "Chol/V/R~", "Al x", "up panel", "ll block", "lo panel", "lr block", "end"]
+lab = ["start", "scalars", "operands", "planes req.", "generator", "xn back", "RK4", "coupling", "Chol/V/R~", "Al x", "up panel", "ll block", "lo panel", "lr block", "end"]
 tl = []
+kinds = []
 for sid in ids[cnt == 3]:
     m = np.where(simd == sid)[0]
     m = m[np.argsort(st[m, 0])]
     z = st[m[0], 0]
     tl.append([[st[m[k], q] - z for q in order_s] for k in range(3)])
+    kinds.append(tuple(int(cont[m[k]]) for k in range(3)))
 tl = np.median(np.array(tl), axis=0)
+print("continuation flags of the three batches (start order): %s" % dict(zip(*np.unique(np.array(kinds), axis=0, return_counts=True))) if False else "kinds: %s" % {k: kinds.count(k) for k in set(kinds)})
 print("%-14s %8s %8s %8s" % ("stamp", "first", "second", "third"))
 for q in range(len(order_s)):
     print("%-14s %8d %8d %8d" % (lab[q], tl[0, q], tl[1, q], tl[2, q]))
