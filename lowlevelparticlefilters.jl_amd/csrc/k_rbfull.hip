@@ -59,9 +59,9 @@ template <class Model, int NN, int NL, int NY>
 static hipError_t launch_rbfull_t(const BankDev& b, int mode, const StepArgs& a, hipStream_t s) {
     dim3 g(rbfull_grid_x(b, NL, mode), (unsigned)b.F, 1);
     switch (mode) {
-        case MODE_WEIGHT: hipLaunchKernelGGL((k_rbfull<Model, NN, NL, NY, MODE_WEIGHT>), g, dim3(RBF_BLOCK), 0, s, b, b.models, b.scal, a); break;
-        case MODE_PROP: hipLaunchKernelGGL((k_rbfull<Model, NN, NL, NY, MODE_PROP>), g, dim3(RBF_BLOCK), 0, s, b, b.models, b.scal, a); break;
-        case MODE_PROP_WEIGHT: hipLaunchKernelGGL((k_rbfull<Model, NN, NL, NY, MODE_PROP_WEIGHT>), g, dim3(RBF_BLOCK), 0, s, b, b.models, b.scal, a); break;
+        case MODE_WEIGHT: hipLaunchKernelGGL((k_rbfull<Model, NN, NL, NY, MODE_WEIGHT>), g, dim3(RBF_BLOCK), 0, s, LLPF_RBF_HOT_ARGS(b, a), b, a); break;
+        case MODE_PROP: hipLaunchKernelGGL((k_rbfull<Model, NN, NL, NY, MODE_PROP>), g, dim3(RBF_BLOCK), 0, s, LLPF_RBF_HOT_ARGS(b, a), b, a); break;
+        case MODE_PROP_WEIGHT: hipLaunchKernelGGL((k_rbfull<Model, NN, NL, NY, MODE_PROP_WEIGHT>), g, dim3(RBF_BLOCK), 0, s, LLPF_RBF_HOT_ARGS(b, a), b, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

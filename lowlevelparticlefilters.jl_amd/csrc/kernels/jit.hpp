@@ -227,9 +227,8 @@ hipError_t launch_rbfull_jit(int fk, int nn, int nl, int ny, const BankDev& b, i
         fn = pd.fn[mode];
     }
     BankDev bd = b;
-    const ModelD* models = b.models;
-    const FilterScal* scal = b.scal;
     StepArgs aa = a;
-    void* args[] = {&bd, &models, &scal, &aa};
+    // LLPF_RBF_HOT_PARAMS (kernels/rbfull.hpp), then the two structs
+    void* args[] = {&bd.scal, &bd.bank_flag, &bd.anc, &bd.models, &aa.u, &bd.Ns, &bd.nu, &aa.u_stride, &aa.y, &bd, &aa};
     return hipModuleLaunchKernel(fn, rbfull_grid_x(b, nl, mode), (unsigned)b.F, 1, 64, 1, 1, 0, s, args, nullptr);
 }

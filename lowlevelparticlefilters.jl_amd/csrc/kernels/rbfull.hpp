@@ -33,6 +33,9 @@ DEV void rbf_model_ready(const M& m, uint32_t& dep) {
 DEV double* rbf_at(double* base, uint32_t idx) { return reinterpret_cast<double*>(reinterpret_cast<char*>(base) + (size_t)(idx * 8u)); }
 DEV uint64_t* rbf_at(uint64_t* base, uint32_t idx) { return reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(base) + (size_t)(idx * 8u)); }
 DEV const int32_t* rbf_at(const int32_t* base, uint32_t idx) { return reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(base) + (size_t)(idx * 4u)); }
+#define LLPF_RBF_HOT_PARAMS const FilterScal* hot_scal, const uint32_t* hot_flag, const int32_t* hot_anc, const ModelD* hot_models, const double* hot_u, \
+                            int64_t hot_Ns, int32_t hot_nu, int32_t hot_ustride, const double* hot_y
+#define LLPF_RBF_HOT_ARGS(b, a) (b).scal, (b).bank_flag, (b).anc, (b).models, (a).u, (b).Ns, (b).nu, (a).u_stride, (a).y
 #ifndef LLPF_RBF_WAVES
 #define LLPF_RBF_WAVES 2
 #endif
@@ -50,8 +53,13 @@ typedef __attribute__((address_space(3))) void* rbf_lds_ptr;
 typedef const __attribute__((address_space(1))) void* rbf_glb_ptr;
 #endif
 template <class Model, int NN, int NL, int NY, int MODE>
-__global__ __launch_bounds__(RBF_BLOCK) __attribute__((amdgpu_waves_per_eu(NL >= 8 ? LLPF_RBF_WAVES : 1))) void k_rbfull(BankDev b, const ModelD* __restrict__ models,
-                                                   const FilterScal* scal, StepArgs a) {
+__global__ __launch_bounds__(RBF_BLOCK) __attribute__((amdgpu_waves_per_eu(NL >= 8 ? LLPF_RBF_WAVES : 1))) void k_rbfull(LLPF_RBF_HOT_PARAMS, BankDev b, StepArgs a) {
+    // What the first loads are addressed with arrives in SGPRs with the wave (kernarg preload, -amdgpu-kernarg-preload-count=16; a struct
+    // by value as the first argument switches it off): the filter's scalars, the ancestor index (requested whether or not this step
+    // resamples), the generator's tables and the row of Bl u go out with the wave's first instructions, beside the scalar load of the rest
+    // of the argument block instead of behind it — one memory round trip in front of the gather instead of three.
+    const ModelD* __restrict__ models = hot_models;
+    const FilterScal* scal = hot_scal;
     static_assert(MODE == MODE_WEIGHT || MODE == MODE_PROP || MODE == MODE_PROP_WEIGHT, "no auxiliary form");
     constexpr int NP = LLPF_RBF_NP(NL), ROWS = NN + NL + NP;
     constexpr bool DMA = NL >= 8 && MODE != MODE_WEIGHT;       // covariance planes through LDS (the persistent form)
@@ -67,15 +75,37 @@ __global__ __launch_bounds__(RBF_BLOCK) __attribute__((amdgpu_waves_per_eu(NL >=
     { uint32_t hw_, xcc_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));
       g_rbf_dbg[(size_t)bb * 32 + 13] = hw_; g_rbf_dbg[(size_t)bb * 32 + 14] = xcc_; }
 #endif
+    // ---- with the wave's first instructions (everything here is addressed from preloaded SGPRs) ----
+    const int t = (int)threadIdx.x;
+    // 32-bit particle index and byte offsets from uniform bases: what stays in registers through the loop is one word per quantity
+    uint32_t i = bb * (uint32_t)RBF_BLOCK + (uint32_t)t;
+    const int32_t* ancf = hot_anc + (size_t)f * hot_Ns;
+    const int32_t anc_i = *rbf_at(ancf, i);          // requested whether or not the step resamples: it does not wait for do_resample
+    const double* uf = hot_u + (size_t)f * hot_ustride;       // banks on data of their own (llpf_bank_run_multi): filter f's row
+    const llpf_rbf_par* par = &md->rbf;
+    __shared__ __attribute__((aligned(16))) double sh_rng_lg[2 * LLPF_RNG_LG_ENTRIES], sh_rng_sc[2 * LLPF_RNG_SC_ENTRIES];
+    __shared__ double sh_blu[LLPF_RBF_MAXL], sh_y[LLPF_RBF_MAXY + 1], sh_w[RBF_BLOCK];      // sh_y[NY]: c0 of the measurement density
+    __shared__ __attribute__((aligned(16))) uint32_t sh_R[DMA ? NPD * 128 : 4];                // plane d: 64 low words, 64 high words
+    static_assert(RBF_BLOCK >= LLPF_RNG_SC_ENTRIES && RBF_BLOCK >= LLPF_RNG_LG_ENTRIES, "one table entry per lane");
+    double rt0 = 0.0, rt1 = 0.0, rt2 = 0.0, rt3 = 0.0, blv[8], uv[8], yv = 0.0, wN = 0.0;
+    const int nu = hot_nu;
+    if (MODE != MODE_WEIGHT) {
+        rt0 = LLPF_SIN64[t]; rt1 = LLPF_COS64[t];
+        if (t < LLPF_RNG_LG_ENTRIES) { rt2 = LLPF_LOG_INVC[t]; rt3 = LLPF_LOG_LNC[t]; }
+        if (nu > 0 && t < NL) {      // lane r: row r of Bl (stride nu) and u; entries beyond nu are read (inside the arrays) and not used
+#pragma unroll
+            for (int c = 0; c < 8; ++c) { const int cc = c < nu ? c : 0; blv[c] = par->Bl[t * nu + cc]; uv[c] = uf[cc]; }
+        }
+    }
     // everything the prologue reads is REQUESTED first and tested afterwards (as in k_step): tested one by one, the stop flag, the
     // fallback flag and the scalars were eight scalar-cache round trips in a row in front of the gather
-    const uint32_t stop_flag = *b.bank_flag;
+    const uint32_t stop_flag = *hot_flag;
     const int fb_flag = sc->fallback;
     const int do_res = (MODE != MODE_WEIGHT) ? sc->do_resample : 0;
     const int uniform = sc->uniform, pend = sc->norm_pending;
     const double m = sc->m, l = sc->l, wconst = sc->wconst, wmax_prev = sc->wmax;
     const uint32_t k0 = sc->k0, k1 = sc->k1, sb = sc->step_base;
-    const int64_t Ns = b.Ns, N = b.N;
+    const int64_t Ns = hot_Ns, N = b.N;
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("" : : "s"(stop_flag), "s"(fb_flag), "s"(do_res), "s"(uniform), "s"(pend), "s"(m), "s"(l), "s"(wconst), "s"(wmax_prev), "s"(k0), "s"(k1),
                  "s"(sb), "s"(Ns), "s"(N), "s"(a.k), "s"(a.only_fallback), "s"(a.has_y), "s"(a.step));
@@ -87,8 +117,7 @@ __global__ __launch_bounds__(RBF_BLOCK) __attribute__((amdgpu_waves_per_eu(NL >=
     const double* __restrict__ xc = b.xcur + (size_t)f * ROWS * Ns;
     double* __restrict__ xo = (MODE == MODE_WEIGHT) ? const_cast<double*>(xc) : b.xnext + (size_t)f * ROWS * Ns;
     double* w = b.w + (size_t)f * Ns;
-    const int32_t* ancf = b.anc + (size_t)f * Ns;
-    const llpf_rbf_par* par = &md->rbf;
+    uint64_t* qnf = b.quanta_next + (size_t)f * Ns;
     const uint32_t nbatch = (uint32_t)(Ns / RBF_BLOCK), gstep = gridDim.x;
     const bool need_w = MODE != MODE_PROP && !do_res && !uniform;
 
@@ -96,28 +125,7 @@ __global__ __launch_bounds__(RBF_BLOCK) __attribute__((amdgpu_waves_per_eu(NL >=
     // with all of it: the ancestor index goes first, then every particle-independent operand (generator tables, the row of Bl and u
     // of lane r < NL, y, the model's constants), then the planes; the Gaussian's operands come through scalar loads (a counter of
     // their own).  Behind the planes' issue: the generator (it needs nothing of them), then the dynamics (xn), then the recursion (R).
-    const int t = (int)threadIdx.x;
-    // 32-bit particle index and byte offsets from uniform bases: what stays in registers through the loop is one word per quantity
-    uint32_t i = bb * (uint32_t)RBF_BLOCK + (uint32_t)t;
-    uint64_t* qnf = b.quanta_next + (size_t)f * Ns;
-    int32_t anc_i = 0;
-    if (do_res) anc_i = *rbf_at(ancf, i);
-    const double* uf = a.u + (size_t)f * a.u_stride;       // banks on data of their own (llpf_bank_run_multi): filter f's row
-    __shared__ __attribute__((aligned(16))) double sh_rng_lg[2 * LLPF_RNG_LG_ENTRIES], sh_rng_sc[2 * LLPF_RNG_SC_ENTRIES];
-    __shared__ double sh_blu[LLPF_RBF_MAXL], sh_y[LLPF_RBF_MAXY + 1], sh_w[RBF_BLOCK];      // sh_y[NY]: c0 of the measurement density
-    __shared__ __attribute__((aligned(16))) uint32_t sh_R[DMA ? NPD * 128 : 4];                // plane d: 64 low words, 64 high words
-    static_assert(RBF_BLOCK >= LLPF_RNG_SC_ENTRIES && RBF_BLOCK >= LLPF_RNG_LG_ENTRIES, "one table entry per lane");
-    double rt0 = 0.0, rt1 = 0.0, rt2 = 0.0, rt3 = 0.0, blv[8], uv[8], yv = 0.0, wN = 0.0;
-    const int nu = b.nu;
-    if (MODE != MODE_WEIGHT) {
-        rt0 = LLPF_SIN64[t]; rt1 = LLPF_COS64[t];
-        if (t < LLPF_RNG_LG_ENTRIES) { rt2 = LLPF_LOG_INVC[t]; rt3 = LLPF_LOG_LNC[t]; }
-        if (nu > 0 && t < NL) {      // lane r: row r of Bl (stride nu) and u; entries beyond nu are read (inside the arrays) and not used
-#pragma unroll
-            for (int c = 0; c < 8; ++c) { const int cc = c < nu ? c : 0; blv[c] = par->Bl[t * nu + cc]; uv[c] = uf[cc]; }
-        }
-    }
-    if (MODE != MODE_PROP && a.has_y && t <= NY) yv = t < NY ? a.y[(size_t)f * a.y_stride + t] : md->dg.c0;
+    if (MODE != MODE_PROP && a.has_y && t <= NY) yv = t < NY ? hot_y[(size_t)f * a.y_stride + t] : md->dg.c0;
     if (need_w) wN = *rbf_at(w, i);
     RBF_TSTAMP(16, t);                 // prologue scalars back, ancestor and operands requested
     // 32-bit byte offsets from ONE uniform base per buffer (48 planes: 64-bit addresses would hold 96 registers and cost two
@@ -176,7 +184,7 @@ __global__ __launch_bounds__(RBF_BLOCK) __attribute__((amdgpu_waves_per_eu(NL >=
     // The model's constants through scalar loads (their own counter: no place in the queue of the planes), where they are used: held
     // across the loop they would sit in registers through the recursion.  The pointers pass an empty asm tied to a value of the batch
     // in hand, so the loads can be neither hoisted out of the loop nor issued before that value exists.
-    auto prepared = [&](double dep) {
+    auto prepared = [&](auto dep) {
         Model mdl;
 #if defined(__HIP_DEVICE_COMPILE__)
         const __attribute__((address_space(4))) ModelD* mk = (const __attribute__((address_space(4))) ModelD*)md;
@@ -190,7 +198,9 @@ __global__ __launch_bounds__(RBF_BLOCK) __attribute__((amdgpu_waves_per_eu(NL >=
     };
     // what does not need the covariance: the noise of particle idx, then (xn back) the dynamics
     auto front = [&](uint32_t idx) {
+        Model mdl;
         if (MODE != MODE_WEIGHT) {
+            mdl = prepared(idx);       // the constants' scalar loads go out first and are back when the noise is done
             double xi[NN];
             llpf_normals_tab(idx, sb + a.step, LLPF_STREAM_DYNAMICS, k0, k1, NN, xi, sh_rng_lg, sh_rng_sc);
             gauss_sample_c<NN>((gauss_cptr)&md->df, xi, nz);
@@ -198,7 +208,6 @@ __global__ __launch_bounds__(RBF_BLOCK) __attribute__((amdgpu_waves_per_eu(NL >=
         }
         RBF_TSTAMP(20, xn[NN - 1]);            // xn back
         if (MODE != MODE_WEIGHT) {
-            const Model mdl = prepared(nz[0]);
             mdl.dynamics(xn, fi);
 #if defined(LLPF_RBF_TIMING) && defined(__HIP_DEVICE_COMPILE__)
             asm volatile("" : : "v"(fi[NN - 1]), "v"(nz[NN - 1]));      // RK4 and the generator are done before stamp 1
@@ -238,7 +247,7 @@ __global__ __launch_bounds__(RBF_BLOCK) __attribute__((amdgpu_waves_per_eu(NL >=
 #endif
         if (MODE != MODE_WEIGHT) {
             double xn1[NN], xl1[NL], R1[NP];
-            llpf_rbf_predict(par, NN, NL, b.nu, xn, xl, R, uf, sh_blu, fi, nz, xn1, xl1, R1);
+            llpf_rbf_predict(par, NN, NL, nu, xn, xl, R, uf, sh_blu, fi, nz, xn1, xl1, R1);
 #pragma unroll
             for (int d = 0; d < NN; ++d) xn[d] = xn1[d];
 #pragma unroll
