@@ -68,7 +68,7 @@ struct PropCtx {
         if constexpr (LTAB) llpf_normals_tab(o, pstep, LLPF_STREAM_DYNAMICS, k0, k1, NX, xi, rng_lg, rng_sc);
         else llpf_normals(o, pstep, LLPF_STREAM_DYNAMICS, k0, k1, NX, xi);
 #endif
-        gauss_sample<NX>(md->df, xi, nz);
+        gauss_sample_c<NX>((gauss_cptr)&md->df, xi, nz);
 #pragma unroll
         for (int d = 0; d < NX; ++d) {
             xs[d] = fx[d] + nz[d];
@@ -85,7 +85,7 @@ struct PropCtx {
                 model.measurement(xs, g);
 #pragma unroll
                 for (int k = 0; k < NY; ++k) v[k] = y[k] - g[k];
-                wv = wv + gauss_logpdf<NY>(md->dg, v);
+                wv = wv + gauss_logpdf_c<NY>((gauss_cptr)&md->dg, v);
             }
             if (o >= (uint32_t)b.N) wv = -LLPF_INF;
             bad = bad || (wv != wv);
