@@ -36,6 +36,9 @@ DEV const int32_t* rbf_at(const int32_t* base, uint32_t idx) { return reinterpre
 #define LLPF_RBF_HOT_PARAMS const FilterScal* hot_scal, const uint32_t* hot_flag, const int32_t* hot_anc, const ModelD* hot_models, const double* hot_u, \
                             int64_t hot_Ns, int32_t hot_nu, int32_t hot_ustride, const double* hot_y
 #define LLPF_RBF_HOT_ARGS(b, a) (b).scal, (b).bank_flag, (b).anc, (b).models, (a).u, (b).Ns, (b).nu, (a).u_stride, (a).y
+#ifndef LLPF_RBF_DMA_AUX
+#define LLPF_RBF_DMA_AUX 2      /* cache policy of the global -> LDS loads: nontemporal, like the register planes (same box: +2 %) */
+#endif
 #ifndef LLPF_RBF_WAVES
 #define LLPF_RBF_WAVES 2
 #endif
@@ -133,7 +136,8 @@ __global__ __launch_bounds__(RBF_BLOCK) __attribute__((amdgpu_waves_per_eu(NL >=
     const uint32_t stride = (uint32_t)Ns * 8u;
     uint32_t so = (do_res ? (uint32_t)anc_i : i) * 8u;
     RBF_TSTAMP(17, so);                // ancestor and operands back
-    auto ld = [&](int row, uint32_t off) { return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(xc) + (off + (uint32_t)row * stride)); };
+    // nontemporal: every plane is read once per launch (same box: 50.0 -> 47.3 us; only on the steps that do not resample: no better)
+    auto ld = [&](int row, uint32_t off) { return __builtin_nontemporal_load(reinterpret_cast<const double*>(reinterpret_cast<const char*>(xc) + (off + (uint32_t)row * stride))); };
     // the planes of one batch: xn, xl and the last NDIR planes of R into registers, the first NPD planes of R into LDS
     double xn[NN], xl[NL], RN[NDIR], fi[NN], nz[NN];
     auto request_regs = [&](uint32_t off) {
@@ -151,8 +155,8 @@ __global__ __launch_bounds__(RBF_BLOCK) __attribute__((amdgpu_waves_per_eu(NL >=
 #pragma unroll
             for (int d = 0; d < NPD; ++d) {      // the instruction's offset moves the global AND the LDS address: the high word's LDS base is taken 4 back
                 const uint32_t o = off + (uint32_t)(NN + NL + d) * stride;
-                __builtin_amdgcn_global_load_lds((rbf_glb_ptr)(base + o), (rbf_lds_ptr)(sh_R + d * 128), 4, 0, 0);
-                __builtin_amdgcn_global_load_lds((rbf_glb_ptr)(base + o), (rbf_lds_ptr)(sh_R + d * 128 + 63), 4, 4, 0);
+                __builtin_amdgcn_global_load_lds((rbf_glb_ptr)(base + o), (rbf_lds_ptr)(sh_R + d * 128), 4, 0, LLPF_RBF_DMA_AUX);
+                __builtin_amdgcn_global_load_lds((rbf_glb_ptr)(base + o), (rbf_lds_ptr)(sh_R + d * 128 + 63), 4, 4, LLPF_RBF_DMA_AUX);
             }
         }
 #endif
@@ -224,7 +228,9 @@ __global__ __launch_bounds__(RBF_BLOCK) __attribute__((amdgpu_waves_per_eu(NL >=
         const bool has_next = DMA && bb + gstep < nbatch;          // uniform
         const uint32_t i_n = i + gstep * (uint32_t)RBF_BLOCK;
         const uint32_t io = i * 8u;
-        auto st = [&](int row, double v) { *reinterpret_cast<double*>(reinterpret_cast<char*>(xo) + (io + (uint32_t)row * stride)) = v; };
+                // written through (global_store ... sc1, kernels/reduce.hpp): the planes are the next launch's input; left dirty in the L2s they are
+        // written back at the kernel boundary, and the persistent wave's next batch queues behind them (same box: 51.4 -> 50.0 us)
+        auto st = [&](int row, double v) { wt_store(reinterpret_cast<double*>(reinterpret_cast<char*>(xo) + (io + (uint32_t)row * stride)), v); };
         // the next batch's ancestor: requested here, wanted after the time update
         int32_t anc_n = 0;
         if (has_next && do_res) anc_n = *rbf_at(ancf, i_n);

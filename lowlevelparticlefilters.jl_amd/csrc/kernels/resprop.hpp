@@ -44,7 +44,7 @@ struct PropCtx {
         const uint32_t so = src << 3, oo = o << 3;
         double xp[NX], fx[NX], xi[NX], nz[NX];
 #pragma unroll
-        for (int d = 0; d < NX; ++d) xp[d] = Mem<COH>::ld_off(xc + (size_t)d * Ns, so);
+        for (int d = 0; d < NX; ++d) xp[d] = Mem<COH>::ld_off(xc + (size_t)d * Ns, so);      // (nontemporal: C2 22.8 against 20.7 us — duplicated ancestors are re-read from the L2)
         if constexpr (Model::RB) {     // Rao-Blackwellized model: own noise structure, and correct! updates xl before the store
             model.rb_propagate(xp, o, pstep, k0, k1, st.rb_pred + blockIdx.y, xs);
             double wr = wprev;
