@@ -49,4 +49,5 @@ python tools/rocprof_pmc_summary.py $OUT/pmc_traffic_c5.txt $(find $OUT/pmc_fetc
 for w in quadtank bank; do python tools/rocprof_pmc_summary.py $OUT/pmc_traffic_$w.txt $(find $OUT/pmc_FETCH_SIZE_$w -name "*.db" | head -1) $(find $OUT/pmc_WRITE_SIZE_$w -name "*.db" | head -1); rm -rf $OUT/pmc_FETCH_SIZE_$w $OUT/pmc_WRITE_SIZE_$w; done
 python tools/make_pmc_json.py $OUT $OUT/pmc_traffic.json $TAG
 rm -rf $OUT/kt_rbpf_full $OUT/pmc_fetch_c5 $OUT/pmc_write_c5 $OUT/kt $OUT/kt_bank $OUT/kt_qt $OUT/kt_aux $OUT/kt_rbpf $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/*.log
+bash tools/dbg/pmc_sq_other.sh $TAG > /dev/null 2>&1      # SQ counters of the C3 / C5 kernels: pmc_sq_quadtank.txt, pmc_sq_rbpf_full.txt
 ls -la $OUT
