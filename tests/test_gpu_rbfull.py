@@ -131,12 +131,13 @@ def test_rbfull_api_and_errors():
         _capi.FilterHandle(_cfg(bad, 1000))
 
 
-@pytest.mark.parametrize("name,N,T", [("lin_2_2_2", 3000, 30), ("quadtank_4_8_2", 20000, 12)])
+@pytest.mark.parametrize("name,N,T", [("lin_2_2_2", 3000, 30), ("quadtank_4_8_2", 20000, 12), ("quadtank_4_8_2", 60000, 5)])
 def test_bank_of_rb_filters(name, N, T):
     """A parameter sweep over Rao-Blackwellized filters — BASELINE config C4's pattern applied to C5's model (reference:
     `map(svec) do s ... loglik(pfs, u, y) end`, test/runtests.jl:412-417, over the filters of test/test_rbpf.jl:111-166): a bank of 8
     filters with different measurement-noise levels returns, filter by filter, the bits of 8 single filters (key seed + k) and of the
-    device-order oracle, in both schedules (exp-sums inside k_rbfull / by k_norm), also sharded over two folded devices."""
+    device-order oracle, in both schedules (exp-sums inside k_rbfull / by k_norm), also sharded over two folded devices.  The
+    persistent waves of the 8x8 kernel are shared among the bank's filters: at N = 6e4 every wave takes three or four batches."""
     import os
     base = CASES[name]()
     U, Y = M.simulate_io(base, T)
