@@ -89,3 +89,11 @@ print("continuation flags of the three batches (start order): %s" % dict(zip(*np
 print("%-14s %8s %8s %8s" % ("stamp", "first", "second", "third"))
 for q in range(len(order_s)):
     print("%-14s %8d %8d %8d" % (lab[q], tl[0, q], tl[1, q], tl[2, q]))
+# when does a SIMD finish, by the number of batches it ran (N = 2e5 is 3125 batches on 1024 SIMDs: 53 of them run four)
+fin = {}
+for sid in ids:
+    m = np.where(simd == sid)[0]
+    fin.setdefault(len(m), []).append(int(st[m, 12].max() - st[m, 0].min()))
+for n in sorted(fin):
+    v = np.array(fin[n])
+    print("SIMDs with %d batches: %d; first start -> last end: median %d  p90 %d  max %d ticks" % (n, len(v), np.median(v), np.percentile(v, 90), v.max()))
