@@ -100,6 +100,27 @@ def test_rbfull_large_and_repeated_runs(N, T, thr):
         ob.set_threads(1)
 
 
+@pytest.mark.parametrize("N,thr", [(65, 0.5), (1000, 0.9), (131071, 0.3), (131073, 0.9), (150001, 0.1), (131072 + 64, 1.0)])
+def test_rbfull_awkward_sizes(N, thr):
+    """The persistent kernel at sizes that are not its grain: below one 64-particle batch, not a multiple of 64 or of the 1024-particle
+    tile, one particle below / above the 131072 the resident waves take in their first pass, a single batch beyond them; resampling at
+    every step, sometimes, rarely.  Log-likelihood per step, particles, linear means and covariances bit-identical to the device-order oracle."""
+    model = M.quadtank_case()
+    T = 4
+    U, Y = M.simulate_io(model, T, seed=N % 97)
+    cfg = _cfg(model, N, S.RESAMPLE_SYSTEMATIC, thr, seed=7 + N)
+    g = _capi.FilterHandle(cfg); o = ob.OracleFilter(cfg, ob.ORDER_DEVICE)
+    ob.set_threads(8)
+    try:
+        g.reset(); o.reset()
+        rg = g.run(U, Y, 0.0, ll_steps=True); ro = o.run(U, Y, 0.0, ll_steps=True)
+        assert _same_bits(rg["ll_steps"], ro["ll_steps"])
+        assert g.resample_count() == o.resample_count()
+        _compare_linear_state(g, o)
+    finally:
+        ob.set_threads(1)
+
+
 def test_rbfull_api_and_errors():
     """RBPF(...; An = StateAffineCoupling(...)) through the reference-shaped API; unsupported combinations fail loudly."""
     model, mats = M.linear_case(2, 2, 2, seed=1)
