@@ -1,6 +1,11 @@
 // k_resprop.hip — k_resprop (the fused timestep) and, in DEVTOOLS builds, the persistent multi-step form
 // One of the engine's device translation units (kernels.hip has the map); split so that they build in parallel.
 
+// the Horner constants of the shared math stay in VGPRs here: as SGPR pairs (the other translation units) the fused single-filter kernel
+// spills 112 SGPRs to VGPR lanes and loses 6 % (C2 22.0 against 20.8 us)
+#ifndef LLPF_HORNER_C
+#define LLPF_HORNER_C(c) "v"(c)
+#endif
 #include "engine.hpp"
 
 namespace llpf {
@@ -12,10 +17,24 @@ namespace llpf {
 #include "kernels/accum.hpp"
 #include "kernels/resample.hpp"
 #include "kernels/resprop.hpp"
-#ifdef LLPF_DEVTOOLS
+#if defined(LLPF_DEVTOOLS) && !defined(LLPF_RESPROP_SPLIT_TU)
 #include "kernels/persist.hpp"      // experiment kept for reference: measured slower than the graph of per-timestep launches
 #endif
 
+#ifdef LLPF_RESPROP_SPLIT_TU
+// This translation unit compiled a second time (k_resprop_split.hip): the split-schedule forms of the fused kernel — weights written, exp-sums
+// left to k_norm (banks beyond 3 M particles), or no weighting at all — with the Horner constants as SGPR pairs (bank -4 %; the merged
+// single-filter form loses 6 % with them and stays in the first unit)
+template <class Model, int NX, int NY>
+static hipError_t launch_resprop_t(const BankDev& b, const ResArgs& a, const StepArgs& st, int weight, hipStream_t s) {
+    dim3 g((unsigned)b.P2, (unsigned)b.F, 1);
+    if (st.aux) return hipErrorInvalidValue;
+    if (weight) hipLaunchKernelGGL((k_resprop<Model, NX, NY, true, false>), g, dim3(BLOCK), 0, s, LLPF_HOT_ARGS(b, a), b, b.models, a, st);
+    else hipLaunchKernelGGL((k_resprop<Model, NX, NY, false, false>), g, dim3(BLOCK), 0, s, LLPF_HOT_ARGS(b, a), b, b.models, a, st);
+    return hipGetLastError();
+}
+#else
+hipError_t launch_resprop_split(const BankDev& b, const ResArgs& a, const StepArgs& st, int weight, hipStream_t s);
 template <class Model, int NX, int NY>
 static hipError_t launch_resprop_t(const BankDev& b, const ResArgs& a, const StepArgs& st, int weight, hipStream_t s) {
     dim3 g((unsigned)b.P2, (unsigned)b.F, 1);
@@ -24,10 +43,10 @@ static hipError_t launch_resprop_t(const BankDev& b, const ResArgs& a, const Ste
     else if (st.aux) hipLaunchKernelGGL((k_resprop<NoModel<NX>, NX, 1, true, true, true>), g, dim3(BLOCK), 0, s, LLPF_HOT_ARGS(b, a), b, b.models, a, st);
     else if (weight && st.accumulate && one) hipLaunchKernelGGL((k_resprop<Model, NX, NY, true, true, false, true>), g, dim3(BLOCK), 0, s, LLPF_HOT_ARGS(b, a), b, b.models, a, st);
     else if (weight && st.accumulate) hipLaunchKernelGGL((k_resprop<Model, NX, NY, true, true>), g, dim3(BLOCK), 0, s, LLPF_HOT_ARGS(b, a), b, b.models, a, st);
-    else if (weight) hipLaunchKernelGGL((k_resprop<Model, NX, NY, true, false>), g, dim3(BLOCK), 0, s, LLPF_HOT_ARGS(b, a), b, b.models, a, st);
-    else hipLaunchKernelGGL((k_resprop<Model, NX, NY, false, false>), g, dim3(BLOCK), 0, s, LLPF_HOT_ARGS(b, a), b, b.models, a, st);
+    else return launch_resprop_split(b, a, st, weight, s);      // the split-schedule forms live in k_resprop_split.hip
     return hipGetLastError();
 }
+#endif
 template <int NX>
 static hipError_t launch_resprop_lg_ny(const BankDev& b, const ResArgs& a, const StepArgs& st, int weight, hipStream_t s) {
     if (st.aux) return launch_resprop_t<LinGauss<NX, 1>, NX, 1>(b, a, st, weight, s);     // the auxiliary second half does not see the measurement
@@ -52,16 +71,24 @@ static hipError_t launch_resprop_rb_ny(const BankDev& b, const ResArgs& a, const
 // state dimensions 5..8 (models compiled on demand): only the auxiliary filter's second half comes here, which propagates nothing
 template <int NX>
 static hipError_t launch_resprop_aux_only(const BankDev& b, const ResArgs& a, const StepArgs& st, hipStream_t s) {
+#ifdef LLPF_RESPROP_SPLIT_TU
+    return hipErrorInvalidValue;
+#else
     if (!st.aux) return hipErrorInvalidValue;
     dim3 g((unsigned)b.P2, (unsigned)b.F, 1);
     if (b.P2 == 1) hipLaunchKernelGGL((k_resprop<NoModel<NX>, NX, 1, true, true, true, true>), g, dim3(BLOCK), 0, s, LLPF_HOT_ARGS(b, a), b, b.models, a, st);
     else hipLaunchKernelGGL((k_resprop<NoModel<NX>, NX, 1, true, true, true>), g, dim3(BLOCK), 0, s, LLPF_HOT_ARGS(b, a), b, b.models, a, st);
     return hipGetLastError();
+#endif
 }
+#ifdef LLPF_RESPROP_SPLIT_TU
+hipError_t launch_resprop_split(const BankDev& b, const ResArgs& a, const StepArgs& st, int weight, hipStream_t s) {
+#else
 hipError_t launch_resprop(const BankDev& b, const ResArgs& a0, const StepArgs& st, int weight, hipStream_t s) {
     ResArgs a = a0;
     a.K = llpf_qbits(b.N);
     a.mode = RES_FINALIZE | RES_RESAMPLE;
+#endif
     // a run-time compiled model has no fused kernel: only the auxiliary second half (which propagates nothing: NoModel) may come here
     if (b.model_id >= LLPF_MODEL_USER_BASE && !st.aux) return hipErrorInvalidValue;
     if (b.model_id == LLPF_MODEL_QUADTANK_RK4) return launch_resprop_t<QuadTank<4, 2>, 4, 2>(b, a, st, weight, s);
@@ -86,6 +113,7 @@ hipError_t launch_resprop(const BankDev& b, const ResArgs& a0, const StepArgs& s
     }
 }
 
+#ifndef LLPF_RESPROP_SPLIT_TU      // the persistent form and its stubs belong to the first unit only
 #ifdef LLPF_DEVTOOLS
 // ---- persistent multi-step launch (kernels/persist.hpp): linear-Gaussian single filters whose tiles are all co-resident ----
 template <class Model, int NX, int NY>
@@ -139,6 +167,7 @@ int persist_bar_words() { return BAR_WORDS + 2 * GQ_WORDS64; }
 hipError_t launch_persist(const BankDev&, const PersistArgsHost&, hipStream_t) { return hipErrorNotSupported; }
 hipError_t persist_capacity(const BankDev&, int* blocks) { *blocks = 0; return hipSuccess; }
 int persist_bar_words() { return 64; }
+#endif
 #endif
 
 

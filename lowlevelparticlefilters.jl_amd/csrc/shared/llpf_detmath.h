@@ -34,10 +34,13 @@ LLPF_HD double   llpf_u2d(uint64_t u) { double x; __builtin_memcpy(&x, &u, 8); r
 LLPF_HD double   llpf_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 /* one Horner step q*r + c with a constant c.  Same fused operation as llpf_fma; on the device it is pinned to the
  * three-address v_fma_f64 (the compiler otherwise copies the constant into the destination for a two-address v_fmac) */
+#ifndef LLPF_HORNER_C
+#define LLPF_HORNER_C(c) "s"(c)      /* the constant as an SGPR pair: built by the scalar unit, no VGPR moves */
+#endif
 LLPF_HD double   llpf_horner(double q, double r, double c) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(LLPF_NO_ASM_HORNER)
     double d;
-    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(q), "v"(r), "v"(c));
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(q), "v"(r), LLPF_HORNER_C(c));
     return d;
 #else
     return __builtin_fma(q, r, c);
