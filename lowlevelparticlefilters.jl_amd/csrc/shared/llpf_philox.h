@@ -60,13 +60,16 @@ LLPF_HD double llpf_u01_half(uint32_t lo, uint32_t hi) {
     return (double)(a >> 11) * 1.1102230246251565e-16;
 }
 
+/* sqrt of the Box-Muller radius' argument a = -2 log u, u in (0, 1]: a is 0 (u == 1) or in [2.2e-16, 1.5e3] — the core of the
+ * correctly rounded square root without the expansion's scaling of tiny arguments and its 0 / inf / NaN cases: the same bits as llpf_sqrt */
+LLPF_HD double llpf_sqrt_rad(double a) { return a == 0.0 ? a : llpf_sqrt_pos(a); }     /* sqrt(-0.0) == -0.0 */
 /* one Philox block -> two independent N(0,1) draws (Box–Muller on deterministic log/sqrt/sincos) */
 LLPF_HD void llpf_normal_pair(uint32_t idx, uint32_t step, uint32_t sub, uint32_t stream,
                               uint32_t k0, uint32_t k1, double* z0, double* z1) {
     llpf_philox4 r = llpf_philox4x32_10(idx, step, sub, stream, k0, k1);
     double u1 = llpf_u01_open(r.v[0], r.v[1]);
     double u2 = llpf_u01_half(r.v[2], r.v[3]);
-    double rad = llpf_sqrt(-2.0 * llpf_log_unit(u1));
+    double rad = llpf_sqrt_rad(-2.0 * llpf_log_unit(u1));
     double sn, cs;
     llpf_sincos2pi_fast(u2, &sn, &cs);
     *z0 = rad * cs;
@@ -83,7 +86,7 @@ LLPF_HD void llpf_normal_pair_tab(uint32_t idx, uint32_t step, uint32_t sub, uin
     double m, dk, f;
     const int i = llpf_log_unit_split(u1, &m, &dk);
     const int j = llpf_sincos2pi_split(u2, &f);
-    double rad = llpf_sqrt(-2.0 * llpf_log_unit_eval(m, dk, lg[2 * i], lg[2 * i + 1]));
+    double rad = llpf_sqrt_rad(-2.0 * llpf_log_unit_eval(m, dk, lg[2 * i], lg[2 * i + 1]));
     double sn, cs;
     llpf_sincos2pi_eval(f, sc[2 * j], sc[2 * j + 1], &sn, &cs);
     *z0 = rad * cs;
