@@ -166,7 +166,12 @@ struct BankDev {
     int32_t pad0;
     int32_t xrows;       // rows of one filter's particle plane: nx, or xn + xl + packed R for LLPF_MODEL_RB_BILINEAR (the stride between
     int32_t pad1;        //   the filters of a bank in xcur / xnext; kernels that know the model use their own constant)
+    // source-side dynamics (k_resample_fx + k_step with StepArgs::marks; kernels/resfx.hpp): allocated on first use
+    int32_t* mark;       // [F][Ns] run-start marks of a resampling: 1 + ancestor at the first output of every surviving source and at
+                         //         every k_step block boundary inside its output range; zero everywhere else (k_step clears what it reads)
+    double* fxs;         // [F][NX][Ns] f(x_j) of the surviving sources j, written by k_resample_fx, gathered by k_step
 };
+constexpr int32_t MARK_OWN = 0x40000000;     // flag of a mark that holds for its own output only: an output without an owner (resample.jl:27-35 writes nothing: j keeps its previous value)
 
 // MODE_AUX: first half of the AuxiliaryParticleFilter predict! (reference src/filtering.jl:195-205): noise-free
 // propagate of every particle (no ancestors), lambda = logpdf(y1 - g(x)), w <- w_norm + lambda, exp-sums of the new w
@@ -194,6 +199,8 @@ struct StepArgs {
     const RBStep* rb_pred; // LLPF_MODEL_RB_LINEAR: [F] parameters of the propagate (predict!) of this launch
     int32_t u_stride;      // doubles between the u / y of consecutive filters of a bank; 0: all filters share one u / y
     int32_t y_stride;
+    int32_t marks;         // 1: the resampling of this predict! was done by k_resample_fx: ancestors come as run-start marks (BankDev::mark),
+    int32_t pad_m;         //    f(x[ancestor]) from BankDev::fxs; k_step expands the marks and writes the ancestors itself
 };
 
 // FFBS smoother (reference src/smoothing.jl:116-143): one backward step t for all M trajectories
@@ -261,6 +268,10 @@ hipError_t launch_replicate_models(ModelD* models, int F, hipStream_t s);   // m
 // failed bound test: zero the exp-sums of `slot` (mode 0) / clear the flags (mode 1) of the filters that asked for the exact form
 hipError_t launch_fb_clear(const BankDev& b, int slot, int mode, hipStream_t s);
 hipError_t launch_resample(const BankDev& b, const ResArgs& a, hipStream_t s);
+// resample with the dynamics evaluated on the SOURCE side, once per surviving particle (kernels/resfx.hpp): finalize + scan + counts,
+// f(x_j) -> BankDev::fxs and run-start marks -> BankDev::mark for the k_step launch that follows with StepArgs::marks = 1
+hipError_t launch_resample_fx(const BankDev& b, const ResArgs& a, const StepArgs& st, hipStream_t s);
+bool resample_fx_supported(int model_id, int nx, int ny, int strategy);
 // fused finalize + resample + propagate [+ weight]: one launch for predict!(u_k) and the weighting of correct!(u_{k+1}, y_{k+1})
 hipError_t launch_resprop(const BankDev& b, const ResArgs& a, const StepArgs& st, int weight, hipStream_t s);
 // Persistent multi-step launch (kernels/persist.hpp): timesteps [k_begin, k_end) of a single linear-Gaussian filter in one

@@ -36,6 +36,8 @@ struct Bank {
     size_t cap_rbseq = 0;
     uint64_t* d_rtile = nullptr;      // [F][2][P2] residual resampling: per-tile counts / residual sums and their prefixes
     double* d_lam = nullptr;          // [F][Ns] lambda of the AuxiliaryParticleFilter predict! (allocated on first use)
+    int32_t* d_mark = nullptr;        // [F][Ns] run-start marks / [F][nx][Ns] f(x_j): resampling with source-side dynamics (kernels/resfx.hpp),
+    double* d_fxs = nullptr;          //   allocated on first use (ensure_fx)
     bool aux_pending = false;         // w holds lambda - log N of an aux predict!; their exp-sums wait in slot (parity+2)%3
     bool we_is_lambda = false;        // expweights(pf) returns lambda until the next correct! (the reference keeps it in `we`)
     int parity = 0;                  // accumulator slot (0..2) the NEXT weighting kernel writes (engine.hpp ACC_NSLOT)
@@ -91,7 +93,7 @@ struct Bank {
         b.models = d_models; b.scal = d_scal;
         b.xcur = d_x[cur]; b.xnext = d_x[cur ^ 1];
         b.w = d_w; b.anc = d_anc; b.acc = d_acc; b.quanta = d_quanta[qcur]; b.quanta_next = d_quanta[qcur ^ 1]; b.tileq = d_tileq;
-        b.bank_flag = d_flag; b.xmpart = d_xmpart; b.lam = d_lam; b.rtile = d_rtile;
+        b.bank_flag = d_flag; b.xmpart = d_xmpart; b.lam = d_lam; b.rtile = d_rtile; b.mark = d_mark; b.fxs = d_fxs;
         b.anc_slot = (int32_t)(n_predict & 1u);
         b.pad0 = (cfg.model.model_id == LLPF_MODEL_RB_BILINEAR) ? (cfg.model.rb.nxl | (cfg.model.rb.fn_kind << 8)) : 0;
         b.xrows = xrows; b.pad1 = 0;
@@ -118,7 +120,7 @@ static void free_bank(Bank& b) {
     for (auto& g : b.graphs) if (g.exec) hipGraphExecDestroy(g.exec);
     b.graphs.clear();
     hipFree(b.d_pool);               // models, scal, x, w, anc, acc, quanta, tileq, flag, xmpart, rtile, rb, uy, tmp
-    hipFree(b.d_lam); hipFree(b.d_rbseq); hipFree(b.d_hist); hipFree(b.d_U); hipFree(b.d_Y);
+    hipFree(b.d_lam); hipFree(b.d_mark); hipFree(b.d_fxs); hipFree(b.d_rbseq); hipFree(b.d_hist); hipFree(b.d_U); hipFree(b.d_Y);
     hipFree(b.d_ll_steps); hipFree(b.d_xmean);
     for (auto e : b.ev_pool) hipEventDestroy(e);
     for (auto& e : b.pending) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
@@ -183,6 +185,16 @@ static void prof_collect(Bank& b) {
         b.ev_pool.push_back(e.b);
     }
     b.pending.clear();
+}
+
+// the scratch of the resampling with source-side dynamics: marks (zero between timesteps) and the plane of f(x_j)
+static int ensure_fx(Bank& b) {
+    if (b.d_mark && b.d_fxs) return LLPF_OK;
+    const size_t FN = (size_t)b.F * b.Ns;
+    if (!b.d_mark) { HIPC(hipMalloc(&b.d_mark, sizeof(int32_t) * FN)); HIPC(hipMemsetAsync(b.d_mark, 0, sizeof(int32_t) * FN, b.stream)); }
+    if (!b.d_fxs) { HIPC(hipMalloc(&b.d_fxs, sizeof(double) * FN * b.nx)); HIPC(hipMemsetAsync(b.d_fxs, 0, sizeof(double) * FN * b.nx, b.stream)); }
+    HIPC(hipStreamSynchronize(b.stream));
+    return LLPF_OK;
 }
 
 static bool is_rbfull(const Bank& b) { return b.cfg.model.model_id == LLPF_MODEL_RB_BILINEAR; }

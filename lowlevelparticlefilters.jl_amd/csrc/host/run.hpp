@@ -79,6 +79,11 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
     const bool rbfull = is_rbfull(b);     // per-particle covariance: its own step kernel, balanced form, exp-sums by k_norm
     const bool user_model = b.cfg.model.model_id >= LLPF_MODEL_USER_BASE;   // run-time compiled model: only its k_step exists
     const bool unfused = user_model || rbfull || hist || residual || (unf_env ? atoi(unf_env) != 0 : heavy_dynamics);
+    // models whose dynamics are worth a table: the resampling launch evaluates f(x_j) once per surviving source and leaves run-start marks,
+    // the step kernel gathers (kernels/resfx.hpp).  LLPF_SOURCE_FX=0 takes the round-3 form (ancestors to HBM, f per distinct ancestor of a block)
+    static const char* sfx_env = getenv("LLPF_SOURCE_FX");
+    const bool source_fx = unfused && !(sfx_env && atoi(sfx_env) == 0) && resample_fx_supported(b.cfg.model.model_id, b.nx, b.ny, b.cfg.resampling_strategy);
+    if (source_fx) CHK(ensure_fx(b));
     if (rbm) {
         // the whole gain schedule of the run (data independent): corr_0, pred_0, corr_1, pred_1, ..., [F] each
         const size_t need = (size_t)(2 * T + 1) * b.F;
@@ -187,7 +192,8 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
             {
                 ra.mode = RES_FINALIZE | RES_RESAMPLE;
                 ProfScope ps(b, LLPF_PROF_RESAMPLE);
-                HIPC(launch_resample(d, ra, b.stream));
+                if (source_fx) { st.only_fallback = only_fb; st.marks = 1; HIPC(launch_resample_fx(d, ra, st, b.stream)); }
+                else HIPC(launch_resample(d, ra, b.stream));
             }
             if (xm_launch) { ProfScope ps(b, LLPF_PROF_OTHER); CHK(bank_wmean(b, b.d_xmean + (size_t)k * b.nxp)); }
             if (hist_dev) {   // x[:,t] .= particles(pf); w[:,t] .= weights(pf); we[:,t] .= expweights(pf)  (filtering.jl:357-359)
@@ -295,7 +301,7 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
     if (use_graph) {
         Bank::RunGraph key{};
         key.T = T; key.t_index0 = t_index0; key.par0 = par0; key.cur0 = cur0; key.qcur0 = qcur0;
-        key.flags = (merged ? 1 : 0) | (unfused ? 2 : 0) | (want_xm ? 4 : 0) | (ll_steps ? 8 : 0) | (xm_launch ? 16 : 0) | (multi ? 32 : 0) | ((abl_env ? atoi(abl_env) : 0) << 8);
+        key.flags = (merged ? 1 : 0) | (unfused ? 2 : 0) | (want_xm ? 4 : 0) | (ll_steps ? 8 : 0) | (xm_launch ? 16 : 0) | (multi ? 32 : 0) | (source_fx ? 64 : 0) | ((abl_env ? atoi(abl_env) : 0) << 8);
         key.np_parity = (int)(np0 & 1u);
         key.dU = b.d_U; key.dY = b.d_Y; key.dll = ll_steps ? b.d_ll_steps : nullptr; key.dxm = xmean ? b.d_xmean : nullptr; key.drb = b.d_rbseq;
         key.yhash = 1469598103934665603ULL;

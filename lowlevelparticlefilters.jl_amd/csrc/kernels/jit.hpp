@@ -147,7 +147,7 @@ static hipError_t launch_step_user(const BankDev& b, int mode, const StepArgs& a
     const FilterScal* scal = b.scal;
     StepArgs aa = a;
     void* args[] = {&bd, &models, &scal, &aa};
-    return hipModuleLaunchKernel(fn, (unsigned)(b.Ns / (BLOCK * STEP_PPT * STEP_ITERS)), (unsigned)b.F, 1, BLOCK, 1, 1, 0, s, args, nullptr);
+    return hipModuleLaunchKernel(fn, (unsigned)(b.Ns / (BLOCK * STEP_PPT)), (unsigned)b.F, 1, BLOCK, 1, 1, 0, s, args, nullptr);
 }
 
 // ---- k_rbfull for shapes the library was not precompiled for (kernels/rbfull.hpp is part of the prelude) -----------------------------

@@ -4,19 +4,40 @@
 // ------------------------------------------------------------------------------------------------
 // PPT particles per thread (16-B vector accesses at 2; 1 halves the registers: models whose dynamics dominate, e.g. the quad-tank's
 // RK4 with 32 square roots per particle, gain more from the doubled occupancy than they lose on 8-B accesses)
-template <class Model, int NX, int NY, int MODE, int PPT = STEP_PPT>
+#if defined(LLPF_STEP_TIMING) && defined(__HIP_DEVICE_COMPILE__)   // developer build: phase stamps (tools/dbg/qt_phases.py)
+#define DBG_STAMP(arr, k, dep) do { asm volatile("" : : "v"(dep)); if (threadIdx.x == 0 && blockIdx.y == 0 && arr && dbg_on) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)); arr[(size_t)blockIdx.x * 16 + (k)] = t_; } } while (0)
+#define DBG_HWID(arr) do { if (threadIdx.x == 0 && blockIdx.y == 0 && arr && dbg_on) { uint32_t hw_, xcc_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_)); arr[(size_t)blockIdx.x * 16 + 13] = hw_; arr[(size_t)blockIdx.x * 16 + 14] = xcc_; } } while (0)
+#else
+#define DBG_STAMP(arr, k, dep) ((void)0)
+#define DBG_HWID(arr) ((void)0)
+#endif
+#define STEP_STAMP(k, dep) DBG_STAMP(g_step_dbg, k, dep)
+#define FX_STAMP(k, dep) DBG_STAMP(g_fx_dbg, k, dep)
+
+// MARKS = true: the form that follows k_resample_fx (kernels/resfx.hpp).  The resampling launch has evaluated f(x_j) for every
+// source the step needs (BankDev::fxs) and left run-start marks instead of ancestors (BankDev::mark): the kernel contains NO
+// dynamics, a block walks its 512-particle tiles grid-stride (launched with four workgroups per CU: one prologue and one set of
+// reductions per block, the next tile's marks in flight while this one is computed), and per tile it turns the marks into ancestors
+// with one inclusive max-scan, clears them, writes the ancestor array for the accessors, gathers fxs[ancestor] and adds noise and
+// weight.  The dynamics must stay out of this loop: hoisted out of it their particle-independent terms (the quad-tank's input terms
+// and stage times) stay live across it and cost a wave per SIMD.  MARKS = false: one tile per block, ancestors from HBM, f inline.
+template <class Model, int NX, int NY, int MODE, int PPT = STEP_PPT, bool MARKS = false>
 __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restrict__ models,
                                                  const FilterScal* scal, StepArgs a) {
+    static_assert(!MARKS || (share_dynamics<Model>::value && !Model::RB && PPT == STEP_PPT && (MODE == MODE_PROP || MODE == MODE_PROP_WEIGHT)),
+                  "the marks form: models whose dynamics are worth a table, propagating modes, two particles per thread");
     __shared__ double sm_max[BLOCK / 64];
     __shared__ uint64_t sm_acc[BLOCK / 64][5];
     __shared__ double sm_x[BLOCK / 64][MAXD];
     // dynamics shared between the outputs of one ancestor (below): models whose f is worth a table
-    constexpr bool SHARE = share_dynamics<Model>::value && !Model::RB && MODE != MODE_WEIGHT && MODE != MODE_AUX;
-    __shared__ int32_t sh_prev[SHARE ? BLOCK : 1], sh_run[SHARE ? BLOCK : 1], sh_wcnt[BLOCK / 64];
+    constexpr bool SHARE = !MARKS && share_dynamics<Model>::value && !Model::RB && MODE != MODE_WEIGHT && MODE != MODE_AUX;
+    __shared__ int32_t sh_prev[SHARE ? BLOCK : 1], sh_run[SHARE ? BLOCK : 1], sh_wcnt[BLOCK / 64], sh_mcnt[2][BLOCK / 64];
     __shared__ double sh_fx[SHARE ? BLOCK : 1][NX];
     const int f = blockIdx.y;
     const ModelD* md = models + f;
     const FilterScal* sc = scal + f;
+    const bool dbg_on = a.k == 5; (void)dbg_on;
+    STEP_STAMP(0, threadIdx.x); DBG_HWID(g_step_dbg);
     // Everything the prologue reads is REQUESTED first and tested afterwards: tested one by one (stop flag, fallback flag, tables,
     // scalars) each was a memory round trip of its own at the start of every block.
     const uint32_t stop_flag = *b.bank_flag;
@@ -30,6 +51,9 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
         if (t < LLPF_RNG_SC_ENTRIES) { rt0 = LLPF_SIN64[t]; rt1 = LLPF_COS64[t]; }
         else if (t < LLPF_RNG_SC_ENTRIES + LLPF_RNG_LG_ENTRIES) { rt0 = LLPF_LOG_INVC[t - LLPF_RNG_SC_ENTRIES]; rt1 = LLPF_LOG_LNC[t - LLPF_RNG_SC_ENTRIES]; }
     }
+    // the first tile's marks: their address needs nothing from memory, so they travel with the scalars (zero when nothing was resampled)
+    int2 mnext; mnext.x = 0; mnext.y = 0;
+    if constexpr (MARKS) mnext = *reinterpret_cast<const int2*>(b.mark + (size_t)f * b.Ns + (int64_t)blockIdx.x * (BLOCK * PPT) + (int64_t)threadIdx.x * PPT);
     const int do_res = (MODE == MODE_AUX2) ? 1 : ((MODE != MODE_WEIGHT && MODE != MODE_AUX) ? sc->do_resample : 0);   // AUX2: always resampled (filtering.jl:206)
     const int uniform = sc->uniform, pend = sc->norm_pending;
     const double m = sc->m, l = sc->l, wconst = sc->wconst;
@@ -53,10 +77,11 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
     double* __restrict__ xn = b.xnext + (size_t)f * NX * Ns;
     double* w = b.w + (size_t)f * Ns;
     const int32_t* __restrict__ anc = b.anc + (size_t)f * Ns;
+    STEP_STAMP(1, rt0);                 // scalars back, tables in LDS
     constexpr bool WT = (MODE != MODE_AUX) && !Model::RB;     // write-through stores where they measured faster (wt_store, reduce.hpp)
 
     Model model;
-    model.prepare(md, a.u + (size_t)f * a.u_stride, a.t_prop);
+    if constexpr (!MARKS || has_loglik<Model>::value || MODE != MODE_PROP) model.prepare(md, a.u + (size_t)f * a.u_stride, a.t_prop);
     double y[NY];
     if (MODE != MODE_PROP) {
         const double* yf = a.y + (size_t)f * a.y_stride;
@@ -69,7 +94,6 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
     // bound of the weights this kernel produces: max of the previous (normalised) weights + the density's peak
     double off = 0.0;
     WeightAcc wacc;
-    uint64_t qsum = 0;
     double xm[NX];
 #pragma unroll
     for (int d = 0; d < NX; ++d) xm[d] = 0.0;
@@ -84,15 +108,66 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
         if (MODE == MODE_AUX2) off = ((a.aux == 2) ? md->dg.c0 : 0.0) - (-b.mlogN);    // w = lambda - log N <= c0 - log N (lambda = 0 when y1 is missing)
         wacc.init();
     }
-#pragma unroll 1
-    for (int it = 0; it < STEP_ITERS; ++it) {
-        const int64_t i0 = ((int64_t)blockIdx.x * STEP_ITERS + it) * (BLOCK * PPT) + (int64_t)threadIdx.x * PPT;
+    // ---- one tile of BLOCK * PPT particles ----
+    auto tile = [&](const int tb, const int itn) {
+        int64_t i0 = (int64_t)tb * (BLOCK * PPT) + (int64_t)threadIdx.x * PPT;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (MARKS) {
+            // opaque per iteration: left visible, the index becomes a 64-bit induction pointer per plane, all live across the loop
+            uint32_t il = (uint32_t)i0;
+            asm volatile("" : "+v"(il));
+            i0 = (int64_t)il;
+        }
+#endif
+        uint64_t qsum = 0;
         double xs[PPT][NX];
         if (MODE != MODE_WEIGHT) {
             double xp[PPT][NX];
-            double fsh[PPT][NX];          // f(x[ancestor]) taken from the block's table when the dynamics were shared
+            double fsh[PPT][NX];          // f(x[ancestor]): from the scratch plane (MARKS) or from the block's table when the dynamics were shared
             bool shared = false;          // block-uniform
-            if (do_res) {
+            if constexpr (MARKS) {
+                if (do_res) {
+                    // run-start marks -> ancestors: 1 + j at the first output of every surviving source j and at every tile boundary inside
+                    // its range, so an inclusive max-scan over the tile gives every output its ancestor (they are non-decreasing); an
+                    // output without an owner carries its own flagged mark (MARK_OWN | 1 + previous j: resample.jl:27-35 writes nothing)
+                    const int t = (int)threadIdx.x;
+                    int32_t* mkp = b.mark + (size_t)f * Ns + i0;
+                    const int2 m2 = mnext;
+                    if (tb + (int)gridDim.x < (int)(Ns / (BLOCK * PPT))) mnext = *reinterpret_cast<const int2*>(mkp + (size_t)gridDim.x * (BLOCK * PPT));   // the next tile's
+                    if (m2.x | m2.y) { int2 z; z.x = 0; z.y = 0; *reinterpret_cast<int2*>(mkp) = z; }
+                    const uint32_t m0 = (uint32_t)m2.x, m1 = (uint32_t)m2.y;
+                    const uint32_t incl = wave_scan_max_u32(m1 > m0 ? m1 : m0);
+                    uint32_t base = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x138 /* wave_shr:1 */, 0xF, 0xF, true);
+                    int32_t* wc = sh_mcnt[itn & 1];            // per iteration parity: a wave may be one barrier ahead of the slowest reader
+                    if ((t & 63) == 63) wc[t >> 6] = (int32_t)incl;
+                    __syncthreads();
+#pragma unroll
+                    for (int k = 0; k < BLOCK / 64 - 1; ++k) { const uint32_t c = (uint32_t)wc[k]; if (k < (t >> 6)) base = c > base ? c : base; }
+                    const uint32_t s0 = m0 > base ? m0 : base, s1 = m1 > s0 ? m1 : s0;
+                    const uint32_t am[2] = {(m0 & (uint32_t)MARK_OWN) ? m0 : s0, (m1 & (uint32_t)MARK_OWN) ? m1 : s1};
+                    STEP_STAMP(2, s1);           // marks back and scanned
+                    int32_t av[PPT];
+#pragma unroll
+                    for (int p = 0; p < PPT; ++p) {
+                        const int32_t v = (int32_t)(am[p] & ~(uint32_t)MARK_OWN) - 1;
+                        av[p] = v < 0 ? 0 : v;                  // no mark at all: a launch that resampled nothing (degenerate weights), or padding
+                    }
+                    { int2 ao; ao.x = (i0 < N) ? av[0] : (int32_t)i0; ao.y = (i0 + 1 < N) ? av[1] : (int32_t)(i0 + 1);      // padding lanes keep the identity
+                      wt_store(reinterpret_cast<int2*>(b.anc + (size_t)f * Ns + i0), ao); }
+                    const double* __restrict__ fxp = b.fxs + (size_t)f * NX * Ns;
+#pragma unroll
+                    for (int d = 0; d < NX; ++d) {
+#pragma unroll
+                        for (int p = 0; p < PPT; ++p) fsh[p][d] = fxp[(size_t)d * Ns + av[p]];
+                    }
+                } else {                                        // nothing resampled: j = 1:N, f(x_i) of every particle is in the plane
+                    const double* __restrict__ fxp = b.fxs + (size_t)f * NX * Ns;
+#pragma unroll
+                    for (int d = 0; d < NX; ++d) { const double2 v = *reinterpret_cast<const double2*>(fxp + (size_t)d * Ns + i0); fsh[0][d] = v.x; fsh[1][d] = v.y; }
+                }
+                shared = true;
+                STEP_STAMP(3, fsh[0][0]);     // f(x[ancestor]) gathered
+            } else if (do_res) {
                 int32_t av[PPT];
                 if constexpr (PPT == 2) { const int2 a2 = *reinterpret_cast<const int2*>(anc + i0); av[0] = a2.x; av[1] = a2.y; }
                 else av[0] = anc[i0];
@@ -100,8 +175,8 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
                     // x' = f(x[j]) + noise: outputs with the same ancestor share f(x[j]).  The ancestors of systematic / stratified /
                     // (the copies of) residual resampling are sorted, so the block's distinct ancestors are the starts of its runs:
                     // they are listed, the first D threads evaluate the dynamics once each, and every output reads its run's value
-                    // back — the same bits, D evaluations instead of BLOCK * PPT.  With a peaked likelihood (quad-tank, BASELINE C3:
-                    // ESS ~ 1e-3 N at every step) D is 1-3 per block and three of the four waves skip the RK4 altogether.
+                    // back — the same bits, D evaluations instead of BLOCK * PPT.  (The run loop of such models takes the MARKS form;
+                    // this one serves the single-step API, the auxiliary filter and residual resampling.)
                     const int t = (int)threadIdx.x;
                     sh_prev[t] = av[PPT - 1];
                     __syncthreads();
@@ -163,11 +238,16 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
                     continue;
                 }
                 double fx[NX], xi[NX], nz[NX];
-                if (shared) {
+                if constexpr (MARKS) {
 #pragma unroll
                     for (int d = 0; d < NX; ++d) fx[d] = fsh[p][d];
                 } else {
-                    model.dynamics(xp[p], fx);
+                    if (shared) {
+#pragma unroll
+                        for (int d = 0; d < NX; ++d) fx[d] = fsh[p][d];
+                    } else {
+                        model.dynamics(xp[p], fx);
+                    }
                 }
                 if (MODE == MODE_AUX) {            // propagate_particles!(pf, u, p, t, nothing): no noise
 #pragma unroll
@@ -180,6 +260,7 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
                     for (int d = 0; d < NX; ++d) xs[p][d] = fx[d] + nz[d];
                 }
             }
+            STEP_STAMP(4, xs[0][0]);               // noise drawn, particles formed
             if (!(Model::RB && MODE == MODE_PROP_WEIGHT && a.has_y)) {
 #pragma unroll
                 for (int d = 0; d < NX; ++d) {
@@ -283,36 +364,39 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
                         for (int p = 0; p < PPT; ++p) xm[d] = xm[d] + xs[p][d] * ev[p];
                     }
                 }
+                // the quanta of this wave's particles into their tile's sum (a wave never straddles a 1024-particle tile)
+                qsum = wave_sum_u64(qsum);
+                if ((threadIdx.x & 63) == 0 && qsum)
+                    atomicAdd(reinterpret_cast<unsigned long long*>(tileq_slot(b, a.parity, f) + (i0 / TILE)), (unsigned long long)qsum);
             }
         }
+    };
+    if constexpr (MARKS) {
+        const int ntb = (int)(Ns / (BLOCK * PPT));
+        int itn = 0;
+#pragma unroll 1
+        for (int tb = (int)blockIdx.x; tb < ntb; tb += (int)gridDim.x, ++itn) tile(tb, itn);
+    } else {
+        tile((int)blockIdx.x, 0);
     }
+    STEP_STAMP(5, bmax);                // weights, exp-sums, stores issued
     if (MODE != MODE_PROP) {
         const double r = block_max(bmax, sm_max);
         const int anybad = __syncthreads_or(bad ? 1 : 0);
         if (threadIdx.x == 0) acc_max(b.acc + (size_t)f * ACC_WORDS, a.parity, r, anybad != 0);
         if (a.accumulate) wacc.flush(b.acc + (size_t)f * ACC_WORDS, a.parity, a.need_e2 != 0, sm_acc);
         if (a.accumulate && a.want_xmean) block_store_xm<NX>(xm, b.xmpart + ((size_t)f * b.P1 + blockIdx.x) * MAXD, sm_x);
-        // all particles of this block lie in one 1024-particle tile
-        qsum = wave_sum_u64(qsum);
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0) sm_acc[threadIdx.x >> 6][0] = qsum;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint64_t q = 0;
-            for (int k = 0; k < BLOCK / 64; ++k) q += sm_acc[k][0];
-            const int64_t tile = ((int64_t)blockIdx.x * (BLOCK * PPT * STEP_ITERS)) / TILE;
-            if (q) atomicAdd(reinterpret_cast<unsigned long long*>(tileq_slot(b, a.parity, f) + tile), (unsigned long long)q);
-            if (blockIdx.x == 0) {
-                FilterScal* scw = b.scal + f;
-                if (a.accumulate) scw->xm_parts = (int32_t)gridDim.x;
-                if (MODE == MODE_AUX2) { scw->norm_pending = 0; scw->uniform = 0; scw->wmax = off; }   // final values, bounded by off (as k_resprop<AUX>)
-                scw->off_slot[a.parity] = off;
-                scw->exact_slot[a.parity] = 0;
-                scw->e2v_slot[a.parity] = a.need_e2;
-                scw->u_slot[a.parity] = llpf_uniform_step(sb + a.next_step, LLPF_STREAM_RESAMPLE, k0, k1);
-            }
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            FilterScal* scw = b.scal + f;
+            if (a.accumulate) scw->xm_parts = (int32_t)gridDim.x;
+            if (MODE == MODE_AUX2) { scw->norm_pending = 0; scw->uniform = 0; scw->wmax = off; }   // final values, bounded by off (as k_resprop<AUX>)
+            scw->off_slot[a.parity] = off;
+            scw->exact_slot[a.parity] = 0;
+            scw->e2v_slot[a.parity] = a.need_e2;
+            scw->u_slot[a.parity] = llpf_uniform_step(sb + a.next_step, LLPF_STREAM_RESAMPLE, k0, k1);
         }
     }
+    STEP_STAMP(6, threadIdx.x);         // block reductions and atomics done
     if (MODE != MODE_WEIGHT && MODE != MODE_AUX && blockIdx.x == 0 && threadIdx.x == 0) {
         // bookkeeping of this predict! (fields no block of this kernel reads): state.j == 1:N unless resampled
         FilterScal* scw = b.scal + f;

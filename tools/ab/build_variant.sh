@@ -8,7 +8,7 @@ ROOT=$(cd "$(dirname "$0")/../.." && pwd)
 C=$ROOT/lowlevelparticlefilters.jl_amd/csrc
 FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -mllvm -amdgpu-kernarg-preload-count=16 --offload-arch=gfx950 -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result -Wno-pass-failed"
 cd $C
-if [ $UNIT = k_rbfull ]; then FLAGS="$FLAGS -mllvm -disable-machine-licm"; fi
+if [ $UNIT = k_rbfull ] || [ $UNIT = k_step ]; then FLAGS="$FLAGS -mllvm -disable-machine-licm"; fi
 /opt/rocm/bin/hipcc $FLAGS "$@" -c $UNIT.hip -o /tmp/${UNIT}_$NAME.o
 OBJS=""
 for u in kernels k_step k_resprop k_resprop_split k_rbfull capi; do if [ $u = $UNIT ]; then OBJS="$OBJS /tmp/${UNIT}_$NAME.o"; else OBJS="$OBJS $u.o"; fi; done
