@@ -274,26 +274,6 @@ hipError_t launch_resample_fx(const BankDev& b, const ResArgs& a, const StepArgs
 bool resample_fx_supported(int model_id, int nx, int ny, int strategy);
 // fused finalize + resample + propagate [+ weight]: one launch for predict!(u_k) and the weighting of correct!(u_{k+1}, y_{k+1})
 hipError_t launch_resprop(const BankDev& b, const ResArgs& a, const StepArgs& st, int weight, hipStream_t s);
-// Persistent multi-step launch (kernels/persist.hpp): timesteps [k_begin, k_end) of a single linear-Gaussian filter in one
-// cooperative launch with a grid barrier between timesteps; every one of them must have a weighting phase (k + 1 < T).
-struct PersistArgsHost {
-    int64_t k_begin, k_end;
-    double t_index0, Ts;
-    const double* U; const double* Y;      // device inputs of the whole run
-    double* x0; double* x1; uint64_t* q0; uint64_t* q1;   // both particle planes / quanta buffers
-    int32_t cur0, qcur0;                   // Bank::cur / Bank::qcur as timestep k_begin sees them
-    int32_t par0;                          // accumulator slot the head of timestep k_begin reads
-    uint32_t step0;                        // relative Philox step of timestep k_begin
-    int32_t np0;                           // Bank::n_predict at timestep k_begin
-    int32_t need_e2;
-    double* ll_steps;
-    uint32_t* bar;                         // barrier counters, persist_bar_words() u32, zero-initialised once
-    int32_t ablate;
-    int32_t dbg_step; uint64_t* dbg;       // developer aid (LLPF_PERSIST_TIMING): phase stamps of one timestep, [P2][8]
-};
-hipError_t launch_persist(const BankDev& b, const PersistArgsHost& a, hipStream_t s);
-hipError_t persist_capacity(const BankDev& b, int* blocks);   // co-resident workgroups of the instance for b's dimensions
-int persist_bar_words();
 hipError_t launch_smooth_fx(const BankDev& b, const SmoothArgs& a, hipStream_t s);
 hipError_t launch_smooth_draw(const BankDev& b, const SmoothArgs& a, hipStream_t s);
 hipError_t launch_bake_weights(const BankDev& b, hipStream_t s);   // w[] <- the normalised / uniform values it stands for (padding -Inf)

@@ -23,8 +23,6 @@ struct Bank {
     int qcur = 0;                    // quanta buffer that holds the quanta of the current weights
     uint64_t* d_tileq = nullptr;
     uint32_t* d_flag = nullptr;
-    uint32_t* d_bar = nullptr;       // grid-barrier counters of the persistent multi-step launch (kernels/persist.hpp)
-    int persist_cap = -1;            // co-resident workgroups of that kernel on this device (-1: not queried yet)
     int64_t last_run_launches = 0, last_run_persistent_steps = 0;
     double* d_xmpart = nullptr;
     // Rao-Blackwellized model: host side of the shared covariance recursion (csrc/shared/llpf_rbkf.h)
@@ -327,7 +325,6 @@ static int bank_create(const llpf_config* cfg, const llpf_model* models, int F, 
         const size_t o_acc = take(sizeof(uint64_t) * (size_t)F * ACC_WORDS);
         const size_t o_q0 = take(sizeof(uint64_t) * FN), o_q1 = take(sizeof(uint64_t) * FN);
         const size_t o_tileq = take(sizeof(uint64_t) * (size_t)ACC_NSLOT * F * b.P2), o_flag = take(sizeof(uint32_t) * 4);
-        const size_t o_bar = take(sizeof(uint32_t) * (size_t)persist_bar_words());
         const size_t o_xmpart = take(sizeof(double) * (size_t)F * b.P1 * MAXD), o_rtile = take(sizeof(uint64_t) * (size_t)F * 2 * b.P2);
         const size_t o_rb = take(m0.model_id == LLPF_MODEL_RB_LINEAR ? sizeof(RBStep) * 2 * (size_t)F : 0);
         const size_t o_uy = take(sizeof(double) * 4 * MAXD);
@@ -341,7 +338,6 @@ static int bank_create(const llpf_config* cfg, const llpf_model* models, int F, 
         b.d_acc = reinterpret_cast<uint64_t*>(base + o_acc);
         b.d_quanta[0] = reinterpret_cast<uint64_t*>(base + o_q0); b.d_quanta[1] = reinterpret_cast<uint64_t*>(base + o_q1);
         b.d_tileq = reinterpret_cast<uint64_t*>(base + o_tileq); b.d_flag = reinterpret_cast<uint32_t*>(base + o_flag);
-        b.d_bar = reinterpret_cast<uint32_t*>(base + o_bar);
         b.d_xmpart = reinterpret_cast<double*>(base + o_xmpart); b.d_rtile = reinterpret_cast<uint64_t*>(base + o_rtile);
         if (m0.model_id == LLPF_MODEL_RB_LINEAR) b.d_rb = reinterpret_cast<RBStep*>(base + o_rb);
         b.d_uy = reinterpret_cast<double*>(base + o_uy); b.d_tmp = reinterpret_cast<double*>(base + o_tmp);
@@ -381,11 +377,6 @@ static int bank_wmean(Bank& b, double* d_out) {
 }
 
 static int check_status(Bank& b, std::vector<FilterScal>& h) {
-    for (int f = 0; f < b.F; ++f)
-        if (h[f].status == 90) {      // LLPF_STATUS_BARRIER_TIMEOUT (kernels/persist.hpp): the counters are no longer consistent
-            hipMemsetAsync(b.d_bar, 0, sizeof(uint32_t) * (size_t)persist_bar_words(), b.stream);
-            return fail(LLPF_ERR_HIP, "the grid barrier of the persistent run timed out (are the device's CUs shared with another process?); set LLPF_PERSIST=0");
-        }
     for (int f = 0; f < b.F; ++f)
         if (h[f].status) return fail(h[f].status, "degenerate weights (all -Inf or NaN) in filter " + std::to_string(f));
     return LLPF_OK;

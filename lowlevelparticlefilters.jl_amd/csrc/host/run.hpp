@@ -245,58 +245,10 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
         HIPC(launch_step(d, MODE_WEIGHT, a, b.stream));
         return LLPF_OK;
     };
-    // Persistent form (kernels/persist.hpp): all timesteps that have a weighting phase in ONE cooperative launch, a grid
-    // barrier instead of a kernel boundary between them.  Single linear-Gaussian filters in the fused, merged schedule whose
-    // tiles are all co-resident.  Opt-in (LLPF_PERSIST=1): measured on the MI355X it does not beat the graph of per-timestep
-    // launches (C2 27.1 vs 26.4 us per timestep on one box) — the barrier costs what the kernel boundary costs
-    // and the step is bounded by the youngest block of every CU, not by the boundary.  The last timestep and the exact redo of
-    // a failed bound test stay ordinary launches.
-    const char* per_env = getenv("LLPF_PERSIST");     // read per run: tests switch it inside one process
-    bool persist = !unfused && merged && b.F == 1 && b.cfg.model.model_id == LLPF_MODEL_LINEAR_GAUSSIAN && !want_xm && !xm_launch &&
-                   !hist && !b.profiling && !dbg_env && !multi && T >= 3 && (per_env && atoi(per_env) != 0);
-    if (persist) {
-        if (b.persist_cap < 0) { int cap = 0; HIPC(persist_capacity(b.dev(), &cap)); b.persist_cap = cap; }
-        persist = b.P2 <= b.persist_cap;
-    }
     b.last_run_launches = 0; b.last_run_persistent_steps = 0;
-    auto launch_persistent = [&](int64_t ka, int64_t kb) -> int {      // timesteps [ka, kb), kb <= T - 1
-        at_step(ka);
-        PersistArgsHost pa{};
-        pa.k_begin = ka; pa.k_end = kb; pa.t_index0 = t_index0; pa.Ts = Ts;
-        pa.U = b.nu > 0 ? b.d_U : nullptr; pa.Y = b.d_Y;
-        pa.x0 = b.d_x[0]; pa.x1 = b.d_x[1]; pa.q0 = b.d_quanta[0]; pa.q1 = b.d_quanta[1];
-        pa.cur0 = b.cur; pa.qcur0 = b.qcur; pa.par0 = head_slot(ka); pa.step0 = rel_step(b); pa.np0 = (int32_t)b.n_predict;
-        pa.need_e2 = ne2; pa.ll_steps = ll_steps ? b.d_ll_steps : nullptr; pa.bar = b.d_bar;
-        pa.ablate = abl_env ? atoi(abl_env) : 0;
-        pa.dbg_step = -1; pa.dbg = nullptr;
-        const char* pt_env = getenv("LLPF_PERSIST_TIMING");          // developer aid: phase stamps of one timestep of the launch
-        uint64_t* d_dbg = nullptr;
-        if (pt_env && atoll(pt_env) >= ka && atoll(pt_env) < kb) {
-            HIPC(hipMalloc(&d_dbg, sizeof(uint64_t) * 8 * b.P2));
-            HIPC(hipMemsetAsync(d_dbg, 0, sizeof(uint64_t) * 8 * b.P2, b.stream));
-            pa.dbg = d_dbg; pa.dbg_step = (int32_t)(atoll(pt_env) - ka);
-        }
-        HIPC(launch_persist(b.dev(), pa, b.stream));
-        if (d_dbg) {
-            std::vector<uint64_t> hd((size_t)8 * b.P2);
-            HIPC(hipMemcpyAsync(hd.data(), d_dbg, sizeof(uint64_t) * hd.size(), hipMemcpyDeviceToHost, b.stream));
-            HIPC(hipStreamSynchronize(b.stream));
-            FILE* fp = fopen("gpurun_out/llpf_ptiming.txt", "w");
-            if (fp) {
-                for (int t = 0; t < b.P2; ++t) {
-                    for (int q = 0; q < 7; ++q) fprintf(fp, "%llu ", (unsigned long long)hd[(size_t)t * 8 + q]);
-                    fprintf(fp, "\n");
-                }
-                fclose(fp);
-            }
-            hipFree(d_dbg);
-        }
-        b.last_run_launches += 1; b.last_run_persistent_steps += kb - ka;
-        return LLPF_OK;
-    };
     // the asynchronous loop as a captured graph, replayed when nothing a launch argument depends on has changed
     static const char* graph_env = getenv("LLPF_GRAPH");
-    const bool use_graph = !persist && !hist && !b.profiling && !dbg_env && !(graph_env && atoi(graph_env) == 0);
+    const bool use_graph = !hist && !b.profiling && !dbg_env && !(graph_env && atoi(graph_env) == 0);
     hipGraphExec_t gexec = nullptr;
     if (use_graph) {
         Bank::RunGraph key{};
@@ -384,9 +336,7 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
         while (k0 < T) {
             const int64_t k1 = replayed ? T : std::min(T, k0 + batch);
             if (!replayed) {
-                int64_t kq = k0;
-                if (persist && std::min(k1, T - 1) > k0) { kq = std::min(k1, T - 1); CHK(launch_persistent(k0, kq)); }
-                for (int64_t k = kq; k < k1; ++k) CHK(launch_timestep(k, true, 0));
+                for (int64_t k = k0; k < k1; ++k) CHK(launch_timestep(k, true, 0));
             }
             replayed = false;
             std::vector<int> fl;

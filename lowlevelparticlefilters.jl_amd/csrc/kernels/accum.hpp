@@ -103,6 +103,43 @@ struct WeightAcc {
     }
 };
 
+// The end of a weighting block in ONE barrier: the block's maximum / NaN flag and (accumulate) the exp-sums of its weights go to the
+// sharded accumulators of `slot`.  Same values as block_max + __syncthreads_or + acc_max + WeightAcc::flush (nine barriers): in the
+// kernels whose blocks all reach their tails together (k_step<..., MARKS>) those were 4.5 k cycles per block with nothing to hide under.
+DEV void block_flush(uint64_t* acc, int slot, double bmax, bool bad, const WeightAcc& wa, bool accumulate, bool need_e2, uint64_t (*sm)[8]) {
+    const double wm = wave_max(bmax);
+    const uint64_t nb = __ballot(bad) ? 1u : 0u;
+    llpf_u128 s = {0, 0}, e2 = {0, 0};
+    uint64_t bd = 0;
+    if (accumulate) {
+        s = wave_sum_u128(wa.S);
+        if (need_e2) e2 = wave_sum_u128(wa.E2);
+        bd = (uint64_t)__builtin_popcountll(__ballot(wa.bad != 0));
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { sm[wv][0] = llpf_d2u(wm); sm[wv][1] = nb; sm[wv][2] = s.lo; sm[wv][3] = s.hi; sm[wv][4] = e2.lo; sm[wv][5] = e2.hi; sm[wv][6] = bd; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = llpf_u2d(sm[0][0]);
+        uint64_t anybad = sm[0][1], tb = sm[0][6];
+        llpf_u128 ts = {sm[0][2], sm[0][3]}, te = {sm[0][4], sm[0][5]};
+        for (int k = 1; k < BLOCK / 64; ++k) {
+            r = llpf_fmax(r, llpf_u2d(sm[k][0]));
+            anybad |= sm[k][1];
+            llpf_u128 a1 = {sm[k][2], sm[k][3]}, a2 = {sm[k][4], sm[k][5]};
+            ts = llpf_u128_add(ts, a1);
+            te = llpf_u128_add(te, a2);
+            tb += sm[k][6];
+        }
+        acc_max(acc, slot, r, anybad != 0);
+        if (accumulate) {
+            acc_add_u128(acc, ACC_S(slot), ts);
+            if (need_e2) acc_add_u128(acc, ACC_E2(slot), te);
+            if (tb) atomicAdd(reinterpret_cast<unsigned long long*>(acc_slot(acc, ACC_BAD(slot), blockIdx.x & (NSHARD - 1))), (unsigned long long)tb);
+        }
+    }
+}
+
 // fixed-order fp64 block sum of the per-thread partial sums e_i x_i (weighted-mean output only; never fed back)
 template <int NX>
 DEV void block_store_xm(const double* xm, double* dst /* [MAXD] */, double (*smx)[MAXD]) {

@@ -372,6 +372,35 @@ struct QuadTank {   // reference examples/example_quadtank.jl:8-35 with rk4 of s
         out[0] = x[0];
         out[1] = x[1];
     }
+    // The same RK4 with the four states on the four lanes of a quad (lane & 3 = state): every lane runs the chain of ITS state — the same
+    // IEEE operations in the same order as dynamics() — and the one cross term of the right-hand side (h1' takes sqrt(h3), h2' takes
+    // sqrt(h4)) arrives through a quad permute.  One evaluation is a third of the dependent instructions: for the launches in which a
+    // handful of lanes evaluate f while everything else waits (k_resample_fx: ~8 surviving sources per tile at BASELINE C3).
+    // All four lanes of the quad must be active.  Returns the lane's own component of f(x).
+    DEV double dynamics_quad(double xc, int c) const {
+        const double A = c == 0 ? c1a : (c == 1 ? c2a : (c == 2 ? c3a : c4a));
+        const double Asw = c == 0 ? c1a_sw : A;
+        const double B = c == 0 ? c1b : c2b;
+        const double pu = c == 0 ? c1u * u0 : (c == 1 ? c2u * u1 : (c == 2 ? c3u * u1 : c4u * u0));
+        auto rhs1 = [&](double h, double t) {
+            const double v = tg * h;
+            const double sq = llpf_sqrt_pos((v > 0.0 ? v : 0.0) + eps);
+            const double so = llpf_u2d(dpp_u64<0xEE /* quad_perm [2,3,2,3] */, 0xF, false>(llpf_d2u(sq), llpf_d2u(sq)));
+            const double a = (t > tsw) ? Asw : A;
+            const double t1 = a * sq;
+            return c < 2 ? (t1 + B * so) + pu : t1 + pu;
+        };
+        double x = xc, t = t0;
+        for (int it = 0; it < ss; ++it) {
+            const double f1 = rhs1(x, t);
+            const double f2 = rhs1(x + Ts2 * f1, t + Ts2);
+            const double f3 = rhs1(x + Ts2 * f2, t + Ts2);
+            const double f4 = rhs1(x + Ts * f3, t + Ts);
+            x = x + Ts6 * (((f1 + 2.0 * f2) + 2.0 * f3) + f4);
+            t = t + Ts;
+        }
+        return x;
+    }
 };
 
 // placeholder model of the AuxiliaryParticleFilter's second half: the dynamics were applied by k_step<MODE_AUX>
@@ -393,6 +422,10 @@ template <class Model> struct share_dynamics { static constexpr bool value = tru
 template <int NX, int NY> struct share_dynamics<LinGauss<NX, NY>> { static constexpr bool value = false; };
 template <int NX, int NY> struct share_dynamics<RBLin<NX, NY>> { static constexpr bool value = false; };
 template <int NX> struct share_dynamics<NoModel<NX>> { static constexpr bool value = false; };
+
+// a model whose dynamics can also run with the states spread over the lanes of a quad (NX == 4): dynamics_quad(x_own, lane & 3)
+template <class M, class = void> struct has_quad_dynamics { static constexpr bool value = false; };
+template <class M> struct has_quad_dynamics<M, decltype((void)&M::dynamics_quad)> { static constexpr bool value = true; };
 
 // Optional hooks of a model (run-time compiled user models, kernels/jit.hpp):
 //   DEV double loglik(const double* x, const double* y, double t) const   log p(y | x) — the reference's measurement_likelihood(x, u, y, p, t)

@@ -19,13 +19,12 @@
 // reference writes nothing there, resample.jl:27-35: j keeps its previous value) — such an output gets a mark of its own, flagged
 // MARK_OWN —; and, when shouldresample says no, all particles (j = 1:N, filtering.jl:148).
 // ------------------------------------------------------------------------------------------------
-constexpr int FX_INLINE_BND = 8;    // block boundaries a lane marks by itself; longer ranges are finished by the whole block
+constexpr int FX_INLINE_BND = 8;    // tile boundaries a lane marks by itself; longer ranges are finished by its wave
 
 template <class Model, int NX, int STRATEGY>
 __global__ __launch_bounds__(BLOCK) void k_resample_fx(BankDev b, ResArgs a, StepArgs st) {
     __shared__ ResShared sh;
     __shared__ uint32_t sh_list[TILE];       // tile-local indices of the surviving sources (any order: each is handled on its own)
-    __shared__ uint32_t sh_heavy[TILE];
     __shared__ uint32_t sh_cnt[2];
     const int f = blockIdx.y;
     const int tile = blockIdx.x;
@@ -115,48 +114,74 @@ __global__ __launch_bounds__(BLOCK) void k_resample_fx(BankDev b, ResArgs a, Ste
     const int D = (int)sh_cnt[0];
     FX_STAMP(3, D);                     // survivors listed
 
-    // first pass over the survivors: request x_j (the first BLOCK of them: a tile with more has near-uniform weights), leave the marks
+    // A handful of survivors (peaked likelihoods: ~8 per tile at BASELINE C3) and a model whose dynamics can run with its states
+    // spread over a quad: four lanes per survivor, a third of the dependent chain (QuadTank::dynamics_quad).  Survivor q sits on lanes
+    // 4q .. 4q+3 counted from wave (tile & 3): the four workgroups of a CU would otherwise all put their one busy wave on SIMD 0.
+    bool quad = false;                   // block-uniform
+    if constexpr (has_quad_dynamics<Model>::value && NX == 4) quad = D <= BLOCK / 4;
+    const int tq = (t - 64 * (tile & 3)) & (BLOCK - 1);
+    const int qstep = quad ? BLOCK / 4 : BLOCK;
+    const int q0 = quad ? (tq >> 2) : tq, cq = tq & 3;
+    // first pass over the survivors: request x_j (the first round of them: a tile with more has near-uniform weights), leave the marks
     // a lane can leave by itself
     double xq0[NX];
-    const int32_t j0 = (t < D) ? (int32_t)((int64_t)tile * TILE + (int)sh_list[t]) : -1;
+    const int32_t j0 = (q0 < D) ? (int32_t)((int64_t)tile * TILE + (int)sh_list[q0]) : -1;
     if (j0 >= 0) {
+        if (quad) xq0[0] = xc[(size_t)cq * Ns + j0];
+        else {
 #pragma unroll
-        for (int d = 0; d < NX; ++d) xq0[d] = xc[(size_t)d * Ns + j0];
+            for (int d = 0; d < NX; ++d) xq0[d] = xc[(size_t)d * Ns + j0];
+        }
     }
+    // run-start marks: the first output of the source and every k_step tile boundary inside its range.  A lane leaves the first
+    // FX_INLINE_BND boundaries itself; the rest of a long range (a heavy particle: up to N / STEP_TILE boundaries) is written by the
+    // whole wave, one such source after the other — no block-wide list, no barrier
 #pragma unroll 1
-    for (int q = t; q < D; q += BLOCK) {
-        const uint32_t idx = sh_list[q];
-        const int32_t j = (int32_t)((int64_t)tile * TILE + (int)idx);
-        const uint32_t lo = idx ? sh.cl[idx - 1] : (uint32_t)c_start, hi = sh.cl[idx];
-        wt_store(mk + lo, j + 1);
-        uint32_t bnd = (lo / STEP_TILE + 1) * STEP_TILE;
+    for (int qb = 0; qb < D; qb += qstep) {              // block-uniform trip count
+        const int q = qb + q0;
+        uint32_t bnd = 0, hi = 0;
+        int32_t j = 0;
+        if (q < D && (!quad || cq == 0)) {
+            const uint32_t idx = sh_list[q];
+            j = (int32_t)((int64_t)tile * TILE + (int)idx);
+            const uint32_t lo = idx ? sh.cl[idx - 1] : (uint32_t)c_start;
+            hi = sh.cl[idx];
+            wt_store(mk + lo, j + 1);
+            bnd = (lo / STEP_TILE + 1) * STEP_TILE;
 #pragma unroll 1
-        for (int n = 0; n < FX_INLINE_BND && bnd < hi; ++n, bnd += STEP_TILE) wt_store(mk + bnd, j + 1);
-        if (bnd < hi) sh_heavy[atomicAdd(&sh_cnt[1], 1u)] = idx;      // a heavy particle: the rest of its boundaries by the whole block
+            for (int n = 0; n < FX_INLINE_BND && bnd < hi; ++n, bnd += STEP_TILE) wt_store(mk + bnd, j + 1);
+        }
+        uint64_t more = __ballot(bnd < hi);
+        while (more) {                                    // wave-uniform
+            const int l = __builtin_ctzll(more);
+            more &= more - 1;
+            const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)bnd, l), h0 = (uint32_t)__builtin_amdgcn_readlane((int)hi, l);
+            const int32_t jl = __builtin_amdgcn_readlane(j, l);
+            for (uint32_t bb = b0 + (uint32_t)lane * STEP_TILE; bb < h0; bb += 64u * STEP_TILE) wt_store(mk + bb, jl + 1);
+        }
     }
-    FX_STAMP(4, xq0[0]);                // x of the survivors back, own marks left
-    __syncthreads();
-    const int H = (int)sh_cnt[1];
-    for (int hq = 0; hq < H; ++hq) {                      // block-uniform
-        const uint32_t idx = sh_heavy[hq];
-        const uint32_t lo = idx ? sh.cl[idx - 1] : (uint32_t)c_start, hi = sh.cl[idx];
-        const int32_t j = (int32_t)((int64_t)tile * TILE + (int)idx);
-        for (uint32_t bnd = (lo / STEP_TILE + 1 + FX_INLINE_BND + (uint32_t)t) * STEP_TILE; bnd < hi; bnd += BLOCK * STEP_TILE) wt_store(mk + bnd, j + 1);
-    }
-    FX_STAMP(5, H);                     // heavy and stale marks
+    FX_STAMP(4, xq0[0]);                // x of the survivors back, marks left
+    FX_STAMP(5, t);
     // the dynamics, once per surviving source
+    if constexpr (has_quad_dynamics<Model>::value && NX == 4) {
+        if (quad) {
+            if (j0 >= 0) wt_store(fxo + (size_t)cq * Ns + j0, model.dynamics_quad(xq0[0], cq));      // D <= BLOCK / 4: one round
+        }
+    }
+    if (!quad) {
 #pragma unroll 1
-    for (int q = t; q < D; q += BLOCK) {
-        const int32_t j = (q == t) ? j0 : (int32_t)((int64_t)tile * TILE + (int)sh_list[q]);
-        double xq[NX];
+        for (int q = q0; q < D; q += BLOCK) {
+            const int32_t j = (q == q0) ? j0 : (int32_t)((int64_t)tile * TILE + (int)sh_list[q]);
+            double xq[NX];
 #pragma unroll
-        for (int d = 0; d < NX; ++d) xq[d] = (q == t) ? xq0[d] : xc[(size_t)d * Ns + j];
-        eval_store(j, xq);
+            for (int d = 0; d < NX; ++d) xq[d] = (q == q0) ? xq0[d] : xc[(size_t)d * Ns + j];
+            eval_store(j, xq);
+        }
     }
     // outputs whose threshold is >= bins[N] (at most a few, at the very end)
     if (tile == b.P2 - 1 && c_end < a.M) unowned((int64_t)c_end);
     FX_STAMP(6, t);                     // dynamics evaluated and stored
 #if defined(LLPF_STEP_TIMING) && defined(__HIP_DEVICE_COMPILE__)
-    if (t == 0 && blockIdx.y == 0 && g_fx_dbg && dbg_on) { g_fx_dbg[(size_t)blockIdx.x * 16 + 8] = (unsigned long long)D; g_fx_dbg[(size_t)blockIdx.x * 16 + 9] = (unsigned long long)H; g_fx_dbg[(size_t)blockIdx.x * 16 + 10] = (unsigned long long)(c_end - c_start); }
+    if (t == 0 && blockIdx.y == 0 && g_fx_dbg && dbg_on) { g_fx_dbg[(size_t)blockIdx.x * 16 + 8] = (unsigned long long)D; g_fx_dbg[(size_t)blockIdx.x * 16 + 9] = 0; g_fx_dbg[(size_t)blockIdx.x * 16 + 10] = (unsigned long long)(c_end - c_start); }
 #endif
 }

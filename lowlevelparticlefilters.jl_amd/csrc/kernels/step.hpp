@@ -26,8 +26,7 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
                                                  const FilterScal* scal, StepArgs a) {
     static_assert(!MARKS || (share_dynamics<Model>::value && !Model::RB && PPT == STEP_PPT && (MODE == MODE_PROP || MODE == MODE_PROP_WEIGHT)),
                   "the marks form: models whose dynamics are worth a table, propagating modes, two particles per thread");
-    __shared__ double sm_max[BLOCK / 64];
-    __shared__ uint64_t sm_acc[BLOCK / 64][5];
+    __shared__ uint64_t sm_fl[BLOCK / 64][8];
     __shared__ double sm_x[BLOCK / 64][MAXD];
     // dynamics shared between the outputs of one ancestor (below): models whose f is worth a table
     constexpr bool SHARE = !MARKS && share_dynamics<Model>::value && !Model::RB && MODE != MODE_WEIGHT && MODE != MODE_AUX;
@@ -52,8 +51,12 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
         else if (t < LLPF_RNG_SC_ENTRIES + LLPF_RNG_LG_ENTRIES) { rt0 = LLPF_LOG_INVC[t - LLPF_RNG_SC_ENTRIES]; rt1 = LLPF_LOG_LNC[t - LLPF_RNG_SC_ENTRIES]; }
     }
     // the first tile's marks: their address needs nothing from memory, so they travel with the scalars (zero when nothing was resampled)
-    int2 mnext; mnext.x = 0; mnext.y = 0;
-    if constexpr (MARKS) mnext = *reinterpret_cast<const int2*>(b.mark + (size_t)f * b.Ns + (int64_t)blockIdx.x * (BLOCK * PPT) + (int64_t)threadIdx.x * PPT);
+    int2 mA, mB; mA.x = 0; mA.y = 0; mB = mA;      // marks of the block's next tile and of the one after it
+    if constexpr (MARKS) {
+        const int32_t* mk0 = b.mark + (size_t)f * b.Ns + (int64_t)blockIdx.x * (BLOCK * PPT) + (int64_t)threadIdx.x * PPT;
+        mA = *reinterpret_cast<const int2*>(mk0);
+        if ((int64_t)(blockIdx.x + gridDim.x) * (BLOCK * PPT) < b.Ns) mB = *reinterpret_cast<const int2*>(mk0 + (size_t)gridDim.x * (BLOCK * PPT));
+    }
     const int do_res = (MODE == MODE_AUX2) ? 1 : ((MODE != MODE_WEIGHT && MODE != MODE_AUX) ? sc->do_resample : 0);   // AUX2: always resampled (filtering.jl:206)
     const int uniform = sc->uniform, pend = sc->norm_pending;
     const double m = sc->m, l = sc->l, wconst = sc->wconst;
@@ -108,8 +111,57 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
         if (MODE == MODE_AUX2) off = ((a.aux == 2) ? md->dg.c0 : 0.0) - (-b.mlogN);    // w = lambda - log N <= c0 - log N (lambda = 0 when y1 is missing)
         wacc.init();
     }
+    // ---- MARKS: f(x[ancestor]) of one tile's particles — marks -> ancestors -> gather — requested one tile ahead of the arithmetic ----
+    auto fetch = [&](const int tb, const int itn, double (&fo)[PPT][NX]) {
+        if constexpr (MARKS) {
+            int64_t i0 = (int64_t)tb * (BLOCK * PPT) + (int64_t)threadIdx.x * PPT;
+#if defined(__HIP_DEVICE_COMPILE__)
+            { uint32_t il = (uint32_t)i0; asm volatile("" : "+v"(il)); i0 = (int64_t)il; }      // opaque per iteration (see tile())
+#endif
+            const double* __restrict__ fxp = b.fxs + (size_t)f * NX * Ns;
+            if (do_res) {
+                // run-start marks -> ancestors: 1 + j at the first output of every surviving source j and at every tile boundary inside
+                // its range, so an inclusive max-scan over the tile gives every output its ancestor (they are non-decreasing); an
+                // output without an owner carries its own flagged mark (MARK_OWN | 1 + previous j: resample.jl:27-35 writes nothing)
+                const int t = (int)threadIdx.x;
+                int32_t* mkp = b.mark + (size_t)f * Ns + i0;
+                const int2 m2 = mA;
+                mA = mB;
+                mB.x = 0; mB.y = 0;
+                if ((int64_t)(tb + 2 * (int)gridDim.x) * (BLOCK * PPT) < Ns) mB = *reinterpret_cast<const int2*>(mkp + (size_t)gridDim.x * (2 * BLOCK * PPT));
+                if (m2.x | m2.y) { int2 z; z.x = 0; z.y = 0; *reinterpret_cast<int2*>(mkp) = z; }
+                const uint32_t m0 = (uint32_t)m2.x, m1 = (uint32_t)m2.y;
+                const uint32_t incl = wave_scan_max_u32(m1 > m0 ? m1 : m0);
+                uint32_t base = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x138 /* wave_shr:1 */, 0xF, 0xF, true);
+                int32_t* wc = sh_mcnt[itn & 1];            // per tile parity: a wave may be one barrier ahead of the slowest reader
+                if ((t & 63) == 63) wc[t >> 6] = (int32_t)incl;
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < BLOCK / 64 - 1; ++k) { const uint32_t c = (uint32_t)wc[k]; if (k < (t >> 6)) base = c > base ? c : base; }
+                const uint32_t s0 = m0 > base ? m0 : base, s1 = m1 > s0 ? m1 : s0;
+                const uint32_t am[2] = {(m0 & (uint32_t)MARK_OWN) ? m0 : s0, (m1 & (uint32_t)MARK_OWN) ? m1 : s1};
+                STEP_STAMP(2, s1);           // marks back and scanned
+                int32_t av[PPT];
+#pragma unroll
+                for (int p = 0; p < PPT; ++p) {
+                    const int32_t v = (int32_t)(am[p] & ~(uint32_t)MARK_OWN) - 1;
+                    av[p] = v < 0 ? 0 : v;                  // no mark at all: a launch that resampled nothing (degenerate weights), or padding
+                }
+                { int2 ao; ao.x = (i0 < N) ? av[0] : (int32_t)i0; ao.y = (i0 + 1 < N) ? av[1] : (int32_t)(i0 + 1);      // padding lanes keep the identity
+                  wt_store(reinterpret_cast<int2*>(b.anc + (size_t)f * Ns + i0), ao); }
+#pragma unroll
+                for (int d = 0; d < NX; ++d) {
+#pragma unroll
+                    for (int p = 0; p < PPT; ++p) fo[p][d] = fxp[(size_t)d * Ns + av[p]];
+                }
+            } else {                                        // nothing resampled: j = 1:N, f(x_i) of every particle is in the plane
+#pragma unroll
+                for (int d = 0; d < NX; ++d) { const double2 v = *reinterpret_cast<const double2*>(fxp + (size_t)d * Ns + i0); fo[0][d] = v.x; fo[1][d] = v.y; }
+            }
+        }
+    };
     // ---- one tile of BLOCK * PPT particles ----
-    auto tile = [&](const int tb, const int itn) {
+    auto tile = [&](const int tb, const int itn, const double (*fpre)[NX]) {
         int64_t i0 = (int64_t)tb * (BLOCK * PPT) + (int64_t)threadIdx.x * PPT;
 #if defined(__HIP_DEVICE_COMPILE__)
         if constexpr (MARKS) {
@@ -126,44 +178,10 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
             double fsh[PPT][NX];          // f(x[ancestor]): from the scratch plane (MARKS) or from the block's table when the dynamics were shared
             bool shared = false;          // block-uniform
             if constexpr (MARKS) {
-                if (do_res) {
-                    // run-start marks -> ancestors: 1 + j at the first output of every surviving source j and at every tile boundary inside
-                    // its range, so an inclusive max-scan over the tile gives every output its ancestor (they are non-decreasing); an
-                    // output without an owner carries its own flagged mark (MARK_OWN | 1 + previous j: resample.jl:27-35 writes nothing)
-                    const int t = (int)threadIdx.x;
-                    int32_t* mkp = b.mark + (size_t)f * Ns + i0;
-                    const int2 m2 = mnext;
-                    if (tb + (int)gridDim.x < (int)(Ns / (BLOCK * PPT))) mnext = *reinterpret_cast<const int2*>(mkp + (size_t)gridDim.x * (BLOCK * PPT));   // the next tile's
-                    if (m2.x | m2.y) { int2 z; z.x = 0; z.y = 0; *reinterpret_cast<int2*>(mkp) = z; }
-                    const uint32_t m0 = (uint32_t)m2.x, m1 = (uint32_t)m2.y;
-                    const uint32_t incl = wave_scan_max_u32(m1 > m0 ? m1 : m0);
-                    uint32_t base = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x138 /* wave_shr:1 */, 0xF, 0xF, true);
-                    int32_t* wc = sh_mcnt[itn & 1];            // per iteration parity: a wave may be one barrier ahead of the slowest reader
-                    if ((t & 63) == 63) wc[t >> 6] = (int32_t)incl;
-                    __syncthreads();
 #pragma unroll
-                    for (int k = 0; k < BLOCK / 64 - 1; ++k) { const uint32_t c = (uint32_t)wc[k]; if (k < (t >> 6)) base = c > base ? c : base; }
-                    const uint32_t s0 = m0 > base ? m0 : base, s1 = m1 > s0 ? m1 : s0;
-                    const uint32_t am[2] = {(m0 & (uint32_t)MARK_OWN) ? m0 : s0, (m1 & (uint32_t)MARK_OWN) ? m1 : s1};
-                    STEP_STAMP(2, s1);           // marks back and scanned
-                    int32_t av[PPT];
+                for (int p = 0; p < PPT; ++p) {
 #pragma unroll
-                    for (int p = 0; p < PPT; ++p) {
-                        const int32_t v = (int32_t)(am[p] & ~(uint32_t)MARK_OWN) - 1;
-                        av[p] = v < 0 ? 0 : v;                  // no mark at all: a launch that resampled nothing (degenerate weights), or padding
-                    }
-                    { int2 ao; ao.x = (i0 < N) ? av[0] : (int32_t)i0; ao.y = (i0 + 1 < N) ? av[1] : (int32_t)(i0 + 1);      // padding lanes keep the identity
-                      wt_store(reinterpret_cast<int2*>(b.anc + (size_t)f * Ns + i0), ao); }
-                    const double* __restrict__ fxp = b.fxs + (size_t)f * NX * Ns;
-#pragma unroll
-                    for (int d = 0; d < NX; ++d) {
-#pragma unroll
-                        for (int p = 0; p < PPT; ++p) fsh[p][d] = fxp[(size_t)d * Ns + av[p]];
-                    }
-                } else {                                        // nothing resampled: j = 1:N, f(x_i) of every particle is in the plane
-                    const double* __restrict__ fxp = b.fxs + (size_t)f * NX * Ns;
-#pragma unroll
-                    for (int d = 0; d < NX; ++d) { const double2 v = *reinterpret_cast<const double2*>(fxp + (size_t)d * Ns + i0); fsh[0][d] = v.x; fsh[1][d] = v.y; }
+                    for (int d = 0; d < NX; ++d) fsh[p][d] = fpre[p][d];
                 }
                 shared = true;
                 STEP_STAMP(3, fsh[0][0]);     // f(x[ancestor]) gathered
@@ -255,7 +273,8 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
                 } else {
                     if constexpr (LTAB) llpf_normals_tab((uint32_t)(i0 + p), sb + a.step, LLPF_STREAM_DYNAMICS, k0, k1, NX, xi, sh_rng_lg, sh_rng_sc);
                     else llpf_normals((uint32_t)(i0 + p), sb + a.step, LLPF_STREAM_DYNAMICS, k0, k1, NX, xi);
-                    gauss_sample<NX>(md->df, xi, nz);
+                    if constexpr (MARKS) gauss_sample_c<NX>((gauss_cptr)&md->df, xi, nz);     // the covariance kind tested once, operands through scalar loads
+                    else gauss_sample<NX>(md->df, xi, nz);
 #pragma unroll
                     for (int d = 0; d < NX; ++d) xs[p][d] = fx[d] + nz[d];
                 }
@@ -325,7 +344,8 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
                         model.measurement(xs[p], g);
 #pragma unroll
                         for (int k = 0; k < NY; ++k) v[k] = y[k] - g[k];
-                        wv = wv + gauss_logpdf<NY>(md->dg, v);
+                        if constexpr (MARKS) wv = wv + gauss_logpdf_c<NY>((gauss_cptr)&md->dg, v);
+                        else wv = wv + gauss_logpdf<NY>(md->dg, v);
                     }
                 }
                 if (i0 + p >= N) wv = -LLPF_INF;   // padding lanes carry zero weight
@@ -372,19 +392,29 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
         }
     };
     if constexpr (MARKS) {
-        const int ntb = (int)(Ns / (BLOCK * PPT));
-        int itn = 0;
+        // two buffers, the loop written out twice: a tile's gather travels under the arithmetic of the tile before it, and the FIRST tile's
+        // under its own noise (copied from a "next" buffer at the top of every pass, the values were waited for before anything was drawn)
+        const int ntb = (int)(Ns / (BLOCK * PPT)), G = (int)gridDim.x;
+        double fA[PPT][NX], fB[PPT][NX];
+        int tb = (int)blockIdx.x;
+        fetch(tb, 0, fA);
 #pragma unroll 1
-        for (int tb = (int)blockIdx.x; tb < ntb; tb += (int)gridDim.x, ++itn) tile(tb, itn);
+        for (;;) {
+            const int tb1 = tb + G;
+            if (tb1 < ntb) fetch(tb1, 1, fB);
+            tile(tb, 0, fA);
+            if (tb1 >= ntb) break;
+            tb = tb1 + G;
+            if (tb < ntb) fetch(tb, 0, fA);
+            tile(tb1, 1, fB);
+            if (tb >= ntb) break;
+        }
     } else {
-        tile((int)blockIdx.x, 0);
+        tile((int)blockIdx.x, 0, nullptr);
     }
     STEP_STAMP(5, bmax);                // weights, exp-sums, stores issued
     if (MODE != MODE_PROP) {
-        const double r = block_max(bmax, sm_max);
-        const int anybad = __syncthreads_or(bad ? 1 : 0);
-        if (threadIdx.x == 0) acc_max(b.acc + (size_t)f * ACC_WORDS, a.parity, r, anybad != 0);
-        if (a.accumulate) wacc.flush(b.acc + (size_t)f * ACC_WORDS, a.parity, a.need_e2 != 0, sm_acc);
+        block_flush(b.acc + (size_t)f * ACC_WORDS, a.parity, bmax, bad, wacc, a.accumulate != 0, a.need_e2 != 0, sm_fl);
         if (a.accumulate && a.want_xmean) block_store_xm<NX>(xm, b.xmpart + ((size_t)f * b.P1 + blockIdx.x) * MAXD, sm_x);
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             FilterScal* scw = b.scal + f;

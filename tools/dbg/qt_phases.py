@@ -23,14 +23,23 @@ for w in (0, 1):
     assert L.llpf_debug_timing_arm(w, ctypes.c_int64(nb[w])) == 0
 pf.reset()
 pf.run(U, Y, 1.0)
-names = [["", "scalars back, tables in LDS", "marks back and scanned", "f(x[anc]) gathered", "noise drawn, particles formed",
-          "weights, exp-sums, stores issued", "block reductions, atomics"],
-         ["", "head", "scan + counts", "survivors listed", "x of survivors back, own marks", "heavy / stale marks", "dynamics + stores"]]
-for w, title in ((1, "k_resample_fx"), (0, "k_step")):
+NAMES = {"k_step": ["", "scalars back, tables in LDS", "marks back and scanned", "f(x[anc]) gathered", "noise drawn, particles formed",
+                    "weights, exp-sums, stores issued", "block reductions, atomics"],
+         "k_resample_fx": ["", "head", "scan + counts", "survivors listed", "x of survivors back, own marks", "heavy / stale marks", "dynamics + stores"],
+         "k_fxstep": ["", "head", "noise of tile A", "scan + counts", "survivors, marks, noise of tile B", "heavy marks, dynamics + stores", "grid barrier",
+                      "both output tiles", "block reductions, atomics"]}
+for w in (1, 0):
     buf = np.zeros((nb[w], 16), dtype=np.uint64)
     assert L.llpf_debug_timing_read(w, buf.ctypes.data_as(ctypes.c_void_p)) == 0
-    st = buf[:, :7].astype(np.int64)
-    ok = st[:, 6] > 0
+    fused = w == 1 and (buf[:, 8] > 1 << 20).any()
+    title = "k_fxstep" if fused else ("k_resample_fx" if w == 1 else "k_step")
+    names = NAMES[title]
+    last = len(names) - 1
+    st = buf[:, :last + 1].astype(np.int64)
+    ok = st[:, last] > 0
+    if ok.sum() == 0:
+        print("== %s: no stamps" % title)
+        continue
     print("== %s: %d blocks, %d stamped to the end" % (title, nb[w], ok.sum()))
     hw = buf[:, 13].astype(np.int64)
     xcc = buf[:, 14].astype(np.int64) & 0xf
@@ -42,7 +51,7 @@ for w, title in ((1, "k_resample_fx"), (0, "k_step")):
         m = ok & (cu == c)
         z = st[m, 0].min()
         start[m] = st[m, 0] - z
-        end[m] = st[m, 6] - z
+        end[m] = st[m, last] - z
     ids, cnt = np.unique(cu[ok], return_counts=True)
     print("CUs seen %d; blocks per CU: %s" % (len(ids), dict(zip(*np.unique(cnt, return_counts=True)))))
     early = ok & (start < 3000)
@@ -51,15 +60,10 @@ for w, title in ((1, "k_resample_fx"), (0, "k_step")):
         if sel.sum() == 0:
             continue
         print("blocks that %s: %d; start p50 %d, end p50 %d p90 %d max %d" % (nm, sel.sum(), np.median(start[sel]), np.median(end[sel]), np.percentile(end[sel], 90), end[sel].max()))
-        for k in range(1, 7):
+        for k in range(1, last + 1):
             d = (st[:, k] - st[:, k - 1])[sel]
-            print("    %-36s median %6d  p10 %6d  p90 %6d  max %6d" % (names[w][k], np.median(d), np.percentile(d, 10), np.percentile(d, 90), d.max()))
-        print("    %-36s median %6d" % ("whole block", np.median((st[:, 6] - st[:, 0])[sel])))
-    if w == 1:
+            print("    %-36s median %6d  p10 %6d  p90 %6d  max %6d" % (names[k], np.median(d), np.percentile(d, 10), np.percentile(d, 90), d.max()))
+        print("    %-36s median %6d" % ("whole block", np.median((st[:, last] - st[:, 0])[sel])))
+    if title == "k_resample_fx":
         D = buf[ok, 8].astype(np.int64); H = buf[ok, 9].astype(np.int64); outs = buf[ok, 10].astype(np.int64)
         print("survivors per tile: mean %.2f max %d, total %d; heavy sources %d; outputs per tile max %d" % (D.mean(), D.max(), D.sum(), H.sum(), outs.max()))
-        tot = (st[:, 6] - st[:, 0])[ok]
-        for lo, hi in ((0, 0), (1, 1), (2, 3), (4, 1 << 30)):
-            m = (D >= lo) & (D <= hi)
-            if m.sum():
-                print("    tiles with %d..%d survivors: %d, whole block median %d" % (lo, min(hi, D.max()), m.sum(), np.median(tot[m])))
