@@ -250,12 +250,26 @@ int  llpf_smooth(llpf_filter* f, int64_t M, const double* U, int64_t T, const do
  * csrc/shared/llpf_detmath.h — is in scope, and the source is compiled with -ffp-contract=off like the engine.)  The snippet is
  * compiled with hiprtc for the visible device into the engine's own step kernel; *model_id (>= LLPF_MODEL_USER_BASE) then goes
  * into llpf_model.model_id with the same nx, ny (1..4 each: the kernels around the compiled one are precompiled for those).  Process
- * noise and initial density remain the Gaussian descriptors of llpf_model, and so does the measurement likelihood unless the snippet
- * defines `loglik` (measurement_density is then unused, but must still be a valid Gaussian of dimension ny).  Such filters and banks
+ * noise and initial density are the Gaussian descriptors of llpf_model unless the snippet defines `noise` / `initial` (below), and so is
+ * the measurement likelihood unless the snippet defines `loglik` (measurement_density is then unused, but must still be a valid Gaussian of dimension ny).  Such filters and banks
  * run the balanced two-launch timestep; the auxiliary verbs and the smoother work (their kernels are compiled with the snippet too), the
  * Rao-Blackwellized forms are not provided for them.  Compiling the same (source, nx, ny) again returns the same id.
  * On failure the compiler log is in llpf_last_error(). */
 int  llpf_model_compile(const char* device_src, int32_t nx, int32_t ny, int32_t* model_id);
+/* Optional members of the snippet, beyond `loglik` / `loglik_bound` (round 4) — the random part of the step in the user's hands:
+ *   DEV void noise(const double* x, const double* fx, const double* xi, const double* uu, double* out) const;
+ *       the next state of a particle with previous state x and noise-free prediction fx = dynamics(x), from nx standard normals xi and nx
+ *       uniforms uu in [0,1) of the particle's own Philox streams; replaces out = fx + rand(dynamics_density).  The reference's
+ *       AdvancedParticleFilter hands the noise to the user the same way — dynamics(x, u, p, t, noise = true), src/PFtypes.jl:242-259,
+ *       test/runtests.jl:553-599 — and its ParticleFilter draws from ANY dynamics_density (rand!(rng, d, noise), src/PFtypes.jl:122-139).
+ *       (dynamics_density is then unused by the propagate but must still be a valid Gaussian; the FFBS smoother, whose backward weights
+ *       are logpdf(dynamics_density, .), and the auxiliary filter over a LLPF_PARTICLE_FILTER, whose add_noise! draws from it, keep using it.)
+ *   DEV void initial(const double* xi, const double* uu, double* out) const;
+ *       one draw of the initial density: x_i = rand(rng, initial_density) of reset! / the constructor (src/filtering.jl:4-14, src/PFtypes.jl:66).
+ * llpf_model_traits reports which optional members a compiled model has (bit set of LLPF_TRAIT_*), so that a binding can refuse a
+ * UserLikelihood paired with a snippet without `loglik`, or a Gaussian likelihood paired with a snippet that defines one. */
+enum { LLPF_TRAIT_LOGLIK = 1, LLPF_TRAIT_LOGLIK_BOUND = 2, LLPF_TRAIT_NOISE = 4, LLPF_TRAIT_INITIAL = 8 };
+int  llpf_model_traits(int32_t model_id, int32_t* traits);
 
 /* ---- accessors (reference src/PFtypes.jl:296-334) --------------------------------------- */
 int  llpf_num_particles(const llpf_filter* f, int64_t* n);                /* num_particles(pf) */

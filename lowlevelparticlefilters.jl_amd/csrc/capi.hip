@@ -283,6 +283,13 @@ int llpf_weighted_mean(llpf_filter* f, double* xh) {
     return LLPF_OK;
 }
 int llpf_resample_count(llpf_filter* f, int64_t* n) { NEEDF(f); if (n) *n = f->bank.run_resamples; return LLPF_OK; }
+int llpf_model_traits(int32_t model_id, int32_t* traits) {
+    if (!traits) return fail(LLPF_ERR_ARG, "null pointer");
+    const int t = jit_model_traits(model_id);
+    if (t < 0) return fail(LLPF_ERR_ARG, "llpf_model_traits: not the id of a run-time compiled model");
+    *traits = t;
+    return LLPF_OK;
+}
 int llpf_last_run_stats(llpf_filter* f, int64_t* fused_launches, int64_t* persistent_timesteps) {
     NEEDF(f);
     if (fused_launches) *fused_launches = f->bank.last_run_launches;

@@ -216,7 +216,6 @@ struct SmoothArgs {
     int32_t M;
     uint32_t step;          // Philox step of the draws (= t)
 };
-// ---- end of the part the run-time compiled user-model kernels see (tools/gen_jit_prelude.py cuts here) ----
 enum { RES_FINALIZE = 1, RES_RESAMPLE = 2 };
 
 // arguments of the resample(+finalize) kernel
@@ -247,8 +246,11 @@ struct ResArgs {
     uint64_t* dbg;         // optional [P2][8] phase timestamps of one launch (s_memrealtime, 100 MHz), or nullptr
 };
 
+// ---- end of the part the run-time compiled user-model kernels see (tools/gen_jit_prelude.py cuts here) ----
 // launchers (kernels.hip)
 hipError_t launch_init(const BankDev& b, uint32_t step, int init_anc, hipStream_t s);
+hipError_t launch_init_user(const BankDev& b, const double* zero_u, uint32_t step, int init_anc, hipStream_t s);   // kernels/jit.hpp: UserModel::initial
+int jit_model_traits(int model_id);   // LLPF_TRAIT_* bits of a run-time compiled model (-1: unknown id)
 hipError_t launch_rbfull_jit(int fn_kind, int nn, int nl, int ny, const BankDev& b, int mode, const StepArgs& a, hipStream_t s);   // kernels/jit.hpp
 int jit_prepare_rbfull(int fn_kind, int nn, int nl, int ny, std::string& err);   // compiles the shape if needed (bank construction reports the log)
 int jit_builtin_lg(int nx, int ny, std::string& err);   // kernels/jit.hpp: LinGauss<nx, ny> compiled on demand (nx or ny above 4), id as a user model

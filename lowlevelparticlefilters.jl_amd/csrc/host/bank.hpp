@@ -228,7 +228,10 @@ static int bank_init_particles(Bank& b, bool is_reset) {
     HIPC(hipMemsetAsync(b.d_tileq, 0, sizeof(uint64_t) * (size_t)ACC_NSLOT * b.F * b.P2, b.stream));
     HIPC(hipMemsetAsync(b.d_flag, 0, sizeof(uint32_t) * 4, b.stream));
     b.parity = 0;
-    HIPC(launch_init(d, b.n_reset, is_reset ? 0 : 1, b.stream));
+    if (b.cfg.model.model_id >= LLPF_MODEL_USER_BASE && (jit_model_traits(b.cfg.model.model_id) & LLPF_TRAIT_INITIAL) > 0)
+        HIPC(launch_init_user(d, b.d_uy, b.n_reset, is_reset ? 0 : 1, b.stream));      // an initial density of the model's own (d_uy is zero-filled)
+    else
+        HIPC(launch_init(d, b.n_reset, is_reset ? 0 : 1, b.stream));
     if (is_rbfull(b)) HIPC(launch_rbfull_init(d, b.stream));
     b.n_reset++;
     b.t_index = is_reset ? 1 : 0;
@@ -309,6 +312,11 @@ static int bank_create(const llpf_config* cfg, const llpf_model* models, int F, 
         b.hmodels[f] = mf;
         if (mf.model_id != m0.model_id || mf.nx != m0.nx || mf.nu != m0.nu || mf.ny != m0.ny)
             return fail(LLPF_ERR_ARG, "all filters of a bank must share model id and dimensions");
+        // the kernel instance (shape, nonlinear part), the rows of a particle plane and BankDev::pad0 are taken from models[0]
+        if (m0.model_id == LLPF_MODEL_RB_BILINEAR && (mf.rb.nxl != m0.rb.nxl || mf.rb.fn_kind != m0.rb.fn_kind))
+            return fail(LLPF_ERR_ARG, "all filters of a bank must share model id and dimensions (LLPF_MODEL_RB_BILINEAR: also rb.nxl and rb.fn_kind)");
+        if (m0.model_id == LLPF_MODEL_RB_LINEAR && mf.nxn != m0.nxn)
+            return fail(LLPF_ERR_ARG, "all filters of a bank must share model id and dimensions (LLPF_MODEL_RB_LINEAR: also nxn)");
         int rc = model_prepare(&mf, &hm[f]);
         if (rc) return fail(LLPF_ERR_ARG, "invalid density (covariance not positive definite or dimension mismatch), code " + std::to_string(rc));
     }

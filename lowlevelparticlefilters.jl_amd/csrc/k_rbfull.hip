@@ -11,6 +11,8 @@ __device__ unsigned long long* g_rbf_dbg;
 __shared__ unsigned int g_rbf_row;      // the batch a persistent wave has in hand: the row its stamps go to
 #endif
 #endif
+#include <atomic>
+
 #include "engine.hpp"
 
 namespace llpf {
@@ -42,15 +44,17 @@ int rbfull_rows(int nn, int nl) { return nn + nl + LLPF_RBF_NP(nl); }
 unsigned rbfull_grid_x(const BankDev& b, int nl, int mode) {
     const unsigned nbatch = (unsigned)(b.Ns / RBF_BLOCK);
     if (nl < 8 || mode == MODE_WEIGHT) return nbatch;
-    static int cus[64] = {0};
+    static std::atomic<int> cus[64];     // per ordinal; filled on first use (distinct handles may be driven from distinct host threads)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nbatch;
-    if (cus[dev] == 0) {
+    int nc = cus[dev].load(std::memory_order_relaxed);
+    if (nc == 0) {
         int n = 0;
-        cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : -1;
+        nc = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : -1;
+        cus[dev].store(nc, std::memory_order_relaxed);
     }
-    if (cus[dev] < 0) return nbatch;
-    const unsigned resident = (unsigned)cus[dev] * 4u * (unsigned)LLPF_RBF_WAVES;
+    if (nc < 0) return nbatch;
+    const unsigned resident = (unsigned)nc * 4u * (unsigned)LLPF_RBF_WAVES;
     const unsigned per_filter = resident / (unsigned)(b.F > 0 ? b.F : 1);
     return nbatch < per_filter ? nbatch : (per_filter > 0 ? per_filter : 1u);
 }

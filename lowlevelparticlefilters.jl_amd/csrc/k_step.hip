@@ -157,12 +157,14 @@ hipError_t launch_step(const BankDev& b, int mode, const StepArgs& a, hipStream_
 // ---- resampling with source-side dynamics (kernels/resfx.hpp) ----
 bool resample_fx_supported(int model_id, int nx, int ny, int strategy) {
     if (strategy != LLPF_RESAMPLE_SYSTEMATIC && strategy != LLPF_RESAMPLE_STRATIFIED) return false;   // residual ancestors are not sorted
+    if (model_id >= LLPF_MODEL_USER_BASE) return jit_marks(model_id);
     return model_id == LLPF_MODEL_QUADTANK_RK4 && nx == 4 && ny == 2 && LLPF_QT_PPT == STEP_PPT;
 }
 hipError_t launch_resample_fx(const BankDev& b, const ResArgs& a0, const StepArgs& st, hipStream_t s) {
     if (!resample_fx_supported(b.model_id, b.nx, b.ny, b.strategy) || !b.mark || !b.fxs) return hipErrorInvalidValue;
     ResArgs a = a0;
     a.K = llpf_qbits(b.N);
+    if (b.model_id >= LLPF_MODEL_USER_BASE) return launch_resample_fx_user(b, a, st, s);
     const dim3 g((unsigned)b.P2, (unsigned)b.F, 1);
     if (b.strategy == LLPF_RESAMPLE_SYSTEMATIC) hipLaunchKernelGGL((k_resample_fx<QuadTank<4, 2>, 4, LLPF_RESAMPLE_SYSTEMATIC>), g, dim3(BLOCK), 0, s, b, a, st);
     else hipLaunchKernelGGL((k_resample_fx<QuadTank<4, 2>, 4, LLPF_RESAMPLE_STRATIFIED>), g, dim3(BLOCK), 0, s, b, a, st);

@@ -19,9 +19,14 @@ struct JitModel {
     int nx = 0, ny = 0;
     std::string src;                           // the snippet: a second llpf_model_compile of the same (source, nx, ny) returns the same id
     std::vector<char> code;
-    std::string name[6];                       // lowered names of k_step<UserModel, nx, ny, MODE, STEP_PPT>, MODE = 0..3; [4]: k_user_bound<UserModel>;
-                                               // [5]: k_smooth_fx<UserModel, nx, ny>
-    struct PerDevice { hipModule_t mod = nullptr; hipFunction_t fn[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; };
+    static constexpr int NK = 12;
+    std::string name[NK];                      // lowered names of k_step<UserModel, nx, ny, MODE, STEP_PPT>, MODE = 0..3; [4]: k_user_bound<UserModel>;
+                                               // [5]: k_smooth_fx<UserModel, nx, ny>; models whose dynamics are worth a table (marks): [6], [7]:
+                                               // k_step<..., MODE_PROP / MODE_PROP_WEIGHT, STEP_PPT, true>; [8], [9]: k_resample_fx<UserModel, nx, systematic / stratified>;
+                                               // [10]: k_init_user<UserModel, nx>; [11]: k_traits_tag<model_traits<UserModel>::value> (never launched)
+    bool marks = false;
+    int traits = 0;                            // LLPF_TRAIT_*: the optional members the snippet defines
+    struct PerDevice { hipModule_t mod = nullptr; hipFunction_t fn[NK] = {}; };
     std::vector<PerDevice> dev;                // indexed by device ordinal, loaded on first use
 };
 static std::mutex g_jit_mutex;
@@ -54,18 +59,31 @@ static int jit_compile_model(const char* device_src, int nx, int ny, bool intern
     src += "\n}  // namespace llpf\n";
     hiprtcProgram prog = nullptr;
     if (hiprtcCreateProgram(&prog, src.c_str(), "llpf_user_model.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) { err = "hiprtcCreateProgram failed"; return -1; }
-    std::string expr[6];
+    std::string expr[JitModel::NK];
     for (int mode = 0; mode < 4; ++mode)
         expr[mode] = "llpf::k_step<llpf::UserModel, " + std::to_string(nx) + ", " + std::to_string(ny) + ", " + std::to_string(mode) + ", " + std::to_string(STEP_PPT) + ">";
     expr[4] = "llpf::k_user_bound<llpf::UserModel>";
     expr[5] = "llpf::k_smooth_fx<llpf::UserModel, " + std::to_string(nx) + ", " + std::to_string(ny) + ">";
-    for (int mode = 0; mode < 6; ++mode) hiprtcAddNameExpression(prog, expr[mode].c_str());
+    // a user's dynamics are taken to be worth a table (share_dynamics, kernels/models.hpp): the resampling launch evaluates them once per
+    // surviving source and the step kernel gathers (kernels/resfx.hpp); the internally generated linear-Gaussian snippet opts out
+    const bool marks = !internal;
+    const int nk = marks ? JitModel::NK : 6;
+    if (marks) {
+        expr[10] = "llpf::k_init_user<llpf::UserModel, " + std::to_string(nx) + ">";
+        expr[11] = "llpf::k_traits_tag<llpf::model_traits<llpf::UserModel>::value>";
+        for (int m = 0; m < 2; ++m)
+            expr[6 + m] = "llpf::k_step<llpf::UserModel, " + std::to_string(nx) + ", " + std::to_string(ny) + ", " + std::to_string(m == 0 ? (int)MODE_PROP : (int)MODE_PROP_WEIGHT) + ", " + std::to_string(STEP_PPT) + ", true>";
+        expr[8] = "llpf::k_resample_fx<llpf::UserModel, " + std::to_string(nx) + ", " + std::to_string((int)LLPF_RESAMPLE_SYSTEMATIC) + ">";
+        expr[9] = "llpf::k_resample_fx<llpf::UserModel, " + std::to_string(nx) + ", " + std::to_string((int)LLPF_RESAMPLE_STRATIFIED) + ">";
+    }
+    for (int mode = 0; mode < nk; ++mode) hiprtcAddNameExpression(prog, expr[mode].c_str());
     int devid = 0;
     hipDeviceProp_t prop;
     std::string arch = "gfx950";
     if (hipGetDevice(&devid) == hipSuccess && hipGetDeviceProperties(&prop, devid) == hipSuccess && prop.gcnArchName[0]) arch = prop.gcnArchName;
     const std::string archopt = "--offload-arch=" + arch;
-    const char* opts[] = {archopt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-Wno-unused-value"};
+    // -disable-machine-licm: as for k_step.hip (Makefile) — the tile loop of k_step<..., MARKS>
+    const char* opts[] = {archopt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-Wno-unused-value", "-mllvm", "-disable-machine-licm"};
     const hiprtcResult rc = hiprtcCompileProgram(prog, (int)(sizeof(opts) / sizeof(opts[0])), opts);
     if (rc != HIPRTC_SUCCESS) {
         size_t n = 0;
@@ -77,18 +95,27 @@ static int jit_compile_model(const char* device_src, int nx, int ny, bool intern
         return -1;
     }
     JitModel* jm = new JitModel();
-    jm->nx = nx; jm->ny = ny; jm->src = device_src;
+    jm->nx = nx; jm->ny = ny; jm->src = device_src; jm->marks = marks;
     size_t sz = 0;
     hiprtcGetCodeSize(prog, &sz);
     jm->code.resize(sz);
     hiprtcGetCode(prog, jm->code.data());
-    for (int mode = 0; mode < 6; ++mode) {
+    for (int mode = 0; mode < nk; ++mode) {
         const char* low = nullptr;
         if (hiprtcGetLoweredName(prog, expr[mode].c_str(), &low) != HIPRTC_SUCCESS || !low) { err = "hiprtcGetLoweredName failed for " + expr[mode]; delete jm; hiprtcDestroyProgram(&prog); return -1; }
         jm->name[mode] = low;
     }
+    if (marks) {      // "...k_traits_tagILi<value>EEEvv": what the snippet provides, without running anything
+        const size_t at = jm->name[11].find("k_traits_tagILi");
+        if (at == std::string::npos) { err = "could not read the model's traits from " + jm->name[11]; delete jm; hiprtcDestroyProgram(&prog); return -1; }
+        jm->traits = atoi(jm->name[11].c_str() + at + 15);
+        if (jm->traits & LLPF_TRAIT_NOISE) jm->marks = false;      // a model that forms its own noise needs x next to f(x): inline dynamics
+    }
     hiprtcDestroyProgram(&prog);
     std::lock_guard<std::mutex> lk(g_jit_mutex);
+    // two threads may have compiled the same snippet side by side: the first registration wins, "the same (source, nx, ny) returns the same id"
+    for (size_t k = 0; k < g_jit_models.size(); ++k)
+        if (g_jit_models[k]->nx == nx && g_jit_models[k]->ny == ny && g_jit_models[k]->src == device_src) { delete jm; return LLPF_MODEL_USER_BASE + (int)k; }
     g_jit_models.push_back(jm);
     return LLPF_MODEL_USER_BASE + (int)g_jit_models.size() - 1;
 }
@@ -136,18 +163,49 @@ hipError_t launch_smooth_fx_user(const BankDev& b, const SmoothArgs& a, hipStrea
     void* args[] = {&bd, &models, &aa};
     return hipModuleLaunchKernel(fn, (unsigned)((b.N + BLOCK - 1) / BLOCK), 1, 1, BLOCK, 1, 1, 0, s, args, nullptr);
 }
+int jit_model_traits(int model_id) { JitModel* jm = jit_model(model_id); return jm ? jm->traits : -1; }
+// reset! of a model with an initial density of its own (UserModel::initial)
+hipError_t launch_init_user(const BankDev& b, const double* zero_u, uint32_t step, int init_anc, hipStream_t s) {
+    JitModel* jm = jit_model(b.model_id);
+    if (!jm || !(jm->traits & LLPF_TRAIT_INITIAL)) return hipErrorInvalidValue;
+    hipFunction_t fn = nullptr;
+    hipError_t e = jit_function(jm, 10, &fn);
+    if (e != hipSuccess) return e;
+    BankDev bd = b;
+    const ModelD* models = b.models;
+    const FilterScal* scal = b.scal;
+    void* args[] = {&bd, &models, &scal, &zero_u, &step, &init_anc};
+    return hipModuleLaunchKernel(fn, (unsigned)((b.Ns + BLOCK - 1) / BLOCK), (unsigned)b.F, 1, BLOCK, 1, 1, 0, s, args, nullptr);
+}
+static unsigned step_grid_x_marks(const BankDev& b);      // k_step.hip
+static bool jit_marks(int model_id) { JitModel* jm = jit_model(model_id); return jm && jm->marks; }
 static hipError_t launch_step_user(const BankDev& b, int mode, const StepArgs& a, hipStream_t s) {
     JitModel* jm = jit_model(b.model_id);
     if (!jm || mode < 0 || mode > 3) return hipErrorInvalidValue;
+    const bool marks = a.marks && jm->marks && (mode == MODE_PROP || mode == MODE_PROP_WEIGHT);      // the form that follows k_resample_fx
+    if (marks && (!b.mark || !b.fxs)) return hipErrorInvalidValue;
     hipFunction_t fn = nullptr;
-    hipError_t e = jit_function(jm, mode, &fn);
+    hipError_t e = jit_function(jm, marks ? (mode == MODE_PROP ? 6 : 7) : mode, &fn);
     if (e != hipSuccess) return e;
     BankDev bd = b;
     const ModelD* models = b.models;
     const FilterScal* scal = b.scal;
     StepArgs aa = a;
     void* args[] = {&bd, &models, &scal, &aa};
-    return hipModuleLaunchKernel(fn, (unsigned)(b.Ns / (BLOCK * STEP_PPT)), (unsigned)b.F, 1, BLOCK, 1, 1, 0, s, args, nullptr);
+    const unsigned gx = marks ? step_grid_x_marks(b) : (unsigned)(b.Ns / (BLOCK * STEP_PPT));
+    return hipModuleLaunchKernel(fn, gx, (unsigned)b.F, 1, BLOCK, 1, 1, 0, s, args, nullptr);
+}
+static hipError_t launch_resample_fx_user(const BankDev& b, const ResArgs& a, const StepArgs& st, hipStream_t s) {
+    JitModel* jm = jit_model(b.model_id);
+    if (!jm || !jm->marks) return hipErrorInvalidValue;
+    hipFunction_t fn = nullptr;
+    hipError_t e = jit_function(jm, b.strategy == LLPF_RESAMPLE_SYSTEMATIC ? 8 : 9, &fn);
+    if (e != hipSuccess) return e;
+    BankDev bd = b;
+    ResArgs aa = a;
+    StepArgs ss = st;
+    void* args[] = {&bd, &aa, &ss};
+    return hipModuleLaunchKernel(fn, (unsigned)b.P2, (unsigned)b.F, 1, BLOCK, 1, 1, 0, s, args, nullptr);
 }
 
 // ---- k_rbfull for shapes the library was not precompiled for (kernels/rbfull.hpp is part of the prelude) -----------------------------
@@ -207,6 +265,7 @@ int jit_prepare_rbfull(int fk, int nn, int nl, int ny, std::string& err) {
     }
     hiprtcDestroyProgram(&prog);
     std::lock_guard<std::mutex> lk(g_jit_mutex);
+    if (jit_rbfull_find(fk, nn, nl, ny)) { delete j; return 0; }      // another thread registered the shape meanwhile
     g_jit_rbfull.push_back(j);
     return 0;
 }

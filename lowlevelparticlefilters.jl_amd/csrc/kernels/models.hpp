@@ -415,10 +415,25 @@ struct NoModel {
     DEV void measurement(const double*, double*) const {}
 };
 
+// Optional hooks of a model (run-time compiled user models, kernels/jit.hpp) for the random part of the step:
+//   DEV void noise(const double* x, const double* fx, const double* xi, const double* uu, double* out) const
+//        the NEXT state of a particle whose previous state is x and whose noise-free prediction is fx = dynamics(x), given nx standard
+//        normals xi and nx uniforms uu in [0, 1) of the particle's own Philox streams — replaces out = fx + (mu + L xi) of the Gaussian
+//        descriptor: state-dependent / multiplicative noise, heavy tails, anything.  This is the reference's AdvancedParticleFilter
+//        contract, dynamics(x, u, p, t, noise = true) "adds its own noise" (src/PFtypes.jl:242-259), and a ParticleFilter whose
+//        dynamics_density is not Gaussian (rand!(rng, d, noise), src/PFtypes.jl:122-139)
+//   DEV void initial(const double* xi, const double* uu, double* out) const
+//        one draw of the initial density (reset! / the constructor: x_i = rand(rng, initial_density), src/filtering.jl:4-14)
+// detected without <type_traits> (hiprtc has no system headers)
+template <class M, class = void> struct has_user_noise { static constexpr bool value = false; };
+template <class M> struct has_user_noise<M, decltype((void)&M::noise)> { static constexpr bool value = true; };
+template <class M, class = void> struct has_user_initial { static constexpr bool value = false; };
+template <class M> struct has_user_initial<M, decltype((void)&M::initial)> { static constexpr bool value = true; };
+
 // Is f(x) expensive enough to be computed once per distinct ancestor of a block and handed to the outputs that share it
 // (k_step)?  Yes unless the model says otherwise: run-time compiled user models and the quad-tank's RK4 are; a matrix-vector
-// product is not.
-template <class Model> struct share_dynamics { static constexpr bool value = true; };
+// product is not, and a model that forms its own noise needs x next to f(x) anyway.
+template <class Model> struct share_dynamics { static constexpr bool value = !has_user_noise<Model>::value; };
 template <int NX, int NY> struct share_dynamics<LinGauss<NX, NY>> { static constexpr bool value = false; };
 template <int NX, int NY> struct share_dynamics<RBLin<NX, NY>> { static constexpr bool value = false; };
 template <int NX> struct share_dynamics<NoModel<NX>> { static constexpr bool value = false; };

@@ -24,8 +24,8 @@
 template <class Model, int NX, int NY, int MODE, int PPT = STEP_PPT, bool MARKS = false>
 __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restrict__ models,
                                                  const FilterScal* scal, StepArgs a) {
-    static_assert(!MARKS || (share_dynamics<Model>::value && !Model::RB && PPT == STEP_PPT && (MODE == MODE_PROP || MODE == MODE_PROP_WEIGHT)),
-                  "the marks form: models whose dynamics are worth a table, propagating modes, two particles per thread");
+    static_assert(!MARKS || (!Model::RB && PPT == STEP_PPT && (MODE == MODE_PROP || MODE == MODE_PROP_WEIGHT)),
+                  "the marks form: propagating modes, two particles per thread (launched for models whose dynamics are worth a table)");
     __shared__ uint64_t sm_fl[BLOCK / 64][8];
     __shared__ double sm_x[BLOCK / 64][MAXD];
     // dynamics shared between the outputs of one ancestor (below): models whose f is worth a table
@@ -270,6 +270,14 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
                 if (MODE == MODE_AUX) {            // propagate_particles!(pf, u, p, t, nothing): no noise
 #pragma unroll
                     for (int d = 0; d < NX; ++d) xs[p][d] = fx[d];
+                } else if constexpr (has_user_noise<Model>::value && !MARKS) {
+                    // the model adds its own noise (AdvancedParticleFilter: dynamics(x, u, p, t, noise = true), PFtypes.jl:254; a
+                    // ParticleFilter with any dynamics_density, :135): nx normals and nx uniforms of the particle's own streams
+                    double uu[NX];
+                    if constexpr (LTAB) llpf_normals_tab((uint32_t)(i0 + p), sb + a.step, LLPF_STREAM_DYNAMICS, k0, k1, NX, xi, sh_rng_lg, sh_rng_sc);
+                    else llpf_normals((uint32_t)(i0 + p), sb + a.step, LLPF_STREAM_DYNAMICS, k0, k1, NX, xi);
+                    llpf_uniforms((uint32_t)(i0 + p), sb + a.step, LLPF_STREAM_USER, k0, k1, NX, uu);
+                    model.noise(xp[p], fx, xi, uu, xs[p]);
                 } else {
                     if constexpr (LTAB) llpf_normals_tab((uint32_t)(i0 + p), sb + a.step, LLPF_STREAM_DYNAMICS, k0, k1, NX, xi, sh_rng_lg, sh_rng_sc);
                     else llpf_normals((uint32_t)(i0 + p), sb + a.step, LLPF_STREAM_DYNAMICS, k0, k1, NX, xi);
@@ -455,6 +463,38 @@ __global__ void k_user_bound(ModelD* models, const double* zero_u) {
         }
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// k_init_user — reset! / the constructor's draw for a model with an initial density of its own (UserModel::initial):
+// x_i = rand(rng, initial_density), reference src/filtering.jl:4-14, src/PFtypes.jl:66.  Everything else as k_init (kernels/init.hpp).
+// ------------------------------------------------------------------------------------------------
+template <class Model, int NX>
+__global__ __launch_bounds__(BLOCK) void k_init_user(BankDev b, const ModelD* __restrict__ models, const FilterScal* __restrict__ scal,
+                                                      const double* zero_u, uint32_t step, int init_anc) {
+    if constexpr (has_user_initial<Model>::value) {
+        const int f = blockIdx.y;
+        const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+        if (i >= b.Ns) return;
+        Model model;
+        model.prepare(models + f, zero_u, 0.0);
+        double xi[NX], uu[NX], x0[NX];
+        llpf_normals((uint32_t)i, step, LLPF_STREAM_INIT, scal[f].k0, scal[f].k1, NX, xi);
+        llpf_uniforms((uint32_t)i, step, LLPF_STREAM_USER_INIT, scal[f].k0, scal[f].k1, NX, uu);
+        model.initial(xi, uu, x0);
+        double* xc = b.xcur + (size_t)f * b.xrows * b.Ns;
+#pragma unroll
+        for (int d = 0; d < NX; ++d) xc[(size_t)d * b.Ns + i] = x0[d];
+        b.w[(size_t)f * b.Ns + i] = -LLPF_INF;
+        if (init_anc) b.anc[(size_t)f * b.Ns + i] = (i < b.N) ? (int32_t)i : 0;
+    }
+}
+
+// what a run-time compiled model provides: the instantiation's template argument is read back from its lowered name (kernels/jit.hpp)
+template <int TRAITS> __global__ void k_traits_tag() {}
+template <class Model> struct model_traits {
+    static constexpr int value = (has_loglik<Model>::value ? LLPF_TRAIT_LOGLIK : 0) | (has_loglik_bound<Model>::value ? LLPF_TRAIT_LOGLIK_BOUND : 0) |
+                                 (has_user_noise<Model>::value ? LLPF_TRAIT_NOISE : 0) | (has_user_initial<Model>::value ? LLPF_TRAIT_INITIAL : 0);
+};
 
 // ------------------------------------------------------------------------------------------------
 // k_max — maxima of the raw log-weights (when no weighting kernel produced them: llpf_set_weights,

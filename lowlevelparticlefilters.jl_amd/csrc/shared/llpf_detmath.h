@@ -37,10 +37,22 @@ LLPF_HD double   llpf_fma(double a, double b, double c) { return __builtin_fma(a
 #ifndef LLPF_HORNER_C
 #define LLPF_HORNER_C(c) "s"(c)      /* the constant as an SGPR pair: built by the scalar unit, no VGPR moves */
 #endif
-LLPF_HD double   llpf_horner(double q, double r, double c) {
+/* Horner step q r + c pinned to the three-address v_fma_f64.  llpf_horner_k: the engine's own polynomial sites, whose c is a
+ * LITERAL — bound as an SGPR pair by default (LLPF_HORNER_C), i.e. c must be wave-uniform; llpf_horner: any operands (this header is
+ * part of the prelude of run-time compiled user models, where a per-lane c would silently read lane 0's value through the "s" form). */
+LLPF_HD double   llpf_horner_k(double q, double r, double c) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(LLPF_NO_ASM_HORNER)
     double d;
     asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(q), "v"(r), LLPF_HORNER_C(c));
+    return d;
+#else
+    return __builtin_fma(q, r, c);
+#endif
+}
+LLPF_HD double   llpf_horner(double q, double r, double c) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(LLPF_NO_ASM_HORNER)
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(q), "v"(r), "v"(c));
     return d;
 #else
     return __builtin_fma(q, r, c);
@@ -88,17 +100,17 @@ LLPF_HD double llpf_exp_core(double xc) {      /* xc in [-746, 709.78] or NaN */
     r = llpf_fma(-kf, LN2_LO, r);
     /* q(r) = 1/2! + r/3! + ... + r^11/13! */
     double q = 1.6059043836821613e-10;              /* 1/13! */
-    q = llpf_horner(q, r, 2.08767569878681e-09);       /* 1/12! */
-    q = llpf_horner(q, r, 2.505210838544172e-08);      /* 1/11! */
-    q = llpf_horner(q, r, 2.755731922398589e-07);      /* 1/10! */
-    q = llpf_horner(q, r, 2.7557319223985893e-06);     /* 1/9!  */
-    q = llpf_horner(q, r, 2.48015873015873e-05);       /* 1/8!  */
-    q = llpf_horner(q, r, 1.984126984126984e-04);      /* 1/7!  */
-    q = llpf_horner(q, r, 1.388888888888889e-03);      /* 1/6!  */
-    q = llpf_horner(q, r, 8.333333333333333e-03);      /* 1/5!  */
-    q = llpf_horner(q, r, 4.1666666666666664e-02);     /* 1/4!  */
-    q = llpf_horner(q, r, 1.6666666666666666e-01);     /* 1/3!  */
-    q = llpf_horner(q, r, 0.5);                        /* 1/2!  */
+    q = llpf_horner_k(q, r, 2.08767569878681e-09);       /* 1/12! */
+    q = llpf_horner_k(q, r, 2.505210838544172e-08);      /* 1/11! */
+    q = llpf_horner_k(q, r, 2.755731922398589e-07);      /* 1/10! */
+    q = llpf_horner_k(q, r, 2.7557319223985893e-06);     /* 1/9!  */
+    q = llpf_horner_k(q, r, 2.48015873015873e-05);       /* 1/8!  */
+    q = llpf_horner_k(q, r, 1.984126984126984e-04);      /* 1/7!  */
+    q = llpf_horner_k(q, r, 1.388888888888889e-03);      /* 1/6!  */
+    q = llpf_horner_k(q, r, 8.333333333333333e-03);      /* 1/5!  */
+    q = llpf_horner_k(q, r, 4.1666666666666664e-02);     /* 1/4!  */
+    q = llpf_horner_k(q, r, 1.6666666666666666e-01);     /* 1/3!  */
+    q = llpf_horner_k(q, r, 0.5);                        /* 1/2!  */
     double p = llpf_fma(r * r, q, r);               /* r + r^2 q(r) */
     double y = 1.0 + p;
     /* kf is an integer in [-1077, 1024] (or NaN, in which case y is NaN and the scale factors are irrelevant

@@ -24,7 +24,9 @@ enum {
     LLPF_STREAM_STRATIFY = 3,   /* stratified per-stratum rand()         (resample.jl:49)     */
     LLPF_STREAM_MEASURE  = 4,   /* host-side simulate() measurement noise                     */
     LLPF_STREAM_SMOOTH   = 5,   /* backward simulation: rand() of draw_one_categorical (resample.jl:137) */
-    LLPF_STREAM_SMOOTH_INIT = 6 /* backward simulation: rand() of the time-T resample (smoothing.jl:123) */
+    LLPF_STREAM_SMOOTH_INIT = 6, /* backward simulation: rand() of the time-T resample (smoothing.jl:123) */
+    LLPF_STREAM_USER     = 7,   /* uniforms handed to a model's own process noise (UserModel::noise; PFtypes.jl:135, :254) */
+    LLPF_STREAM_USER_INIT = 8   /* uniforms handed to a model's own initial density (UserModel::initial; filtering.jl:8) */
 };
 
 typedef struct { uint32_t v[4]; } llpf_philox4;
@@ -116,6 +118,18 @@ LLPF_HD void llpf_normals(uint32_t idx, uint32_t step, uint32_t stream, uint32_t
         llpf_normal_pair(idx, step, (uint32_t)b, stream, k0, k1, &z0, &z1);
         xi[2 * b] = z0;
         if (2 * b + 1 < nd) xi[2 * b + 1] = z1;
+    }
+}
+
+/* nd uniforms in [0, 1) for particle idx at a step: dims (2b, 2b+1) come from sub-block b (a model's own noise / initial density) */
+LLPF_HD void llpf_uniforms(uint32_t idx, uint32_t step, uint32_t stream, uint32_t k0, uint32_t k1, int nd, double* uu) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int b = 0; 2 * b < nd; ++b) {
+        llpf_philox4 r = llpf_philox4x32_10(idx, step, (uint32_t)b, stream, k0, k1);
+        uu[2 * b] = llpf_u01_half(r.v[0], r.v[1]);
+        if (2 * b + 1 < nd) uu[2 * b + 1] = llpf_u01_half(r.v[2], r.v[3]);
     }
 }
 
