@@ -74,6 +74,7 @@ SYMBOLS = {
     "llpf_mbank_set_profiling": [_vp, C.c_int32],
     "llpf_mbank_get_profile": [_vp, C.c_int32, _dp, _ip],
     "llpf_model_compile": [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32)],
+    "llpf_model_traits": [C.c_int32, C.POINTER(C.c_int32)],
     "llpf_set_profiling": [_vp, C.c_int32],
     "llpf_get_profile": [_vp, _dp, _ip],
     "llpf_bank_set_profiling": [_vp, C.c_int32],
@@ -602,6 +603,16 @@ def model_compile(device_src, nx, ny):
     mid = C.c_int32(-1)
     check(lib().llpf_model_compile(device_src.encode("utf-8"), int(nx), int(ny), C.byref(mid)))
     return mid.value
+
+
+TRAIT_LOGLIK, TRAIT_LOGLIK_BOUND, TRAIT_NOISE, TRAIT_INITIAL = 1, 2, 4, 8
+
+
+def model_traits(model_id):
+    """llpf_model_traits: which optional members (loglik, loglik_bound, noise, initial) a compiled model has, as TRAIT_* bits"""
+    t = C.c_int32(0)
+    check(lib().llpf_model_traits(int(model_id), C.byref(t)))
+    return t.value
 
 
 # array primitives -----------------------------------------------------------------------------------

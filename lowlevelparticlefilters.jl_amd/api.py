@@ -29,7 +29,7 @@ __all__ = [
     "particles", "weights", "expweights", "state", "num_particles", "index", "effective_particles",
     "shouldresample", "resample", "weighted_mean", "logsumexp", "simulate", "parameters",
     "dynamics", "measurement", "measurement_likelihood", "dynamics_density", "measurement_density",
-    "initial_density", "resample_threshold", "resampling_strategy", "UserDynamics", "UserMeasurement", "UserLikelihood",
+    "initial_density", "resample_threshold", "resampling_strategy", "UserDynamics", "UserMeasurement", "UserLikelihood", "UserNoise", "UserInitial",
 ]
 
 
@@ -189,12 +189,44 @@ class UserLikelihood:
         return self.host(x, u, y, p, t)
 
 
-def _build_model(dyn, meas, df, dg, d0, Ts):
+class UserNoise:
+    """dynamics_density of a filter whose model adds its own process noise: the `noise(x, fx, xi, uu, out)` member of the paired
+    UserDynamics snippet — the reference's AdvancedParticleFilter contract, dynamics(x, u, p, t, noise = true) (src/PFtypes.jl:242-259),
+    or a ParticleFilter with a dynamics_density that is not Gaussian (rand!(rng, d, noise), :122-139).  `gaussian`: the MvNormal the
+    FFBS smoother and the auxiliary filter's add_noise! keep using (default: standard normal)."""
+
+    def __init__(self, gaussian=None, host=None):
+        self.gaussian, self.host = gaussian, host
+
+
+class UserInitial:
+    """initial_density of a filter whose model draws its own initial particles: the `initial(xi, uu, out)` member of the paired
+    UserDynamics snippet (x_i = rand(rng, initial_density), reference src/filtering.jl:4-14)."""
+
+    def __init__(self, host=None):
+        self.host = host
+
+
+def _build_model(dyn, meas, df, dg, d0, Ts, user_likelihood=False):
     if isinstance(dyn, UserDynamics):
         if not isinstance(meas, UserMeasurement):
             raise TypeError("pair UserDynamics with UserMeasurement (the snippet's own measurement)")
         m = S.Model()
         m.model_id = _capi.model_compile(dyn.src, dyn.nx, dyn.ny)
+        # what the snippet defines must be what the filter was told to use: a missing member would silently fall back to the Gaussian
+        # descriptor, a present one silently override it
+        traits = _capi.model_traits(m.model_id)
+        for what, wanted, bit, member in (("measurement likelihood", user_likelihood, _capi.TRAIT_LOGLIK, "loglik"),
+                                          ("dynamics_density", isinstance(df, UserNoise), _capi.TRAIT_NOISE, "noise"),
+                                          ("initial_density", isinstance(d0, UserInitial), _capi.TRAIT_INITIAL, "initial")):
+            if wanted and not traits & bit:
+                raise TypeError("the %s is a User* descriptor but the snippet defines no `%s` member" % (what, member))
+            if not wanted and traits & bit:
+                raise TypeError("the snippet defines `%s`, which would override the Gaussian %s: pass the matching User* descriptor" % (member, what))
+        if isinstance(df, UserNoise):
+            df = df.gaussian if df.gaussian is not None else MvNormal(np.zeros(dyn.nx), 1.0)
+        if isinstance(d0, UserInitial):
+            d0 = MvNormal(np.zeros(dyn.nx), 1.0)
         m.nx, m.nu, m.ny = dyn.nx, dyn.nu, dyn.ny
         for name, mat in (("A", dyn.A), ("B", dyn.B), ("C", dyn.C)):
             if mat is not None:
@@ -231,7 +263,9 @@ class _AbstractParticleFilter:
         self.p = p
         self.threads = threads                          # accepted for signature parity; the GPU is always parallel
         self.Ts = float(Ts)
-        self._model = _build_model(dyn, meas, df, dg, d0, Ts)
+        if not isinstance(dyn, UserDynamics) and (isinstance(df, UserNoise) or isinstance(d0, UserInitial)):
+            raise TypeError("UserNoise / UserInitial are members of a UserDynamics snippet")
+        self._model = _build_model(dyn, meas, df, dg, d0, Ts, getattr(self, "_user_likelihood", False))
         self.nx, self.nu, self.ny = self._model.nx, self._model.nu, self._model.ny
         if nu not in (-1, self.nu) or ny not in (-1, self.ny):
             raise ValueError("nu / ny do not match the model descriptor")
@@ -269,6 +303,7 @@ class AdvancedParticleFilter(_AbstractParticleFilter):
     def __init__(self, N, dynamics, measurement, measurement_likelihood, dynamics_density, initial_density, *,
                  resample_threshold=0.5, resampling_strategy=ResampleSystematic, rng=None, p=None,
                  threads=False, Ts=1.0, nu=-1, ny=-1, device=0):
+        self._user_likelihood = isinstance(measurement_likelihood, UserLikelihood)
         if isinstance(measurement_likelihood, UserLikelihood):
             if not isinstance(dynamics, UserDynamics):
                 raise TypeError("a UserLikelihood is the loglik member of a UserDynamics snippet")

@@ -34,7 +34,7 @@ import LowLevelParticleFilters: AbstractParticleFilter, ParticleFilteringSolutio
 
 export GPUParticleFilter, GPUAdvancedParticleFilter, GPUAuxiliaryParticleFilter, GPURBPF, GPUFilterBank, GPUMultiBank,
        LinearDynamics, LinearMeasurement, QuadTankDynamics, QuadTankMeasurement, GaussianLikelihood,
-       RBLinearModel, RBBilinearModel, GaussianSpec, UserDynamics, UserMeasurement, UserLikelihood, linear_state, shared_covariance, loglik_multi, mbank_unique_id,
+       RBLinearModel, RBBilinearModel, GaussianSpec, UserDynamics, UserMeasurement, UserLikelihood, UserNoise, UserInitial, linear_state, shared_covariance, loglik_multi, mbank_unique_id,
        seed!, ancestors, last_resampled
 
 const LIB = get(ENV, "LLPF_HIP_LIB", joinpath(@__DIR__, "..", "libllpf_hip.so"))
@@ -265,11 +265,45 @@ struct UserLikelihood
 end
 UserLikelihood() = UserLikelihood(nothing)
 (l::UserLikelihood)(x, u, y, p, t) = l.host === nothing ? error("no host version of this device likelihood was given") : l.host(x, u, y, p, t)
-function cmodel(f::UserDynamics, ::UserMeasurement, df, dg, d0, Ts)
+"""
+    UserNoise(gaussian = nothing; host = nothing)
+
+`dynamics_density` of a filter whose model adds its own process noise: the `noise(x, fx, xi, uu, out)` member of the paired `UserDynamics`
+snippet — the reference's `AdvancedParticleFilter` contract, `dynamics(x, u, p, t, noise = true)` (src/PFtypes.jl:242-259), or a
+`ParticleFilter` whose `dynamics_density` is not Gaussian (`rand!(rng, d, noise)`, :122-139).  `gaussian`: the density the FFBS smoother
+and the auxiliary filter's `add_noise!` keep using (default: standard normal)."""
+struct UserNoise
+    gaussian
+    host
+end
+UserNoise(gaussian = nothing; host = nothing) = UserNoise(gaussian, host)
+"""
+    UserInitial(host = nothing)
+
+`initial_density` of a filter whose model draws its own initial particles: the `initial(xi, uu, out)` member of the paired `UserDynamics`
+snippet (`x_i = rand(rng, initial_density)`, reference src/filtering.jl:4-14)."""
+struct UserInitial
+    host
+end
+UserInitial() = UserInitial(nothing)
+const TRAIT_LOGLIK, TRAIT_LOGLIK_BOUND, TRAIT_NOISE, TRAIT_INITIAL = Int32(1), Int32(2), Int32(4), Int32(8)
+function cmodel(f::UserDynamics, ::UserMeasurement, df, dg, d0, Ts; user_likelihood::Bool = false)
     id = Ref{Int32}(-1)
     check(ccall((:llpf_model_compile, LIB), Cint, (Cstring, Int32, Int32, Ref{Int32}), f.src, f.nx, f.ny, id))
+    # what the snippet defines must be what the filter was told to use: a missing member would silently fall back to the Gaussian
+    # descriptor, a present one silently override it
+    traits = Ref{Int32}(0)
+    check(ccall((:llpf_model_traits, LIB), Cint, (Int32, Ref{Int32}), id[], traits))
+    for (what, wanted, bit, member) in (("measurement likelihood", user_likelihood, TRAIT_LOGLIK, "loglik"),
+                                        ("dynamics_density", df isa UserNoise, TRAIT_NOISE, "noise"),
+                                        ("initial_density", d0 isa UserInitial, TRAIT_INITIAL, "initial"))
+        wanted && traits[] & bit == 0 && error("the $what is a User* descriptor but the snippet defines no `$member` member")
+        !wanted && traits[] & bit != 0 && error("the snippet defines `$member`, which would override the Gaussian $what: pass the matching User* descriptor")
+    end
+    dfg = df isa UserNoise ? (df.gaussian === nothing ? GaussianSpec(zeros(f.nx), 1.0) : df.gaussian) : df
+    d0g = d0 isa UserInitial ? GaussianSpec(zeros(f.nx), 1.0) : d0
     CModel(id[], f.nx, f.nu, f.ny, pad(isempty(f.A) ? Float64[] : rowmajor(f.A), 64), pad(isempty(f.B) ? Float64[] : rowmajor(f.B), 64),
-           pad(isempty(f.C) ? Float64[] : rowmajor(f.C), 64), pad(f.qt, 16), f.supersample, 0, Ts, cgauss(df), cgauss(dg), cgauss(d0),
+           pad(isempty(f.C) ? Float64[] : rowmajor(f.C), 64), pad(f.qt, 16), f.supersample, 0, Ts, cgauss(dfg), cgauss(dg), cgauss(d0g),
            NOGAUSS, NOGAUSS, NOCOUPLING)
 end
 
@@ -382,7 +416,7 @@ function GPUAdvancedParticleFilter(N::Integer, dynamics::UserDynamics, measureme
                                    resampling_strategy::Type{<:ResamplingStrategy} = ResampleSystematic,
                                    p = NullParameters(), Ts = 1.0, seed = 0, device = 0, rng = Xoshiro(), kwargs...)
     dg = GaussianSpec(zeros(dynamics.ny), 1.0)
-    cm = cmodel(dynamics, measurement, dynamics_density, dg, initial_density, Float64(Ts))
+    cm = cmodel(dynamics, measurement, dynamics_density, dg, initial_density, Float64(Ts); user_likelihood = true)
     create_filter(N, cm, true, Float64(resample_threshold), resampling_strategy, seed, device, dynamics, measurement,
                   measurement_likelihood, dynamics_density, dg, initial_density, p, rng)
 end

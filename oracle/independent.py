@@ -82,6 +82,43 @@ class StudentT:
         return np.sum(self.c1 - (self.nu + 1.0) / 2.0 * np.log1p((v / self.sigma) ** 2 / self.nu), axis=1)
 
 
+# ---- process noise / initial densities other than a Gaussian ---------------------------------------------------------------
+# The reference's AdvancedParticleFilter hands the noise to the user — x[i] = dynamics(xprev[j[i]], u, p, t, true) adds its own
+# (src/PFtypes.jl:242-259, test/runtests.jl:553-599) — and its ParticleFilter draws from ANY dynamics_density / initial_density
+# (rand!(rng, d, noise) src/PFtypes.jl:135, rand(rng, initial_density) src/filtering.jl:8).  The draws are inputs here too: per
+# particle, nx standard normals xi and nx uniforms uu in [0, 1).
+class MultiplicativeGaussianNoise:
+    """x' = f(x) + (s0 + s1 |x|) .* xi : Gaussian noise whose standard deviation grows with the state it leaves"""
+
+    def __init__(self, s0, s1):
+        self.s0, self.s1 = float(s0), float(s1)
+
+    def propagate(self, x, fx, xi, uu):
+        return fx + (self.s0 + self.s1 * np.abs(x)) * xi
+
+
+class LaplaceNoise:
+    """x' = f(x) + Laplace(0, b) per component, drawn through the inverse CDF of one uniform each"""
+
+    def __init__(self, b):
+        self.b = float(b)
+
+    def propagate(self, x, fx, xi, uu):
+        v = 2.0 * uu - 1.0
+        t = np.maximum(1.0 - np.abs(v), 2.0 ** -53)
+        return fx + np.sign(v) * self.b * (-np.log(t))
+
+
+class UniformBox:
+    """initial density: independent uniforms on [lo_d, hi_d]"""
+
+    def __init__(self, lo, hi):
+        self.lo, self.hi = np.asarray(lo, dtype=np.float64), np.asarray(hi, dtype=np.float64)
+
+    def sample_u(self, xi, uu):
+        return self.lo + (self.hi - self.lo) * uu
+
+
 # ---- models -------------------------------------------------------------------------------------------------------------------
 class LinearModel:
     """dynamics A x + B u, measurement C x (examples/example_lineargaussian.jl:28-29)"""
@@ -184,8 +221,8 @@ class ParticleFilter:
         self.thr, self.stratified, self.Ts = resample_threshold, stratified, Ts
         self.j = np.arange(N)
 
-    def reset(self, xi):
-        self.x = self.d0.sample(xi)                              # x_i ~ d0
+    def reset(self, xi, uu=None):
+        self.x = self.d0.sample_u(xi, uu) if hasattr(self.d0, "sample_u") else self.d0.sample(xi)      # x_i ~ d0
         self.w = np.full(self.N, -math.log(self.N))
         self.we = np.full(self.N, 1.0 / self.N)
         self.t = 1
@@ -196,7 +233,7 @@ class ParticleFilter:
         self.w, self.we, ll = logsumexp_inplace(self.w)
         return ll
 
-    def predict(self, u, t, xi, U):
+    def predict(self, u, t, xi, U, uu=None):
         N = self.N
         ess = 1.0 / float(np.sum(self.we * self.we))
         self.resampled = self.thr == 1.0 or ess < N * self.thr
@@ -211,10 +248,13 @@ class ParticleFilter:
         else:
             self.j = np.arange(N)
             xprev = self.x
-        self.x = self.model.f(xprev, u, t) + self.df.sample(xi)
+        if hasattr(self.df, "propagate"):                        # the model adds its own noise (PFtypes.jl:254 / any dynamics_density, :135)
+            self.x = self.df.propagate(xprev, self.model.f(xprev, u, t), xi, uu)
+        else:
+            self.x = self.model.f(xprev, u, t) + self.df.sample(xi)
         self.t += 1
 
-    def run(self, U, Y, t_index0, normals, uniforms, step0=0):
+    def run(self, U, Y, t_index0, normals, uniforms, step0=0, user_uniforms=None):
         """T iterations of correct!(u_k, y_k, t_k); predict!(u_k, t_k), t_k = (t_index0 + k) Ts: forward_trajectory
         (t_index0 = 0) / loglik (t_index0 = 1).  normals(step, n, nd), uniforms(step, n): the draws of predict! number `step`."""
         T = len(Y)
@@ -224,7 +264,8 @@ class ParticleFilter:
             t = (t_index0 + k) * self.Ts
             u = U[k] if U is not None and len(U) else None
             ll_steps[k] = self.correct(u, Y[k], t)
-            self.predict(u, t, normals(step0 + k, self.N, self.x.shape[1]), uniforms(step0 + k, self.N))
+            uu = user_uniforms(step0 + k, self.N, self.x.shape[1]) if user_uniforms is not None else None
+            self.predict(u, t, normals(step0 + k, self.N, self.x.shape[1]), uniforms(step0 + k, self.N), uu)
             nres += int(self.resampled)
         return ll_steps, nres
 
@@ -274,7 +315,7 @@ class RBPF:
         self.w, self.we, ll = logsumexp_inplace(self.w)
         return ll
 
-    def predict(self, u, t, xi, U):
+    def predict(self, u, t, xi, U, uu=None):
         N = self.N
         ess = 1.0 / float(np.sum(self.we * self.we))
         self.resampled = self.thr == 1.0 or ess < N * self.thr
@@ -307,7 +348,7 @@ class RBPF:
         self.xn, self.xl, self.R = xn1, xl1, R1
         self.t += 1
 
-    def run(self, U, Y, t_index0, normals, uniforms, step0=0):
+    def run(self, U, Y, t_index0, normals, uniforms, step0=0, user_uniforms=None):
         T = len(Y)
         ll_steps = np.zeros(T)
         nres = 0

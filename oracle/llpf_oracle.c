@@ -571,6 +571,12 @@ struct orc_filter {
      * density (ext/LowLevelParticleFiltersDistributionsExt.jl:80) */
     int user_ll_kind;
     double user_par[4], user_c, user_bound;
+    /* process noise / initial density of the model's own (orc_set_user_noise / orc_set_user_initial): the counterpart of the
+     * reference's AdvancedParticleFilter dynamics(x, u, p, t, noise = true) (src/PFtypes.jl:242-259) / of a dynamics_density or
+     * initial_density that is not Gaussian (rand!(rng, d, noise) :135, rand(rng, initial_density) src/filtering.jl:8) */
+    int user_noise_kind, user_init_kind;
+    double noise_par[4], init_par[2 * MAXD];
+    double* uu_buf;             /* N x nx uniforms of the particle streams LLPF_STREAM_USER / LLPF_STREAM_USER_INIT */
     double *x, *xprev;          /* N*nx, AoS like Vector{SVector} */
     double *w, *we, *bins, *e;  /* e: exp(w_raw - m) of the last normalisation (device order) */
     int64_t* j;
@@ -622,9 +628,15 @@ static void fill_uniform_weights(orc_filter* f, double wval) {
     f->wmax = wval;
 }
 
+/* x_i = rand(rng, initial_density) — src/filtering.jl:8, src/PFtypes.jl:66.  User kind 1: a uniform box, x_d = lo_d + (hi_d - lo_d) uu_d */
 static void init_particles(orc_filter* f, const double* xi) {
     for (int64_t i = 0; i < f->N; ++i) {
-        gauss_sample(&f->d0, xi + i * f->nx, f->xprev + i * f->nx);
+        if (f->user_init_kind == 1) {
+            for (int d = 0; d < f->nx; ++d)
+                f->xprev[i * f->nx + d] = f->init_par[d] + (f->init_par[f->nx + d] - f->init_par[d]) * f->uu_buf[i * f->nx + d];
+        } else {
+            gauss_sample(&f->d0, xi + i * f->nx, f->xprev + i * f->nx);
+        }
         for (int d = 0; d < f->nx; ++d) f->x[i * f->nx + d] = f->xprev[i * f->nx + d];
     }
 }
@@ -633,6 +645,39 @@ static void gen_normals(orc_filter* f, uint32_t step, uint32_t stream, double* o
     ORC_PAR
     for (int64_t i = 0; i < f->N; ++i)
         llpf_normals((uint32_t)i, step, stream, f->k0, f->k1, f->nx, out + i * f->nx);
+}
+static void gen_uniforms(orc_filter* f, uint32_t step, uint32_t stream, double* out) {
+    ORC_PAR
+    for (int64_t i = 0; i < f->N; ++i)
+        llpf_uniforms((uint32_t)i, step, stream, f->k0, f->k1, f->nx, out + i * f->nx);
+}
+
+/* the next state from the previous state x, its noise-free prediction fx, and the particle's draws.  Gaussian descriptor:
+ * fx + rand(df) (src/PFtypes.jl:135).  User kinds (test-side counterparts of the device snippets in tests/user_models.py):
+ *   1  multiplicative Gaussian, standard deviation par[0] + par[1] |x_d| of the state it leaves:   fx_d + (par[0] + par[1] |x_d|) xi_d
+ *   2  Laplace of scale b = par[0] through the inverse CDF of one uniform per dimension:            fx_d +/- b (-log(1 - |2 uu_d - 1|))
+ * Device order: the deterministic log of llpf_detmath.h, as the device snippet; reference order: libm. */
+static void apply_noise(const orc_filter* f, const double* x, const double* fx, const double* xi, const double* uu, double* out) {
+    const int nx = f->nx;
+    if (f->user_noise_kind == 1) {
+        for (int d = 0; d < nx; ++d) {
+            const double sd = f->noise_par[0] + f->noise_par[1] * fabs(x[d]);
+            out[d] = fx[d] + sd * xi[d];
+        }
+    } else if (f->user_noise_kind == 2) {
+        const int dev = f->order == ORC_ORDER_DEVICE;
+        for (int d = 0; d < nx; ++d) {
+            const double v = 2.0 * uu[d] - 1.0;
+            double tt = 1.0 - fabs(v);
+            if (!(tt > 0.0)) tt = 1.1102230246251565e-16;
+            const double mg = f->noise_par[0] * (-(dev ? llpf_log(tt) : log(tt)));
+            out[d] = fx[d] + (v < 0.0 ? -mg : mg);
+        }
+    } else {
+        double nz[MAXD];
+        gauss_sample(&f->df, xi, nz);
+        for (int d = 0; d < nx; ++d) out[d] = fx[d] + nz[d];
+    }
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -1050,6 +1095,7 @@ orc_filter* orc_create(const llpf_config* cfg, int order) {
     f->bins = (double*)calloc(N, 8); f->e = (double*)calloc(N, 8);
     f->j = (int64_t*)calloc(N, 8);
     f->xi_buf = (double*)calloc(N * f->nx, 8); f->U_buf = (double*)calloc(N, 8);
+    f->uu_buf = (double*)calloc(N * f->nx, 8);
     set_key(f, cfg->seed);
     /* constructor: particles ~ d0, w = log(1/N), we = 1/N, j = 1:N, t = 0 — src/PFtypes.jl:65-75 */
     gen_normals(f, f->n_reset, LLPF_STREAM_INIT, f->xi_buf);
@@ -1066,7 +1112,7 @@ void orc_destroy(orc_filter* f) {
     if (!f) return;
     free(f->x); free(f->xprev); free(f->w); free(f->we); free(f->bins); free(f->e); free(f->j);
     free(f->rbf.xl); free(f->rbf.xlprev); free(f->rbf.R); free(f->rbf.Rprev);
-    free(f->xi_buf); free(f->U_buf); free(f->lam); free(f);
+    free(f->xi_buf); free(f->U_buf); free(f->uu_buf); free(f->lam); free(f);
 }
 
 void orc_seed(orc_filter* f, uint64_t seed) { set_key(f, seed); }
@@ -1081,6 +1127,7 @@ void orc_reset_explicit(orc_filter* f, const double* xi) {
 }
 void orc_reset(orc_filter* f) {
     gen_normals(f, f->n_reset, LLPF_STREAM_INIT, f->xi_buf);
+    if (f->user_init_kind) gen_uniforms(f, f->n_reset, LLPF_STREAM_USER_INIT, f->uu_buf);
     f->n_reset++;
     orc_reset_explicit(f, f->xi_buf);
 }
@@ -1129,6 +1176,24 @@ int orc_set_user_loglik(orc_filter* f, int kind, const double* par, int npar) {
         double b = 0.0;
         for (int k = 0; k < f->ny; ++k) b = b + f->user_par[2];
         f->user_bound = b;
+    }
+    return 0;
+}
+/* the model's own process noise (apply_noise above) / initial density (init_particles).  Installing an initial density redraws the
+ * constructor's particles when nothing else has happened to the filter yet (the engine's constructor draws from the model's own) */
+int orc_set_user_noise(orc_filter* f, int kind, const double* par, int npar) {
+    if (!f || kind < 0 || kind > 2 || npar > 4) return -1;
+    f->user_noise_kind = kind;
+    for (int i = 0; i < 4; ++i) f->noise_par[i] = (par && i < npar) ? par[i] : 0.0;
+    return 0;
+}
+int orc_set_user_initial(orc_filter* f, int kind, const double* par, int npar) {
+    if (!f || kind < 0 || kind > 1 || npar > 2 * MAXD) return -1;
+    f->user_init_kind = kind;
+    for (int i = 0; i < 2 * MAXD; ++i) f->init_par[i] = (par && i < npar) ? par[i] : 0.0;
+    if (kind && f->n_reset == 1 && f->t == 0 && f->n_predict == 0) {
+        gen_uniforms(f, 0, LLPF_STREAM_USER_INIT, f->uu_buf);
+        init_particles(f, f->xi_buf);
     }
     return 0;
 }
@@ -1267,10 +1332,9 @@ void orc_predict_explicit(orc_filter* f, const double* u, double t, const double
         /* propagate_particles!(pf,u,j,p,t) — src/PFtypes.jl:122-139 (PF), :242-259 (Advanced) */
         ORC_PAR
         for (int64_t i = 0; i < N; ++i) {
-            double fx[MAXD], nz[MAXD];
+            double fx[MAXD];
             orc_dynamics(&f->cfg.model, f->xprev + f->j[i] * nx, u, t, fx);
-            gauss_sample(&f->df, xi + i * nx, nz);
-            for (int d = 0; d < nx; ++d) f->x[i * nx + d] = fx[d] + nz[d];
+            apply_noise(f, f->xprev + f->j[i] * nx, fx, xi + i * nx, f->uu_buf + i * nx, f->x + i * nx);
         }
         /* reset_weights!(s) — src/utils.jl:73-79: fill!(w, log(1/N)); fill!(we, 1/N); maxw = 0 */
         fill_uniform_weights(f, f->order == ORC_ORDER_DEVICE ? llpf_log(1.0 / (double)N) : log(1.0 / (double)N));
@@ -1281,10 +1345,9 @@ void orc_predict_explicit(orc_filter* f, const double* u, double t, const double
         /* propagate_particles!(pf,u,p,t) — DistributionsExt:83-93 (PF), src/PFtypes.jl:276-289 (Advanced) */
         ORC_PAR
         for (int64_t i = 0; i < N; ++i) {
-            double fx[MAXD], nz[MAXD];
+            double fx[MAXD];
             orc_dynamics(&f->cfg.model, f->xprev + i * nx, u, t, fx);
-            gauss_sample(&f->df, xi + i * nx, nz);
-            for (int d = 0; d < nx; ++d) f->x[i * nx + d] = fx[d] + nz[d];
+            apply_noise(f, f->xprev + i * nx, fx, xi + i * nx, f->uu_buf + i * nx, f->x + i * nx);
         }
     }
     memcpy(f->xprev, f->x, sizeof(double) * (size_t)N * nx);   /* copyto!(s.xprev, s.x), :151 */
@@ -1295,6 +1358,7 @@ void orc_predict_explicit(orc_filter* f, const double* u, double t, const double
 void orc_predict(orc_filter* f, const double* u, double t) {
     uint32_t step = f->n_predict++;
     gen_normals(f, step, LLPF_STREAM_DYNAMICS, f->xi_buf);
+    if (f->user_noise_kind) gen_uniforms(f, step, LLPF_STREAM_USER, f->uu_buf);
     if (f->cfg.resampling_strategy == LLPF_RESAMPLE_SYSTEMATIC)
         f->U_buf[0] = llpf_uniform_step(step, LLPF_STREAM_RESAMPLE, f->k0, f->k1);
     else
@@ -1331,6 +1395,7 @@ void orc_aux_predict(orc_filter* f, const double* u, const double* y1, double t)
     const int nx = f->nx;
     const uint32_t step = f->n_predict++;
     gen_normals(f, step, LLPF_STREAM_DYNAMICS, f->xi_buf);
+    if (f->user_noise_kind) gen_uniforms(f, step, LLPF_STREAM_USER, f->uu_buf);
     if (f->cfg.resampling_strategy == LLPF_RESAMPLE_SYSTEMATIC)
         f->U_buf[0] = llpf_uniform_step(step, LLPF_STREAM_RESAMPLE, f->k0, f->k1);
     else
@@ -1373,10 +1438,9 @@ void orc_aux_predict(orc_filter* f, const double* u, const double* y1, double t)
          * permutation" — from the PREVIOUS particles xprev[j], the noise-free prediction in s.x is overwritten */
         ORC_PAR
         for (int64_t i = 0; i < N; ++i) {
-            double fx[MAXD], nz[MAXD];
+            double fx[MAXD];
             orc_dynamics(&f->cfg.model, f->xprev + f->j[i] * nx, u, t, fx);
-            gauss_sample(&f->df, f->xi_buf + i * nx, nz);
-            for (int d = 0; d < nx; ++d) f->x[i * nx + d] = fx[d] + nz[d];
+            apply_noise(f, f->xprev + f->j[i] * nx, fx, f->xi_buf + i * nx, f->uu_buf + i * nx, f->x + i * nx);
         }
         fill_uniform_weights(f, dev ? llpf_log(1.0 / (double)N) : log(1.0 / (double)N));
         f->maxw = 0.0;
@@ -1790,6 +1854,10 @@ void orc_philox_block(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32
 void orc_normals(uint64_t seed, uint32_t step, uint32_t stream, int nd, double* out, int64_t n) {
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     for (int64_t i = 0; i < n; ++i) llpf_normals((uint32_t)i, step, stream, k0, k1, nd, out + i * nd);
+}
+void orc_uniforms_nd(uint64_t seed, uint32_t step, uint32_t stream, int nd, double* out, int64_t n) {
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    for (int64_t i = 0; i < n; ++i) llpf_uniforms((uint32_t)i, step, stream, k0, k1, nd, out + i * nd);
 }
 void orc_fix96(double e, uint64_t* lo_hi) {
     llpf_u128 r = llpf_fix96(e);

@@ -95,6 +95,8 @@ int64_t orc_exact_steps(const orc_filter* f);   /* device order: weightings norm
 void   orc_set_threads(int n);
 /* a measurement likelihood other than the Gaussian descriptor: kind 0 none, 1 Laplace (par: b), 2 Student-t (par: nu, sigma, c1) */
 int    orc_set_user_loglik(orc_filter* f, int kind, const double* par, int npar);
+int    orc_set_user_noise(orc_filter* f, int kind, const double* par, int npar);     /* 1: multiplicative Gaussian (s0, s1); 2: Laplace (b) */
+int    orc_set_user_initial(orc_filter* f, int kind, const double* par, int npar);   /* 1: uniform box (lo[nx], hi[nx]) */
 int    orc_get_threads(void);
 
 /* array primitives */
@@ -118,6 +120,7 @@ double orc_pairwise_sum(const double* a, int64_t n);
 void   orc_math_vec(int which, const double* in, double* out, int64_t n);
 void   orc_philox_block(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out4);
 void   orc_normals(uint64_t seed, uint32_t step, uint32_t stream, int nd, double* out, int64_t n);
+void   orc_uniforms_nd(uint64_t seed, uint32_t step, uint32_t stream, int nd, double* out, int64_t n);   /* llpf_uniforms of particles 0..n-1 */
 void   orc_fix96(double e, uint64_t* lo_hi);
 uint64_t orc_q64(double e, int K);
 void   orc_fix96_unit(double e, uint64_t* lo_hi);

@@ -15,7 +15,7 @@ import models as M
 import rbfull_models as RM
 from llpf_amd import _structs as S
 
-STREAM_INIT, STREAM_DYNAMICS = 0, 1
+STREAM_INIT, STREAM_DYNAMICS, STREAM_USER, STREAM_USER_INIT = 0, 1, 7, 8
 SEED = 7
 
 
@@ -56,6 +56,16 @@ def cases():
                              ("pf_lg_student_t", st, (2, [4.0, 0.7, st.c1], UM.STUDENT_T_SRC, [4.0, 0.7, st.c1]))):
         out[name] = dict(model=lg, kind=S.ADVANCED_PARTICLE_FILTER, N=400, T=60, thr=0.5, strategy=S.RESAMPLE_SYSTEMATIC, t0=0.0, U=U, Y=Y, user=user,
                          make=lambda dens=dens: ind.ParticleFilter(400, _lg_objects(lg), _gauss(lg.dynamics_density), dens, _gauss(lg.initial_density), 0.5, False, lg.Ts))
+    # process noise / initial density of the model's own (UserModel::noise / ::initial): `noise` = (oracle kind, oracle parameters),
+    # `initial` likewise, `user` = (-, -, device snippet, qt parameter block)
+    box = ([-1.0, 0.5], [3.0, 2.5])
+    for name, dfo, d0o, extra in (
+            ("pf_lg_mult_noise_box", ind.MultiplicativeGaussianNoise(0.1, 0.25), ind.UniformBox(*box),
+             dict(noise=(1, [0.1, 0.25]), initial=(1, box[0] + box[1]), user=(0, [], UM.MULT_NOISE_BOX_SRC, [0.1, 0.25] + box[0] + box[1]))),
+            ("pf_lg_laplace_noise", ind.LaplaceNoise(0.2), _gauss(lg.initial_density),
+             dict(noise=(2, [0.2]), user=(0, [], UM.LAPLACE_NOISE_SRC, [0.2])))):
+        out[name] = dict(model=lg, kind=S.ADVANCED_PARTICLE_FILTER, N=400, T=60, thr=0.5, strategy=S.RESAMPLE_SYSTEMATIC, t0=0.0, U=U, Y=Y,
+                         make=lambda dfo=dfo, d0o=d0o: ind.ParticleFilter(400, _lg_objects(lg), dfo, _gauss(lg.measurement_density), d0o, 0.5, False, lg.Ts), **extra)
     qt = M.quadtank_model()
     Uq, Yq = M.quadtank_data(40, seed=2)
     out["pf_quadtank"] = dict(model=qt, kind=S.ADVANCED_PARTICLE_FILTER, N=300, T=40, thr=0.5, strategy=S.RESAMPLE_SYSTEMATIC, t0=485.0, U=Uq, Y=Yq,
@@ -97,8 +107,16 @@ def draws(ob, case):
 def run_independent(ob, case):
     f = case["make"]()
     xi0, normals, uniforms = draws(ob, case)
-    f.reset(xi0)
-    ll_steps, nres = f.run(case["U"], case["Y"], case["t0"], normals, uniforms)
+    nd = case["model"].nx
+    if case.get("initial"):
+        f.reset(xi0, ob.uniforms_nd(SEED, 1, STREAM_USER_INIT, nd, case["N"]))
+    else:
+        f.reset(xi0)
+    if case.get("noise"):
+        ll_steps, nres = f.run(case["U"], case["Y"], case["t0"], normals, uniforms,
+                               user_uniforms=lambda step, n, k: ob.uniforms_nd(SEED, step, STREAM_USER, nd, n)[:, :k])
+    else:
+        ll_steps, nres = f.run(case["U"], case["Y"], case["t0"], normals, uniforms)
     res = dict(ll_steps=ll_steps, resamples=np.int64(nres), anc_final=np.asarray(f.j, dtype=np.int64))
     if case.get("rb"):
         res.update(x_final=np.hstack([f.xn, f.xl]), R_final=f.R)
@@ -114,8 +132,12 @@ def config_of(case):
 def oracle_of(ob, case, order):
     """the C oracle for a case (with the case's own measurement likelihood installed)"""
     o = ob.OracleFilter(config_of(case), order)
-    if case.get("user"):
+    if case.get("user") and case["user"][0]:
         o.set_user_loglik(case["user"][0], case["user"][1])
+    if case.get("noise"):
+        o.set_user_noise(*case["noise"])
+    if case.get("initial"):
+        o.set_user_initial(*case["initial"])
     return o
 
 

@@ -29,6 +29,8 @@ def load():
     lib.orc_destroy.argtypes = [C.c_void_p]
     lib.orc_seed.argtypes = [C.c_void_p, C.c_uint64]
     lib.orc_set_user_loglik.argtypes = [C.c_void_p, C.c_int, _dp, C.c_int]
+    lib.orc_set_user_noise.argtypes = [C.c_void_p, C.c_int, _dp, C.c_int]
+    lib.orc_set_user_initial.argtypes = [C.c_void_p, C.c_int, _dp, C.c_int]
     lib.orc_reset.argtypes = [C.c_void_p]
     lib.orc_reset_explicit.argtypes = [C.c_void_p, _dp]
     lib.orc_correct.restype = C.c_double
@@ -94,6 +96,7 @@ def load():
     lib.orc_math_vec.argtypes = [C.c_int, _dp, _dp, C.c_int64]
     lib.orc_philox_block.argtypes = [C.c_uint32] * 6 + [C.POINTER(C.c_uint32)]
     lib.orc_normals.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, _dp, C.c_int64]
+    lib.orc_uniforms_nd.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, _dp, C.c_int64]
     lib.orc_fix96.argtypes = [C.c_double, C.POINTER(C.c_uint64)]
     lib.orc_q64.restype = C.c_uint64
     lib.orc_q64.argtypes = [C.c_double, C.c_int]
@@ -154,6 +157,18 @@ class OracleFilter:
 
     def seed(self, s):
         self.L.orc_seed(self.h, s)
+
+    def set_user_noise(self, kind, par):
+        """process noise of the model's own (oracle/llpf_oracle.c: apply_noise): 1 multiplicative Gaussian (s0, s1), 2 Laplace (b)"""
+        a = np.ascontiguousarray(par, dtype=np.float64)
+        if self.L.orc_set_user_noise(self.h, int(kind), dptr(a), int(a.size)) != 0:
+            raise ValueError("orc_set_user_noise")
+
+    def set_user_initial(self, kind, par):
+        """initial density of the model's own: 1 uniform box (lo[nx], hi[nx])"""
+        a = np.ascontiguousarray(par, dtype=np.float64)
+        if self.L.orc_set_user_initial(self.h, int(kind), dptr(a), int(a.size)) != 0:
+            raise ValueError("orc_set_user_initial")
 
     def set_user_loglik(self, kind, par):
         """a measurement likelihood other than the Gaussian descriptor (llpf_oracle.c: 1 Laplace [b], 2 Student-t [nu, sigma, c1])"""
@@ -356,6 +371,13 @@ def math_vec(which, x):
 def normals(seed, step, stream, nd, n):
     out = np.empty((n, nd))
     lib().orc_normals(seed, step, stream, nd, dptr(out), n)
+    return out
+
+
+def uniforms_nd(seed, step, stream, nd, n):
+    """nd uniforms in [0, 1) per particle (llpf_uniforms): what a model's own noise / initial density is handed"""
+    out = np.empty((n, nd))
+    lib().orc_uniforms_nd(seed, step, stream, nd, dptr(out), n)
     return out
 
 

@@ -22,6 +22,14 @@ def test_snippets_compile_for_gfx950_without_a_device():
         assert _capi.model_compile(UM.QUADTANK_SRC, 4, 2) == a                 # the same (source, nx, ny) again: the same id, no recompilation
         ids = [_capi.model_compile(src, 2, 1) for src in (UM.LAPLACE_SRC, UM.STUDENT_T_SRC, UM.LAPLACE_NO_BOUND_SRC)]   # likelihood hooks
         assert len(set(ids)) == 3 and "loglik_bound" not in UM.LAPLACE_NO_BOUND_SRC
+        # what a snippet defines is reported without running anything (the template argument of a tag kernel's lowered name)
+        T = _capi
+        assert _capi.model_traits(a) == 0 and _capi.model_traits(ids[0]) == T.TRAIT_LOGLIK | T.TRAIT_LOGLIK_BOUND
+        assert _capi.model_traits(ids[2]) == T.TRAIT_LOGLIK
+        n1, n2 = _capi.model_compile(UM.MULT_NOISE_BOX_SRC, 2, 1), _capi.model_compile(UM.LAPLACE_NOISE_SRC, 2, 1)    # noise / initial hooks
+        assert _capi.model_traits(n1) == T.TRAIT_NOISE | T.TRAIT_INITIAL and _capi.model_traits(n2) == T.TRAIT_NOISE
+        with pytest.raises(_capi.LLPFError):
+            _capi.model_traits(7)
         with pytest.raises(_capi.LLPFError) as ei:
             _capi.model_compile("struct UserModel { int broken }", 2, 1)
         assert "hiprtc" in str(ei.value)
@@ -180,3 +188,86 @@ def test_user_likelihood_through_the_filter_objects():
     assert abs(sol.ll - ro["ll"]) <= 1e-9
     with pytest.raises(TypeError):
         llpf_amd.AdvancedParticleFilter(100, llpf_amd.LinearDynamics(A, B), llpf_amd.LinearMeasurement(Cm), llpf_amd.UserLikelihood(), df, d0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["pf_lg_mult_noise_box", "pf_lg_laplace_noise"])
+def test_user_process_noise_and_initial_density(name):
+    """The random part of the step in the user's hands — the reference's AdvancedParticleFilter contract, dynamics(x, u, p, t, noise = true)
+    adds its own noise (src/PFtypes.jl:242-259, test/runtests.jl:553-599), and a ParticleFilter with any dynamics_density / initial_density
+    (rand!(rng, d, noise) src/PFtypes.jl:135, rand(rng, initial_density) src/filtering.jl:8) — as `noise` / `initial` members of a run-time
+    compiled model: multiplicative (state-dependent) Gaussian noise with a uniform-box prior, and Laplace process noise.  Bit-identical to the
+    device-order oracle (whose C counterparts are held to the independent numpy restatement), within 1e-10 per step of the reference order;
+    the constructor's draw, whole runs, single steps, the auxiliary filter over it, and a bank."""
+    import independent_cases as IC
+    case = IC.cases()[name]
+    U, Y = case["U"], case["Y"]
+    g = IC.engine_of(case)
+    od, orf = IC.oracle_of(ob, case, ob.ORDER_DEVICE), IC.oracle_of(ob, case, ob.ORDER_REFERENCE)
+    assert np.array_equal(g.particles().view(np.uint64), od.particles().view(np.uint64))      # the constructor draws from the model's own prior
+    if case.get("initial"):
+        lo, hi = np.array(case["initial"][1][:2]), np.array(case["initial"][1][2:])
+        x0 = g.particles()
+        assert np.all(x0 >= lo) and np.all(x0 < hi) and np.std(x0[:, 0]) > 0.5
+    for h in (g, od, orf):
+        h.reset()
+    assert np.array_equal(g.particles().view(np.uint64), od.particles().view(np.uint64))
+    rg, rd, rr = (h.run(U, Y, 0.0, ll_steps=True) for h in (g, od, orf))
+    assert np.array_equal(rg["ll_steps"].view(np.uint64), rd["ll_steps"].view(np.uint64))
+    assert np.array_equal(g.particles().view(np.uint64), od.particles().view(np.uint64)) and np.array_equal(g.ancestors(), od.ancestors())
+    assert np.array_equal(g.weights().view(np.uint64), od.weights().view(np.uint64))
+    assert np.max(np.abs(rg["ll_steps"] - rr["ll_steps"])) <= 1e-10 and g.resample_count() == od.resample_count() > 3
+    # step by step
+    g.reset(); od.reset()
+    for k in range(12):
+        assert g.correct(U[k], Y[k], float(k)) == od.correct(U[k], Y[k], float(k))
+        g.predict(U[k], float(k)); od.predict(U[k], float(k))
+    assert np.array_equal(g.particles().view(np.uint64), od.particles().view(np.uint64))
+    # the auxiliary filter over it: look-ahead from the noise-free prediction, then the propagate WITH the model's own noise (filtering.jl:219-234)
+    g.reset(); od.reset()
+    ra, ro = g.run_aux(U, Y, 0, ll_steps=True), od.run_aux(U, Y, 0, ll_steps=True)
+    assert np.array_equal(ra["ll_steps"].view(np.uint64), ro["ll_steps"].view(np.uint64))
+    assert np.array_equal(g.particles().view(np.uint64), od.particles().view(np.uint64))
+    # a bank: filter k is the single filter with seed + k
+    kind, par, src, qt = case["user"]
+    m = S.Model.from_buffer_copy(bytes(case["model"]))
+    m.model_id = _capi.model_compile(src, m.nx, m.ny)
+    for i, v in enumerate(qt):
+        m.qt[i] = v
+    cfg = S.make_config(m, case["N"], case["kind"], case["strategy"], case["thr"], IC.SEED, 0)
+    bank = _capi.BankHandle(cfg, None, n_filters=3)
+    bank.reset()
+    rb = bank.run(U, Y, 0.0, ll_steps=True)
+    g2 = _capi.FilterHandle(cfg)         # a fresh handle: the same reset! number as the bank's
+    g2.reset()
+    assert np.array_equal(rb["ll_steps"][:, 0], g2.run(U, Y, 0.0, ll_steps=True)["ll_steps"])
+    assert not np.array_equal(rb["ll_steps"][:, 1], rb["ll_steps"][:, 0])
+
+
+@pytest.mark.gpu
+def test_user_noise_through_the_filter_objects():
+    """UserNoise / UserInitial descriptors in the constructors that mirror the reference's (lowlevelparticlefilters.jl_amd/api.py; julia/LLPFAmd.jl
+    has the same), and the pairing checks: a User* descriptor needs the member in the snippet, a member in the snippet needs the descriptor"""
+    import llpf_amd
+    import independent_cases as IC
+    case = IC.cases()["pf_lg_mult_noise_box"]
+    lg = case["model"]
+    A = np.array(lg.A[:4]).reshape(2, 2); B = np.array(lg.B[:2]).reshape(2, 1); Cm = np.array(lg.C[:2]).reshape(1, 2)
+    dyn = llpf_amd.UserDynamics(UM.MULT_NOISE_BOX_SRC, 2, 1, 1, A=A, B=B, C=Cm, qt=case["user"][3])
+    dg = llpf_amd.MvNormal(np.zeros(1), S.gaussian_cov_matrix(lg.measurement_density))
+    pf = llpf_amd.AdvancedParticleFilter(case["N"], dyn, llpf_amd.UserMeasurement(), llpf_amd.GaussianLikelihood(llpf_amd.UserMeasurement(), dg), llpf_amd.UserNoise(), llpf_amd.UserInitial(),
+                                         resample_threshold=case["thr"], rng=IC.SEED)
+    o = IC.oracle_of(ob, case, ob.ORDER_REFERENCE)
+    o.reset()
+    ro = o.run(case["U"], case["Y"], 0.0, ll_steps=True)
+    sol = llpf_amd.forward_trajectory(pf, case["U"], case["Y"])
+    assert abs(sol.ll - ro["ll"]) <= 1e-9
+    df = llpf_amd.MvNormal(np.zeros(2), 0.1)
+    with pytest.raises(TypeError):      # the snippet defines `noise`: a Gaussian dynamics_density would be silently overridden
+        llpf_amd.AdvancedParticleFilter(100, dyn, llpf_amd.UserMeasurement(), llpf_amd.GaussianLikelihood(llpf_amd.UserMeasurement(), dg), df, llpf_amd.UserInitial())
+    with pytest.raises(TypeError):      # UserNoise without a `noise` member in the snippet
+        d2 = llpf_amd.UserDynamics(UM.LAPLACE_SRC, 2, 1, 1, A=A, B=B, C=Cm, qt=[0.8])
+        llpf_amd.AdvancedParticleFilter(100, d2, llpf_amd.UserMeasurement(), llpf_amd.UserLikelihood(), llpf_amd.UserNoise(), df)
+    with pytest.raises(TypeError):      # a snippet with `loglik` paired with a Gaussian likelihood (advisor finding, round 3)
+        d2 = llpf_amd.UserDynamics(UM.LAPLACE_SRC, 2, 1, 1, A=A, B=B, C=Cm, qt=[0.8])
+        llpf_amd.AdvancedParticleFilter(100, d2, llpf_amd.UserMeasurement(), llpf_amd.GaussianLikelihood(llpf_amd.UserMeasurement(), dg), df, df)

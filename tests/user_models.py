@@ -166,3 +166,53 @@ struct UserModel {
 
 # the same Laplace likelihood WITHOUT a declared bound: every step is normalised in the exact-max form (one host round trip each)
 LAPLACE_NO_BOUND_SRC = LAPLACE_SRC.replace("    DEV double loglik_bound() const { return -c; }\n", "")
+
+# ---- process noise / initial density of the model's own (include/llpf.h: optional members `noise`, `initial`) ------------------
+# The reference's AdvancedParticleFilter hands the noise to the user (dynamics(x, u, p, t, noise = true), src/PFtypes.jl:242-259,
+# test/runtests.jl:553-599); its ParticleFilter draws from any dynamics_density / initial_density (:135, src/filtering.jl:8).
+# Multiplicative Gaussian noise — standard deviation s0 + s1 |x_d| of the state the particle leaves, (s0, s1) = qt[0..1] — and a
+# uniform box as initial density, lo = qt[2..3], hi = qt[4..5]
+MULT_NOISE_BOX_SRC = r"""
+struct UserModel {
+    static constexpr int NXU = 2, NYU = 1;
+""" + _LINEAR_PART + r"""
+    double s0, s1, lo[NXU], hi[NXU];
+    DEV void prepare(const ModelD* m, const double* u, double t) {
+        prepare_linear(m, u);
+        s0 = m->qt[0]; s1 = m->qt[1];
+        for (int d = 0; d < NXU; ++d) { lo[d] = m->qt[2 + d]; hi[d] = m->qt[2 + NXU + d]; }
+    }
+    DEV void noise(const double* x, const double* fx, const double* xi, const double* uu, double* out) const {
+        for (int d = 0; d < NXU; ++d) {
+            const double sd = s0 + s1 * llpf_fabs(x[d]);
+            out[d] = fx[d] + sd * xi[d];
+        }
+    }
+    DEV void initial(const double* xi, const double* uu, double* out) const {
+        for (int d = 0; d < NXU; ++d) out[d] = lo[d] + (hi[d] - lo[d]) * uu[d];
+    }
+};
+"""
+
+# Laplace process noise of scale b = qt[0], one uniform per component through the inverse CDF (heavy tails: a non-Gaussian
+# dynamics_density); the initial density stays the Gaussian descriptor
+LAPLACE_NOISE_SRC = r"""
+struct UserModel {
+    static constexpr int NXU = 2, NYU = 1;
+""" + _LINEAR_PART + r"""
+    double b;
+    DEV void prepare(const ModelD* m, const double* u, double t) {
+        prepare_linear(m, u);
+        b = m->qt[0];
+    }
+    DEV void noise(const double* x, const double* fx, const double* xi, const double* uu, double* out) const {
+        for (int d = 0; d < NXU; ++d) {
+            const double v = 2.0 * uu[d] - 1.0;
+            double tt = 1.0 - llpf_fabs(v);
+            if (!(tt > 0.0)) tt = 1.1102230246251565e-16;
+            const double mg = b * (-llpf_log(tt));
+            out[d] = fx[d] + (v < 0.0 ? -mg : mg);
+        }
+    }
+};
+"""
