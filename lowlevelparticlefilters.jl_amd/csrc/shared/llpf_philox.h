@@ -1,12 +1,12 @@
-/* llpf_philox.h — Philox4x32-10 counter-based RNG + fp64 uniform / normal transforms,
+/* llpf_philox.h — Philox4x32 counter-based RNG (7 rounds for the engine's draws, see LLPF_PHILOX_ROUNDS) + fp64 uniform / normal transforms,
  * shared bit-for-bit by the HIP kernels and the device-order oracle.
  *
  * The reference draws process noise sequentially from a per-filter Xoshiro via ziggurat
  * randn (reference src/PFtypes.jl:30,135) and the resampling offset from the *global* RNG
  * (reference src/resample.jl:23,49); no reference test pins either stream (SURVEY.md §8c:
  * "parity unpinned"), and a sequential stream cannot be consumed by 10^6 particles in
- * parallel.  This engine therefore defines its own stream: Philox4x32-10 (Salmon et al.,
- * SC'11), pinned by the published Random123 known-answer vectors in tests/test_philox.py.
+ * parallel.  This engine therefore defines its own stream: Philox4x32 (Salmon et al.,
+ * SC'11); its 10-round instance is pinned by the published Random123 known-answer vectors in tests/test_detmath.py.
  *
  *   key     = (seed_lo, seed_hi)
  *   counter = (particle index, step counter, sub-block, stream id)
@@ -31,13 +31,25 @@ enum {
 
 typedef struct { uint32_t v[4]; } llpf_philox4;
 
-LLPF_HD llpf_philox4 llpf_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                        uint32_t k0, uint32_t k1) {
+/* Rounds of the generator every draw of the engine (and of the oracle: one header) goes through.  Round 4 made this an explicit
+ * choice: Philox4x32-7.  Salmon, Moraes, Dror, Shaw, "Parallel random numbers: as easy as 1, 2, 3" (SC'11) report Philox4x32 Crush-
+ * resistant (SmallCrush, Crush, BigCrush of TestU01) from 7 rounds on; 10 is their default with a safety margin.  The filters' kernels
+ * are bound by instruction issue and the generator is a third of the normal pair's cost: on one MI355X, 10 -> 7 rounds took the
+ * quad-tank timestep (BASELINE C3, 8 normals = 2 blocks per particle) from 32.4 to 30.9 us (-4.7 %), C5 -1 %, C2 -0.4 %
+ * (profiles/r04_philox_ab.txt).  The round function and key schedule are the published ones — the 10-round instance llpf_philox4x32_10
+ * below is held to the Random123 known-answer vectors (tests/test_detmath.py), and the engine's generator is the same loop stopped after
+ * LLPF_PHILOX_ROUNDS rounds.  Build with -DLLPF_PHILOX_ROUNDS=10 (engine AND oracle) for the conservative variant: parity is unaffected. */
+#ifndef LLPF_PHILOX_ROUNDS
+#define LLPF_PHILOX_ROUNDS 7
+#endif
+
+LLPF_HD llpf_philox4 llpf_philox4x32_r(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                       uint32_t k0, uint32_t k1, const int rounds) {
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < rounds; ++r) {
         uint64_t p0 = (uint64_t)M0 * c0;
         uint64_t p1 = (uint64_t)M1 * c2;
         uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
@@ -50,6 +62,14 @@ LLPF_HD llpf_philox4 llpf_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, u
     llpf_philox4 o;
     o.v[0] = c0; o.v[1] = c1; o.v[2] = c2; o.v[3] = c3;
     return o;
+}
+/* Philox4x32-10 as published (the Random123 known-answer vectors pin this one, tests/test_detmath.py) */
+LLPF_HD llpf_philox4 llpf_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+    return llpf_philox4x32_r(c0, c1, c2, c3, k0, k1, 10);
+}
+/* the generator of the engine's draws */
+LLPF_HD llpf_philox4 llpf_philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+    return llpf_philox4x32_r(c0, c1, c2, c3, k0, k1, LLPF_PHILOX_ROUNDS);
 }
 
 /* 53-bit uniforms: u_open in (0,1]  (safe for log),  u_half in [0,1) */
@@ -68,7 +88,7 @@ LLPF_HD double llpf_sqrt_rad(double a) { return a == 0.0 ? a : llpf_sqrt_pos(a);
 /* one Philox block -> two independent N(0,1) draws (Box–Muller on deterministic log/sqrt/sincos) */
 LLPF_HD void llpf_normal_pair(uint32_t idx, uint32_t step, uint32_t sub, uint32_t stream,
                               uint32_t k0, uint32_t k1, double* z0, double* z1) {
-    llpf_philox4 r = llpf_philox4x32_10(idx, step, sub, stream, k0, k1);
+    llpf_philox4 r = llpf_philox4x32(idx, step, sub, stream, k0, k1);
     double u1 = llpf_u01_open(r.v[0], r.v[1]);
     double u2 = llpf_u01_half(r.v[2], r.v[3]);
     double rad = llpf_sqrt_rad(-2.0 * llpf_log_unit(u1));
@@ -82,7 +102,7 @@ LLPF_HD void llpf_normal_pair(uint32_t idx, uint32_t step, uint32_t sub, uint32_
  * identical values, so identical results */
 LLPF_HD void llpf_normal_pair_tab(uint32_t idx, uint32_t step, uint32_t sub, uint32_t stream, uint32_t k0, uint32_t k1,
                                   const double* lg, const double* sc, double* z0, double* z1) {
-    llpf_philox4 r = llpf_philox4x32_10(idx, step, sub, stream, k0, k1);
+    llpf_philox4 r = llpf_philox4x32(idx, step, sub, stream, k0, k1);
     double u1 = llpf_u01_open(r.v[0], r.v[1]);
     double u2 = llpf_u01_half(r.v[2], r.v[3]);
     double m, dk, f;
@@ -127,7 +147,7 @@ LLPF_HD void llpf_uniforms(uint32_t idx, uint32_t step, uint32_t stream, uint32_
 #pragma unroll
 #endif
     for (int b = 0; 2 * b < nd; ++b) {
-        llpf_philox4 r = llpf_philox4x32_10(idx, step, (uint32_t)b, stream, k0, k1);
+        llpf_philox4 r = llpf_philox4x32(idx, step, (uint32_t)b, stream, k0, k1);
         uu[2 * b] = llpf_u01_half(r.v[0], r.v[1]);
         if (2 * b + 1 < nd) uu[2 * b + 1] = llpf_u01_half(r.v[2], r.v[3]);
     }
@@ -135,12 +155,12 @@ LLPF_HD void llpf_uniforms(uint32_t idx, uint32_t step, uint32_t stream, uint32_
 
 /* the single uniform a systematic resample consumes at a step */
 LLPF_HD double llpf_uniform_step(uint32_t step, uint32_t stream, uint32_t k0, uint32_t k1) {
-    llpf_philox4 r = llpf_philox4x32_10(0u, step, 0u, stream, k0, k1);
+    llpf_philox4 r = llpf_philox4x32(0u, step, 0u, stream, k0, k1);
     return llpf_u01_half(r.v[0], r.v[1]);
 }
 /* per-stratum uniform for stratified resampling (stratum index i0 is 0-based) */
 LLPF_HD double llpf_uniform_idx(uint32_t i0, uint32_t step, uint32_t stream, uint32_t k0, uint32_t k1) {
-    llpf_philox4 r = llpf_philox4x32_10(i0, step, 0u, stream, k0, k1);
+    llpf_philox4 r = llpf_philox4x32(i0, step, 0u, stream, k0, k1);
     return llpf_u01_half(r.v[0], r.v[1]);
 }
 

@@ -4,7 +4,7 @@ tests/golden/ref_<case>.npz are written by lowlevelparticlefilters.jl_amd/julia/
 reset! / correct! / predict! on the committed inputs tests/golden/ref_inputs_<case>.npz with its random numbers replayed from the Philox
 draws this engine consumes (a ReplayRNG as `pf.rng` and as `Random.default_rng()`).  Julia is not in the build image, so the outputs
 cannot be produced here: while they are absent the comparisons SKIP with the reason below — they are the one route from "parity
-unpinned" to a reference-pinned oracle (DESIGN.md section 2, INTEGRATION.md section 5).  What always runs: the committed inputs are
+unpinned" to a reference-pinned oracle (DESIGN.md section 2, INTEGRATION.md section 4).  What always runs: the committed inputs are
 exactly the draws the oracle and the engine consume for that seed (so a fixture generated from them is comparable at all)."""
 import os
 
@@ -17,7 +17,7 @@ from llpf_amd import _capi, _structs as S
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASES = ("lg", "quadtank")
 SKIP = ("REFERENCE FIXTURES ABSENT: tests/golden/ref_%s.npz has not been generated.  It needs Julia with LowLevelParticleFilters.jl: "
-        "`julia --project=<env> lowlevelparticlefilters.jl_amd/julia/make_reference_fixtures.jl <repo root>` (INTEGRATION.md section 5).  "
+        "`julia --project=<env> lowlevelparticlefilters.jl_amd/julia/make_reference_fixtures.jl <repo root>` (INTEGRATION.md section 4).  "
         "Until then parity is pinned by this repository's own restatements only.")
 TOL_LL, TOL_WE, TOL_X = 1e-10, 1e-12, 1e-9       # the north-star tolerances: per-step log-likelihood, exp-weights (relative), states
 
