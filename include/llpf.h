@@ -166,6 +166,9 @@ typedef struct llpf_run_outputs {
     double* x_hist;      /* [T*N*nx] particles(pf) at each step, time-major (column t of the reference's N x T Matrix), or NULL */
     double* w_hist;      /* [T*N] weights(pf)    (reference src/filtering.jl:358), or NULL */
     double* we_hist;     /* [T*N] expweights(pf) (reference src/filtering.jl:359), or NULL */
+    double* xcov;        /* [T*nx*nx] weighted_cov after each correct! (reference src/filtering.jl:571-581: StatsBase's corrected covariance under
+                          * probability weights), computed on the device from the state the history outputs would copy out, or NULL.  llpf_run only
+                          * (single filters that are not LLPF_MODEL_RB_BILINEAR); asks for the balanced two-launch timestep like the history outputs. */
 } llpf_run_outputs;
 
 /* T iterations of {correct!(u_k,y_k,t_k); predict!(u_k,t_k)} with t_k = (t_index0 + k) * Ts, k = 0..T-1,
@@ -393,6 +396,8 @@ int  llpf_get_profile(llpf_filter* f, double* ms /* LLPF_PROF_CLASSES */, int64_
 int  llpf_bank_set_profiling(llpf_bank* b, int32_t on);
 int  llpf_bank_get_profile(llpf_bank* b, double* ms, int64_t* launches);
 /* number of predict! calls of the last run that resampled (summed over filters for a bank) */
+/* weighted_cov of the current particles under the current weights (reference src/filtering.jl:571-581), nx*nx row-major, on the device */
+int  llpf_weighted_cov(llpf_filter* f, double* cov);
 int  llpf_resample_count(llpf_filter* f, int64_t* n);
 int  llpf_bank_resample_count(llpf_bank* b, int64_t* n);
 /* elapsed device milliseconds of the last llpf_run / llpf_bank_run (hipEvents on the handle's stream) */

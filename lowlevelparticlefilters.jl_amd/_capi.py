@@ -75,6 +75,7 @@ SYMBOLS = {
     "llpf_mbank_get_profile": [_vp, C.c_int32, _dp, _ip],
     "llpf_model_compile": [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32)],
     "llpf_model_traits": [C.c_int32, C.POINTER(C.c_int32)],
+    "llpf_weighted_cov": [_vp, _dp],
     "llpf_set_profiling": [_vp, C.c_int32],
     "llpf_get_profile": [_vp, _dp, _ip],
     "llpf_bank_set_profiling": [_vp, C.c_int32],
@@ -214,12 +215,15 @@ class FilterHandle:
         check(self.L.llpf_update(self.h, dptr(u), dptr(y), float(t), C.byref(ll)))
         return ll.value
 
-    def run(self, U, Y, t_index0=0.0, ll_steps=False, xmean=False, history=False):
+    def run(self, U, Y, t_index0=0.0, ll_steps=False, xmean=False, history=False, xcov=False):
         Y = f64(Y).reshape(-1, self.ny)
         T = Y.shape[0]
         U = f64(U).reshape(T, self.nu) if self.nu else None
         outs = S.RunOutputs()
         res = {}
+        if xcov:
+            res["xcov"] = np.zeros((T, self.nx, self.nx))
+            outs.xcov = dptr(res["xcov"])
         if ll_steps:
             res["ll_steps"] = np.zeros(T)
             outs.ll_steps = dptr(res["ll_steps"])
@@ -235,6 +239,12 @@ class FilterHandle:
         check(self.L.llpf_run(self.h, dptr(U), dptr(Y), T, float(t_index0), C.byref(ll), C.byref(outs)))
         res["ll"] = ll.value
         return res
+
+    def weighted_cov(self):
+        """weighted_cov of the current particles under the current weights (reference src/filtering.jl:571-581), on the device"""
+        a = np.zeros((self.nx, self.nx))
+        check(self.L.llpf_weighted_cov(self.h, dptr(a)))
+        return a
 
     def rb_covariance(self):
         """x[1].R of an RBPF: the covariance of the linear substate shared by all particles."""

@@ -50,7 +50,7 @@ class Config(C.Structure):
 class RunOutputs(C.Structure):
     _fields_ = [("ll_steps", C.POINTER(C.c_double)), ("xmean", C.POINTER(C.c_double)),
                 ("x_hist", C.POINTER(C.c_double)), ("w_hist", C.POINTER(C.c_double)),
-                ("we_hist", C.POINTER(C.c_double))]
+                ("we_hist", C.POINTER(C.c_double)), ("xcov", C.POINTER(C.c_double))]
 
 
 class MBankInfo(C.Structure):

@@ -523,7 +523,10 @@ def loglik(pf, u, y, p=None):
 
 def weighted_cov(x, we=None):
     """weighted_cov(x, we) / weighted_cov(sol) — reference src/filtering.jl:573-581: per time step the covariance of
-    the particles under probability weights with StatsBase's correction n / ((n - 1) sum(w)), n = count(w != 0)."""
+    the particles under probability weights with StatsBase's correction n / ((n - 1) sum(w)), n = count(w != 0).
+    weighted_cov(pf): the current particles and weights of a filter, computed on the device (llpf_weighted_cov)."""
+    if isinstance(x, _AbstractParticleFilter):
+        return x._h.weighted_cov()
     if isinstance(x, ParticleFilteringSolution):
         x, we = x.x, x.we
     x, we = np.asarray(x), np.asarray(we)

@@ -118,7 +118,7 @@ int llpf_run(llpf_filter* f, const double* U, const double* Y, int64_t T, double
     NEEDF(f);
     double lt = 0.0;
     int rc = bank_run(f->bank, U, Y, T, t_index0, &lt, o ? o->ll_steps : nullptr, o ? o->xmean : nullptr,
-                      o ? o->x_hist : nullptr, o ? o->w_hist : nullptr, o ? o->we_hist : nullptr);
+                      o ? o->x_hist : nullptr, o ? o->w_hist : nullptr, o ? o->we_hist : nullptr, false, o ? o->xcov : nullptr);
     if (ll_total) *ll_total = lt;
     return rc;
 }
@@ -140,6 +140,7 @@ int llpf_aux_update(llpf_filter* f, const double* u, const double* y1, double t,
 int llpf_aux_run(llpf_filter* f, const double* U, const double* Y, int64_t T, int32_t mode,
                  double* ll_total, const llpf_run_outputs* o) {
     NEEDF(f);
+    if (o && o->xcov) return fail(LLPF_ERR_ARG, "the xcov output is provided by llpf_run only");
     double lt = 0.0;
     int rc = bank_aux_run(f->bank, U, Y, T, mode, &lt, o ? o->ll_steps : nullptr, o ? o->xmean : nullptr,
                           o ? o->x_hist : nullptr, o ? o->w_hist : nullptr, o ? o->we_hist : nullptr);
@@ -279,6 +280,18 @@ int llpf_weighted_mean(llpf_filter* f, double* xh) {
     CHK(use_device(b));
     CHK(bank_wmean(b, b.d_tmp));
     HIPC(hipMemcpyAsync(xh, b.d_tmp, sizeof(double) * b.nxp, hipMemcpyDeviceToHost, b.stream));
+    HIPC(hipStreamSynchronize(b.stream));
+    return LLPF_OK;
+}
+int llpf_weighted_cov(llpf_filter* f, double* cov) {
+    NEEDF(f);
+    Bank& b = f->bank;
+    if (!cov) return fail(LLPF_ERR_ARG, "null output");
+    if (is_rbfull(b)) return fail(LLPF_ERR_ARG, "weighted_cov is not provided for LLPF_MODEL_RB_BILINEAR (take it from the particles)");
+    CHK(use_device(b));
+    CHK(bank_wmean(b, b.d_tmp));
+    HIPC(launch_wcov(b.dev(), b.d_tmp, b.d_tmp + MAXD, b.stream));
+    HIPC(hipMemcpyAsync(cov, b.d_tmp + MAXD, sizeof(double) * b.nx * b.nx, hipMemcpyDeviceToHost, b.stream));
     HIPC(hipStreamSynchronize(b.stream));
     return LLPF_OK;
 }

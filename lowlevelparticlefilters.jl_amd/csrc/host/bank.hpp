@@ -45,7 +45,8 @@ struct Bank {
     size_t capU = 0, capY = 0;
     double* d_ll_steps = nullptr;
     double* d_xmean = nullptr;
-    size_t cap_ll = 0, cap_xm = 0;
+    double* d_xcov = nullptr;         // [T][nx*nx] + a mean: the xcov output of a run
+    size_t cap_ll = 0, cap_xm = 0, cap_xc = 0;
     double* d_tmp = nullptr;         // F*N*max(nx,1) doubles (also reinterpreted as int64 / double staging)
     uint64_t seed = 0;
     uint64_t key_off = 0, key_stride = 1;   // filter f of this bank is filter key_off + f * key_stride of a sharded sweep (llpf_mbank): its
@@ -119,7 +120,7 @@ static void free_bank(Bank& b) {
     b.graphs.clear();
     hipFree(b.d_pool);               // models, scal, x, w, anc, acc, quanta, tileq, flag, xmpart, rtile, rb, uy, tmp
     hipFree(b.d_lam); hipFree(b.d_mark); hipFree(b.d_fxs); hipFree(b.d_rbseq); hipFree(b.d_hist); hipFree(b.d_U); hipFree(b.d_Y);
-    hipFree(b.d_ll_steps); hipFree(b.d_xmean);
+    hipFree(b.d_ll_steps); hipFree(b.d_xmean); hipFree(b.d_xcov);
     for (auto e : b.ev_pool) hipEventDestroy(e);
     for (auto& e : b.pending) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     if (b.ev_run0) hipEventDestroy(b.ev_run0);

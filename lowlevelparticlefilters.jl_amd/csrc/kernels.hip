@@ -182,6 +182,10 @@ hipError_t launch_wmean(const BankDev& b, double* out, hipStream_t s) {
     hipLaunchKernelGGL(k_wmean, dim3((unsigned)b.F), dim3(BLOCK), 0, s, b, out);
     return hipGetLastError();
 }
+hipError_t launch_wcov(const BankDev& b, const double* mean, double* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_wcov, dim3((unsigned)b.F), dim3(BLOCK), 0, s, b, mean, out);
+    return hipGetLastError();
+}
 hipError_t launch_anc64(const BankDev& b, int64_t* dst, hipStream_t s) {
     hipLaunchKernelGGL(k_anc64, grid1(b.N, b.F), dim3(BLOCK), 0, s, b, dst);
     return hipGetLastError();

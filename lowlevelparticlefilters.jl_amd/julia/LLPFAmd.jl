@@ -28,7 +28,7 @@ import LowLevelParticleFilters: AbstractParticleFilter, ParticleFilteringSolutio
     ResamplingStrategy, ResampleSystematic, ResampleStratified, ResampleResidual, SimpleMvNormal,
     reset!, predict!, correct!, update!, forward_trajectory, loglik, smooth, sample_state,
     particles, weights, expweights, state, num_particles, index, particletype, parameters,
-    effective_particles, shouldresample, weighted_mean,
+    effective_particles, shouldresample, weighted_mean, weighted_cov,
     dynamics, measurement, measurement_likelihood, dynamics_density, measurement_density, initial_density,
     resample_threshold, resampling_strategy
 
@@ -90,6 +90,7 @@ struct CRunOutputs                    # llpf_run_outputs
     x_hist::Ptr{Float64}
     w_hist::Ptr{Float64}
     we_hist::Ptr{Float64}
+    xcov::Ptr{Float64}
 end
 struct CMBankInfo                     # llpf_mbank_info_t
     n_filters::Int32
@@ -524,7 +525,7 @@ function run!(pf::GPF, u, y, tindex0; history = false)
     w = history ? Array{Float64}(undef, pf.N, T) : Array{Float64}(undef, 0, 0)
     we = history ? Array{Float64}(undef, pf.N, T) : Array{Float64}(undef, 0, 0)
     GC.@preserve U Y x w we begin
-        outs = Ref(CRunOutputs(C_NULL, C_NULL, history ? pointer(x) : C_NULL, history ? pointer(w) : C_NULL, history ? pointer(we) : C_NULL))
+        outs = Ref(CRunOutputs(C_NULL, C_NULL, history ? pointer(x) : C_NULL, history ? pointer(w) : C_NULL, history ? pointer(we) : C_NULL, C_NULL))
         check(ccall((:llpf_run, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64, Float64, Ref{Float64}, Ref{CRunOutputs}),
                     pf.h, pf.nu > 0 ? pointer(U) : C_NULL, pointer(Y), T, Float64(tindex0), ll, outs))
     end
@@ -565,6 +566,8 @@ particles(pf::GPF{NX}) where {NX} = collect(reinterpret(SVector{NX,Float64}, get
 weights(pf::GPF) = getvec(:llpf_get_weights, pf.h, pf.N)
 expweights(pf::GPF) = getvec(:llpf_get_expweights, pf.h, pf.N)
 weighted_mean(pf::GPF) = getvec(:llpf_weighted_mean, pf.h, pf.nx)
+"weighted_cov of the CURRENT particles and weights, on the device: one time step of the reference's weighted_cov(x, we) (src/filtering.jl:571-581)"
+weighted_cov(pf::GPF) = reshape(getvec(:llpf_weighted_cov, pf.h, pf.nx * pf.nx), pf.nx, pf.nx)
 "state(pf).j, 1-based — src/PFtypes.jl:14"
 function ancestors(pf::GPF)
     j = Vector{Int64}(undef, pf.N)
@@ -677,7 +680,7 @@ function run_aux!(a::GAPF, u, y, mode; history = false)
     w = history ? Array{Float64}(undef, pf.N, T) : Array{Float64}(undef, 0, 0)
     we = history ? Array{Float64}(undef, pf.N, T) : Array{Float64}(undef, 0, 0)
     GC.@preserve U Y x w we begin
-        outs = Ref(CRunOutputs(C_NULL, C_NULL, history ? pointer(x) : C_NULL, history ? pointer(w) : C_NULL, history ? pointer(we) : C_NULL))
+        outs = Ref(CRunOutputs(C_NULL, C_NULL, history ? pointer(x) : C_NULL, history ? pointer(w) : C_NULL, history ? pointer(we) : C_NULL, C_NULL))
         check(ccall((:llpf_aux_run, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64, Int32, Ref{Float64}, Ref{CRunOutputs}),
                     pf.h, pf.nu > 0 ? pointer(U) : C_NULL, pointer(Y), T, Int32(mode), ll, outs))
     end

@@ -909,3 +909,32 @@ def test_c3_full_size_full_length():
     finally:
         ob.set_threads(1)
     assert np.array_equal(r["ll_steps"][:8].view(np.uint64), ro["ll_steps"].view(np.uint64))
+
+
+def test_weighted_cov_on_the_device():
+    """weighted_cov (reference src/filtering.jl:571-581: StatsBase's corrected covariance under probability weights) of the current state as
+    an accessor and per step as a run output: against numpy on the particles / exp-weights the engine returns, and the run output against
+    the accessor; the xcov output does not change the run (same ll, particles, ancestors as a run without it)."""
+    model = M.lg_test_model()
+    _, U, Y = M.simulate_lg(model, 25)
+    cfg = S.make_config(model, 5000, S.PARTICLE_FILTER, S.RESAMPLE_SYSTEMATIC, 0.5, 21, 0)
+    g, g2 = _capi.FilterHandle(cfg), _capi.FilterHandle(cfg)
+    g.reset(); g2.reset()
+
+    def ref_cov(x, we):
+        s = we.sum()
+        mu = (x * we[:, None]).sum(axis=0) / s
+        d = x - mu
+        n = np.count_nonzero(we)
+        return (d * we[:, None]).T @ d * (n / ((n - 1) * s))
+
+    np.testing.assert_allclose(g.weighted_cov(), ref_cov(g.particles(), g.expweights()), rtol=1e-11, atol=1e-15)      # uniform weights after reset!
+    r = g.run(U, Y, 0.0, ll_steps=True, history=True, xcov=True)
+    r2 = g2.run(U, Y, 0.0, ll_steps=True)
+    assert np.array_equal(r["ll_steps"].view(np.uint64), r2["ll_steps"].view(np.uint64)) and np.array_equal(g.ancestors(), g2.ancestors())
+    for k in range(25):
+        np.testing.assert_allclose(r["xcov"][k], ref_cov(r["x"][k], r["we"][k]), rtol=1e-11, atol=1e-15)
+    g.correct(U[0], Y[0], 0.0)
+    np.testing.assert_allclose(g.weighted_cov(), ref_cov(g.particles(), g.expweights()), rtol=1e-11, atol=1e-15)
+    c1 = g.weighted_cov()
+    assert np.array_equal(c1, g.weighted_cov()) and np.array_equal(c1, c1.T)         # fixed order: the same bits again

@@ -168,6 +168,29 @@ def test_user_likelihood_without_a_declared_bound_takes_the_exact_form():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("strategy", [S.RESAMPLE_SYSTEMATIC, S.RESAMPLE_RESIDUAL])
+def test_auxiliary_filter_with_a_likelihood_without_a_declared_bound(strategy):
+    """advisor finding of round 3: a likelihood without `loglik_bound` under the AuxiliaryParticleFilter — the "no bound" marker travels
+    through the auxiliary second half (k_resprop<AUX> / k_step<MODE_AUX2>) and the next weighting as an offset before the exact form
+    replaces it; the results must be the bounded model's to rounding and the reference order's within tolerance, with both resamplers"""
+    import independent_cases as IC
+    case = dict(IC.cases()["pf_lg_laplace"])
+    case["strategy"] = strategy
+    g1 = IC.engine_of(case)
+    case0 = dict(case)
+    case0["user"] = case["user"][:2] + (UM.LAPLACE_NO_BOUND_SRC,) + case["user"][3:]
+    g0 = IC.engine_of(case0)
+    orf = IC.oracle_of(ob, case, ob.ORDER_REFERENCE)
+    for mode in (0, 1):
+        for h in (g0, g1, orf):
+            h.reset()
+        r0, r1, rr = (h.run_aux(case["U"], case["Y"], mode, ll_steps=True) for h in (g0, g1, orf))
+        assert np.all(np.isfinite(r0["ll_steps"]))
+        assert np.max(np.abs(r0["ll_steps"] - r1["ll_steps"])) <= 1e-12 and np.max(np.abs(r0["ll_steps"] - rr["ll_steps"])) <= 1e-10
+        assert np.array_equal(g0.ancestors(), g1.ancestors()) and np.max(np.abs(g0.particles() - g1.particles())) <= 1e-12
+
+
+@pytest.mark.gpu
 def test_user_likelihood_through_the_filter_objects():
     """the mirror of the reference's constructor: AdvancedParticleFilter(N, dynamics, measurement, measurement_likelihood, df, d0) with
     UserDynamics / UserMeasurement / UserLikelihood descriptors (lowlevelparticlefilters.jl_amd/api.py; julia/LLPFAmd.jl has the same)"""
