@@ -551,6 +551,9 @@ def main():
         fused = aux or not n_cls[2]               # no standalone resample launches => the fused k_resprop ran
         names = ["k_resprop(finalize+resample+propagate+weight)" if fused else "k_step(propagate+weight)",
                  "k_norm(exp-weights, sums, quanta)", "k_resample(finalize+scan+counts+ancestors)", "other"]
+        if args.workload == "quadtank":
+            names[0] = "k_step<MARKS>(marks->ancestors, gather f(x[anc]), noise, weight, exp-sums)"
+            names[2] = "k_resample_fx(finalize+scan+counts, f(x_j) per surviving source, run-start marks)"
         if aux:
             names = ["k_resprop<AUX>(expnormalize+resample+permute+noise+weights)", "k_step<MODE_AUX>(noise-free propagate + look-ahead lambda)",
                      "finalize(logsumexp of lambda - log N)", "other"]
@@ -575,6 +578,8 @@ def main():
             b_step = b_model = 16 * nx + 20
         else:
             b_step = b_model = 16 * nx + (20 if not n_cls[1] else 12)
+            if args.workload == "quadtank":      # k_step<..., MARKS>: run-start marks read (4) AND ancestors written (4) by the step kernel
+                b_step = b_model = 16 * nx + 24
         if rbfull:
             # the particle plane of this model has rows = xn + xl + packed lower triangle of R (4 + 8 + 36 = 48):
             # k_rbfull reads ancestor 4 + gathers 8 rows + writes 8 rows + writes w 8; whole timestep adds the k_norm /

@@ -395,16 +395,18 @@ int  llpf_set_profiling(llpf_filter* f, int32_t on);
 int  llpf_get_profile(llpf_filter* f, double* ms /* LLPF_PROF_CLASSES */, int64_t* launches /* LLPF_PROF_CLASSES */);
 int  llpf_bank_set_profiling(llpf_bank* b, int32_t on);
 int  llpf_bank_get_profile(llpf_bank* b, double* ms, int64_t* launches);
-/* number of predict! calls of the last run that resampled (summed over filters for a bank) */
 /* weighted_cov of the current particles under the current weights (reference src/filtering.jl:571-581), nx*nx row-major, on the device */
 int  llpf_weighted_cov(llpf_filter* f, double* cov);
+/* number of predict! calls of the last run that resampled (summed over filters for a bank) */
 int  llpf_resample_count(llpf_filter* f, int64_t* n);
 int  llpf_bank_resample_count(llpf_bank* b, int64_t* n);
 /* elapsed device milliseconds of the last llpf_run / llpf_bank_run (hipEvents on the handle's stream) */
 int  llpf_last_run_ms(llpf_filter* f, double* ms);
-/* how the last llpf_run drove its fused timesteps: launches of the fused predict! kernel (a persistent multi-step launch counts
- * once) and the number of timesteps that ran inside persistent launches (0: one launch per timestep) */
-int  llpf_last_run_stats(llpf_filter* f, int64_t* fused_launches, int64_t* persistent_timesteps);
+/* how the last llpf_run drove its timesteps: launches of the fused predict! kernel (0: the balanced form ran); timesteps that took the
+ * source-side form of the balanced timestep (dynamics once per surviving source, k_resample_fx; 0: dynamics per output particle); and
+ * the survivor fraction the choice for the NEXT run is made by (distinct ancestors per predict! / N, a step that did not resample
+ * counting as 1; -1 when the model cannot take the source-side form).  Results do not depend on the form: the choice is a schedule. */
+int  llpf_last_run_stats(llpf_filter* f, int64_t* fused_launches, int64_t* source_side_timesteps, double* survivor_fraction);
 int  llpf_bank_last_run_ms(llpf_bank* b, double* ms);
 
 /* ---- misc -------------------------------------------------------------------------------- */

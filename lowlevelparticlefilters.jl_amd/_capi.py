@@ -83,7 +83,7 @@ SYMBOLS = {
     "llpf_resample_count": [_vp, _ip],
     "llpf_bank_resample_count": [_vp, _ip],
     "llpf_last_run_ms": [_vp, _dp],
-    "llpf_last_run_stats": [_vp, _ip, _ip],
+    "llpf_last_run_stats": [_vp, _ip, _ip, _dp],
     "llpf_bank_last_run_ms": [_vp, _dp],
     "llpf_last_error": [],
     "llpf_version": [C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
@@ -388,9 +388,9 @@ class FilterHandle:
         return v.value
 
     def last_run_stats(self):
-        a, b = C.c_int64(0), C.c_int64(0)
-        check(self.L.llpf_last_run_stats(self.h, C.byref(a), C.byref(b)))
-        return {"fused_launches": a.value, "persistent_timesteps": b.value}
+        a, b, c = C.c_int64(0), C.c_int64(0), C.c_double(0.0)
+        check(self.L.llpf_last_run_stats(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"fused_launches": a.value, "source_side_timesteps": b.value, "survivor_fraction": c.value}
 
     def set_profiling(self, on):
         check(self.L.llpf_set_profiling(self.h, 1 if on else 0))

@@ -303,10 +303,11 @@ int llpf_model_traits(int32_t model_id, int32_t* traits) {
     *traits = t;
     return LLPF_OK;
 }
-int llpf_last_run_stats(llpf_filter* f, int64_t* fused_launches, int64_t* persistent_timesteps) {
+int llpf_last_run_stats(llpf_filter* f, int64_t* fused_launches, int64_t* source_side_timesteps, double* survivor_fraction) {
     NEEDF(f);
     if (fused_launches) *fused_launches = f->bank.last_run_launches;
-    if (persistent_timesteps) *persistent_timesteps = f->bank.last_run_persistent_steps;
+    if (source_side_timesteps) *source_side_timesteps = f->bank.last_run_fx_steps;
+    if (survivor_fraction) *survivor_fraction = f->bank.last_run_surv;
     return LLPF_OK;
 }
 int llpf_last_run_ms(llpf_filter* f, double* ms) { NEEDF(f); if (ms) *ms = f->bank.last_run_ms; return LLPF_OK; }

@@ -169,6 +169,9 @@ struct BankDev {
     // source-side dynamics (k_resample_fx + k_step with StepArgs::marks; kernels/resfx.hpp): allocated on first use
     int32_t* mark;       // [F][Ns] run-start marks of a resampling: 1 + ancestor at the first output of every surviving source and at
                          //         every k_step block boundary inside its output range; zero everywhere else (k_step clears what it reads)
+    unsigned long long* surv;   // [F][P2][4] per tile (and wave of k_resample), over the predict!s of a run: sources whose f(x) the step needed (distinct ancestors; the tile's
+                         //   particles when nothing was resampled) — what the host chooses the next run's form of the balanced timestep by
+                         //   (host/run.hpp).  One plain read-modify-write per block and step: same-address atomics from 977 blocks cost 8 us.
     double* fxs;         // [F][NX][Ns] f(x_j) of the surviving sources j, written by k_resample_fx, gathered by k_step
 };
 constexpr int32_t MARK_OWN = 0x40000000;     // flag of a mark that holds for its own output only: an output without an owner (resample.jl:27-35 writes nothing: j keeps its previous value)
@@ -242,6 +245,7 @@ struct ResArgs {
     double* xmean;         // [T][F][nx] or nullptr
     int64_t k;             // epoch of this launch within a run (for the bank_flag stop test; recorded by a failed bound test)
     int64_t row;           // row of ll_steps / xmean this finalize writes
+    int32_t count_surv;    // k_resample: add the number of distinct ancestors to BankDev::surv (models that could take the source-side form)
     int32_t ablate;        // developer aid (LLPF_ABLATE): bit0 skip RNG, bit1 skip owner search, bit2 skip model math; results invalid
     uint64_t* dbg;         // optional [P2][8] phase timestamps of one launch (s_memrealtime, 100 MHz), or nullptr
 };

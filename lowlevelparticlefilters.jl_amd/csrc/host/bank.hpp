@@ -23,7 +23,8 @@ struct Bank {
     int qcur = 0;                    // quanta buffer that holds the quanta of the current weights
     uint64_t* d_tileq = nullptr;
     uint32_t* d_flag = nullptr;
-    int64_t last_run_launches = 0, last_run_persistent_steps = 0;
+    int64_t last_run_launches = 0, last_run_fx_steps = 0;
+    double last_run_surv = -1.0;
     double* d_xmpart = nullptr;
     // Rao-Blackwellized model: host side of the shared covariance recursion (csrc/shared/llpf_rbkf.h)
     struct RBHost { double R[16], kfx[4], kfR[16]; };
@@ -34,6 +35,9 @@ struct Bank {
     size_t cap_rbseq = 0;
     uint64_t* d_rtile = nullptr;      // [F][2][P2] residual resampling: per-tile counts / residual sums and their prefixes
     double* d_lam = nullptr;          // [F][Ns] lambda of the AuxiliaryParticleFilter predict! (allocated on first use)
+    double surv_frac = -1.0;          // distinct ancestors per predict! / N over the last run of a model that can take the source-side form (-1: none yet)
+    bool use_fx = true;               //   ... and the form the next run takes (hysteresis: host/run.hpp)
+    unsigned long long* d_surv = nullptr;   // [F][P2][4] survivor counters of a run (BankDev::surv)
     int32_t* d_mark = nullptr;        // [F][Ns] run-start marks / [F][nx][Ns] f(x_j): resampling with source-side dynamics (kernels/resfx.hpp),
     double* d_fxs = nullptr;          //   allocated on first use (ensure_fx)
     bool aux_pending = false;         // w holds lambda - log N of an aux predict!; their exp-sums wait in slot (parity+2)%3
@@ -92,7 +96,7 @@ struct Bank {
         b.models = d_models; b.scal = d_scal;
         b.xcur = d_x[cur]; b.xnext = d_x[cur ^ 1];
         b.w = d_w; b.anc = d_anc; b.acc = d_acc; b.quanta = d_quanta[qcur]; b.quanta_next = d_quanta[qcur ^ 1]; b.tileq = d_tileq;
-        b.bank_flag = d_flag; b.xmpart = d_xmpart; b.lam = d_lam; b.rtile = d_rtile; b.mark = d_mark; b.fxs = d_fxs;
+        b.bank_flag = d_flag; b.xmpart = d_xmpart; b.lam = d_lam; b.rtile = d_rtile; b.mark = d_mark; b.fxs = d_fxs; b.surv = d_surv;
         b.anc_slot = (int32_t)(n_predict & 1u);
         b.pad0 = (cfg.model.model_id == LLPF_MODEL_RB_BILINEAR) ? (cfg.model.rb.nxl | (cfg.model.rb.fn_kind << 8)) : 0;
         b.xrows = xrows; b.pad1 = 0;
@@ -119,7 +123,7 @@ static void free_bank(Bank& b) {
     for (auto& g : b.graphs) if (g.exec) hipGraphExecDestroy(g.exec);
     b.graphs.clear();
     hipFree(b.d_pool);               // models, scal, x, w, anc, acc, quanta, tileq, flag, xmpart, rtile, rb, uy, tmp
-    hipFree(b.d_lam); hipFree(b.d_mark); hipFree(b.d_fxs); hipFree(b.d_rbseq); hipFree(b.d_hist); hipFree(b.d_U); hipFree(b.d_Y);
+    hipFree(b.d_lam); hipFree(b.d_surv); hipFree(b.d_mark); hipFree(b.d_fxs); hipFree(b.d_rbseq); hipFree(b.d_hist); hipFree(b.d_U); hipFree(b.d_Y);
     hipFree(b.d_ll_steps); hipFree(b.d_xmean); hipFree(b.d_xcov);
     for (auto e : b.ev_pool) hipEventDestroy(e);
     for (auto& e : b.pending) { hipEventDestroy(e.a); hipEventDestroy(e.b); }

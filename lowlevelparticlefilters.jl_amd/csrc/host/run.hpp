@@ -73,8 +73,11 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
     // ancestor round trip but its propagate work follows the weight distribution; models whose dynamics dominate the
     // timestep (quad-tank RK4: 32 fp64 sqrt per particle) and whose ESS is small run faster balanced (measured 69 vs
     // 121 us per timestep at N = 1e6), the linear-Gaussian model faster fused.  LLPF_UNFUSED=0/1 overrides.
-    static const char* unf_env = getenv("LLPF_UNFUSED");
-    const bool heavy_dynamics = b.cfg.model.model_id == LLPF_MODEL_QUADTANK_RK4;
+    const char* unf_env = getenv("LLPF_UNFUSED");
+    // ... and so does the linear-Gaussian model from three states on (measured at N = 1e6 on model-simulated data, tools/bench_nx.py:
+    // nx 2 fused 21.1 / balanced 24.8 us per timestep, nx 3 33.8 / 28.8, nx 4 38.2 / 30.5 — the fused kernel drops to three waves per SIMD there)
+    const bool heavy_dynamics = b.cfg.model.model_id == LLPF_MODEL_QUADTANK_RK4 ||
+                                (b.cfg.model.model_id == LLPF_MODEL_LINEAR_GAUSSIAN && b.nx >= 3 && !is_rb(b));
     // residual resampling produces unsorted ancestors (copies first, multinomial draws after): always the balanced form
     const bool residual = b.cfg.resampling_strategy == LLPF_RESAMPLE_RESIDUAL;
     const bool rbm = is_rb(b);
@@ -84,8 +87,20 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
     const bool unfused = user_model || rbfull || hist || residual || xcov != nullptr || (unf_env ? atoi(unf_env) != 0 : heavy_dynamics);
     // models whose dynamics are worth a table: the resampling launch evaluates f(x_j) once per surviving source and leaves run-start marks,
     // the step kernel gathers (kernels/resfx.hpp).  LLPF_SOURCE_FX=0 takes the round-3 form (ancestors to HBM, f per distinct ancestor of a block)
-    static const char* sfx_env = getenv("LLPF_SOURCE_FX");
-    const bool source_fx = unfused && !(sfx_env && atoi(sfx_env) == 0) && resample_fx_supported(b.cfg.model.model_id, b.nx, b.ny, b.cfg.resampling_strategy);
+    const char* sfx_env = getenv("LLPF_SOURCE_FX");
+    // Which of the two pays depends on how many sources survive a resampling — every f(x) of the source-side form makes a round trip
+    // through HBM.  Quad-tank, N = 1e6, us per timestep (tools/dbg/qt_regimes.py; EXPERIMENTS.md 4.13): 0.8 % distinct ancestors
+    // (BASELINE C3) 31.7 source-side / 36.3 per output, 4.9 % 35.1 / 36.0, 10.5 % 39.6 / 37.2, 24.6 % 47.0 / 38.9, 71 % 54.0 / 47.2.  Both launches count the sources whose f the step
+    // needed (BankDev::surv, per tile); the host switches the NEXT run's form with a hysteresis (below 5 % -> source-side, above 8 % -> per
+    // output).  A handle's first run takes the source-side form.  LLPF_SOURCE_FX=0/1 pins it.
+    const bool fx_capable = unfused && resample_fx_supported(b.cfg.model.model_id, b.nx, b.ny, b.cfg.resampling_strategy);
+    if (fx_capable && b.surv_frac >= 0.0) { if (b.surv_frac < 0.05) b.use_fx = true; else if (b.surv_frac > 0.08) b.use_fx = false; }
+    const bool source_fx = fx_capable && (sfx_env ? atoi(sfx_env) != 0 : b.use_fx);
+    const size_t n_surv = (size_t)b.F * b.P2 * 4;
+    if (fx_capable) {
+        if (!b.d_surv) HIPC(hipMalloc(&b.d_surv, sizeof(unsigned long long) * n_surv));
+        HIPC(hipMemsetAsync(b.d_surv, 0, sizeof(unsigned long long) * n_surv, b.stream));
+    }
     if (source_fx) CHK(ensure_fx(b));
     if (rbm) {
         // the whole gain schedule of the run (data independent): corr_0, pred_0, corr_1, pred_1, ..., [F] each
@@ -133,7 +148,7 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
     auto res_args = [&](int64_t k, bool fast) {
         ResArgs ra{};
         ra.parity = head_slot(k); ra.step = rel_step(b); ra.M = (int32_t)b.N; ra.anc_out = b.d_anc;
-        ra.accumulate = 1; ra.want_xmean = want_xm; ra.u_from_scal = 1;
+        ra.accumulate = 1; ra.want_xmean = want_xm; ra.u_from_scal = 1; ra.count_surv = fx_capable ? 1 : 0;
         ra.ll_steps = ll_steps ? b.d_ll_steps : nullptr;
         ra.xmean = want_xm ? b.d_xmean : nullptr;
         ra.k = k; ra.row = k; ra.fast_head = fast ? 1 : 0;
@@ -254,7 +269,7 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
         HIPC(launch_step(d, MODE_WEIGHT, a, b.stream));
         return LLPF_OK;
     };
-    b.last_run_launches = 0; b.last_run_persistent_steps = 0;
+    b.last_run_launches = 0; b.last_run_fx_steps = source_fx ? T : 0; b.last_run_surv = -1.0;
     // the asynchronous loop as a captured graph, replayed when nothing a launch argument depends on has changed
     static const char* graph_env = getenv("LLPF_GRAPH");
     const bool use_graph = !hist && !b.profiling && !dbg_env && !(graph_env && atoi(graph_env) == 0);
@@ -398,5 +413,12 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
         if (ll_total) ll_total[f] = h[f].ll_total;
         b.run_resamples += h[f].resample_count;
     }
+    double surv = 0.0;
+    if (fx_capable) {
+        std::vector<unsigned long long> hs(n_surv);
+        HIPC(hipMemcpy(hs.data(), b.d_surv, sizeof(unsigned long long) * n_surv, hipMemcpyDeviceToHost));
+        for (unsigned long long v : hs) surv += (double)v;
+    }
+    if (fx_capable && T >= 1) b.last_run_surv = b.surv_frac = surv / ((double)T * (double)b.N * (double)b.F);
     return check_status(b, h);
 }

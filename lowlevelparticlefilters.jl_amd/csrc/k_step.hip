@@ -67,7 +67,7 @@ static unsigned step_grid_x_marks(const BankDev& b) {
 }
 template <class Model, int NX, int NY, int PPT = STEP_PPT>
 static hipError_t launch_step_t(const BankDev& b, int mode, const StepArgs& a, hipStream_t s) {
-    if constexpr (share_dynamics<Model>::value && !Model::RB && PPT == STEP_PPT) {
+    if constexpr (marks_path<Model>::value && PPT == STEP_PPT) {
         if (a.marks && (mode == MODE_PROP || mode == MODE_PROP_WEIGHT)) {      // the form that follows k_resample_fx
             if (!b.mark || !b.fxs) return hipErrorInvalidValue;
             dim3 g(step_grid_x_marks(b), (unsigned)b.F, 1);
@@ -160,15 +160,19 @@ bool resample_fx_supported(int model_id, int nx, int ny, int strategy) {
     if (model_id >= LLPF_MODEL_USER_BASE) return jit_marks(model_id);
     return model_id == LLPF_MODEL_QUADTANK_RK4 && nx == 4 && ny == 2 && LLPF_QT_PPT == STEP_PPT;
 }
+template <class Model, int NX>
+static hipError_t launch_resample_fx_t(const BankDev& b, const ResArgs& a, const StepArgs& st, hipStream_t s) {
+    const dim3 g((unsigned)b.P2, (unsigned)b.F, 1);
+    if (b.strategy == LLPF_RESAMPLE_SYSTEMATIC) hipLaunchKernelGGL((k_resample_fx<Model, NX, LLPF_RESAMPLE_SYSTEMATIC>), g, dim3(BLOCK), 0, s, b, a, st);
+    else hipLaunchKernelGGL((k_resample_fx<Model, NX, LLPF_RESAMPLE_STRATIFIED>), g, dim3(BLOCK), 0, s, b, a, st);
+    return hipGetLastError();
+}
 hipError_t launch_resample_fx(const BankDev& b, const ResArgs& a0, const StepArgs& st, hipStream_t s) {
     if (!resample_fx_supported(b.model_id, b.nx, b.ny, b.strategy) || !b.mark || !b.fxs) return hipErrorInvalidValue;
     ResArgs a = a0;
     a.K = llpf_qbits(b.N);
     if (b.model_id >= LLPF_MODEL_USER_BASE) return launch_resample_fx_user(b, a, st, s);
-    const dim3 g((unsigned)b.P2, (unsigned)b.F, 1);
-    if (b.strategy == LLPF_RESAMPLE_SYSTEMATIC) hipLaunchKernelGGL((k_resample_fx<QuadTank<4, 2>, 4, LLPF_RESAMPLE_SYSTEMATIC>), g, dim3(BLOCK), 0, s, b, a, st);
-    else hipLaunchKernelGGL((k_resample_fx<QuadTank<4, 2>, 4, LLPF_RESAMPLE_STRATIFIED>), g, dim3(BLOCK), 0, s, b, a, st);
-    return hipGetLastError();
+    return launch_resample_fx_t<QuadTank<4, 2>, 4>(b, a, st, s);
 }
 
 hipError_t launch_max(const BankDev& b, int parity, hipStream_t s) {

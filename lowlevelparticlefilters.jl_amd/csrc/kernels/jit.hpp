@@ -65,7 +65,8 @@ static int jit_compile_model(const char* device_src, int nx, int ny, bool intern
     expr[4] = "llpf::k_user_bound<llpf::UserModel>";
     expr[5] = "llpf::k_smooth_fx<llpf::UserModel, " + std::to_string(nx) + ", " + std::to_string(ny) + ">";
     // a user's dynamics are taken to be worth a table (share_dynamics, kernels/models.hpp): the resampling launch evaluates them once per
-    // surviving source and the step kernel gathers (kernels/resfx.hpp); the internally generated linear-Gaussian snippet opts out
+    // surviving source and the step kernel gathers (kernels/resfx.hpp)
+    // (not the internally generated linear-Gaussian snippet, nx or ny above 4: kernels/models.hpp, marks_path)
     const bool marks = !internal;
     const int nk = marks ? JitModel::NK : 6;
     if (marks) {

@@ -437,6 +437,10 @@ template <class Model> struct share_dynamics { static constexpr bool value = !ha
 template <int NX, int NY> struct share_dynamics<LinGauss<NX, NY>> { static constexpr bool value = false; };
 template <int NX, int NY> struct share_dynamics<RBLin<NX, NY>> { static constexpr bool value = false; };
 template <int NX> struct share_dynamics<NoModel<NX>> { static constexpr bool value = false; };
+// Can the run loop of this model take the source-side form of the balanced timestep (k_resample_fx + k_step<..., MARKS>,
+// kernels/resfx.hpp)?  The models whose dynamics are worth a table.  (The linear-Gaussian model is not: measured at nx = 3..8 the form
+// costs it 60-130 % — f is a matrix-vector product and with healthy weights half of the particles survive — tools/bench_nx.py.)
+template <class Model> struct marks_path { static constexpr bool value = share_dynamics<Model>::value && !Model::RB; };
 
 // a model whose dynamics can also run with the states spread over the lanes of a quad (NX == 4): dynamics_quad(x_own, lane & 3)
 template <class M, class = void> struct has_quad_dynamics { static constexpr bool value = false; };

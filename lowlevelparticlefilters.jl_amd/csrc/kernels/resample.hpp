@@ -473,11 +473,24 @@ __global__ __launch_bounds__(BLOCK) void k_resample(BankDev b, ResArgs a) {
     if (h.status == RES_STATUS_SKIP) return;
     if (!(a.mode & RES_RESAMPLE)) return;
     if (h.status) return;
-    if (!a.force && !h.dr) return;
+    if (!a.force && !h.dr) {
+        if (SRC == SRC_FILTER && a.count_surv && threadIdx.x == 0) {      // j = 1:N: every particle is its own ancestor
+            const int64_t left = b.N - (int64_t)tile * TILE;
+            if (left > 0) b.surv[((size_t)f * b.P2 + tile) * 4] += (unsigned long long)(left < TILE ? left : TILE);
+        }
+        return;
+    }
     if (h.tot == 0) return;
     int32_t c_start, c_end;
     res_counts<STRATEGY>(b, a, f, tile, h, qv, sh, c_start, c_end);
     if (a.only_bins) return;
+    if (SRC == SRC_FILTER && a.count_surv) {      // distinct ancestors of this tile: sources with a non-empty output range
+        const uint4 c4 = *reinterpret_cast<const uint4*>(sh.cl + 4 * threadIdx.x);
+        const uint32_t p0 = threadIdx.x ? sh.cl[4 * threadIdx.x - 1] : (uint32_t)c_start;
+        const int n = (c4.x > p0) + (c4.y > c4.x) + (c4.z > c4.y) + (c4.w > c4.z);
+        const unsigned long long ws = wave_sum_u64((uint64_t)n);
+        if ((threadIdx.x & 63) == 0 && ws) b.surv[((size_t)f * b.P2 + tile) * 4 + (threadIdx.x >> 6)] += ws;      // one entry per wave: no block reduction
+    }
     int32_t* ao = a.anc_out + (size_t)f * b.Ns;
     const bool table = c_end - c_start >= BLOCK;       // block-uniform; a table for a handful of outputs would not pay
     if (table) {

@@ -72,6 +72,7 @@ __global__ __launch_bounds__(BLOCK) void k_resample_fx(BankDev b, ResArgs a, Ste
         }
     };
     if (!a.force && !h.dr) {
+        if (t == 0) { const int64_t left = b.N - (int64_t)tile * TILE; if (left > 0) b.surv[((size_t)f * b.P2 + tile) * 4] += (unsigned long long)(left < TILE ? left : TILE); }
         // no resampling in this predict!: j = 1:N, every particle propagates itself — f(x_i) for the tile's particles
 #pragma unroll 1
         for (int k = 0; k < NORM_IPT; ++k) {
@@ -113,6 +114,7 @@ __global__ __launch_bounds__(BLOCK) void k_resample_fx(BankDev b, ResArgs a, Ste
     __syncthreads();
     const int D = (int)sh_cnt[0];
     FX_STAMP(3, D);                     // survivors listed
+    if (t == 0 && D) b.surv[((size_t)f * b.P2 + tile) * 4] += (unsigned long long)D;      // what the host chooses the next run's form by (host/run.hpp)
 
     // A handful of survivors (peaked likelihoods: ~8 per tile at BASELINE C3) and a model whose dynamics can run with its states
     // spread over a quad: four lanes per survivor, a third of the dependent chain (QuadTank::dynamics_quad).  Survivor q sits on lanes

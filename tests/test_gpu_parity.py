@@ -224,6 +224,44 @@ def test_quadtank_bit_exact_and_tolerance():
     assert g.resample_count() == o.resample_count() > 0
 
 
+@pytest.mark.parametrize("form", ["1", "0"])
+def test_quadtank_both_forms_of_the_balanced_timestep_give_the_oracles_bits(form, monkeypatch):
+    """Dynamics once per surviving source (k_resample_fx + k_step<MARKS>, LLPF_SOURCE_FX=1) or once per output particle (=0): a schedule,
+    not a result — both the device-order oracle's bits, at a size of several tiles, with a step that does not resample in between."""
+    monkeypatch.setenv("LLPF_SOURCE_FX", form)
+    model = M.quadtank_model()
+    U, Y = M.quadtank_data(30)
+    Y[11] = np.nan
+    cfg = _cfg(model, 9001, thr=0.5, kind=S.ADVANCED_PARTICLE_FILTER, seed=31)
+    g = _capi.FilterHandle(cfg); o = ob.OracleFilter(cfg, ob.ORDER_DEVICE)
+    g.reset(); o.reset()
+    rg = g.run(U, Y, 490.0, ll_steps=True); ro = o.run(U, Y, 490.0, ll_steps=True)
+    assert np.array_equal(rg["ll_steps"].view(np.uint64), ro["ll_steps"].view(np.uint64))
+    _compare_state(g, o)
+    assert g.last_run_stats()["source_side_timesteps"] == (30 if form == "1" else 0)
+
+
+def test_quadtank_handle_chooses_the_form_by_the_survivor_fraction(monkeypatch):
+    """A handle's first run takes the source-side form; from then on the form follows the survivor fraction of the run before (distinct
+    ancestors per predict! / N: below 5 % source-side, above 8 % per output particle).  Healthy weights (wide measurement noise): the
+    second run switches; peaked weights (BASELINE C3's 1 cm noise): it stays.  Either way the oracle's bits."""
+    monkeypatch.delenv("LLPF_SOURCE_FX", raising=False)
+    U, Y = M.quadtank_data(25)
+    for sig, stays in ((0.5, False), (0.01, True)):
+        model = M.quadtank_model()
+        model.measurement_density = S.make_gaussian(np.zeros(2), np.full(2, sig ** 2))
+        cfg = _cfg(model, 20000, thr=0.5, kind=S.ADVANCED_PARTICLE_FILTER, seed=32)
+        g = _capi.FilterHandle(cfg); o = ob.OracleFilter(cfg, ob.ORDER_DEVICE)
+        for run in range(2):
+            g.reset(); o.reset()
+            rg = g.run(U, Y, 1.0, ll_steps=True); ro = o.run(U, Y, 1.0, ll_steps=True)
+            assert np.array_equal(rg["ll_steps"].view(np.uint64), ro["ll_steps"].view(np.uint64)), (sig, run)
+            _compare_state(g, o)
+            st = g.last_run_stats()
+            assert st["source_side_timesteps"] == (25 if run == 0 or stays else 0), (sig, run, st)
+            assert (st["survivor_fraction"] < 0.03) == stays, (sig, run, st)
+
+
 def test_missing_measurement():
     model = M.lg_c1_model()
     _, U, Y = M.simulate_lg(model, 30)

@@ -24,6 +24,7 @@ python bench.py --workload rbpf_full > $OUT/bench_c5_rbpf_full.json 2>> $OUT/ben
 python tools/bench_smooth.py > $OUT/bench_ffbs_smoother.json 2>> $OUT/bench_c2.err
 python tools/bench_smooth.py --particles 1000 --T 200 --M 100 --cpu-M 100 >> $OUT/bench_ffbs_smoother.json 2>> $OUT/bench_c2.err
 python tools/bench_mc.py > $OUT/bench_reference_mc_run_test.json 2>> $OUT/bench_c2.err
+python tools/bench_nx.py > $OUT/bench_state_dimension.json 2>> $OUT/bench_c2.err
 tools/ab/schedules.sh > $OUT/schedules_ab.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace -d $OUT/kt -o kt -- python $ROOT/bench.py --no-cpu-baseline > $OUT/kt.log 2>&1

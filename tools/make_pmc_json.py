@@ -50,9 +50,13 @@ if e:
 e = entry(os.path.join(d, "pmc_traffic_c5.txt"), "k_rbfull<", 788 * 200000)
 if e:
     j["c5"] = {"source": "profiles/%s_pmc_traffic_c5.txt (same recipe, workload rbpf_full N=2e5, T=200)" % tag, "k_rbfull": e, "n_particles": 200000}
-e = entry(os.path.join(d, "pmc_traffic_quadtank.txt"), "k_step<llpf::QuadTank", 84 * N)
+# round 4: k_step<..., MARKS>: marks 4 + gather f(x[anc]) 8 nx (mostly L2 hits: few distinct ancestors) + ancestors 4 + x 8 nx + w 8 + quanta 8
+e = entry(os.path.join(d, "pmc_traffic_quadtank.txt"), "k_step<llpf::QuadTank", 88 * N)
+er = entry(os.path.join(d, "pmc_traffic_quadtank.txt"), "k_resample_fx<llpf::QuadTank", 8 * N)
 if e:
     j["c3"] = {"source": "profiles/%s_pmc_traffic_quadtank.txt (same recipe, workload quadtank N=1e6, T=100)" % tag, "k_step": e, "n_particles": N}
+    if er:
+        j["c3"]["k_resample_fx"] = er
 e1 = entry(os.path.join(d, "pmc_traffic_bank.txt"), "k_resprop<llpf::LinGauss<2, 1>", 52 * 12800000)
 e2 = entry(os.path.join(d, "pmc_traffic_bank.txt"), "k_norm", 16 * 12800000)
 if e1 and e2:
