@@ -558,7 +558,7 @@ def main():
             names = ["k_resprop<AUX>(expnormalize+resample+permute+noise+weights)", "k_step<MODE_AUX>(noise-free propagate + look-ahead lambda)",
                      "finalize(logsumexp of lambda - log N)", "other"]
         kernel_us = {names[i]: (1e3 * ms_cls[i] / n_cls[i] if n_cls[i] else None) for i in range(4)}
-        # Dominant kernel and its algorithmic bytes (DESIGN.md §4, SURVEY.md §8(d)).
+        # Dominant kernel and its algorithmic bytes (DESIGN.md §4-5, SURVEY.md §8(d)).
         #   one-launch timestep (fused k_resprop that also forms the exp-sums: no k_norm launches): the launch IS the
         #     particle-step, so it is priced with SURVEY §8(d)'s figure B_alg = 16 nx + 40 bytes per particle-step;
         #     the bytes this kernel itself has to move (its HBM model, compared with the PMC traffic) are fewer:

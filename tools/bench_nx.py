@@ -1,9 +1,11 @@
 """The timestep of a single linear-Gaussian filter (N = 1e6, resample every step) against the state dimension and the schedule:
   fused      one launch (k_resprop), precompiled for nx <= 4                                   LLPF_UNFUSED=0
-  balanced   k_resample + k_step, ancestors through HBM (round-3 form)                         LLPF_UNFUSED=1 LLPF_SOURCE_FX=0
-  marks      k_resample_fx + k_step<MARKS> (round 4; the default from nx = 3 on, kernels/models.hpp: marks_path)
-nx >= 5 is compiled on demand (hiprtc).  VERDICT r3 weak #8 asked for the cliff between nx = 4 and nx = 5 to be visible: measuring it
-showed the cliff was at nx = 3 — the fused kernel needs three waves per SIMD there — which is why those dimensions now take the marks form.
+  balanced   k_resample + k_step, ancestors through HBM                                        LLPF_UNFUSED=1
+  default    what the engine picks with no switch set (host/run.hpp: fused for nx <= 2, balanced from nx = 3 on)
+nx >= 5 is compiled on demand (hiprtc) and has the balanced form only.  The round-3 review asked for the step between nx = 4 and nx = 5
+to be visible: measuring it showed the cliff was at nx = 3 — the fused kernel needs three waves per SIMD there — which is why those
+dimensions now run balanced.  (The source-side form of the quad-tank, k_resample_fx + k_step<MARKS>, was measured for this model too and
+costs it 60-130 %: EXPERIMENTS.md 4.14.)
     python tools/bench_nx.py [--particles 1000000] [--T 200]          (one subprocess per row: the schedule switches are read per process)"""
 import argparse, json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -44,12 +46,10 @@ if a.one:
 
 rows = []
 for nx in (2, 3, 4, 5, 8):
-    for name, env in (("fused", {"LLPF_UNFUSED": "0"}), ("balanced", {"LLPF_UNFUSED": "1", "LLPF_SOURCE_FX": "0"}), ("marks", {"LLPF_UNFUSED": "1"})):
+    for name, env in (("fused", {"LLPF_UNFUSED": "0"}), ("balanced", {"LLPF_UNFUSED": "1"}), ("default", {})):
         if nx > 4 and name == "fused":
             continue
-        if nx == 2 and name == "marks":
-            continue
-        e = dict(os.environ); e.update(env)
+        e = dict(os.environ); e.pop("LLPF_UNFUSED", None); e.update(env)
         out = subprocess.run([sys.executable, os.path.abspath(__file__), "--one", str(nx), "--particles", str(a.particles), "--T", str(a.T)],
                              env=e, capture_output=True, text=True)
         try:
@@ -59,4 +59,4 @@ for nx in (2, 3, 4, 5, 8):
             continue
         rows.append({"nx": nx, "ny": 2, "schedule": name, "compiled": "hiprtc" if nx > 4 else "precompiled", "us_per_timestep": round(d["us"], 2), "loglik": d["ll"],
                      "B_alg_bytes": 16 * nx + 40, "whole_timestep_roofline_frac": round(a.particles * (16 * nx + 40) / (d["us"] * 1e-6) / 8e12, 4)})
-print(json.dumps({"particles": a.particles, "T": a.T, "default_schedule": "fused for nx <= 2, marks from nx = 3 on", "rows": rows}, indent=1))
+print(json.dumps({"particles": a.particles, "T": a.T, "default_schedule": "fused for nx <= 2, balanced from nx = 3 on", "rows": rows}, indent=1))

@@ -1,5 +1,5 @@
 // tools/first_load.hip — how long after a workgroup's first instruction do its first loads return, at the start of a launch that
-// depends on the previous one?  (The head of the fused kernel spends 2.2 us there)
+// depends on the previous one?  (The head of the fused kernel spends 2.2 us there, EXPERIMENTS.md Appendix A.)
 //   hipcc --offload-arch=gfx950 -O3 tools/first_load.hip -o tools/first_load && tools/first_load
 // Producer kernel writes a small "hot" array (64 words, read by every block of the consumer, like the accumulator words) and a
 // large array (8 KB per block, like the tile's quanta), with plain stores or write-through (sc1) stores; the consumer (977 x 256,

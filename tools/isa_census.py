@@ -6,7 +6,7 @@
 Compiles csrc/k_resprop.hip for gfx950 with the Makefile's flags to assembly (hipcc --cuda-device-only -S, ~3 min), cuts the
 kernel out, splits it at the s_setprio markers of k_resprop (head+counts | output loop | tail) when they are present, and prints
 per region the number of vector / scalar / LDS / memory instructions and the most frequent opcodes, plus the register and scratch
-figures of the kernel.  This is the census DESIGN.md section 4 (round 2) quotes."""
+figures of the kernel.  This is the census EXPERIMENTS.md Appendix A (round 2) quotes."""
 import collections, os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
