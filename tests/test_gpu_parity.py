@@ -241,6 +241,33 @@ def test_quadtank_both_forms_of_the_balanced_timestep_give_the_oracles_bits(form
     assert g.last_run_stats()["source_side_timesteps"] == (30 if form == "1" else 0)
 
 
+@pytest.mark.parametrize("N", [1, 63, 511, 512, 513, 1025, 2049, 70001])
+@pytest.mark.parametrize("strategy,thr,sig", [(S.RESAMPLE_SYSTEMATIC, 1.0, 0.01), (S.RESAMPLE_STRATIFIED, 0.5, 0.003), (S.RESAMPLE_SYSTEMATIC, 0.5, 0.3)])
+def test_source_side_form_ragged_and_degenerate(N, strategy, thr, sig, monkeypatch):
+    """The source-side form pinned (LLPF_SOURCE_FX=1) where its bookkeeping is exercised hardest: ragged last tiles, a filter of one
+    partly filled tile, tile counts that do not divide by the step kernel's rounds, likelihoods so peaked that one source owns the outputs
+    of many tiles (run-start marks at every 512-output boundary, written by the whole wave), likelihoods so flat that most steps do not
+    resample (f for ALL particles), a missing measurement, both resamplers.  The device-order oracle's bits throughout."""
+    monkeypatch.setenv("LLPF_SOURCE_FX", "1")
+    model = M.quadtank_model()
+    model.measurement_density = S.make_gaussian(np.zeros(2), np.full(2, sig ** 2))
+    T = 10
+    U, Y = M.quadtank_data(T, seed=5)
+    Y[6] = np.nan
+    cfg = _cfg(model, N, strategy=strategy, thr=thr, kind=S.ADVANCED_PARTICLE_FILTER, seed=900 + N % 97)
+    g = _capi.FilterHandle(cfg); o = ob.OracleFilter(cfg, ob.ORDER_DEVICE)
+    g.reset(); o.reset()
+    rg = g.run(U, Y, 497.0, ll_steps=True); ro = o.run(U, Y, 497.0, ll_steps=True)      # crosses the t > 500 switch of the model
+    assert np.array_equal(rg["ll_steps"].view(np.uint64), ro["ll_steps"].view(np.uint64))
+    _compare_state(g, o)
+    assert g.resample_count() == o.resample_count()
+    assert g.last_run_stats()["source_side_timesteps"] == T
+    # ... and the single-step verbs on top of the state the run left (they take the per-output form: same bits)
+    g.correct(U[0], Y[0], 507.0); o.correct(U[0], Y[0], 507.0)
+    g.predict(U[0], 507.0); o.predict(U[0], 507.0)
+    _compare_state(g, o)
+
+
 def test_quadtank_handle_chooses_the_form_by_the_survivor_fraction(monkeypatch):
     """A handle's first run takes the source-side form; from then on the form follows the survivor fraction of the run before (distinct
     ancestors per predict! / N: below 5 % source-side, above 8 % per output particle).  Healthy weights (wide measurement noise): the
@@ -368,6 +395,32 @@ def test_set_state_roundtrip_and_teacher_forced_step():
     o2 = ob.OracleFilter(cfg, ob.ORDER_DEVICE)
     o2.set_particles(x); o2.set_weights(w); o2.predict(u, 0.0)
     _compare_state(g, o2)
+
+
+@pytest.mark.parametrize("N", [4, 8192])
+def test_shouldresample_at_an_exact_tie(N):
+    """shouldresample (src/resample.jl:5-10) is `1/sum(abs2, we) < N * threshold`; the engine tests `stot^2 < (N * threshold) * sum(e^2)` on
+    its fixed-point sums, without the division.  The two can only part at a tie — exercised here: half of the particles carry equal
+    weight, the others none, threshold 0.5, so that ESS == N/2 == N * threshold EXACTLY (powers of two: no rounding anywhere).  `<` is
+    false on all three sides, and the predict! that follows does not resample; one particle fewer in the support and all three resample."""
+    model = M.lg_test_model()
+    cfg = _cfg(model, N, thr=0.5, seed=41)
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((N, 2))
+    u = np.array([0.2])
+    for support, expect in ((N // 2, False), (N // 2 - 1, True), (N // 2 + 1, False)):
+        w = np.full(N, -np.inf)
+        w[:support] = -1.25
+        g = _capi.FilterHandle(cfg); o = ob.OracleFilter(cfg, ob.ORDER_DEVICE); r = ob.OracleFilter(cfg, ob.ORDER_REFERENCE)
+        for h in (g, o, r):
+            h.set_particles(x); h.set_weights(w)
+        if support == N // 2:
+            assert r.ess() == N / 2 == g.ess() == o.ess()
+        assert bool(g.shouldresample()) == bool(o.shouldresample()) == bool(r.shouldresample()) == expect, support
+        for h in (g, o, r):
+            h.predict(u, 0.0)
+        assert bool(g.last_resampled()) == bool(o.last_resampled()) == bool(r.last_resampled()) == expect, support      # (resample_count is per run)
+        _compare_state(g, o)
 
 
 def o_bins_after_predict(o, cfg):

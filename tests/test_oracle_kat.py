@@ -164,3 +164,23 @@ def test_predict_correct_sequence_semantics():
     np.testing.assert_array_equal(o.weights(), np.log(1 / 200))
     assert o.maxw() == 0.0
     assert np.all(np.diff(o.ancestors()) >= 0)
+
+
+@pytest.mark.parametrize("N", [4, 8192])
+def test_shouldresample_at_an_exact_tie_both_orders(N):
+    """src/resample.jl:5-10 is `1/sum(abs2, we) < N * threshold`; the device order tests `stot^2 < (N * threshold) * sum(e^2)` on integer sums.
+    At an exact tie (half of the particles with equal weight, the others with none, threshold 0.5: powers of two, nothing rounds) `<` is
+    false in both forms; one particle fewer in the support and both resample.  (The engine's side: tests/test_gpu_parity.py.)"""
+    cfg = S.make_config(M.lg_test_model(), N, resample_threshold=0.5, seed=41)
+    x = np.random.default_rng(5).standard_normal((N, 2))
+    for support, expect in ((N // 2, False), (N // 2 - 1, True), (N // 2 + 1, False)):
+        w = np.full(N, -np.inf)
+        w[:support] = -1.25
+        for order in ORDERS:
+            o = ob.OracleFilter(cfg, order)
+            o.set_particles(x); o.set_weights(w)
+            if support == N // 2:
+                assert o.ess() == N / 2
+            assert bool(o.shouldresample()) == expect
+            o.predict([0.2], 0.0)
+            assert o.resample_count() == (1 if expect else 0)
