@@ -397,6 +397,10 @@ int  llpf_bank_set_profiling(llpf_bank* b, int32_t on);
 int  llpf_bank_get_profile(llpf_bank* b, double* ms, int64_t* launches);
 /* weighted_cov of the current particles under the current weights (reference src/filtering.jl:571-581), nx*nx row-major, on the device */
 int  llpf_weighted_cov(llpf_filter* f, double* cov);
+/* weighted_quantile of the current particles under the current weights, per state dimension: the reference's weighted_quantile(x, we, q)
+ * (src/filtering.jl:583-595) = StatsBase.quantile(v, ProbabilityWeights(we), q) — sort, running sums, linear interpolation between the two
+ * particles around h = q (sum(we) - we_first) + we_first — on the device; q [nq] in [0, 1], out [nq][nx] */
+int  llpf_weighted_quantile(llpf_filter* f, const double* q, int32_t nq, double* out);
 /* number of predict! calls of the last run that resampled (summed over filters for a bank) */
 int  llpf_resample_count(llpf_filter* f, int64_t* n);
 int  llpf_bank_resample_count(llpf_bank* b, int64_t* n);

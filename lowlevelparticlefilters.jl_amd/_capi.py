@@ -76,6 +76,7 @@ SYMBOLS = {
     "llpf_model_compile": [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32)],
     "llpf_model_traits": [C.c_int32, C.POINTER(C.c_int32)],
     "llpf_weighted_cov": [_vp, _dp],
+    "llpf_weighted_quantile": [_vp, _dp, C.c_int32, _dp],
     "llpf_set_profiling": [_vp, C.c_int32],
     "llpf_get_profile": [_vp, _dp, _ip],
     "llpf_bank_set_profiling": [_vp, C.c_int32],
@@ -245,6 +246,13 @@ class FilterHandle:
         a = np.zeros((self.nx, self.nx))
         check(self.L.llpf_weighted_cov(self.h, dptr(a)))
         return a
+
+    def weighted_quantile(self, q):
+        """weighted_quantile of the current particles under the current weights (reference src/filtering.jl:583-595), on the device: [len(q), nx]"""
+        q = np.ascontiguousarray(np.atleast_1d(q), dtype=np.float64)
+        out = np.empty((q.size, self.nx))
+        check(self.L.llpf_weighted_quantile(self.h, dptr(q), q.size, dptr(out)))
+        return out
 
     def rb_covariance(self):
         """x[1].R of an RBPF: the covariance of the linear substate shared by all particles."""

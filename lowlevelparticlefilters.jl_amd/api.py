@@ -24,7 +24,7 @@ __all__ = [
     "StateAffineCoupling",
     "MvNormal", "ResampleSystematic", "ResampleStratified",
     "LinearDynamics", "LinearMeasurement", "QuadTankDynamics", "QuadTankMeasurement", "GaussianLikelihood",
-    "ResampleResidual", "weighted_cov", "mode_trajectory", "KalmanFilter", "RBMeasurementModel", "RBPF", "smooth", "smoothed_mean", "smoothed_cov", "smoothed_trajs", "ParticleFilter", "AdvancedParticleFilter", "AuxiliaryParticleFilter", "FilterBank", "ParticleFilteringSolution",
+    "ResampleResidual", "weighted_cov", "weighted_quantile", "mode_trajectory", "KalmanFilter", "RBMeasurementModel", "RBPF", "smooth", "smoothed_mean", "smoothed_cov", "smoothed_trajs", "ParticleFilter", "AdvancedParticleFilter", "AuxiliaryParticleFilter", "FilterBank", "ParticleFilteringSolution",
     "reset", "predict", "correct", "update", "forward_trajectory", "mean_trajectory", "loglik",
     "particles", "weights", "expweights", "state", "num_particles", "index", "effective_particles",
     "shouldresample", "resample", "weighted_mean", "logsumexp", "simulate", "parameters",
@@ -538,6 +538,42 @@ def weighted_cov(x, we=None):
         d = x[t] - mu
         n = np.count_nonzero(w)
         out.append((d * w[:, None]).T @ d * (n / ((n - 1) * s)))
+    return out
+
+
+def _statsbase_quantile(v, w, q):
+    """StatsBase.quantile(v, ProbabilityWeights(w), q) (src/weights.jl, the branch for non-frequency weights), vectorised over q"""
+    q = np.atleast_1d(np.asarray(q, dtype=np.float64))
+    if np.isnan(v).any():
+        return np.full(q.shape, np.nan)
+    keep = w != 0
+    order = np.lexsort((w[keep], v[keep]))           # tuples (v, w) sort lexicographically
+    vs, ws = v[keep][order], w[keep][order]
+    S = np.cumsum(ws)
+    h = q * (w.sum() - ws[0]) + ws[0]
+    k = np.searchsorted(S, h, side="right")          # first k with S_k > h
+    past = k >= vs.size
+    k = np.minimum(k, vs.size - 1)
+    Skold = np.where(k > 0, S[np.maximum(k - 1, 0)], 0.0)
+    vkold = np.where(k > 0, vs[np.maximum(k - 1, 0)], 0.0)
+    return np.where(past, vs[-1], vkold + (h - Skold) / (S[k] - Skold) * (vs[k] - vkold))
+
+
+def weighted_quantile(x, we=None, q=None):
+    """weighted_quantile(x, we, q) / weighted_quantile(sol, q) — reference src/filtering.jl:583-595: per time step and state dimension the
+    weighted quantile of the particles (StatsBase's definition), a list of length T of [len(q), nx] arrays (of nx-vectors for a scalar q).
+    weighted_quantile(pf, q): the current particles and weights of a filter, sorted and summed on the device (llpf_weighted_quantile)."""
+    if isinstance(x, _AbstractParticleFilter):
+        qq = we if q is None else q
+        out = x._h.weighted_quantile(qq)
+        return out[0] if np.isscalar(qq) else out
+    if isinstance(x, ParticleFilteringSolution):
+        x, we, q = x.x, x.we, (we if q is None else q)
+    x, we = np.asarray(x), np.asarray(we)
+    out = []
+    for t in range(x.shape[0]):
+        r = np.stack([_statsbase_quantile(x[t][:, d], we[t], q) for d in range(x.shape[2])], axis=1)
+        out.append(r[0] if np.isscalar(q) else r)
     return out
 
 

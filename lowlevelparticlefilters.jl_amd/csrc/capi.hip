@@ -295,6 +295,27 @@ int llpf_weighted_cov(llpf_filter* f, double* cov) {
     HIPC(hipStreamSynchronize(b.stream));
     return LLPF_OK;
 }
+int llpf_weighted_quantile(llpf_filter* f, const double* q, int32_t nq, double* out) {
+    NEEDF(f);
+    Bank& b = f->bank;
+    if (!q || !out) return fail(LLPF_ERR_ARG, "null pointer");
+    if (nq < 1 || nq > 1024) return fail(LLPF_ERR_ARG, "llpf_weighted_quantile: 1 <= nq <= 1024");
+    for (int i = 0; i < nq; ++i) if (!(q[i] >= 0.0 && q[i] <= 1.0)) return fail(LLPF_ERR_ARG, "llpf_weighted_quantile: a probability outside [0, 1]");
+    if (is_rbfull(b)) return fail(LLPF_ERR_ARG, "weighted_quantile is not provided for LLPF_MODEL_RB_BILINEAR (take it from the particles)");
+    if (b.we_is_lambda) return fail(LLPF_ERR_ARG, "weighted_quantile between the halves of an auxiliary predict!: expweights(pf) holds lambda there");
+    CHK(use_device(b));
+    BankDev d = b.dev();
+    HIPC(launch_materialize(d, nullptr, b.d_tmp, b.stream));                  // we = expweights(pf), [N]
+    double *dq = nullptr, *dout = nullptr;
+    HIPC(hipMalloc(&dq, sizeof(double) * nq));
+    if (hipMalloc(&dout, sizeof(double) * nq * b.nx) != hipSuccess) { hipFree(dq); return fail(LLPF_ERR_ALLOC, "llpf_weighted_quantile: out of device memory"); }
+    hipError_t e = hipMemcpyAsync(dq, q, sizeof(double) * nq, hipMemcpyHostToDevice, b.stream);
+    if (e == hipSuccess) e = launch_wquantile(d.xcur, b.Ns, b.nx, b.d_tmp, b.N, dq, nq, dout, b.stream);
+    if (e == hipSuccess) e = hipMemcpy(out, dout, sizeof(double) * nq * b.nx, hipMemcpyDeviceToHost);
+    hipFree(dq); hipFree(dout);
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? LLPF_ERR_ALLOC : LLPF_ERR_HIP, hipGetErrorString(e));
+    return LLPF_OK;
+}
 int llpf_resample_count(llpf_filter* f, int64_t* n) { NEEDF(f); if (n) *n = f->bank.run_resamples; return LLPF_OK; }
 int llpf_model_traits(int32_t model_id, int32_t* traits) {
     if (!traits) return fail(LLPF_ERR_ARG, "null pointer");

@@ -263,6 +263,8 @@ hipError_t launch_user_bound(int model_id, ModelD* models, int F, const double* 
 hipError_t launch_rbfull(const BankDev& b, int mode, const StepArgs& a, hipStream_t s);   // k_rbfull.hip (called by launch_step)
 hipError_t launch_rbfull_init(const BankDev& b, hipStream_t s);   // LLPF_MODEL_RB_BILINEAR: xl, R of reset!
 hipError_t launch_wmean(const BankDev& b, double* out /* [F][nx] */, hipStream_t s);
+// weighted_quantile of one filter's particles (k_quantile.hip): x [nx][Ns] planes, we [N] exp-weights, q / out on the device ([nq], [nq][nx]); synchronises
+hipError_t launch_wquantile(const double* x, int64_t Ns, int nx, const double* we, int64_t N, const double* q, int nq, double* out, hipStream_t s);
 hipError_t launch_wcov(const BankDev& b, const double* mean /* [F][nx]: launch_wmean of the same state */, double* out /* [F][nx*nx] */, hipStream_t s);
 hipError_t launch_step(const BankDev& b, int mode, const StepArgs& a, hipStream_t s);
 hipError_t launch_max(const BankDev& b, int parity, hipStream_t s);           // maxima of the raw w into acc

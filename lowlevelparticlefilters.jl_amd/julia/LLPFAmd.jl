@@ -28,7 +28,7 @@ import LowLevelParticleFilters: AbstractParticleFilter, ParticleFilteringSolutio
     ResamplingStrategy, ResampleSystematic, ResampleStratified, ResampleResidual, SimpleMvNormal,
     reset!, predict!, correct!, update!, forward_trajectory, loglik, smooth, sample_state,
     particles, weights, expweights, state, num_particles, index, particletype, parameters,
-    effective_particles, shouldresample, weighted_mean, weighted_cov,
+    effective_particles, shouldresample, weighted_mean, weighted_cov, weighted_quantile,
     dynamics, measurement, measurement_likelihood, dynamics_density, measurement_density, initial_density,
     resample_threshold, resampling_strategy
 
@@ -568,6 +568,20 @@ expweights(pf::GPF) = getvec(:llpf_get_expweights, pf.h, pf.N)
 weighted_mean(pf::GPF) = getvec(:llpf_weighted_mean, pf.h, pf.nx)
 "weighted_cov of the CURRENT particles and weights, on the device: one time step of the reference's weighted_cov(x, we) (src/filtering.jl:571-581)"
 weighted_cov(pf::GPF) = reshape(getvec(:llpf_weighted_cov, pf.h, pf.nx * pf.nx), pf.nx, pf.nx)
+"""
+    weighted_quantile(pf, q)
+
+Weighted quantile(s) `q` of the CURRENT particles and weights per state dimension, sorted and summed on the device: one time step of the
+reference's `weighted_quantile(x, we, q)` (src/filtering.jl:583-595, StatsBase's `quantile(v, ProbabilityWeights(we), q)`).  A vector of
+length nx for a scalar `q`, an nx x length(q) matrix for a vector.
+"""
+function weighted_quantile(pf::GPF, q::AbstractVector{<:Real})
+    qq = collect(Float64, q)
+    out = Matrix{Float64}(undef, pf.nx, length(qq))      # the ABI writes [nq][nx] row-major = nx x nq column-major
+    check(ccall((:llpf_weighted_quantile, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int32, Ptr{Float64}), pf.h, qq, Int32(length(qq)), out))
+    out
+end
+weighted_quantile(pf::GPF, q::Real) = vec(weighted_quantile(pf, [q]))
 "state(pf).j, 1-based — src/PFtypes.jl:14"
 function ancestors(pf::GPF)
     j = Vector{Int64}(undef, pf.N)

@@ -1614,6 +1614,69 @@ void orc_weighted_mean(const orc_filter* f, double* xh) {
     }
 }
 
+/* weighted_quantile(x, we, q) (src/filtering.jl:583-595): per state dimension StatsBase.quantile(v, ProbabilityWeights(we), q).  StatsBase is
+ * a dependency of the reference (Project.toml: StatsBase) that /root/reference does not vendor; this restates the published algorithm of its
+ * src/weights.jl `quantile(v::RealVector, w::AbstractWeights, p::RealVector)`, the branch for weights that are not FrequencyWeights:
+ *   wsum = sum(w) (Julia's pairwise sum); pairs with w == 0 dropped; pairs sorted as tuples (v, w); out prefilled with the largest v;
+ *   a NaN anywhere in v -> every quantile NaN; p ascending: h = p (wsum - w_1) + w_1; `while Sk <= h` advance k (past the end: return);
+ *   out = v_{k-1} + (h - S_{k-1}) / (S_k - S_{k-1}) (v_k - v_{k-1}), with v_0 = S_0 = 0.
+ * Pinned by: equal weights reproduce the ordinary quantile (type 7, numpy's default), which StatsBase's own tests assert; a literal Python
+ * restatement (tests/test_quantile.py).  v, w: [n]; p: [np] in [0, 1]; out: [np].  Returns 0, or 1 for an empty / weightless input. */
+typedef struct { double v, w; } vw_pair;
+static int vw_less(const void* a, const void* b) {
+    const vw_pair *x = (const vw_pair*)a, *y = (const vw_pair*)b;
+    if (x->v < y->v) return -1;
+    if (x->v > y->v) return 1;
+    if (signbit(x->v) != signbit(y->v)) return signbit(x->v) ? -1 : 1;      /* isless(-0.0, 0.0); NaNs never get here (tested before the sort) */
+    return x->w < y->w ? -1 : (x->w > y->w ? 1 : 0);
+}
+int orc_weighted_quantile(const double* v, const double* w, int64_t n, const double* p, int np, double* out) {
+    if (n < 1 || np < 1) return 1;
+    const double wsum = orc_pairwise_sum(w, n);
+    for (int64_t i = 0; i < n; ++i) if (v[i] != v[i]) { for (int k = 0; k < np; ++k) out[k] = v[i]; return 0; }      /* (StatsBase tests this after the sort: same result) */
+    vw_pair* vw = (vw_pair*)malloc(sizeof(vw_pair) * (size_t)n);
+    int64_t N = 0;
+    for (int64_t i = 0; i < n; ++i) if (w[i] != 0.0) { vw[N].v = v[i]; vw[N].w = w[i]; ++N; }
+    if (N == 0 || !(wsum > 0.0)) { free(vw); return 1; }
+    qsort(vw, (size_t)N, sizeof(vw_pair), vw_less);
+    int* perm = (int*)malloc(sizeof(int) * (size_t)np);
+    for (int i = 0; i < np; ++i) perm[i] = i;
+    for (int i = 1; i < np; ++i) { const int k = perm[i]; int j = i - 1; while (j >= 0 && p[perm[j]] > p[k]) { perm[j + 1] = perm[j]; --j; } perm[j + 1] = k; }
+    for (int i = 0; i < np; ++i) out[i] = vw[N - 1].v;
+    double Sk = 0.0, Skold = 0.0, vk = 0.0, vkold = 0.0;
+    int64_t k = 0;
+    const double w1 = vw[0].w;
+    for (int i = 0; i < np; ++i) {
+        const double h = p[perm[i]] * (wsum - w1) + w1;
+        while (Sk <= h) {
+            k += 1;
+            if (k > N) { free(vw); free(perm); return 0; }
+            Skold = Sk; vkold = vk;
+            vk = vw[k - 1].v;
+            Sk += vw[k - 1].w;
+        }
+        out[perm[i]] = vkold + (h - Skold) / (Sk - Skold) * (vk - vkold);
+    }
+    free(vw); free(perm);
+    return 0;
+}
+/* ... of the filter's current particles and exp-weights: out [np][particle_dim] */
+int orc_filter_weighted_quantile(const orc_filter* f, const double* p, int np, double* out) {
+    const int pd = particle_dim(f);
+    double* col = (double*)malloc(8 * (size_t)f->N);
+    double* x = (double*)malloc(8 * (size_t)f->N * pd);
+    double* o1 = (double*)malloc(8 * (size_t)np);
+    copy_particles(f, x);
+    int rc = 0;
+    for (int d = 0; d < pd && !rc; ++d) {
+        for (int64_t i = 0; i < f->N; ++i) col[i] = x[i * pd + d];
+        rc = orc_weighted_quantile(col, f->we, f->N, p, np, o1);
+        for (int k = 0; k < np; ++k) out[(size_t)k * pd + d] = o1[k];
+    }
+    free(col); free(x); free(o1);
+    return rc;
+}
+
 /* the loop of forward_trajectory (src/filtering.jl:351-363, t_index0 = 0 after reset!) and of
  * loglik (src/smoothing.jl:227-230: t = index(pf)*Ts, index = 1 after reset!, so t_index0 = 1) */
 double orc_run(orc_filter* f, const double* U, const double* Y, int64_t T, double t_index0,

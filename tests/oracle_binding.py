@@ -61,6 +61,8 @@ def load():
                "orc_set_particles", "orc_set_weights", "orc_weighted_mean"):
         getattr(lib, nm).argtypes = [C.c_void_p, _dp]
     lib.orc_get_ancestors.argtypes = [C.c_void_p, _ip]
+    lib.orc_weighted_quantile.argtypes = [_dp, _dp, C.c_int64, _dp, C.c_int, _dp]
+    lib.orc_filter_weighted_quantile.argtypes = [C.c_void_p, _dp, C.c_int, _dp]
     lib.orc_set_index.argtypes = [C.c_void_p, C.c_int64]
     lib.orc_filter_ess.restype = C.c_double
     lib.orc_filter_ess.argtypes = [C.c_void_p]
@@ -326,6 +328,22 @@ class OracleFilter:
         a = np.empty(self.nx)
         self.L.orc_weighted_mean(self.h, dptr(a))
         return a
+
+    def weighted_quantile(self, q):
+        q = _f64(np.atleast_1d(q))
+        out = np.empty((q.size, self.nx))
+        if self.L.orc_filter_weighted_quantile(self.h, dptr(q), q.size, dptr(out)):
+            raise ValueError("weighted_quantile: no particle carries weight")
+        return out
+
+
+def weighted_quantile(v, w, q):
+    """StatsBase.quantile(v, ProbabilityWeights(w), q) as restated in the oracle (orc_weighted_quantile)"""
+    v, w, q = _f64(v), _f64(w), _f64(np.atleast_1d(q))
+    out = np.empty(q.size)
+    if lib().orc_weighted_quantile(dptr(v), dptr(w), v.size, dptr(q), q.size, dptr(out)):
+        raise ValueError("weighted_quantile: empty or weightless input")
+    return out
 
 
 def draw_one_categorical(w, u, order=ORDER_REFERENCE):
