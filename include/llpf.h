@@ -146,6 +146,8 @@ int  llpf_destroy(llpf_filter* f);
 int  llpf_reset(llpf_filter* f);
 /* re-key the RNG and zero its step counters (no reference equivalent: the reference never seeds pf.rng) */
 int  llpf_seed(llpf_filter* f, uint64_t seed);
+/* new parameters for this handle (same model id and dimensions): see llpf_bank_set_models */
+int  llpf_set_model(llpf_filter* f, const llpf_model* model);
 
 /* ---- the step --------------------------------------------------------------------------- */
 /* correct!(pf,u,y,p,t) -> (ll, 0) — reference src/filtering.jl:164-168 (measurement_equation!
@@ -313,6 +315,11 @@ int  llpf_bank_create(const llpf_config* base, const llpf_model* models, int32_t
 int  llpf_bank_destroy(llpf_bank* b);
 int  llpf_bank_reset(llpf_bank* b);
 int  llpf_bank_seed(llpf_bank* b, uint64_t seed);
+/* New parameters for an existing handle — what the reference's filter_from_parameters(theta, pf) of log_likelihood_fun / metropolis
+ * (src/smoothing.jl:266-283, 311-330) returns: same model id and dimensions, everything else of the n_filters descriptors may differ.
+ * Nothing is allocated, captured run loops stay valid (unless Ts changes); particles, weights and random streams are untouched — loglik /
+ * forward_trajectory reset! first, as in the reference.  A Metropolis iteration over a bank of chains is llpf_bank_set_models + llpf_bank_run. */
+int  llpf_bank_set_models(llpf_bank* b, const llpf_model* models /* [n_filters] */);
 /* as llpf_run, shared U / Y, ll_total has n_filters entries; ll_steps (optional) is [T * n_filters] */
 int  llpf_bank_run(llpf_bank* b, const double* U, const double* Y, int64_t T, double t_index0,
                    double* ll_total, double* ll_steps);
@@ -361,6 +368,7 @@ int  llpf_mbank_create_rank(const llpf_config* base, const llpf_model* models, i
 int  llpf_mbank_destroy(llpf_mbank* m);
 int  llpf_mbank_reset(llpf_mbank* m);
 int  llpf_mbank_seed(llpf_mbank* m, uint64_t seed);
+int  llpf_mbank_set_models(llpf_mbank* m, const llpf_model* models /* [n_filters], every rank passes all of them */);      /* llpf_bank_set_models of every local shard */
 /* as llpf_bank_run on every shard, then the exchange: ll_total [n_filters] holds every filter's log-likelihood in every
  * process, *ll_sum their sum in index order (the global log-likelihood of the sweep); either may be NULL */
 int  llpf_mbank_run(llpf_mbank* m, const double* U, const double* Y, int64_t T, double t_index0,

@@ -24,6 +24,7 @@ SYMBOLS = {
     "llpf_destroy": [_vp],
     "llpf_reset": [_vp],
     "llpf_seed": [_vp, C.c_uint64],
+    "llpf_set_model": [_vp, _vp],
     "llpf_correct": [_vp, _dp, _dp, C.c_double, _dp],
     "llpf_predict": [_vp, _dp, C.c_double],
     "llpf_update": [_vp, _dp, _dp, C.c_double, _dp],
@@ -58,6 +59,7 @@ SYMBOLS = {
     "llpf_bank_destroy": [_vp],
     "llpf_bank_reset": [_vp],
     "llpf_bank_seed": [_vp, C.c_uint64],
+    "llpf_bank_set_models": [_vp, _vp],
     "llpf_bank_run": [_vp, _dp, _dp, C.c_int64, C.c_double, _dp, _dp],
     "llpf_bank_run_multi": [_vp, _dp, _dp, C.c_int64, C.c_double, _dp, _dp, _dp],
     "llpf_mbank_create": [C.POINTER(S.Config), C.POINTER(S.Model), C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.POINTER(_vp)],
@@ -67,6 +69,7 @@ SYMBOLS = {
     "llpf_mbank_destroy": [_vp],
     "llpf_mbank_reset": [_vp],
     "llpf_mbank_seed": [_vp, C.c_uint64],
+    "llpf_mbank_set_models": [_vp, _vp],
     "llpf_mbank_run": [_vp, _dp, _dp, C.c_int64, C.c_double, _dp, _dp],
     "llpf_mbank_aux_run": [_vp, _dp, _dp, C.c_int64, C.c_int32, _dp, _dp],
     "llpf_mbank_info": [_vp, C.POINTER(S.MBankInfo)],
@@ -183,6 +186,10 @@ class FilterHandle:
 
     def seed(self, s):
         check(self.L.llpf_seed(self.h, int(s) & 0xFFFFFFFFFFFFFFFF))
+
+    def set_model(self, model):
+        """new parameters, same model family and dimensions (the reference's filter_from_parameters(theta, pf)): nothing is reallocated"""
+        check(self.L.llpf_set_model(self.h, C.byref(model)))
 
     def _u(self, u):
         if self.nu == 0:
@@ -449,6 +456,14 @@ class BankHandle:
     def seed(self, s):
         check(self.L.llpf_bank_seed(self.h, int(s) & 0xFFFFFFFFFFFFFFFF))
 
+    def set_models(self, models):
+        """new parameters for every filter of the bank (len(models) == n_filters), same model family and dimensions"""
+        if len(models) != self.F:
+            raise ValueError("set_models: %d models for a bank of %d filters" % (len(models), self.F))
+        arr = (S.Model * self.F)(*models)
+        check(self.L.llpf_bank_set_models(self.h, arr))
+        self._models = arr
+
     def run(self, U, Y, t_index0=0.0, ll_steps=False):
         Y = f64(Y).reshape(-1, self.ny)
         T = Y.shape[0]
@@ -559,6 +574,14 @@ class MBankHandle:
 
     def seed(self, s):
         check(self.L.llpf_mbank_seed(self.h, int(s) & 0xFFFFFFFFFFFFFFFF))
+
+    def set_models(self, models):
+        """new parameters for every filter of the sweep (all n_filters descriptors, on every rank)"""
+        if len(models) != self.F:
+            raise ValueError("set_models: %d models for a sweep of %d filters" % (len(models), self.F))
+        arr = (S.Model * self.F)(*models)
+        check(self.L.llpf_mbank_set_models(self.h, arr))
+        self._models = arr
 
     def _io(self, U, Y):
         Y = f64(Y).reshape(-1, self.ny)

@@ -24,7 +24,7 @@ __all__ = [
     "StateAffineCoupling",
     "MvNormal", "ResampleSystematic", "ResampleStratified",
     "LinearDynamics", "LinearMeasurement", "QuadTankDynamics", "QuadTankMeasurement", "GaussianLikelihood",
-    "ResampleResidual", "weighted_cov", "weighted_quantile", "mode_trajectory", "KalmanFilter", "RBMeasurementModel", "RBPF", "smooth", "smoothed_mean", "smoothed_cov", "smoothed_trajs", "ParticleFilter", "AdvancedParticleFilter", "AuxiliaryParticleFilter", "FilterBank", "ParticleFilteringSolution",
+    "ResampleResidual", "weighted_cov", "weighted_quantile", "log_likelihood_fun", "metropolis", "metropolis_bank", "naive_sampler", "mode_trajectory", "KalmanFilter", "RBMeasurementModel", "RBPF", "smooth", "smoothed_mean", "smoothed_cov", "smoothed_trajs", "ParticleFilter", "AdvancedParticleFilter", "AuxiliaryParticleFilter", "FilterBank", "ParticleFilteringSolution",
     "reset", "predict", "correct", "update", "forward_trajectory", "mean_trajectory", "loglik",
     "particles", "weights", "expweights", "state", "num_particles", "index", "effective_particles",
     "shouldresample", "resample", "weighted_mean", "logsumexp", "simulate", "parameters",
@@ -273,6 +273,20 @@ class _AbstractParticleFilter:
         self._h = _capi.FilterHandle(self._cfg)
         self.N = int(N)
 
+    def set_parameters(self, *, dynamics=None, measurement=None, dynamics_density=None, measurement_density=None, initial_density=None):
+        """New parameters for THIS filter (same model family and dimensions): what the reference's `filter_from_parameters(theta, pf)` is
+        handed the old filter for (src/smoothing.jl:266-283) — nothing is reallocated on the device (llpf_set_model).  Returns self."""
+        dyn = self.dynamics if dynamics is None else dynamics
+        meas = self.measurement if measurement is None else measurement
+        df = self.dynamics_density if dynamics_density is None else dynamics_density
+        dg = self.measurement_density if measurement_density is None else measurement_density
+        d0 = self.initial_density if initial_density is None else initial_density
+        model = _build_model(dyn, meas, df, dg, d0, self.Ts, getattr(self, "_user_likelihood", False))
+        self._h.set_model(model)
+        self.dynamics, self.measurement, self.dynamics_density, self.measurement_density, self.initial_density = dyn, meas, df, dg, d0
+        self._model = model
+        return self
+
     # pf(u, y, p, t): one update! step (reference src/filtering.jl:238,240)
     def __call__(self, u, y, p=None, t=None):
         return update(self, u, y, p, t)
@@ -519,6 +533,94 @@ def loglik(pf, u, y, p=None):
     if isinstance(pf, AuxiliaryParticleFilter):
         return pf._h.run_aux(u, y, mode=1)["ll"]
     return pf._h.run(u, y, t_index0=1.0)["ll"]
+
+
+def log_likelihood_fun(filter_from_parameters, priors, u, y):
+    """ll = log_likelihood_fun(filter_from_parameters, priors, u, y) — reference src/smoothing.jl:266-283: theta -> log prior + loglik of
+    the filter built from theta; -inf outside the priors' support or when the filter degenerates.  `filter_from_parameters(theta, pf)` is
+    called with the previous filter (None the first time) so that it can return `pf.set_parameters(...)` instead of a new filter;
+    a function of theta alone is accepted too.  `priors[i]` is anything with a `logpdf(x)` method (scipy.stats frozen distributions)."""
+    import inspect
+    try:
+        two = len(inspect.signature(filter_from_parameters).parameters) >= 2
+    except (TypeError, ValueError):
+        two = False
+    state = {"pf": None}
+
+    def ll(theta):
+        theta = np.asarray(theta, dtype=np.float64)
+        if theta.size != len(priors):
+            raise ValueError("Input must have same length as priors")
+        lp = float(sum(np.float64(priors[i].logpdf(theta[i])) for i in range(theta.size)))
+        if not np.isfinite(lp):
+            return -np.inf
+        state["pf"] = filter_from_parameters(theta, state["pf"]) if two else filter_from_parameters(theta)
+        try:
+            return lp + loglik(state["pf"], u, y)
+        except (_capi.LLPFError, ValueError, FloatingPointError):
+            return -np.inf
+    return ll
+
+
+def naive_sampler(theta0, rng=None):
+    """theta -> theta + N(0, diag(0.1 |theta0|)) — reference src/smoothing.jl:284-287"""
+    theta0 = np.asarray(theta0, dtype=np.float64)
+    if np.any(theta0 == 0):
+        raise ValueError("Naive sampler does not work if initial parameter vector contains zeros")
+    rng = np.random.default_rng() if rng is None else rng
+    sd = np.sqrt(0.1 * np.abs(theta0))
+    return lambda theta: np.asarray(theta) + sd * rng.standard_normal(theta0.size)
+
+
+def metropolis(ll, R, theta0, draw=None, rng=None):
+    """params, lls = metropolis(ll, R, theta0, draw) — reference src/smoothing.jl:311-330: marginal Metropolis with a symmetric proposal;
+    `rng` (numpy Generator) supplies the acceptance uniforms (the reference uses the global rand())."""
+    rng = np.random.default_rng() if rng is None else rng
+    draw = naive_sampler(theta0, rng) if draw is None else draw
+    params, lls = [np.asarray(theta0, dtype=np.float64)], [float(ll(theta0))]
+    for _ in range(1, int(R)):
+        theta = np.asarray(draw(params[-1]), dtype=np.float64)
+        lli = float(ll(theta))
+        if rng.random() < np.exp(lli - lls[-1]):
+            params.append(theta); lls.append(lli)
+        else:
+            params.append(params[-1]); lls.append(lls[-1])
+    return params, np.array(lls)
+
+
+def metropolis_bank(bank, spec_from_parameters, priors, u, y, R, theta0s, draw=None, burnin=0, rng=None):
+    """The GPU form of the reference's metropolis_threaded (src/smoothing.jl:335-347: one independent chain per thread): the chains advance in
+    lockstep and every iteration is ONE bank run — llpf_bank_set_models with the chains' candidates, then the bank's loglik.
+    `bank`: a FilterBank with one filter per chain; `spec_from_parameters(theta)` -> (dynamics, measurement, df, dg, d0) of a candidate;
+    `theta0s`: [n_chains, n_parameters].  Returns an array [(R - burnin) * n_chains, n_parameters + 1], log-likelihoods (with the log
+    prior) in the last column, chain after chain — the layout metropolis_threaded returns."""
+    rng = np.random.default_rng() if rng is None else rng
+    theta0s = np.atleast_2d(np.asarray(theta0s, dtype=np.float64))
+    n = theta0s.shape[0]
+    if n != bank.n_filters:
+        raise ValueError("one chain per filter of the bank")
+    draw = (lambda th, d=naive_sampler(theta0s[0], rng): d(th)) if draw is None else draw
+
+    def lls_of(thetas):
+        lp = np.array([sum(np.float64(priors[i].logpdf(th[i])) for i in range(th.size)) for th in thetas])
+        ok = np.isfinite(lp)
+        # chains whose candidate lies outside the priors' support keep a valid model in their slot; its likelihood is not used
+        bank.set_parameters([spec_from_parameters(thetas[k] if ok[k] else cur[k]) for k in range(n)])
+        out = np.where(ok, lp + bank.loglik(u, y), -np.inf)
+        return np.where(np.isnan(out), -np.inf, out)
+
+    cur = theta0s.copy()
+    ll_cur = lls_of(cur)
+    chain = np.empty((int(R), n, theta0s.shape[1] + 1))
+    chain[0, :, :-1], chain[0, :, -1] = cur, ll_cur
+    for i in range(1, int(R)):
+        cand = np.stack([np.asarray(draw(cur[k]), dtype=np.float64) for k in range(n)])
+        ll_c = lls_of(cand)
+        acc = rng.random(n) < np.exp(ll_c - ll_cur)
+        cur = np.where(acc[:, None], cand, cur)
+        ll_cur = np.where(acc, ll_c, ll_cur)
+        chain[i, :, :-1], chain[i, :, -1] = cur, ll_cur
+    return np.concatenate([chain[int(burnin):, k, :] for k in range(n)], axis=0)
 
 
 def weighted_cov(x, we=None):
@@ -789,6 +891,10 @@ class FilterBank:
         cfg = S.make_config(models[0], N, S.PARTICLE_FILTER, resampling_strategy.code, resample_threshold, self.rng, device)
         self._h = _capi.BankHandle(cfg, models)
         self.n_filters = len(models)
+
+    def set_parameters(self, filters_spec):
+        """new (dynamics, measurement, df, dg, d0) for every filter of the bank, nothing reallocated (llpf_bank_set_models)"""
+        self._h.set_models([_build_model(dy, me, df, dg, d0, self.Ts) for (dy, me, df, dg, d0) in filters_spec])
 
     def loglik(self, u, y):
         """[loglik(pf_k, u, y) for k] — reference src/smoothing.jl:227-230 applied to every filter."""

@@ -97,6 +97,7 @@ static int bank_seed(Bank& b, uint64_t seed) {
     return scal_upload(b, h);
 }
 int llpf_seed(llpf_filter* f, uint64_t seed) { NEEDF(f); return bank_seed(f->bank, seed); }
+int llpf_set_model(llpf_filter* f, const llpf_model* model) { NEEDF(f); return bank_set_models(f->bank, model); }
 
 int llpf_correct(llpf_filter* f, const double* u, const double* y, double t, double* ll) {
     NEEDF(f);
@@ -381,6 +382,7 @@ int llpf_bank_destroy(llpf_bank* b) {
 }
 int llpf_bank_reset(llpf_bank* b) { NEEDF(b); CHK(use_device(b->bank)); return bank_init_particles(b->bank, true); }
 int llpf_bank_seed(llpf_bank* b, uint64_t seed) { NEEDF(b); return bank_seed(b->bank, seed); }
+int llpf_bank_set_models(llpf_bank* b, const llpf_model* models) { NEEDF(b); return bank_set_models(b->bank, models); }
 int llpf_bank_run(llpf_bank* b, const double* U, const double* Y, int64_t T, double t_index0,
                   double* ll_total, double* ll_steps) {
     NEEDF(b);
@@ -496,6 +498,17 @@ int llpf_mbank_reset(llpf_mbank* m) {
 int llpf_mbank_seed(llpf_mbank* m, uint64_t seed) {
     NEEDF(m);
     return mbank_foreach(*m, [&](int s) -> int { return bank_seed(m->shards[s]->bank, seed); });
+}
+int llpf_mbank_set_models(llpf_mbank* m, const llpf_model* models) {
+    NEEDF(m);
+    if (!models) return fail(LLPF_ERR_ARG, "null models");
+    return mbank_foreach(*m, [&](int s) -> int {
+        MShard& sh = *m->shards[s];
+        std::vector<llpf_model> mine;
+        mine.reserve(sh.owned.size());
+        for (int k : sh.owned) mine.push_back(models[k]);      // the same partition as at creation: filter k lives on shard k mod n_shards
+        return bank_set_models(sh.bank, mine.data());
+    });
 }
 int llpf_mbank_run(llpf_mbank* m, const double* U, const double* Y, int64_t T, double t_index0, double* ll_total, double* ll_sum) {
     NEEDF(m);

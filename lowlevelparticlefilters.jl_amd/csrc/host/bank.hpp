@@ -379,6 +379,57 @@ static int bank_create(const llpf_config* cfg, const llpf_model* models, int F, 
     return bank_init_particles(b, false);
 }
 
+// New parameters for an existing bank: the reference's `filter_from_parameters(theta, pf)` of log_likelihood_fun / metropolis
+// (src/smoothing.jl:266-283, 311-330) hands the old filter back so that nothing is allocated per candidate.  Same model family and
+// dimensions; the descriptors are prepared and uploaded in place (kernels read them from device memory: captured run loops stay valid
+// unless the sampling time changes, which rides in launch arguments).  Particles, weights and the random streams are not touched —
+// loglik / forward_trajectory reset! first, as in the reference.  models == NULL is not accepted for a bank of replicas of more than
+// one filter (pass F descriptors).
+static int bank_set_models(Bank& b, const llpf_model* models) {
+    if (!models) return fail(LLPF_ERR_ARG, "null models");
+    CHK(use_device(b));
+    const llpf_model m0 = b.cfg.model;
+    const int F = b.F;
+    const bool was_replicas = (int)b.hmodels.size() < F;
+    std::vector<ModelD> hm(F);
+    std::vector<llpf_model> mm(models, models + F);
+    for (int f = 0; f < F; ++f) {
+        llpf_model& mf = mm[f];
+        if (mf.model_id == LLPF_MODEL_LINEAR_GAUSSIAN && m0.model_id >= LLPF_MODEL_USER_BASE && (mf.nx > 4 || mf.ny > 4)) {
+            std::string err;                                     // created above the precompiled dimensions: the bank holds the compiled model's id
+            const int id = jit_builtin_lg(mf.nx, mf.ny, err);
+            if (id == m0.model_id) mf.model_id = id;
+        }
+        if (mf.model_id != m0.model_id || mf.nx != m0.nx || mf.nu != m0.nu || mf.ny != m0.ny)
+            return fail(LLPF_ERR_ARG, "set_model: the new model must have the model id and the dimensions the handle was created with");
+        if (m0.model_id == LLPF_MODEL_RB_BILINEAR && (mf.rb.nxl != m0.rb.nxl || mf.rb.fn_kind != m0.rb.fn_kind))
+            return fail(LLPF_ERR_ARG, "set_model: LLPF_MODEL_RB_BILINEAR must keep rb.nxl and rb.fn_kind");
+        if (m0.model_id == LLPF_MODEL_RB_LINEAR && mf.nxn != m0.nxn) return fail(LLPF_ERR_ARG, "set_model: LLPF_MODEL_RB_LINEAR must keep nxn");
+        const int rc = model_prepare(&mf, &hm[f]);
+        if (rc) return fail(LLPF_ERR_ARG, "invalid density (covariance not positive definite or dimension mismatch), code " + std::to_string(rc));
+    }
+    if (mm[0].Ts != m0.Ts) {          // the time of a step rides in launch arguments: captured run loops are of no use any more
+        for (auto& g : b.graphs) if (g.exec) hipGraphExecDestroy(g.exec);
+        b.graphs.clear();
+    }
+    (void)was_replicas;
+    b.hmodels = mm;
+    b.cfg.model = mm[0];
+    HIPC(hipMemcpyAsync(b.d_models, hm.data(), sizeof(ModelD) * F, hipMemcpyHostToDevice, b.stream));
+    if (m0.model_id >= LLPF_MODEL_USER_BASE) HIPC(launch_user_bound(m0.model_id, b.d_models, F, b.d_uy, b.stream));
+    HIPC(hipStreamSynchronize(b.stream));
+    if (m0.model_id == LLPF_MODEL_RB_LINEAR) {               // the inner KalmanFilter object of the new filter: kf.x = d0.mu, kf.R = d0.Sigma
+        for (int f = 0; f < F; ++f) {
+            double S0[16];
+            gauss_cov_dense(&b.hmodels[f].linear_initial, S0);
+            const int nl = m0.nx - m0.nxn;
+            for (int i = 0; i < nl * nl; ++i) { b.rb[f].R[i] = S0[i]; b.rb[f].kfR[i] = S0[i]; }
+            for (int i = 0; i < nl; ++i) b.rb[f].kfx[i] = b.hmodels[f].linear_initial.mu[i];
+        }
+    }
+    return LLPF_OK;
+}
+
 // weighted_mean of the particle as the accessors see it (nxp values per filter), MAXD rows per launch
 static int bank_wmean(Bank& b, double* d_out) {
     for (int r0 = 0; r0 < b.nxp; r0 += MAXD) {

@@ -35,7 +35,7 @@ import LowLevelParticleFilters: AbstractParticleFilter, ParticleFilteringSolutio
 export GPUParticleFilter, GPUAdvancedParticleFilter, GPUAuxiliaryParticleFilter, GPURBPF, GPUFilterBank, GPUMultiBank,
        LinearDynamics, LinearMeasurement, QuadTankDynamics, QuadTankMeasurement, GaussianLikelihood,
        RBLinearModel, RBBilinearModel, GaussianSpec, UserDynamics, UserMeasurement, UserLikelihood, UserNoise, UserInitial, linear_state, shared_covariance, loglik_multi, mbank_unique_id,
-       seed!, ancestors, last_resampled
+       seed!, ancestors, last_resampled, set_parameters!
 
 const LIB = get(ENV, "LLPF_HIP_LIB", joinpath(@__DIR__, "..", "libllpf_hip.so"))
 const MAXD = 8
@@ -435,6 +435,32 @@ function GPURBPF(N::Integer, model, R1n, R2, d0n; resample_threshold = 0.1,
 end
 
 const GPF = GPUParticleFilter
+
+"""
+    set_parameters!(pf; dynamics, measurement, dynamics_density, measurement_density, initial_density)
+
+New parameters for an existing GPU filter — same model family and dimensions, densities of the types the filter was built with — without
+reallocating anything on the device (`llpf_set_model`): what the reference's `filter_from_parameters(θ, pf)` of `log_likelihood_fun` /
+`metropolis` (src/smoothing.jl:266-283, 311-330) is handed the old filter for.  Both drivers are generic over `AbstractParticleFilter`
+and run unchanged on a `GPUParticleFilter` (`loglik` is a method of this module).  Returns `pf`.
+
+    filter_from_parameters(θ, pf = nothing) = pf === nothing ?
+        GPUParticleFilter(N, dyn, meas, GaussianSpec(zeros(2), exp(2θ[1])), GaussianSpec(zeros(1), exp(2θ[2])), d0) :
+        set_parameters!(pf; dynamics_density = GaussianSpec(zeros(2), exp(2θ[1])), measurement_density = GaussianSpec(zeros(1), exp(2θ[2])))
+"""
+function set_parameters!(pf::GPUParticleFilter; dynamics = pf.dynamics, measurement = pf.measurement, dynamics_density = pf.dynamics_density,
+                         measurement_density = pf.measurement_density, initial_density = pf.initial_density)
+    cm = pf.measurement_likelihood isa UserLikelihood ?
+        cmodel(dynamics, measurement, dynamics_density, measurement_density, initial_density, pf.Ts; user_likelihood = true) :
+        cmodel(dynamics, measurement, dynamics_density, measurement_density, initial_density, pf.Ts)
+    check(ccall((:llpf_set_model, LIB), Cint, (Ptr{Cvoid}, Ref{CModel}), pf.h, Ref(cm)))
+    pf.dynamics = dynamics; pf.measurement = measurement
+    pf.dynamics_density = dynamics_density; pf.measurement_density = measurement_density; pf.initial_density = initial_density
+    if pf.measurement_likelihood isa GaussianLikelihood
+        pf.measurement_likelihood = GaussianLikelihood(measurement, measurement_density)
+    end
+    pf
+end
 # `pf.state` is materialised from the device on demand; every other property is a field (this method is more specific than
 # the reference's getproperty(::AbstractParticleFilter, ...) of src/PFtypes.jl:84-99)
 Base.getproperty(pf::GPF, s::Symbol) = s === :state ? state(pf) : getfield(pf, s)
