@@ -1,0 +1,74 @@
+"""A block-structure check for the Julia sources (Julia is not in the build image, so the files never run here): strings, docstrings,
+comments and character literals are blanked, then brackets and block keywords are matched with a stack — `end` inside `[...]` is an index,
+`for` / `if` / `while` directly inside brackets are generators, `:end` / `x.end` are not closers.  Catches what a missing or stray `end`,
+an unclosed string or an unbalanced bracket would do to the file; it does not replace a parser."""
+import re
+
+OPENERS = {"function", "if", "for", "while", "let", "begin", "struct", "module", "baremodule", "do", "try", "quote", "macro"}
+GENERATORS = {"for", "if", "while"}
+_CHAR = re.compile(r"'(\\.|[^\\'])'")
+_TOKEN = re.compile(r"\n|[A-Za-z_¡-￿][A-Za-z_0-9!¡-￿]*|[()\[\]{}]|\S")
+
+
+def blank(src):
+    out, i, n = [], 0, len(src)
+    while i < n:
+        c = src[i]
+        if src.startswith('"""', i):
+            j = src.index('"""', i + 3)
+            out.append("\n" * src[i:j + 3].count("\n"))
+            i = j + 3
+        elif c == '"':
+            j = i + 1
+            while src[j] != '"':
+                j += 2 if src[j] == "\\" else 1
+            out.append('""' + "\n" * src[i:j].count("\n"))
+            i = j + 1
+        elif src.startswith("#=", i):
+            j = src.index("=#", i + 2)
+            out.append("\n" * src[i:j].count("\n"))
+            i = j + 2
+        elif c == "#":
+            j = src.find("\n", i)
+            i = n if j < 0 else j
+        elif c == "'" and _CHAR.match(src, i):
+            out.append("' '")
+            i = _CHAR.match(src, i).end()
+        else:
+            out.append(c)
+            i += 1
+    return "".join(out)
+
+
+def check(path):
+    """list of problems (empty: balanced)"""
+    src = blank(open(path, encoding="utf-8").read())
+    stack, line, errs, prev = [], 1, [], ""
+    for m in _TOKEN.finditer(src):
+        t = m.group(0)
+        if t == "\n":
+            line += 1
+            continue
+        if t in "([{":
+            stack.append((t, line))
+        elif t in ")]}":
+            want = {")": "(", "]": "[", "}": "{"}[t]
+            if not stack or stack[-1][0] != want:
+                errs.append("line %d: unmatched %s (innermost open: %s)" % (line, t, stack[-1] if stack else None))
+            else:
+                stack.pop()
+        elif t == "end" and prev not in (":", "."):
+            if stack and stack[-1][0] == "[":
+                pass                                               # a[end]
+            elif not stack or stack[-1][0] in "({":
+                errs.append("line %d: `end` closes nothing (innermost open: %s)" % (line, stack[-1] if stack else None))
+            else:
+                stack.pop()
+        elif t in OPENERS and prev not in (":", "."):
+            if not (t in GENERATORS and stack and stack[-1][0] in "([{"):
+                stack.append((t, line))
+        elif t == "type" and prev in ("abstract", "primitive"):
+            stack.append((t, line))
+        prev = t
+    errs += ["unclosed %s opened at line %d" % s for s in stack]
+    return errs

@@ -183,3 +183,28 @@ def test_integration_md_example_is_the_wrappers_own_method():
     assert len(lines) >= 8
     for l in lines:
         assert l in jl, l
+
+
+def test_julia_sources_are_block_balanced(tmp_path):
+    """The Julia files never run in this image: at least their block structure (function / if / for / struct / do ... end, brackets, strings,
+    docstrings) must be consistent — and the checker must notice when it is not (one `end` removed, one added, a bracket dropped)."""
+    import julia_blocks as jb
+    jdir = os.path.join(ROOT, "lowlevelparticlefilters.jl_amd", "julia")
+    for name in ("LLPFAmd.jl", "make_reference_fixtures.jl"):
+        path = os.path.join(jdir, name)
+        assert jb.check(path) == [], (name, jb.check(path)[:5])
+        lines = open(path, encoding="utf-8").read().split("\n")
+        ends = [i for i, l in enumerate(lines) if l.strip() == "end"]
+        for mutate in ("drop", "add", "bracket"):
+            m = list(lines)
+            if mutate == "drop":
+                del m[ends[len(ends) // 2]]
+            elif mutate == "add":
+                m.insert(ends[len(ends) // 3], "end")
+            else:
+                code = jb.blank("\n".join(lines)).split("\n")           # line for line what the checker sees (docstrings and comments blanked)
+                k = next(i for i, l in enumerate(code) if l.count("(") == l.count(")") >= 1 and l.rstrip().endswith(")") and l.rstrip() == lines[i].rstrip())
+                m[k] = m[k].rstrip()[:-1]
+            p = tmp_path / ("mut_" + mutate + "_" + name)
+            p.write_text("\n".join(m), encoding="utf-8")
+            assert jb.check(str(p)), (name, mutate)
