@@ -390,7 +390,6 @@ static int bank_set_models(Bank& b, const llpf_model* models) {
     CHK(use_device(b));
     const llpf_model m0 = b.cfg.model;
     const int F = b.F;
-    const bool was_replicas = (int)b.hmodels.size() < F;
     std::vector<ModelD> hm(F);
     std::vector<llpf_model> mm(models, models + F);
     for (int f = 0; f < F; ++f) {
@@ -412,7 +411,6 @@ static int bank_set_models(Bank& b, const llpf_model* models) {
         for (auto& g : b.graphs) if (g.exec) hipGraphExecDestroy(g.exec);
         b.graphs.clear();
     }
-    (void)was_replicas;
     b.hmodels = mm;
     b.cfg.model = mm[0];
     HIPC(hipMemcpyAsync(b.d_models, hm.data(), sizeof(ModelD) * F, hipMemcpyHostToDevice, b.stream));

@@ -90,9 +90,10 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
     const char* sfx_env = getenv("LLPF_SOURCE_FX");
     // Which of the two pays depends on how many sources survive a resampling — every f(x) of the source-side form makes a round trip
     // through HBM.  Quad-tank, N = 1e6, us per timestep (tools/dbg/qt_regimes.py; EXPERIMENTS.md 4.13): 0.8 % distinct ancestors
-    // (BASELINE C3) 31.7 source-side / 36.3 per output, 4.9 % 35.1 / 36.0, 10.5 % 39.6 / 37.2, 24.6 % 47.0 / 38.9, 71 % 54.0 / 47.2.  Both launches count the sources whose f the step
-    // needed (BankDev::surv, per tile); the host switches the NEXT run's form with a hysteresis (below 5 % -> source-side, above 8 % -> per
-    // output).  A handle's first run takes the source-side form.  LLPF_SOURCE_FX=0/1 pins it.
+    // (BASELINE C3) 31.7 source-side / 36.3 per output, 4.9 % 35.1 / 36.0, 10.5 % 39.6 / 37.2, 24.6 % 47.0 / 38.9, 71 % 54.0 / 47.2.
+    // Both launches count the sources whose f the step needed (BankDev::surv, per tile); the host switches the NEXT run's form with a
+    // hysteresis (below 5 % -> source-side, above 8 % -> per output).  A handle's first run takes the source-side form.
+    // LLPF_SOURCE_FX=0/1 pins it.
     const bool fx_capable = unfused && resample_fx_supported(b.cfg.model.model_id, b.nx, b.ny, b.cfg.resampling_strategy);
     if (fx_capable && b.surv_frac >= 0.0) { if (b.surv_frac < 0.05) b.use_fx = true; else if (b.surv_frac > 0.08) b.use_fx = false; }
     const bool source_fx = fx_capable && (sfx_env ? atoi(sfx_env) != 0 : b.use_fx);

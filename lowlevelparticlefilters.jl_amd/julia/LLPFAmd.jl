@@ -354,7 +354,7 @@ strategy_code(::Type{ResampleResidual}) = Int32(2)
                       seed = 0, device = 0)
 
 `ParticleFilter(N, dynamics, measurement, df, dg, d0; ...)` of the reference (src/PFtypes.jl:21-36, 65-75) on the GPU:
-same positional arguments, same keyword names and defaults (`seed` keys the engine's generator, Philox4x32-10; `rng` is
+same positional arguments, same keyword names and defaults (`seed` keys the engine's generator, Philox4x32 (7 rounds); `rng` is
 only used by the host-side `simulate`; `threads` has no meaning here).  `NX` is the dimension of a particle as the accessors return it."""
 mutable struct GPUParticleFilter{NX,RST<:DataType,FT,GT,GLT,FDT,GDT,IDT,P,RNGT} <: AbstractParticleFilter
     h::Ptr{Cvoid}

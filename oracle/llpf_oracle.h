@@ -16,7 +16,7 @@
  *   (iii) agreement with the closed-form Kalman log-likelihood (reference src/filtering.jl:52-128)
  *         within Monte-Carlo error.
  * The RNG streams (Xoshiro + ziggurat randn, global rand()) are unpinned by the reference (no
- * seeded expectation exists) and are replaced by Philox4x32-10; see llpf_philox.h.
+ * seeded expectation exists) and are replaced by Philox4x32 (7 rounds since round 4; the 10-round instance is held to the Random123 vectors); see llpf_philox.h.
  *
  * Two arithmetic orders:
  *   ORC_ORDER_REFERENCE — literal: findmax / SLEEF-like exp (libm) / pairwise sum / serial fp64
