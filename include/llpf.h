@@ -248,8 +248,10 @@ int  llpf_smooth(llpf_filter* f, int64_t M, const double* U, int64_t T, const do
  *         DEV double loglik_bound() const;     // an upper bound of loglik over x and y for the parameters prepare() saw (it is
  *                                              // evaluated once, when the filter is built, with u = 0, t = 0): what the engine's
  *                                              // bound-offset normalisation needs.  Without this member every step is normalised
- *                                              // against the true maximum instead (same results to rounding, one host round trip
- *                                              // per step).  A bound that does not hold is reported as LLPF_ERR_DEGENERATE.
+ *                                              // against the true maximum instead (same results to rounding; llpf_run then
+ *                                              // launches the exact-form normalisation in front of every step: about 20 %
+ *                                              // slower, no host round trips).  A bound that does not hold is reported as
+ *                                              // LLPF_ERR_DEGENERATE.
  *     };
  * (DEV = __device__ __forceinline__; the engine's deterministic math — llpf_exp, llpf_log, llpf_sqrt_pos, ... of
  * csrc/shared/llpf_detmath.h — is in scope, and the source is compiled with -ffp-contract=off like the engine.)  The snippet is

@@ -83,6 +83,11 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
     const bool rbm = is_rb(b);
     const bool rbfull = is_rbfull(b);     // per-particle covariance: its own step kernel, balanced form, exp-sums by k_norm
     const bool user_model = b.cfg.model.model_id >= LLPF_MODEL_USER_BASE;   // run-time compiled model: only its k_step exists
+    // a likelihood of the model's own that declares no bound (loglik without loglik_bound): there is nothing to normalise against ahead
+    // of the weights, so every timestep takes the exact-max form — as launches of the run loop (k_norm in exact form in front of the
+    // head), not as a failed bound test that the host notices and redoes (one round trip per timestep until round 4)
+    const int model_traits_v = user_model ? jit_model_traits(b.cfg.model.model_id) : 0;
+    const bool no_bound = user_model && model_traits_v > 0 && (model_traits_v & LLPF_TRAIT_LOGLIK) && !(model_traits_v & LLPF_TRAIT_LOGLIK_BOUND);
     // (xcov: the covariance is taken from the state between correct! and predict!, which only the balanced form leaves in memory)
     const bool unfused = user_model || rbfull || hist || residual || xcov != nullptr || (unf_env ? atoi(unf_env) != 0 : heavy_dynamics);
     // models whose dynamics are worth a table: the resampling launch evaluates f(x_j) once per surviving source and leaves run-start marks,
@@ -130,6 +135,9 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
     // Measured on MI355X: C2 single filter 29.4 vs 30.2 us, bank 128 x 1e5: 4.3e10 vs 5.0e10 particle-steps/s.
     const char* sch_env = getenv("LLPF_SCHEDULE");       // "merged" | "split" override
     const bool merged = (hist || (sch_env ? (strcmp(sch_env, "merged") == 0) : ((int64_t)b.F * b.Ns <= ((int64_t)3 << 20))));
+    // (a model without a bound: the weighting launches form no sums at all — a step without a measurement would otherwise leave real ones
+    // in the slot, against the finite bound max(w), and the exact-form k_norm in front of the next head would add to them)
+    const bool acc_in_weighting = merged && !no_bound;
     static const char* abl_env = getenv("LLPF_ABLATE");
     static const char* dbg_env = getenv("LLPF_DEBUG_TIMING");
 
@@ -163,7 +171,7 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
         st.t_prop = tk(k);
         st.step = rel_step(b);
         st.parity = b.parity;
-        st.need_e2 = ne2; st.K = K; st.k = k; st.next_step = rel_step(b) + 1; st.want_xmean = want_xm; st.accumulate = merged ? 1 : 0;
+        st.need_e2 = ne2; st.K = K; st.k = k; st.next_step = rel_step(b) + 1; st.want_xmean = want_xm; st.accumulate = acc_in_weighting ? 1 : 0;
         if (rbm) { st.rb_pred = b.d_rbseq + (size_t)(2 * k + 1) * b.F; st.rb_corr = b.d_rbseq + (size_t)(2 * k + 2) * b.F; }
         const bool weight = (k + 1 < T);
         if (weight) { st.y = b.d_Y + (k + 1) * FM * b.ny; st.t_meas = tk(k + 1); st.has_y = has_y(k + 1) ? 1 : 0; }
@@ -264,7 +272,7 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
         BankDev d = b.dev();
         StepArgs a{};
         a.u = b.nu > 0 ? b.d_U : nullptr; a.y = b.d_Y; a.u_stride = multi ? b.nu : 0; a.y_stride = multi ? b.ny : 0; a.t_prop = tk(0); a.t_meas = tk(0); a.step = 0; a.has_y = has_y(0) ? 1 : 0;
-        a.parity = par0; a.need_e2 = ne2; a.K = K; a.k = 0; a.next_step = 0; a.want_xmean = want_xm; a.accumulate = merged ? 1 : 0;
+        a.parity = par0; a.need_e2 = ne2; a.K = K; a.k = 0; a.next_step = 0; a.want_xmean = want_xm; a.accumulate = acc_in_weighting ? 1 : 0;
         if (rbm) a.rb_corr = b.d_rbseq;
         ProfScope ps(b, LLPF_PROF_PROPAGATE);
         HIPC(launch_step(d, MODE_WEIGHT, a, b.stream));
@@ -278,7 +286,7 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
     if (use_graph) {
         Bank::RunGraph key{};
         key.T = T; key.t_index0 = t_index0; key.par0 = par0; key.cur0 = cur0; key.qcur0 = qcur0;
-        key.flags = (merged ? 1 : 0) | (unfused ? 2 : 0) | (want_xm ? 4 : 0) | (ll_steps ? 8 : 0) | (xm_launch ? 16 : 0) | (multi ? 32 : 0) | (source_fx ? 64 : 0) | (xcov ? 128 : 0) | ((abl_env ? atoi(abl_env) : 0) << 8);
+        key.flags = (merged ? 1 : 0) | (unfused ? 2 : 0) | (want_xm ? 4 : 0) | (ll_steps ? 8 : 0) | (xm_launch ? 16 : 0) | (multi ? 32 : 0) | (source_fx ? 64 : 0) | (xcov ? 128 : 0) | ((abl_env ? atoi(abl_env) : 0) << 8);      // (no_bound is a property of the model id, which a handle keeps)
         key.np_parity = (int)(np0 & 1u);
         key.dU = b.d_U; key.dY = b.d_Y; key.dll = ll_steps ? b.d_ll_steps : nullptr; key.dxm = xmean ? b.d_xmean : (xcov ? b.d_xcov : nullptr); key.drb = b.d_rbseq;
         key.yhash = 1469598103934665603ULL;
@@ -295,7 +303,7 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
             hipGraph_t graph = nullptr;
             HIPC(hipStreamBeginCapture(b.stream, hipStreamCaptureModeThreadLocal));
             int rc = first_weighting();
-            for (int64_t k = 0; rc == LLPF_OK && k < T; ++k) rc = launch_timestep(k, true, 0);
+            for (int64_t k = 0; rc == LLPF_OK && k < T; ++k) rc = launch_timestep(k, !no_bound, 0);
             const hipError_t ee = hipStreamEndCapture(b.stream, &graph);
             if (rc != LLPF_OK) { if (graph) hipGraphDestroy(graph); return rc; }
             if (ee != hipSuccess) return fail(LLPF_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ee));
@@ -366,7 +374,7 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
         while (k0 < T) {
             const int64_t k1 = replayed ? T : std::min(T, k0 + batch);
             if (!replayed) {
-                for (int64_t k = k0; k < k1; ++k) CHK(launch_timestep(k, true, 0));
+                for (int64_t k = k0; k < k1; ++k) CHK(launch_timestep(k, !no_bound, 0));
             }
             replayed = false;
             std::vector<int> fl;

@@ -152,8 +152,8 @@ def test_user_measurement_likelihood(name):
 
 @pytest.mark.gpu
 def test_user_likelihood_without_a_declared_bound_takes_the_exact_form():
-    """no `loglik_bound` in the snippet: every step is normalised against the true maximum (the exact form, one host round trip
-    each) — the results are the bounded model's to rounding, and the reference order's within tolerance"""
+    """no `loglik_bound` in the snippet: every step is normalised against the true maximum (the exact form: a k_norm launch in
+    front of every head, no host round trip) — the results are the bounded model's to rounding, and the reference order's within tolerance"""
     import independent_cases as IC
     case = dict(IC.cases()["pf_lg_laplace"])
     g1 = IC.engine_of(case)
