@@ -110,6 +110,23 @@ def test_c4_as_stated_1024_filters_over_8_shards():
         ob.set_threads(1)
 
 
+def test_set_models_of_a_sharded_sweep():
+    """llpf_mbank_set_models: every shard takes its own slice of the new descriptors (the partition of the creation); a sweep that was
+    given new parameters returns the bits of a sweep (and of a plain bank) created with them"""
+    cfg, models, U, Y = _sweep(F=7)
+    models2 = [M.lg_test_model(s) for s in 10.0 ** np.linspace(-1.5, 0.3, 7)]
+    fresh = _capi.BankHandle(S.make_config(models2[0], cfg.n_particles, S.PARTICLE_FILTER, S.RESAMPLE_SYSTEMATIC, cfg.resample_threshold, cfg.seed, 0), models2)
+    fresh.seed(cfg.seed); fresh.reset()                      # (seed restarts the reset! / predict! counters: the same draws on both sides)
+    ref2 = fresh.run(U, Y, 1.0)["ll"]
+    mb = _capi.MBankHandle(cfg, models, devices=[0, 0, 0])
+    mb.reset(); mb.run(U, Y, 1.0)
+    mb.set_models(models2)
+    mb.seed(cfg.seed); mb.reset()
+    assert _same_bits(mb.run(U, Y, 1.0)["ll"], ref2)
+    with pytest.raises(ValueError):
+        mb.set_models(models2[:3])
+
+
 def test_reseeding_and_aux_runs_shard_too():
     cfg, models, U, Y = _sweep(F=6)
     b = _capi.BankHandle(cfg, models)
