@@ -761,6 +761,20 @@ function GPUFilterBank(N::Integer, dynamics::Vector, measurement, dfs::Vector, d
     b
 end
 "log-likelihood of every filter of the bank on shared data u, y (vectors of vectors)"
+"""
+    set_parameters!(bank, dynamics::Vector, measurement, dfs::Vector, dg, d0; Ts = 1.0)
+
+New parameters for every filter of a `GPUFilterBank` / `GPUMultiBank` (the arguments of its constructor, same count and dimensions) without
+reallocating anything: a Metropolis iteration over one chain per filter — the reference's `metropolis_threaded` (src/smoothing.jl:335-347) —
+is `set_parameters!` with the chains' candidates followed by `loglik(bank, u, y)`.
+"""
+function set_parameters!(b::GPUFilterBank, dynamics::Vector, measurement, dfs::Vector, dg, d0; Ts = 1.0)
+    cms = bank_models(dynamics, measurement, dfs, dg, d0, Ts)
+    length(cms) == b.F || throw(ArgumentError("set_parameters!: $(length(cms)) models for a bank of $(b.F) filters"))
+    check(ccall((:llpf_bank_set_models, LIB), Cint, (Ptr{Cvoid}, Ptr{CModel}), b.h, cms))
+    b
+end
+
 function loglik(b::GPUFilterBank, u, y)
     T = length(y)
     U = rows(u, b.nu)
@@ -825,6 +839,13 @@ function mbank_unique_id()
     id
 end
 "log-likelihood of every filter of the sweep (all-reduced: the same vector in every process); `sum(ll)` is the global log-likelihood"
+function set_parameters!(b::GPUMultiBank, dynamics::Vector, measurement, dfs::Vector, dg, d0; Ts = 1.0)
+    cms = bank_models(dynamics, measurement, dfs, dg, d0, Ts)
+    length(cms) == b.F || throw(ArgumentError("set_parameters!: $(length(cms)) models for a sweep of $(b.F) filters"))
+    check(ccall((:llpf_mbank_set_models, LIB), Cint, (Ptr{Cvoid}, Ptr{CModel}), b.h, cms))
+    b
+end
+
 function loglik(b::GPUMultiBank, u, y)
     T = length(y)
     U = rows(u, b.nu)
