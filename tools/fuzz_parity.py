@@ -124,10 +124,43 @@ def check(c):
     return why
 
 
+def check_hooked(rng):
+    """the cases with user hooks (likelihood / noise / initial density of the model's own) and the Rao-Blackwellized models of
+    tests/independent_cases.py under random sizes, thresholds, resamplers, seeds and run lengths"""
+    import independent_cases as IC
+    if not hasattr(check_hooked, "cases"):
+        check_hooked.cases = IC.cases()
+    name = str(rng.choice([k for k in check_hooked.cases if k not in ("pf_lg_systematic", "pf_lg_stratified", "pf_quadtank")]))
+    case = dict(check_hooked.cases[name])
+    T = int(rng.integers(3, min(16, len(case["Y"])) + 1))
+    case.update(N=int(rng.choice([1, 63, 64, 65, 300, 1023, 1025, 2500])), thr=float(rng.choice([0.1, 0.5, 0.9, 1.0])),
+                strategy=int(rng.choice([S.RESAMPLE_SYSTEMATIC, S.RESAMPLE_STRATIFIED])), U=case["U"][:T], Y=case["Y"][:T])
+    IC.SEED = int(rng.integers(1, 2 ** 31))
+    try:
+        g, o = IC.engine_of(case), IC.oracle_of(ob, case, ob.ORDER_DEVICE)
+        g.reset(); o.reset()
+        rg, ro = g.run(case["U"], case["Y"], case["t0"], ll_steps=True), o.run(case["U"], case["Y"], case["t0"], ll_steps=True)
+        why = [] if eq(rg["ll_steps"], ro["ll_steps"]) else ["ll_steps"]
+        for nm, fg, fo in (("x", g.particles, o.particles), ("w", g.weights, o.weights), ("j", g.ancestors, o.ancestors)):
+            if not eq(fg(), fo()):
+                why.append(nm)
+    finally:
+        seed_used, IC.SEED = IC.SEED, 7
+    return "hooked:" + name, ("%s N=%d thr=%g strat=%d T=%d seed=%d" % (name, case["N"], case["thr"], case["strategy"], T, seed_used)), why
+
+
 def sweep(cases, seed, verbose=True):
     rng = np.random.default_rng(seed)
     bad, drivers = [], {}
     for i in range(cases):
+        if rng.random() < 0.2:
+            drv, desc, why = check_hooked(rng)
+            drivers["hooked"] = drivers.get("hooked", 0) + 1
+            if why:
+                bad.append("case %d: %s : %s" % (i, desc, "; ".join(why)))
+                if verbose:
+                    print("FAIL " + bad[-1], flush=True)
+            continue
         c = rand_case(rng)
         drivers[c["driver"]] = drivers.get(c["driver"], 0) + 1
         why = check(c)
