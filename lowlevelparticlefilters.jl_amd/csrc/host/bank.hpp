@@ -414,7 +414,10 @@ static int bank_set_models(Bank& b, const llpf_model* models) {
     b.hmodels = mm;
     b.cfg.model = mm[0];
     HIPC(hipMemcpyAsync(b.d_models, hm.data(), sizeof(ModelD) * F, hipMemcpyHostToDevice, b.stream));
-    if (m0.model_id >= LLPF_MODEL_USER_BASE) HIPC(launch_user_bound(m0.model_id, b.d_models, F, b.d_uy, b.stream));
+    if (m0.model_id >= LLPF_MODEL_USER_BASE) {               // the declared bound of the new parameters, evaluated as at creation: u = 0, t = 0
+        HIPC(hipMemsetAsync(b.d_uy, 0, sizeof(double) * 4 * MAXD, b.stream));     // (the staging area of the single-step verbs)
+        HIPC(launch_user_bound(m0.model_id, b.d_models, F, b.d_uy, b.stream));
+    }
     HIPC(hipStreamSynchronize(b.stream));
     if (m0.model_id == LLPF_MODEL_RB_LINEAR) {               // the inner KalmanFilter object of the new filter: kf.x = d0.mu, kf.R = d0.Sigma
         for (int f = 0; f < F; ++f) {
