@@ -23,12 +23,17 @@ def rand_cov(rng, n, scale):
     return S.make_gaussian(np.zeros(n), scale * (L @ L.T))
 
 
+BIG = False      # --big: few timesteps at 7e4 .. 1e6 particles (many tiles, several rounds of the persistent step kernel, heavy tiles)
+
+
 def rand_case(rng):
     fam = rng.choice(["lg", "lg", "lg", "quadtank", "lg_big"])
     N = int(rng.choice([1, 2, 7, 63, 64, 65, 255, 511, 512, 513, 1000, 1023, 1024, 1025, 2047, 2049, 3000, 4097, 10000, 33000]))
     thr = float(rng.choice([0.0, 0.1, 0.3, 0.5, 0.9, 1.0]))
     strat = int(rng.choice([S.RESAMPLE_SYSTEMATIC, S.RESAMPLE_STRATIFIED, S.RESAMPLE_RESIDUAL]))
     T = int(rng.integers(3, 14))
+    if BIG:
+        N, T = int(rng.choice([70001, 131077, 262145, 500000, 1000000, 1048577])), int(rng.integers(3, 6))
     if fam == "quadtank":
         sig = float(rng.choice([0.003, 0.01, 0.05, 0.3]))
         m = S.make_quadtank_model(S.make_gaussian(np.zeros(4), np.full(4, 0.1 * (0.5 + rng.random()))), S.make_gaussian(np.zeros(2), np.full(2, sig ** 2)),
@@ -153,7 +158,7 @@ def sweep(cases, seed, verbose=True):
     rng = np.random.default_rng(seed)
     bad, drivers = [], {}
     for i in range(cases):
-        if rng.random() < 0.2:
+        if rng.random() < 0.2 and not BIG:
             drv, desc, why = check_hooked(rng)
             drivers["hooked"] = drivers.get("hooked", 0) + 1
             if why:
@@ -176,7 +181,9 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=300)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--big", action="store_true")
     a = ap.parse_args()
+    BIG = a.big
     bad, drivers = sweep(a.cases, a.seed)
     print("%d cases (%s), %d failed (seed %d)" % (a.cases, ", ".join("%s %d" % kv for kv in sorted(drivers.items())), len(bad), a.seed))
     sys.exit(1 if bad else 0)
