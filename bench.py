@@ -77,7 +77,7 @@ def build_workload(name, n_particles, T):
     return model, U, Y, kind, thr, label
 
 
-def cpu_baseline(model, U, Y, kind, thr, n_particles, budget_steps, seed, ll_gpu=None, aux=False):
+def cpu_baseline(model, U, Y, kind, thr, n_particles, budget_steps, seed, ll_gpu=None, aux=False, quick=False):
     """The reference-order oracle (literal CPU restatement) timed on a bounded sample of the same workload:
     1 thread (the reference's ParticleFilter path is single-threaded, src/PFtypes.jl:107-139) and, as an upper bound
     for its `threads=true` option, OpenMP over the per-particle loops (scan and sums stay serial).
@@ -93,7 +93,8 @@ def cpu_baseline(model, U, Y, kind, thr, n_particles, budget_steps, seed, ll_gpu
         ncpu = len(os.sched_getaffinity(0))
     except AttributeError:
         ncpu = os.cpu_count() or 1
-    for label, threads in (("cpu_baseline", 1), ("cpu_baseline_multithread", max(1, min(16, ncpu)))):
+    legs = (("cpu_baseline", 1),) if quick else (("cpu_baseline", 1), ("cpu_baseline_multithread", max(1, min(16, ncpu))))
+    for label, threads in legs:
         ob.set_threads(threads)
         o = ob.OracleFilter(cfg, ob.ORDER_REFERENCE)
         o.reset()
@@ -114,7 +115,7 @@ def cpu_baseline(model, U, Y, kind, thr, n_particles, budget_steps, seed, ll_gpu
                         "two particle systems are different, equally valid realisations and differ at Monte-Carlo level "
                         "(~1/sqrt(N) per step)"}}
         del o
-    if ll_gpu is not None:      # the bit-exact contract: device-order oracle, same inputs (bounded: 20 timesteps)
+    if ll_gpu is not None and not quick:      # the bit-exact contract: device-order oracle, same inputs (bounded: 20 timesteps)
         ob.set_threads(max(1, min(16, ncpu)))
         Td = min(20, Ts)
         o = ob.OracleFilter(cfg, ob.ORDER_DEVICE)
@@ -127,6 +128,19 @@ def cpu_baseline(model, U, Y, kind, thr, n_particles, budget_steps, seed, ll_gpu
         del o
     ob.set_threads(1)
     return res
+
+
+RCCL_COLLECTIVE = "RCCL ncclAllReduce(fp64, sum) of the log-likelihood vector inside libllpf_hip.so (llpf_mbank_run)"
+
+
+def rccl_requirement_failure(collective, ranks_seen, world):
+    """--require-rccl: None when the N-rank line was produced by the in-library RCCL all-reduce with every rank reporting in, else the
+    reason (the run then exits non-zero: a scaling line must never silently come from the gloo fallback or from fewer ranks)."""
+    if world > 1 and collective != RCCL_COLLECTIVE:
+        return "the log-likelihood exchange was not the in-library RCCL all-reduce: " + collective
+    if sorted(ranks_seen) != list(range(world)):
+        return "ranks seen %s, expected 0..%d" % (sorted(ranks_seen), world - 1)
+    return None
 
 
 def main_bank(args, rank, world, dev):
@@ -181,7 +195,7 @@ def main_bank(args, rank, world, dev):
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 1:
             bank = box["bank"]
-            collective = "RCCL ncclAllReduce(fp64, sum) of the log-likelihood vector inside libllpf_hip.so (llpf_mbank_run)"
+            collective = RCCL_COLLECTIVE
         else:
             errs = [None] * world
             dist.all_gather_object(errs, err)
@@ -283,6 +297,7 @@ def main_bank(args, rank, world, dev):
                             "whole_timestep": {"algorithmic_bytes": Fl * N * b_alg, "us": timestep_s * 1e6,
                                                "achieved": Fl * N * b_alg / timestep_s / 1e9, "frac": Fl * N * b_alg / timestep_s / 8e12}}}
         if solo is not None:
+            out["scaling_efficiency"] = value / (world * solo)      # = one_gpu_same_share.efficiency: THE weak-scaling figure of this line
             out["one_gpu_same_share"] = {"value": solo, "unit": "particle-steps/s", "n_gpus": 1,
                                          "note": "rank 0 alone on its per-GPU share (%d filters) while the other ranks wait: aggregate / (n_gpus x this) "
                                                  "is the weak-scaling efficiency of this workload" % args.filters_per_gpu,
@@ -298,12 +313,22 @@ def main_bank(args, rank, world, dev):
             out["roofline"]["traffic_source"] = pm["c4"]["source"] + "; " + pm["correction"]
         if world == 1 and not args.no_cpu_baseline:
             cs = args.cpu_steps if args.cpu_steps else 1000
-            out.update(cpu_baseline(models[len(models) // 2], U, Y, S.PARTICLE_FILTER, thr, N, min(cs, T), 77, None))
+            if args.cpu_quick:
+                cs = max(2, min(cs, int(8 * 2.9e7 / N)))          # ~8 s at the measured one-core rate
+            out.update(cpu_baseline(models[len(models) // 2], U, Y, S.PARTICLE_FILTER, thr, N, min(cs, T), 77, None, quick=args.cpu_quick))
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+        if args.require_rccl:
+            why = rccl_requirement_failure(collective, [r["rank"] for r in ranks_seen], world)
+            out["require_rccl"] = "ok" if why is None else "FAILED: " + why
         print(json.dumps(out))
+    rccl_why = rccl_requirement_failure(collective, [r["rank"] for r in ranks_seen], world) if args.require_rccl else None
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rccl_why is not None:       # every rank decides alike (the collective and the gathered ranks are agreed values): the launcher sees rc != 0
+        sys.stderr.write("bench.py --require-rccl: %s\n" % rccl_why)
+        sys.stdout.flush()
+        os._exit(3)
     if getattr(args, "stuck_thread", False):      # a thread is still inside RCCL: do not let interpreter shutdown wait for it
         sys.stdout.flush()
         os._exit(0)
@@ -337,17 +362,18 @@ def main_reference_mc(args, rank, world):
 
 
 def other_configs():
-    """The default line also carries the other single-GPU BASELINE configs, each from a short run of this same script (2 timed
-    passes, no CPU baseline) with its own roofline block: C3 quad-tank (N = 1e6, T = 2000), one GPU's share of C4 (128 filters x
-    1e5), C5 RBPF with per-particle covariance (N = 2e5).  Their full lines (with the CPU baseline) are `--workload ...`."""
+    """The default line also carries the other single-GPU BASELINE configs, each from a short run of this same script (5 timed
+    passes, a bounded one-thread CPU baseline of ~8 s) with its own roofline and cpu_baseline blocks: C3 quad-tank (N = 1e6, T = 2000), one GPU's share of C4 (128 filters x
+    1e5), C5 RBPF with per-particle covariance (N = 2e5).  Their full lines (with the multi-thread leg and the accuracy block) are `--workload ...`."""
     import subprocess
     res = {}
     for key, wl in (("C3_quadtank", "quadtank"), ("C4_share_128x1e5", "bank"), ("C5_rbpf_full", "rbpf_full")):
         try:
-            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", wl, "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", wl, "--steps", "5", "--warmup", "1", "--cpu-quick"],
                                capture_output=True, text=True, timeout=300)
             d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
-            res[key] = {k: d.get(k) for k in ("metric", "value", "unit", "steps", "ms_per_step", "dtype", "config", "kernel_us", "roofline") if k in d}
+            res[key] = {k: d.get(k) for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "kernel_us", "roofline",
+                                              "cpu_baseline", "speedup_vs_cpu_baseline") if k in d}
         except Exception as e:      # a failed side run must not cost the headline line
             res[key] = {"error": repr(e)[:300]}
     return res
@@ -402,7 +428,7 @@ SCALING_REFERENCE_DOC = ("every bench line carries `scaling_reference.value_one_
                          "(BASELINE config C4), so that a scaling ratio never divides a C4 sweep by the C2 single filter of the N = 1 default line")
 
 
-def main_spawn_check(rank, local_rank, world, backend):
+def main_spawn_check(rank, local_rank, world, backend, require_rccl=False):
     """--spawn-check: every rank reports in and rank 0 prints what it saw; no GPU work (the CPU test of the launcher logic)."""
     import torch
     import torch.distributed as dist
@@ -419,6 +445,16 @@ def main_spawn_check(rank, local_rank, world, backend):
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if require_rccl and world > 1 and backend != "nccl":
+        # what the real run would decide in this mode, decided here too so that the flag's wiring is testable without a GPU
+        why = rccl_requirement_failure("torch.distributed all_reduce (gloo, CPU tensors): ranks share a GPU", [r["rank"] for r in seen], world)
+        sys.stderr.write("bench.py --require-rccl: %s\n" % why)
+        return 3
+    if require_rccl:
+        why = rccl_requirement_failure(RCCL_COLLECTIVE, [r["rank"] for r in seen], world)
+        if why is not None:
+            sys.stderr.write("bench.py --require-rccl: %s\n" % why)
+            return 3
     return 0
 
 
@@ -441,6 +477,11 @@ def main():
     ap.add_argument("--rccl-timeout", type=float, default=120.0,
                     help="N > 1: seconds the in-library RCCL communicator and its first all-reduce may take before the run falls back "
                          "to exchanging the log-likelihood vector through torch.distributed (and says so in config.collective)")
+    ap.add_argument("--require-rccl", action="store_true",
+                    help="N > 1: exit non-zero (after printing the line, which then carries require_rccl: FAILED ...) unless the log-likelihood exchange "
+                         "was the in-library RCCL all-reduce and every one of the N ranks reported in — no silent gloo fallback in a scaling run")
+    ap.add_argument("--cpu-quick", action="store_true",
+                    help="bounded CPU baseline for the side runs of other_configs: the one-thread leg only, ~8 s of CPU, no accuracy block")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, the measured path): one rank per GPU, the log-likelihood all-reduce over RCCL INSIDE the library; "
                          "gloo: that exchange through torch.distributed on CPU tensors, ranks may share devices (exercises the multi-rank "
@@ -459,7 +500,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.spawn_check:
-        return main_spawn_check(rank, local_rank, world, args.dist_backend)
+        sys.exit(main_spawn_check(rank, local_rank, world, args.dist_backend, args.require_rccl))
 
     import torch
     import torch.distributed as dist
@@ -658,14 +699,16 @@ def main():
                "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
             per = 2.5e7 if args.workload == "lg" else (5e5 if rbfull else 4.5e6)   # measured 1-core rates, to size a ~10 s sample
-            cs = args.cpu_steps if args.cpu_steps else max(2, min(T, int(10 * per / N)))
-            pf2 = _capi.FilterHandle(cfg)          # a fresh handle: same Philox counters as a fresh oracle (first reset!)
-            pf2.reset()
-            ll_gpu = run_once(pf2, ll_steps=True)["ll_steps"]
-            del pf2
-            out.update(cpu_baseline(model, U, Y, kind, thr, N, min(cs, T - 1), 1000 + rank, ll_gpu, aux))
+            cs = args.cpu_steps if args.cpu_steps else max(2, min(T, int((8 if args.cpu_quick else 10) * per / N)))
+            ll_gpu = None
+            if not args.cpu_quick:
+                pf2 = _capi.FilterHandle(cfg)          # a fresh handle: same Philox counters as a fresh oracle (first reset!)
+                pf2.reset()
+                ll_gpu = run_once(pf2, ll_steps=True)["ll_steps"]
+                del pf2
+            out.update(cpu_baseline(model, U, Y, kind, thr, N, min(cs, T - 1), 1000 + rank, ll_gpu, aux, quick=args.cpu_quick))
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
-            if args.workload == "lg":
+            if args.workload == "lg" and not args.cpu_quick:
                 # ancestor mismatches against the reference order at full size, teacher forced (tests/gpu_common.py)
                 from gpu_common import teacher_forced_ancestor_mismatches
                 tf = teacher_forced_ancestor_mismatches(cfg, U, Y, min(50, T - 1))

@@ -588,6 +588,16 @@ def metropolis(ll, R, theta0, draw=None, rng=None):
     return params, np.array(lls)
 
 
+def _spec_builds(spec_from_parameters, theta):
+    """does this candidate give a model the library accepts? (densities positive definite, dimensions as declared)"""
+    try:
+        dy, me, df, dg, d0 = spec_from_parameters(theta)
+        _build_model(dy, me, df, dg, d0, 1.0)
+        return True
+    except Exception:
+        return False
+
+
 def metropolis_bank(bank, spec_from_parameters, priors, u, y, R, theta0s, draw=None, burnin=0, rng=None):
     """The GPU form of the reference's metropolis_threaded (src/smoothing.jl:335-347: one independent chain per thread): the chains advance in
     lockstep and every iteration is ONE bank run — llpf_bank_set_models with the chains' candidates, then the bank's loglik.
@@ -601,12 +611,30 @@ def metropolis_bank(bank, spec_from_parameters, priors, u, y, R, theta0s, draw=N
         raise ValueError("one chain per filter of the bank")
     draw = (lambda th, d=naive_sampler(theta0s[0], rng): d(th)) if draw is None else draw
 
+    import re
+
     def lls_of(thetas):
         lp = np.array([sum(np.float64(priors[i].logpdf(th[i])) for i in range(th.size)) for th in thetas])
         ok = np.isfinite(lp)
-        # chains whose candidate lies outside the priors' support keep a valid model in their slot; its likelihood is not used
-        bank.set_parameters([spec_from_parameters(thetas[k] if ok[k] else cur[k]) for k in range(n)])
-        out = np.where(ok, lp + bank.loglik(u, y), -np.inf)
+        # Chains whose candidate lies outside the priors' support keep a valid model in their slot; its likelihood is not used.  A chain
+        # whose candidate cannot be built (covariance not positive definite) or degenerates the filter scores -inf ALONE — the reference
+        # wraps each chain's loglik in try / catch (src/smoothing.jl:276-280), so one bad proposal must not stop the others: the failing
+        # slot (the library's message names the filter) is given its chain's current parameters and the bank runs again.
+        ll = None
+        for _ in range(n + 1):
+            try:
+                bank.set_parameters([spec_from_parameters(thetas[k] if ok[k] else cur[k]) for k in range(n)])
+                ll = bank.loglik(u, y)
+                break
+            except (_capi.LLPFError, ValueError, FloatingPointError, np.linalg.LinAlgError) as e:
+                m = re.search(r"in filter (\d+)", str(e))
+                bad = int(m.group(1)) if m else next((k for k in range(n) if ok[k] and not _spec_builds(spec_from_parameters, thetas[k])), None)
+                if bad is None or not ok[bad]:
+                    raise
+                ok[bad] = False
+        if ll is None:
+            raise RuntimeError("metropolis_bank: the bank fails with every chain on its current parameters")
+        out = np.where(ok, lp + ll, -np.inf)
         return np.where(np.isnan(out), -np.inf, out)
 
     cur = theta0s.copy()
@@ -663,19 +691,21 @@ def _statsbase_quantile(v, w, q):
 
 def weighted_quantile(x, we=None, q=None):
     """weighted_quantile(x, we, q) / weighted_quantile(sol, q) — reference src/filtering.jl:583-595: per time step and state dimension the
-    weighted quantile of the particles (StatsBase's definition), a list of length T of [len(q), nx] arrays (of nx-vectors for a scalar q).
-    weighted_quantile(pf, q): the current particles and weights of a filter, sorted and summed on the device (llpf_weighted_quantile)."""
+    weighted quantile of the particles (StatsBase's definition), a list of length T of [nx, len(q)] arrays (of nx-vectors for a scalar q):
+    the reference's nesting [t][state][q].
+    weighted_quantile(pf, q): the current particles and weights of a filter, sorted and summed on the device (llpf_weighted_quantile);
+    [nx, len(q)] like one time step of the above (the C ABI itself writes [nq][nx]; the Julia accessor returns nx x nq as well)."""
     if isinstance(x, _AbstractParticleFilter):
         qq = we if q is None else q
         out = x._h.weighted_quantile(qq)
-        return out[0] if np.isscalar(qq) else out
+        return out[0] if np.isscalar(qq) else np.ascontiguousarray(out.T)
     if isinstance(x, ParticleFilteringSolution):
         x, we, q = x.x, x.we, (we if q is None else q)
     x, we = np.asarray(x), np.asarray(we)
     out = []
     for t in range(x.shape[0]):
-        r = np.stack([_statsbase_quantile(x[t][:, d], we[t], q) for d in range(x.shape[2])], axis=1)
-        out.append(r[0] if np.isscalar(q) else r)
+        r = np.stack([_statsbase_quantile(x[t][:, d], we[t], q) for d in range(x.shape[2])], axis=0)      # [state][q]
+        out.append(r[:, 0] if np.isscalar(q) else r)
     return out
 
 

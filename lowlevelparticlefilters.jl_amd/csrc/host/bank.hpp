@@ -61,12 +61,12 @@ struct Bank {
     // (tools/launch_floor.hip: 1.6 vs 2.8 us per dependent empty launch).  Keyed by everything a launch argument depends on.
     struct RunGraph {
         int64_t T; double t_index0; int par0, cur0, qcur0, flags, np_parity;
-        const void *dU, *dY, *dll, *dxm, *drb;
+        const void *dU, *dY, *dll, *dxm, *dxc, *drb;      // every device buffer a captured launch addresses that ensure() may reallocate
         uint64_t yhash;
         hipGraphExec_t exec;
         bool same(const RunGraph& o) const {
             return T == o.T && t_index0 == o.t_index0 && par0 == o.par0 && cur0 == o.cur0 && qcur0 == o.qcur0 && flags == o.flags &&
-                   np_parity == o.np_parity && dU == o.dU && dY == o.dY && dll == o.dll && dxm == o.dxm && drb == o.drb && yhash == o.yhash;
+                   np_parity == o.np_parity && dU == o.dU && dY == o.dY && dll == o.dll && dxm == o.dxm && dxc == o.dxc && drb == o.drb && yhash == o.yhash;
         }
     };
     std::vector<RunGraph> graphs;
@@ -233,9 +233,12 @@ static int bank_init_particles(Bank& b, bool is_reset) {
     HIPC(hipMemsetAsync(b.d_tileq, 0, sizeof(uint64_t) * (size_t)ACC_NSLOT * b.F * b.P2, b.stream));
     HIPC(hipMemsetAsync(b.d_flag, 0, sizeof(uint32_t) * 4, b.stream));
     b.parity = 0;
-    if (b.cfg.model.model_id >= LLPF_MODEL_USER_BASE && (jit_model_traits(b.cfg.model.model_id) & LLPF_TRAIT_INITIAL) > 0)
-        HIPC(launch_init_user(d, b.d_uy, b.n_reset, is_reset ? 0 : 1, b.stream));      // an initial density of the model's own (d_uy is zero-filled)
-    else
+    if (b.cfg.model.model_id >= LLPF_MODEL_USER_BASE && (jit_model_traits(b.cfg.model.model_id) & LLPF_TRAIT_INITIAL) > 0) {
+        // an initial density of the model's own: prepare() sees u = 0 — whatever the single-step verbs staged in d_uy last (a reset! after
+        // predict!/correct! must equal the reset! of a fresh handle)
+        HIPC(hipMemsetAsync(b.d_uy, 0, sizeof(double) * 4 * MAXD, b.stream));
+        HIPC(launch_init_user(d, b.d_uy, b.n_reset, is_reset ? 0 : 1, b.stream));
+    } else
         HIPC(launch_init(d, b.n_reset, is_reset ? 0 : 1, b.stream));
     if (is_rbfull(b)) HIPC(launch_rbfull_init(d, b.stream));
     b.n_reset++;
@@ -405,7 +408,7 @@ static int bank_set_models(Bank& b, const llpf_model* models) {
             return fail(LLPF_ERR_ARG, "set_model: LLPF_MODEL_RB_BILINEAR must keep rb.nxl and rb.fn_kind");
         if (m0.model_id == LLPF_MODEL_RB_LINEAR && mf.nxn != m0.nxn) return fail(LLPF_ERR_ARG, "set_model: LLPF_MODEL_RB_LINEAR must keep nxn");
         const int rc = model_prepare(&mf, &hm[f]);
-        if (rc) return fail(LLPF_ERR_ARG, "invalid density (covariance not positive definite or dimension mismatch), code " + std::to_string(rc));
+        if (rc) return fail(LLPF_ERR_ARG, "invalid density (covariance not positive definite or dimension mismatch), code " + std::to_string(rc) + ", in filter " + std::to_string(f));
     }
     if (mm[0].Ts != m0.Ts) {          // the time of a step rides in launch arguments: captured run loops are of no use any more
         for (auto& g : b.graphs) if (g.exec) hipGraphExecDestroy(g.exec);

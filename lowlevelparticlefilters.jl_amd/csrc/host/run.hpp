@@ -288,7 +288,7 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
         key.T = T; key.t_index0 = t_index0; key.par0 = par0; key.cur0 = cur0; key.qcur0 = qcur0;
         key.flags = (merged ? 1 : 0) | (unfused ? 2 : 0) | (want_xm ? 4 : 0) | (ll_steps ? 8 : 0) | (xm_launch ? 16 : 0) | (multi ? 32 : 0) | (source_fx ? 64 : 0) | (xcov ? 128 : 0) | ((abl_env ? atoi(abl_env) : 0) << 8);      // (no_bound is a property of the model id, which a handle keeps)
         key.np_parity = (int)(np0 & 1u);
-        key.dU = b.d_U; key.dY = b.d_Y; key.dll = ll_steps ? b.d_ll_steps : nullptr; key.dxm = xmean ? b.d_xmean : (xcov ? b.d_xcov : nullptr); key.drb = b.d_rbseq;
+        key.dU = b.d_U; key.dY = b.d_Y; key.dll = ll_steps ? b.d_ll_steps : nullptr; key.dxm = xmean ? b.d_xmean : nullptr; key.dxc = xcov ? b.d_xcov : nullptr; key.drb = b.d_rbseq;
         key.yhash = 1469598103934665603ULL;
         for (int64_t k = 0; k < T; ++k) key.yhash = (key.yhash ^ (uint64_t)(has_y(k) ? 1 : 2)) * 1099511628211ULL;
         // a run shape is captured the second time it is seen (capture + instantiation of ~T nodes costs several ms:

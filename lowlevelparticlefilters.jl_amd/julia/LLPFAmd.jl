@@ -760,7 +760,6 @@ function GPUFilterBank(N::Integer, dynamics::Vector, measurement, dfs::Vector, d
     finalizer(x -> ccall((:llpf_bank_destroy, LIB), Cint, (Ptr{Cvoid},), x.h), b)
     b
 end
-"log-likelihood of every filter of the bank on shared data u, y (vectors of vectors)"
 """
     set_parameters!(bank, dynamics::Vector, measurement, dfs::Vector, dg, d0; Ts = 1.0)
 
@@ -774,7 +773,7 @@ function set_parameters!(b::GPUFilterBank, dynamics::Vector, measurement, dfs::V
     check(ccall((:llpf_bank_set_models, LIB), Cint, (Ptr{Cvoid}, Ptr{CModel}), b.h, cms))
     b
 end
-
+"log-likelihood of every filter of the bank on shared data u, y (vectors of vectors)"
 function loglik(b::GPUFilterBank, u, y)
     T = length(y)
     U = rows(u, b.nu)
@@ -838,14 +837,14 @@ function mbank_unique_id()
     check(ccall((:llpf_mbank_unique_id, LIB), Cint, (Ptr{UInt8},), id))
     id
 end
-"log-likelihood of every filter of the sweep (all-reduced: the same vector in every process); `sum(ll)` is the global log-likelihood"
+"set_parameters! for a sweep sharded over GPUs (`llpf_mbank_set_models`): same contract as for a `GPUFilterBank`"
 function set_parameters!(b::GPUMultiBank, dynamics::Vector, measurement, dfs::Vector, dg, d0; Ts = 1.0)
     cms = bank_models(dynamics, measurement, dfs, dg, d0, Ts)
     length(cms) == b.F || throw(ArgumentError("set_parameters!: $(length(cms)) models for a sweep of $(b.F) filters"))
     check(ccall((:llpf_mbank_set_models, LIB), Cint, (Ptr{Cvoid}, Ptr{CModel}), b.h, cms))
     b
 end
-
+"log-likelihood of every filter of the sweep (all-reduced: the same vector in every process); `sum(ll)` is the global log-likelihood"
 function loglik(b::GPUMultiBank, u, y)
     T = length(y)
     U = rows(u, b.nu)

@@ -38,3 +38,22 @@ def test_single_rank_spawn_check():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--spawn-check"], env=_env(), capture_output=True, text=True, timeout=120)
     r = json.loads(out.stdout.strip().splitlines()[-1])
     assert r["n_gpus"] == 1 and r["ranks_seen"] == [0]
+
+
+def test_require_rccl_refuses_the_gloo_exchange():
+    """--require-rccl: a scaling line must come from the in-library RCCL all-reduce with all N ranks seen.  In gloo mode (ranks share
+    devices, the exchange goes through torch.distributed) the flag makes the run exit non-zero and say why; without it the same
+    command succeeds.  (The decision function is the one main_bank applies to the real line.)"""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--spawn-check", "--dist-backend", "gloo"]
+    ok = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=300)
+    assert ok.returncode == 0, ok.stderr[-2000:]
+    bad = subprocess.run(cmd + ["--require-rccl"], env=_env(), capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "not the in-library RCCL all-reduce" in bad.stderr, bad.stderr[-2000:]
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.rccl_requirement_failure(bench.RCCL_COLLECTIVE, [0, 1, 2, 3], 4) is None
+    assert "ranks seen" in bench.rccl_requirement_failure(bench.RCCL_COLLECTIVE, [0, 1, 3], 4)
+    assert bench.rccl_requirement_failure("torch.distributed all_reduce (gloo) ...; in-library communicator failed: x", [0, 1], 2) is not None
+    assert bench.rccl_requirement_failure("none (one shard)", [0], 1) is None
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'out["scaling_efficiency"]' in src and 'out["require_rccl"]' in src

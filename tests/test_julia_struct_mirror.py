@@ -193,7 +193,13 @@ def test_julia_sources_are_block_balanced(tmp_path):
     for name in ("LLPFAmd.jl", "make_reference_fixtures.jl"):
         path = os.path.join(jdir, name)
         assert jb.check(path) == [], (name, jb.check(path)[:5])
+        assert jb.doc_problems(path) == [], (name, jb.doc_problems(path)[:5])
         lines = open(path, encoding="utf-8").read().split("\n")
+        # a docstring pushed away from its function by a second one (the file would not load: round-4 advisor finding) must be noticed
+        k = next(i for i, l in enumerate(lines) if l.startswith('"') and l.rstrip().endswith('"') and i + 1 < len(lines) and lines[i + 1].startswith("function ")) if name == "LLPFAmd.jl" else 0
+        p2 = tmp_path / ("mut_doc_" + name)
+        p2.write_text("\n".join(lines[:k + 1] + ['"""', "    other(x)", "", "another docstring", '"""'] + lines[k + 1:]), encoding="utf-8")
+        assert jb.doc_problems(str(p2)) or name != "LLPFAmd.jl", name
         ends = [i for i, l in enumerate(lines) if l.strip() == "end"]
         for mutate in ("drop", "add", "bracket"):
             m = list(lines)

@@ -145,9 +145,9 @@ def test_host_function_of_the_python_mirror():
     we /= we.sum(axis=1, keepdims=True)
     q = [0.05, 0.5, 0.95]
     out = llpf_amd.weighted_quantile(x, we, q)
-    assert len(out) == T and out[0].shape == (3, nx)
+    assert len(out) == T and out[0].shape == (nx, 3)              # the reference's nesting: [t][state][q] (src/filtering.jl:592-594)
     for t in range(T):
         for d in range(nx):
-            np.testing.assert_allclose(out[t][:, d], ob.weighted_quantile(x[t, :, d], we[t], q), rtol=1e-10, atol=1e-12)
+            np.testing.assert_allclose(out[t][d], ob.weighted_quantile(x[t, :, d], we[t], q), rtol=1e-10, atol=1e-12)
     med = llpf_amd.weighted_quantile(x, we, 0.5)
-    np.testing.assert_allclose(med[1], out[1][1], rtol=0, atol=0)
+    np.testing.assert_allclose(med[1], out[1][:, 1], rtol=0, atol=0)
