@@ -117,8 +117,14 @@ LLPF_HD double llpf_exp_core(double xc) {      /* xc in [-746, 709.78] or NaN */
      * but must not trap: the conversion below is done on a clamped copy) */
     double kc = kf == kf ? kf : 0.0;
     int k = (int)kc;
+#if defined(__HIP_DEVICE_COMPILE__) && defined(LLPF_EXP_LDEXP)
+    /* experiment (EXPERIMENTS 5.x): v_ldexp_f64 scales in one instruction and rounds a subnormal result once, like the two exact
+     * steps below — bit-identity with the host is checked by the host-vs-device test of the shared math */
+    return __builtin_amdgcn_ldexp(y, k);
+#else
     int k1 = k / 2, k2 = k - k1;
     return (y * llpf_pow2i(k1)) * llpf_pow2i(k2);
+#endif
 }
 
 LLPF_HD double llpf_exp(double x) {

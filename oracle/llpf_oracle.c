@@ -1914,6 +1914,12 @@ void orc_philox_block(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32
     llpf_philox4 r = llpf_philox4x32_10(c0, c1, c2, c3, k0, k1);
     for (int i = 0; i < 4; ++i) out4[i] = r.v[i];
 }
+/* the generator the engine's draws actually go through (LLPF_PHILOX_ROUNDS rounds: 7 since round 4); returns the round count */
+int orc_philox_block_engine(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out4) {
+    llpf_philox4 r = llpf_philox4x32(c0, c1, c2, c3, k0, k1);
+    for (int i = 0; i < 4; ++i) out4[i] = r.v[i];
+    return LLPF_PHILOX_ROUNDS;
+}
 void orc_normals(uint64_t seed, uint32_t step, uint32_t stream, int nd, double* out, int64_t n) {
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     for (int64_t i = 0; i < n; ++i) llpf_normals((uint32_t)i, step, stream, k0, k1, nd, out + i * nd);

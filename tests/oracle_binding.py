@@ -97,6 +97,8 @@ def load():
     lib.orc_pairwise_sum.argtypes = [_dp, C.c_int64]
     lib.orc_math_vec.argtypes = [C.c_int, _dp, _dp, C.c_int64]
     lib.orc_philox_block.argtypes = [C.c_uint32] * 6 + [C.POINTER(C.c_uint32)]
+    lib.orc_philox_block_engine.argtypes = [C.c_uint32] * 6 + [C.POINTER(C.c_uint32)]
+    lib.orc_philox_block_engine.restype = C.c_int
     lib.orc_normals.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, _dp, C.c_int64]
     lib.orc_uniforms_nd.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, _dp, C.c_int64]
     lib.orc_fix96.argtypes = [C.c_double, C.POINTER(C.c_uint64)]

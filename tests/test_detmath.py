@@ -95,6 +95,40 @@ def test_philox_known_answers():
         [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
 
 
+def test_philox_known_answers_of_the_shipped_generator():
+    """The generator every draw of the engine goes through is Philox4x32 stopped after LLPF_PHILOX_ROUNDS rounds (7 since round 4).
+    Random123's kat_vectors hold known answers for that instance too ("philox4x32 7 ..."): the same three inputs as the 10-round test.
+    (The expected words were cross-checked with a literal Python evaluation of the published round function, which shares nothing
+    with the C header.)"""
+    L = ob.lib()
+
+    def ph(c, k):
+        out = (C.c_uint32 * 4)()
+        rounds = L.orc_philox_block_engine(c[0], c[1], c[2], c[3], k[0], k[1], out)
+        return rounds, [x for x in out]
+    kat = {7: ([0x5f6fb709, 0x0d893f64, 0x4f121f81, 0x4f730a48], [0x5207ddc2, 0x45165e59, 0x4d8ee751, 0x8c52f662],
+               [0x4dfccaba, 0x190a87f0, 0xc47362ba, 0xb6b5242a]),
+           10: ([0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8], [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd],
+                [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1])}
+    rounds, a = ph([0] * 4, [0] * 2)
+    assert rounds in kat, "no Random123 vector for a %d-round build" % rounds
+    assert a == kat[rounds][0]
+    assert ph([0xffffffff] * 4, [0xffffffff] * 2)[1] == kat[rounds][1]
+    assert ph([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0])[1] == kat[rounds][2]
+
+    def py_philox(c, k, R):            # the published round function, literally
+        c, k = list(c), list(k)
+        for _ in range(R):
+            p0, p1 = 0xD2511F53 * c[0], 0xCD9E8D57 * c[2]
+            c = [(p1 >> 32) ^ c[1] ^ k[0], p1 & 0xffffffff, (p0 >> 32) ^ c[3] ^ k[1], p0 & 0xffffffff]
+            k = [(k[0] + 0x9E3779B9) & 0xffffffff, (k[1] + 0xBB67AE85) & 0xffffffff]
+        return c
+    rng = np.random.default_rng(5)
+    for _ in range(200):
+        c, k = [int(v) for v in rng.integers(0, 2 ** 32, 4)], [int(v) for v in rng.integers(0, 2 ** 32, 2)]
+        assert ph(c, k)[1] == py_philox(c, k, rounds)
+
+
 def test_normals_are_standard_normal():
     from scipy import stats
     z = ob.normals(2024, 3, 1, 4, 500000)

@@ -1029,3 +1029,28 @@ def test_weighted_cov_on_the_device():
     np.testing.assert_allclose(g.weighted_cov(), ref_cov(g.particles(), g.expweights()), rtol=1e-11, atol=1e-15)
     c1 = g.weighted_cov()
     assert np.array_equal(c1, g.weighted_cov()) and np.array_equal(c1, c1.T)         # fixed order: the same bits again
+
+
+def test_run_graphs_with_mean_and_covariance_outputs_survive_a_growing_run_length():
+    """Round-4 advisor finding: the captured run loop was keyed on the xmean buffer only; a later, longer run reallocates the xcov buffer
+    while the others keep their addresses, and the short run's graph then replayed launches against the freed pointer.  Short runs
+    (captured the second time), a long run, the short run again: the same outputs every time."""
+    model = M.lg_test_model()
+    _, U, Y = M.simulate_lg(model, 400)
+    cfg = S.make_config(model, 3000, S.PARTICLE_FILTER, S.RESAMPLE_SYSTEMATIC, 0.5, 33, 0)
+    g = _capi.FilterHandle(cfg)
+    g.seed(5); g.reset()
+    first = g.run(U[:400], Y[:400], 0.0, xmean=True)             # xmean (and U, Y, ll) buffers sized for the longest run up front
+    short = []
+    for _ in range(3):
+        g.seed(5); g.reset()
+        short.append(g.run(U[:20], Y[:20], 0.0, xmean=True, xcov=True))
+    g.seed(5); g.reset()
+    long_ = g.run(U[:400], Y[:400], 0.0, xmean=True, xcov=True)   # xcov grows: 20 -> 400 steps
+    g.seed(5); g.reset()
+    again = g.run(U[:20], Y[:20], 0.0, xmean=True, xcov=True)
+    for r in short[1:] + [again]:
+        assert np.array_equal(r["xcov"].view(np.uint64), short[0]["xcov"].view(np.uint64))
+        assert np.array_equal(r["xmean"].view(np.uint64), short[0]["xmean"].view(np.uint64))
+    assert np.array_equal(long_["xmean"].view(np.uint64), first["xmean"].view(np.uint64))
+    assert np.array_equal(long_["xcov"][:20].view(np.uint64), short[0]["xcov"].view(np.uint64)) and np.all(np.isfinite(long_["xcov"]))

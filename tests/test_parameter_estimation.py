@@ -197,3 +197,36 @@ def test_log_likelihood_fun_and_metropolis_on_the_engine():
     assert out.shape == (10 * n_chains, 3) and np.all(np.isfinite(out))
     # a chain's first retained state has the likelihood its own parameters give in a one-filter evaluation of the same bank slot
     assert np.all(out[:, 2] < 0)
+
+
+@pytest.mark.gpu
+def test_metropolis_bank_isolates_a_failing_chain():
+    """The reference wraps every chain's loglik in try / catch and scores -Inf for that chain only (src/smoothing.jl:276-280), so
+    metropolis_threaded keeps sampling when ONE proposal cannot be built (covariance not positive definite) or degenerates the filter
+    (all weights -Inf).  One bank run serves all chains here, so the failing slot is retried on its chain's current parameters and the
+    chain scores -inf alone (round-4 advisor finding: the exception used to abort every chain)."""
+    A = np.array([[0.97043, -0.097368], [0.09736, 0.970437]]); B = np.array([[0.1], [0.0]]); Cm = np.array([[0.0, 1.0]])
+    d0 = llpf_amd.MvNormal(np.array([0.3, -0.5]), 4.0)
+    dyn, meas = llpf_amd.LinearDynamics(A, B), llpf_amd.LinearMeasurement(Cm)
+    truth = llpf_amd.ParticleFilter(1000, dyn, meas, llpf_amd.MvNormal(np.zeros(2), 0.01), llpf_amd.MvNormal(np.zeros(1), 1.0), d0, rng=1)
+    _, u, y = llpf_amd.simulate(truth, 40, llpf_amd.MvNormal(np.zeros(1), 1.0), rng=np.random.default_rng(3))
+    spec = lambda th: (dyn, meas, llpf_amd.MvNormal(np.zeros(2), float(np.exp(2 * th[0]))), llpf_amd.MvNormal(np.zeros(1), float(np.exp(2 * th[1]))), d0)
+    priors = [_Normal(np.log(0.1), 1000.0), _Normal(0.0, 1000.0)]      # wide: the wild proposals below stay inside the support
+    n_chains = 4
+    th0 = np.tile(np.log([0.3, 0.5]), (n_chains, 1))
+    bank = llpf_amd.FilterBank(1000, [spec(t) for t in th0], resample_threshold=0.1, rng=1)
+    it = {"i": 0}
+
+    def draw(th):
+        k, i = it["i"] % n_chains, it["i"] // n_chains
+        it["i"] += 1
+        if i == 1 and k == 1:
+            return np.array([th[0], -400.0])        # measurement variance exp(-800) = 0: the density cannot be built
+        if i == 2 and k == 2:
+            return np.array([th[0], 400.0])         # variance +Inf: every weight -Inf (or the density is refused): the filter degenerates
+        return th + 0.05 * np.array([np.sin(it["i"]), np.cos(it["i"])])
+    out = llpf_amd.metropolis_bank(bank, spec, priors, u, y, 6, th0, draw=draw, burnin=0, rng=np.random.default_rng(9))
+    assert out.shape == (6 * n_chains, 3) and np.all(np.isfinite(out))       # the bad proposals were rejected, every chain went on
+    ch = out.reshape(n_chains, 6, 3)
+    assert np.all(np.abs(ch[1, :, 1]) < 10) and np.all(np.abs(ch[2, :, 1]) < 10)      # chains 1 and 2 never accepted the wild values
+    assert len({tuple(r) for r in ch[0, :, :2]}) > 1                                   # and the healthy chains kept moving

@@ -294,3 +294,32 @@ def test_user_noise_through_the_filter_objects():
     with pytest.raises(TypeError):      # a snippet with `loglik` paired with a Gaussian likelihood (advisor finding, round 3)
         d2 = llpf_amd.UserDynamics(UM.LAPLACE_SRC, 2, 1, 1, A=A, B=B, C=Cm, qt=[0.8])
         llpf_amd.AdvancedParticleFilter(100, d2, llpf_amd.UserMeasurement(), llpf_amd.GaussianLikelihood(llpf_amd.UserMeasurement(), dg), df, df)
+
+
+@pytest.mark.gpu
+def test_reset_after_single_steps_sees_the_same_input_as_a_fresh_handle():
+    """An initial density whose prepare() reads u (here: the box is shifted by u[0]).  reset! evaluates it with u = 0 — also after the
+    single-step verbs have staged a non-zero u in the handle's scratch (round-4 advisor finding: llpf_reset used that scratch as if
+    it were still zero-filled)."""
+    import independent_cases as IC
+    case = IC.cases()["pf_lg_mult_noise_box"]
+    src = UM.MULT_NOISE_BOX_SRC.replace("out[d] = lo[d] + (hi[d] - lo[d]) * uu[d];", "out[d] = (lo[d] + ushift) + (hi[d] - lo[d]) * uu[d];") \
+                               .replace("double s0, s1, lo[NXU], hi[NXU];", "double s0, s1, lo[NXU], hi[NXU], ushift;") \
+                               .replace("s0 = m->qt[0]; s1 = m->qt[1];", "s0 = m->qt[0]; s1 = m->qt[1]; ushift = 100.0 * u[0];")
+    assert "ushift" in src
+    kind, par, _, qt = case["user"]
+    m = S.Model.from_buffer_copy(bytes(case["model"]))
+    m.model_id = _capi.model_compile(src, m.nx, m.ny)
+    for i, v in enumerate(qt):
+        m.qt[i] = v
+    cfg = S.make_config(m, case["N"], case["kind"], case["strategy"], case["thr"], IC.SEED, 0)
+    a, b = _capi.FilterHandle(cfg), _capi.FilterHandle(cfg)
+    a.reset(); b.reset()
+    x_fresh = b.particles()
+    assert np.array_equal(a.particles().view(np.uint64), x_fresh.view(np.uint64)) and np.all(x_fresh < 10.0)      # u = 0: the unshifted box
+    U, Y = case["U"], case["Y"]
+    u = np.array(U[0], dtype=np.float64).copy(); u[0] = 0.7
+    a.correct(u, Y[0], 0.0); a.predict(u, 0.0)
+    a.reset(); b.reset()            # second reset! of both handles: same counters, and for `a` a scratch that held u = 0.7
+    assert np.array_equal(a.particles().view(np.uint64), b.particles().view(np.uint64))
+    assert np.all(a.particles() < 10.0)
