@@ -58,7 +58,7 @@ static void launch_norm_e2(const BankDev& b, int parity, int need_e2, uint32_t s
     else hipLaunchKernelGGL((k_norm<NX, XMEAN, false>), g, dim3(BLOCK), 0, s, b, K, parity, step, only_fallback, bound, kstep);
 }
 #ifndef LLPF_NORM_WAVE_TILE
-#define LLPF_NORM_WAVE_TILE 1
+#define LLPF_NORM_WAVE_TILE 0
 #endif
 hipError_t launch_norm(const BankDev& b, int parity, int want_xmean, int need_e2, uint32_t step, int only_fallback, int bound, int64_t kstep, hipStream_t s) {
     static const char* wt_env = getenv("LLPF_NORM_WAVE_TILE");

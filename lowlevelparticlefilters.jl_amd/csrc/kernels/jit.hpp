@@ -288,7 +288,9 @@ hipError_t launch_rbfull_jit(int fk, int nn, int nl, int ny, const BankDev& b, i
     }
     BankDev bd = b;
     StepArgs aa = a;
+    const RbfullShape sh = rbfull_launch_shape(b, nl, mode);
+    aa.rbf_tail = (int32_t)sh.tail;
     // LLPF_RBF_HOT_PARAMS (kernels/rbfull.hpp), then the two structs
     void* args[] = {&bd.scal, &bd.bank_flag, &bd.anc, &bd.models, &aa.u, &bd.Ns, &bd.nu, &aa.u_stride, &aa.y, &bd, &aa};
-    return hipModuleLaunchKernel(fn, rbfull_grid_x(b, nl, mode), (unsigned)b.F, 1, 64, 1, 1, 0, s, args, nullptr);
+    return hipModuleLaunchKernel(fn, sh.grid_x, (unsigned)b.F, 1, sh.block, 1, 1, 0, s, args, nullptr);
 }

@@ -1052,5 +1052,7 @@ def test_run_graphs_with_mean_and_covariance_outputs_survive_a_growing_run_lengt
     for r in short[1:] + [again]:
         assert np.array_equal(r["xcov"].view(np.uint64), short[0]["xcov"].view(np.uint64))
         assert np.array_equal(r["xmean"].view(np.uint64), short[0]["xmean"].view(np.uint64))
-    assert np.array_equal(long_["xmean"].view(np.uint64), first["xmean"].view(np.uint64))
+    # (with the covariance requested the mean comes from the launch that also feeds it: another fixed summation order than the
+    # partial sums of the weighting kernel — equal to rounding, not to the bit)
+    np.testing.assert_allclose(long_["xmean"], first["xmean"], rtol=1e-12, atol=1e-14)
     assert np.array_equal(long_["xcov"][:20].view(np.uint64), short[0]["xcov"].view(np.uint64)) and np.all(np.isfinite(long_["xcov"]))
