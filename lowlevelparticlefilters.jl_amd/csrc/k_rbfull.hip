@@ -8,7 +8,10 @@
 #if defined(LLPF_RBF_TIMING)
 __device__ unsigned long long* g_rbf_dbg;
 #if defined(__HIP_DEVICE_COMPILE__)
-__shared__ unsigned int g_rbf_row;      // the batch a persistent wave has in hand: the row its stamps go to
+__shared__ unsigned int g_rbf_rows[4];  // the batch a persistent wave has in hand: the row its stamps go to (one entry per wave of the workgroup)
+#define g_rbf_row g_rbf_rows[threadIdx.x >> 6]
+// the shared tail batches (kernels/rbfull.hpp): stamps of the nonlinear wave, which passes every barrier as soon as the Kalman waves reach it
+#define RBF_TAILSTAMP(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)); g_rbf_dbg[(size_t)(nfull + tj) * 32 + (k)] = t_; } while (0)
 #endif
 #endif
 #include <atomic>

@@ -26,8 +26,10 @@ DEV void rbf_model_ready(const M& m, uint32_t& dep) {
 
 #if defined(LLPF_RBF_TIMING) && defined(__HIP_DEVICE_COMPILE__)
 #define RBF_TSTAMP(k, dep) do { asm volatile("" : : "v"(dep)); RBF_STAMP(k); } while (0)
+#define RBF_TAILSTAMP_DEP(k, dep) do { asm volatile("" : : "v"(dep)); RBF_TAILSTAMP(k); } while (0)
 #else
 #define RBF_TSTAMP(k, dep) ((void)0)
+#define RBF_TAILSTAMP_DEP(k, dep) ((void)0)
 #endif
 // element idx of an array through a 32-bit byte offset from its (uniform) base: one address register, saddr + voffset addressing
 DEV double* rbf_at(double* base, uint32_t idx) { return reinterpret_cast<double*>(reinterpret_cast<char*>(base) + (size_t)(idx * 8u)); }
@@ -403,12 +405,20 @@ __global__ __launch_bounds__(RBF_BLOCK * rbf_wpg(NL, MODE)) __attribute__((amdgp
                 double twN = 0.0;
                 if (need_w) twN = *rbf_at(w, ti);
                 double xi[NN], tnz[NN], tfi[NN], tax[NN], txn1[NN];
+#if defined(LLPF_RBF_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+                { uint32_t hw_, xcc_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));
+                  g_rbf_dbg[(size_t)(nfull + tj) * 32 + 13] = hw_; g_rbf_dbg[(size_t)(nfull + tj) * 32 + 14] = xcc_; }
+#endif
+                RBF_TAILSTAMP_DEP(0, t);
+                RBF_TAILSTAMP_DEP(1, txl[NL - 1]);
                 Model mdl = prepared(ti);
                 llpf_normals_tab(ti, sb + a.step, LLPF_STREAM_DYNAMICS, k0, k1, NN, xi, sh_rng_lg, sh_rng_sc);
                 gauss_sample_c<NN>((gauss_cptr)&md->df, xi, tnz);
 #pragma unroll
                 for (int d = 0; d < NN; ++d) xb[(LLPF_RBC_XNZ + d) * 64 + t] = tnz[d];
+                RBF_TAILSTAMP_DEP(2, tnz[NN - 1]);
                 __syncthreads();                               // 1
+                RBF_TAILSTAMP_DEP(3, t);
                 {
                     llpf_rbf_cptr pp = RBF_KCPTR(par);
 #pragma unroll
@@ -423,7 +433,9 @@ __global__ __launch_bounds__(RBF_BLOCK * rbf_wpg(NL, MODE)) __attribute__((amdgp
                         for (int c = 1; c < NL; ++c) tax[r] = llpf_fma(arow[c], txl[c], tax[r]);
                     }
                 }
+                RBF_TAILSTAMP_DEP(4, tax[NN - 1]);
                 mdl.dynamics(txn, tfi);
+                RBF_TAILSTAMP_DEP(5, tfi[NN - 1]);
 #pragma unroll
                 for (int d = 0; d < NN; ++d) { const double z = tax[d] + tnz[d]; txn1[d] = tfi[d] + z; }      // llpf_rbf_predict: z = An xl + nz ; xn1 = fi + z
                 if (has_corr) {
@@ -433,11 +445,15 @@ __global__ __launch_bounds__(RBF_BLOCK * rbf_wpg(NL, MODE)) __attribute__((amdgp
                     for (int q = 0; q < NY; ++q) xs[(LLPF_RBC_SYN + q) * 64 + t] = yn[q];
                 }
                 __syncthreads();                               // 2
+                RBF_TAILSTAMP_DEP(6, t);
                 __syncthreads();                               // 3
+                RBF_TAILSTAMP_DEP(7, t);
                 double tll = 0.0;
                 if (has_corr) {
                     __syncthreads();                           // 4
+                    RBF_TAILSTAMP_DEP(8, t);
                     __syncthreads();                           // 5
+                    RBF_TAILSTAMP_DEP(9, t);
                     tll = xs[LLPF_RBC_SLL * 64 + t];
                 }
 #pragma unroll
@@ -470,6 +486,7 @@ __global__ __launch_bounds__(RBF_BLOCK * rbf_wpg(NL, MODE)) __attribute__((amdgp
                         acc_max(b.acc + (size_t)f * ACC_WORDS, a.parity, r, anybad != 0);
                     }
                 }
+                RBF_TAILSTAMP_DEP(10, t);
             } else {
                 // a Kalman wave: the columns c = k (mod 3) of the covariance — requested as full columns (the mirrored entries from their twins' planes)
                 const int kk = wvi - 1;

@@ -3,7 +3,7 @@
 # produced by this repository's own restatements (Julia is not in the build image, so the file is checked statically only —
 # tests/test_julia_struct_mirror.py — and tests/test_reference_fixtures.py skips, loudly, while the fixtures are absent).
 #
-#   1. python tests/golden/make_reference_inputs.py                      (already run: tests/golden/ref_inputs_{lg,quadtank}.npz are committed)
+#   1. python tests/golden/make_reference_inputs.py                      (already run: tests/golden/ref_inputs_<case>.npz are committed)
 #   2. julia --project=<env with LowLevelParticleFilters (v3.31), Distributions, StaticArrays, NPZ> \
 #          lowlevelparticlefilters.jl_amd/julia/make_reference_fixtures.jl <repo root>
 #   3. python -m pytest tests/test_reference_fixtures.py                 (CPU: both oracle orders; -m gpu: the engine)
@@ -16,6 +16,13 @@
 # tape.  Before every timestep the tapes are positioned at that step's draws (the engine indexes its Philox streams by (particle, step):
 # a step that does not resample simply leaves its uniform unused).  The loop is forward_trajectory's own (src/filtering.jl:343-365):
 # reset!, then per step correct! -> record -> predict!, with the reference's verbs and nothing else.
+#
+# Cases (round 5: one Julia session pins the whole path).  lg / lg_thr1: ParticleFilter, systematic resampling (src/resample.jl:17-36),
+# one missing measurement (src/PFtypes.jl:109), threshold 0.5 / 1.0;  lg_stratified (:38-61: one rand() per output);  lg_residual
+# (:63-117: the engine indexes the uniform of the multinomial part by OUTPUT, so the tape is positioned behind the deterministic
+# copies before every predict!);  quadtank: AdvancedParticleFilter through the reference's rk4;  aux_lg: AuxiliaryParticleFilter
+# (src/filtering.jl:170-217, the loop of :367-384: predict!(pf, u[t], y[t+1]) for t < T);  rbpf: RBPF with a state-dependent coupling
+# An(xn) — singleR off, one Kalman filter per particle (src/rbpf.jl:163-283).
 using LowLevelParticleFilters, Distributions, StaticArrays, LinearAlgebra, Random, NPZ
 import LowLevelParticleFilters: reset!, correct!, predict!, particles, weights, expweights, state
 
@@ -38,80 +45,145 @@ Random.default_rng() = REPLAY            # the global `rand()` of resample (src/
 # row i of a [N, nx] table in the order the reference consumes it: particle 1's nx normals, particle 2's, ...
 tape(a::AbstractMatrix) = vec(permutedims(a))
 
-function run_case(name, root)
-    d = npzread(joinpath(root, "tests", "golden", "ref_inputs_$name.npz"))
-    N, T, nx, nu, ny = Int(d["N"]), Int(d["T"]), Int(d["nx"]), Int(d["nu"]), Int(d["ny"])
-    Ts, thr, t_index0 = Float64(d["Ts"]), Float64(d["thr"]), Float64(d["t_index0"])
-    U, Y = d["U"], d["Y"]
+strategy_type(code) = (ResampleSystematic, ResampleStratified, ResampleResidual)[Int(code)+1]      # include/llpf.h: LLPF_RESAMPLE_*
+
+# number of outputs the residual resampler fills deterministically (src/resample.jl:66-84, the same arithmetic): where its rand() calls start
+function residual_copies(we)
+    N = length(we)
+    wsum = zero(eltype(we))
+    for i = 1:N
+        wsum += we[i]
+    end
+    inv_wsum = 1 / wsum
+    num = 0
+    for i = 1:N
+        num += floor(Int, we[i] * inv_wsum * N)
+    end
+    num
+end
+
+# examples/example_quadtank.jl:8-27
+function quadtank(h, u, p, t)
+    k1, k2, g = 1.6, 1.6, 9.81
+    A1 = A3 = A2 = A4 = 4.9
+    a1, a3, a2, a4 = 0.03, 0.03, 0.03, 0.03
+    γ1, γ2 = 0.2, 0.2
+    if t > 500
+        a1 *= 2
+    end
+    ssqrt(x) = √(max(x, zero(x)) + 1e-3)
+    SA[-a1/A1 * ssqrt(2g*h[1]) + a3/A1*ssqrt(2g*h[3]) +     γ1*k1/A1 * u[1]
+       -a2/A2 * ssqrt(2g*h[2]) + a4/A2*ssqrt(2g*h[4]) +     γ2*k2/A2 * u[2]
+       -a3/A3*ssqrt(2g*h[3])                          + (1-γ2)*k2/A3 * u[2]
+       -a4/A4*ssqrt(2g*h[4])                          + (1-γ1)*k1/A4 * u[1]]
+end
+
+function build_filter(family, d)
+    N, nx, nu, ny = Int(d["N"]), Int(d["nx"]), Int(d["nu"]), Int(d["ny"])
+    Ts, thr = Float64(d["Ts"]), Float64(d["thr"])
     df = MvNormal(vec(d["df_mu"]), Matrix(d["df_cov"]))
     dg = MvNormal(vec(d["dg_mu"]), Matrix(d["dg_cov"]))
     d0 = MvNormal(vec(d["d0_mu"]), Matrix(d["d0_cov"]))
-    if name == "lg"
+    strategy = strategy_type(d["strategy"])
+    if family == "pf" || family == "aux"
         A, B, C = SMatrix{nx,nx}(d["A"]), SMatrix{nx,nu}(d["B"]), SMatrix{ny,nx}(d["C"])
         dynamics(x, u, p, t) = A * x + B * u                          # examples/example_lineargaussian.jl:28
         measurement(x, u, p, t) = C * x                               # :29
-        pf = ParticleFilter(N, dynamics, measurement, df, dg, d0; resample_threshold = thr, rng = REPLAY, Ts = Ts)
-    else
-        # examples/example_quadtank.jl:8-35, discretised with the reference's own rk4 (src/utils.jl:220-237), supersample = 2
-        function quadtank(h, u, p, t)
-            k1, k2, g = 1.6, 1.6, 9.81
-            A1 = A3 = A2 = A4 = 4.9
-            a1, a3, a2, a4 = 0.03, 0.03, 0.03, 0.03
-            γ1, γ2 = 0.2, 0.2
-            if t > 500
-                a1 *= 2
-            end
-            ssqrt(x) = √(max(x, zero(x)) + 1e-3)
-            SA[-a1/A1 * ssqrt(2g*h[1]) + a3/A1*ssqrt(2g*h[3]) +     γ1*k1/A1 * u[1]
-               -a2/A2 * ssqrt(2g*h[2]) + a4/A2*ssqrt(2g*h[4]) +     γ2*k2/A2 * u[2]
-               -a3/A3*ssqrt(2g*h[3])                          + (1-γ2)*k2/A3 * u[2]
-               -a4/A4*ssqrt(2g*h[4])                          + (1-γ1)*k1/A4 * u[1]]
-        end
+        pf = ParticleFilter(N, dynamics, measurement, df, dg, d0; resample_threshold = thr, resampling_strategy = strategy, rng = REPLAY, Ts = Ts)
+        return family == "aux" ? AuxiliaryParticleFilter(pf) : pf
+    elseif family == "apf"
+        # discretised with the reference's own rk4 (src/utils.jl:220-237), supersample = 2 (examples/example_quadtank.jl:35)
         step = LowLevelParticleFilters.rk4(quadtank, Ts; supersample = Int(d["supersample"]))
         # AdvancedParticleFilter: the dynamics adds its own noise when asked to (src/PFtypes.jl:254; test/runtests.jl:553-599)
         dynamics_apf(x, u, p, t, noise = false) = noise ? step(x, u, p, t) + SVector{4}(rand(REPLAY, df)) : step(x, u, p, t)
         measurement_apf(x, u, p, t, noise = false) = SA[x[1], x[2]]
         measurement_likelihood(x, u, y, p, t) = logpdf(dg, y - measurement_apf(x, u, p, t))
-        pf = AdvancedParticleFilter(N, dynamics_apf, measurement_apf, measurement_likelihood, df, d0; resample_threshold = thr, rng = REPLAY, Ts = Ts)
+        return AdvancedParticleFilter(N, dynamics_apf, measurement_apf, measurement_likelihood, df, d0; resample_threshold = thr, rng = REPLAY, Ts = Ts)
+    else
+        # RBPF (src/rbpf.jl:84-110): inner KalmanFilter (A, B, C, D, R1, R2, d0) for the linear substate, f_n and g for the nonlinear one, and a
+        # coupling that is a FUNCTION of the nonlinear state (get_mat(pf.An, xi.xn, u, p, t), :208) so that singleR (:176, :247) is off
+        nl = Int(d["nxl"])
+        Fn, Bn, Gn = SMatrix{nx,nx}(d["Fn"]), SMatrix{nx,nu}(d["Bn"]), SMatrix{ny,nx}(d["Gn"])
+        Al, Bl, Cl = SMatrix{nl,nl}(d["Al"]), SMatrix{nl,nu}(d["Bl"]), SMatrix{ny,nl}(d["Cl"])
+        AnT = d["An"]                                                 # [1 + nx, nx, nl]
+        An0 = SMatrix{nx,nl}(AnT[1, :, :])
+        Ank = [SMatrix{nx,nl}(AnT[1+k, :, :]) for k in 1:nx]
+        An(xn, u, p, t) = An0 + sum(xn[k] * Ank[k] for k in 1:nx)
+        f_n(xn, u, p, t) = Fn * xn + Bn * u
+        g_n(xn, u, p, t) = Gn * xn
+        R1l, R2 = SMatrix{nl,nl}(d["R1l"]), SMatrix{ny,ny}(d["dg_cov"])
+        d0l = LowLevelParticleFilters.SimpleMvNormal(SVector{nl}(vec(d["d0l_mu"])), SMatrix{nl,nl}(d["d0l_cov"]))
+        d0n = LowLevelParticleFilters.SimpleMvNormal(SVector{nx}(vec(d["d0_mu"])), SMatrix{nx,nx}(d["d0_cov"]))
+        R1n = LowLevelParticleFilters.SimpleMvNormal(SVector{nx}(vec(d["df_mu"])), SMatrix{nx,nx}(d["df_cov"]))
+        kf = KalmanFilter(Al, Bl, Cl, 0, R1l, R2, d0l)
+        mm = RBMeasurementModel(g_n, R2, ny)
+        names = SignalNames(x = ["x$i" for i in 1:nx+nl], u = ["u$i" for i in 1:nu], y = ["y$i" for i in 1:ny], name = "RBPF")
+        return RBPF(N, kf, f_n, mm, R1n, d0n; nu, An, Ts = Ts, names, rng = REPLAY, resample_threshold = thr)
     end
+end
+
+function run_case(name, root)
+    d = npzread(joinpath(root, "tests", "golden", "ref_inputs_$name.npz"))
+    family = String(UInt8.(d["family"]))
+    N, T, nx, nu, ny = Int(d["N"]), Int(d["T"]), Int(d["nx"]), Int(d["nu"]), Int(d["ny"])
+    Ts, t_index0 = Float64(d["Ts"]), Float64(d["t_index0"])
+    U, Y = d["U"], d["Y"]
+    residual = Int(d["strategy"]) == 2
+    nrec = family == "rbpf" ? nx + Int(d["nxl"]) : nx                 # an RBParticle indexes like [xn; xl] (src/rbpf.jl:24-30)
+    load_normals!(REPLAY, tape(d["xi_reset"]))
+    pf = build_filter(family, d)                                      # (the constructor draws too: from the tape just loaded, then reset! reloads it)
     p = LowLevelParticleFilters.parameters(pf)
     load_normals!(REPLAY, tape(d["xi_reset"]))
-    reset!(pf)                                                         # src/filtering.jl:4-14
+    reset!(pf)                                                         # src/filtering.jl:4-14, src/rbpf.jl:146-160
     ll_steps = zeros(T)
-    xh, wh, weh = zeros(T, N, nx), zeros(T, N), zeros(T, N)
+    xh, wh, weh = zeros(T, N, nrec), zeros(T, N), zeros(T, N)
     jh = zeros(Int64, T, N)
     resampled = zeros(Int64, T)
+    Rh = family == "rbpf" ? zeros(T, N, Int(d["nxl"]), Int(d["nxl"])) : zeros(0, 0, 0, 0)
     xi_dyn, u_res = d["xi_dyn"], d["u_res"]
+    yvec(k) = any(isnan, Y[k, :]) ? fill(missing, ny) : SVector{ny}(Y[k, :])
     for k in 1:T
         ti = (t_index0 + k - 1) * Ts
-        load_normals!(REPLAY, tape(xi_dyn[k, :, :]))                   # predict! number k-1: its N x nx normals ...
-        load_uniforms!(REPLAY, [u_res[k]])                             # ... and its systematic offset
+        load_normals!(REPLAY, tape(xi_dyn[k, :, :]))                   # predict! number k-1: its N x nd normals ...
+        load_uniforms!(REPLAY, ndims(u_res) == 1 ? [u_res[k]] : vec(u_res[k, :]))      # ... and its systematic offset / its per-output uniforms
         u = SVector{nu}(U[k, :])
-        y = any(isnan, Y[k, :]) ? fill(missing, ny) : SVector{ny}(Y[k, :])
-        ll, _ = correct!(pf, u, y, p, ti)                              # src/filtering.jl:164-168
+        ll, _ = correct!(pf, u, yvec(k), p, ti)                        # src/filtering.jl:164-168 (:170-174 for the auxiliary filter, src/rbpf.jl:231-283)
         ll_steps[k] = ll
         for i in 1:N                                                   # x[:,t] .= particles(pf); w[:,t] .= weights(pf); we[:,t] .= expweights(pf), :357-359
             xh[k, i, :] .= particles(pf)[i]
+            if family == "rbpf"
+                Rh[k, i, :, :] .= particles(pf)[i].R
+            end
         end
         wh[k, :] .= weights(pf)
         weh[k, :] .= expweights(pf)
+        if residual
+            REPLAY.upos = residual_copies(expweights(pf))              # the multinomial part's rand() number m reads the uniform of output m
+        end
         n_before = REPLAY.upos
-        predict!(pf, u, p, ti)                                         # src/filtering.jl:140-153
-        resampled[k] = REPLAY.upos - n_before                          # 1 iff this predict! drew its rand()
+        if family == "aux"
+            k < T && predict!(pf, u, yvec(k + 1), p, ti)               # src/filtering.jl:381: predict!(pf, u[t], y[t+1], p, ti) for t < T
+        else
+            predict!(pf, u, p, ti)                                     # src/filtering.jl:140-153, src/rbpf.jl:163-229
+        end
+        resampled[k] = REPLAY.upos > n_before ? 1 : 0                  # this predict! drew from the uniform tape
         jh[k, :] .= state(pf).j .- 1                                   # 0-based, as the C ABI returns them
-        REPLAY.npos == N * nx || error("step $k consumed $(REPLAY.npos) normals, expected $(N * nx)")
+        (family == "aux" && k == T) || REPLAY.npos == N * size(xi_dyn, 3) || error("step $k consumed $(REPLAY.npos) normals, expected $(N * size(xi_dyn, 3))")
     end
-    xf = zeros(N, nx)
+    xf = zeros(N, nrec)
     for i in 1:N
         xf[i, :] .= particles(pf)[i]
     end
-    npzwrite(joinpath(root, "tests", "golden", "ref_$name.npz"),
-             Dict("ll_steps" => ll_steps, "x" => xh, "w" => wh, "we" => weh, "j" => jh, "resampled" => resampled, "x_final" => xf,
-                  "reference_version" => collect(UInt8, string(pkgversion(LowLevelParticleFilters))), "julia_version" => collect(UInt8, string(VERSION))))
+    out = Dict{String,Any}("ll_steps" => ll_steps, "x" => xh, "w" => wh, "we" => weh, "j" => jh, "resampled" => resampled, "x_final" => xf,
+                           "reference_version" => collect(UInt8, string(pkgversion(LowLevelParticleFilters))), "julia_version" => collect(UInt8, string(VERSION)))
+    if family == "rbpf"
+        out["R"] = Rh
+    end
+    npzwrite(joinpath(root, "tests", "golden", "ref_$name.npz"), out)
     println("$name: ll = $(sum(ll_steps)), resampled $(sum(resampled)) of $T steps -> tests/golden/ref_$name.npz")
 end
 
 root = length(ARGS) >= 1 ? ARGS[1] : normpath(joinpath(@__DIR__, "..", ".."))
-for name in ("lg", "quadtank")
+for name in ("lg", "quadtank", "lg_stratified", "lg_residual", "lg_thr1", "aux_lg", "rbpf")
     run_case(name, root)
 end

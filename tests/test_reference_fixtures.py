@@ -15,7 +15,7 @@ import oracle_binding as ob
 from llpf_amd import _capi, _structs as S
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = ("lg", "quadtank")
+CASES = ("lg", "quadtank", "lg_stratified", "lg_residual", "lg_thr1", "aux_lg", "rbpf")
 SKIP = ("REFERENCE FIXTURES ABSENT: tests/golden/ref_%s.npz has not been generated.  It needs Julia with LowLevelParticleFilters.jl: "
         "`julia --project=<env> lowlevelparticlefilters.jl_amd/julia/make_reference_fixtures.jl <repo root>` (INTEGRATION.md section 4).  "
         "Until then parity is pinned by this repository's own restatements only.")
@@ -30,7 +30,7 @@ def _inputs(name):
 
 
 def _config(MRI, case):
-    return S.make_config(case["model"], case["N"], case["kind"], S.RESAMPLE_SYSTEMATIC, case["thr"], MRI.SEED, 0)
+    return S.make_config(case["model"], case["N"], case["kind"], case.get("strategy", S.RESAMPLE_SYSTEMATIC), case["thr"], MRI.SEED, 0)
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -40,6 +40,8 @@ def test_committed_inputs_are_the_draws_the_filters_consume(name):
     assert np.array_equal(d["xi_reset"], xi_reset) and np.array_equal(d["xi_dyn"], xi_dyn) and np.array_equal(d["u_res"], u_res)
     assert np.array_equal(d["U"], case["U"]) and np.array_equal(d["Y"], case["Y"], equal_nan=True) and int(d["seed"]) == MRI.SEED
     # a filter fed the tapes explicitly is the filter that draws them itself: the tapes are what reset! / predict! number k consume
+    if case["family"] in ("aux", "rbpf"):
+        return                      # (their predict! has no explicit-tape entry point in the oracle's binding; the streams are the same ones)
     cfg = _config(MRI, case)
     a, b = ob.OracleFilter(cfg, ob.ORDER_REFERENCE), ob.OracleFilter(cfg, ob.ORDER_REFERENCE)
     a.reset()
@@ -49,30 +51,77 @@ def test_committed_inputs_are_the_draws_the_filters_consume(name):
         t = (case["t_index0"] + k) * Ts
         assert a.correct(case["U"][k], case["Y"][k], t) == b.correct(case["U"][k], case["Y"][k], t)
         a.predict(case["U"][k], t)
-        b.predict(case["U"][k], t, d["xi_dyn"][k], d["u_res"][k:k + 1])
+        b.predict(case["U"][k], t, d["xi_dyn"][k], np.atleast_1d(d["u_res"][k]))
         assert np.array_equal(a.particles(), b.particles()) and np.array_equal(a.ancestors(), b.ancestors())
 
 
 def _compare(h, case, ref, tol_scale=1.0):
     """step the handle through the run the reference was stepped through; everything is compared while the ancestries coincide (one
     differing ancestor decorrelates the two particle systems), and they must coincide for at least half the run"""
-    Ts, T = case["model"].Ts, case["T"]
+    Ts, T, fam = case["model"].Ts, case["T"], case["family"]
     h.reset()
     agree = 0
     for k in range(T):
         t = (case["t_index0"] + k) * Ts
-        ll = h.correct(case["U"][k], case["Y"][k], t)
+        # correct!: the auxiliary filter's is the normalisation only (src/filtering.jl:170-174: its weighting happened in predict!)
+        ll = h.aux_correct() if fam == "aux" else h.correct(case["U"][k], case["Y"][k], t)
         assert abs(ll - ref["ll_steps"][k]) <= TOL_LL * tol_scale, (k, ll, ref["ll_steps"][k])
-        assert np.max(np.abs(h.particles() - ref["x"][k])) <= TOL_X
+        assert np.max(np.abs(h.particles() - ref["x"][k])) <= TOL_X          # an RBParticle reads [xn; xl] on both sides
+        if fam == "rbpf":
+            assert np.max(np.abs(h.rb_linear_state()[1] - ref["R"][k])) <= TOL_X
         we = h.expweights()
         assert np.max(np.abs(we - ref["we"][k]) / np.maximum(ref["we"][k], 1e-300)) <= TOL_WE * 10 or np.max(np.abs(we - ref["we"][k])) <= 1e-15
-        h.predict(case["U"][k], t)
+        if fam == "aux":
+            if k == T - 1:
+                agree += 1
+                break
+            h.aux_predict(case["U"][k], case["Y"][k + 1], t)              # forward_trajectory(::AuxiliaryParticleFilter), src/filtering.jl:381
+        else:
+            h.predict(case["U"][k], t)
         assert int(h.last_resampled()) == int(ref["resampled"][k])
         if ref["resampled"][k] and not np.array_equal(h.ancestors(), ref["j"][k]):
             break
         agree += 1
     assert agree >= T // 2, "ancestries diverged from the reference's after %d of %d steps" % (agree, T)
     return agree
+
+
+def _record_like_the_julia_script(h, case):
+    """what make_reference_fixtures.jl records, taken from a handle of ours instead of the reference: for the dry run of the comparison
+    code below (NOT a fixture: nothing here is written to tests/golden)"""
+    Ts, T, fam, N = case["model"].Ts, case["T"], case["family"], case["N"]
+    h.reset()
+    out = dict(ll_steps=np.zeros(T), x=[], w=[], we=[], j=np.zeros((T, N), dtype=np.int64), resampled=np.zeros(T, dtype=np.int64), R=[])
+    for k in range(T):
+        t = (case["t_index0"] + k) * Ts
+        out["ll_steps"][k] = h.aux_correct() if fam == "aux" else h.correct(case["U"][k], case["Y"][k], t)
+        out["x"].append(h.particles()); out["we"].append(h.expweights())
+        if fam == "rbpf":
+            out["R"].append(h.rb_linear_state()[1])
+        if fam == "aux":
+            if k < T - 1:
+                h.aux_predict(case["U"][k], case["Y"][k + 1], t)
+        else:
+            h.predict(case["U"][k], t)
+        out["resampled"][k] = int(h.last_resampled()) if not (fam == "aux" and k == T - 1) else 0
+        out["j"][k] = h.ancestors()
+    for key in ("x", "we", "R"):
+        out[key] = np.array(out[key])
+    return out
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_comparison_code_dry_run(name):
+    """The comparisons below only run once somebody has generated the fixtures; until then their code would be untested.  Dry run: the
+    reference-order oracle plays the reference (recorded exactly as the Julia script records), the device-order oracle is held to it with
+    the same function and tolerances — every family's stepping sequence (auxiliary filter: predict!(u[t], y[t+1]) for t < T; RBPF: the
+    per-particle covariances) and the 'while the ancestries coincide' rule execute in every CPU run."""
+    MRI, case, _ = _inputs(name)
+    cfg = _config(MRI, case)
+    ref = _record_like_the_julia_script(ob.OracleFilter(cfg, ob.ORDER_REFERENCE), case)
+    assert ref["resampled"].sum() >= 3 and np.all(np.isfinite(ref["ll_steps"]))
+    agree = _compare(ob.OracleFilter(cfg, ob.ORDER_DEVICE), case, ref)
+    assert agree >= case["T"] // 2
 
 
 @pytest.mark.parametrize("order", [ob.ORDER_REFERENCE, ob.ORDER_DEVICE])

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 5, GPU lease 2: the shared tail batches of k_rbfull — parity first, then C5 with and without them, then the whole suite
-O=gpurun_out/r05b; mkdir -p $O
+O=gpurun_out/r05c; mkdir -p $O
 timeout 600 python -m pytest tests/test_gpu_rbfull.py -x -q > $O/rbfull_tests.log 2>&1; echo "rbfull tests rc=$?" >> $O/rbfull_tests.log
 if grep -q "rc=0" $O/rbfull_tests.log; then
 for rep in 1 2; do for v in 0 auto; do
