@@ -31,7 +31,6 @@
 #include "shared/llpf_fixed.h"
 #include "shared/llpf_philox.h"
 #include "shared/llpf_rbfull.h"
-#include "shared/llpf_rbfull_coop.h"
 
 namespace llpf {
 
@@ -204,8 +203,7 @@ struct StepArgs {
     int32_t u_stride;      // doubles between the u / y of consecutive filters of a bank; 0: all filters share one u / y
     int32_t y_stride;
     int32_t marks;         // 1: the resampling of this predict! was done by k_resample_fx: ancestors come as run-start marks (BankDev::mark),
-    int32_t rbf_tail;      //    f(x[ancestor]) from BankDev::fxs; k_step expands the marks and writes the ancestors itself
-                           // rbf_tail (k_rbfull only, set by its launcher): the last rbf_tail batches of particles are shared by the four waves of a workgroup
+    int32_t pad_m;         //    f(x[ancestor]) from BankDev::fxs; k_step expands the marks and writes the ancestors itself
 };
 
 // FFBS smoother (reference src/smoothing.jl:116-143): one backward step t for all M trajectories
@@ -300,8 +298,6 @@ bool step_supported(int model_id, int nx, int ny);
 int jit_compile_user_model(const char* device_src, int nx, int ny, std::string& err);
 bool rbfull_supported(int fn_kind, int nn, int nl, int ny);
 int rbfull_rows(int nn, int nl);   // rows of the particle plane: xn, xl, packed R
-struct RbfullShape { unsigned grid_x, block, tail; };          // workgroups along x, threads per workgroup, batches shared by a whole workgroup (StepArgs::rbf_tail)
-RbfullShape rbfull_launch_shape(const BankDev& b, int nl, int mode);
 unsigned rbfull_grid_x(const BankDev& b, int nl, int mode);   // workgroups along x of a k_rbfull launch (persistent for the 8x8 form)
 
 }  // namespace llpf

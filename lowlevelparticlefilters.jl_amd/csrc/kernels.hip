@@ -57,18 +57,7 @@ static void launch_norm_e2(const BankDev& b, int parity, int need_e2, uint32_t s
     if (need_e2) hipLaunchKernelGGL((k_norm<NX, XMEAN, true>), g, dim3(BLOCK), 0, s, b, K, parity, step, only_fallback, bound, kstep);
     else hipLaunchKernelGGL((k_norm<NX, XMEAN, false>), g, dim3(BLOCK), 0, s, b, K, parity, step, only_fallback, bound, kstep);
 }
-#ifndef LLPF_NORM_WAVE_TILE
-#define LLPF_NORM_WAVE_TILE 0
-#endif
 hipError_t launch_norm(const BankDev& b, int parity, int want_xmean, int need_e2, uint32_t step, int only_fallback, int bound, int64_t kstep, hipStream_t s) {
-    static const char* wt_env = getenv("LLPF_NORM_WAVE_TILE");
-    if (!want_xmean && b.P2 > 1 && (wt_env ? atoi(wt_env) != 0 : LLPF_NORM_WAVE_TILE != 0)) {      // one wave per tile (kernels/norm.hpp: k_norm_wt): the same integers
-        const dim3 g((unsigned)((b.P2 + BLOCK / 64 - 1) / (BLOCK / 64)), (unsigned)b.F, 1);
-        const int K = llpf_qbits(b.N);
-        if (need_e2) hipLaunchKernelGGL((k_norm_wt<true>), g, dim3(BLOCK), 0, s, b, K, parity, step, only_fallback, bound, kstep);
-        else hipLaunchKernelGGL((k_norm_wt<false>), g, dim3(BLOCK), 0, s, b, K, parity, step, only_fallback, bound, kstep);
-        return hipGetLastError();
-    }
     if (!want_xmean) { launch_norm_e2<0, false>(b, parity, need_e2, step, only_fallback, bound, kstep, s); return hipGetLastError(); }
     switch (b.nx) {
         case 1: launch_norm_e2<1, true>(b, parity, need_e2, step, only_fallback, bound, kstep, s); break;

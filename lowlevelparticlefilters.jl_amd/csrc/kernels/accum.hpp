@@ -72,7 +72,7 @@ struct WeightAcc {
         llpf_u128 s = wave_sum_u128(S), e2 = {0, 0};
         if (need_e2) e2 = wave_sum_u128(E2);
         const uint64_t bd = (uint64_t)__builtin_popcountll(__ballot(bad != 0));
-        if ((threadIdx.x & 63u) == 0) {               // every wave for itself (k_rbfull's persistent form has four per workgroup)
+        if (threadIdx.x == 0) {
             acc_add_u128(acc, ACC_S(slot), s);
             if (need_e2) acc_add_u128(acc, ACC_E2(slot), e2);
             if (bd) atomicAdd(reinterpret_cast<unsigned long long*>(acc_slot(acc, ACC_BAD(slot), blockIdx.x & (NSHARD - 1))), (unsigned long long)bd);

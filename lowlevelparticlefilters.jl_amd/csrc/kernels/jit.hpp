@@ -84,7 +84,8 @@ static int jit_compile_model(const char* device_src, int nx, int ny, bool intern
     if (hipGetDevice(&devid) == hipSuccess && hipGetDeviceProperties(&prop, devid) == hipSuccess && prop.gcnArchName[0]) arch = prop.gcnArchName;
     const std::string archopt = "--offload-arch=" + arch;
     // -disable-machine-licm: as for k_step.hip (Makefile) — the tile loop of k_step<..., MARKS>
-    const char* opts[] = {archopt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-Wno-unused-value", "-mllvm", "-disable-machine-licm"};
+    // (-DLLPF_EXP_LDEXP: as for k_step.hip in the Makefile — the same bits, one instruction instead of six for exp's scaling)
+    const char* opts[] = {archopt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-Wno-unused-value", "-DLLPF_EXP_LDEXP=1", "-mllvm", "-disable-machine-licm"};
     const hiprtcResult rc = hiprtcCompileProgram(prog, (int)(sizeof(opts) / sizeof(opts[0])), opts);
     if (rc != HIPRTC_SUCCESS) {
         size_t n = 0;
@@ -288,9 +289,7 @@ hipError_t launch_rbfull_jit(int fk, int nn, int nl, int ny, const BankDev& b, i
     }
     BankDev bd = b;
     StepArgs aa = a;
-    const RbfullShape sh = rbfull_launch_shape(b, nl, mode);
-    aa.rbf_tail = (int32_t)sh.tail;
     // LLPF_RBF_HOT_PARAMS (kernels/rbfull.hpp), then the two structs
     void* args[] = {&bd.scal, &bd.bank_flag, &bd.anc, &bd.models, &aa.u, &bd.Ns, &bd.nu, &aa.u_stride, &aa.y, &bd, &aa};
-    return hipModuleLaunchKernel(fn, sh.grid_x, (unsigned)b.F, 1, sh.block, 1, 1, 0, s, args, nullptr);
+    return hipModuleLaunchKernel(fn, rbfull_grid_x(b, nl, mode), (unsigned)b.F, 1, 64, 1, 1, 0, s, args, nullptr);
 }

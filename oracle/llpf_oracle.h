@@ -122,8 +122,6 @@ double orc_pairwise_sum(const double* a, int64_t n);
 /* shared-primitive probes (host evaluation of csrc/shared headers) */
 void   orc_math_vec(int which, const double* in, double* out, int64_t n);
 void   orc_philox_block(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out4);
-/* host emulation of the cooperative form of the per-particle Kalman recursion (csrc/shared/llpf_rbfull_coop.h) against the sequential one */
-int64_t orc_rbf_coop_check(orc_filter* f, int has_corr, int64_t n, uint64_t seed, double* xl_seq, double* R_seq, double* ll_seq);
 int    orc_philox_block_engine(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out4);
 void   orc_normals(uint64_t seed, uint32_t step, uint32_t stream, int nd, double* out, int64_t n);
 void   orc_uniforms_nd(uint64_t seed, uint32_t step, uint32_t stream, int nd, double* out, int64_t n);   /* llpf_uniforms of particles 0..n-1 */

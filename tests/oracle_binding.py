@@ -53,8 +53,6 @@ def load():
     lib.orc_smooth.argtypes = [C.c_void_p, C.c_int64, _dp, C.c_int64, _dp, _dp, _dp, _dp, _ip]
     lib.orc_rb_get_R.argtypes = [C.c_void_p, _dp]
     lib.orc_rb_get_linear_state.argtypes = [C.c_void_p, _dp, _dp]
-    lib.orc_rbf_coop_check.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_uint64, _dp, _dp, _dp]
-    lib.orc_rbf_coop_check.restype = C.c_int64
     lib.orc_num_particles.restype = C.c_int64
     lib.orc_num_particles.argtypes = [C.c_void_p]
     lib.orc_index.restype = C.c_int64
@@ -272,14 +270,6 @@ class OracleFilter:
         R = np.zeros((self.N, nl, nl))
         self.L.orc_rb_get_linear_state(self.h, dptr(xl), dptr(R))
         return xl, R
-
-    def rbf_coop_check(self, has_corr, n, seed=1):
-        """host emulation of the cooperative (four-wave) form of the per-particle Kalman recursion against the sequential shared form on n
-        random particles of this filter's model: (number of differing output words, last particle's xl, packed R, ll of the sequential form)"""
-        nl = self.cfg.model.rb.nxl
-        xl, R, ll = np.zeros(nl), np.zeros(nl * (nl + 1) // 2), np.zeros(1)
-        bad = self.L.orc_rbf_coop_check(self.h, int(has_corr), int(n), int(seed), dptr(xl), dptr(R), dptr(ll))
-        return int(bad), xl, R, float(ll[0])
 
     def particles(self):
         a = np.empty((self.N, self.nx))

@@ -8,7 +8,10 @@
 #if defined(LLPF_RBF_TIMING)
 __device__ unsigned long long* g_rbf_dbg;
 #if defined(__HIP_DEVICE_COMPILE__)
-__shared__ unsigned int g_rbf_row;      // the batch a persistent wave has in hand: the row its stamps go to
+__shared__ unsigned int g_rbf_rows[4];  // the batch a persistent wave has in hand: the row its stamps go to (one entry per wave of the workgroup)
+#define g_rbf_row g_rbf_rows[threadIdx.x >> 6]
+// the shared tail batches (kernels/rbfull.hpp): stamps of the nonlinear wave, which passes every barrier as soon as the Kalman waves reach it
+#define RBF_TAILSTAMP(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)); g_rbf_dbg[(size_t)(nfull + tj) * 32 + (k)] = t_; } while (0)
 #endif
 #endif
 #include <atomic>
@@ -39,33 +42,58 @@ bool rbfull_supported(int fn_kind, int nn, int nl, int ny) {
 }
 int rbfull_rows(int nn, int nl) { return nn + nl + LLPF_RBF_NP(nl); }
 
-// Workgroups (single waves) along x.  The 8x8 form is persistent (kernels/rbfull.hpp): as many waves as the device holds at once —
-// two per SIMD, eight per CU — shared among the bank's filters; every wave takes batches blockIdx.x, blockIdx.x + gridDim.x, ...
-unsigned rbfull_grid_x(const BankDev& b, int nl, int mode) {
+// Launch shape.  The 8x8 form is persistent (kernels/rbfull.hpp): as many waves as the device holds at once — two per SIMD, eight per
+// CU — shared among the bank's filters, in workgroups of four; every wave takes batches w, w + waves, ...  `tail` (StepArgs::rbf_tail):
+// when the batches do not divide evenly over the SIMDs and the remainder is small, the last batches are shared by the four waves
+// of a workgroup (shared/llpf_rbfull_coop.h) instead of being a whole extra batch for a few SIMDs.  LLPF_RBF_TAIL: 0 = never, k > 0 =
+// exactly k batches (tests: small filters), unset = the rule below.  Every other form: one wave per batch.
+RbfullShape rbfull_launch_shape(const BankDev& b, int nl, int mode) {
+    RbfullShape sh;
     const unsigned nbatch = (unsigned)(b.Ns / RBF_BLOCK);
-    if (nl < 8 || mode == MODE_WEIGHT) return nbatch;
+    sh.block = (unsigned)(RBF_BLOCK * rbf_wpg(nl, mode)); sh.tail = 0; sh.grid_x = nbatch;
+    if (!rbf_dma(nl, mode)) return sh;
     static std::atomic<int> cus[64];     // per ordinal; filled on first use (distinct handles may be driven from distinct host threads)
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nbatch;
-    int nc = cus[dev].load(std::memory_order_relaxed);
-    if (nc == 0) {
-        int n = 0;
-        nc = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : -1;
-        cus[dev].store(nc, std::memory_order_relaxed);
+    int dev = 0, nc = -1;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+        nc = cus[dev].load(std::memory_order_relaxed);
+        if (nc == 0) {
+            int n = 0;
+            nc = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : -1;
+            cus[dev].store(nc, std::memory_order_relaxed);
+        }
     }
-    if (nc < 0) return nbatch;
-    const unsigned resident = (unsigned)nc * 4u * (unsigned)LLPF_RBF_WAVES;
-    const unsigned per_filter = resident / (unsigned)(b.F > 0 ? b.F : 1);
-    return nbatch < per_filter ? nbatch : (per_filter > 0 ? per_filter : 1u);
+    const unsigned nreal = (unsigned)((b.N + RBF_BLOCK - 1) / RBF_BLOCK);
+    unsigned per_filter = nreal;          // waves of one filter
+    if (nc > 0) {
+        const unsigned resident = (unsigned)nc * 4u * (unsigned)LLPF_RBF_WAVES;
+        per_filter = resident / (unsigned)(b.F > 0 ? b.F : 1);
+        per_filter -= per_filter % 4u;
+        if (per_filter < 4u) per_filter = 4u;
+    }
+    const char* tail_env = getenv("LLPF_RBF_TAIL");       // (read per launch: the tests switch it inside one process)
+    unsigned tail = 0;
+    const unsigned simds = per_filter / (unsigned)LLPF_RBF_WAVES;      // SIMDs this filter's waves occupy
+    if (tail_env) tail = (unsigned)atoi(tail_env);
+    else if (nc > 0 && nreal > simds && nreal % simds != 0 && nreal % simds <= simds / 8u) tail = nreal % simds;
+    unsigned waves = nreal - tail < per_filter ? nreal - tail : per_filter;
+    unsigned groups = (waves + 3u) / 4u;
+    if (tail >= nreal || tail > groups) { tail = 0; waves = nreal < per_filter ? nreal : per_filter; groups = (waves + 3u) / 4u; }      // at least one ordinary batch; one shared batch per workgroup at most
+    sh.grid_x = groups; sh.tail = tail;
+    return sh;
 }
+// (kept for callers that only need the number of workgroups)
+unsigned rbfull_grid_x(const BankDev& b, int nl, int mode) { return rbfull_launch_shape(b, nl, mode).grid_x; }
 
 template <class Model, int NN, int NL, int NY>
-static hipError_t launch_rbfull_t(const BankDev& b, int mode, const StepArgs& a, hipStream_t s) {
-    dim3 g(rbfull_grid_x(b, NL, mode), (unsigned)b.F, 1);
+static hipError_t launch_rbfull_t(const BankDev& b, int mode, const StepArgs& a0, hipStream_t s) {
+    const RbfullShape sh = rbfull_launch_shape(b, NL, mode);
+    dim3 g(sh.grid_x, (unsigned)b.F, 1);
+    StepArgs a = a0;
+    a.rbf_tail = (int32_t)sh.tail;
     switch (mode) {
-        case MODE_WEIGHT: hipLaunchKernelGGL((k_rbfull<Model, NN, NL, NY, MODE_WEIGHT>), g, dim3(RBF_BLOCK), 0, s, LLPF_RBF_HOT_ARGS(b, a), b, a); break;
-        case MODE_PROP: hipLaunchKernelGGL((k_rbfull<Model, NN, NL, NY, MODE_PROP>), g, dim3(RBF_BLOCK), 0, s, LLPF_RBF_HOT_ARGS(b, a), b, a); break;
-        case MODE_PROP_WEIGHT: hipLaunchKernelGGL((k_rbfull<Model, NN, NL, NY, MODE_PROP_WEIGHT>), g, dim3(RBF_BLOCK), 0, s, LLPF_RBF_HOT_ARGS(b, a), b, a); break;
+        case MODE_WEIGHT: hipLaunchKernelGGL((k_rbfull<Model, NN, NL, NY, MODE_WEIGHT>), g, dim3(sh.block), 0, s, LLPF_RBF_HOT_ARGS(b, a), b, a); break;
+        case MODE_PROP: hipLaunchKernelGGL((k_rbfull<Model, NN, NL, NY, MODE_PROP>), g, dim3(sh.block), 0, s, LLPF_RBF_HOT_ARGS(b, a), b, a); break;
+        case MODE_PROP_WEIGHT: hipLaunchKernelGGL((k_rbfull<Model, NN, NL, NY, MODE_PROP_WEIGHT>), g, dim3(sh.block), 0, s, LLPF_RBF_HOT_ARGS(b, a), b, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -26,8 +26,10 @@ DEV void rbf_model_ready(const M& m, uint32_t& dep) {
 
 #if defined(LLPF_RBF_TIMING) && defined(__HIP_DEVICE_COMPILE__)
 #define RBF_TSTAMP(k, dep) do { asm volatile("" : : "v"(dep)); RBF_STAMP(k); } while (0)
+#define RBF_TAILSTAMP_DEP(k, dep) do { asm volatile("" : : "v"(dep)); RBF_TAILSTAMP(k); } while (0)
 #else
 #define RBF_TSTAMP(k, dep) ((void)0)
+#define RBF_TAILSTAMP_DEP(k, dep) ((void)0)
 #endif
 // element idx of an array through a 32-bit byte offset from its (uniform) base: one address register, saddr + voffset addressing
 DEV double* rbf_at(double* base, uint32_t idx) { return reinterpret_cast<double*>(reinterpret_cast<char*>(base) + (size_t)(idx * 8u)); }
@@ -51,12 +53,19 @@ DEV const int32_t* rbf_at(const int32_t* base, uint32_t idx) { return reinterpre
 // SIMD started its gather when the memory system was busy with the first round's stores, and the memory-bound and the issue-bound
 // phases of the launch added up (tools/dbg/rbf_timing.py: 40k + 49k of 89k cycles).
 constexpr int RBF_BLOCK = 64;
+// Round 5: the persistent (8x8) form is launched as workgroups of FOUR waves — each wave still takes batches of its own, exactly as
+// before (its own slice of the LDS, virtual wave index 4 blockIdx.x + wave) — so that the launch can END with batches that the four
+// waves of a workgroup share by OUTPUT instead of by particle (shared/llpf_rbfull_coop.h): N = 2e5 is 3125 batches on 1024 SIMDs,
+// and the 53 batches beyond 3 x 1024 used to run as a fourth batch on 53 SIMDs while 971 idled (EXPERIMENTS 4.18, 5.x).
+template <int V> struct rbf_const { static constexpr int value = V; };
+constexpr __host__ __device__ bool rbf_dma(int nl, int mode) { return nl >= 8 && mode != MODE_WEIGHT; }
+constexpr __host__ __device__ int rbf_wpg(int nl, int mode) { return rbf_dma(nl, mode) ? 4 : 1; }      // waves per workgroup
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef __attribute__((address_space(3))) void* rbf_lds_ptr;
 typedef const __attribute__((address_space(1))) void* rbf_glb_ptr;
 #endif
 template <class Model, int NN, int NL, int NY, int MODE>
-__global__ __launch_bounds__(RBF_BLOCK) __attribute__((amdgpu_waves_per_eu(NL >= 8 ? LLPF_RBF_WAVES : 1))) void k_rbfull(LLPF_RBF_HOT_PARAMS, BankDev b, StepArgs a) {
+__global__ __launch_bounds__(RBF_BLOCK * rbf_wpg(NL, MODE)) __attribute__((amdgpu_waves_per_eu(NL >= 8 ? LLPF_RBF_WAVES : 1))) void k_rbfull(LLPF_RBF_HOT_PARAMS, BankDev b, StepArgs a) {
     // What the first loads are addressed with arrives in SGPRs with the wave (kernarg preload, -amdgpu-kernarg-preload-count=16; a struct
     // by value as the first argument switches it off): the filter's scalars, the ancestor index (requested whether or not this step
     // resamples), the generator's tables and the row of Bl u go out with the wave's first instructions, beside the scalar load of the rest
@@ -65,21 +74,30 @@ __global__ __launch_bounds__(RBF_BLOCK) __attribute__((amdgpu_waves_per_eu(NL >=
     const FilterScal* scal = hot_scal;
     static_assert(MODE == MODE_WEIGHT || MODE == MODE_PROP || MODE == MODE_PROP_WEIGHT, "no auxiliary form");
     constexpr int NP = LLPF_RBF_NP(NL), ROWS = NN + NL + NP;
-    constexpr bool DMA = NL >= 8 && MODE != MODE_WEIGHT;       // covariance planes through LDS (the persistent form)
+    constexpr bool DMA = rbf_dma(NL, MODE);                    // covariance planes through LDS (the persistent form)
+    constexpr int WPG = rbf_wpg(NL, MODE);                     // waves of the workgroup: every wave has batches of its own
     constexpr int NPD = DMA ? NP - 1 : 0, NDIR = NP - NPD;     // planes of R through LDS / straight into registers
     const int f = blockIdx.y;
     const ModelD* md = models + f;
     const FilterScal* sc = scal + f;
-    uint32_t bb = blockIdx.x;                                   // the batch (64 particles) in hand
+    const int wvi = WPG > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;     // wave of the workgroup (uniform: a scalar)
+    // batches: [0, nfull) one particle per lane by the waves in turn; [nfull, nreal) shared by the four waves of a workgroup (the tail);
+    // [nreal, Ns / 64) hold padding only (their weights are written below, nothing else of them is ever read)
+    const uint32_t nreal = (uint32_t)((b.N + RBF_BLOCK - 1) / RBF_BLOCK);
+    const uint32_t ntail = DMA ? (uint32_t)a.rbf_tail : 0u;
+    const uint32_t nfull = DMA ? nreal - ntail : (uint32_t)(hot_Ns / RBF_BLOCK);
+    const uint32_t bb0 = blockIdx.x * (uint32_t)WPG + (uint32_t)wvi;      // this wave's first batch
+    const bool active = bb0 < nfull;                            // (the grid is rounded up to whole workgroups)
+    uint32_t bb = active ? bb0 : 0u;                            // the batch (64 particles) in hand; an idle wave addresses batch 0 and stores nothing
 #if defined(LLPF_RBF_TIMING) && defined(__HIP_DEVICE_COMPILE__)
-    if (threadIdx.x == 0) g_rbf_row = bb;
+    if ((threadIdx.x & 63) == 0) g_rbf_row = bb;
     __syncthreads();
     RBF_STAMP(0);
     { uint32_t hw_, xcc_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));
       g_rbf_dbg[(size_t)bb * 32 + 13] = hw_; g_rbf_dbg[(size_t)bb * 32 + 14] = xcc_; }
 #endif
     // ---- with the wave's first instructions (everything here is addressed from preloaded SGPRs) ----
-    const int t = (int)threadIdx.x;
+    const int t = (int)(threadIdx.x & 63u);
     // 32-bit particle index and byte offsets from uniform bases: what stays in registers through the loop is one word per quantity
     uint32_t i = bb * (uint32_t)RBF_BLOCK + (uint32_t)t;
     const int32_t* ancf = hot_anc + (size_t)f * hot_Ns;
@@ -87,8 +105,10 @@ __global__ __launch_bounds__(RBF_BLOCK) __attribute__((amdgpu_waves_per_eu(NL >=
     const double* uf = hot_u + (size_t)f * hot_ustride;       // banks on data of their own (llpf_bank_run_multi): filter f's row
     const llpf_rbf_par* par = &md->rbf;
     __shared__ __attribute__((aligned(16))) double sh_rng_lg[2 * LLPF_RNG_LG_ENTRIES], sh_rng_sc[2 * LLPF_RNG_SC_ENTRIES];
-    __shared__ double sh_blu[LLPF_RBF_MAXL], sh_y[LLPF_RBF_MAXY + 1], sh_w[RBF_BLOCK];      // sh_y[NY]: c0 of the measurement density
-    __shared__ __attribute__((aligned(16))) uint32_t sh_R[DMA ? NPD * 128 : 4];                // plane d: 64 low words, 64 high words
+    __shared__ double sh_blu[LLPF_RBF_MAXL], sh_y[LLPF_RBF_MAXY + 1], sh_w_all[WPG][RBF_BLOCK];      // sh_y[NY]: c0 of the measurement density
+    __shared__ __attribute__((aligned(16))) uint32_t sh_R_all[WPG][DMA ? NPD * 128 : 4];                // per wave; plane d: 64 low words, 64 high words
+    double* const sh_w = sh_w_all[wvi];
+    uint32_t* const sh_R = sh_R_all[wvi];
     static_assert(RBF_BLOCK >= LLPF_RNG_SC_ENTRIES && RBF_BLOCK >= LLPF_RNG_LG_ENTRIES, "one table entry per lane");
     double rt0 = 0.0, rt1 = 0.0, rt2 = 0.0, rt3 = 0.0, blv[8], uv[8], yv = 0.0, wN = 0.0;
     const int nu = hot_nu;
@@ -121,23 +141,211 @@ __global__ __launch_bounds__(RBF_BLOCK) __attribute__((amdgpu_waves_per_eu(NL >=
     double* __restrict__ xo = (MODE == MODE_WEIGHT) ? const_cast<double*>(xc) : b.xnext + (size_t)f * ROWS * Ns;
     double* w = b.w + (size_t)f * Ns;
     uint64_t* qnf = b.quanta_next + (size_t)f * Ns;
-    const uint32_t nbatch = (uint32_t)(Ns / RBF_BLOCK), gstep = gridDim.x;
+    const uint32_t gstep = gridDim.x * (uint32_t)WPG;
     const bool need_w = MODE != MODE_PROP && !do_res && !uniform;
+    if (DMA && MODE != MODE_PROP) {      // the batches that hold padding only: weight -Inf, no quantum; one store each, by the first waves
+        const uint32_t npad = (uint32_t)(Ns / RBF_BLOCK) - nreal;
+        if (bb0 < npad) {
+            const uint32_t ip = (nreal + bb0) * (uint32_t)RBF_BLOCK + (uint32_t)t;
+            *rbf_at(w, ip) = -LLPF_INF;
+            if (a.accumulate) *rbf_at(qnf, ip) = 0;
+        }
+    }
+
+    if (MODE != MODE_PROP && a.has_y && t <= NY) yv = t < NY ? hot_y[(size_t)f * a.y_stride + t] : md->dg.c0;
+    const uint32_t stride = (uint32_t)Ns * 8u;
+    // nontemporal: every plane is read once per launch (same box: 50.0 -> 47.3 us; only on the steps that do not resample: no better)
+    auto ld = [&](int row, uint32_t off) { return __builtin_nontemporal_load(reinterpret_cast<const double*>(reinterpret_cast<const char*>(xc) + (off + (uint32_t)row * stride))); };
+    // The model's constants through scalar loads (their own counter: no place in the queue of the planes), where they are used: held
+    // across the loop they would sit in registers through the recursion.  The pointers pass an empty asm tied to a value of the batch
+    // in hand, so the loads can be neither hoisted out of the loop nor issued before that value exists.
+    auto prepared = [&](auto dep) {
+        Model mdl;
+#if defined(__HIP_DEVICE_COMPILE__)
+        const __attribute__((address_space(4))) ModelD* mk = (const __attribute__((address_space(4))) ModelD*)md;
+        const __attribute__((address_space(4))) double* uk = (const __attribute__((address_space(4))) double*)uf;
+        asm volatile("" : "+s"(mk), "+s"(uk) : "v"(dep));
+        mdl.prepare((const ModelD*)mk, (const double*)uk, a.t_prop);
+#else
+        mdl.prepare(md, uf, a.t_prop);
+#endif
+        return mdl;
+    };
+    // Bl u is particle-independent and nu a run-time number: formed once per wave (lane r: row r), read back by the time update from
+    // LDS (as a branch inside the unrolled body it cut the body into blocks that each kept their constants' SGPRs alive)
+    auto tables_to_lds = [&]() {
+        if (MODE != MODE_WEIGHT) {
+            sh_rng_sc[2 * t] = rt0; sh_rng_sc[2 * t + 1] = rt1;
+            if (t < LLPF_RNG_LG_ENTRIES) { sh_rng_lg[2 * t] = rt2; sh_rng_lg[2 * t + 1] = rt3; }
+            if (t < NL) {
+                double b2 = -0.0;                                        // llpf_rbf_blu_row: x + (-0.0) == x for every x
+                if (nu > 0) {
+                    b2 = blv[0] * uv[0];
+#pragma unroll
+                    for (int c = 1; c < 8; ++c) { const double t2 = llpf_fma(blv[c], uv[c], b2); b2 = c < nu ? t2 : b2; }
+                }
+                sh_blu[t] = b2;
+            }
+        }
+        if (MODE != MODE_PROP && a.has_y && t <= NY) sh_y[t] = yv;
+    };
+
+    // ---- the shared batches: batch nfull + j belongs to the four waves of workgroup gridDim.x - 1 - j together (the high workgroups are
+    // the ones whose waves have the fewest batches of their own) and is done FIRST.  shared/llpf_rbfull_coop.h: wave 0 the nonlinear
+    // state and the weight, waves 1..3 the Kalman recursion by columns; the exchange buffer is the four waves' covariance slices of the
+    // LDS, not yet in use.  First, because that is where the launch has room: every other wave of the chip starts by waiting ~9 us for
+    // its 48 planes while the vector units idle, and the waves of these workgroups have slack behind their single batch of their own
+    // (EXPERIMENTS 4.16: a one-batch wave may start 13 us late at no cost).  Done LAST — after the workgroup's own batches, which end
+    // at 30-40 us of a 47 us launch — the ~10 us of a shared batch ended the launch later than the fourth batch it replaced
+    // (same box: 47.9 against 46.2 us, EXPERIMENTS 5.x). ----
+    if constexpr (DMA) {
+        const uint32_t tj = gridDim.x - 1u - blockIdx.x;
+        if (tj < ntail) {
+            static_assert(sizeof(sh_R_all) >= sizeof(double) * 64 * LLPF_RBC_XTOT, "the exchange buffer lies in the workgroup's covariance slices");
+            tables_to_lds();
+            __syncthreads();                                   // the generator's tables, Bl u and y are in the LDS
+            double* const xb = reinterpret_cast<double*>(&sh_R_all[0][0]);
+            double* const xs = &sh_w_all[0][0];
+            const uint32_t ti = (nfull + tj) * (uint32_t)RBF_BLOCK + (uint32_t)t;
+            const int32_t tanc = do_res ? *rbf_at(ancf, ti) : 0;
+            const uint32_t tso = (do_res ? (uint32_t)tanc : ti) * 8u, tio = ti * 8u;
+            const bool has_corr = MODE != MODE_PROP && a.has_y != 0;
+            auto tst = [&](int row, double v) { wt_store(reinterpret_cast<double*>(reinterpret_cast<char*>(xo) + (tio + (uint32_t)row * stride)), v); };
+            double txn[NN], txl[NL];
+#pragma unroll
+            for (int d = 0; d < NN; ++d) txn[d] = ld(d, tso);
+#pragma unroll
+            for (int d = 0; d < NL; ++d) txl[d] = ld(NN + d, tso);
+            if (wvi == 0) {
+                // the nonlinear wave: noise, An(xn) xl, f_n(xn), the new xn, the measurement prediction, the weight
+                double twN = 0.0;
+                if (need_w) twN = *rbf_at(w, ti);
+                double xi[NN], tnz[NN], tfi[NN], tax[NN], txn1[NN];
+#if defined(LLPF_RBF_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+                { uint32_t hw_, xcc_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));
+                  g_rbf_dbg[(size_t)(nfull + tj) * 32 + 13] = hw_; g_rbf_dbg[(size_t)(nfull + tj) * 32 + 14] = xcc_; }
+#endif
+                RBF_TAILSTAMP_DEP(0, t);
+                RBF_TAILSTAMP_DEP(1, txl[NL - 1]);
+                Model mdl = prepared(ti);
+                llpf_normals_tab(ti, sb + a.step, LLPF_STREAM_DYNAMICS, k0, k1, NN, xi, sh_rng_lg, sh_rng_sc);
+                gauss_sample_c<NN>((gauss_cptr)&md->df, xi, tnz);
+#pragma unroll
+                for (int d = 0; d < NN; ++d) xb[(LLPF_RBC_XNZ + d) * 64 + t] = tnz[d];
+                RBF_TAILSTAMP_DEP(2, tnz[NN - 1]);
+                __syncthreads();                               // 1
+                RBF_TAILSTAMP_DEP(3, t);
+                {
+                    llpf_rbf_cptr pp = RBF_KCPTR(par);
+#pragma unroll
+                    for (int r = 0; r < NN; ++r) {
+                        double arow[NL];
+#if defined(__HIP_DEVICE_COMPILE__)
+                        { const double dep_ = r == 0 ? tnz[NN - 1] : tax[r - 1]; asm volatile("" : "+s"(pp) : "v"(dep_)); }
+#endif
+                        llpf_rbf_coupling_row(pp, NN, NL, r, txn, arow);
+                        tax[r] = arow[0] * txl[0];
+#pragma unroll
+                        for (int c = 1; c < NL; ++c) tax[r] = llpf_fma(arow[c], txl[c], tax[r]);
+                    }
+                }
+                RBF_TAILSTAMP_DEP(4, tax[NN - 1]);
+                mdl.dynamics(txn, tfi);
+                RBF_TAILSTAMP_DEP(5, tfi[NN - 1]);
+#pragma unroll
+                for (int d = 0; d < NN; ++d) { const double z = tax[d] + tnz[d]; txn1[d] = tfi[d] + z; }      // llpf_rbf_predict: z = An xl + nz ; xn1 = fi + z
+                if (has_corr) {
+                    double yn[NY];
+                    prepared(txn1[0]).measurement(txn1, yn);
+#pragma unroll
+                    for (int q = 0; q < NY; ++q) xs[(LLPF_RBC_SYN + q) * 64 + t] = yn[q];
+                }
+                __syncthreads();                               // 2
+                RBF_TAILSTAMP_DEP(6, t);
+                __syncthreads();                               // 3
+                RBF_TAILSTAMP_DEP(7, t);
+                double tll = 0.0;
+                if (has_corr) {
+                    __syncthreads();                           // 4
+                    RBF_TAILSTAMP_DEP(8, t);
+                    __syncthreads();                           // 5
+                    RBF_TAILSTAMP_DEP(9, t);
+                    tll = xs[LLPF_RBC_SLL * 64 + t];
+                }
+#pragma unroll
+                for (int d = 0; d < NN; ++d) tst(d, txn1[d]);
+                if (MODE != MODE_PROP) {
+                    // the weight of the batch: as in the loop above
+                    WeightAcc wacc;
+                    wacc.init();
+                    const double wmx = do_res ? b.log1N : (uniform ? wconst : wmax_prev);
+                    const double off = a.has_y ? (wmx + sh_y[NY]) + RBF_BOUND_SLACK : wmx;
+                    double wv;
+                    if (do_res) wv = b.log1N;
+                    else if (uniform) wv = wconst;
+                    else wv = pend ? (twN - m) - l : twN;
+                    if (a.has_y) wv = wv + tll;
+                    if (ti >= (uint32_t)N) wv = -LLPF_INF;
+                    const bool bad = wv != wv;
+                    uint64_t qsum = 0;
+                    if (a.accumulate) qsum = wacc.add(wv, off, a.K, a.need_e2 != 0);
+                    *rbf_at(w, ti) = wv;
+                    if (a.accumulate) *rbf_at(qnf, ti) = qsum;
+                    const double r = wave_max(wv);
+                    const int anybad = __ballot(bad) != 0 ? 1 : 0;
+                    if (a.accumulate) {
+                        wacc.flush_wave(b.acc + (size_t)f * ACC_WORDS, a.parity, a.need_e2 != 0);
+                        qsum = wave_sum_u64(qsum);
+                    }
+                    if (t == 0) {
+                        if (a.accumulate && qsum) atomicAdd(reinterpret_cast<unsigned long long*>(tileq_slot(b, a.parity, f) + (ti / TILE)), (unsigned long long)qsum);
+                        acc_max(b.acc + (size_t)f * ACC_WORDS, a.parity, r, anybad != 0);
+                    }
+                }
+                RBF_TAILSTAMP_DEP(10, t);
+            } else {
+                // a Kalman wave: the columns c = k (mod 3) of the covariance — requested as full columns (the mirrored entries from their twins' planes)
+                const int kk = wvi - 1;
+                double tR[NP], txlo[NL], tRo[NP];
+                double ty[NY > 0 ? NY : 1];
+#pragma unroll
+                for (int q = 0; q < NY; ++q) ty[q] = has_corr ? sh_y[q] : 0.0;
+                auto role = [&](auto KC) {
+                    constexpr int K = decltype(KC)::value;
+#pragma unroll
+                    for (int c = 0; c < NL; ++c) {
+                        if (c % LLPF_RBC_NK != K) continue;
+#pragma unroll
+                        for (int r = 0; r < NL; ++r) tR[llpf_rbf_idx(r, c)] = ld(NN + NL + llpf_rbf_idx(r, c), tso);
+                    }
+                    llpf_rbc_kalman(par, NN, NL, NY, nu, K, has_corr ? 1 : 0, txn, txl, tR, uf, sh_blu, ty, txlo, tRo, xb, xs, t);
+#pragma unroll
+                    for (int c = 0; c < NL; ++c) {
+                        if (c % LLPF_RBC_NK != K) continue;
+                        tst(NN + c, txlo[c]);
+#pragma unroll
+                        for (int r = c; r < NL; ++r) tst(NN + NL + llpf_rbf_idx(r, c), tRo[llpf_rbf_idx(r, c)]);
+                    }
+                };
+                if (kk == 0) role(rbf_const<0>());
+                else if (kk == 1) role(rbf_const<1>());
+                else role(rbf_const<2>());
+            }
+            __syncthreads();                                   // the exchange buffer is the covariance slices of the waves' own batches again
+        }
+    }
+
 
     // Order of the requests.  Vector loads return in order, so whatever is requested AFTER a gather can only be waited for together
     // with all of it: the ancestor index goes first, then every particle-independent operand (generator tables, the row of Bl and u
     // of lane r < NL, y, the model's constants), then the planes; the Gaussian's operands come through scalar loads (a counter of
     // their own).  Behind the planes' issue: the generator (it needs nothing of them), then the dynamics (xn), then the recursion (R).
-    if (MODE != MODE_PROP && a.has_y && t <= NY) yv = t < NY ? hot_y[(size_t)f * a.y_stride + t] : md->dg.c0;
     if (need_w) wN = *rbf_at(w, i);
     RBF_TSTAMP(16, t);                 // prologue scalars back, ancestor and operands requested
     // 32-bit byte offsets from ONE uniform base per buffer (48 planes: 64-bit addresses would hold 96 registers and cost two
     // instructions each); the launcher checks that a filter's planes span less than 4 GB
-    const uint32_t stride = (uint32_t)Ns * 8u;
     uint32_t so = (do_res ? (uint32_t)anc_i : i) * 8u;
     RBF_TSTAMP(17, so);                // ancestor and operands back
-    // nontemporal: every plane is read once per launch (same box: 50.0 -> 47.3 us; only on the steps that do not resample: no better)
-    auto ld = [&](int row, uint32_t off) { return __builtin_nontemporal_load(reinterpret_cast<const double*>(reinterpret_cast<const char*>(xc) + (off + (uint32_t)row * stride))); };
     // the planes of one batch: xn, xl and the last NDIR planes of R into registers, the first NPD planes of R into LDS
     double xn[NN], xl[NL], RN[NDIR], fi[NN], nz[NN];
     auto request_regs = [&](uint32_t off) {
@@ -166,40 +374,10 @@ __global__ __launch_bounds__(RBF_BLOCK) __attribute__((amdgpu_waves_per_eu(NL >=
 #pragma unroll
     for (int d = 0; d < NPD; ++d) Rf[d] = ld(NN + NL + d, so);
 
-    // Bl u is particle-independent and nu a run-time number: formed once per wave (lane r: row r), read back by the time update from
-    // LDS (as a branch inside the unrolled body it cut the body into blocks that each kept their constants' SGPRs alive)
-    if (MODE != MODE_WEIGHT) {
-        sh_rng_sc[2 * t] = rt0; sh_rng_sc[2 * t + 1] = rt1;
-        if (t < LLPF_RNG_LG_ENTRIES) { sh_rng_lg[2 * t] = rt2; sh_rng_lg[2 * t + 1] = rt3; }
-        if (t < NL) {
-            double b2 = -0.0;                                        // llpf_rbf_blu_row: x + (-0.0) == x for every x
-            if (nu > 0) {
-                b2 = blv[0] * uv[0];
-#pragma unroll
-                for (int c = 1; c < 8; ++c) { const double t2 = llpf_fma(blv[c], uv[c], b2); b2 = c < nu ? t2 : b2; }
-            }
-            sh_blu[t] = b2;
-        }
-    }
-    if (MODE != MODE_PROP && a.has_y && t <= NY) sh_y[t] = yv;
+    tables_to_lds();
     __syncthreads();
     RBF_TSTAMP(18, t);                 // planes requested, tables in LDS
 
-    // The model's constants through scalar loads (their own counter: no place in the queue of the planes), where they are used: held
-    // across the loop they would sit in registers through the recursion.  The pointers pass an empty asm tied to a value of the batch
-    // in hand, so the loads can be neither hoisted out of the loop nor issued before that value exists.
-    auto prepared = [&](auto dep) {
-        Model mdl;
-#if defined(__HIP_DEVICE_COMPILE__)
-        const __attribute__((address_space(4))) ModelD* mk = (const __attribute__((address_space(4))) ModelD*)md;
-        const __attribute__((address_space(4))) double* uk = (const __attribute__((address_space(4))) double*)uf;
-        asm volatile("" : "+s"(mk), "+s"(uk) : "v"(dep));
-        mdl.prepare((const ModelD*)mk, (const double*)uk, a.t_prop);
-#else
-        mdl.prepare(md, uf, a.t_prop);
-#endif
-        return mdl;
-    };
     // what does not need the covariance: the noise of particle idx, then (xn back) the dynamics
     auto front = [&](uint32_t idx) {
         Model mdl;
@@ -218,14 +396,14 @@ __global__ __launch_bounds__(RBF_BLOCK) __attribute__((amdgpu_waves_per_eu(NL >=
 #endif
         }
     };
-    front(i);
-    if (DMA) {
+    if (active) front(i);
+    if (DMA && active) {
 #pragma unroll
         for (int d = 0; d < NPD; ++d) { sh_R[d * 128 + t] = (uint32_t)__double2loint(Rf[d]); sh_R[d * 128 + 64 + t] = (uint32_t)__double2hiint(Rf[d]); }
     }
 
-    for (;;) {
-        const bool has_next = DMA && bb + gstep < nbatch;          // uniform
+    for (; active;) {
+        const bool has_next = DMA && bb + gstep < nfull;           // uniform
         const uint32_t i_n = i + gstep * (uint32_t)RBF_BLOCK;
         const uint32_t io = i * 8u;
                 // written through (global_store ... sc1, kernels/reduce.hpp): the planes are the next launch's input; left dirty in the L2s they are
@@ -313,13 +491,13 @@ __global__ __launch_bounds__(RBF_BLOCK) __attribute__((amdgpu_waves_per_eu(NL >=
             if (need_w) wN = *rbf_at(w, i_n);
         }
         if (MODE != MODE_PROP) {
-            const double r = wave_max(bmax);                        // the workgroup is one wave
+            const double r = wave_max(bmax);                        // a batch is one wave
             const int anybad = __ballot(bad) != 0 ? 1 : 0;
             if (a.accumulate) {
                 wacc.flush_wave(b.acc + (size_t)f * ACC_WORDS, a.parity, a.need_e2 != 0);
                 qsum = wave_sum_u64(qsum);     // the wave's 64 particles lie in one 1024-particle tile
             }
-            if (threadIdx.x == 0) {
+            if (t == 0) {
                 if (a.accumulate && qsum) atomicAdd(reinterpret_cast<unsigned long long*>(tileq_slot(b, a.parity, f) + (i / TILE)), (unsigned long long)qsum);
                 acc_max(b.acc + (size_t)f * ACC_WORDS, a.parity, r, anybad != 0);
                 if (bb == 0) {
@@ -334,7 +512,7 @@ __global__ __launch_bounds__(RBF_BLOCK) __attribute__((amdgpu_waves_per_eu(NL >=
 #if defined(LLPF_RBF_TIMING) && defined(__HIP_DEVICE_COMPILE__)
         RBF_STAMP(12);
 #endif
-        if (MODE != MODE_WEIGHT && bb == 0 && threadIdx.x == 0) {
+        if (MODE != MODE_WEIGHT && bb == 0 && t == 0) {
             FilterScal* scw = b.scal + f;
             scw->anc_ident_s[b.anc_slot ^ 1] = do_res ? 0 : 1;
             scw->last_resampled = do_res;
@@ -344,8 +522,7 @@ __global__ __launch_bounds__(RBF_BLOCK) __attribute__((amdgpu_waves_per_eu(NL >=
         bb += gstep;
         i = i_n;
 #if defined(LLPF_RBF_TIMING) && defined(__HIP_DEVICE_COMPILE__)
-        if (threadIdx.x == 0) g_rbf_row = bb;
-        __syncthreads();
+        if (t == 0) g_rbf_row = bb;
         RBF_STAMP(0);
         { uint32_t hw_, xcc_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));
           g_rbf_dbg[(size_t)bb * 32 + 13] = hw_; g_rbf_dbg[(size_t)bb * 32 + 14] = xcc_; g_rbf_dbg[(size_t)bb * 32 + 15] = 1; }
