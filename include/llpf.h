@@ -33,8 +33,10 @@ extern "C" {
 #endif
 
 #define LLPF_VERSION_MAJOR 0
-#define LLPF_VERSION_MINOR 4
-#define LLPF_MAX_DIM 8
+#define LLPF_VERSION_MINOR 5
+#define LLPF_MAX_DIM 16       /* states and outputs of a model (round 5: 8 -> 16; above 4 the linear-Gaussian model and every user model are compiled at run time) */
+#define LLPF_MAX_INPUTS 8     /* inputs u */
+#define LLPF_RB_MAX_LINEAR 8  /* linear states of LLPF_MODEL_RB_BILINEAR */
 
 /* status codes */
 enum {
@@ -61,7 +63,7 @@ typedef struct llpf_gaussian {
 
 /* built-in models */
 enum {
-    LLPF_MODEL_LINEAR_GAUSSIAN = 0,  /* f = A x + B u, g = C x  (reference examples/example_lineargaussian.jl:28-29); nx, ny, nu in 1..8 (nu from 0):
+    LLPF_MODEL_LINEAR_GAUSSIAN = 0,  /* f = A x + B u, g = C x  (reference examples/example_lineargaussian.jl:28-29); nx, ny in 1..16, nu in 0..8:
                                       * precompiled up to 4 (one fused launch per timestep), compiled on demand through hiprtc above (two launches) */
     LLPF_MODEL_QUADTANK_RK4    = 1,  /* quad-tank, RK4          (reference examples/example_quadtank.jl:8-35, src/utils.jl:220-237) */
     /* Rao-Blackwellized particle filter with constant matrices (reference src/rbpf.jl:63-283, "model 2" of :92-98):
@@ -77,7 +79,7 @@ enum {
      *   xl' = Al xl + Bl u + wl,             y = g(xn) + Cl xl + e
      * llpf_model.nx = nxn <= 4 (what f_n, g and the densities df, d0 see); f_n / g are the linear-Gaussian descriptors A, B, C of this
      * struct sized for nxn (rb.fn_kind 0) or the quad-tank RK4 dynamics / measurement (rb.fn_kind 1, nxn = 4, ny = 2).
-     * nxl = rb.nxl <= 8, ny <= 2; dynamics_density = R1n (must be Gaussian), linear_noise = R1l, linear_initial = d0l.
+     * nxl = rb.nxl <= 8, ny <= 4 (round 5; 2 before); dynamics_density = R1n (must be Gaussian), linear_noise = R1l, linear_initial = d0l.
      * Shapes (nxn, nxl, ny) = (1,2,1), (2,2,2), (4,8,2) are precompiled, every other one is compiled through hiprtc when the filter is
      * built.  Banks and multi-GPU sweeps of such filters are provided (without weighted means); the auxiliary filter and the smoother are not. */
     LLPF_MODEL_RB_BILINEAR     = 3,
@@ -89,9 +91,9 @@ enum {
 typedef struct llpf_rb_coupling {
     int32_t nxl;                              /* number of linear states (1..8) */
     int32_t fn_kind;                          /* 0: f_n = A xn + B u, g = C xn;  1: quad-tank RK4 f_n, g (qt, supersample) */
-    double  Al[LLPF_MAX_DIM * LLPF_MAX_DIM];  /* nxl x nxl row-major: kf.A */
-    double  Bl[LLPF_MAX_DIM * LLPF_MAX_DIM];  /* nxl x nu  row-major: kf.B */
-    double  Cl[LLPF_MAX_DIM * LLPF_MAX_DIM];  /* ny  x nxl row-major: kf.C (must not be zero) */
+    double  Al[LLPF_RB_MAX_LINEAR * LLPF_RB_MAX_LINEAR];  /* nxl x nxl row-major: kf.A */
+    double  Bl[LLPF_RB_MAX_LINEAR * LLPF_MAX_INPUTS];     /* nxl x nu  row-major: kf.B */
+    double  Cl[LLPF_RB_MAX_LINEAR * LLPF_RB_MAX_LINEAR];  /* ny  x nxl row-major: kf.C (must not be zero) */
     double  An[5][32];                        /* An[0]: constant term; An[1+k]: multiplies xn[k]; each nxn x nxl row-major */
 } llpf_rb_coupling;
 
@@ -106,7 +108,7 @@ typedef struct llpf_model {
     int32_t model_id;
     int32_t nx, nu, ny;
     double  A[LLPF_MAX_DIM * LLPF_MAX_DIM];   /* nx x nx row-major (linear-Gaussian) */
-    double  B[LLPF_MAX_DIM * LLPF_MAX_DIM];   /* nx x nu row-major                   */
+    double  B[LLPF_MAX_DIM * LLPF_MAX_INPUTS]; /* nx x nu row-major                  */
     double  C[LLPF_MAX_DIM * LLPF_MAX_DIM];   /* ny x nx row-major                   */
     double  qt[LLPF_QT_COUNT];                /* quad-tank constants                 */
     int32_t supersample;                      /* rk4 supersample (reference src/utils.jl:220) */

@@ -4,7 +4,8 @@ import ctypes as C
 
 import numpy as np
 
-MAX_DIM = 8
+MAX_DIM = 16         # states / outputs (LLPF_MAX_DIM)
+MAX_INPUTS = 8       # inputs (LLPF_MAX_INPUTS)
 
 COV_SCAL, COV_DIAG, COV_FULL = 0, 1, 2
 MODEL_LINEAR_GAUSSIAN, MODEL_QUADTANK_RK4, MODEL_RB_LINEAR, MODEL_RB_BILINEAR = 0, 1, 2, 3
@@ -29,7 +30,7 @@ class RBCoupling(C.Structure):
 
 class Model(C.Structure):
     _fields_ = [("model_id", C.c_int32), ("nx", C.c_int32), ("nu", C.c_int32), ("ny", C.c_int32),
-                ("A", C.c_double * 64), ("B", C.c_double * 64), ("C", C.c_double * 64),
+                ("A", C.c_double * (MAX_DIM * MAX_DIM)), ("B", C.c_double * (MAX_DIM * MAX_INPUTS)), ("C", C.c_double * (MAX_DIM * MAX_DIM)),
                 ("qt", C.c_double * QT_COUNT),
                 ("supersample", C.c_int32), ("nxn", C.c_int32),
                 ("Ts", C.c_double),
@@ -121,8 +122,8 @@ def make_lg_model(A, B, Cm, df, dg, d0, Ts=1.0):
     nu = B.shape[1]
     if A.shape != (nx, nx) or Cm.shape != (ny, nx):
         raise ValueError("A must be nx x nx and C ny x nx")
-    if max(nx, nu, ny) > MAX_DIM:
-        raise ValueError("dimensions above %d are not supported" % MAX_DIM)
+    if max(nx, ny) > MAX_DIM or nu > MAX_INPUTS:
+        raise ValueError("more than %d states / outputs or %d inputs are not supported" % (MAX_DIM, MAX_INPUTS))
     m = Model()
     m.model_id = MODEL_LINEAR_GAUSSIAN
     m.nx, m.nu, m.ny = nx, nu, ny

@@ -34,7 +34,8 @@
 
 namespace llpf {
 
-constexpr int MAXD = LLPF_MAX_DIM;
+constexpr int MAXD = LLPF_MAX_DIM;        // states / outputs
+constexpr int MAXU = LLPF_MAX_INPUTS;     // inputs
 constexpr int BLOCK = 256;            // 4 wave64 per workgroup
 constexpr int STEP_PPT = 2;           // particles per thread per iteration in the step kernel (16-B vectors)
 constexpr int STEP_ITERS = 1;         // iterations per block  -> 512 particles per block
@@ -86,7 +87,7 @@ struct RBStep {
 enum { QTC_1A = 0, QTC_1A_SW, QTC_1B, QTC_1U, QTC_2A, QTC_2B, QTC_2U, QTC_3A, QTC_3U, QTC_4A, QTC_4U, QTC_TG, QTC_H, QTC_H2, QTC_H6, QTC_COUNT };
 struct ModelD {
     int32_t model_id, nx, nu, ny;
-    double A[MAXD * MAXD], B[MAXD * MAXD], C[MAXD * MAXD];
+    double A[MAXD * MAXD], B[MAXD * MAXU], C[MAXD * MAXD];
     double qt[LLPF_QT_COUNT];
     double qtc[QTC_COUNT];         // quad-tank: coefficients of the right-hand side and the RK4 step sizes, formed once on the host (host/densities.hpp)
     int32_t supersample, nxn;      // nxn: LLPF_MODEL_RB_LINEAR, number of nonlinear states (A = [Fn An; 0 Al], B = [Bn; Bl], C = [Gn Cl])

@@ -136,6 +136,7 @@ static int aux_predict_dev_advanced(Bank& b, const double* d_u, const double* d_
 // Single-call predict!(pf::AuxiliaryParticleFilter, u, y1, p, t): synchronous.  d_u / d_y1 are device pointers.
 static int aux_predict_dev(Bank& b, const double* d_u, const double* d_y1, bool has_y1, double t, int want_xm) {
     if (is_rb(b) || is_rbfull(b)) return fail(LLPF_ERR_ARG, "the auxiliary filter is not defined for the Rao-Blackwellized model");
+    if (b.nx > 8) return fail(LLPF_ERR_ARG, "the auxiliary filter is compiled for up to 8 states (this filter has " + std::to_string(b.nx) + ")");
     if (b.cfg.filter_kind == LLPF_ADVANCED_PARTICLE_FILTER) {
         if (b.aux_pending) CHK(bank_aux_correct(b, nullptr, AuxOuts{}, 0));
         return aux_predict_dev_advanced(b, d_u, d_y1, has_y1, t);

@@ -45,6 +45,14 @@ hipError_t launch_init(const BankDev& b, uint32_t step, int init_anc, hipStream_
         case 6: hipLaunchKernelGGL(k_init<6>, g, dim3(BLOCK), 0, s, b, b.models, b.scal, step, init_anc); break;
         case 7: hipLaunchKernelGGL(k_init<7>, g, dim3(BLOCK), 0, s, b, b.models, b.scal, step, init_anc); break;
         case 8: hipLaunchKernelGGL(k_init<8>, g, dim3(BLOCK), 0, s, b, b.models, b.scal, step, init_anc); break;
+        case 9: hipLaunchKernelGGL(k_init<9>, g, dim3(BLOCK), 0, s, b, b.models, b.scal, step, init_anc); break;
+        case 10: hipLaunchKernelGGL(k_init<10>, g, dim3(BLOCK), 0, s, b, b.models, b.scal, step, init_anc); break;
+        case 11: hipLaunchKernelGGL(k_init<11>, g, dim3(BLOCK), 0, s, b, b.models, b.scal, step, init_anc); break;
+        case 12: hipLaunchKernelGGL(k_init<12>, g, dim3(BLOCK), 0, s, b, b.models, b.scal, step, init_anc); break;
+        case 13: hipLaunchKernelGGL(k_init<13>, g, dim3(BLOCK), 0, s, b, b.models, b.scal, step, init_anc); break;
+        case 14: hipLaunchKernelGGL(k_init<14>, g, dim3(BLOCK), 0, s, b, b.models, b.scal, step, init_anc); break;
+        case 15: hipLaunchKernelGGL(k_init<15>, g, dim3(BLOCK), 0, s, b, b.models, b.scal, step, init_anc); break;
+        case 16: hipLaunchKernelGGL(k_init<16>, g, dim3(BLOCK), 0, s, b, b.models, b.scal, step, init_anc); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -68,6 +76,14 @@ hipError_t launch_norm(const BankDev& b, int parity, int want_xmean, int need_e2
         case 6: launch_norm_e2<6, true>(b, parity, need_e2, step, only_fallback, bound, kstep, s); break;
         case 7: launch_norm_e2<7, true>(b, parity, need_e2, step, only_fallback, bound, kstep, s); break;
         case 8: launch_norm_e2<8, true>(b, parity, need_e2, step, only_fallback, bound, kstep, s); break;
+        case 9: launch_norm_e2<9, true>(b, parity, need_e2, step, only_fallback, bound, kstep, s); break;
+        case 10: launch_norm_e2<10, true>(b, parity, need_e2, step, only_fallback, bound, kstep, s); break;
+        case 11: launch_norm_e2<11, true>(b, parity, need_e2, step, only_fallback, bound, kstep, s); break;
+        case 12: launch_norm_e2<12, true>(b, parity, need_e2, step, only_fallback, bound, kstep, s); break;
+        case 13: launch_norm_e2<13, true>(b, parity, need_e2, step, only_fallback, bound, kstep, s); break;
+        case 14: launch_norm_e2<14, true>(b, parity, need_e2, step, only_fallback, bound, kstep, s); break;
+        case 15: launch_norm_e2<15, true>(b, parity, need_e2, step, only_fallback, bound, kstep, s); break;
+        case 16: launch_norm_e2<16, true>(b, parity, need_e2, step, only_fallback, bound, kstep, s); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -158,6 +174,14 @@ hipError_t launch_smooth_draw(const BankDev& b, const SmoothArgs& a, hipStream_t
         case 6: hipLaunchKernelGGL((k_smooth_draw<6>), g, dim3(BLOCK), 0, s, b, b.models, a); break;
         case 7: hipLaunchKernelGGL((k_smooth_draw<7>), g, dim3(BLOCK), 0, s, b, b.models, a); break;
         case 8: hipLaunchKernelGGL((k_smooth_draw<8>), g, dim3(BLOCK), 0, s, b, b.models, a); break;
+        case 9: hipLaunchKernelGGL((k_smooth_draw<9>), g, dim3(BLOCK), 0, s, b, b.models, a); break;
+        case 10: hipLaunchKernelGGL((k_smooth_draw<10>), g, dim3(BLOCK), 0, s, b, b.models, a); break;
+        case 11: hipLaunchKernelGGL((k_smooth_draw<11>), g, dim3(BLOCK), 0, s, b, b.models, a); break;
+        case 12: hipLaunchKernelGGL((k_smooth_draw<12>), g, dim3(BLOCK), 0, s, b, b.models, a); break;
+        case 13: hipLaunchKernelGGL((k_smooth_draw<13>), g, dim3(BLOCK), 0, s, b, b.models, a); break;
+        case 14: hipLaunchKernelGGL((k_smooth_draw<14>), g, dim3(BLOCK), 0, s, b, b.models, a); break;
+        case 15: hipLaunchKernelGGL((k_smooth_draw<15>), g, dim3(BLOCK), 0, s, b, b.models, a); break;
+        case 16: hipLaunchKernelGGL((k_smooth_draw<16>), g, dim3(BLOCK), 0, s, b, b.models, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -183,7 +207,8 @@ hipError_t launch_wmean(const BankDev& b, double* out, hipStream_t s) {
     return hipGetLastError();
 }
 hipError_t launch_wcov(const BankDev& b, const double* mean, double* out, hipStream_t s) {
-    hipLaunchKernelGGL(k_wcov, dim3((unsigned)b.F), dim3(BLOCK), 0, s, b, mean, out);
+    if (b.nx <= 8) hipLaunchKernelGGL((k_wcov<8>), dim3((unsigned)b.F), dim3(BLOCK), 0, s, b, mean, out);
+    else hipLaunchKernelGGL((k_wcov<MAXD>), dim3((unsigned)b.F), dim3(BLOCK), 0, s, b, mean, out);
     return hipGetLastError();
 }
 hipError_t launch_anc64(const BankDev& b, int64_t* dst, hipStream_t s) {

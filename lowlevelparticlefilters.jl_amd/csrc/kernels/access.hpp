@@ -92,6 +92,8 @@ __global__ __launch_bounds__(BLOCK) void k_wmean(BankDev b, double* out) {
 // n / ((n - 1) sum we), n = count(we != 0).  One block per filter, fixed order (thread-strided partial sums, a shuffle tree, four
 // wave sums added in order): the same bits whatever the launch geometry of the kernels that produced the weights.
 // `mean`: [F][nx] sum_i we_i x_i of the same state (k_wmean); out: [F][nx * nx] row-major.
+// MD: bound of the unrolled loops (8 for nx <= 8: 36 accumulators in registers; 16 above: 136, slower — an accessor, off the hot path)
+template <int MD>
 __global__ __launch_bounds__(BLOCK) void k_wcov(BankDev b, const double* mean, double* out) {
     __shared__ double sm_c[BLOCK / 64][MAXD * MAXD + 2];
     const int f = blockIdx.x;
@@ -112,21 +114,21 @@ __global__ __launch_bounds__(BLOCK) void k_wcov(BankDev b, const double* mean, d
     double stot = sm_c[0][0], ntot = sm_c[0][1];
     for (int k = 1; k < BLOCK / 64; ++k) { stot = stot + sm_c[k][0]; ntot = ntot + sm_c[k][1]; }
     __syncthreads();
-    double mu[MAXD];
+    double mu[MD];
 #pragma unroll
-    for (int d = 0; d < MAXD; ++d) mu[d] = d < nx ? mean[(size_t)f * nx + d] / stot : 0.0;
-    double acc[MAXD * (MAXD + 1) / 2];
+    for (int d = 0; d < MD; ++d) mu[d] = d < nx ? mean[(size_t)f * nx + d] / stot : 0.0;
+    double acc[MD * (MD + 1) / 2];
 #pragma unroll
-    for (int k = 0; k < MAXD * (MAXD + 1) / 2; ++k) acc[k] = 0.0;
+    for (int k = 0; k < MD * (MD + 1) / 2; ++k) acc[k] = 0.0;
     for (int64_t i = threadIdx.x; i < b.N; i += BLOCK) {
         const double wr = b.w[(size_t)f * b.Ns + i];
         const double we = sc->uniform ? 1.0 / (double)b.N : llpf_exp_le0(wr - sc->m) * sc->inv;
-        double dv[MAXD];
+        double dv[MD];
 #pragma unroll
-        for (int d = 0; d < MAXD; ++d) dv[d] = d < nx ? xc[(size_t)d * b.Ns + i] - mu[d] : 0.0;
+        for (int d = 0; d < MD; ++d) dv[d] = d < nx ? xc[(size_t)d * b.Ns + i] - mu[d] : 0.0;
         int k = 0;
 #pragma unroll
-        for (int r = 0; r < MAXD; ++r) {
+        for (int r = 0; r < MD; ++r) {
 #pragma unroll
             for (int c = 0; c <= r; ++c, ++k)
                 if (r < nx) acc[k] = acc[k] + (we * dv[r]) * dv[c];
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(BLOCK) void k_wcov(BankDev b, const double* mean, d
     {
         int k = 0;
 #pragma unroll
-        for (int r = 0; r < MAXD; ++r) {
+        for (int r = 0; r < MD; ++r) {
 #pragma unroll
             for (int c = 0; c <= r; ++c, ++k) {
                 const double v = wave_sum_f64(acc[k]);

@@ -34,9 +34,9 @@ static std::vector<JitModel*> g_jit_models;
 
 static int jit_compile_model(const char* device_src, int nx, int ny, bool internal, std::string& err);
 int jit_compile_user_model(const char* device_src, int nx, int ny, std::string& err) { return jit_compile_model(device_src, nx, ny, false, err); }
-// The linear-Gaussian model at dimensions the library was not precompiled for (nx or ny in 5..8; the reference is generic in the
+// The linear-Gaussian model at dimensions the library was not precompiled for (nx or ny in 5..16; the reference is generic in the
 // state dimension, src/PFtypes.jl:65-75): the engine's own LinGauss<NX, NY> compiled on demand like a user model, cached per shape.
-// Such filters run the balanced form (k_resample + the compiled k_step); k_init / k_norm / the auxiliary second half exist for 1..8.
+// Such filters run the balanced form (k_resample + the compiled k_step); k_init / k_norm / the smoother's draw exist for 1..16, the auxiliary filter's second half for 1..8.
 int jit_builtin_lg(int nx, int ny, std::string& err) {
     const std::string src = "struct UserModel : LinGauss<" + std::to_string(nx) + ", " + std::to_string(ny) + "> {};\n"
                             "template <> struct share_dynamics<UserModel> { static constexpr bool value = false; };\n";
@@ -47,7 +47,7 @@ static int jit_compile_model(const char* device_src, int nx, int ny, bool intern
     // the kernels around the compiled k_step (k_init, k_norm with the weighted mean, k_resample, the auxiliary second half) are
     // precompiled for 1..4 state and measurement dimensions
     if (!internal && (nx < 1 || nx > 4 || ny < 1 || ny > 4)) { err = "user models: nx and ny must be in 1..4"; return -1; }
-    if (nx < 1 || nx > MAXD || ny < 1 || ny > MAXD) { err = "nx, ny must be in 1..8"; return -1; }
+    if (nx < 1 || nx > MAXD || ny < 1 || ny > MAXD) { err = "nx, ny must be in 1..16"; return -1; }
     {   // parameter sweeps and PMMH loops rebuild filters with the same snippet: compile once
         std::lock_guard<std::mutex> lk(g_jit_mutex);
         for (size_t k = 0; k < g_jit_models.size(); ++k)

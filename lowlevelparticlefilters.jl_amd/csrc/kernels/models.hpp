@@ -142,16 +142,16 @@ struct LinGauss {   // f = A x .+ B u ; g = C x   (reference examples/example_li
         has_u = nu > 0 && u != nullptr;
         // the input row first, as independent loads (no wait between them), then B u in the reference's order
         // (measured: ONE block with every operand requested at once and the columns selected is slower, C2 21.14 against 20.7 us)
-        double ur[MAXD];
+        double ur[MAXU];
 #pragma unroll
-        for (int c = 0; c < MAXD; ++c) ur[c] = (has_u && c < nu) ? u[c] : 0.0;
+        for (int c = 0; c < MAXU; ++c) ur[c] = (has_u && c < nu) ? u[c] : 0.0;
 #pragma unroll
         for (int r = 0; r < NX; ++r) {
             double acc = 0.0;
             if (has_u) {
                 acc = m->B[r * nu + 0] * ur[0];
 #pragma unroll
-                for (int c = 1; c < MAXD; ++c)
+                for (int c = 1; c < MAXU; ++c)
                     if (c < nu) acc = acc + m->B[r * nu + c] * ur[c];
             }
             bu[r] = acc;

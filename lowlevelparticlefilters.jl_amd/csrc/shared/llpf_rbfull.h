@@ -15,7 +15,7 @@
 
 #define LLPF_RBF_MAXN 4
 #define LLPF_RBF_MAXL 8
-#define LLPF_RBF_MAXY 2
+#define LLPF_RBF_MAXY 4
 #define LLPF_RBF_NP(nl) ((nl) * ((nl) + 1) / 2)
 
 #if defined(__HIP_DEVICE_COMPILE__)

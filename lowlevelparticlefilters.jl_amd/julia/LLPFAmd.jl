@@ -38,14 +38,16 @@ export GPUParticleFilter, GPUAdvancedParticleFilter, GPUAuxiliaryParticleFilter,
        seed!, ancestors, last_resampled, set_parameters!
 
 const LIB = get(ENV, "LLPF_HIP_LIB", joinpath(@__DIR__, "..", "libllpf_hip.so"))
-const MAXD = 8
+const MAXD = 16          # LLPF_MAX_DIM: states / outputs
+const MAXU = 8           # LLPF_MAX_INPUTS
+const ND2 = MAXD * MAXD  # slots of a dim x dim matrix
 
 # ---- plain-data mirrors of include/llpf.h (field order and padding identical; checked by the static test) ------------
 struct CGaussian                      # llpf_gaussian
     dim::Int32
     kind::Int32                       # 0 ScalMat, 1 PDiagMat, 2 PDMat
-    mu::NTuple{8,Float64}
-    cov::NTuple{64,Float64}
+    mu::NTuple{16,Float64}
+    cov::NTuple{256,Float64}
 end
 struct CRBCoupling                    # llpf_rb_coupling (LLPF_MODEL_RB_BILINEAR only; zeroed otherwise)
     nxl::Int32
@@ -60,9 +62,9 @@ struct CModel                         # llpf_model
     nx::Int32
     nu::Int32
     ny::Int32
-    A::NTuple{64,Float64}
-    B::NTuple{64,Float64}
-    C::NTuple{64,Float64}
+    A::NTuple{256,Float64}
+    B::NTuple{128,Float64}
+    C::NTuple{256,Float64}
     qt::NTuple{16,Float64}
     supersample::Int32
     nxn::Int32
@@ -105,8 +107,10 @@ struct CMBankInfo                     # llpf_mbank_info_t
 end
 
 const ZERO64 = ntuple(_ -> 0.0, 64)
+const ZEROA = ntuple(_ -> 0.0, ND2)
+const ZEROB = ntuple(_ -> 0.0, MAXD * MAXU)
 const NOCOUPLING = CRBCoupling(0, 0, ZERO64, ZERO64, ZERO64, ntuple(_ -> 0.0, 160))
-const NOGAUSS = CGaussian(0, 0, ntuple(_ -> 0.0, 8), ZERO64)         # unused density slot
+const NOGAUSS = CGaussian(0, 0, ntuple(_ -> 0.0, MAXD), ZEROA)         # unused density slot
 
 pad(v, n) = ntuple(i -> i <= length(v) ? Float64(v[i]) : 0.0, n)
 rowmajor(M) = vec(permutedims(Matrix{Float64}(M)))                   # Julia is column-major, the ABI is row-major
@@ -146,11 +150,11 @@ function cgauss(d)
     n = length(g.mu)
     n <= MAXD || error("density dimension $n exceeds $MAXD")
     if g.cov isa Real
-        CGaussian(n, 0, pad(g.mu, 8), pad([g.cov], 64))
+        CGaussian(n, 0, pad(g.mu, MAXD), pad([g.cov], ND2))
     elseif g.cov isa AbstractVector
-        CGaussian(n, 1, pad(g.mu, 8), pad(g.cov, 64))
+        CGaussian(n, 1, pad(g.mu, MAXD), pad(g.cov, ND2))
     else
-        CGaussian(n, 2, pad(g.mu, 8), pad(rowmajor(g.cov), 64))
+        CGaussian(n, 2, pad(g.mu, MAXD), pad(rowmajor(g.cov), ND2))
     end
 end
 
@@ -303,8 +307,8 @@ function cmodel(f::UserDynamics, ::UserMeasurement, df, dg, d0, Ts; user_likelih
     end
     dfg = df isa UserNoise ? (df.gaussian === nothing ? GaussianSpec(zeros(f.nx), 1.0) : df.gaussian) : df
     d0g = d0 isa UserInitial ? GaussianSpec(zeros(f.nx), 1.0) : d0
-    CModel(id[], f.nx, f.nu, f.ny, pad(isempty(f.A) ? Float64[] : rowmajor(f.A), 64), pad(isempty(f.B) ? Float64[] : rowmajor(f.B), 64),
-           pad(isempty(f.C) ? Float64[] : rowmajor(f.C), 64), pad(f.qt, 16), f.supersample, 0, Ts, cgauss(dfg), cgauss(dg), cgauss(d0g),
+    CModel(id[], f.nx, f.nu, f.ny, pad(isempty(f.A) ? Float64[] : rowmajor(f.A), ND2), pad(isempty(f.B) ? Float64[] : rowmajor(f.B), MAXD * MAXU),
+           pad(isempty(f.C) ? Float64[] : rowmajor(f.C), ND2), pad(f.qt, 16), f.supersample, 0, Ts, cgauss(dfg), cgauss(dg), cgauss(d0g),
            NOGAUSS, NOGAUSS, NOCOUPLING)
 end
 
@@ -313,11 +317,11 @@ model_dims(::QuadTankDynamics, ::QuadTankMeasurement) = (4, 2, 2)
 
 function cmodel(f::LinearDynamics, g::LinearMeasurement, df, dg, d0, Ts)
     nx, nu, ny = model_dims(f, g)
-    CModel(0, nx, nu, ny, pad(rowmajor(f.A), 64), pad(nu > 0 ? rowmajor(f.B) : Float64[], 64), pad(rowmajor(g.C), 64),
+    CModel(0, nx, nu, ny, pad(rowmajor(f.A), ND2), pad(nu > 0 ? rowmajor(f.B) : Float64[], MAXD * MAXU), pad(rowmajor(g.C), ND2),
            ntuple(_ -> 0.0, 16), 1, 0, Ts, cgauss(df), cgauss(dg), cgauss(d0), NOGAUSS, NOGAUSS, NOCOUPLING)
 end
 cmodel(f::QuadTankDynamics, ::QuadTankMeasurement, df, dg, d0, Ts) =
-    CModel(1, 4, 2, 2, ZERO64, ZERO64, ZERO64, f.consts, f.supersample, 0, Ts, cgauss(df), cgauss(dg), cgauss(d0),
+    CModel(1, 4, 2, 2, ZEROA, ZEROB, ZEROA, f.consts, f.supersample, 0, Ts, cgauss(df), cgauss(dg), cgauss(d0),
            NOGAUSS, NOGAUSS, NOCOUPLING)
 # RBPF: df = R1n, dg = R2, d0 = d0n (all of the nonlinear substate's dimension); A = [Fn An; 0 Al], B = [Bn; Bl], C = [Gn Cl]
 function cmodel(m::RBLinearModel, ::Nothing, df, dg, d0, Ts)
@@ -325,7 +329,7 @@ function cmodel(m::RBLinearModel, ::Nothing, df, dg, d0, Ts)
     An = m.An === nothing ? zeros(nn, nl) : m.An
     Cl = m.Cl === nothing ? zeros(ny, nl) : m.Cl
     A = [m.Fn An; zeros(nl, nn) m.Al]; B = [m.Bn; m.Bl]; C = [m.Gn Cl]
-    CModel(2, nn + nl, nu, ny, pad(rowmajor(A), 64), pad(rowmajor(B), 64), pad(rowmajor(C), 64), ntuple(_ -> 0.0, 16),
+    CModel(2, nn + nl, nu, ny, pad(rowmajor(A), ND2), pad(rowmajor(B), MAXD * MAXU), pad(rowmajor(C), ND2), ntuple(_ -> 0.0, 16),
            1, nn, Ts, cgauss(df), cgauss(dg), cgauss(d0), cgauss(GaussianSpec(zeros(nl), Matrix{Float64}(m.R1l))), cgauss(m.d0l), NOCOUPLING)
 end
 function cmodel(m::RBBilinearModel, ::Nothing, df, dg, d0, Ts)

@@ -707,7 +707,7 @@ static int rb_setup(orc_filter* f, int order) {
     }
     f->rb.zeroAn = 1; for (int i = 0; i < nn * nl; ++i) if (f->rb.An[i] != 0.0) f->rb.zeroAn = 0;   /* iszero(An), :175 */
     f->rb.zeroC = 1;  for (int i = 0; i < ny * nl; ++i) if (f->rb.Cl[i] != 0.0) f->rb.zeroC = 0;    /* iszero(C), :244 */
-    double tmp[64];
+    double tmp[MAXD * MAXD];
     gauss_cov_full(&m->linear_noise, tmp);       for (int i = 0; i < nl * nl; ++i) f->rb.R1l[i] = tmp[i];
     gauss_cov_full(&m->dynamics_density, tmp);   for (int i = 0; i < nn * nn; ++i) f->rb.R1nS[i] = tmp[i];
     gauss_cov_full(&m->measurement_density, tmp);for (int i = 0; i < ny * ny; ++i) f->rb.R2S[i] = tmp[i];
@@ -1769,7 +1769,7 @@ static void gauss_cov_full(const llpf_gaussian* g, double* S) {
 
 double orc_kalman_loglik(const llpf_model* m, const double* U, const double* Y, int64_t T) {
     int nx = m->nx, nu = m->nu, ny = m->ny;
-    double R1[64], R2[64], P[64], x[MAXD];
+    double R1[MAXD * MAXD], R2[MAXD * MAXD], P[MAXD * MAXD], x[MAXD];
     gauss_cov_full(&m->dynamics_density, R1);
     gauss_cov_full(&m->measurement_density, R2);
     gauss_cov_full(&m->initial_density, P);
@@ -1780,7 +1780,7 @@ double orc_kalman_loglik(const llpf_model* m, const double* U, const double* Y, 
         const double* y = Y + k * ny;
         if (y[0] == y[0]) {
             /* e = y - C x ; S = sym(C P C') + R2 */
-            double e[MAXD], CP[64], S[64], Lc[MAXD * MAXD];
+            double e[MAXD], CP[MAXD * MAXD], S[MAXD * MAXD], Lc[MAXD * MAXD];
             for (int r = 0; r < ny; ++r) {
                 double cx = 0.0;
                 for (int c = 0; c < nx; ++c) cx += m->C[r * nx + c] * x[c];
@@ -1822,7 +1822,7 @@ double orc_kalman_loglik(const llpf_model* m, const double* U, const double* Y, 
             for (int i = 0; i < ny; ++i) quad += e[i] * z2[i];
             LL += -((double)ny * log(2.0 * 3.141592653589793) + logdet) / 2.0 - quad / 2.0;
             /* K = P C' Sinv ; x += K e ; P = sym((I - K C) P) */
-            double K[64], KC[64], Pn[64];
+            double K[MAXD * MAXD], KC[MAXD * MAXD], Pn[MAXD * MAXD];
             for (int r = 0; r < nx; ++r) {
                 /* row r of P C' is CP[:, r]; solve S k' = (P C')[r,:]' */
                 double b[MAXD], t1[MAXD], t2[MAXD];
@@ -1860,7 +1860,7 @@ double orc_kalman_loglik(const llpf_model* m, const double* U, const double* Y, 
                 for (int c = 0; c < nx; ++c) P[r * nx + c] = 0.5 * (Pn[r * nx + c] + Pn[c * nx + r]);
         }
         /* x = A x + B u (+ mean of df) ; P = sym(A P A') + R1 */
-        double xn[MAXD], AP[64], Pn[64];
+        double xn[MAXD], AP[MAXD * MAXD], Pn[MAXD * MAXD];
         for (int r = 0; r < nx; ++r) {
             double a = 0.0;
             for (int c = 0; c < nx; ++c) a += m->A[r * nx + c] * x[c];

@@ -595,14 +595,20 @@ def test_invalid_run_arguments():
     g = _capi.FilterHandle(_cfg(model, 100))
     with pytest.raises(_capi.LLPFError):
         g.run(np.zeros((0, 1)), np.zeros((0, 1)), 0.0)           # empty trajectory
-    cfg = _cfg(S.make_lg_model(np.eye(9) * 0.5, None, np.eye(9)[:2], S.make_gaussian(np.zeros(9), 1.0),
-                               S.make_gaussian(np.zeros(2), 1.0), S.make_gaussian(np.zeros(9), 1.0)), 100) if S.MAX_DIM >= 9 else None
-    if cfg is not None:
-        with pytest.raises(_capi.LLPFError):
-            _capi.FilterHandle(cfg)                              # above LLPF_MAX_DIM
+    n = S.MAX_DIM + 1
+    with pytest.raises(ValueError):                              # above LLPF_MAX_DIM: refused by the binding ...
+        S.make_lg_model(np.eye(n) * 0.5, None, np.eye(n)[:2], S.make_gaussian(np.zeros(2), 1.0), S.make_gaussian(np.zeros(2), 1.0), S.make_gaussian(np.zeros(2), 1.0))
+    bad = M.lg_test_model()
+    bad.nx = n
+    with pytest.raises(_capi.LLPFError):                         # ... and by the library
+        _capi.FilterHandle(_cfg(bad, 100))
+    bad = M.lg_test_model()
+    bad.nu = S.MAX_INPUTS + 1
+    with pytest.raises(_capi.LLPFError):
+        _capi.FilterHandle(_cfg(bad, 100))
 
 
-@pytest.mark.parametrize("nx,ny,nu", [(5, 2, 1), (2, 6, 0), (8, 8, 2)])
+@pytest.mark.parametrize("nx,ny,nu", [(5, 2, 1), (2, 6, 0), (8, 8, 2), (12, 4, 2), (16, 8, 2)])
 def test_linear_gaussian_above_the_precompiled_dimensions(nx, ny, nu):
     """The reference is generic in the state dimension (src/PFtypes.jl:65-75); the library is precompiled for nx, ny <= 4 and
     compiles LinGauss<nx, ny> on demand above that (kernels/jit.hpp: jit_builtin_lg): whole trajectories with weighted means,
@@ -630,7 +636,13 @@ def test_linear_gaussian_above_the_precompiled_dimensions(nx, ny, nu):
         assert g.update(U[k] if nu else None, Y[k], float(k)) == o.update(U[k] if nu else None, Y[k], float(k))
     _compare_state(g, o)
     g.reset(); o.reset()
-    assert np.array_equal(g.run_aux(U, Y, 1, ll_steps=True)["ll_steps"].view(np.uint64), o.run_aux(U, Y, 1, ll_steps=True)["ll_steps"].view(np.uint64))
+    if nx <= 8:
+        assert np.array_equal(g.run_aux(U, Y, 1, ll_steps=True)["ll_steps"].view(np.uint64), o.run_aux(U, Y, 1, ll_steps=True)["ll_steps"].view(np.uint64))
+    else:                                          # the auxiliary filter's second half is compiled for up to 8 states: refused above, loudly
+        with pytest.raises(_capi.LLPFError):
+            g.run_aux(U, Y, 1, ll_steps=True)
+        g.reset()
+        np.testing.assert_allclose(g.weighted_cov(), np.cov(g.particles().T), rtol=1e-9, atol=1e-12)      # k_wcov<16>: uniform weights after reset!
     b = _capi.BankHandle(cfg, [model, model, model])
     b.reset()
     g2 = _capi.FilterHandle(_cfg(model, 3000, thr=0.5, seed=79)); g2.reset()

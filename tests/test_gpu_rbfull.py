@@ -28,6 +28,8 @@ CASES = {
     "lin_2_2_2": lambda: M.linear_case(2, 2, 2, seed=1)[0],
     "lin_4_8_2": lambda: M.linear_case(4, 8, 2, seed=1)[0],
     "quadtank_4_8_2": lambda: M.quadtank_case(),
+    "lin_2_3_3": lambda: M.linear_case(2, 3, 3, seed=1)[0],          # three and four outputs (round 5): compiled on demand
+    "lin_4_8_4": lambda: M.linear_case(4, 8, 4, seed=1)[0],
 }
 
 

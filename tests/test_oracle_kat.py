@@ -184,3 +184,29 @@ def test_shouldresample_at_an_exact_tie_both_orders(N):
             assert bool(o.shouldresample()) == expect
             o.predict([0.2], 0.0)
             assert o.resample_count() == (1 if expect else 0)
+
+
+def test_linear_gaussian_at_twelve_and_sixteen_states():
+    """Round 5: LLPF_MAX_DIM 8 -> 16 (the reference is generic in length(d0), src/PFtypes.jl:65-75).  Both oracle orders agree per step to
+    the north-star tolerance while their ancestries coincide, the filter tracks (its log-likelihood is within Monte-Carlo distance of the
+    Kalman filter's, test/runtests.jl:447's bound scaled by the run length), on 12 x 4 and 16 x 8 systems."""
+    import oracle_binding as ob
+    from llpf_amd import _structs as S
+    import models as M
+    for nx, ny, nu in ((12, 4, 2), (16, 8, 2)):
+        rng = np.random.default_rng(100 + nx + ny)
+        A = 0.9 * np.linalg.qr(rng.standard_normal((nx, nx)))[0]
+        B = 0.2 * rng.standard_normal((nx, nu))
+        Cm = rng.standard_normal((ny, nx))
+        model = S.make_lg_model(A, B, Cm, S.make_gaussian(np.zeros(nx), 0.05), S.make_gaussian(np.zeros(ny), 0.5 + rng.random(ny)),
+                                S.make_gaussian(rng.standard_normal(nx), 1.0))
+        _, U, Y = M.simulate_lg(model, 25, seed=4)
+        cfg = S.make_config(model, 4000, S.PARTICLE_FILTER, S.RESAMPLE_SYSTEMATIC, 0.5, 77, 0)
+        lls = []
+        for order in (ob.ORDER_REFERENCE, ob.ORDER_DEVICE):
+            o = ob.OracleFilter(cfg, order)
+            o.reset()
+            lls.append(o.run(U, Y, 0.0, ll_steps=True)["ll_steps"])
+            assert np.all(np.isfinite(lls[-1])) and o.resample_count() > 2
+        assert np.max(np.abs(lls[0] - lls[1])[:8]) < 1e-10
+        assert abs(lls[0].sum() - ob.kalman_loglik(model, U, Y)) < 0.25 * abs(ob.kalman_loglik(model, U, Y))

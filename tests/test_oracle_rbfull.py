@@ -57,7 +57,7 @@ def test_all_linear_matches_kalman_filter():
 
 
 def test_state_dependent_coupling_orders_agree_and_covariances_differ():
-    for shape in ((1, 2, 1), (2, 2, 2), (4, 8, 2)):
+    for shape in ((1, 2, 1), (2, 2, 2), (4, 8, 2), (2, 3, 3), (4, 8, 4)):        # ny = 3, 4: round 5 (LLPF_RBF_MAXY 2 -> 4)
         m, _ = M.linear_case(*shape, seed=1)
         U, Y = M.simulate_io(m, 40)
         lls, Rs = [], []
