@@ -274,7 +274,7 @@ static int bank_create(const llpf_config* cfg, const llpf_model* models, int F, 
         return fail(LLPF_ERR_ARG, "n_particles must be in 1..2^29-2048");
     if (m0.nx < 1 || m0.nx > MAXD || m0.ny < 1 || m0.ny > MAXD || m0.nu < 0 || m0.nu > MAXU) return fail(LLPF_ERR_ARG, "bad dimensions (states and outputs 1.." + std::to_string(MAXD) + ", inputs 0.." + std::to_string(MAXU) + ")");
     if (!step_supported(m0.model_id, m0.nx, m0.ny))
-        return fail(LLPF_ERR_ARG, "no kernel instantiated for this model/dimension (linear-Gaussian nx,ny in 1..4; quad-tank 4/2)");
+        return fail(LLPF_ERR_ARG, "no kernel for this model / dimension (linear-Gaussian nx, ny in 1..16; quad-tank 4 / 2; Rao-Blackwellized: see llpf.h)");
     if (m0.model_id == LLPF_MODEL_RB_BILINEAR) {
         if ((uint64_t)rbfull_rows(m0.nx, m0.rb.nxl) * (uint64_t)((cfg->n_particles + TILE - 1) / TILE * TILE) * 8u >= ((uint64_t)1 << 32))
             return fail(LLPF_ERR_ARG, "LLPF_MODEL_RB_BILINEAR: the planes of one filter (rows x particles x 8 bytes) must span less than 4 GB");

@@ -28,7 +28,7 @@ namespace llpf {
 
 bool step_supported(int model_id, int nx, int ny) {
     if (model_id >= LLPF_MODEL_USER_BASE) return jit_supported(model_id, nx, ny);
-    if (model_id == LLPF_MODEL_RB_BILINEAR) return nx >= 1 && nx <= 4 && ny >= 1 && ny <= 2;   // shape checked by rbfull_supported
+    if (model_id == LLPF_MODEL_RB_BILINEAR) return nx >= 1 && nx <= LLPF_RBF_MAXN && ny >= 1 && ny <= LLPF_RBF_MAXY;   // shape checked by rbfull_supported
     if (model_id == LLPF_MODEL_QUADTANK_RK4) return nx == 4 && ny == 2;
     if (model_id == LLPF_MODEL_RB_LINEAR) return nx >= 2 && nx <= 4 && ny >= 1 && ny <= 4;
     if (model_id == LLPF_MODEL_LINEAR_GAUSSIAN) return nx >= 1 && nx <= MAXD && ny >= 1 && ny <= MAXD;   // above 4: compiled on demand (jit_builtin_lg)
