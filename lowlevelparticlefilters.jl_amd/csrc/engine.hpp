@@ -15,7 +15,7 @@
 //   quanta [F][Ns]         u64   q_i = floor(exp(w_i - m) 2^K), written by the normalise kernel so that the scan
 //                                kernel does not recompute exp (8 B/particle of extra traffic buys ~60 VALU instr.)
 //   tileq  [F][P2]         u64   per-tile sums of the resampling quanta (tile prefix for the scan kernel)
-//   xmpart [F][P1][8]      fp64  per-block sums e_i x_i (weighted_mean output only; never fed back)
+//   xmpart [3][F][P1][16]  fp64  per-block sums e_i x_i, one set per accumulator slot (weighted_mean output only; never fed back)
 //   scal   [F]             FilterScal    per-filter scalars (maxw, log1p(s), 1/(s+1), ESS, flags, ...)
 // Ns = N rounded up to a multiple of TILE (padding lanes carry zero weight).
 // The exp-weights `we` and the cumulative `bins` of the reference (src/PFtypes.jl:12,15) are never
@@ -160,7 +160,7 @@ struct BankDev {
     uint64_t* tileq;     // [ACC_NSLOT][F][P2] per-tile quanta sums, one set per accumulator slot
     uint32_t* bank_flag; // [1] 0, or 1 + the run-step index at which some filter's bound test failed: every later
                          //     launch of the run is a no-op until the host has redone that step in exact form
-    double* xmpart;      // [F][P1][MAXD]
+    double* xmpart;      // [ACC_NSLOT][F][P1][MAXD] (kernels/accum.hpp: xmpart_slot)
     double* lam;         // [F][Ns] lambda of the AuxiliaryParticleFilter predict! (nullptr until first used)
     uint64_t* rtile;     // [F][2][P2] residual resampling: per-tile copy counts / residual sums, then their inclusive prefixes
     int32_t anc_slot;    // n_predict & 1: index of the current FilterScal::anc_ident_s entry

@@ -341,7 +341,7 @@ static int bank_create(const llpf_config* cfg, const llpf_model* models, int F, 
         const size_t o_acc = take(sizeof(uint64_t) * (size_t)F * ACC_WORDS);
         const size_t o_q0 = take(sizeof(uint64_t) * FN), o_q1 = take(sizeof(uint64_t) * FN);
         const size_t o_tileq = take(sizeof(uint64_t) * (size_t)ACC_NSLOT * F * b.P2), o_flag = take(sizeof(uint32_t) * 4);
-        const size_t o_xmpart = take(sizeof(double) * (size_t)F * b.P1 * MAXD), o_rtile = take(sizeof(uint64_t) * (size_t)F * 2 * b.P2);
+        const size_t o_xmpart = take(sizeof(double) * (size_t)ACC_NSLOT * F * b.P1 * MAXD), o_rtile = take(sizeof(uint64_t) * (size_t)F * 2 * b.P2);
         const size_t o_rb = take(m0.model_id == LLPF_MODEL_RB_LINEAR ? sizeof(RBStep) * 2 * (size_t)F : 0);
         const size_t o_uy = take(sizeof(double) * 4 * MAXD);
         const size_t o_tmp = take(sizeof(double) * (size_t)F * b.N * (b.nxp > 1 ? b.nxp : 1) + 64);

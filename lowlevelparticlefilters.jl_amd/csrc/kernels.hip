@@ -62,8 +62,8 @@ template <int NX, bool XMEAN>
 static void launch_norm_e2(const BankDev& b, int parity, int need_e2, uint32_t step, int only_fallback, int bound, int64_t kstep, hipStream_t s) {
     dim3 g((unsigned)b.P2, (unsigned)b.F, 1);
     const int K = llpf_qbits(b.N);
-    if (need_e2) hipLaunchKernelGGL((k_norm<NX, XMEAN, true>), g, dim3(BLOCK), 0, s, b, K, parity, step, only_fallback, bound, kstep);
-    else hipLaunchKernelGGL((k_norm<NX, XMEAN, false>), g, dim3(BLOCK), 0, s, b, K, parity, step, only_fallback, bound, kstep);
+    if (need_e2) hipLaunchKernelGGL((k_norm<NX, XMEAN, true>), g, dim3(BLOCK), 0, s, LLPF_NORM_HOT_ARGS(b), kstep, K, parity, only_fallback, bound, step, b);
+    else hipLaunchKernelGGL((k_norm<NX, XMEAN, false>), g, dim3(BLOCK), 0, s, LLPF_NORM_HOT_ARGS(b), kstep, K, parity, only_fallback, bound, step, b);
 }
 hipError_t launch_norm(const BankDev& b, int parity, int want_xmean, int need_e2, uint32_t step, int only_fallback, int bound, int64_t kstep, hipStream_t s) {
     if (!want_xmean) { launch_norm_e2<0, false>(b, parity, need_e2, step, only_fallback, bound, kstep, s); return hipGetLastError(); }

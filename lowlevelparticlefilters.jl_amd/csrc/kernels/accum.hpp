@@ -46,6 +46,10 @@ DEV llpf_u128 acc_combine_u128(uint64_t a0, uint64_t a1, uint64_t a2) {
 }
 
 DEV uint64_t* tileq_slot(const BankDev& b, int slot, int f) { return b.tileq + ((size_t)slot * b.F + f) * b.P2; }
+// The per-block parts of the weighted mean belong to an accumulator slot like the sums they travel with: in the fused kernel tile 0's
+// head reads the parts of the PREVIOUS weighting while the other blocks of the same launch already store the next ones (round 5: one
+// set of parts was a read-after-write hazard between blocks of one launch whenever block 0 ran late; seen as a rare wrong xmean row).
+DEV double* xmpart_slot(const BankDev& b, int slot, int f) { return b.xmpart + ((size_t)slot * b.F + f) * b.P1 * MAXD; }
 
 // a launch of run-step k is a no-op when an EARLIER launch flagged a failed bound test (flag = 1 + its step)
 DEV bool run_is_stopped(const BankDev& b, int64_t k) {

@@ -23,9 +23,13 @@ template <bool WT = true, class T> DEV void wt_store(T* p, T v) {
     } else if constexpr (sizeof(T) == 16) {
         llpf_u32x4 r;
         __builtin_memcpy(&r, &v, 16);
-        // s_nop: a store of more than 64 bits needs one wait state before a VALU instruction may overwrite its data
-        // registers; the compiler keeps that hazard for its own stores but does not see into this one
-        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" : : "v"(p), "v"(r) : "memory");
+        // s_nop 1: on gfx940 / gfx950 a store of more than 64 bits needs TWO wait states before a VALU instruction may overwrite
+        // its data registers (one on gfx90a); the compiler keeps that hazard for its own stores (`s_nop 1` behind a
+        // global_store_dwordx4 whose registers it reuses: tools/r05, hz.hip) but does not see into this one.  With `s_nop 0`
+        // (rounds 1-4) the first of the two values of lanes 12-15 of every 16-lane row was, once in ~600 runs of a
+        // 10^6-particle filter, replaced by what the next instruction wrote into that register — the address of the next
+        // store — found by tools/fuzz_parity.py --big in round 5 (EXPERIMENTS 5.9, tools/r05/stress_hist.py).
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(r) : "memory");
     } else {
         __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }

@@ -299,7 +299,7 @@ DEV ResHead res_head(const BankDev& b, const ResArgs& a, int f, int tile, ResSha
     if (fin && a.xmean && tile == 0 && !h.status) {
         __syncthreads();
         const double invb = sh.dval[0];
-        const double* xp = b.xmpart + (size_t)f * b.P1 * MAXD;
+        const double* xp = xmpart_slot(b, a.parity, f);
         const int nparts = sc->xm_parts;
         for (int d = 0; d < b.nx; ++d) {
             double accx = 0.0;

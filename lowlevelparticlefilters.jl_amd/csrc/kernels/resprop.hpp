@@ -370,7 +370,7 @@ _Pragma("unroll") \
             __syncthreads();
             if (threadIdx.x < 8 && sh_tq[threadIdx.x])
                 atomicAdd(reinterpret_cast<unsigned long long*>(tq_next + tbase + threadIdx.x), (unsigned long long)sh_tq[threadIdx.x]);
-            if (st.want_xmean) block_store_xm<NX>(xm, b.xmpart + ((size_t)f * b.P1 + tile) * MAXD, sm_x);
+            if (st.want_xmean) block_store_xm<NX>(xm, xmpart_slot(b, st.parity, f) + (size_t)tile * MAXD, sm_x);
         }
         if (tile == 0 && threadIdx.x == 0) {
             if (AUX) {     // the weights just written are final values (no pending normalisation); aux_off bounds them

@@ -423,7 +423,7 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
     STEP_STAMP(5, bmax);                // weights, exp-sums, stores issued
     if (MODE != MODE_PROP) {
         block_flush(b.acc + (size_t)f * ACC_WORDS, a.parity, bmax, bad, wacc, a.accumulate != 0, a.need_e2 != 0, sm_fl);
-        if (a.accumulate && a.want_xmean) block_store_xm<NX>(xm, b.xmpart + ((size_t)f * b.P1 + blockIdx.x) * MAXD, sm_x);
+        if (a.accumulate && a.want_xmean) block_store_xm<NX>(xm, xmpart_slot(b, a.parity, f) + (size_t)blockIdx.x * MAXD, sm_x);
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             FilterScal* scw = b.scal + f;
             if (a.accumulate) scw->xm_parts = (int32_t)gridDim.x;

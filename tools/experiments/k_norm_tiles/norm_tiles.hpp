@@ -4,54 +4,27 @@
 // effective_particles resample.jl:1-2; optional weighted_mean filtering.jl:541-549)
 // ------------------------------------------------------------------------------------------------
 // The wave's first requests are addressed from preloaded SGPRs (kernarg preload covers the leading scalar arguments; a struct by value
-// in front switches it off): the weights of the tile leave with the first instructions, the filter's flags, the bound and the rest of
-// the argument block follow as ONE batch of scalar loads, and the flags are tested afterwards.  Written the other way round — and also
-// when the source merely asked for the weights first, without the fence below: the compiler sank the loads behind the tests — the
-// flags were four dependent scalar round trips in front of the weights' request (round 5, EXPERIMENTS 5.8).
+// in front switches it off): the weights of the tile, the filter's flags and the bound leave with the first instructions and are tested
+// afterwards.  Tested first — as the compiler arranged the same source without the fence below — the flags were four dependent
+// scalar round trips in front of the weights' request (round 5: the waves of this launch spend 40 % of their life parked).
 #define LLPF_NORM_HOT_PARAMS const double* hot_w, const FilterScal* hot_scal, const uint32_t* hot_flag, int64_t hot_Ns
 #define LLPF_NORM_HOT_ARGS(b) (b).w, (b).scal, (b).bank_flag, (b).Ns
+// One tile's elements of a thread: exp-weights against m, their fixed-point forms added to S / E2 / bad (carried by the caller),
+// the quanta stored, the tile's quanta sum and weighted state sums returned in Q / xm.
+// `refill`: the block has a further tile — the pair of weights just consumed is replaced by the next tile's (requested into the
+// registers it frees: the prefetch costs no registers and has the rest of this tile's arithmetic to arrive).
+// Addresses: a uniform base per tile and pair (scalar arithmetic) plus the thread's 32-bit byte offset — one address register for all.
 template <int NX, bool XMEAN, bool NEED_E2>
-__global__ __launch_bounds__(BLOCK) void k_norm(LLPF_NORM_HOT_PARAMS, int64_t kstep, int K, int parity, int only_fallback, int bound, uint32_t step, BankDev b) {
-    __shared__ uint64_t sm_u[BLOCK / 64][6];
-    __shared__ double sm_x[BLOCK / 64][MAXD];
-    const int f = blockIdx.y;
-    const int tile = blockIdx.x;
-    const double* __restrict__ w = hot_w + (size_t)f * hot_Ns;
-    double2 wv[NORM_IPT / 2];
+DEV void norm_tile(const BankDev& b, const double* __restrict__ xc, int f, int tile, int K, double m, double2* wv, const double* __restrict__ w, bool refill,
+                   llpf_u128& S, llpf_u128& E2, uint64_t& bad, uint64_t& Q, double* xm) {
+    const uint32_t toff = threadIdx.x * 16u;                                   // bytes: two doubles per thread
+    const char* wt = reinterpret_cast<const char*>(w + (size_t)(tile + 1) * TILE);            // the NEXT tile's weights
+    char* qt = reinterpret_cast<char*>(b.quanta + (size_t)f * b.Ns + (size_t)tile * TILE);
 #pragma unroll
     for (int k = 0; k < NORM_IPT / 2; ++k) {
-        const int64_t i0 = (int64_t)tile * TILE + (int64_t)k * (BLOCK * 2) + threadIdx.x * 2;
-        wv[k] = *reinterpret_cast<const double2*>(w + i0);
-    }
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("" ::: "memory");                 // the requests above are not to be sunk below the tests
-    // constant address space: scalar loads whatever the fence says about memory (these words are written by EARLIER launches only)
-    const __attribute__((address_space(4))) FilterScal* sc0 = (const __attribute__((address_space(4))) FilterScal*)(hot_scal + f);
-    const int fb_flag = sc0->fallback;
-    const uint32_t stop_flag = bound ? *(const __attribute__((address_space(4))) uint32_t*)hot_flag : 0u;
-    const double m_bound = sc0->off_slot[parity];
-    asm volatile("" : : "s"(fb_flag), "s"(stop_flag), "s"(m_bound), "s"(b.acc), "s"(b.quanta), "s"(b.Ns), "s"(b.tileq), "s"(b.P1), "s"(b.P2), "s"(b.xcur),
-                 "s"(b.xmpart));
-#else
-    const int fb_flag = 0; const uint32_t stop_flag = 0; const double m_bound = 0.0;
-#endif
-    if (only_fallback && !fb_flag) return;
-    if (bound && stop_flag != 0 && (int64_t)(stop_flag - 1) < kstep) return;      // run_is_stopped
-    if (bound && fb_flag) return;
-    uint64_t* acc = b.acc + (size_t)f * ACC_WORDS;
-    const double* __restrict__ xc = b.xcur + (size_t)f * NX * b.Ns;
-    const double m = bound ? m_bound : acc_read_max_wave(acc, parity);
-
-    llpf_u128 S = {0, 0}, E2 = {0, 0};
-    uint64_t Q = 0, bad = 0;
-    double xm[NX > 0 ? NX : 1];
-#pragma unroll
-    for (int d = 0; d < NX; ++d) xm[d] = 0.0;
-#pragma unroll
-    for (int k = 0; k < NORM_IPT / 2; ++k) {
-        const int64_t i0 = (int64_t)tile * TILE + (int64_t)k * (BLOCK * 2) + threadIdx.x * 2;
         const double e0 = llpf_exp_le0(wv[k].x - m);
         const double e1 = llpf_exp_le0(wv[k].y - m);
+        if (refill) wv[k] = *reinterpret_cast<const double2*>(wt + (size_t)k * (BLOCK * 16) + toff);
         bad += (e0 != e0) ? 1u : 0u;
         bad += (e1 != e1) ? 1u : 0u;
         S = llpf_u128_add(S, llpf_fix96_unit(e0));
@@ -63,10 +36,11 @@ __global__ __launch_bounds__(BLOCK) void k_norm(LLPF_NORM_HOT_PARAMS, int64_t ks
         ulonglong2 qv;
         qv.x = llpf_q64_unit(e0, K);
         qv.y = llpf_q64_unit(e1, K);
-        *reinterpret_cast<ulonglong2*>(b.quanta + (size_t)f * b.Ns + i0) = qv;
+        *reinterpret_cast<ulonglong2*>(qt + (size_t)k * (BLOCK * 16) + toff) = qv;
         Q += qv.x;
         Q += qv.y;
         if (XMEAN) {
+            const int64_t i0 = (int64_t)tile * TILE + (int64_t)k * (BLOCK * 2) + threadIdx.x * 2;
 #pragma unroll
             for (int d = 0; d < NX; ++d) {
                 const double2 xv = *reinterpret_cast<const double2*>(xc + (size_t)d * b.Ns + i0);
@@ -75,14 +49,92 @@ __global__ __launch_bounds__(BLOCK) void k_norm(LLPF_NORM_HOT_PARAMS, int64_t ks
             }
         }
     }
+}
+
+// A block takes `tpb` consecutive tiles of one filter (launch_norm: one when the launch has fewer tiles than the chip has block slots;
+// banks: as many as make the whole launch resident at once).  The integer sums S / E2 / bad do not depend on how they are grouped:
+// a thread carries them across its tiles and the block reduces them ONCE; what belongs to a tile — its quanta sum, its part of the
+// weighted mean — is reduced per tile exactly as before, so every output keeps its bits.  The next tile's weights are requested
+// before the current tile's arithmetic.  (Round 5: the one-tile form spent 100 of its 494 vector instructions per wave on the
+// reduction and 40 % of a wave's life parked behind its prologue and its only load.)
+template <int NX, bool XMEAN, bool NEED_E2, bool ONE_TILE>
+__global__ __launch_bounds__(BLOCK) void k_norm(LLPF_NORM_HOT_PARAMS, int64_t kstep, int K, int parity, int only_fallback, int bound, int tpb, uint32_t step, BankDev b) {
+    __shared__ uint64_t sm_u[BLOCK / 64][6];
+    __shared__ uint64_t sm_q[2][BLOCK / 64];
+    __shared__ double sm_x[2][BLOCK / 64][MAXD];
+    const int f = blockIdx.y;
+    const int tile0 = (int)blockIdx.x * tpb;
+    const double* __restrict__ w = hot_w + (size_t)f * hot_Ns;
+    double2 wv[NORM_IPT / 2];
+#pragma unroll
+    for (int k = 0; k < NORM_IPT / 2; ++k) {
+        const int64_t i0 = (int64_t)tile0 * TILE + (int64_t)k * (BLOCK * 2) + threadIdx.x * 2;
+        wv[k] = *reinterpret_cast<const double2*>(w + i0);
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" ::: "memory");                 // the requests above are not to be sunk below the tests
+    // constant address space: scalar loads whatever the fence above says about memory (written by EARLIER launches only)
+    const __attribute__((address_space(4))) FilterScal* sc0 = (const __attribute__((address_space(4))) FilterScal*)(hot_scal + f);
+    const int fb_flag = sc0->fallback;
+    const uint32_t stop_flag = bound ? *(const __attribute__((address_space(4))) uint32_t*)hot_flag : 0u;
+    const double m_bound = sc0->off_slot[parity];
+    asm volatile("" : : "s"(fb_flag), "s"(stop_flag), "s"(m_bound), "s"(b.acc), "s"(b.quanta), "s"(b.Ns), "s"(b.tileq), "s"(b.P1), "s"(b.P2), "s"(b.xcur),
+                 "s"(b.xmpart));      // one batch of scalar loads: the flags and what is left of the argument block
+#else
+    const int fb_flag = 0; const uint32_t stop_flag = 0; const double m_bound = 0.0;
+#endif
+    if (only_fallback && !fb_flag) return;
+    if (bound && stop_flag != 0 && (int64_t)(stop_flag - 1) < kstep) return;      // run_is_stopped
+    if (bound && fb_flag) return;
+    uint64_t* acc = b.acc + (size_t)f * ACC_WORDS;
+    const double* __restrict__ xc = b.xcur + (size_t)f * NX * b.Ns;
+    const double m = bound ? m_bound : acc_read_max_wave(acc, parity);
+    const int tile1 = (tile0 + tpb < b.P2) ? tile0 + tpb : b.P2;
+    const int lane = threadIdx.x & 63, wvid = threadIdx.x >> 6;
+
+    llpf_u128 S = {0, 0}, E2 = {0, 0};
+    uint64_t bad = 0;
     int exact = 0;
-    if (bound && gridDim.x == 1) {
-        // one-tile filter in the split schedule: the coming head's bound test is made here; if it fails the sums are
+    // what belongs to a tile: its quanta sum and its part of the weighted mean (LDS rows alternate: one barrier per tile)
+    auto tile_outputs = [&](int tile, int row, uint64_t Q, double* xm) {
+        Q = wave_sum_u64(Q);
+        if (XMEAN) {
+#pragma unroll
+            for (int d = 0; d < NX; ++d) xm[d] = wave_sum_f64(xm[d]);
+        }
+        if (lane == 0) {
+            sm_q[row][wvid] = Q;
+            if (XMEAN) {
+#pragma unroll
+                for (int d = 0; d < NX; ++d) sm_x[row][wvid][d] = xm[d];
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint64_t q = sm_q[row][0];
+            for (int k = 1; k < BLOCK / 64; ++k) q += sm_q[row][k];
+            tileq_slot(b, parity, f)[tile] = q;
+            if (XMEAN) {
+                for (int d = 0; d < NX; ++d) {
+                    double a = sm_x[row][0][d];
+                    for (int k = 1; k < BLOCK / 64; ++k) a = a + sm_x[row][k][d];
+                    b.xmpart[((size_t)f * b.P1 + tile) * MAXD + d] = a;
+                }
+            }
+        }
+    };
+    if (ONE_TILE) {
+        // one-tile filter in the split schedule (launch_norm: bound && P2 == 1): the coming head's bound test is made here; if it fails the sums are
         // redone at once against the true maximum (what the host would otherwise ask for in a separate launch)
         __shared__ double sm_m[BLOCK / 64];
+        uint64_t Q = 0;
+        double xm[NX > 0 ? NX : 1];
+#pragma unroll
+        for (int d = 0; d < NX; ++d) xm[d] = 0.0;
+        norm_tile<NX, XMEAN, NEED_E2>(b, xc, f, tile0, K, m, wv, w, false, S, E2, bad, Q, xm);
         const llpf_u128 sw = wave_sum_u128(S);
         const uint64_t bw = wave_sum_u64(bad);
-        if ((threadIdx.x & 63) == 0) { sm_u[threadIdx.x >> 6][0] = sw.lo; sm_u[threadIdx.x >> 6][1] = sw.hi; sm_u[threadIdx.x >> 6][5] = bw; }
+        if (lane == 0) { sm_u[wvid][0] = sw.lo; sm_u[wvid][1] = sw.hi; sm_u[wvid][5] = bw; }
         __syncthreads();
         llpf_u128 tot = {sm_u[0][0], sm_u[0][1]};
         uint64_t tb = sm_u[0][5];
@@ -102,68 +154,41 @@ __global__ __launch_bounds__(BLOCK) void k_norm(LLPF_NORM_HOT_PARAMS, int64_t ks
             S.lo = 0; S.hi = 0; E2.lo = 0; E2.hi = 0; Q = 0; bad = 0;
 #pragma unroll
             for (int d = 0; d < NX; ++d) xm[d] = 0.0;
+            norm_tile<NX, XMEAN, NEED_E2>(b, xc, f, tile0, K, mx, wv, w, false, S, E2, bad, Q, xm);
+        }
+        tile_outputs(tile0, 0, Q, xm);
+    } else {
+#pragma unroll 1
+        for (int tile = tile0; tile < tile1; ++tile) {
+            uint64_t Q = 0;
+            double xm[NX > 0 ? NX : 1];
 #pragma unroll
-            for (int k = 0; k < NORM_IPT / 2; ++k) {
-                const int64_t i0 = (int64_t)tile * TILE + (int64_t)k * (BLOCK * 2) + threadIdx.x * 2;
-                const double e0 = llpf_exp_le0(wv[k].x - mx);
-                const double e1 = llpf_exp_le0(wv[k].y - mx);
-                bad += (e0 != e0) ? 1u : 0u;
-                bad += (e1 != e1) ? 1u : 0u;
-                S = llpf_u128_add(S, llpf_fix96_unit(e0));
-                S = llpf_u128_add(S, llpf_fix96_unit(e1));
-                if (NEED_E2) {
-                    E2 = llpf_u128_add(E2, llpf_fix96_unit(e0 * e0));
-                    E2 = llpf_u128_add(E2, llpf_fix96_unit(e1 * e1));
-                }
-                ulonglong2 qv;
-                qv.x = llpf_q64_unit(e0, K);
-                qv.y = llpf_q64_unit(e1, K);
-                *reinterpret_cast<ulonglong2*>(b.quanta + (size_t)f * b.Ns + i0) = qv;
-                Q += qv.x;
-                Q += qv.y;
-                if (XMEAN) {
-#pragma unroll
-                    for (int d = 0; d < NX; ++d) {
-                        const double2 xv = *reinterpret_cast<const double2*>(xc + (size_t)d * b.Ns + i0);
-                        xm[d] = xm[d] + xv.x * e0;
-                        xm[d] = xm[d] + xv.y * e1;
-                    }
-                }
-            }
+            for (int d = 0; d < NX; ++d) xm[d] = 0.0;
+            norm_tile<NX, XMEAN, NEED_E2>(b, xc, f, tile, K, m, wv, w, tile + 1 < tile1, S, E2, bad, Q, xm);
+            tile_outputs(tile, (tile - tile0) & 1, Q, xm);
         }
     }
     S = wave_sum_u128(S);
     if (NEED_E2) E2 = wave_sum_u128(E2);
-    Q = wave_sum_u64(Q);
     bad = wave_sum_u64(bad);
-    if (XMEAN) {
-#pragma unroll
-        for (int d = 0; d < NX; ++d) xm[d] = wave_sum_f64(xm[d]);
-    }
-    const int lane = threadIdx.x & 63, wvid = threadIdx.x >> 6;
     if (lane == 0) {
         sm_u[wvid][0] = S.lo; sm_u[wvid][1] = S.hi;
         sm_u[wvid][2] = E2.lo; sm_u[wvid][3] = E2.hi;
-        sm_u[wvid][4] = Q; sm_u[wvid][5] = bad;
-        if (XMEAN) {
-#pragma unroll
-            for (int d = 0; d < NX; ++d) sm_x[wvid][d] = xm[d];
-        }
+        sm_u[wvid][5] = bad;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         llpf_u128 s = {sm_u[0][0], sm_u[0][1]}, e2 = {sm_u[0][2], sm_u[0][3]};
-        uint64_t q = sm_u[0][4], bd = sm_u[0][5];
+        uint64_t bd = sm_u[0][5];
         for (int k = 1; k < BLOCK / 64; ++k) {
             llpf_u128 t1 = {sm_u[k][0], sm_u[k][1]}, t2 = {sm_u[k][2], sm_u[k][3]};
             s = llpf_u128_add(s, t1);
             e2 = llpf_u128_add(e2, t2);
-            q += sm_u[k][4];
             bd += sm_u[k][5];
         }
         acc_add_u128(acc, ACC_S(parity), s);
         if (NEED_E2) acc_add_u128(acc, ACC_E2(parity), e2);
-        if (tile == 0) {   // the single uniform a systematic resample of this step consumes (reference: rand(), resample.jl:23)
+        if (tile0 == 0) {   // the single uniform a systematic resample of this step consumes (reference: rand(), resample.jl:23)
             FilterScal* sc = b.scal + f;
             sc->u_slot[parity] = llpf_uniform_step(sc->step_base + step, LLPF_STREAM_RESAMPLE, sc->k0, sc->k1);
             sc->e2v_slot[parity] = NEED_E2 ? 1 : 0;
@@ -171,14 +196,6 @@ __global__ __launch_bounds__(BLOCK) void k_norm(LLPF_NORM_HOT_PARAMS, int64_t ks
             sc->xm_parts = b.P2;
         }
         if (bd) atomicAdd(reinterpret_cast<unsigned long long*>(acc_slot(acc, ACC_BAD(parity), blockIdx.x & (NSHARD - 1))), (unsigned long long)bd);
-        tileq_slot(b, parity, f)[tile] = q;
-        if (XMEAN) {
-            for (int d = 0; d < NX; ++d) {
-                double a = sm_x[0][d];
-                for (int k = 1; k < BLOCK / 64; ++k) a = a + sm_x[k][d];
-                xmpart_slot(b, parity, f)[(size_t)tile * MAXD + d] = a;
-            }
-        }
     }
 }
 

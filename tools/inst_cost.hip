@@ -19,6 +19,12 @@ __global__ void k(double* out, int iters) {
             if (KIND == 5) { a = __builtin_sqrt(a) + 1.0; d = __builtin_sqrt(d) + 1.0; e = __builtin_sqrt(e) + 1.0; f = __builtin_sqrt(f) + 1.0; }
             if (KIND == 6) { p = p * q + 1; r = r * q + 1; s2 = s2 * q + 1; q = q * 3 + 1; }
             if (KIND == 7) { a = a * b; d = d + c; e = e * b; f = f + c; }
+            // round 5 (k_norm's fixed-point conversions): 64-bit shifts by a per-lane amount, 64-bit adds, selects, fp64 <-> u32 conversions, ldexp
+            if (KIND == 8) { x = (x >> ((uint32_t)z & 63)) ^ w; z = (z << ((uint32_t)w & 63)) ^ y; w = (w >> ((uint32_t)y & 63)) ^ x; y = (y << ((uint32_t)x & 63)) ^ z; }
+            if (KIND == 9) { x += z; z += w; w += y; y += x; }
+            if (KIND == 10) { p = (p > q) ? r : s2; r = (r > s2) ? q : p; s2 = (s2 > p) ? r : q; q = (q > r) ? p : s2; }
+            if (KIND == 11) { a = (double)(uint32_t)a + c; d = (double)(uint32_t)d + c; e = (double)(uint32_t)e + c; f = (double)(uint32_t)f + c; }
+            if (KIND == 13) { a = __builtin_rint(a) + c; d = __builtin_rint(d) + c; e = __builtin_rint(e) + c; f = __builtin_rint(f) + c; }
         }
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = a + d + e + f + g + h + (double)(x + z + w + y) + (double)(p + r + s2 + q);
@@ -47,5 +53,10 @@ int main() {
     run<3>("ds_bpermute_b32", 4);
     run<4>("fp64 divide", 4);
     run<5>("fp64 sqrt (+add)", 4);
+    run<8>("v_lsh{l,r}rev_b64 by VGPR + 2 v_xor_b32 (as one)", 4);
+    run<9>("64-bit add (add_co + addc)", 4);
+    run<10>("v_cmp_gt_u32 + v_cndmask_b32", 8);
+    run<11>("v_cvt_u32_f64 + v_cvt_f64_u32 + v_add_f64", 12);
+    run<13>("v_rndne_f64 + v_add_f64", 8);
     return 0;
 }
