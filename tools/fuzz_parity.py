@@ -23,6 +23,7 @@ def rand_cov(rng, n, scale):
     return S.make_gaussian(np.zeros(n), scale * (L @ L.T))
 
 
+HOOKED = None    # --hooked P: the share of cases with user hooks / Rao-Blackwellized models (default 0.2, none with --big unless given)
 BIG = False      # --big: few timesteps at 7e4 .. 1e6 particles (many tiles, several rounds of the persistent step kernel, heavy tiles)
 
 
@@ -95,10 +96,28 @@ def check(c):
             if not eq(ra["ll_steps"], rb["ll_steps"]):
                 why.append("aux ll_steps first diff at %s" % np.flatnonzero(ra["ll_steps"] != rb["ll_steps"])[:3])
         if c["driver"] == "history":
-            ra, rb = g.run(U, Y, t0, ll_steps=True, history=True), o.run(U, Y, t0, ll_steps=True, history=True)
+            want_cov = bool(c["seed"] & 2)
+            ra, rb = g.run(U, Y, t0, ll_steps=True, history=True, xcov=want_cov), o.run(U, Y, t0, ll_steps=True, history=True)
             for k in ("ll_steps", "x", "w", "we"):
                 if not eq(ra[k], rb[k]):
                     why.append("history " + k)
+            if want_cov and not why:                           # weighted_cov of every step against numpy on the history
+                for k in range(T):
+                    x, we = rb["x"][k], rb["we"][k]
+                    if not np.all(np.isfinite(we)) or not np.all(np.isfinite(x)):
+                        continue
+                    sw, nnz = we.sum(), np.count_nonzero(we)      # StatsBase's corrected covariance under probability weights (filtering.jl:571-581)
+                    if nnz < 2:
+                        continue
+                    mu = (x * we[:, None]).sum(axis=0) / sw
+                    ref = ((x - mu) * we[:, None]).T @ (x - mu) * (nnz / ((nnz - 1) * sw))
+                    if not np.allclose(ra["xcov"][k], ref, rtol=1e-8, atol=1e-12):
+                        why.append("xcov step %d" % k); break
+            if c["seed"] & 4 and not why and c["fam"] != "quadtank":   # the backward sampler on that history (FFBS, src/smoothing.jl:103-143)
+                Ms = min(c["N"], int(3 + (c["seed"] >> 3) % (6 if c["N"] > 50000 else 40)))        # M <= N (src/smoothing.jl:121)
+                xg, ig = g.smooth(Ms, U, ra["x"], ra["w"], ra["we"]); xo, io = o.smooth(Ms, U, rb["x"], rb["w"], rb["we"])
+                if not (eq(xg, xo) and eq(ig, io)):
+                    why.append("smoother (M=%d)" % Ms)
         if c["driver"] == "bank" and c["fam"] != "quadtank":
             ms = []
             for sc in c["bank_scales"]:
@@ -159,7 +178,8 @@ def check_hooked(rng):
     name = str(rng.choice([k for k in check_hooked.cases if k not in ("pf_lg_systematic", "pf_lg_stratified", "pf_quadtank")]))
     case = dict(check_hooked.cases[name])
     T = int(rng.integers(3, min(16, len(case["Y"])) + 1))
-    case.update(N=int(rng.choice([1, 63, 64, 65, 300, 1023, 1025, 2500])), thr=float(rng.choice([0.1, 0.5, 0.9, 1.0])),
+    sizes = [70001, 131077, 200000, 262145] if BIG else [1, 63, 64, 65, 300, 1023, 1025, 2500]
+    case.update(N=int(rng.choice(sizes)), thr=float(rng.choice([0.1, 0.5, 0.9, 1.0])),
                 strategy=int(rng.choice([S.RESAMPLE_SYSTEMATIC, S.RESAMPLE_STRATIFIED])), U=case["U"][:T], Y=case["Y"][:T])
     IC.SEED = int(rng.integers(1, 2 ** 31))
     try:
@@ -179,7 +199,7 @@ def sweep(cases, seed, verbose=True):
     rng = np.random.default_rng(seed)
     bad, drivers = [], {}
     for i in range(cases):
-        if rng.random() < 0.2 and not BIG:
+        if rng.random() < (HOOKED if HOOKED is not None else 0.2) and (not BIG or HOOKED is not None):
             drv, desc, why = check_hooked(rng)
             drivers["hooked"] = drivers.get("hooked", 0) + 1
             if why:
@@ -208,8 +228,10 @@ if __name__ == "__main__":
     ap.add_argument("--cases", type=int, default=300)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--big", action="store_true")
+    ap.add_argument("--hooked", type=float, default=None)
     a = ap.parse_args()
     BIG = a.big
+    HOOKED = a.hooked
     bad, drivers = sweep(a.cases, a.seed)
     print("%d cases (%s), %d failed (seed %d)" % (a.cases, ", ".join("%s %d" % kv for kv in sorted(drivers.items())), len(bad), a.seed))
     sys.exit(1 if bad else 0)
