@@ -134,6 +134,28 @@ def check(c):
                 of.reset()
                 if not eq(rb["ll_steps"][:, f].copy(), of.run(U, Y, t0, ll_steps=True)["ll_steps"]):
                     why.append("bank filter %d" % f)
+            if not why and c["N"] <= 300000:
+                # the same sweep sharded over 1..4 shards that share the device (filter k on shard k mod S): the unsharded bits
+                shards = 1 + (c["seed"] >> 5) % len(ms)                 # every shard needs a filter
+                mb = _capi.MBankHandle(cfg, ms, devices=[0] * shards)
+                mb.seed(c["seed"] + 3); mb.reset()                      # (seed + reset: the constructor's draw of the initial particles)
+                ll_m = np.asarray(mb.run(U, Y, t0)["ll"])
+                bank.seed(c["seed"] + 3); bank.reset()
+                ll_b = np.asarray(bank.run(U, Y, t0)["ll"])
+                if not eq(ll_m, ll_b):
+                    why.append("mbank over %d shards" % shards)
+                # new parameters for the existing bank = a fresh bank on them (llpf_bank_set_models)
+                ms2 = []
+                for m in ms[::-1]:
+                    m2 = S.Model.from_buffer_copy(bytes(m))
+                    for i in range(m2.nx * m2.nx):
+                        m2.A[i] = m2.A[i] * 0.9
+                    ms2.append(m2)
+                fresh = _capi.BankHandle(S.make_config(ms2[0], c["N"], c["kind"], c["strat"], c["thr"], c["seed"], 0), ms2)
+                bank.set_models(ms2)
+                bank.seed(99); bank.reset(); fresh.seed(99); fresh.reset()
+                if not eq(bank.run(U, Y, t0, ll_steps=True)["ll_steps"], fresh.run(U, Y, t0, ll_steps=True)["ll_steps"]):
+                    why.append("set_models")
         if c["driver"] in ("run", "run_twice", "run_then_steps"):
             for rep in range(2 if c["driver"] == "run_twice" else 1):
                 if rep:
@@ -153,6 +175,20 @@ def check(c):
                 if not (lg_ == lo_ or (lg_ != lg_ and lo_ != lo_)):
                     why.append("ll step %d: %r vs %r" % (k, lg_, lo_)); break
                 g.predict(u, t); o.predict(u, t)
+        if c["driver"] in ("run", "steps") and c["N"] >= 63 and c["seed"] & 8 and c["thr"] >= 0.5:
+            # weighted_quantile of the state the run left (src/filtering.jl:583-595), interior quantiles of a healthy weight vector.
+            # (Not compared: p = 0 and 1 and degenerate weights.  The engine's running sums are 2^-96 fixed point: particles lighter
+            # than 2^-96 of the heaviest carry no mass, so for p -> 0 it returns the LAST such value below the first particle with
+            # mass where StatsBase returns the smallest; and StatsBase's interpolation (h - S_{k-1}) / (S_k - S_{k-1}) cancels
+            # where w_k << S, in both implementations, to different roundings.)
+            qs = np.array([0.1, 0.25, 0.5, 0.75, 0.9])
+            qg, qo = g.weighted_quantile(qs), o.weighted_quantile(qs)
+            xs = o.particles()
+            spread = np.ptp(xs[np.isfinite(xs).all(axis=1)], axis=0) + 1.0 if np.isfinite(xs).all(axis=1).any() else 1.0
+            # (the engine's running sums are exact 2^-96 fixed point, the restated StatsBase algorithm sums in fp64: the interpolation
+            # weight differs by rounding where neighbouring weights are tiny)
+            if not np.all((np.abs(qg - qo) <= 1e-7 * spread) | (np.isnan(qg) & np.isnan(qo))):
+                why.append("weighted_quantile: max difference %g" % np.nanmax(np.abs(qg - qo)))
         for name, fg, fo in (("x", g.particles, o.particles), ("w", g.weights, o.weights), ("we", g.expweights, o.expweights), ("j", g.ancestors, o.ancestors)):
             vg, vo = np.ascontiguousarray(fg()), np.ascontiguousarray(fo())
             _note("engine", name, vg); _note("oracle", name, vo)
