@@ -7,11 +7,11 @@ ROOT=$PWD
 OUT=$ROOT/gpurun_out/r05s
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for w in bank quadtank lg; do
+for w in ${WORKLOADS:-bank quadtank lg}; do
   timeout 300 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU -d $OUT/pmc_sq_$w -o p -- python $ROOT/bench.py --workload $w --steps 1 --warmup 0 --T 100 --no-cpu-baseline > $OUT/pmc_sq_$w.log 2>&1
 done
 cd $ROOT
-for w in bank quadtank lg; do
+for w in ${WORKLOADS:-bank quadtank lg}; do
   python tools/rocprof_pmc_summary.py $OUT/pmc_sq_$w.txt $(find $OUT/pmc_sq_$w -name "*.db" | head -1)
   rm -rf $OUT/pmc_sq_$w
   grep -v "rocclr\|k_init\|k_post" $OUT/pmc_sq_$w.txt | cut -c1-60,70-200
