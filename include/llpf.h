@@ -9,7 +9,9 @@
  * is the identical binding in ctypes (the one the tests drive, since Julia is not in this image).
  *
  * Conventions
- *   - every function returns an int status (LLPF_OK == 0); no C++ exception crosses the ABI;
+ *   - every function returns an int status (LLPF_OK == 0); no C++ exception crosses the ABI
+ *     (every export is a function-try-block: std::bad_alloc -> LLPF_ERR_ALLOC, anything else ->
+ *     LLPF_ERR_INTERNAL; host threads of a multi-GPU bank catch inside the thread);
  *     llpf_last_error() returns a thread-local message for the last non-zero status.
  *   - all host pointers are borrowed for the duration of the call only.
  *   - the library owns all device memory behind the opaque handle; one handle = one device +
@@ -45,7 +47,8 @@ enum {
     LLPF_ERR_HIP        = 2,   /* HIP runtime error (message has the hipError string)    */
     LLPF_ERR_NO_DEVICE  = 3,   /* no gfx950 device visible: the engine has NO CPU fallback */
     LLPF_ERR_DEGENERATE = 4,   /* all weights -Inf or NaN (the reference would return NaN) */
-    LLPF_ERR_ALLOC      = 5
+    LLPF_ERR_ALLOC      = 5,   /* host or device memory could not be had (std::bad_alloc stops here) */
+    LLPF_ERR_INTERNAL   = 6    /* any other C++ exception of the host code, caught at the boundary; message = what() */
 };
 
 /* covariance storage kinds — mirror PDMats ScalMat / PDiagMat / PDMat, whose quadratic

@@ -96,7 +96,7 @@ SYMBOLS = {
     "llpf_selftest_normals": [C.c_int32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int32, _dp, C.c_int64],
 }
 
-OK, ERR_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_DEGENERATE, ERR_ALLOC = 0, 1, 2, 3, 4, 5
+OK, ERR_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_DEGENERATE, ERR_ALLOC, ERR_INTERNAL = 0, 1, 2, 3, 4, 5, 6
 PROF_CLASSES = 4
 
 

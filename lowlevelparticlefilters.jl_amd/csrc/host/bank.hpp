@@ -251,6 +251,7 @@ static int bank_create(const llpf_config* cfg, const llpf_model* models, int F, 
     if (!cfg) return fail(LLPF_ERR_ARG, "null config");
     if (cfg->struct_size != sizeof(llpf_config)) return fail(LLPF_ERR_ARG, "llpf_config.struct_size mismatch (ABI)");
     if (F < 1) return fail(LLPF_ERR_ARG, "n_filters must be >= 1");
+    test_throw("create");
     const llpf_model& m0 = models ? models[0] : cfg->model;
     if (m0.model_id == LLPF_MODEL_LINEAR_GAUSSIAN && (m0.nx > 4 || m0.ny > 4) && m0.nx >= 1 && m0.nx <= MAXD && m0.ny >= 1 && m0.ny <= MAXD) {
         // the linear-Gaussian model above the precompiled dimensions: LinGauss<nx, ny> compiled on demand (kernels/jit.hpp), after

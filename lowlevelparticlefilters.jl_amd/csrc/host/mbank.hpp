@@ -107,9 +107,22 @@ static int mbank_foreach(llpf_mbank& m, Fn fn) {
     std::vector<std::string> msg(S);
     std::vector<std::thread> th;
     th.reserve(S);
-    for (int s = 0; s < S; ++s)
-        th.emplace_back([&, s]() { rc[s] = fn(s); if (rc[s] != LLPF_OK) msg[s] = g_err; });
+    // nothing may leave a thread's function as an exception (std::terminate), and a thread that cannot be started is a status:
+    // the shards already started are joined, the others never run
+    int spawn_rc = LLPF_OK;
+    for (int s = 0; s < S && spawn_rc == LLPF_OK; ++s) {
+        try {
+            test_throw("thread");
+            th.emplace_back([&, s]() noexcept {
+                try { test_throw("shard"); rc[s] = fn(s); } catch (...) { rc[s] = guard_catch("shard worker"); }
+                if (rc[s] != LLPF_OK) { try { msg[s] = g_err; } catch (...) {} }
+            });
+        } catch (...) {
+            spawn_rc = guard_catch("starting a shard's host thread");
+        }
+    }
     for (auto& t : th) t.join();
+    if (spawn_rc != LLPF_OK) return spawn_rc;
     for (int s = 0; s < S; ++s)
         if (rc[s] != LLPF_OK) return fail(rc[s], "shard " + std::to_string(m.first_shard + s) + " (device " + std::to_string(m.shards[s]->device) + "): " + msg[s]);
     return LLPF_OK;

@@ -19,6 +19,7 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
     if (T < 1) return fail(LLPF_ERR_ARG, "T must be >= 1");
     if (!Y) return fail(LLPF_ERR_ARG, "Y is null");
     if (b.nu > 0 && !U) return fail(LLPF_ERR_ARG, "U is null");
+    test_throw("run");
     if ((x_hist || w_hist || we_hist) && b.F != 1) return fail(LLPF_ERR_ARG, "history outputs need a single filter");
     if (xcov && (b.F != 1 || is_rbfull(b))) return fail(LLPF_ERR_ARG, "the xcov output needs a single filter that is not LLPF_MODEL_RB_BILINEAR");
     if (xcov) CHK(ensure(&b.d_xcov, &b.cap_xc, (size_t)T * b.nx * b.nx + MAXD));

@@ -1,4 +1,18 @@
 """parked with the experiment (EXPERIMENTS.md 5.2): was part of tests/test_gpu_rbfull.py; green on the MI355X (29 passed, gpurun_out r05c / r05e)"""
+# (not collected: pytest.ini restricts collection to tests/, and the file name does not match test_*.py.  To run it, build the
+#  parked variant library of this directory, point LLPF_LIB at it and invoke pytest on this file explicitly.)
+import os
+import sys
+
+import numpy as np
+import pytest
+
+_ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", ".."))
+sys.path[:0] = [_ROOT, os.path.join(_ROOT, "tests")]
+from llpf_amd import _capi, _structs as S      # noqa: E402
+import oracle_binding as ob                     # noqa: E402
+import rbfull_models as M                       # noqa: E402
+from test_gpu_rbfull import CASES, _cfg, _same_bits, _compare_state, _compare_linear_state      # noqa: E402
 
 @pytest.mark.parametrize("name,strategy,tail", [("lin_4_8_2", S.RESAMPLE_SYSTEMATIC, 3), ("quadtank_4_8_2", S.RESAMPLE_SYSTEMATIC, 5),
                                                 ("quadtank_4_8_2", S.RESAMPLE_STRATIFIED, 1), ("lin_4_8_2", S.RESAMPLE_RESIDUAL, 7),
