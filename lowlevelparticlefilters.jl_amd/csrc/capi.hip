@@ -54,11 +54,15 @@ static void test_throw(const char* site) {
     if (!strncmp(e, "error", 5)) throw std::runtime_error(std::string("injected at ") + site);
     throw 42;
 }
+// (a failed runtime call also leaves its code in the runtime's "last error", which the next launch wrapper's hipGetLastError() would
+//  report as its own — a refused hipMalloc used to poison the handle's next, unrelated call: cleared here; out of memory is LLPF_ERR_ALLOC)
 #define HIPC(expr)                                                                                   \
     do {                                                                                             \
         hipError_t _e = (expr);                                                                      \
-        if (_e != hipSuccess)                                                                        \
-            return fail(LLPF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));            \
+        if (_e != hipSuccess) {                                                                      \
+            (void)hipGetLastError();                                                                 \
+            return fail(_e == hipErrorOutOfMemory ? LLPF_ERR_ALLOC : LLPF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+        }                                                                                            \
     } while (0)
 #define CHK(expr)                                                                                    \
     do {                                                                                             \

@@ -158,6 +158,8 @@ struct BankDev {
     uint64_t* quanta;    // [F][Ns]  quanta of the CURRENT weights (read by the scan)
     uint64_t* quanta_next; // [F][Ns] written by a weighting phase (ping-pong: other blocks may still read `quanta`)
     uint64_t* tileq;     // [ACC_NSLOT][F][P2] per-tile quanta sums, one set per accumulator slot
+    uint64_t* tpre;      // [F][P2] filters above 1024 tiles only (else nullptr): exclusive prefix of each tile's sum inside its group of
+    uint64_t* gsum;      // [F][ceil(P2/1024)] 1024 tiles, and the group totals — k_tile_prefix, in front of every kernel with a head
     uint32_t* bank_flag; // [1] 0, or 1 + the run-step index at which some filter's bound test failed: every later
                          //     launch of the run is a no-op until the host has redone that step in exact form
     double* xmpart;      // [ACC_NSLOT][F][P1][MAXD] (kernels/accum.hpp: xmpart_slot)
@@ -278,6 +280,7 @@ hipError_t launch_replicate_models(ModelD* models, int F, hipStream_t s);   // m
 // failed bound test: zero the exp-sums of `slot` (mode 0) / clear the flags (mode 1) of the filters that asked for the exact form
 hipError_t launch_fb_clear(const BankDev& b, int slot, int mode, hipStream_t s);
 hipError_t launch_resample(const BankDev& b, const ResArgs& a, hipStream_t s);
+hipError_t launch_tile_prefix(const BankDev& b, int parity, hipStream_t s);   // no-op up to 1024 tiles; kernels/resample.hpp: k_tile_prefix
 // resample with the dynamics evaluated on the SOURCE side, once per surviving particle (kernels/resfx.hpp): finalize + scan + counts,
 // f(x_j) -> BankDev::fxs and run-start marks -> BankDev::mark for the k_step launch that follows with StepArgs::marks = 1
 hipError_t launch_resample_fx(const BankDev& b, const ResArgs& a, const StepArgs& st, hipStream_t s);

@@ -22,6 +22,7 @@ struct Bank {
     uint64_t* d_quanta[2] = {nullptr, nullptr};
     int qcur = 0;                    // quanta buffer that holds the quanta of the current weights
     uint64_t* d_tileq = nullptr;
+    uint64_t *d_tpre = nullptr, *d_gsum = nullptr;      // filters above 1024 tiles: k_tile_prefix (kernels/resample.hpp)
     uint32_t* d_flag = nullptr;
     int64_t last_run_launches = 0, last_run_fx_steps = 0;
     double last_run_surv = -1.0;
@@ -95,7 +96,7 @@ struct Bank {
         b.mlogN = -llpf_log((double)N);
         b.models = d_models; b.scal = d_scal;
         b.xcur = d_x[cur]; b.xnext = d_x[cur ^ 1];
-        b.w = d_w; b.anc = d_anc; b.acc = d_acc; b.quanta = d_quanta[qcur]; b.quanta_next = d_quanta[qcur ^ 1]; b.tileq = d_tileq;
+        b.w = d_w; b.anc = d_anc; b.acc = d_acc; b.quanta = d_quanta[qcur]; b.quanta_next = d_quanta[qcur ^ 1]; b.tileq = d_tileq; b.tpre = d_tpre; b.gsum = d_gsum;
         b.bank_flag = d_flag; b.xmpart = d_xmpart; b.lam = d_lam; b.rtile = d_rtile; b.mark = d_mark; b.fxs = d_fxs; b.surv = d_surv;
         b.anc_slot = (int32_t)(n_predict & 1u);
         b.pad0 = (cfg.model.model_id == LLPF_MODEL_RB_BILINEAR) ? (cfg.model.rb.nxl | (cfg.model.rb.fn_kind << 8)) : 0;
@@ -344,6 +345,8 @@ static int bank_create(const llpf_config* cfg, const llpf_model* models, int F, 
         const size_t o_tileq = take(sizeof(uint64_t) * (size_t)ACC_NSLOT * F * b.P2), o_flag = take(sizeof(uint32_t) * 4);
         const size_t o_xmpart = take(sizeof(double) * (size_t)ACC_NSLOT * F * b.P1 * MAXD), o_rtile = take(sizeof(uint64_t) * (size_t)F * 2 * b.P2);
         const size_t o_rb = take(m0.model_id == LLPF_MODEL_RB_LINEAR ? sizeof(RBStep) * 2 * (size_t)F : 0);
+        const bool two_level = b.P2 > 4 * BLOCK;           // (kernels/resample.hpp: TQ_GROUP)
+        const size_t o_tpre = take(two_level ? sizeof(uint64_t) * (size_t)F * b.P2 : 0), o_gsum = take(two_level ? sizeof(uint64_t) * (size_t)F * ((b.P2 + 4 * BLOCK - 1) / (4 * BLOCK)) : 0);
         const size_t o_uy = take(sizeof(double) * 4 * MAXD);
         const size_t o_tmp = take(sizeof(double) * (size_t)F * b.N * (b.nxp > 1 ? b.nxp : 1) + 64);
         HIPC(hipMalloc(&b.d_pool, off));
@@ -357,6 +360,7 @@ static int bank_create(const llpf_config* cfg, const llpf_model* models, int F, 
         b.d_tileq = reinterpret_cast<uint64_t*>(base + o_tileq); b.d_flag = reinterpret_cast<uint32_t*>(base + o_flag);
         b.d_xmpart = reinterpret_cast<double*>(base + o_xmpart); b.d_rtile = reinterpret_cast<uint64_t*>(base + o_rtile);
         if (m0.model_id == LLPF_MODEL_RB_LINEAR) b.d_rb = reinterpret_cast<RBStep*>(base + o_rb);
+        if (two_level) { b.d_tpre = reinterpret_cast<uint64_t*>(base + o_tpre); b.d_gsum = reinterpret_cast<uint64_t*>(base + o_gsum); }
         b.d_uy = reinterpret_cast<double*>(base + o_uy); b.d_tmp = reinterpret_cast<double*>(base + o_tmp);
     }
     if (m0.model_id == LLPF_MODEL_RB_LINEAR) {

@@ -85,6 +85,7 @@ hipError_t launch_resprop(const BankDev& b, const ResArgs& a0, const StepArgs& s
     ResArgs a = a0;
     a.K = llpf_qbits(b.N);
     a.mode = RES_FINALIZE | RES_RESAMPLE;
+    { const hipError_t e = launch_tile_prefix(b, a.parity, s); if (e != hipSuccess) return e; }      // (above 1024 tiles)
 #endif
     // a run-time compiled model has no fused kernel: only the auxiliary second half (which propagates nothing: NoModel) may come here
     if (b.model_id >= LLPF_MODEL_USER_BASE && !st.aux) return hipErrorInvalidValue;

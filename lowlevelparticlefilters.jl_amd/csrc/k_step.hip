@@ -171,6 +171,7 @@ hipError_t launch_resample_fx(const BankDev& b, const ResArgs& a0, const StepArg
     if (!resample_fx_supported(b.model_id, b.nx, b.ny, b.strategy) || !b.mark || !b.fxs) return hipErrorInvalidValue;
     ResArgs a = a0;
     a.K = llpf_qbits(b.N);
+    { const hipError_t e = launch_tile_prefix(b, a.parity, s); if (e != hipSuccess) return e; }      // (above 1024 tiles)
     if (b.model_id >= LLPF_MODEL_USER_BASE) return launch_resample_fx_user(b, a, st, s);
     return launch_resample_fx_t<QuadTank<4, 2>, 4>(b, a, st, s);
 }

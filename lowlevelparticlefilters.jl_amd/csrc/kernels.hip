@@ -108,12 +108,20 @@ hipError_t launch_post_predict(const BankDev& b, hipStream_t s) {
     return hipGetLastError();
 }
 
+hipError_t launch_tile_prefix(const BankDev& b, int parity, hipStream_t s) {
+    if (b.P2 <= TQ_GROUP) return hipSuccess;          // a head reads the tile sums themselves
+    if (!b.tpre || !b.gsum) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_tile_prefix<0>, dim3((unsigned)((b.P2 + TQ_GROUP - 1) / TQ_GROUP), (unsigned)b.F, 1), dim3(BLOCK), 0, s, b, parity);
+    return hipGetLastError();
+}
+
 hipError_t launch_resample(const BankDev& b, const ResArgs& a0, hipStream_t s) {
     ResArgs a = a0;
     a.K = llpf_qbits(b.N);
     // a finalize-only launch needs just one block per filter
     dim3 g((a.mode & RES_RESAMPLE) ? (unsigned)b.P2 : 1u, (unsigned)b.F, 1);
     if (a.src_values) hipLaunchKernelGGL(k_qpart, dim3((unsigned)b.P2, (unsigned)b.F, 1), dim3(BLOCK), 0, s, b, a.K);
+    if (a.mode & RES_RESAMPLE) { const hipError_t e = launch_tile_prefix(b, a.parity, s); if (e != hipSuccess) return e; }      // (above 1024 tiles)
     if (b.strategy == LLPF_RESAMPLE_RESIDUAL && (a.mode & RES_RESAMPLE) && !a.only_bins) {
         const dim3 gt((unsigned)b.P2, (unsigned)b.F, 1), gf((unsigned)b.F, 1, 1);
         if (!a.src_values) {

@@ -17,25 +17,37 @@ typedef uint32_t llpf_u32x4 __attribute__((ext_vector_type(4)));
 #define LLPF_WT 1
 #endif
 template <bool WT = true, class T> DEV void wt_store(T* p, T v) {
+    static_assert(sizeof(T) <= 8, "16 bytes at once: wt_store2");
 #if LLPF_WT
-    if constexpr (!WT) {
-        *p = v;
-    } else if constexpr (sizeof(T) == 16) {
-        llpf_u32x4 r;
-        __builtin_memcpy(&r, &v, 16);
-        // s_nop 1: on gfx940 / gfx950 a store of more than 64 bits needs TWO wait states before a VALU instruction may overwrite
-        // its data registers (one on gfx90a); the compiler keeps that hazard for its own stores (`s_nop 1` behind a
-        // global_store_dwordx4 whose registers it reuses: tools/r05, hz.hip) but does not see into this one.  With `s_nop 0`
-        // (rounds 1-4) the first of the two values of lanes 12-15 of every 16-lane row was, once in ~600 runs of a
-        // 10^6-particle filter, replaced by what the next instruction wrote into that register — the address of the next
-        // store — found by tools/fuzz_parity.py --big in round 5 (EXPERIMENTS 5.9, tools/r05/stress_hist.py).
-        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(r) : "memory");
-    } else {
-        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if constexpr (!WT) *p = v;
+    else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #else
     *p = v;
 #endif
+}
+// Two consecutive 8-byte values, base[i] and base[i + 1], as ONE 16-byte write-through store (the two-particles-per-thread step kernel).
+// Rounds 1-5 wrote this instruction by hand (asm "global_store_dwordx4 ... sc1"): the compiler cannot see into an asm block, so the
+// wait states between the store and the next VALU write of its data registers were ours to keep — and were one short for gfx950
+// (two are needed for a store of more than 64 bits; one wrong particle in ~600 runs of a 10^6-particle filter for four rounds,
+// EXPERIMENTS 5.9).  Round 6: the same instruction class through a builtin the compiler schedules and pads itself — a raw buffer store
+// (128 bits, cache policy sc1) on a descriptor made from the UNIFORM plane base, the lane's byte offset in the VGPR; `base` must be
+// wave-uniform (a divergent one would be served by a waterfall loop).  Byte offsets fit 32 bits: Ns * 8 < 2^32 is checked at create.
+template <bool WT = true, class T> DEV void wt_store2(T* base, int64_t i, T a, T b) {
+    static_assert(sizeof(T) == 8, "two 8-byte values");
+#if LLPF_WT && defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (WT) {
+        llpf_u32x4 r;
+        __builtin_memcpy(&r, &a, 8);
+        __builtin_memcpy(reinterpret_cast<char*>(&r) + 8, &b, 8);
+        // dword 3 of the descriptor: raw buffer (no swizzle, no format conversion) as the compiler's own buffer accesses on gfx9 use it
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)0x7fffffff, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b128(r, rs, (int)((uint32_t)i * 8u), 0, 16 /* sc1 */);
+        return;
+    }
+#endif
+    struct alignas(16) Pair { T x, y; };
+    Pair v{a, b};
+    *reinterpret_cast<Pair*>(base + i) = v;
 }
 
 #define DPP_ROW_SHR(n) (0x110 + (n))

@@ -75,14 +75,37 @@ struct Mem {
         st(reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off), v);
     }
 };
-// block-uniform values a persistent kernel carries from one timestep to the next in registers (an ordinary launch reads
-// them from FilterScal, where tile 0 of the previous launch published them)
-struct StepCarry {
-    double off;        // offset (bound) the previous weighting phase used for its exp-sums   (FilterScal::off_slot)
-    int32_t e2v;       // it accumulated sum e^2                                                (FilterScal::e2v_slot)
-    int32_t status;    // sticky status                                                          (FilterScal::status)
-    const uint64_t* gq; // sums of the tile sums over groups of 32 tiles, one 128-B line each (nullptr: read every tile sum)
-};
+// ---- tile prefix above 1024 tiles --------------------------------------------------------------------------------
+// The head needs the sum of the tile sums in front of its tile and their total.  Up to 1024 tiles every block reads all of them
+// (four independent loads per thread; measured cheaper than any two-level form, EXPERIMENTS 5.4).  Above, that is a P2^2 burst —
+// 15 625 tiles at N = 1.6e7: 2 GB of L2 reads per timestep; 292 969 tiles at N = 3e8: 690 GB — where the reference's cumsum is
+// O(N) (src/resample.jl:19-22).  k_tile_prefix (one block per group of 1024 tiles, launched in front of every kernel with a head when
+// P2 > 1024) leaves the exclusive prefix of every tile inside its group and the group totals; a head then reads <= 512 group totals
+// (two per thread) and ONE prefix.  Integer sums: the same values whichever way they are added.
+constexpr int TQ_GROUP = 4 * BLOCK;                   // tiles per group = what one block scans with four tiles per thread
+static_assert(((int64_t)1 << 29) / TILE / TQ_GROUP <= 2 * BLOCK, "at most two group totals per thread of a head");
+DEV int tq_groups(int P2) { return (P2 + TQ_GROUP - 1) / TQ_GROUP; }
+template <int ONE_TU = 0>      // (a template so that the header can sit in several translation units; instantiated in kernels.hip only)
+__global__ __launch_bounds__(BLOCK) void k_tile_prefix(BankDev b, int parity) {
+    __shared__ uint64_t red[BLOCK / 64];
+    const int f = blockIdx.y, g = blockIdx.x, t = (int)threadIdx.x, lane = t & 63, wvid = t >> 6;
+    const uint64_t* __restrict__ tq = tileq_slot(b, parity, f);
+    const int p0 = g * TQ_GROUP + 4 * t;
+    uint64_t v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = (p0 + k < b.P2) ? tq[p0 + k] : 0;
+    const uint64_t tsum = (v[0] + v[1]) + (v[2] + v[3]);
+    const uint64_t incl = wave_scan_u64(tsum);
+    if (lane == 63) red[wvid] = incl;
+    __syncthreads();
+    uint64_t run = incl - tsum, tot = 0;
+#pragma unroll
+    for (int k = 0; k < BLOCK / 64; ++k) { if (k < wvid) run += red[k]; tot += red[k]; }
+    uint64_t* tp = b.tpre + (size_t)f * b.P2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { if (p0 + k < b.P2) tp[p0 + k] = run; run += v[k]; }
+    if (t == 0) b.gsum[(size_t)f * tq_groups(b.P2) + g] = tot;
+}
 
 // ---- shared machinery of the resample kernels -----------------------------------------------------------------
 struct __attribute__((aligned(16))) ResShared {   // LDS scratch
@@ -98,7 +121,7 @@ struct ResHead {                   // block-uniform results of res_head()
     double stot, e2;               // sum e_i (all particles), sum e_i^2 (-1: not accumulated)
     uint64_t prefix, tot;          // exclusive prefix of this tile's quanta, total of all quanta
     int dr, status, uniform, fast;
-    int has_u; double u_sys;       // systematic offset of this step supplied by the caller (persistent kernel)
+    int has_u; double u_sys;       // systematic offset of this step supplied by the caller
 };
 enum { RES_STATUS_FALLBACK = 100, RES_STATUS_SKIP = 101 };   // SKIP: this launch is a no-op for the filter   // internal: bound test failed, the host redoes this step in exact form
 
@@ -120,8 +143,7 @@ struct NoOverlap { DEV void operator()() const {} };
 // own scalar loads); it runs after the head's vector loads are issued and before the first of them is consumed
 template <int SRC, bool COH = false, class Overlap = NoOverlap>
 DEV ResHead res_head(const BankDev& b, const ResArgs& a, int f, int tile, ResShared& sh,
-                     bool defer_skip = false, uint32_t stop_flag = 0, int fb_flag = 0, const StepCarry* carry = nullptr,
-                     Overlap&& overlap = NoOverlap()) {
+                     bool defer_skip = false, uint32_t stop_flag = 0, int fb_flag = 0, Overlap&& overlap = NoOverlap()) {
     FilterScal* sc = b.scal + f;
     uint64_t* acc = b.acc + (size_t)f * ACC_WORDS;
     const int lane = threadIdx.x & 63, wvid = threadIdx.x >> 6;
@@ -131,10 +153,10 @@ DEV ResHead res_head(const BankDev& b, const ResArgs& a, int f, int tile, ResSha
     const bool fin = (a.mode & RES_FINALIZE) != 0;
     const bool unif0 = (SRC == SRC_FILTER) && !fin && sc->uniform;
     // scalars of the previous launch that are needed after the barrier below: fetched now, with the other loads
-    double off_pre = carry ? carry->off : sc->off_slot[a.parity];
-    int e2v_pre = carry ? carry->e2v : sc->e2v_slot[a.parity];
-    int exact_pre = carry ? 0 : sc->exact_slot[a.parity];
-    int status_pre = carry ? carry->status : sc->status;
+    double off_pre = sc->off_slot[a.parity];
+    int e2v_pre = sc->e2v_slot[a.parity];
+    int exact_pre = sc->exact_slot[a.parity];
+    int status_pre = sc->status;
 
     // loads.  wave 0: lane group g (8 lanes = 8 shards) fetches word g of this slot's accumulator set
     uint64_t accv = 0;
@@ -145,23 +167,19 @@ DEV ResHead res_head(const BankDev& b, const ResArgs& a, int f, int tile, ResSha
     const bool tq_small = b.P2 <= 4 * BLOCK;   // up to 1024 tiles: four INDEPENDENT loads per thread (a loop waits for every one in turn)
     const uint64_t* __restrict__ tq = tileq_slot(b, a.parity, f);
     uint64_t tqv[4] = {0, 0, 0, 0};
-    const uint64_t* gq = carry ? carry->gq : nullptr;
-    if (want_tq && gq) {
-        // two-level form: 32 group sums + the <= 31 tile sums before this tile inside its own group: one load per lane of
-        // wave 0 instead of P2 loads per block (P2 blocks reading all P2 tile sums is a P2^2 burst on 8 KB of memory)
-        const int t = (int)threadIdx.x, G = (b.P2 + 31) >> 5, gs = (tile >> 5) << 5;
-        if (t < G) tqv[0] = Mem<COH>::ld(gq + (size_t)t * 16);
-        else if (t >= 32 && t < 64 && gs + (t - 32) < b.P2) tqv[0] = Mem<COH>::ld(tq + gs + (t - 32));
-    } else if (want_tq && tq_small) {
+    if (want_tq && tq_small) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) { const int p = (int)threadIdx.x + j * BLOCK; tqv[j] = Mem<COH>::ld(tq + (p < b.P2 ? p : 0)); }
+    } else if (want_tq) {
+        // above 1024 tiles: the group totals and this tile's prefix inside its group, left by k_tile_prefix (launched in front of this kernel)
+        const int t = (int)threadIdx.x, G = tq_groups(b.P2);
+        const uint64_t* __restrict__ gs = b.gsum + (size_t)f * G;
+        tqv[0] = Mem<COH>::ld(gs + (t < G ? t : 0));
+        tqv[1] = Mem<COH>::ld(gs + (t + BLOCK < G ? t + BLOCK : 0));
+        if (t == 0) tqv[2] = Mem<COH>::ld(b.tpre + (size_t)f * b.P2 + tile);
     }
     overlap();
-    if (want_tq && gq) {
-        const int t = (int)threadIdx.x;
-        if (t < 32) { all = tqv[0]; pre = (t < (tile >> 5)) ? tqv[0] : 0; }
-        else if (t < 64) pre = ((t - 32) < (tile & 31)) ? tqv[0] : 0;
-    } else if (want_tq) {
+    if (want_tq) {
         if (tq_small) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -171,11 +189,10 @@ DEV ResHead res_head(const BankDev& b, const ResArgs& a, int f, int tile, ResSha
                 if (p < tile) pre += q;
             }
         } else {
-            for (int p = threadIdx.x; p < b.P2; p += BLOCK) {
-                const uint64_t q = Mem<COH>::ld(tq + p);
-                all += q;
-                if (p < tile) pre += q;
-            }
+            const int t = (int)threadIdx.x, G = tq_groups(b.P2), g = tile / TQ_GROUP;
+            const uint64_t q0 = t < G ? tqv[0] : 0, q1 = t + BLOCK < G ? tqv[1] : 0;
+            all = q0 + q1;
+            pre = (t < g ? q0 : 0) + (t + BLOCK < g ? q1 : 0) + tqv[2];
         }
     }
     if (fin && wvid == 0) {
@@ -189,7 +206,7 @@ DEV ResHead res_head(const BankDev& b, const ResArgs& a, int f, int tile, ResSha
     all = wave_sum_u64(all);
     if (lane == 0) { sh.red[wvid][0] = pre; sh.red[wvid][1] = all; }
     __syncthreads();
-    if (SRC == SRC_FILTER && !carry) {
+    if (SRC == SRC_FILTER) {
         // FilterScal is written by these kernels, so the scalars fetched above are vector loads made uniform with
         // v_readfirstlane — placed by the compiler right behind the loads, with a wait, BEFORE the accumulator and tile-sum
         // loads are issued.  The asm pins their first use here, behind the barrier.
@@ -469,7 +486,7 @@ __global__ __launch_bounds__(BLOCK) void k_resample(BankDev b, ResArgs a) {
             for (int k = 0; k < NORM_IPT / 2; ++k) qv[k] = *reinterpret_cast<const ulonglong2*>(qsrc + ib + 2 * k);
         }
     };
-    const ResHead h = res_head<SRC>(b, a, f, tile, sh, SRC == SRC_FILTER, stop_flag, fb_flag, nullptr, load_quanta);
+    const ResHead h = res_head<SRC>(b, a, f, tile, sh, SRC == SRC_FILTER, stop_flag, fb_flag, load_quanta);
     if (h.status == RES_STATUS_SKIP) return;
     if (!(a.mode & RES_RESAMPLE)) return;
     if (h.status) return;

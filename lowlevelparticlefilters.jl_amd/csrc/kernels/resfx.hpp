@@ -43,7 +43,7 @@ __global__ __launch_bounds__(BLOCK) void k_resample_fx(BankDev b, ResArgs a, Ste
         for (int k = 0; k < NORM_IPT / 2; ++k) qv[k] = *reinterpret_cast<const ulonglong2*>(qsrc + ib + 2 * k);
         model.prepare(b.models + f, st.u + (size_t)f * st.u_stride, st.t_prop);   // particle-independent terms: scalar loads of their own
     };
-    const ResHead h = res_head<SRC_FILTER>(b, a, f, tile, sh, true, stop_flag, fb_flag, nullptr, overlap);
+    const ResHead h = res_head<SRC_FILTER>(b, a, f, tile, sh, true, stop_flag, fb_flag, overlap);
     FX_STAMP(1, h.tot);                 // head: loads back, scalars derived
     if (h.status == RES_STATUS_SKIP) return;
     if (h.status) return;

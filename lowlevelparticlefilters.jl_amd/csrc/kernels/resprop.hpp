@@ -100,16 +100,12 @@ struct PropCtx {
 struct TileSum {
     int32_t tcur;
     uint64_t run;
-    uint64_t* gq;       // group sums (32 tiles per group, 16 u64 apart) kept by the persistent kernel, or nullptr
-    DEV void init(uint64_t* g = nullptr) { tcur = -1; run = 0; gq = g; }
+    DEV void init() { tcur = -1; run = 0; }
     DEV void flush(uint64_t* sh_tq, uint64_t* tq_global, int32_t tbase) {
         if (run) {
             const int32_t idx = tcur - tbase;
             if (idx >= 0 && idx < 8) atomicAdd(reinterpret_cast<unsigned long long*>(sh_tq + idx), (unsigned long long)run);
-            else {
-                atomicAdd(reinterpret_cast<unsigned long long*>(tq_global + tcur), (unsigned long long)run);
-                if (gq) atomicAdd(reinterpret_cast<unsigned long long*>(gq + (size_t)(tcur >> 5) * 16), (unsigned long long)run);
-            }
+            else atomicAdd(reinterpret_cast<unsigned long long*>(tq_global + tcur), (unsigned long long)run);
         }
         run = 0;
     }
@@ -202,7 +198,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!Model::
             else if (t < LLPF_RNG_SC_ENTRIES + LLPF_RNG_LG_ENTRIES) { rt0 = LLPF_LOG_INVC[t - LLPF_RNG_SC_ENTRIES]; rt1 = LLPF_LOG_LNC[t - LLPF_RNG_SC_ENTRIES]; }
         }
     };
-    const ResHead h = res_head<SRC_FILTER, false>(b, a, f, tile, sh, true, stop_flag, fb_flag, nullptr, prepare);
+    const ResHead h = res_head<SRC_FILTER, false>(b, a, f, tile, sh, true, stop_flag, fb_flag, prepare);
     if (h.status) return;
     // Values of FilterScal fetched above with the head's loads but wanted only from here on.  FilterScal is written by this
     // kernel, so they are vector loads made uniform with v_readfirstlane — which the compiler otherwise places right behind the

@@ -148,7 +148,8 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
                     av[p] = v < 0 ? 0 : v;                  // no mark at all: a launch that resampled nothing (degenerate weights), or padding
                 }
                 { int2 ao; ao.x = (i0 < N) ? av[0] : (int32_t)i0; ao.y = (i0 + 1 < N) ? av[1] : (int32_t)(i0 + 1);      // padding lanes keep the identity
-                  wt_store(reinterpret_cast<int2*>(b.anc + (size_t)f * Ns + i0), ao); }
+                  uint64_t a2; __builtin_memcpy(&a2, &ao, 8);
+                  wt_store(reinterpret_cast<uint64_t*>(b.anc + (size_t)f * Ns + i0), a2); }
 #pragma unroll
                 for (int d = 0; d < NX; ++d) {
 #pragma unroll
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
             if (!(Model::RB && MODE == MODE_PROP_WEIGHT && a.has_y)) {
 #pragma unroll
                 for (int d = 0; d < NX; ++d) {
-                    if constexpr (PPT == 2) { double2 v; v.x = xs[0][d]; v.y = xs[1][d]; wt_store<WT>(reinterpret_cast<double2*>(xn + (size_t)d * Ns + i0), v); }
+                    if constexpr (PPT == 2) wt_store2<WT>(xn + (size_t)d * Ns, i0, xs[0][d], xs[1][d]);
                     else wt_store<WT>(xn + (size_t)d * Ns + i0, xs[0][d]);
                 }
             }
@@ -362,14 +363,14 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
                 if constexpr (has_loglik<Model>::value) bad = bad || (a.has_y && wv > off);   // the user's declared bound does not hold: reported like NaN weights
                 bmax = llpf_fmax(bmax, wv);
             }
-            if constexpr (PPT == 2) { double2 wo; wo.x = wn[0]; wo.y = wn[1]; wt_store<WT>(reinterpret_cast<double2*>(w + i0), wo); }
+            if constexpr (PPT == 2) wt_store2<WT>(w, i0, wn[0], wn[1]);
             else wt_store<WT>(w + i0, wn[0]);
             if constexpr (Model::RB) {             // correct! has updated xl (Kalman measurement update)
                 if (a.has_y) {
                     double* xdst = (MODE == MODE_WEIGHT) ? const_cast<double*>(xc) : xn;
 #pragma unroll
                     for (int d = 0; d < NX; ++d) {
-                        if constexpr (PPT == 2) { double2 v; v.x = xs[0][d]; v.y = xs[1][d]; wt_store<WT>(reinterpret_cast<double2*>(xdst + (size_t)d * Ns + i0), v); }
+                        if constexpr (PPT == 2) wt_store2<WT>(xdst + (size_t)d * Ns, i0, xs[0][d], xs[1][d]);
                         else wt_store<WT>(xdst + (size_t)d * Ns + i0, xs[0][d]);
                     }
                 }
@@ -383,7 +384,7 @@ __global__ __launch_bounds__(BLOCK) void k_step(BankDev b, const ModelD* __restr
                 double ev[PPT];
 #pragma unroll
                 for (int p = 0; p < PPT; ++p) { qv[p] = wacc.add(wn[p], off, a.K, a.need_e2 != 0, &ev[p]); qsum += qv[p]; }
-                if constexpr (PPT == 2) { ulonglong2 q2; q2.x = qv[0]; q2.y = qv[1]; wt_store<WT>(reinterpret_cast<ulonglong2*>(b.quanta_next + (size_t)f * Ns + i0), q2); }
+                if constexpr (PPT == 2) wt_store2<WT>(b.quanta_next + (size_t)f * Ns, i0, qv[0], qv[1]);
                 else wt_store<WT>(b.quanta_next + (size_t)f * Ns + i0, qv[0]);
                 if (a.want_xmean) {
 #pragma unroll

@@ -74,7 +74,7 @@ def test_a_throw_inside_a_run_leaves_a_usable_handle():
     model = M.lg_test_model()
     _, U, Y = M.simulate_lg(model, 12)
     g = _capi.FilterHandle(S.make_config(model, 4096, S.PARTICLE_FILTER, S.RESAMPLE_SYSTEMATIC, 0.5, 7, 0))
-    g.reset()
+    g.seed(7); g.reset()
     ref = g.run(U, Y, 0.0)["ll"]
     g.reset()
     for kind, code in (("alloc", _capi.ERR_ALLOC), ("error", _capi.ERR_INTERNAL)):
@@ -82,7 +82,7 @@ def test_a_throw_inside_a_run_leaves_a_usable_handle():
             with pytest.raises(_capi.LLPFError) as ei:
                 g.run(U, Y, 0.0)
             assert ei.value.code == code
-    g.reset()
+    g.seed(7); g.reset()          # (reset! alone keeps drawing fresh noise: the same seed again gives the same run)
     assert g.run(U, Y, 0.0)["ll"] == ref
 
 
@@ -97,9 +97,12 @@ def test_an_absurd_horizon_is_a_status():
     u = np.zeros((4, max(model.nu, 1)))
     ll = C.c_double()
     rc = L.llpf_run(g.h, _capi.dptr(u), _capi.dptr(y), C.c_int64(1 << 46), C.c_double(0.0), C.byref(ll), None)
-    assert rc in (_capi.ERR_ALLOC, _capi.ERR_HIP, _capi.ERR_ARG), rc
+    assert rc == _capi.ERR_ALLOC, rc
     assert L.llpf_last_error()
-    g.reset()
+    # ... and the refused allocation does not poison the handle's next call (the runtime's sticky last-error is cleared)
+    _, U, Y = M.simulate_lg(model, 5)
+    g.seed(7); g.reset()
+    assert np.isfinite(g.run(U, Y, 0.0)["ll"])
 
 
 @pytest.mark.gpu
@@ -110,12 +113,12 @@ def test_a_throw_in_a_shard_thread_is_a_status(site):
     _, U, Y = M.simulate_lg(model, 6)
     cfg = S.make_config(model, 2048, S.PARTICLE_FILTER, S.RESAMPLE_SYSTEMATIC, 0.5, 7, 0)
     mb = _capi.MBankHandle(cfg, None, 4, devices=[0, 0])
-    mb.reset()
+    mb.seed(7); mb.reset()
     ref = mb.run(U, Y, 0.0)["ll"]
     for kind, code in (("alloc", _capi.ERR_ALLOC), ("error", _capi.ERR_INTERNAL)):
         with _Inject(kind + ":" + site):
             with pytest.raises(_capi.LLPFError) as ei:
                 mb.reset()
             assert ei.value.code == code
-    mb.reset()
+    mb.seed(7); mb.reset()
     assert np.array_equal(ref, mb.run(U, Y, 0.0)["ll"])

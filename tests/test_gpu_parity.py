@@ -838,6 +838,53 @@ def test_launches_larger_than_the_resident_set(schedule, monkeypatch):
     assert g.resample_count() == o.resample_count() >= 1
 
 
+@pytest.mark.parametrize("case", ["fused_1.6e7", "balanced", "stratified", "residual", "threshold_half", "quadtank_source_side", "aux"])
+def test_beyond_1024_tiles_bit_identical_to_the_device_order_oracle(case, monkeypatch):
+    """Above 1024 tiles (N > 1 048 576) the head of every resampling kernel takes its tile prefix from k_tile_prefix (group totals +
+    the prefix inside the group, kernels/resample.hpp) instead of reading every tile sum: O(tiles) like the reference's cumsum
+    (src/resample.jl:19-22) where it used to be O(tiles^2).  Whole trajectories against the device-order oracle, bit for bit: the fused
+    kernel at N = 1.6e7 (15 625 tiles, 16 groups; the working set is beyond the 256 MB Infinity Cache), and at N = 1.1e6 + 77 (1075
+    tiles: the second group holds 51 tiles, the last tile is ragged) the balanced form, stratified and residual resampling, a threshold
+    that mixes resampling and non-resampling steps, the quad-tank's source-side form and the auxiliary filter."""
+    strategy, thr, N, T, kind = S.RESAMPLE_SYSTEMATIC, 1.0, 1_100_077, 6, S.PARTICLE_FILTER
+    model = M.lg_test_model()
+    if case == "fused_1.6e7":
+        N, T = 16_000_000, 8
+    elif case == "balanced":
+        monkeypatch.setenv("LLPF_UNFUSED", "1")
+    elif case == "stratified":
+        strategy = S.RESAMPLE_STRATIFIED
+    elif case == "residual":
+        strategy = S.RESAMPLE_RESIDUAL
+    elif case == "threshold_half":
+        thr, T = 0.5, 10
+    elif case == "quadtank_source_side":
+        model, kind, thr, T = M.quadtank_model(), S.ADVANCED_PARTICLE_FILTER, 0.5, 5
+    if case == "quadtank_source_side":
+        U, Y = M.quadtank_data(T, seed=2)
+    else:
+        _, U, Y = M.simulate_lg(model, T, seed=1)
+    cfg = S.make_config(model, N, kind, strategy, thr, 321, 0)
+    ob.set_threads(16)
+    try:
+        o = ob.OracleFilter(cfg, ob.ORDER_DEVICE)
+        o.reset()
+        ro = o.run_aux(U, Y, 0, ll_steps=True) if case == "aux" else o.run(U, Y, 1.0, ll_steps=True)
+    finally:
+        ob.set_threads(1)
+    g = _capi.FilterHandle(cfg)
+    g.reset()
+    rg = g.run_aux(U, Y, 0, ll_steps=True) if case == "aux" else g.run(U, Y, 1.0, ll_steps=True)
+    assert np.array_equal(rg["ll_steps"].view(np.uint64), ro["ll_steps"].view(np.uint64))
+    assert g.resample_count() == o.resample_count() >= 1
+    _compare_state(g, o)
+    if case == "fused_1.6e7":
+        # the captured run loop (second and third run of the shape) gives what the enqueued one gave
+        g.seed(321); g.reset(); r2 = g.run(U, Y, 1.0, ll_steps=True)
+        g.seed(321); g.reset(); r3 = g.run(U, Y, 1.0, ll_steps=True)
+        assert np.array_equal(r2["ll_steps"].view(np.uint64), r3["ll_steps"].view(np.uint64))
+
+
 def test_near_maximum_particle_count():
     """3e8 particles (2.4 GB per state plane: byte offsets above 2^31, 292 969 tiles): the 32-bit offset addressing,
     the tile-sum prefix over ~3e5 tiles and the 63-bit quanta total; checked through size-independent properties
@@ -855,6 +902,13 @@ def test_near_maximum_particle_count():
     assert np.max(np.abs(rb["xmean"] - rs["xmean"])) < 0.02
     assert big.resample_count() == 4
     assert abs(big.ess() - 3e8) < 1.0          # after the last resampling predict! the weights are uniform
+    # linear in N (round 6: the head's tile prefix is O(tiles)): 72 B per particle-step at no less than a quarter of the HBM peak;
+    # with every block reading all 292 969 tile sums a timestep took several times this bound
+    big.seed(11); big.reset()
+    big.run(U, Y, 1.0)
+    us_per_step = 1e3 * big.last_run_ms() / 4
+    print("N = 3e8: %.0f us per timestep, %.3f of the HBM roofline" % (us_per_step, 3e8 * 72 / (us_per_step * 1e-6) / 8e12))
+    assert us_per_step < 3e8 * 72 / 2.0e12 * 1e6
 
 
 def test_c_client_of_the_abi():
