@@ -285,6 +285,7 @@ def main_bank(args, rank, world, dev):
                           "resamples_per_pass_rank0": int(bank.resample_count()),
                           "parallelism": "filter k on rank k mod %d (llpf_mbank_*), one all-reduce of the log-likelihood vector per pass" % world,
                           "collective": collective, "control_plane": "torch.distributed gloo (rendezvous, barriers, timing reduction)"},
+               "collective": collective,
                "ranks_seen": sorted(r["rank"] for r in ranks_seen), "rank_devices": {str(r["rank"]): r["device"] for r in ranks_seen},
                "rank_seconds": {str(r["rank"]): r["seconds"] for r in ranks_seen},
                "device_ms_per_step": dev_ms / args.steps, "collective_ms_per_step": coll_ms / args.steps,
@@ -440,7 +441,7 @@ def main_spawn_check(rank, local_rank, world, backend, require_rccl=False):
         dist.all_gather_object(seen, me)
     if rank == 0:
         print(json.dumps({"spawn_check": True, "n_gpus": world, "ranks_seen": sorted(r["rank"] for r in seen),
-                          "distinct_processes": len({r["pid"] for r in seen}), "ranks": seen,
+                          "distinct_processes": len({r["pid"] for r in seen}), "ranks": seen, "require_rccl": bool(require_rccl),
                           "default_workload": "C4 share (bank) per GPU" if world > 1 else "C2 (lg)", "scaling_reference_doc": SCALING_REFERENCE_DOC}))
     if world > 1:
         dist.barrier()
@@ -479,7 +480,11 @@ def main():
                          "to exchanging the log-likelihood vector through torch.distributed (and says so in config.collective)")
     ap.add_argument("--require-rccl", action="store_true",
                     help="N > 1: exit non-zero (after printing the line, which then carries require_rccl: FAILED ...) unless the log-likelihood exchange "
-                         "was the in-library RCCL all-reduce and every one of the N ranks reported in — no silent gloo fallback in a scaling run")
+                         "was the in-library RCCL all-reduce and every one of the N ranks reported in — no silent gloo fallback in a scaling run.  "
+                         "Since round 6 this is the DEFAULT for N > 1 with --dist-backend nccl; the flag remains for --dist-backend gloo / N = 1")
+    ap.add_argument("--allow-gloo-exchange", action="store_true",
+                    help="N > 1, --dist-backend nccl: opt out of the default above — if the in-library RCCL communicator cannot be built the run falls "
+                         "back to exchanging the log-likelihood vector through torch.distributed (gloo), says so in `collective`, and exits 0")
     ap.add_argument("--cpu-quick", action="store_true",
                     help="bounded CPU baseline for the side runs of other_configs: the one-thread leg only, ~8 s of CPU, no accuracy block")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -496,6 +501,9 @@ def main():
         raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks; they must agree" % (args.gpus, world))
     if args.workload is None:
         args.workload = "lg" if world == 1 else "bank"
+    # a scaling line must not silently come from the fallback exchange: required by default when the measured path (nccl) was asked for
+    if world > 1 and args.dist_backend == "nccl" and not args.allow_gloo_exchange:
+        args.require_rccl = True
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

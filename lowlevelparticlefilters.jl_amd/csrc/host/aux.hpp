@@ -226,6 +226,9 @@ static int bank_aux_run(Bank& b, const double* U, const double* Y, int64_t T, in
     if (b.nu > 0 && !U) return fail(LLPF_ERR_ARG, "U is null");
     if (mode != 0 && mode != 1) return fail(LLPF_ERR_ARG, "mode must be 0 (forward_trajectory) or 1 (loglik)");
     if ((x_hist || w_hist || we_hist) && b.F != 1) return fail(LLPF_ERR_ARG, "history outputs need a single filter");
+    // refused HERE, before any state of the handle moves (the back-to-back epochs below never pass through aux_predict_dev's own check)
+    if (is_rb(b) || is_rbfull(b)) return fail(LLPF_ERR_ARG, "the auxiliary filter is not defined for the Rao-Blackwellized model");
+    if (b.nx > 8) return fail(LLPF_ERR_ARG, "the auxiliary filter is compiled for up to 8 states (this filter has " + std::to_string(b.nx) + ")");
     CHK(ensure(&b.d_U, &b.capU, (size_t)T * (b.nu > 0 ? b.nu : 1)));
     CHK(ensure(&b.d_Y, &b.capY, (size_t)T * b.ny));
     if (b.nu > 0) HIPC(hipMemcpyAsync(b.d_U, U, sizeof(double) * T * b.nu, hipMemcpyHostToDevice, b.stream));
@@ -237,6 +240,7 @@ static int bank_aux_run(Bank& b, const double* U, const double* Y, int64_t T, in
     const double Ts = b.cfg.model.Ts;
     const bool hist = x_hist || w_hist || we_hist;
     const int want_xm = xmean ? 1 : 0;
+    if (want_xm) CHK(ensure_xmpart(b));
     b.run_resamples = 0;
     {
         std::vector<FilterScal> h;

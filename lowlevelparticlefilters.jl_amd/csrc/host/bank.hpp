@@ -123,8 +123,8 @@ static void free_bank(Bank& b) {
     if (b.stream) hipStreamSynchronize(b.stream);
     for (auto& g : b.graphs) if (g.exec) hipGraphExecDestroy(g.exec);
     b.graphs.clear();
-    hipFree(b.d_pool);               // models, scal, x, w, anc, acc, quanta, tileq, flag, xmpart, rtile, rb, uy, tmp
-    hipFree(b.d_lam); hipFree(b.d_surv); hipFree(b.d_mark); hipFree(b.d_fxs); hipFree(b.d_rbseq); hipFree(b.d_hist); hipFree(b.d_U); hipFree(b.d_Y);
+    hipFree(b.d_pool);               // models, scal, x, w, anc, acc, quanta, tileq, flag, rtile, rb, uy, tmp
+    hipFree(b.d_xmpart); hipFree(b.d_lam); hipFree(b.d_surv); hipFree(b.d_mark); hipFree(b.d_fxs); hipFree(b.d_rbseq); hipFree(b.d_hist); hipFree(b.d_U); hipFree(b.d_Y);
     hipFree(b.d_ll_steps); hipFree(b.d_xmean); hipFree(b.d_xcov);
     for (auto e : b.ev_pool) hipEventDestroy(e);
     for (auto& e : b.pending) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
@@ -192,6 +192,16 @@ static void prof_collect(Bank& b) {
 }
 
 // the scratch of the resampling with source-side dynamics: marks (zero between timesteps) and the plane of f(x_j)
+// per-block parts of the weighted mean, one set per accumulator slot: [ACC_NSLOT][F][P1][MAXD] — 400 MB for a filter near 2^29 particles,
+// so it is not part of every handle's pool but allocated by the first run that asks for the means (kernels touch it under want_xmean only)
+static int ensure_xmpart(Bank& b) {
+    if (b.d_xmpart) return LLPF_OK;
+    const size_t n = (size_t)ACC_NSLOT * b.F * b.P1 * MAXD;
+    HIPC(hipMalloc(&b.d_xmpart, sizeof(double) * n));
+    HIPC(hipMemsetAsync(b.d_xmpart, 0, sizeof(double) * n, b.stream));
+    return LLPF_OK;
+}
+
 static int ensure_fx(Bank& b) {
     if (b.d_mark && b.d_fxs) return LLPF_OK;
     const size_t FN = (size_t)b.F * b.Ns;
@@ -343,7 +353,7 @@ static int bank_create(const llpf_config* cfg, const llpf_model* models, int F, 
         const size_t o_acc = take(sizeof(uint64_t) * (size_t)F * ACC_WORDS);
         const size_t o_q0 = take(sizeof(uint64_t) * FN), o_q1 = take(sizeof(uint64_t) * FN);
         const size_t o_tileq = take(sizeof(uint64_t) * (size_t)ACC_NSLOT * F * b.P2), o_flag = take(sizeof(uint32_t) * 4);
-        const size_t o_xmpart = take(sizeof(double) * (size_t)ACC_NSLOT * F * b.P1 * MAXD), o_rtile = take(sizeof(uint64_t) * (size_t)F * 2 * b.P2);
+        const size_t o_rtile = take(sizeof(uint64_t) * (size_t)F * 2 * b.P2);      // (xmpart: on the first run that asks for weighted means, ensure_xmpart)
         const size_t o_rb = take(m0.model_id == LLPF_MODEL_RB_LINEAR ? sizeof(RBStep) * 2 * (size_t)F : 0);
         const bool two_level = b.P2 > 4 * BLOCK;           // (kernels/resample.hpp: TQ_GROUP)
         const size_t o_tpre = take(two_level ? sizeof(uint64_t) * (size_t)F * b.P2 : 0), o_gsum = take(two_level ? sizeof(uint64_t) * (size_t)F * ((b.P2 + 4 * BLOCK - 1) / (4 * BLOCK)) : 0);
@@ -358,7 +368,7 @@ static int bank_create(const llpf_config* cfg, const llpf_model* models, int F, 
         b.d_acc = reinterpret_cast<uint64_t*>(base + o_acc);
         b.d_quanta[0] = reinterpret_cast<uint64_t*>(base + o_q0); b.d_quanta[1] = reinterpret_cast<uint64_t*>(base + o_q1);
         b.d_tileq = reinterpret_cast<uint64_t*>(base + o_tileq); b.d_flag = reinterpret_cast<uint32_t*>(base + o_flag);
-        b.d_xmpart = reinterpret_cast<double*>(base + o_xmpart); b.d_rtile = reinterpret_cast<uint64_t*>(base + o_rtile);
+        b.d_rtile = reinterpret_cast<uint64_t*>(base + o_rtile);
         if (m0.model_id == LLPF_MODEL_RB_LINEAR) b.d_rb = reinterpret_cast<RBStep*>(base + o_rb);
         if (two_level) { b.d_tpre = reinterpret_cast<uint64_t*>(base + o_tpre); b.d_gsum = reinterpret_cast<uint64_t*>(base + o_gsum); }
         b.d_uy = reinterpret_cast<double*>(base + o_uy); b.d_tmp = reinterpret_cast<double*>(base + o_tmp);

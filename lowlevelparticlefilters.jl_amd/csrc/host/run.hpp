@@ -62,6 +62,7 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
     // weighted means come out of the normalise / weighting kernels (partial sums over the nx rows they read anyway); the
     // model with per-particle covariance takes them from a k_wmean launch per step over its [xn; xl] rows instead
     const int want_xm = (xmean && !is_rbfull(b)) ? 1 : 0;
+    if (want_xm) CHK(ensure_xmpart(b));
     const bool xm_launch = xmean && is_rbfull(b);
     if (xm_launch && b.F != 1) return fail(LLPF_ERR_ARG, "weighted means of a BANK of filters with per-particle covariance are not provided (run without xmean)");
     const int K = llpf_qbits(b.N);

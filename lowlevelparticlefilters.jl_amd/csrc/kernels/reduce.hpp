@@ -40,7 +40,9 @@ template <bool WT = true, class T> DEV void wt_store2(T* base, int64_t i, T a, T
         __builtin_memcpy(&r, &a, 8);
         __builtin_memcpy(reinterpret_cast<char*>(&r) + 8, &b, 8);
         // dword 3 of the descriptor: raw buffer (no swizzle, no format conversion) as the compiler's own buffer accesses on gfx9 use it
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)0x7fffffff, 0x00020000);
+        // (num_records = 2^32 - 1 bytes: offsets are compared UNSIGNED against it, and a plane of 3e8 particles reaches 2.4e9 — with
+        //  2^31 - 1 the upper half of such a filter was silently dropped by the range check: tests/test_gpu_parity.py, near-maximum test)
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)0xffffffffu, 0x00020000);
         __builtin_amdgcn_raw_buffer_store_b128(r, rs, (int)((uint32_t)i * 8u), 0, 16 /* sc1 */);
         return;
     }

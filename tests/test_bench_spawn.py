@@ -57,3 +57,17 @@ def test_require_rccl_refuses_the_gloo_exchange():
     assert bench.rccl_requirement_failure("none (one shard)", [0], 1) is None
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert 'out["scaling_efficiency"]' in src and 'out["require_rccl"]' in src
+
+
+def test_rccl_is_required_by_default_for_a_multi_gpu_line():
+    """Round 6: `bench.py --gpus N` (the driver's command, no extra flag) requires the in-library RCCL exchange; --allow-gloo-exchange
+    and an explicit --dist-backend gloo are the two ways out, and the printed line carries `collective` and `ranks_seen` at top level."""
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--spawn-check"]
+    got = {}
+    for name, extra in (("default", []), ("allow", ["--allow-gloo-exchange"]), ("gloo", ["--dist-backend", "gloo"])):
+        out = subprocess.run(base + extra, env=_env(), capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        got[name] = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])["require_rccl"]
+    assert got == {"default": True, "allow": False, "gloo": False}
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert '"collective": collective,\n               "ranks_seen"' in src

@@ -639,8 +639,16 @@ def test_linear_gaussian_above_the_precompiled_dimensions(nx, ny, nu):
     if nx <= 8:
         assert np.array_equal(g.run_aux(U, Y, 1, ll_steps=True)["ll_steps"].view(np.uint64), o.run_aux(U, Y, 1, ll_steps=True)["ll_steps"].view(np.uint64))
     else:                                          # the auxiliary filter's second half is compiled for up to 8 states: refused above, loudly
-        with pytest.raises(_capi.LLPFError):
+        w_before, n_before = g.weights().copy(), g.index()
+        with pytest.raises(_capi.LLPFError) as ei:
             g.run_aux(U, Y, 1, ll_steps=True)
+        assert ei.value.code == _capi.ERR_ARG and "8 states" in str(ei.value)      # (round 6: before anything of the handle has moved)
+        assert g.index() == n_before and np.array_equal(g.weights(), w_before)
+        bk = _capi.BankHandle(cfg, [model, model])
+        bk.reset()
+        with pytest.raises(_capi.LLPFError) as ei:
+            bk.run_aux(U, Y, 1)
+        assert ei.value.code == _capi.ERR_ARG
         g.reset()
         np.testing.assert_allclose(g.weighted_cov(), np.cov(g.particles().T), rtol=1e-9, atol=1e-12)      # k_wcov<16>: uniform weights after reset!
     b = _capi.BankHandle(cfg, [model, model, model])
