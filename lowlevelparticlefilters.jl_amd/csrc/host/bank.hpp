@@ -99,7 +99,8 @@ struct Bank {
         b.w = d_w; b.anc = d_anc; b.acc = d_acc; b.quanta = d_quanta[qcur]; b.quanta_next = d_quanta[qcur ^ 1]; b.tileq = d_tileq; b.tpre = d_tpre; b.gsum = d_gsum;
         b.bank_flag = d_flag; b.xmpart = d_xmpart; b.lam = d_lam; b.rtile = d_rtile; b.mark = d_mark; b.fxs = d_fxs; b.surv = d_surv;
         b.anc_slot = (int32_t)(n_predict & 1u);
-        b.pad0 = (cfg.model.model_id == LLPF_MODEL_RB_BILINEAR) ? (cfg.model.rb.nxl | (cfg.model.rb.fn_kind << 8)) : 0;
+        b.pad0 = (cfg.model.model_id == LLPF_MODEL_RB_BILINEAR) ? (cfg.model.rb.nxl | (cfg.model.rb.fn_kind << 8))
+                 : (cfg.model.model_id == LLPF_MODEL_RB_LINEAR ? cfg.model.nxn : 0);
         b.xrows = xrows; b.pad1 = 0;
         return b;
     }

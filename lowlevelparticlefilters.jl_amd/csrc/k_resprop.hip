@@ -57,6 +57,9 @@ static hipError_t launch_resprop_lg_ny(const BankDev& b, const ResArgs& a, const
 }
 template <int NX>
 static hipError_t launch_resprop_rb_ny(const BankDev& b, const ResArgs& a, const StepArgs& st, int weight, hipStream_t s) {
+    // the split known at compile time where it is measured (the reference's own RBPF benchmark system, test/test_rbpf.jl:5-31: 1 + 1 states,
+    // one output); BankDev::pad0 carries nxn for this model.  Other shapes: the run-time split, same bits.
+    if (NX == 2 && b.ny == 1 && b.pad0 == 1) return launch_resprop_t<RBLin<2, 1, 1>, 2, 1>(b, a, st, weight, s);
     switch (b.ny) {
         case 1: return launch_resprop_t<RBLin<NX, 1>, NX, 1>(b, a, st, weight, s);
         case 2: return launch_resprop_t<RBLin<NX, 2>, NX, 2>(b, a, st, weight, s);

@@ -180,19 +180,29 @@ struct LinGauss {   // f = A x .+ B u ; g = C x   (reference examples/example_li
 // Rao-Blackwellized filter with constant matrices (reference src/rbpf.jl:163-283): the particle is [xn; xl], the
 // covariance of xl is shared by all particles and advanced on the host (csrc/shared/llpf_rbkf.h).  A = [Fn An; 0 Al],
 // B = [Bn; Bl], C = [Gn Cl] (row stride NX / nu / NX).  Operation order identical to oracle/llpf_oracle.c:rb_*.
-template <int NX, int NY>
+// NN: the number of nonlinear states as a compile-time constant (round 6; the fused kernel's instantiations), or 0: read from the model at
+// run time (k_step: every split of NX in one kernel).  With the run-time split the generator's loop `for (2 b < nn)` cannot be unrolled, its
+// output array is indexed dynamically and lives in scratch memory (32-48 bytes per lane in every k_resprop<RBLin> of rounds 1-5), and every
+// inner product runs over all NX columns under a predicate.  Same operations in the same order either way: the same bits.
+template <int NX, int NY, int NN = 0>
 struct RBLin {
     static constexpr bool RB = true;
+    static constexpr bool LEAN = NN > 0;      // split known at compile time: the kernel can afford what the plain model's kernel has (LDS tables, owner table)
+    static_assert(NN >= 0 && NN < NX, "at least one linear state");
     const ModelD* md;
     const double* u;
-    int nn, nl, nu;
+    int nn_rt, nu;
     DEV void prepare(const ModelD* m, const double* __restrict__ uu, double /*t*/) {
-        md = m; u = uu; nn = m->nxn; nl = NX - m->nxn; nu = (uu != nullptr) ? m->nu : 0;
+        md = m; u = uu; nn_rt = m->nxn; nu = (uu != nullptr) ? m->nu : 0;
     }
     // the propagation of predict! (:185-224): xs = [fi + z ; Al xl + Bl u + L (z - An xl)]
-    DEV void rb_propagate(const double* xp, uint32_t idx, uint32_t step, uint32_t k0, uint32_t k1, const RBStep* rp, double* xs) const {
+    // lg / sc: the block's copy of the generator's tables in LDS, or nullptr (constant memory)
+    DEV void rb_propagate(const double* xp, uint32_t idx, uint32_t step, uint32_t k0, uint32_t k1, const RBStep* rp, double* xs,
+                          const double* lg = nullptr, const double* sc = nullptr) const {
+        const int nn = NN > 0 ? NN : nn_rt, nl = NX - nn;
         double xi[NX], nz[NX], fi[NX], xl1[NX];
-        llpf_normals(idx, step, LLPF_STREAM_DYNAMICS, k0, k1, nn, xi);
+        if (lg) llpf_normals_tab(idx, step, LLPF_STREAM_DYNAMICS, k0, k1, nn, xi, lg, sc);
+        else llpf_normals(idx, step, LLPF_STREAM_DYNAMICS, k0, k1, nn, xi);
         const GaussD& g = md->df;
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
@@ -268,6 +278,7 @@ struct RBLin {
     }
     // the per-particle part of correct! (:253-280): returns ll and applies the Kalman measurement update to xl
     DEV double rb_weight(double* xs, const double* y, const RBStep* rc, bool first) const {
+        const int nn = NN > 0 ? NN : nn_rt, nl = NX - nn;
         double yn[NY], yl[NY], e[NY];
 #pragma unroll
         for (int r = 0; r < NY; ++r) {
@@ -425,6 +436,9 @@ struct NoModel {
 //   DEV void initial(const double* xi, const double* uu, double* out) const
 //        one draw of the initial density (reset! / the constructor: x_i = rand(rng, initial_density), src/filtering.jl:4-14)
 // detected without <type_traits> (hiprtc has no system headers)
+// a Rao-Blackwellized model whose nonlinear / linear split is a compile-time constant (RBLin<NX, NY, NN > 0>)
+template <class M, class = void> struct model_lean { static constexpr bool value = false; };
+template <class M> struct model_lean<M, decltype((void)M::LEAN)> { static constexpr bool value = M::LEAN; };
 template <class M, class = void> struct has_user_noise { static constexpr bool value = false; };
 template <class M> struct has_user_noise<M, decltype((void)&M::noise)> { static constexpr bool value = true; };
 template <class M, class = void> struct has_user_initial { static constexpr bool value = false; };

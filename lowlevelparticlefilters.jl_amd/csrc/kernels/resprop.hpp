@@ -18,8 +18,18 @@ template <class T> DEV void st_off(T* base, uint32_t byte_off, T v) {
 }
 
 // stores of the output loop are write-through (wt_store in reduce.hpp says why)
-#define LLPF_STCOH ((LLPF_WT && !Model::RB) ? 1 : COH)
-#define LLPF_STCOH0 ((LLPF_WT && !Model::RB) ? 1 : 0)
+#ifndef LLPF_RBX_TAB
+#define LLPF_RBX_TAB 1      /* RBLin with a compile-time split: generator tables in LDS + owner table, like the plain model's kernel */
+#endif
+#ifndef LLPF_RBX_W4
+#define LLPF_RBX_W4 1       /* ... and four waves per SIMD */
+#endif
+#ifndef LLPF_RBX_WT
+#define LLPF_RBX_WT 1       /* ... and write-through stores (same box, us per timestep at N = 1e6: run-time split 30.0; compile-time split 24.6; + tables 23.1; + four waves 23.3; + these 22.7 — profiles/r06_rbpf_lean_ab.txt) */
+#endif
+#define LLPF_RB_PLAIN_ST (Model::RB && !(model_lean<Model>::value && LLPF_RBX_WT))
+#define LLPF_STCOH ((LLPF_WT && !LLPF_RB_PLAIN_ST) ? 1 : COH)
+#define LLPF_STCOH0 ((LLPF_WT && !LLPF_RB_PLAIN_ST) ? 1 : 0)
 template <class Model, int NX, int NY, bool WEIGHT, bool COH = false, bool LTAB = false>
 struct PropCtx {
     const BankDev& b;
@@ -46,7 +56,8 @@ struct PropCtx {
 #pragma unroll
         for (int d = 0; d < NX; ++d) xp[d] = Mem<COH>::ld_off(xc + (size_t)d * Ns, so);      // (nontemporal: C2 22.8 against 20.7 us — duplicated ancestors are re-read from the L2)
         if constexpr (Model::RB) {     // Rao-Blackwellized model: own noise structure, and correct! updates xl before the store
-            model.rb_propagate(xp, o, pstep, k0, k1, st.rb_pred + blockIdx.y, xs);
+            if constexpr (LTAB) model.rb_propagate(xp, o, pstep, k0, k1, st.rb_pred + blockIdx.y, xs, rng_lg, rng_sc);
+            else model.rb_propagate(xp, o, pstep, k0, k1, st.rb_pred + blockIdx.y, xs);
             double wr = wprev;
             if (WEIGHT) {
                 if (st.has_y) wr = wr + model.rb_weight(xs, y, st.rb_corr + blockIdx.y, o == 0);
@@ -129,7 +140,7 @@ template <class Model, int NX, int NY, bool WEIGHT, bool ACC, bool AUX = false, 
 // larger state dimensions would spill under that cap and keep the compiler's choice; the Rao-Blackwellized propagate uses
 // 130-156 VGPRs and is pinned to three waves per SIMD (<= 168): twice in this round an unrelated change pushed it past 170 and
 // cost it 28 %
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!Model::RB && NX <= 2 && NY <= 2 && !ONE) ? 4 : (Model::RB ? 3 : 1)))) void k_resprop(LLPF_HOT_PARAMS, BankDev b_in, const ModelD* __restrict__ models, ResArgs a_in, StepArgs st) {
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(((!Model::RB || (model_lean<Model>::value && LLPF_RBX_W4)) && NX <= 2 && NY <= 2 && !ONE) ? 4 : (Model::RB ? 3 : 1)))) void k_resprop(LLPF_HOT_PARAMS, BankDev b_in, const ModelD* __restrict__ models, ResArgs a_in, StepArgs st) {
     // what the head's first loads are addressed with arrives in SGPRs with the wave (kernarg preload) instead of through a
     // scalar load of the argument block: one memory round trip less at the start of every launch
     BankDev b = b_in;
@@ -143,7 +154,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!Model::
     __shared__ uint64_t sm_acc[BLOCK / 64][5];
     __shared__ uint64_t sh_tq[8];
     __shared__ double sm_x[BLOCK / 64][MAXD];
-    constexpr bool OWN_TABLE = !Model::RB;      // the Rao-Blackwellized propagate has no registers to spare for it (occupancy 3 -> 2)
+    constexpr bool RBFAT = Model::RB && !(model_lean<Model>::value && LLPF_RBX_TAB);      // run-time split: no registers to spare for the tables (occupancy 3 -> 2)
+    constexpr bool OWN_TABLE = !RBFAT;
     __shared__ __attribute__((aligned(16))) uint32_t sh_own[OWN_TABLE ? OWN_CAP : 4];
     __shared__ __attribute__((aligned(16))) double sh_rng_lg[2 * LLPF_RNG_LG_ENTRIES], sh_rng_sc[2 * LLPF_RNG_SC_ENTRIES];
     // Wave priority by phase: the head / counts / tail phases are short and latency-bound (loads, LDS, barriers, atomics), the
@@ -192,7 +204,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!Model::
         // head waiting 2.5 us for a burst that is only needed by the counts.  Likewise the generator's tables (for the loop).
 #pragma unroll
         for (int k = 0; k < NORM_IPT / 2; ++k) qv[k] = *reinterpret_cast<const ulonglong2*>(qsrc + ib + 2 * k);
-        if (!Model::RB) {
+        if (!RBFAT) {
             const int t = (int)threadIdx.x;
             if (t < LLPF_RNG_SC_ENTRIES) { rt0 = LLPF_SIN64[t]; rt1 = LLPF_COS64[t]; }
             else if (t < LLPF_RNG_SC_ENTRIES + LLPF_RNG_LG_ENTRIES) { rt0 = LLPF_LOG_INVC[t - LLPF_RNG_SC_ENTRIES]; rt1 = LLPF_LOG_LNC[t - LLPF_RNG_SC_ENTRIES]; }
@@ -208,15 +220,15 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!Model::
     const uint32_t key0 = __builtin_amdgcn_readfirstlane(key0_v), key1 = __builtin_amdgcn_readfirstlane(key1_v);
     const uint32_t sb = __builtin_amdgcn_readfirstlane(sb_v);
     const int anc_ident_prev = __builtin_amdgcn_readfirstlane(anc_ident_v);
-    if (!Model::RB) {      // the generator's tables -> LDS (one 16-byte LDS read per lookup instead of two global loads); the
+    if (!RBFAT) {      // the generator's tables -> LDS (one 16-byte LDS read per lookup instead of two global loads); the
         const int t = (int)threadIdx.x;     // barriers of the counts / the one below come before the loop reads them
         if (t < LLPF_RNG_SC_ENTRIES) { sh_rng_sc[2 * t] = rt0; sh_rng_sc[2 * t + 1] = rt1; }
         else if (t < LLPF_RNG_SC_ENTRIES + LLPF_RNG_LG_ENTRIES) { sh_rng_lg[2 * (t - LLPF_RNG_SC_ENTRIES)] = rt0; sh_rng_lg[2 * (t - LLPF_RNG_SC_ENTRIES) + 1] = rt1; }
     }
     LLPF_STAMP(1);
-    PropCtx<Model, NX, NY, WEIGHT, false, !Model::RB> pc{b, model, md, st, y, b.xcur + (size_t)f * NX * Ns, b.xnext + (size_t)f * NX * Ns,
+    PropCtx<Model, NX, NY, WEIGHT, false, !RBFAT> pc{b, model, md, st, y, b.xcur + (size_t)f * NX * Ns, b.xnext + (size_t)f * NX * Ns,
                                       b.w + (size_t)f * Ns, key0, key1, sb + st.step, a.ablate, 0.0, b.quanta_next + (size_t)f * Ns,
-                                      Model::RB ? nullptr : sh_rng_lg, Model::RB ? nullptr : sh_rng_sc};
+                                      RBFAT ? nullptr : sh_rng_lg, RBFAT ? nullptr : sh_rng_sc};
     int32_t* anc = b.anc + (size_t)f * Ns;
     double bmax = -LLPF_INF;
     bool bad = false;
@@ -250,7 +262,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((!Model::
         l = head_log(h);
         first = (int64_t)tile * TILE;
         last = first + TILE;
-        if (!Model::RB) __syncthreads();      // generator tables in LDS
+        if (!RBFAT) __syncthreads();      // generator tables in LDS
     }
     {   // bound of the weights produced below: max of the previous (normalised) weights + the density's peak
         const double wmx = res ? b.log1N : (h.mtrue - h.a) - l;

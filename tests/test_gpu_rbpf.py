@@ -76,6 +76,30 @@ def test_rbpf_bit_exact_and_kalman(name):
         _compare_state(g3, o3)
 
 
+@pytest.mark.parametrize("thr", [0.1, 1.0])
+def test_rbpf_fused_kernel_with_the_split_known_at_compile_time(thr):
+    """Round 6: the fused kernel of the reference's own RBPF benchmark system (test/test_rbpf.jl:5-31: 1 nonlinear + 1 linear state, one
+    output) is instantiated with the split as a compile-time constant — RBLin<2, 1, 1>: no scratch memory, generator tables and owner
+    table in LDS, four waves per SIMD, write-through stores (30.0 -> 22.7 us per timestep at N = 1e6) — while the step kernel keeps the
+    run-time split.  Several tiles (the one-tile form is covered above), resampling seldom and at every step: the asynchronous run
+    (fused kernel), the history run (k_resample + k_step) and the oracle give the same bits."""
+    _, cases = _rb_models()
+    model, U, Y = cases["mixed"]
+    cfg = _cfg(model, 5000 + 13, S.RESAMPLE_SYSTEMATIC, thr, seed=8)
+    g = _capi.FilterHandle(cfg); gh = _capi.FilterHandle(cfg); o = ob.OracleFilter(cfg, ob.ORDER_DEVICE)
+    for h in (g, gh, o):
+        h.reset()
+    rg = g.run(U[:80], Y[:80], 0.0, ll_steps=True)
+    rh = gh.run(U[:80], Y[:80], 0.0, ll_steps=True, history=True)
+    ro = o.run(U[:80], Y[:80], 0.0, ll_steps=True)
+    assert g.last_run_stats()["fused_launches"] > 0, "the fused kernel did not run"
+    assert np.array_equal(rg["ll_steps"].view(np.uint64), ro["ll_steps"].view(np.uint64))
+    assert np.array_equal(rh["ll_steps"].view(np.uint64), ro["ll_steps"].view(np.uint64))
+    assert g.resample_count() == o.resample_count() >= (80 if thr == 1.0 else 1)
+    _compare_state(g, o); _compare_state(gh, o)
+    assert np.array_equal(g.ancestors(), o.ancestors())
+
+
 def test_rbpf_api():
     """RBPF(N, kf, dynamics, nl_measurement_model, R1n, d0n; An, ...) through the reference-shaped API: loglik close to
     the Kalman filter's (test/test_rbpf.jl:110), forward_trajectory shapes, the shared covariance accessor."""
