@@ -35,7 +35,7 @@ extern "C" {
 #endif
 
 #define LLPF_VERSION_MAJOR 0
-#define LLPF_VERSION_MINOR 5
+#define LLPF_VERSION_MINOR 6
 #define LLPF_MAX_DIM 16       /* states and outputs of a model (round 5: 8 -> 16; above 4 the linear-Gaussian model and every user model are compiled at run time) */
 #define LLPF_MAX_INPUTS 8     /* inputs u */
 #define LLPF_RB_MAX_LINEAR 8  /* linear states of LLPF_MODEL_RB_BILINEAR */
@@ -176,6 +176,12 @@ typedef struct llpf_run_outputs {
     double* xcov;        /* [T*nx*nx] weighted_cov after each correct! (reference src/filtering.jl:571-581: StatsBase's corrected covariance under
                           * probability weights), computed on the device from the state the history outputs would copy out, or NULL.  llpf_run only
                           * (single filters that are not LLPF_MODEL_RB_BILINEAR); asks for the balanced two-launch timestep like the history outputs. */
+    double* xquant;      /* [T*nx*nq] weighted_quantile(sol, quant_p) (reference src/filtering.jl:583-595: [t][state][q]) of the same state, computed on
+                          * the device per timestep (radix selection over the exp-weights, csrc/k_quantile.hip), or NULL.  llpf_run only; same
+                          * restrictions as xcov.  (ABI minor 6: the struct grew by these three fields) */
+    const double* quant_p; /* [nq] probabilities in [0, 1] */
+    int32_t nq;          /* 1..1024 */
+    int32_t pad;
 } llpf_run_outputs;
 
 /* T iterations of {correct!(u_k,y_k,t_k); predict!(u_k,t_k)} with t_k = (t_index0 + k) * Ts, k = 0..T-1,

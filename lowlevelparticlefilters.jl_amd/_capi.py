@@ -223,12 +223,17 @@ class FilterHandle:
         check(self.L.llpf_update(self.h, dptr(u), dptr(y), float(t), C.byref(ll)))
         return ll.value
 
-    def run(self, U, Y, t_index0=0.0, ll_steps=False, xmean=False, history=False, xcov=False):
+    def run(self, U, Y, t_index0=0.0, ll_steps=False, xmean=False, history=False, xcov=False, quantiles=None):
+        """quantiles: probabilities q -> res["xquant"] [T, nx, len(q)], weighted_quantile of every timestep's state on the device"""
         Y = f64(Y).reshape(-1, self.ny)
         T = Y.shape[0]
         U = f64(U).reshape(T, self.nu) if self.nu else None
         outs = S.RunOutputs()
         res = {}
+        if quantiles is not None:
+            qp = np.ascontiguousarray(np.atleast_1d(quantiles), dtype=np.float64)
+            res["xquant"] = np.zeros((T, self.nx, qp.size))
+            outs.xquant, outs.quant_p, outs.nq = dptr(res["xquant"]), dptr(qp), int(qp.size)
         if xcov:
             res["xcov"] = np.zeros((T, self.nx, self.nx))
             outs.xcov = dptr(res["xcov"])
@@ -255,7 +260,9 @@ class FilterHandle:
         return a
 
     def weighted_quantile(self, q):
-        """weighted_quantile of the current particles under the current weights (reference src/filtering.jl:583-595), on the device: [len(q), nx]"""
+        """weighted_quantile of the current particles under the current weights (reference src/filtering.jl:583-595), on the device.
+        The raw handle returns the C ABI's layout, [len(q), nx]; the mirror of the reference's function (api.weighted_quantile) transposes it
+        to the reference's [state][q] nesting."""
         q = np.ascontiguousarray(np.atleast_1d(q), dtype=np.float64)
         out = np.empty((q.size, self.nx))
         check(self.L.llpf_weighted_quantile(self.h, dptr(q), q.size, dptr(out)))

@@ -51,7 +51,8 @@ class Config(C.Structure):
 class RunOutputs(C.Structure):
     _fields_ = [("ll_steps", C.POINTER(C.c_double)), ("xmean", C.POINTER(C.c_double)),
                 ("x_hist", C.POINTER(C.c_double)), ("w_hist", C.POINTER(C.c_double)),
-                ("we_hist", C.POINTER(C.c_double)), ("xcov", C.POINTER(C.c_double))]
+                ("we_hist", C.POINTER(C.c_double)), ("xcov", C.POINTER(C.c_double)),
+                ("xquant", C.POINTER(C.c_double)), ("quant_p", C.POINTER(C.c_double)), ("nq", C.c_int32), ("pad", C.c_int32)]
 
 
 class MBankInfo(C.Structure):

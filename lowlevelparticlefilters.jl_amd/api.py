@@ -461,9 +461,12 @@ class ParticleFilteringSolution:
     """Fields f,u,y,x,w,we,ll,t of the reference's struct (src/solutions.jl:334-345).  x is [T, N, nx]
     (column t of the reference's N x T matrix of SVectors is x[t]); w, we are [T, N]."""
 
-    def __init__(self, f, u, y, x, w, we, ll):
+    def __init__(self, f, u, y, x, w, we, ll, quantile_p=None, xquant=None):
         self.f, self.u, self.y, self.x, self.w, self.we, self.ll = f, u, y, x, w, we, ll
         self.t = np.arange(x.shape[0]) * f.Ts
+        # forward_trajectory(..., quantiles=q): weighted_quantile of every timestep, computed on the device inside the run loop
+        self.quantile_p = None if quantile_p is None else np.atleast_1d(np.asarray(quantile_p, dtype=np.float64))
+        self.xquant = xquant                      # [T, nx, len(quantile_p)]
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -513,16 +516,20 @@ def update(pf, u, y, *args, **kw):
     return pf._h.update(u, y, _t(pf, _pt(args, kw, 0)[1])), 0
 
 
-def forward_trajectory(pf, u, y, p=None):
+def forward_trajectory(pf, u, y, p=None, quantiles=None):
     """sol = forward_trajectory(pf, u, y, p) — reference src/filtering.jl:343-365 (:367-384 for the auxiliary
     filter).  The whole T-step loop is enqueued on the device; callbacks of the reference signature are not
-    supported (a fused on-device loop cannot call back into the host) — drive update() step by step if needed."""
+    supported (a fused on-device loop cannot call back into the host) — drive update() step by step if needed.
+    quantiles=q (not for the auxiliary filter): weighted_quantile(sol, q) of every timestep is computed on the device inside the run loop
+    (llpf_run's xquant output) and kept in the solution; weighted_quantile(sol, q') with q' among q is then served from it."""
     reset(pf)
     if isinstance(pf, AuxiliaryParticleFilter):
+        if quantiles is not None:
+            raise ValueError("forward_trajectory(quantiles=...) is not provided for the auxiliary filter: use weighted_quantile(sol, q)")
         r = pf._h.run_aux(u, y, mode=0, history=True)
     else:
-        r = pf._h.run(u, y, t_index0=0.0, history=True)
-    return ParticleFilteringSolution(pf, u, y, r["x"], r["w"], r["we"], r["ll"])
+        r = pf._h.run(u, y, t_index0=0.0, history=True, quantiles=quantiles)
+    return ParticleFilteringSolution(pf, u, y, r["x"], r["w"], r["we"], r["ll"], quantiles, r.get("xquant"))
 
 
 def loglik(pf, u, y, p=None):
@@ -700,7 +707,14 @@ def weighted_quantile(x, we=None, q=None):
         out = x._h.weighted_quantile(qq)
         return out[0] if np.isscalar(qq) else np.ascontiguousarray(out.T)
     if isinstance(x, ParticleFilteringSolution):
-        x, we, q = x.x, x.we, (we if q is None else q)
+        sol, q = x, (we if q is None else q)
+        if sol.xquant is not None:       # computed by the run loop on the device: served from there when every q was asked for
+            qq = np.atleast_1d(np.asarray(q, dtype=np.float64))
+            idx = [np.flatnonzero(sol.quantile_p == v) for v in qq]
+            if all(len(i) for i in idx):
+                sel = sol.xquant[:, :, [int(i[0]) for i in idx]]
+                return [sel[t][:, 0].copy() if np.isscalar(q) else sel[t].copy() for t in range(sel.shape[0])]
+        x, we = sol.x, sol.we
     x, we = np.asarray(x), np.asarray(we)
     out = []
     for t in range(x.shape[0]):

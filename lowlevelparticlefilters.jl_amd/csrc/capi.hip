@@ -151,7 +151,8 @@ int llpf_run(llpf_filter* f, const double* U, const double* Y, int64_t T, double
     NEEDF(f);
     double lt = 0.0;
     int rc = bank_run(f->bank, U, Y, T, t_index0, &lt, o ? o->ll_steps : nullptr, o ? o->xmean : nullptr,
-                      o ? o->x_hist : nullptr, o ? o->w_hist : nullptr, o ? o->we_hist : nullptr, false, o ? o->xcov : nullptr);
+                      o ? o->x_hist : nullptr, o ? o->w_hist : nullptr, o ? o->we_hist : nullptr, false, o ? o->xcov : nullptr,
+                      o ? o->xquant : nullptr, o ? o->quant_p : nullptr, o ? o->nq : 0);
     if (ll_total) *ll_total = lt;
     return rc;
 } LLPF_GUARD(llpf_run)
@@ -173,7 +174,7 @@ int llpf_aux_update(llpf_filter* f, const double* u, const double* y1, double t,
 int llpf_aux_run(llpf_filter* f, const double* U, const double* Y, int64_t T, int32_t mode,
                  double* ll_total, const llpf_run_outputs* o) LLPF_TRY {
     NEEDF(f);
-    if (o && o->xcov) return fail(LLPF_ERR_ARG, "the xcov output is provided by llpf_run only");
+    if (o && (o->xcov || o->xquant)) return fail(LLPF_ERR_ARG, "the xcov / xquant outputs are provided by llpf_run only");
     double lt = 0.0;
     int rc = bank_aux_run(f->bank, U, Y, T, mode, &lt, o ? o->ll_steps : nullptr, o ? o->xmean : nullptr,
                           o ? o->x_hist : nullptr, o ? o->w_hist : nullptr, o ? o->we_hist : nullptr);
@@ -338,15 +339,13 @@ int llpf_weighted_quantile(llpf_filter* f, const double* q, int32_t nq, double* 
     if (b.we_is_lambda) return fail(LLPF_ERR_ARG, "weighted_quantile between the halves of an auxiliary predict!: expweights(pf) holds lambda there");
     CHK(use_device(b));
     BankDev d = b.dev();
-    HIPC(launch_materialize(d, nullptr, b.d_tmp, b.stream));                  // we = expweights(pf), [N]
-    double *dq = nullptr, *dout = nullptr;
-    HIPC(hipMalloc(&dq, sizeof(double) * nq));
-    if (hipMalloc(&dout, sizeof(double) * nq * b.nx) != hipSuccess) { hipFree(dq); return fail(LLPF_ERR_ALLOC, "llpf_weighted_quantile: out of device memory"); }
-    hipError_t e = hipMemcpyAsync(dq, q, sizeof(double) * nq, hipMemcpyHostToDevice, b.stream);
-    if (e == hipSuccess) e = launch_wquantile(d.xcur, b.Ns, b.nx, b.d_tmp, b.N, dq, nq, dout, b.stream);
-    if (e == hipSuccess) e = hipMemcpy(out, dout, sizeof(double) * nq * b.nx, hipMemcpyDeviceToHost);
-    hipFree(dq); hipFree(dout);
-    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? LLPF_ERR_ALLOC : LLPF_ERR_HIP, hipGetErrorString(e));
+    CHK(ensure_wq(b, q, nq));
+    HIPC(hipStreamSynchronize(b.stream));                                     // q is the caller's (pageable) memory
+    HIPC(launch_materialize(d, nullptr, b.d_wq_we, b.stream));               // we = expweights(pf), [N]
+    CHK(ensure(&b.d_xquant, &b.cap_xq, (size_t)nq * b.nx));
+    HIPC(launch_wquantile(d.xcur, b.Ns, b.nx, b.d_wq_we, b.N, b.d_wq_p, nq, b.d_xquant, b.nx, 1, b.d_wq, b.stream));      // [nq][nx]
+    HIPC(hipMemcpyAsync(out, b.d_xquant, sizeof(double) * (size_t)nq * b.nx, hipMemcpyDeviceToHost, b.stream));
+    HIPC(hipStreamSynchronize(b.stream));
     return LLPF_OK;
 } LLPF_GUARD(llpf_weighted_quantile)
 int llpf_resample_count(llpf_filter* f, int64_t* n) LLPF_TRY { NEEDF(f); if (n) *n = f->bank.run_resamples; return LLPF_OK; } LLPF_GUARD(llpf_resample_count)

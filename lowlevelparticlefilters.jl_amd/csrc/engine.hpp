@@ -267,7 +267,10 @@ hipError_t launch_rbfull(const BankDev& b, int mode, const StepArgs& a, hipStrea
 hipError_t launch_rbfull_init(const BankDev& b, hipStream_t s);   // LLPF_MODEL_RB_BILINEAR: xl, R of reset!
 hipError_t launch_wmean(const BankDev& b, double* out /* [F][nx] */, hipStream_t s);
 // weighted_quantile of one filter's particles (k_quantile.hip): x [nx][Ns] planes, we [N] exp-weights, q / out on the device ([nq], [nq][nx]); synchronises
-hipError_t launch_wquantile(const double* x, int64_t Ns, int nx, const double* we, int64_t N, const double* q, int nq, double* out, hipStream_t s);
+// k_quantile.hip: weighted_quantile by radix selection; out[q * stride_q + d * stride_d]; ws: wquantile_workspace_bytes(nx) of device memory
+size_t wquantile_workspace_bytes(int nx);
+hipError_t launch_wquantile(const double* x, int64_t Ns, int nx, const double* we, int64_t N, const double* q, int nq, double* out, int stride_q, int stride_d,
+                            void* ws, hipStream_t s);
 hipError_t launch_wcov(const BankDev& b, const double* mean /* [F][nx]: launch_wmean of the same state */, double* out /* [F][nx*nx] */, hipStream_t s);
 hipError_t launch_step(const BankDev& b, int mode, const StepArgs& a, hipStream_t s);
 hipError_t launch_max(const BankDev& b, int parity, hipStream_t s);           // maxima of the raw w into acc

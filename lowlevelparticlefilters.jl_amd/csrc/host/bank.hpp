@@ -22,6 +22,9 @@ struct Bank {
     uint64_t* d_quanta[2] = {nullptr, nullptr};
     int qcur = 0;                    // quanta buffer that holds the quanta of the current weights
     uint64_t* d_tileq = nullptr;
+    void* d_wq = nullptr;            // weighted_quantile: selection state (k_quantile.hip), the exp-weights [N], the probabilities [cap_wqp]
+    double *d_wq_we = nullptr, *d_wq_p = nullptr, *d_xquant = nullptr;
+    size_t cap_wqp = 0, cap_xq = 0;
     uint64_t *d_tpre = nullptr, *d_gsum = nullptr;      // filters above 1024 tiles: k_tile_prefix (kernels/resample.hpp)
     uint32_t* d_flag = nullptr;
     int64_t last_run_launches = 0, last_run_fx_steps = 0;
@@ -62,12 +65,13 @@ struct Bank {
     // (tools/launch_floor.hip: 1.6 vs 2.8 us per dependent empty launch).  Keyed by everything a launch argument depends on.
     struct RunGraph {
         int64_t T; double t_index0; int par0, cur0, qcur0, flags, np_parity;
-        const void *dU, *dY, *dll, *dxm, *dxc, *drb;      // every device buffer a captured launch addresses that ensure() may reallocate
+        const void *dU, *dY, *dll, *dxm, *dxc, *drb, *dxq, *dqp;      // every device buffer a captured launch addresses that ensure() may reallocate
+        int nq;
         uint64_t yhash;
         hipGraphExec_t exec;
         bool same(const RunGraph& o) const {
             return T == o.T && t_index0 == o.t_index0 && par0 == o.par0 && cur0 == o.cur0 && qcur0 == o.qcur0 && flags == o.flags &&
-                   np_parity == o.np_parity && dU == o.dU && dY == o.dY && dll == o.dll && dxm == o.dxm && dxc == o.dxc && drb == o.drb && yhash == o.yhash;
+                   np_parity == o.np_parity && dU == o.dU && dY == o.dY && dll == o.dll && dxm == o.dxm && dxc == o.dxc && drb == o.drb && dxq == o.dxq && dqp == o.dqp && nq == o.nq && yhash == o.yhash;
         }
     };
     std::vector<RunGraph> graphs;
@@ -125,6 +129,7 @@ static void free_bank(Bank& b) {
     for (auto& g : b.graphs) if (g.exec) hipGraphExecDestroy(g.exec);
     b.graphs.clear();
     hipFree(b.d_pool);               // models, scal, x, w, anc, acc, quanta, tileq, flag, rtile, rb, uy, tmp
+    hipFree(b.d_wq); hipFree(b.d_wq_we); hipFree(b.d_wq_p); hipFree(b.d_xquant);
     hipFree(b.d_xmpart); hipFree(b.d_lam); hipFree(b.d_surv); hipFree(b.d_mark); hipFree(b.d_fxs); hipFree(b.d_rbseq); hipFree(b.d_hist); hipFree(b.d_U); hipFree(b.d_Y);
     hipFree(b.d_ll_steps); hipFree(b.d_xmean); hipFree(b.d_xcov);
     for (auto e : b.ev_pool) hipEventDestroy(e);
@@ -200,6 +205,20 @@ static int ensure_xmpart(Bank& b) {
     const size_t n = (size_t)ACC_NSLOT * b.F * b.P1 * MAXD;
     HIPC(hipMalloc(&b.d_xmpart, sizeof(double) * n));
     HIPC(hipMemsetAsync(b.d_xmpart, 0, sizeof(double) * n, b.stream));
+    return LLPF_OK;
+}
+
+// weighted_quantile state: allocated by the first call that asks for quantiles; p [nq] uploaded
+static int ensure_wq(Bank& b, const double* p, int nq) {
+    if (!b.d_wq) HIPC(hipMalloc(&b.d_wq, wquantile_workspace_bytes(b.nx)));
+    if (!b.d_wq_we) HIPC(hipMalloc(&b.d_wq_we, sizeof(double) * (size_t)b.N));
+    if (b.cap_wqp < (size_t)nq) {
+        if (b.d_wq_p) hipFree(b.d_wq_p);
+        b.d_wq_p = nullptr; b.cap_wqp = 0;
+        HIPC(hipMalloc(&b.d_wq_p, sizeof(double) * (size_t)nq));
+        b.cap_wqp = (size_t)nq;
+    }
+    HIPC(hipMemcpyAsync(b.d_wq_p, p, sizeof(double) * (size_t)nq, hipMemcpyHostToDevice, b.stream));
     return LLPF_OK;
 }
 

@@ -14,7 +14,8 @@ static int ensure(double** p, size_t* cap, size_t n) {
 // reference's own benchmark, examples/example_lineargaussian.jl:282-316, as one bank); missing measurements must coincide.
 static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double t_index0,
                     double* ll_total /* [F] */, double* ll_steps /* [T][F] */, double* xmean /* [T][F][nx] */,
-                    double* x_hist, double* w_hist, double* we_hist, bool multi = false, double* xcov = nullptr) {
+                    double* x_hist, double* w_hist, double* we_hist, bool multi = false, double* xcov = nullptr,
+                    double* xquant = nullptr /* [T][nx][nq] */, const double* quant_p = nullptr /* [nq] */, int nq = 0) {
     CHK(use_device(b));
     if (T < 1) return fail(LLPF_ERR_ARG, "T must be >= 1");
     if (!Y) return fail(LLPF_ERR_ARG, "Y is null");
@@ -23,6 +24,14 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
     if ((x_hist || w_hist || we_hist) && b.F != 1) return fail(LLPF_ERR_ARG, "history outputs need a single filter");
     if (xcov && (b.F != 1 || is_rbfull(b))) return fail(LLPF_ERR_ARG, "the xcov output needs a single filter that is not LLPF_MODEL_RB_BILINEAR");
     if (xcov) CHK(ensure(&b.d_xcov, &b.cap_xc, (size_t)T * b.nx * b.nx + MAXD));
+    if (xquant) {      // weighted_quantile(sol, q) (src/filtering.jl:583-595) of the state the history would copy out, per timestep, on the device
+        if (b.F != 1 || is_rbfull(b)) return fail(LLPF_ERR_ARG, "the xquant output needs a single filter that is not LLPF_MODEL_RB_BILINEAR");
+        if (!quant_p || nq < 1 || nq > 1024) return fail(LLPF_ERR_ARG, "the xquant output needs 1 <= nq <= 1024 probabilities");
+        for (int i = 0; i < nq; ++i) if (!(quant_p[i] >= 0.0 && quant_p[i] <= 1.0)) return fail(LLPF_ERR_ARG, "xquant: a probability outside [0, 1]");
+        CHK(ensure_wq(b, quant_p, nq));
+        HIPC(hipStreamSynchronize(b.stream));
+        CHK(ensure(&b.d_xquant, &b.cap_xq, (size_t)T * b.nx * nq));
+    }
     b.aux_pending = false; b.we_is_lambda = false;
     const int FM = multi ? b.F : 1;                      // input sets on the device, laid out [T][FM][nu | ny]
     CHK(ensure(&b.d_U, &b.capU, (size_t)T * FM * (b.nu > 0 ? b.nu : 1)));
@@ -91,7 +100,7 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
     const int model_traits_v = user_model ? jit_model_traits(b.cfg.model.model_id) : 0;
     const bool no_bound = user_model && model_traits_v > 0 && (model_traits_v & LLPF_TRAIT_LOGLIK) && !(model_traits_v & LLPF_TRAIT_LOGLIK_BOUND);
     // (xcov: the covariance is taken from the state between correct! and predict!, which only the balanced form leaves in memory)
-    const bool unfused = user_model || rbfull || hist || residual || xcov != nullptr || (unf_env ? atoi(unf_env) != 0 : heavy_dynamics);
+    const bool unfused = user_model || rbfull || hist || residual || xcov != nullptr || xquant != nullptr || (unf_env ? atoi(unf_env) != 0 : heavy_dynamics);
     // models whose dynamics are worth a table: the resampling launch evaluates f(x_j) once per surviving source and leaves run-start marks,
     // the step kernel gathers (kernels/resfx.hpp).  LLPF_SOURCE_FX=0 takes the round-3 form (ancestors to HBM, f per distinct ancestor of a block)
     const char* sfx_env = getenv("LLPF_SOURCE_FX");
@@ -231,6 +240,11 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
                 HIPC(launch_wmean(d, mtmp, b.stream));
                 HIPC(launch_wcov(d, mtmp, b.d_xcov + (size_t)k * b.nx * b.nx, b.stream));
             }
+            if (xquant) {    // the quantiles of the same state: exp-weights materialised, then the radix selection (k_quantile.hip), [t][state][q]
+                ProfScope ps(b, LLPF_PROF_OTHER);
+                HIPC(launch_materialize(d, nullptr, b.d_wq_we, b.stream));
+                HIPC(launch_wquantile(d.xcur, b.Ns, b.nx, b.d_wq_we, b.N, b.d_wq_p, nq, b.d_xquant + (size_t)k * b.nx * nq, 1, nq, b.d_wq, b.stream));
+            }
             if (hist_dev) {   // x[:,t] .= particles(pf); w[:,t] .= weights(pf); we[:,t] .= expweights(pf)  (filtering.jl:357-359)
                 ProfScope ps(b, LLPF_PROF_OTHER);
                 if (dx_hist) HIPC(launch_soa2aos(b.devp(), b.d_x[b.cur], dx_hist + (size_t)k * b.N * b.nxp, b.stream));
@@ -288,9 +302,10 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
     if (use_graph) {
         Bank::RunGraph key{};
         key.T = T; key.t_index0 = t_index0; key.par0 = par0; key.cur0 = cur0; key.qcur0 = qcur0;
-        key.flags = (merged ? 1 : 0) | (unfused ? 2 : 0) | (want_xm ? 4 : 0) | (ll_steps ? 8 : 0) | (xm_launch ? 16 : 0) | (multi ? 32 : 0) | (source_fx ? 64 : 0) | (xcov ? 128 : 0) | ((abl_env ? atoi(abl_env) : 0) << 8);      // (no_bound is a property of the model id, which a handle keeps)
+        key.flags = (merged ? 1 : 0) | (unfused ? 2 : 0) | (want_xm ? 4 : 0) | (ll_steps ? 8 : 0) | (xm_launch ? 16 : 0) | (multi ? 32 : 0) | (source_fx ? 64 : 0) | (xcov ? 128 : 0) | (xquant ? 256 : 0) | ((abl_env ? atoi(abl_env) : 0) << 9);      // (no_bound is a property of the model id, which a handle keeps)
         key.np_parity = (int)(np0 & 1u);
         key.dU = b.d_U; key.dY = b.d_Y; key.dll = ll_steps ? b.d_ll_steps : nullptr; key.dxm = xmean ? b.d_xmean : nullptr; key.dxc = xcov ? b.d_xcov : nullptr; key.drb = b.d_rbseq;
+        key.dxq = xquant ? b.d_xquant : nullptr; key.dqp = xquant ? b.d_wq_p : nullptr; key.nq = xquant ? nq : 0;
         key.yhash = 1469598103934665603ULL;
         for (int64_t k = 0; k < T; ++k) key.yhash = (key.yhash ^ (uint64_t)(has_y(k) ? 1 : 2)) * 1099511628211ULL;
         // a run shape is captured the second time it is seen (capture + instantiation of ~T nodes costs several ms:
@@ -344,6 +359,10 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
                 double* mtmp = b.d_xcov + (size_t)T * b.nx * b.nx;
                 HIPC(launch_wmean(d, mtmp, b.stream));
                 HIPC(launch_wcov(d, mtmp, b.d_xcov + (size_t)k * b.nx * b.nx, b.stream));
+            }
+            if (xquant) {
+                HIPC(launch_materialize(d, nullptr, b.d_wq_we, b.stream));
+                HIPC(launch_wquantile(d.xcur, b.Ns, b.nx, b.d_wq_we, b.N, b.d_wq_p, nq, b.d_xquant + (size_t)k * b.nx * nq, 1, nq, b.d_wq, b.stream));
             }
             if (x_hist) {
                 HIPC(launch_soa2aos(b.devp(), b.d_x[b.cur], b.d_tmp, b.stream));
@@ -414,6 +433,7 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
     if (ll_steps) HIPC(hipMemcpyAsync(ll_steps, b.d_ll_steps, sizeof(double) * T * b.F, hipMemcpyDeviceToHost, b.stream));
     if (xmean) HIPC(hipMemcpyAsync(xmean, b.d_xmean, sizeof(double) * T * b.F * b.nxp, hipMemcpyDeviceToHost, b.stream));
     if (xcov) HIPC(hipMemcpyAsync(xcov, b.d_xcov, sizeof(double) * T * b.nx * b.nx, hipMemcpyDeviceToHost, b.stream));
+    if (xquant) HIPC(hipMemcpyAsync(xquant, b.d_xquant, sizeof(double) * T * b.nx * nq, hipMemcpyDeviceToHost, b.stream));
     std::vector<FilterScal> h;
     CHK(scal_download(b, h));
     float ms = 0.f;

@@ -35,7 +35,7 @@ import LowLevelParticleFilters: AbstractParticleFilter, ParticleFilteringSolutio
 export GPUParticleFilter, GPUAdvancedParticleFilter, GPUAuxiliaryParticleFilter, GPURBPF, GPUFilterBank, GPUMultiBank,
        LinearDynamics, LinearMeasurement, QuadTankDynamics, QuadTankMeasurement, GaussianLikelihood,
        RBLinearModel, RBBilinearModel, GaussianSpec, UserDynamics, UserMeasurement, UserLikelihood, UserNoise, UserInitial, linear_state, shared_covariance, loglik_multi, mbank_unique_id,
-       seed!, ancestors, last_resampled, set_parameters!
+       seed!, ancestors, last_resampled, set_parameters!, quantile_trajectory
 
 const LIB = get(ENV, "LLPF_HIP_LIB", joinpath(@__DIR__, "..", "libllpf_hip.so"))
 const MAXD = 16          # LLPF_MAX_DIM: states / outputs
@@ -93,7 +93,12 @@ struct CRunOutputs                    # llpf_run_outputs
     w_hist::Ptr{Float64}
     we_hist::Ptr{Float64}
     xcov::Ptr{Float64}
+    xquant::Ptr{Float64}              # ABI minor 6: weighted_quantile per timestep from the run loop, [nq, nx, T] in Julia's order
+    quant_p::Ptr{Float64}
+    nq::Int32
+    pad::Int32
 end
+CRunOutputs(ll, xm, x, w, we, xc) = CRunOutputs(ll, xm, x, w, we, xc, C_NULL, C_NULL, Int32(0), Int32(0))
 struct CMBankInfo                     # llpf_mbank_info_t
     n_filters::Int32
     n_shards::Int32
@@ -560,6 +565,26 @@ function run!(pf::GPF, u, y, tindex0; history = false)
                     pf.h, pf.nu > 0 ? pointer(U) : C_NULL, pointer(Y), T, Float64(tindex0), ll, outs))
     end
     ll[], x, w, we
+end
+
+"""quantile_trajectory(pf, u, y, q) -> (ll, Q): forward_trajectory's loop (src/filtering.jl:351-363) with
+`weighted_quantile(x[:,t], we[:,t], q)` (src/filtering.jl:583-595) of every timestep computed on the device inside the run loop
+(llpf_run's xquant output: a radix selection over the exp-weights, no history crosses the bus).  Q[t][i] is the vector of the
+length(q) quantiles of state i at step t — the reference's nesting."""
+function quantile_trajectory(pf::GPF, u::AbstractVector, y::AbstractVector, q)
+    reset!(pf)
+    T = length(y)
+    U = rows(u, pf.nu)
+    Y = rows(y, pf.ny)
+    qq = collect(Float64, q)
+    out = Array{Float64}(undef, length(qq), pf.nx, T)
+    ll = Ref{Float64}(0)
+    GC.@preserve U Y qq out begin
+        outs = Ref(CRunOutputs(C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, pointer(out), pointer(qq), Int32(length(qq)), Int32(0)))
+        check(ccall((:llpf_run, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64, Float64, Ref{Float64}, Ref{CRunOutputs}),
+                    pf.h, pf.nu > 0 ? pointer(U) : C_NULL, pointer(Y), T, 0.0, ll, outs))
+    end
+    ll[], [[out[:, i, t] for i in 1:pf.nx] for t in 1:T]
 end
 
 # history [nx, N, T] -> the reference's N x T Matrix{SVector{nx,Float64}} (src/filtering.jl:347), without copying

@@ -1660,6 +1660,89 @@ int orc_weighted_quantile(const double* v, const double* w, int64_t n, const dou
     free(vw); free(perm);
     return 0;
 }
+/* The same quantile in DEVICE ORDER — what the engine computes (csrc/k_quantile.hip, round 6), bit for bit.  StatsBase's running sum is a
+ * serial fp64 sum over the sorted particles; the device finds the crossing by a radix selection over weight histograms, so the sums are
+ * integers: m_i = floor(w_i 2^sc), capped at 2^98, with the scale chosen per quantile so that h 2^sc has its leading bit at 2^64 or above
+ * (sc = 96 for h >= 2^-32) — every particle with w > 0 is PRESENT (it can be the smallest / the predecessor / the largest value) even
+ * when it carries no mass at that scale, which is what makes p -> 0 return the smallest value again (round 5's accessor summed at 2^-96
+ * only).  The crossing test S_k > h is exact in integers; the interpolation is StatsBase's formula in fp64 with S_{k-1} the rounded exact
+ * sum and S_k = fl(S_{k-1} + w_k).  Differences from StatsBase are confined to the rounding of its serial sum (a weight below 2^-53 of
+ * the running sum is absorbed there and counted here).  v, w: [n]; p: [np]; out: [np]; returns 1 when nothing carries weight. */
+typedef unsigned __int128 orc_u128;
+static uint64_t wq_key(double x) { uint64_t u; memcpy(&u, &x, 8); return (u >> 63) ? ~u : (u | 0x8000000000000000ULL); }
+static double wq_unkey(uint64_t k) { const uint64_t u = (k >> 63) ? (k & 0x7fffffffffffffffULL) : ~k; double x; memcpy(&x, &u, 8); return x; }
+static orc_u128 wq_mass(double w, int sc) {            /* min(floor(w 2^sc), 2^98); 0 for subnormal w */
+    uint64_t u; memcpy(&u, &w, 8);
+    const int E = (int)(u >> 52) & 0x7ff;
+    if (E == 0 || E == 0x7ff || (u >> 63)) return 0;
+    const uint64_t M = (u & 0x000fffffffffffffULL) | 0x0010000000000000ULL;
+    const int sh = E - 1075 + sc;
+    const orc_u128 cap = (orc_u128)1 << 98;
+    if (sh >= 0) return sh > 45 ? cap : ((orc_u128)M << sh);      /* M < 2^53: M << 45 < 2^98 */
+    return -sh >= 53 ? 0 : (orc_u128)(M >> -sh);
+}
+static double wq_to_double(orc_u128 a, int sc) {       /* round-to-nearest-even of a 2^-sc */
+    if (a == 0) return 0.0;
+    uint64_t hi = (uint64_t)(a >> 64), lo = (uint64_t)a;
+    if (hi == 0) return ldexp((double)lo, -sc);
+    const int z = __builtin_clzll(hi);
+    uint64_t top = z ? ((hi << z) | (lo >> (64 - z))) : hi;
+    const uint64_t rest = z ? (lo << z) : lo;
+    if (rest) top |= 1;
+    return ldexp((double)top, 64 - z - sc);
+}
+typedef struct { uint64_t key; double w; } wq_pair;
+static int wq_less(const void* a, const void* b) {
+    const wq_pair *x = (const wq_pair*)a, *y = (const wq_pair*)b;
+    if (x->key != y->key) return x->key < y->key ? -1 : 1;
+    return x->w < y->w ? -1 : (x->w > y->w ? 1 : 0);
+}
+int orc_weighted_quantile_dev(const double* v, const double* w, int64_t n, const double* p, int np, double* out) {
+    if (n < 1 || np < 1) return 1;
+    for (int64_t i = 0; i < n; ++i) if (v[i] != v[i]) { for (int k = 0; k < np; ++k) out[k] = NAN; return 0; }
+    wq_pair* s = (wq_pair*)malloc(sizeof(wq_pair) * (size_t)n);
+    int64_t N = 0;
+    orc_u128 tot96 = 0;
+    for (int64_t i = 0; i < n; ++i) if (w[i] > 0.0) { s[N].key = wq_key(v[i]); s[N].w = w[i]; ++N; tot96 += wq_mass(w[i], 96); }
+    if (N == 0) { free(s); return 1; }
+    qsort(s, (size_t)N, sizeof(wq_pair), wq_less);
+    const double w1 = s[0].w;
+    double wsum = wq_to_double(tot96, 96);
+    if (wsum < w1) wsum = w1;
+    for (int q = 0; q < np; ++q) {
+        const double d = wsum - w1;
+        const double pd = p[q] * d;
+        const double h = pd + w1;
+        const int eh = ilogb(h);
+        const int sc = eh >= -32 ? 96 : 96 + (-32 - eh);
+        orc_u128 H;                                                /* h 2^sc: an integer (its lowest set bit is at 2^(eh + sc - 52) >= 2^12) */
+        { uint64_t u; memcpy(&u, &h, 8); const int E = (int)(u >> 52) & 0x7ff;
+          H = (orc_u128)((u & 0x000fffffffffffffULL) | 0x0010000000000000ULL) << (E - 1075 + sc); }
+        orc_u128 S = 0, Slt = 0;
+        int64_t k = 0;                                             /* first index of the group in which the running sum exceeds H */
+        int found = 0;
+        while (k < N) {
+            int64_t e = k;
+            orc_u128 g = 0;
+            while (e < N && s[e].key == s[k].key) { g += wq_mass(s[e].w, sc); ++e; }
+            if (S + g > H) { found = 1; Slt = S; break; }
+            S += g; k = e;
+        }
+        if (!found) { out[q] = wq_unkey(s[N - 1].key); continue; }
+        const double vk = wq_unkey(s[k].key);
+        if (Slt + wq_mass(s[k].w, sc) > H) {                        /* the crossing is at the group's first member (the lightest of the tie) */
+            const double vkold = k ? wq_unkey(s[k - 1].key) : 0.0;
+            const double Skold = k ? wq_to_double(Slt, sc) : 0.0;
+            const double Sk = Skold + s[k].w;
+            const double den = Sk - Skold;
+            out[q] = den > 0.0 ? vkold + (h - Skold) / den * (vk - vkold) : vk;
+        } else {
+            out[q] = vk;                                            /* inside the tie: v_{k-1} == v_k */
+        }
+    }
+    free(s);
+    return 0;
+}
 /* ... of the filter's current particles and exp-weights: out [np][particle_dim] */
 int orc_filter_weighted_quantile(const orc_filter* f, const double* p, int np, double* out) {
     const int pd = particle_dim(f);
@@ -1670,7 +1753,7 @@ int orc_filter_weighted_quantile(const orc_filter* f, const double* p, int np, d
     int rc = 0;
     for (int d = 0; d < pd && !rc; ++d) {
         for (int64_t i = 0; i < f->N; ++i) col[i] = x[i * pd + d];
-        rc = orc_weighted_quantile(col, f->we, f->N, p, np, o1);
+        rc = f->order == ORC_ORDER_DEVICE ? orc_weighted_quantile_dev(col, f->we, f->N, p, np, o1) : orc_weighted_quantile(col, f->we, f->N, p, np, o1);
         for (int k = 0; k < np; ++k) out[(size_t)k * pd + d] = o1[k];
     }
     free(col); free(x); free(o1);

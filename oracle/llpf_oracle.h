@@ -87,6 +87,7 @@ int    orc_shouldresample(const orc_filter* f);
 void   orc_weighted_mean(const orc_filter* f, double* xh);
 /* StatsBase.quantile(v, ProbabilityWeights(w), p) restated (reference src/filtering.jl:583-595); see llpf_oracle.c */
 int    orc_weighted_quantile(const double* v, const double* w, int64_t n, const double* p, int np, double* out);
+int    orc_weighted_quantile_dev(const double* v, const double* w, int64_t n, const double* p, int np, double* out);   /* device order: exact integer crossing */
 int    orc_filter_weighted_quantile(const orc_filter* f, const double* p, int np, double* out /* [np][particle_dim] */);
 int    orc_last_resampled(const orc_filter* f);
 double orc_maxw(const orc_filter* f);

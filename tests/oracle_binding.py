@@ -62,6 +62,7 @@ def load():
         getattr(lib, nm).argtypes = [C.c_void_p, _dp]
     lib.orc_get_ancestors.argtypes = [C.c_void_p, _ip]
     lib.orc_weighted_quantile.argtypes = [_dp, _dp, C.c_int64, _dp, C.c_int, _dp]
+    lib.orc_weighted_quantile_dev.argtypes = [_dp, _dp, C.c_int64, _dp, C.c_int, _dp]
     lib.orc_filter_weighted_quantile.argtypes = [C.c_void_p, _dp, C.c_int, _dp]
     lib.orc_set_index.argtypes = [C.c_void_p, C.c_int64]
     lib.orc_filter_ess.restype = C.c_double
@@ -344,6 +345,15 @@ def weighted_quantile(v, w, q):
     v, w, q = _f64(v), _f64(w), _f64(np.atleast_1d(q))
     out = np.empty(q.size)
     if lib().orc_weighted_quantile(dptr(v), dptr(w), v.size, dptr(q), q.size, dptr(out)):
+        raise ValueError("weighted_quantile: empty or weightless input")
+    return out
+
+
+def weighted_quantile_dev(v, w, q):
+    """the same quantile in device order (orc_weighted_quantile_dev: integer crossing, every particle with w > 0 present)"""
+    v, w, q = _f64(v), _f64(w), _f64(np.atleast_1d(q))
+    out = np.empty(q.size)
+    if lib().orc_weighted_quantile_dev(dptr(v), dptr(w), v.size, dptr(q), q.size, dptr(out)):
         raise ValueError("weighted_quantile: empty or weightless input")
     return out
 
