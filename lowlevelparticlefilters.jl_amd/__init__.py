@@ -6,3 +6,5 @@ libllpf_hip.so (include/llpf.h).  See api.py for the mirrored names.
 from . import _structs  # noqa: F401
 from . import _capi  # noqa: F401
 from .api import *  # noqa: F401,F403
+from . import tracing  # noqa: F401
+from .tracing import traced_dynamics, ifelse, rk4  # noqa: F401

@@ -207,6 +207,27 @@ class UserInitial:
         self.host = host
 
 
+_DESCRIPTORS = ()      # filled below: the descriptor classes a constructor accepts as they are
+
+
+def _is_plain_callable(f):
+    return callable(f) and not isinstance(f, _DESCRIPTORS)
+
+
+def _trace_callables(dyn, meas, mlik, nx, nu, ny, p, likelihood_bound=None):
+    """The reference's constructors take closures (src/PFtypes.jl:59-63, 189-193).  Plain Python callables with the reference's signatures
+    — dynamics(x, u, p, t), measurement(x, u, p, t), measurement_likelihood(x, u, y, p, t) — are traced once (tracing.py) and emitted
+    as the device snippet; returns the (UserDynamics, UserMeasurement, UserLikelihood | None) descriptors that stand for them."""
+    from . import tracing
+    if not _is_plain_callable(meas):
+        raise TypeError("a callable dynamics needs a callable measurement (both are traced into one device model)")
+    if nu < 0:
+        raise ValueError("pass nu= (the number of inputs) with callable dynamics: it cannot be read off a closure")
+    d = tracing.traced_dynamics(dyn, nx, nu, p=p, measurement=meas, ny=ny, measurement_likelihood=mlik if _is_plain_callable(mlik) else None,
+                                loglik_bound=likelihood_bound)
+    return d, d.measurement_model, d.likelihood_model
+
+
 def _build_model(dyn, meas, df, dg, d0, Ts, user_likelihood=False):
     if isinstance(dyn, UserDynamics):
         if not isinstance(meas, UserMeasurement):
@@ -263,6 +284,10 @@ class _AbstractParticleFilter:
         self.p = p
         self.threads = threads                          # accepted for signature parity; the GPU is always parallel
         self.Ts = float(Ts)
+        if _is_plain_callable(dyn):        # closures as the reference takes them: traced into a device model (tracing.py)
+            dyn, meas, _ = _trace_callables(dyn, meas, None, len(d0), nu, len(dg) if ny < 0 else ny, p)
+            self.dynamics, self.measurement = dyn, meas
+            nu = ny = -1
         if not isinstance(dyn, UserDynamics) and (isinstance(df, UserNoise) or isinstance(d0, UserInitial)):
             raise TypeError("UserNoise / UserInitial are members of a UserDynamics snippet")
         self._model = _build_model(dyn, meas, df, dg, d0, Ts, getattr(self, "_user_likelihood", False))
@@ -316,7 +341,13 @@ class AdvancedParticleFilter(_AbstractParticleFilter):
 
     def __init__(self, N, dynamics, measurement, measurement_likelihood, dynamics_density, initial_density, *,
                  resample_threshold=0.5, resampling_strategy=ResampleSystematic, rng=None, p=None,
-                 threads=False, Ts=1.0, nu=-1, ny=-1, device=0):
+                 threads=False, Ts=1.0, nu=-1, ny=-1, device=0, likelihood_bound=None):
+        if _is_plain_callable(measurement_likelihood):      # measurement_likelihood(x, u, y, p, t) as a closure (src/PFtypes.jl:226-239)
+            if not _is_plain_callable(dynamics) or ny < 0:
+                raise TypeError("a callable measurement_likelihood needs callable dynamics / measurement and ny=")
+            dynamics, measurement, measurement_likelihood = _trace_callables(dynamics, measurement, measurement_likelihood, len(initial_density), nu, ny, p,
+                                                                             likelihood_bound)
+            nu = -1
         self._user_likelihood = isinstance(measurement_likelihood, UserLikelihood)
         if isinstance(measurement_likelihood, UserLikelihood):
             if not isinstance(dynamics, UserDynamics):
@@ -329,6 +360,10 @@ class AdvancedParticleFilter(_AbstractParticleFilter):
         self._setup(N, dynamics, measurement, dynamics_density, dgs,
                     initial_density, resample_threshold, resampling_strategy, rng, p, threads, Ts, nu, ny, device)
         self.measurement_likelihood = measurement_likelihood
+
+
+_DESCRIPTORS = (LinearDynamics, LinearMeasurement, QuadTankDynamics, QuadTankMeasurement, GaussianLikelihood, UserDynamics, UserMeasurement,
+                UserLikelihood)
 
 
 class KalmanFilter:

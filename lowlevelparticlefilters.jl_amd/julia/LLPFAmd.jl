@@ -35,7 +35,7 @@ import LowLevelParticleFilters: AbstractParticleFilter, ParticleFilteringSolutio
 export GPUParticleFilter, GPUAdvancedParticleFilter, GPUAuxiliaryParticleFilter, GPURBPF, GPUFilterBank, GPUMultiBank,
        LinearDynamics, LinearMeasurement, QuadTankDynamics, QuadTankMeasurement, GaussianLikelihood,
        RBLinearModel, RBBilinearModel, GaussianSpec, UserDynamics, UserMeasurement, UserLikelihood, UserNoise, UserInitial, linear_state, shared_covariance, loglik_multi, mbank_unique_id,
-       seed!, ancestors, last_resampled, set_parameters!, quantile_trajectory
+       seed!, ancestors, last_resampled, set_parameters!, quantile_trajectory, trace_dynamics, emit_user_model
 
 const LIB = get(ENV, "LLPF_HIP_LIB", joinpath(@__DIR__, "..", "libllpf_hip.so"))
 const MAXD = 16          # LLPF_MAX_DIM: states / outputs
@@ -892,5 +892,7 @@ function Base.show(io::IO, b::GPUMultiBank)
     print(io, "GPUMultiBank($(i.n_filters) filters x $(b.N) particles, $(i.n_shards) shards, $(i.n_local_shards) here, collective = ",
           ("none", "rccl", "host", "external")[i.collective+1], ")")
 end
+
+include(joinpath(@__DIR__, "tracing.jl"))      # closures -> device snippet (trace_dynamics, emit_user_model)
 
 end # module

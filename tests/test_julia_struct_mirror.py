@@ -190,7 +190,7 @@ def test_julia_sources_are_block_balanced(tmp_path):
     docstrings) must be consistent — and the checker must notice when it is not (one `end` removed, one added, a bracket dropped)."""
     import julia_blocks as jb
     jdir = os.path.join(ROOT, "lowlevelparticlefilters.jl_amd", "julia")
-    for name in ("LLPFAmd.jl", "make_reference_fixtures.jl", os.path.join("test", "runtests.jl"), os.path.join("src", "LLPFAmd.jl")):
+    for name in ("LLPFAmd.jl", "tracing.jl", "make_reference_fixtures.jl", os.path.join("test", "runtests.jl"), os.path.join("src", "LLPFAmd.jl")):
         path = os.path.join(jdir, name)
         assert jb.check(path) == [], (name, jb.check(path)[:5])
         assert jb.doc_problems(path) == [], (name, jb.doc_problems(path)[:5])
