@@ -6,12 +6,17 @@ trailing `!` dropped (`reset!` -> `reset`, `predict!` -> `predict`, `correct!` -
 (include/llpf.h); nothing here computes particle data on the host, and there is no fallback when
 the GPU library is missing.
 
-User callables cannot run on the GPU, so the `dynamics` / `measurement` /
+A closure cannot run on the GPU, so the `dynamics` / `measurement` /
 `measurement_likelihood` arguments are *model descriptors*:
 
     LinearDynamics(A, B), LinearMeasurement(C)        x+ = A x + B u,  y = C x
     QuadTankDynamics(...), QuadTankMeasurement()      reference examples/example_quadtank.jl:8-35
     GaussianLikelihood(measurement, dg)               logpdf(dg, y - g(x)) for AdvancedParticleFilter
+    UserDynamics(src, ...) + UserMeasurement / ...    HIP source of a model of one's own (llpf_model_compile)
+
+— or, since round 6, ordinary Python callables with the reference's signatures (`dynamics(x, u, p, t)`, `measurement(x, u, p, t)`,
+`measurement_likelihood(x, u, y, p, t)`; pass `nu=` / `ny=`): straight-line functions are traced once on tracer numbers and emitted as
+the device snippet (tracing.py), operation for operation.
 """
 import ctypes as C
 
@@ -262,8 +267,8 @@ def _build_model(dyn, meas, df, dg, d0, Ts, user_likelihood=False):
         return S.make_lg_model(dyn.A, dyn.B, meas.C, df.struct(), dg.struct(), d0.struct(), Ts)
     if isinstance(dyn, QuadTankDynamics) and isinstance(meas, QuadTankMeasurement):
         return S.make_quadtank_model(df.struct(), dg.struct(), d0.struct(), Ts, dyn.supersample, **dyn.consts)
-    raise TypeError("dynamics/measurement must be built-in model descriptors (LinearDynamics+LinearMeasurement "
-                    "or QuadTankDynamics+QuadTankMeasurement): arbitrary callables cannot run on the GPU")
+    raise TypeError("dynamics / measurement must be model descriptors (LinearDynamics + LinearMeasurement, QuadTankDynamics + "
+                    "QuadTankMeasurement, UserDynamics + UserMeasurement) or a pair of plain callables (traced: tracing.py)")
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -662,15 +667,21 @@ def metropolis_bank(bank, spec_from_parameters, priors, u, y, R, theta0s, draw=N
         # whose candidate cannot be built (covariance not positive definite) or degenerates the filter scores -inf ALONE — the reference
         # wraps each chain's loglik in try / catch (src/smoothing.jl:276-280), so one bad proposal must not stop the others: the failing
         # slot (the library's message names the filter) is given its chain's current parameters and the bank runs again.
+        # Candidates that cannot be BUILT are found on the host first (cheap: no device work), all of them at once — only a filter that
+        # degenerates on the device can still cost a rerun (the library names the first such filter), and an error that names no filter
+        # (bad shapes of u / y, a lost device) is nobody's candidate and propagates at once.
+        for k in range(n):
+            if ok[k] and not _spec_builds(spec_from_parameters, thetas[k]):
+                ok[k] = False
         ll = None
         for _ in range(n + 1):
             try:
                 bank.set_parameters([spec_from_parameters(thetas[k] if ok[k] else cur[k]) for k in range(n)])
                 ll = bank.loglik(u, y)
                 break
-            except (_capi.LLPFError, ValueError, FloatingPointError, np.linalg.LinAlgError) as e:
+            except _capi.DegenerateWeights as e:
                 m = re.search(r"in filter (\d+)", str(e))
-                bad = int(m.group(1)) if m else next((k for k in range(n) if ok[k] and not _spec_builds(spec_from_parameters, thetas[k])), None)
+                bad = int(m.group(1)) if m else None
                 if bad is None or not ok[bad]:
                     raise
                 ok[bad] = False
