@@ -365,12 +365,16 @@ def main_reference_mc(args, rank, world):
 def other_configs():
     """The default line also carries the other single-GPU BASELINE configs, each from a short run of this same script (5 timed
     passes, a bounded one-thread CPU baseline of ~8 s) with its own roofline and cpu_baseline blocks: C3 quad-tank (N = 1e6, T = 2000), one GPU's share of C4 (128 filters x
-    1e5), C5 RBPF with per-particle covariance (N = 2e5).  Their full lines (with the multi-thread leg and the accuracy block) are `--workload ...`."""
+    1e5), C5 RBPF with per-particle covariance (N = 2e5) — and (round 6) the C2 system at N = 1.6e7, whose working set does not fit the
+    Infinity Cache.  Their full lines (with the multi-thread leg and the accuracy block) are `--workload ...`."""
     import subprocess
     res = {}
-    for key, wl in (("C3_quadtank", "quadtank"), ("C4_share_128x1e5", "bank"), ("C5_rbpf_full", "rbpf_full")):
+    for key, wl, extra in (("C3_quadtank", "quadtank", []), ("C4_share_128x1e5", "bank", []), ("C5_rbpf_full", "rbpf_full", []),
+                           # round 6: the C2 system with a working set (1 GB) beyond the 256 MB Infinity Cache: the headline's N = 1e6 (64 MB) is
+                           # served from the MALL, so its "HBM" fraction is not an HBM measurement; this one is (tools/bench_n.py has the sweep)
+                           ("C2_beyond_infinity_cache_N1.6e7", "lg", ["--particles", "16000000", "--T", "100"])):
         try:
-            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", wl, "--steps", "5", "--warmup", "1", "--cpu-quick"],
+            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", wl, "--steps", "5", "--warmup", "1", "--cpu-quick"] + extra,
                                capture_output=True, text=True, timeout=300)
             d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
             res[key] = {k: d.get(k) for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "kernel_us", "roofline",
@@ -689,6 +693,10 @@ def main():
                 if one_launch and pm["n_particles"] == N and pm["nx"] == nx and args.workload == "lg" and thr == pm["resample_threshold"]:
                     roof["traffic"] = pm["k_resprop"]["bytes"]
                     roof["traffic_source"] = pm["file"] + ": " + pm["source"] + "; " + pm["correction"]
+                big = pm.get("c2_big")
+                if one_launch and big and big["n_particles"] == N and args.workload == "lg" and thr == pm["resample_threshold"]:
+                    roof["traffic"] = big["k_resprop"]["bytes"]
+                    roof["traffic_source"] = pm["file"] + ": " + big["source"] + "; " + pm["correction"]
                 if args.workload == "quadtank" and pm["c3"]["n_particles"] == N:
                     roof["traffic"] = pm["c3"][roof["kernel"].split("<")[0]]["bytes"]
                     roof["traffic_source"] = pm["file"] + ": " + pm["c3"]["source"] + "; " + pm["correction"]

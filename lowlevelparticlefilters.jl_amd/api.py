@@ -640,6 +640,11 @@ def _spec_builds(spec_from_parameters, theta):
     try:
         dy, me, df, dg, d0 = spec_from_parameters(theta)
         _build_model(dy, me, df, dg, d0, 1.0)
+        for d in (df, dg, d0):                       # what the library's gauss_prepare (csrc/host/densities.hpp:23) asks of a covariance
+            c = np.asarray(d.cov, dtype=np.float64)
+            if not np.all(np.isfinite(c)) or not np.all(np.diag(c) > 0.0):
+                return False
+            np.linalg.cholesky(c)
         return True
     except Exception:
         return False
@@ -667,9 +672,10 @@ def metropolis_bank(bank, spec_from_parameters, priors, u, y, R, theta0s, draw=N
         # whose candidate cannot be built (covariance not positive definite) or degenerates the filter scores -inf ALONE — the reference
         # wraps each chain's loglik in try / catch (src/smoothing.jl:276-280), so one bad proposal must not stop the others: the failing
         # slot (the library's message names the filter) is given its chain's current parameters and the bank runs again.
-        # Candidates that cannot be BUILT are found on the host first (cheap: no device work), all of them at once — only a filter that
-        # degenerates on the device can still cost a rerun (the library names the first such filter), and an error that names no filter
-        # (bad shapes of u / y, a lost device) is nobody's candidate and propagates at once.
+        # Candidates that cannot be BUILT are found on the host first (cheap: no device work), all of them at once — what can still cost a
+        # rerun is a filter that degenerates on the device or a density that only the library refuses (a variance that underflowed to
+        # zero passes the host's shape checks); the library names the first such filter.  An error that names no filter (bad shapes of
+        # u / y, a lost device) is nobody's candidate and propagates at once.
         for k in range(n):
             if ok[k] and not _spec_builds(spec_from_parameters, thetas[k]):
                 ok[k] = False
@@ -679,7 +685,7 @@ def metropolis_bank(bank, spec_from_parameters, priors, u, y, R, theta0s, draw=N
                 bank.set_parameters([spec_from_parameters(thetas[k] if ok[k] else cur[k]) for k in range(n)])
                 ll = bank.loglik(u, y)
                 break
-            except _capi.DegenerateWeights as e:
+            except _capi.LLPFError as e:                 # DegenerateWeights is one
                 m = re.search(r"in filter (\d+)", str(e))
                 bad = int(m.group(1)) if m else None
                 if bad is None or not ok[bad]:

@@ -57,9 +57,15 @@ static hipError_t launch_resprop_lg_ny(const BankDev& b, const ResArgs& a, const
 }
 template <int NX>
 static hipError_t launch_resprop_rb_ny(const BankDev& b, const ResArgs& a, const StepArgs& st, int weight, hipStream_t s) {
-    // the split known at compile time where it is measured (the reference's own RBPF benchmark system, test/test_rbpf.jl:5-31: 1 + 1 states,
-    // one output); BankDev::pad0 carries nxn for this model.  Other shapes: the run-time split, same bits.
-    if (NX == 2 && b.ny == 1 && b.pad0 == 1) return launch_resprop_t<RBLin<2, 1, 1>, 2, 1>(b, a, st, weight, s);
+    // the nonlinear / linear split as a compile-time constant (kernels/models.hpp: RBLin<NX, NY, NN>; measured on the reference's own RBPF
+    // benchmark system, test/test_rbpf.jl:5-31: 1 + 1 states, one output: 30.0 -> 22.7 us per timestep) for every split with one or two
+    // outputs; BankDev::pad0 carries nxn for this model.  Three and four outputs: the run-time split, same bits.
+    if (b.ny <= 2 && b.pad0 >= 1 && b.pad0 < NX) {
+#define LLPF_RB_LEAN(NN) if constexpr (NN < NX) { if (b.pad0 == NN) return b.ny == 1 ? launch_resprop_t<RBLin<NX, 1, NN>, NX, 1>(b, a, st, weight, s) \
+                                                                                     : launch_resprop_t<RBLin<NX, 2, NN>, NX, 2>(b, a, st, weight, s); }
+        LLPF_RB_LEAN(1) LLPF_RB_LEAN(2) LLPF_RB_LEAN(3)
+#undef LLPF_RB_LEAN
+    }
     switch (b.ny) {
         case 1: return launch_resprop_t<RBLin<NX, 1>, NX, 1>(b, a, st, weight, s);
         case 2: return launch_resprop_t<RBLin<NX, 2>, NX, 2>(b, a, st, weight, s);

@@ -135,5 +135,5 @@ def test_two_ranks_on_the_real_library_match_the_unsharded_bank():
     assert np.array_equal(ll_one, ll_ref)
     assert sorted(n for _, n, _, _ in res) == [2, 3]
     for rank, _, collective, ll in res:
-        assert collective == 3, "MBANK_COLL_EXTERNAL expected"          # the handle left the exchange to the caller
+        assert collective == "external", "MBANK_COLL_EXTERNAL expected"          # the handle left the exchange to the caller
         assert np.array_equal(ll, ll_one), "rank %d" % rank

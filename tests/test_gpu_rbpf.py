@@ -100,6 +100,50 @@ def test_rbpf_fused_kernel_with_the_split_known_at_compile_time(thr):
     assert np.array_equal(g.ancestors(), o.ancestors())
 
 
+def _random_rb_model(nn, nl, ny, seed):
+    rng = np.random.default_rng(seed)
+    g = S.make_gaussian
+
+    def stable(n, rho):
+        Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+        return Q @ np.diag(rho * rng.uniform(0.5, 1.0, n)) @ Q.T
+
+    def spd(n, s):
+        a = rng.standard_normal((n, n))
+        return s * (a @ a.T + n * np.eye(n)) / n
+
+    # the coupling An of the shared-covariance form needs a scalar Nt (host/densities.hpp: nn == 1); with more nonlinear states An = 0
+    An = 0.4 * rng.standard_normal((nn, nl)) if nn == 1 else None
+    return S.make_rb_model(stable(nn, 0.9), 0.3 * rng.standard_normal((nn, 1)), An, stable(nl, 0.95),
+                           0.3 * rng.standard_normal((nl, 1)), rng.standard_normal((ny, nn)), rng.standard_normal((ny, nl)),
+                           g(np.zeros(nn), spd(nn, 0.02)), spd(nl, 0.02), g(np.zeros(ny), spd(ny, 0.2)),
+                           g(0.3 * rng.standard_normal(nn), spd(nn, 0.3)), g(0.3 * rng.standard_normal(nl), spd(nl, 0.5)))
+
+
+@pytest.mark.parametrize("nn,nl,ny", [(1, 1, 2), (1, 2, 1), (2, 1, 2), (1, 3, 2), (2, 2, 1), (3, 1, 1), (2, 2, 3)])
+def test_rbpf_fused_kernel_every_split(nn, nl, ny):
+    """every nonlinear / linear split of up to four states through the fused kernel — with one or two outputs the instantiation that knows
+    the split at compile time (k_resprop.hip: LLPF_RB_LEAN), with three the run-time split — against the device-order oracle: several
+    tiles, a missing measurement, dense covariances everywhere, an input; the one-tile form and the history run (step kernel) as well."""
+    model = _random_rb_model(nn, nl, ny, 100 * nn + 10 * nl + ny)
+    rng = np.random.default_rng(7)
+    T = 40
+    U = rng.standard_normal((T, 1))
+    Y = rng.standard_normal((T, ny))
+    Y[9] = np.nan
+    for N in (3000 + 7, 700):
+        cfg = _cfg(model, N, S.RESAMPLE_SYSTEMATIC, 0.5, seed=13)
+        g = _capi.FilterHandle(cfg); gh = _capi.FilterHandle(cfg); o = ob.OracleFilter(cfg, ob.ORDER_DEVICE)
+        for h in (g, gh, o):
+            h.reset()
+        rg = g.run(U, Y, 0.0, ll_steps=True); rh = gh.run(U, Y, 0.0, ll_steps=True, history=True); ro = o.run(U, Y, 0.0, ll_steps=True)
+        assert g.last_run_stats()["fused_launches"] > 0
+        assert np.array_equal(rg["ll_steps"].view(np.uint64), ro["ll_steps"].view(np.uint64))
+        assert np.array_equal(rh["ll_steps"].view(np.uint64), ro["ll_steps"].view(np.uint64))
+        assert o.resample_count() >= 1 and g.resample_count() == o.resample_count()
+        _compare_state(g, o); _compare_state(gh, o)
+
+
 def test_rbpf_api():
     """RBPF(N, kf, dynamics, nl_measurement_model, R1n, d0n; An, ...) through the reference-shaped API: loglik close to
     the Kalman filter's (test/test_rbpf.jl:110), forward_trajectory shapes, the shared covariance accessor."""

@@ -46,6 +46,11 @@ j = {"engine_source_hash": engine_source_hash(),
 e = entry(os.path.join(d, "pmc_traffic.txt"), "k_resprop<llpf::LinGauss<2, 1>", 60 * N, {"algorithmic_bytes": 72 * N})
 if e:
     j["k_resprop"] = e
+# round 6: the same kernel with a working set beyond the Infinity Cache (N = 1.6e7: 1 GB)
+NB = 16000000
+e = entry(os.path.join(d, "pmc_traffic_c2_big.txt"), "k_resprop<llpf::LinGauss<2, 1>", 60 * NB, {"algorithmic_bytes": 72 * NB})
+if e:
+    j["c2_big"] = {"source": "profiles/%s_pmc_traffic_c2_big.txt (same recipe, C2 system at N=1.6e7, T=20)" % tag, "k_resprop": e, "n_particles": NB}
 # "k_rbfull<": the template kernel, not k_rbfull_init (whose later row a bare substring match would return: round 2's summary did)
 e = entry(os.path.join(d, "pmc_traffic_c5.txt"), "k_rbfull<", 788 * 200000)
 if e:
