@@ -2,4 +2,12 @@
 // second time with the constants of the shared polynomials (llpf_horner) as SGPR pairs.  See the comment at LLPF_RESPROP_SPLIT_TU there.
 #define LLPF_RESPROP_SPLIT_TU 1
 #define LLPF_HORNER_C(c) "s"(c)
+// The split schedule is the one of filters and banks beyond 3 M particles (host/run.hpp): their planes do not fit the Infinity Cache, and
+// what the write-through stores of the output loop buy a 10^6-particle filter (no write-back of dirty L2 lines at the kernel boundary)
+// they lose here — same box, us per timestep of ONE filter, write-through / plain / nontemporal stores: N = 4e6 63.5 / 60.0 / 75.8,
+// N = 1.6e7 272 / 240 / 249; plain stores with the sources of two loop rounds requested together (LLPF_RESPROP_PF): 60.4, 236; one
+// GPU's share of C4 (128 x 1e5): 194 / 193 / 186 (profiles/r06_bign_store_policy_ab.txt)
+#ifndef LLPF_RESPROP_ST
+#define LLPF_RESPROP_ST 0
+#endif
 #include "k_resprop.hip"

@@ -206,13 +206,26 @@ __global__ __launch_bounds__(RBF_BLOCK) __attribute__((amdgpu_waves_per_eu(NL >=
         if (MODE != MODE_WEIGHT) {
             mdl = prepared(idx);       // the constants' scalar loads go out first and are back when the noise is done
             double xi[NN];
+#if defined(LLPF_RBF_ABL_NOISE) && LLPF_RBF_ABL_NOISE == 1      /* timing experiments only (tools/ab/c5_front.sh): no generator ... */
+#pragma unroll
+            for (int d = 0; d < NN; ++d) xi[d] = 0x1p-30 * (double)(idx + d);
+#elif defined(LLPF_RBF_ABL_NOISE) && LLPF_RBF_ABL_NOISE == 2    /* ... or its output read from memory as if a launch before this one had written it */
+#pragma unroll
+            for (int d = 0; d < NN; ++d) xi[d] = 0x1p-30 * *rbf_at(const_cast<double*>(xc) + (size_t)(NN + d) * Ns, idx);
+#else
             llpf_normals_tab(idx, sb + a.step, LLPF_STREAM_DYNAMICS, k0, k1, NN, xi, sh_rng_lg, sh_rng_sc);
+#endif
             gauss_sample_c<NN>((gauss_cptr)&md->df, xi, nz);
             RBF_TSTAMP(19, nz[NN - 1]);        // generator done
         }
         RBF_TSTAMP(20, xn[NN - 1]);            // xn back
         if (MODE != MODE_WEIGHT) {
+#if defined(LLPF_RBF_ABL_DYN)                                   /* timing experiments only: no RK4 */
+#pragma unroll
+            for (int d = 0; d < NN; ++d) fi[d] = xn[d];
+#else
             mdl.dynamics(xn, fi);
+#endif
 #if defined(LLPF_RBF_TIMING) && defined(__HIP_DEVICE_COMPILE__)
             asm volatile("" : : "v"(fi[NN - 1]), "v"(nz[NN - 1]));      // RK4 and the generator are done before stamp 1
 #endif

@@ -27,9 +27,16 @@ template <class T> DEV void st_off(T* base, uint32_t byte_off, T v) {
 #ifndef LLPF_RBX_WT
 #define LLPF_RBX_WT 1       /* ... and write-through stores (same box, us per timestep at N = 1e6: run-time split 30.0; compile-time split 24.6; + tables 23.1; + four waves 23.3; + these 22.7 — profiles/r06_rbpf_lean_ab.txt) */
 #endif
+#ifndef LLPF_RESPROP_PF
+#define LLPF_RESPROP_PF 2      /* rounds of the split-schedule output loop whose sources are requested together (1.6e7 particles, plain stores: 1: 240.5, 2: 236, 4: 250 us) */
+#endif
 #define LLPF_RB_PLAIN_ST (Model::RB && !(model_lean<Model>::value && LLPF_RBX_WT))
-#define LLPF_STCOH ((LLPF_WT && !LLPF_RB_PLAIN_ST) ? 1 : COH)
-#define LLPF_STCOH0 ((LLPF_WT && !LLPF_RB_PLAIN_ST) ? 1 : 0)
+// store policy of the output loop (Mem<>::st): 1 = write-through (sc1), 0 = plain, 2 = nontemporal
+#ifndef LLPF_RESPROP_ST
+#define LLPF_RESPROP_ST 1
+#endif
+#define LLPF_STCOH ((LLPF_WT && !LLPF_RB_PLAIN_ST) ? LLPF_RESPROP_ST : COH)
+#define LLPF_STCOH0 ((LLPF_WT && !LLPF_RB_PLAIN_ST) ? LLPF_RESPROP_ST : 0)
 template <class Model, int NX, int NY, bool WEIGHT, bool COH = false, bool LTAB = false>
 struct PropCtx {
     const BankDev& b;
@@ -49,12 +56,23 @@ struct PropCtx {
     const double* rng_sc = nullptr;   //   tables in constant memory (a global load through the GOT per lookup)
     // propagate output o from source src with previous log-weight wprev; returns the new log-weight
     // Addresses are a uniform plane base (SGPRs) + a 32-bit byte offset (one VGPR): Ns * 8 < 2^32 is checked at create.
-    DEV double one(uint32_t src, uint32_t o, double wprev, bool& bad, double* xs) const {
+    // the source's state (nontemporal: C2 22.8 against 20.7 us — duplicated ancestors are re-read from the L2)
+    DEV void fetch(uint32_t src, double* xp) const {
         const int64_t Ns = b.Ns;
-        const uint32_t so = src << 3, oo = o << 3;
-        double xp[NX], fx[NX], xi[NX], nz[NX];
+        const uint32_t so = src << 3;
 #pragma unroll
-        for (int d = 0; d < NX; ++d) xp[d] = Mem<COH>::ld_off(xc + (size_t)d * Ns, so);      // (nontemporal: C2 22.8 against 20.7 us — duplicated ancestors are re-read from the L2)
+        for (int d = 0; d < NX; ++d) xp[d] = Mem<COH>::ld_off(xc + (size_t)d * Ns, so);
+    }
+    DEV double one(uint32_t src, uint32_t o, double wprev, bool& bad, double* xs) const {
+        double xp[NX];
+        fetch(src, xp);
+        return one_x(xp, o, wprev, bad, xs);
+    }
+    // ... from the state xp of its source (fetch)
+    DEV double one_x(const double* xp, uint32_t o, double wprev, bool& bad, double* xs) const {
+        const int64_t Ns = b.Ns;
+        const uint32_t oo = o << 3;
+        double fx[NX], xi[NX], nz[NX];
         if constexpr (Model::RB) {     // Rao-Blackwellized model: own noise structure, and correct! updates xl before the store
             if constexpr (LTAB) model.rb_propagate(xp, o, pstep, k0, k1, st.rb_pred + blockIdx.y, xs, rng_lg, rng_sc);
             else model.rb_propagate(xp, o, pstep, k0, k1, st.rb_pred + blockIdx.y, xs);
@@ -327,10 +345,52 @@ _Pragma("unroll") \
             } \
         } \
     }
+    // The same loop with the sources of LLPF_RESPROP_PF consecutive rounds requested together, for the split-schedule form — the kernel of
+    // filters and banks beyond 3 M particles, whose states come from HBM instead of the Infinity Cache.  Worth 2 % at depth 2 and
+    // nothing beyond (depth 4 is slower): the loop of such a launch does not wait for its gathers — what moved it was the store policy
+    // (k_resprop_split.hip).  The per-output arithmetic and its order are untouched; the ancestors are stored behind the loads (stores
+    // and loads share a counter).
+#define LLPF_OUTPUT_LOOP_PF(RESX) \
+_Pragma("unroll 1") \
+    for (uint32_t ob = (uint32_t)first + threadIdx.x; ob < ulast; ob += LLPF_RESPROP_PF * BLOCK) { \
+        uint32_t srcs[LLPF_RESPROP_PF]; \
+        double wps[LLPF_RESPROP_PF], xps[LLPF_RESPROP_PF][NX]; \
+_Pragma("unroll") \
+        for (int k = 0; k < LLPF_RESPROP_PF; ++k) { \
+            const uint32_t o = ob + (uint32_t)k * BLOCK; \
+            srcs[k] = o; \
+            if (RESX && o < ulast) { \
+                if (o < ucend) srcs[k] = tile0 + owner_of(o); \
+                else srcs[k] = anc_ident_prev ? o : (uint32_t)ld_off(anc, o << 2); \
+            } \
+        } \
+_Pragma("unroll") \
+        for (int k = 0; k < LLPF_RESPROP_PF; ++k) { \
+            const uint32_t o = ob + (uint32_t)k * BLOCK; \
+            wps[k] = b.log1N; \
+            if (o < ulast) { \
+                pc.fetch(srcs[k], xps[k]); \
+                if (!(RESX) && WEIGHT) wps[k] = (ld_off(pc.w, o << 3) - h.a) - l; \
+            } \
+        } \
+_Pragma("unroll") \
+        for (int k = 0; k < LLPF_RESPROP_PF; ++k) { \
+            const uint32_t o = ob + (uint32_t)k * BLOCK; \
+            if (o < ulast) { \
+                if (RESX) Mem<LLPF_STCOH0>::st_off(anc, o << 2, (int32_t)srcs[k]); \
+                double xs[NX]; \
+                const double wv = pc.one_x(xps[k], o, wps[k], bad, xs); \
+                bmax = llpf_fmax(bmax, wv); \
+            } \
+        } \
+    }
+    constexpr bool PREFETCH = LLPF_RESPROP_PF > 1 && !(WEIGHT && ACC) && !Model::RB && !AUX;
     if constexpr (WEIGHT && ACC && !Model::RB) { LLPF_OUTPUT_LOOP(res) }
+    else if constexpr (PREFETCH) { if (res) { LLPF_OUTPUT_LOOP_PF(true) } else { LLPF_OUTPUT_LOOP_PF(false) } }
     else if (res) { LLPF_OUTPUT_LOOP(true) }
     else { LLPF_OUTPUT_LOOP(false) }
 #undef LLPF_OUTPUT_LOOP
+#undef LLPF_OUTPUT_LOOP_PF
     if (WEIGHT && ACC) ts.flush(sh_tq, tq_next, tbase);
     __builtin_amdgcn_s_setprio(3);
     LLPF_STAMP(3);
