@@ -10,4 +10,11 @@
 #ifndef LLPF_RESPROP_ST
 #define LLPF_RESPROP_ST 0
 #endif
+// ... and by kind of step (same box, tools/ab/bign_store_matrix.sh, us per timestep, plain / nontemporal / write-through): a step that
+// resamples — N = 1.6e7 252.7 / 261.8 / 279.4, C4 share 217.3 / 217.5 / 232.2; a step that does not (every output reads its own index,
+// nothing a store leaves in the L2 is read again by the launch; 97 of 100 steps at the reference's threshold) — N = 1.6e7 237.5 / 234.7 /
+// 241.6, C4 share 204.1 / 195.9 / 209.7: nontemporal stores on those (profiles/r06_bign_store_matrix.txt)
+#ifndef LLPF_RESPROP_ST_ID
+#define LLPF_RESPROP_ST_ID 2
+#endif
 #include "k_resprop.hip"

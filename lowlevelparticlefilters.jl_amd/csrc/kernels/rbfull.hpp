@@ -208,10 +208,11 @@ __global__ __launch_bounds__(RBF_BLOCK) __attribute__((amdgpu_waves_per_eu(NL >=
             double xi[NN];
 #if defined(LLPF_RBF_ABL_NOISE) && LLPF_RBF_ABL_NOISE == 1      /* timing experiments only (tools/ab/c5_front.sh): no generator ... */
 #pragma unroll
-            for (int d = 0; d < NN; ++d) xi[d] = 0x1p-30 * (double)(idx + d);
+            for (int d = 0; d < NN; ++d) xi[d] = 0x1.bp-31 * (double)(int32_t)((idx + (uint32_t)d * 977u + (sb + a.step) * 7919u) * 2654435761u);
 #elif defined(LLPF_RBF_ABL_NOISE) && LLPF_RBF_ABL_NOISE == 2    /* ... or its output read from memory as if a launch before this one had written it */
 #pragma unroll
-            for (int d = 0; d < NN; ++d) xi[d] = 0x1p-30 * *rbf_at(const_cast<double*>(xc) + (size_t)(NN + d) * Ns, idx);
+            for (int d = 0; d < NN; ++d)
+                xi[d] = 0x1p-40 * *rbf_at(const_cast<double*>(xc) + (size_t)(NN + d) * Ns, idx) + 0x1.bp-31 * (double)(int32_t)((idx + (uint32_t)d * 977u + (sb + a.step) * 7919u) * 2654435761u);
 #else
             llpf_normals_tab(idx, sb + a.step, LLPF_STREAM_DYNAMICS, k0, k1, NN, xi, sh_rng_lg, sh_rng_sc);
 #endif
@@ -293,7 +294,11 @@ __global__ __launch_bounds__(RBF_BLOCK) __attribute__((amdgpu_waves_per_eu(NL >=
 #pragma unroll
                 for (int k = 0; k < NY; ++k) y[k] = sh_y[k];
                 prepared(xn[0]).measurement(xn, yn);
+#if defined(LLPF_RBF_ABL_CORR)                                  /* timing experiments only: no measurement update */
+                wv = wv + 0x1p-40 * (xl[0] + yn[0] + y[0]);
+#else
                 wv = wv + llpf_rbf_correct(par, NL, NY, y, yn, xl, R);   // w[i] += ll, src/rbpf.jl:272
+#endif
 #if defined(LLPF_RBF_TIMING) && defined(__HIP_DEVICE_COMPILE__)
                 asm volatile("" : : "v"(wv));
                 RBF_STAMP(11);

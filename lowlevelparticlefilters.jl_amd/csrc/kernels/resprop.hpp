@@ -35,7 +35,11 @@ template <class T> DEV void st_off(T* base, uint32_t byte_off, T v) {
 #ifndef LLPF_RESPROP_ST
 #define LLPF_RESPROP_ST 1
 #endif
-#define LLPF_STCOH ((LLPF_WT && !LLPF_RB_PLAIN_ST) ? LLPF_RESPROP_ST : COH)
+// ... and of the steps that do not resample (every output reads its own index: nothing a store leaves in the L2 is read again by this launch)
+#ifndef LLPF_RESPROP_ST_ID
+#define LLPF_RESPROP_ST_ID LLPF_RESPROP_ST
+#endif
+#define LLPF_STCOH ((LLPF_WT && !LLPF_RB_PLAIN_ST) ? STP : COH)
 #define LLPF_STCOH0 ((LLPF_WT && !LLPF_RB_PLAIN_ST) ? LLPF_RESPROP_ST : 0)
 template <class Model, int NX, int NY, bool WEIGHT, bool COH = false, bool LTAB = false>
 struct PropCtx {
@@ -63,12 +67,14 @@ struct PropCtx {
 #pragma unroll
         for (int d = 0; d < NX; ++d) xp[d] = Mem<COH>::ld_off(xc + (size_t)d * Ns, so);
     }
+    template <int STP = LLPF_RESPROP_ST>
     DEV double one(uint32_t src, uint32_t o, double wprev, bool& bad, double* xs) const {
         double xp[NX];
         fetch(src, xp);
-        return one_x(xp, o, wprev, bad, xs);
+        return one_x<STP>(xp, o, wprev, bad, xs);
     }
-    // ... from the state xp of its source (fetch)
+    // ... from the state xp of its source (fetch); STP: the store policy of this call (LLPF_RESPROP_ST / LLPF_RESPROP_ST_ID)
+    template <int STP = LLPF_RESPROP_ST>
     DEV double one_x(const double* xp, uint32_t o, double wprev, bool& bad, double* xs) const {
         const int64_t Ns = b.Ns;
         const uint32_t oo = o << 3;
@@ -348,8 +354,9 @@ _Pragma("unroll") \
     // The same loop with the sources of LLPF_RESPROP_PF consecutive rounds requested together, for the split-schedule form — the kernel of
     // filters and banks beyond 3 M particles, whose states come from HBM instead of the Infinity Cache.  Worth 2 % at depth 2 and
     // nothing beyond (depth 4 is slower): the loop of such a launch does not wait for its gathers — what moved it was the store policy
-    // (k_resprop_split.hip).  The per-output arithmetic and its order are untouched; the ancestors are stored behind the loads (stores
-    // and loads share a counter).
+    // (k_resprop_split.hip), which this loop takes per kind of step: LLPF_RESPROP_ST on a resampling step, LLPF_RESPROP_ST_ID on a step
+    // whose outputs read their own index.  The per-output arithmetic and its order are untouched; the ancestors are stored behind the
+    // loads (stores and loads share a counter).
 #define LLPF_OUTPUT_LOOP_PF(RESX) \
 _Pragma("unroll 1") \
     for (uint32_t ob = (uint32_t)first + threadIdx.x; ob < ulast; ob += LLPF_RESPROP_PF * BLOCK) { \
@@ -379,7 +386,7 @@ _Pragma("unroll") \
             if (o < ulast) { \
                 if (RESX) Mem<LLPF_STCOH0>::st_off(anc, o << 2, (int32_t)srcs[k]); \
                 double xs[NX]; \
-                const double wv = pc.one_x(xps[k], o, wps[k], bad, xs); \
+                const double wv = pc.template one_x<(RESX) ? LLPF_RESPROP_ST : LLPF_RESPROP_ST_ID>(xps[k], o, wps[k], bad, xs); \
                 bmax = llpf_fmax(bmax, wv); \
             } \
         } \
