@@ -17,4 +17,9 @@
 #ifndef LLPF_RESPROP_ST_ID
 #define LLPF_RESPROP_ST_ID 2
 #endif
+// ... whose sources are read nontemporal as well (each is read once): N = 1.6e7 at threshold 0.1 230.0 -> 219.7, C4 share 192.2 -> 188.9,
+// steps that resample unchanged (profiles/r06_bign_nt_loads_ab.txt)
+#ifndef LLPF_RESPROP_LD_ID
+#define LLPF_RESPROP_LD_ID 1
+#endif
 #include "k_resprop.hip"

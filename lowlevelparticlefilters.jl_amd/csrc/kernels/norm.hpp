@@ -10,6 +10,19 @@
 // flags were four dependent scalar round trips in front of the weights' request (round 5, EXPERIMENTS 5.8).
 #define LLPF_NORM_HOT_PARAMS const double* hot_w, const FilterScal* hot_scal, const uint32_t* hot_flag, int64_t hot_Ns
 #define LLPF_NORM_HOT_ARGS(b) (b).w, (b).scal, (b).bank_flag, (b).Ns
+// the two quanta of a thread: one 16-byte store (LLPF_NORM_ST 2: nontemporal — tools/ab/bign_store_matrix.sh)
+#ifndef LLPF_NORM_ST
+#define LLPF_NORM_ST 0
+#endif
+DEV void norm_store_q(uint64_t* p, ulonglong2 qv) {
+#if LLPF_NORM_ST == 2
+    typedef unsigned long long __attribute__((ext_vector_type(2))) q2_t;
+    q2_t v; v.x = qv.x; v.y = qv.y;
+    __builtin_nontemporal_store(v, reinterpret_cast<q2_t*>(p));
+#else
+    *reinterpret_cast<ulonglong2*>(p) = qv;
+#endif
+}
 template <int NX, bool XMEAN, bool NEED_E2>
 __global__ __launch_bounds__(BLOCK) void k_norm(LLPF_NORM_HOT_PARAMS, int64_t kstep, int K, int parity, int only_fallback, int bound, uint32_t step, BankDev b) {
     __shared__ uint64_t sm_u[BLOCK / 64][6];
@@ -21,7 +34,11 @@ __global__ __launch_bounds__(BLOCK) void k_norm(LLPF_NORM_HOT_PARAMS, int64_t ks
 #pragma unroll
     for (int k = 0; k < NORM_IPT / 2; ++k) {
         const int64_t i0 = (int64_t)tile * TILE + (int64_t)k * (BLOCK * 2) + threadIdx.x * 2;
+#if defined(LLPF_NORM_LD_NT) && LLPF_NORM_LD_NT      /* experiment: the weights read nontemporal */
+        { typedef double __attribute__((ext_vector_type(2))) d2_t; const d2_t t_ = __builtin_nontemporal_load(reinterpret_cast<const d2_t*>(w + i0)); wv[k].x = t_.x; wv[k].y = t_.y; }
+#else
         wv[k] = *reinterpret_cast<const double2*>(w + i0);
+#endif
     }
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("" ::: "memory");                 // the requests above are not to be sunk below the tests
@@ -63,7 +80,7 @@ __global__ __launch_bounds__(BLOCK) void k_norm(LLPF_NORM_HOT_PARAMS, int64_t ks
         ulonglong2 qv;
         qv.x = llpf_q64_unit(e0, K);
         qv.y = llpf_q64_unit(e1, K);
-        *reinterpret_cast<ulonglong2*>(b.quanta + (size_t)f * b.Ns + i0) = qv;
+        norm_store_q(b.quanta + (size_t)f * b.Ns + i0, qv);
         Q += qv.x;
         Q += qv.y;
         if (XMEAN) {
@@ -118,7 +135,7 @@ __global__ __launch_bounds__(BLOCK) void k_norm(LLPF_NORM_HOT_PARAMS, int64_t ks
                 ulonglong2 qv;
                 qv.x = llpf_q64_unit(e0, K);
                 qv.y = llpf_q64_unit(e1, K);
-                *reinterpret_cast<ulonglong2*>(b.quanta + (size_t)f * b.Ns + i0) = qv;
+                norm_store_q(b.quanta + (size_t)f * b.Ns + i0, qv);
                 Q += qv.x;
                 Q += qv.y;
                 if (XMEAN) {

@@ -39,6 +39,9 @@ template <class T> DEV void st_off(T* base, uint32_t byte_off, T v) {
 #ifndef LLPF_RESPROP_ST_ID
 #define LLPF_RESPROP_ST_ID LLPF_RESPROP_ST
 #endif
+#ifndef LLPF_RESPROP_LD_ID
+#define LLPF_RESPROP_LD_ID 0      /* 1: the sources of such a step are read nontemporal as well */
+#endif
 #define LLPF_STCOH ((LLPF_WT && !LLPF_RB_PLAIN_ST) ? STP : COH)
 #define LLPF_STCOH0 ((LLPF_WT && !LLPF_RB_PLAIN_ST) ? LLPF_RESPROP_ST : 0)
 template <class Model, int NX, int NY, bool WEIGHT, bool COH = false, bool LTAB = false>
@@ -61,16 +64,20 @@ struct PropCtx {
     // propagate output o from source src with previous log-weight wprev; returns the new log-weight
     // Addresses are a uniform plane base (SGPRs) + a 32-bit byte offset (one VGPR): Ns * 8 < 2^32 is checked at create.
     // the source's state (nontemporal: C2 22.8 against 20.7 us — duplicated ancestors are re-read from the L2)
+    template <bool NTL = false>
     DEV void fetch(uint32_t src, double* xp) const {
         const int64_t Ns = b.Ns;
         const uint32_t so = src << 3;
 #pragma unroll
-        for (int d = 0; d < NX; ++d) xp[d] = Mem<COH>::ld_off(xc + (size_t)d * Ns, so);
+        for (int d = 0; d < NX; ++d) {
+            if constexpr (NTL) xp[d] = __builtin_nontemporal_load(reinterpret_cast<const double*>(reinterpret_cast<const char*>(xc + (size_t)d * Ns) + so));
+            else xp[d] = Mem<COH>::ld_off(xc + (size_t)d * Ns, so);
+        }
     }
-    template <int STP = LLPF_RESPROP_ST>
+    template <int STP = LLPF_RESPROP_ST, bool NTL = false>
     DEV double one(uint32_t src, uint32_t o, double wprev, bool& bad, double* xs) const {
         double xp[NX];
-        fetch(src, xp);
+        fetch<NTL>(src, xp);
         return one_x<STP>(xp, o, wprev, bad, xs);
     }
     // ... from the state xp of its source (fetch); STP: the store policy of this call (LLPF_RESPROP_ST / LLPF_RESPROP_ST_ID)
@@ -322,7 +329,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(((!Model:
     // the block-uniform resample flag where that measured faster (split-schedule and Rao-Blackwellized kernels: each version
     // keeps only its own uniform values live; the merged single-filter kernel is 0.3 us faster with ONE loop and the flag
     // tested inside).
-#define LLPF_OUTPUT_LOOP(RESX) \
+#define LLPF_OUTPUT_LOOP(RESX, NTLX) \
 _Pragma("unroll 1") \
     for (uint32_t o = (uint32_t)first + threadIdx.x; o < ulast; o += BLOCK) { \
         uint32_t src = o; \
@@ -338,7 +345,7 @@ _Pragma("unroll 1") \
             wprev = (ld_off(pc.w, o << 3) - h.a) - l; \
         } \
         double xs[NX]; \
-        const double wv = pc.one(src, o, wprev, bad, xs); \
+        const double wv = pc.template one<LLPF_RESPROP_ST, NTLX>(src, o, wprev, bad, xs); \
         bmax = llpf_fmax(bmax, wv); \
         if (WEIGHT && ACC) { \
             double e; \
@@ -376,7 +383,7 @@ _Pragma("unroll") \
             const uint32_t o = ob + (uint32_t)k * BLOCK; \
             wps[k] = b.log1N; \
             if (o < ulast) { \
-                pc.fetch(srcs[k], xps[k]); \
+                pc.template fetch<!(RESX) && LLPF_RESPROP_LD_ID>(srcs[k], xps[k]); \
                 if (!(RESX) && WEIGHT) wps[k] = (ld_off(pc.w, o << 3) - h.a) - l; \
             } \
         } \
@@ -392,10 +399,10 @@ _Pragma("unroll") \
         } \
     }
     constexpr bool PREFETCH = LLPF_RESPROP_PF > 1 && !(WEIGHT && ACC) && !Model::RB && !AUX;
-    if constexpr (WEIGHT && ACC && !Model::RB) { LLPF_OUTPUT_LOOP(res) }
+    if constexpr (WEIGHT && ACC && !Model::RB) { LLPF_OUTPUT_LOOP(res, false) }
     else if constexpr (PREFETCH) { if (res) { LLPF_OUTPUT_LOOP_PF(true) } else { LLPF_OUTPUT_LOOP_PF(false) } }
-    else if (res) { LLPF_OUTPUT_LOOP(true) }
-    else { LLPF_OUTPUT_LOOP(false) }
+    else if (res) { LLPF_OUTPUT_LOOP(true, false) }
+    else { LLPF_OUTPUT_LOOP(false, (LLPF_RESPROP_LD_ID != 0)) }
 #undef LLPF_OUTPUT_LOOP
 #undef LLPF_OUTPUT_LOOP_PF
     if (WEIGHT && ACC) ts.flush(sh_tq, tq_next, tbase);
