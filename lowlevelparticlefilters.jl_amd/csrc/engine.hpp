@@ -153,6 +153,7 @@ struct BankDev {
     double* xcur;        // [F][NX][Ns] current particles (read by propagate, by weight-only)
     double* xnext;       // [F][NX][Ns] written by propagate
     double* w;           // [F][Ns]
+    double* w_next;      // where the fused kernel stores the weights it forms: w itself, or the second buffer of a split-schedule run (host/run.hpp)
     int32_t* anc;        // [F][Ns]
     uint64_t* acc;       // [F][ACC_WORDS]
     uint64_t* quanta;    // [F][Ns]  quanta of the CURRENT weights (read by the scan)
@@ -250,6 +251,8 @@ struct ResArgs {
     int64_t row;           // row of ll_steps / xmean this finalize writes
     int32_t count_surv;    // k_resample: add the number of distinct ancestors to BankDev::surv (models that could take the source-side form)
     int32_t ablate;        // developer aid (LLPF_ABLATE): bit0 skip RNG, bit1 skip owner search, bit2 skip model math; results invalid
+    int32_t lazy_q;        // k_resprop (split schedule): the k_norm in front of it stored no quanta — BankDev::quanta points at the WEIGHTS and the scan
+                           // forms the tile's quanta itself, floor(exp(w - offset) 2^K): the same function of the same numbers (host/run.hpp)
     uint64_t* dbg;         // optional [P2][8] phase timestamps of one launch (s_memrealtime, 100 MHz), or nullptr
 };
 
@@ -279,6 +282,7 @@ hipError_t launch_max(const BankDev& b, int parity, hipStream_t s);           //
 hipError_t launch_norm(const BankDev& b, int parity, int want_xmean, int need_e2, uint32_t step, int only_fallback, int bound, int64_t kstep, hipStream_t s);
 hipError_t launch_ess(const BankDev& b, hipStream_t s);   // on-demand sum e^2 / ESS of the current weights (accessor path)
 hipError_t launch_post_predict(const BankDev& b, hipStream_t s);
+hipError_t launch_requant(const BankDev& b, hipStream_t s);   // quanta of the current weights from w and the stored offset (after a run whose k_norm launches stored none)
 hipError_t launch_replicate_models(ModelD* models, int F, hipStream_t s);   // models[1..F) <- models[0]
 // failed bound test: zero the exp-sums of `slot` (mode 0) / clear the flags (mode 1) of the filters that asked for the exact form
 hipError_t launch_fb_clear(const BankDev& b, int slot, int mode, hipStream_t s);

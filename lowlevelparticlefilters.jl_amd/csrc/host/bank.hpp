@@ -16,7 +16,10 @@ struct Bank {
     FilterScal* d_scal = nullptr;
     double* d_x[2] = {nullptr, nullptr};
     int cur = 0;
-    double* d_w = nullptr;
+    double* d_w = nullptr;           // the weights (the CURRENT ones: a split-schedule run of fused steps alternates between this and d_w_spare, host/run.hpp)
+    double* d_w_spare = nullptr;     // second weight buffer, allocated by the first such run
+    double* d_w_alloc = nullptr;     // the allocation behind whichever of the two is not part of the pool
+    bool w_pingpong = false;         // inside such a run: the fused kernel writes the weights it forms to the other buffer
     int32_t* d_anc = nullptr;
     uint64_t* d_acc = nullptr;
     uint64_t* d_quanta[2] = {nullptr, nullptr};
@@ -65,13 +68,13 @@ struct Bank {
     // (tools/launch_floor.hip: 1.6 vs 2.8 us per dependent empty launch).  Keyed by everything a launch argument depends on.
     struct RunGraph {
         int64_t T; double t_index0; int par0, cur0, qcur0, flags, np_parity;
-        const void *dU, *dY, *dll, *dxm, *dxc, *drb, *dxq, *dqp;      // every device buffer a captured launch addresses that ensure() may reallocate
+        const void *dU, *dY, *dll, *dxm, *dxc, *drb, *dxq, *dqp, *dw, *dws;      // every device buffer a captured launch addresses that ensure() may reallocate
         int nq;
         uint64_t yhash;
         hipGraphExec_t exec;
         bool same(const RunGraph& o) const {
             return T == o.T && t_index0 == o.t_index0 && par0 == o.par0 && cur0 == o.cur0 && qcur0 == o.qcur0 && flags == o.flags &&
-                   np_parity == o.np_parity && dU == o.dU && dY == o.dY && dll == o.dll && dxm == o.dxm && dxc == o.dxc && drb == o.drb && dxq == o.dxq && dqp == o.dqp && nq == o.nq && yhash == o.yhash;
+                   np_parity == o.np_parity && dU == o.dU && dY == o.dY && dll == o.dll && dxm == o.dxm && dxc == o.dxc && drb == o.drb && dxq == o.dxq && dqp == o.dqp && dw == o.dw && dws == o.dws && nq == o.nq && yhash == o.yhash;
         }
     };
     std::vector<RunGraph> graphs;
@@ -100,7 +103,7 @@ struct Bank {
         b.mlogN = -llpf_log((double)N);
         b.models = d_models; b.scal = d_scal;
         b.xcur = d_x[cur]; b.xnext = d_x[cur ^ 1];
-        b.w = d_w; b.anc = d_anc; b.acc = d_acc; b.quanta = d_quanta[qcur]; b.quanta_next = d_quanta[qcur ^ 1]; b.tileq = d_tileq; b.tpre = d_tpre; b.gsum = d_gsum;
+        b.w = d_w; b.w_next = (w_pingpong && d_w_spare) ? d_w_spare : d_w; b.anc = d_anc; b.acc = d_acc; b.quanta = d_quanta[qcur]; b.quanta_next = d_quanta[qcur ^ 1]; b.tileq = d_tileq; b.tpre = d_tpre; b.gsum = d_gsum;
         b.bank_flag = d_flag; b.xmpart = d_xmpart; b.lam = d_lam; b.rtile = d_rtile; b.mark = d_mark; b.fxs = d_fxs; b.surv = d_surv;
         b.anc_slot = (int32_t)(n_predict & 1u);
         b.pad0 = (cfg.model.model_id == LLPF_MODEL_RB_BILINEAR) ? (cfg.model.rb.nxl | (cfg.model.rb.fn_kind << 8))
@@ -129,6 +132,7 @@ static void free_bank(Bank& b) {
     for (auto& g : b.graphs) if (g.exec) hipGraphExecDestroy(g.exec);
     b.graphs.clear();
     hipFree(b.d_pool);               // models, scal, x, w, anc, acc, quanta, tileq, flag, rtile, rb, uy, tmp
+    hipFree(b.d_w_alloc);
     hipFree(b.d_wq); hipFree(b.d_wq_we); hipFree(b.d_wq_p); hipFree(b.d_xquant);
     hipFree(b.d_xmpart); hipFree(b.d_lam); hipFree(b.d_surv); hipFree(b.d_mark); hipFree(b.d_fxs); hipFree(b.d_rbseq); hipFree(b.d_hist); hipFree(b.d_U); hipFree(b.d_Y);
     hipFree(b.d_ll_steps); hipFree(b.d_xmean); hipFree(b.d_xcov);

@@ -149,6 +149,22 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
     // (a model without a bound: the weighting launches form no sums at all — a step without a measurement would otherwise leave real ones
     // in the slot, against the finite bound max(w), and the exact-form k_norm in front of the next head would add to them)
     const bool acc_in_weighting = merged && !no_bound;
+    // Split schedule in front of the fused kernel, thresholds below 1: k_norm stores NO quanta (launch_norm, bound bit 1) and the fused
+    // kernel's scan forms its tile's quanta from the weights (ResArgs::lazy_q) — a step that does not resample moves 16 bytes per
+    // particle less (the 8 k_norm stored, the 8 the fused kernel requested before it knew), one that does the same bytes plus an exp per
+    // source, which is why a filter that resamples at every step keeps the stored form.  The scan then reads weights that other blocks
+    // of the same launch are replacing with the next ones: such a run alternates between two weight buffers (BankDev::w / w_next; the
+    // second is allocated here on first use and starts as a copy, so that its padding holds -Inf too).  LLPF_LAZY_Q=0: stored form.
+    const char* lazy_s = getenv("LLPF_LAZY_Q");
+    const bool lazy_run = !merged && !unfused && !no_bound && b.cfg.resample_threshold < 1.0 && !(lazy_s && atoi(lazy_s) == 0);
+    if (lazy_run && !b.d_w_spare) {
+        const size_t bytes = sizeof(double) * (size_t)b.F * b.Ns;
+        if (hipMalloc(&b.d_w_alloc, bytes) != hipSuccess) { (void)hipGetLastError(); b.d_w_alloc = nullptr; return fail(LLPF_ERR_ALLOC, "second weight buffer of the split schedule"); }
+        b.d_w_spare = b.d_w_alloc;
+        HIPC(hipMemcpyAsync(b.d_w_spare, b.d_w, bytes, hipMemcpyDeviceToDevice, b.stream));
+    }
+    double* const wbuf0 = b.d_w;
+    double* const wbuf1 = lazy_run ? b.d_w_spare : b.d_w;
     static const char* abl_env = getenv("LLPF_ABLATE");
     static const char* dbg_env = getenv("LLPF_DEBUG_TIMING");
 
@@ -162,6 +178,11 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
         b.parity = (par0 + 1 + (int)(k % ACC_NSLOT)) % ACC_NSLOT;      // slot the weighting of step k writes
         b.n_predict = np0 + (uint32_t)k;
         b.t_index = ti0 + k;
+        // weights in front of step k: every step before it had a weighting phase that wrote the other buffer (the run's last step has none)
+        const int64_t wsw = std::min<int64_t>(k, T - 1 > 0 ? T - 1 : 0);
+        b.d_w = (wsw & 1) ? wbuf1 : wbuf0;
+        if (lazy_run) b.d_w_spare = (wsw & 1) ? wbuf0 : wbuf1;
+        b.w_pingpong = lazy_run;
     };
     auto head_slot = [&](int64_t k) { return (par0 + (int)(k % ACC_NSLOT)) % ACC_NSLOT; };
 
@@ -218,10 +239,13 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
         ra.only_fallback = only_fb;
         StepArgs st = step_args(k);
         const bool weight = (k + 1 < T);
+        // (lazy_run, above; the exact redo of a failed bound test keeps the stored form — and the two weight buffers)
+        const bool lazy_q = fast && lazy_run;
         if (fast && !merged) {   // split schedule: the sums of the current weights in bound form, as a streaming launch
             ProfScope ps(b, LLPF_PROF_NORMALISE);
-            HIPC(launch_norm(d, ra.parity, want_xm, ne2, rel_step(b), 0, 1, k, b.stream));
+            HIPC(launch_norm(d, ra.parity, want_xm, ne2, rel_step(b), 0, lazy_q ? 3 : 1, k, b.stream));
         }
+        ra.lazy_q = lazy_q ? 1 : 0;
         if (!fast) {
             ProfScope ps(b, LLPF_PROF_NORMALISE);
             HIPC(launch_norm(d, ra.parity, want_xm, 1, rel_step(b), only_fb, 0, k, b.stream));
@@ -285,6 +309,8 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
     auto first_weighting = [&]() -> int {
         // weighting of the first correct! (exp-sums against the bound, quanta, tile sums: no separate normalise pass)
         b.cur = cur0; b.qcur = qcur0; b.parity = par0; b.n_predict = np0; b.t_index = ti0;      // the state at entry
+        b.d_w = wbuf0; if (lazy_run) b.d_w_spare = wbuf1;
+        b.w_pingpong = false;                                                                  // (k_step weights in place)
         BankDev d = b.dev();
         StepArgs a{};
         a.u = b.nu > 0 ? b.d_U : nullptr; a.y = b.d_Y; a.u_stride = multi ? b.nu : 0; a.y_stride = multi ? b.ny : 0; a.t_prop = tk(0); a.t_meas = tk(0); a.step = 0; a.has_y = has_y(0) ? 1 : 0;
@@ -302,9 +328,10 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
     if (use_graph) {
         Bank::RunGraph key{};
         key.T = T; key.t_index0 = t_index0; key.par0 = par0; key.cur0 = cur0; key.qcur0 = qcur0;
-        key.flags = (merged ? 1 : 0) | (unfused ? 2 : 0) | (want_xm ? 4 : 0) | (ll_steps ? 8 : 0) | (xm_launch ? 16 : 0) | (multi ? 32 : 0) | (source_fx ? 64 : 0) | (xcov ? 128 : 0) | (xquant ? 256 : 0) | ((abl_env ? atoi(abl_env) : 0) << 9);      // (no_bound is a property of the model id, which a handle keeps)
+        key.flags = (merged ? 1 : 0) | (unfused ? 2 : 0) | (want_xm ? 4 : 0) | (ll_steps ? 8 : 0) | (xm_launch ? 16 : 0) | (multi ? 32 : 0) | (source_fx ? 64 : 0) | (xcov ? 128 : 0) | (xquant ? 256 : 0) | ((abl_env ? atoi(abl_env) : 0) << 9) | (lazy_run ? (1 << 30) : 0);      // (no_bound is a property of the model id, which a handle keeps)
         key.np_parity = (int)(np0 & 1u);
         key.dU = b.d_U; key.dY = b.d_Y; key.dll = ll_steps ? b.d_ll_steps : nullptr; key.dxm = xmean ? b.d_xmean : nullptr; key.dxc = xcov ? b.d_xcov : nullptr; key.drb = b.d_rbseq;
+        key.dw = wbuf0; key.dws = wbuf1;
         key.dxq = xquant ? b.d_xquant : nullptr; key.dqp = xquant ? b.d_wq_p : nullptr; key.nq = xquant ? nq : 0;
         key.yhash = 1469598103934665603ULL;
         for (int64_t k = 0; k < T; ++k) key.yhash = (key.yhash ^ (uint64_t)(has_y(k) ? 1 : 2)) * 1099511628211ULL;
@@ -411,11 +438,14 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
         }
     }
     at_step(T);
+    b.w_pingpong = false;                                    // the verbs outside a run weight in place, on the buffer the run ended in
     b.qcur = qcur0 ^ (int)(T & 1);                           // the last step has no weighting phase: no quanta swap
     b.parity = (par0 + (int)(T % ACC_NSLOT)) % ACC_NSLOT;
     {
         BankDev d = b.dev();
         ProfScope ps(b, LLPF_PROF_OTHER);
+        // the run's k_norm launches stored no quanta: leave those of the current weights behind, as every later verb expects them
+        if (lazy_run) HIPC(launch_requant(d, b.stream));
         HIPC(launch_post_predict(d, b.stream));
     }
     HIPC(hipEventRecord(b.ev_run1, b.stream));

@@ -23,9 +23,11 @@ namespace llpf {
 // left to k_norm (banks beyond 3 M particles), or no weighting at all — with the Horner constants as SGPR pairs (bank -4 %; the merged
 // single-filter form loses 6 % with them and stays in the first unit)
 template <class Model, int NX, int NY>
-static hipError_t launch_resprop_t(const BankDev& b, const ResArgs& a, const StepArgs& st, int weight, hipStream_t s) {
-    dim3 g((unsigned)b.P2, (unsigned)b.F, 1);
+static hipError_t launch_resprop_t(const BankDev& b0, const ResArgs& a, const StepArgs& st, int weight, hipStream_t s) {
+    dim3 g((unsigned)b0.P2, (unsigned)b0.F, 1);
     if (st.aux) return hipErrorInvalidValue;
+    BankDev b = b0;
+    if (a.lazy_q) b.quanta = reinterpret_cast<uint64_t*>(b0.w);      // ResArgs::lazy_q: the scan forms the quanta from the weights (same layout, [F][Ns] of 8 bytes)
     if (weight) hipLaunchKernelGGL((k_resprop<Model, NX, NY, true, false>), g, dim3(BLOCK), 0, s, LLPF_HOT_ARGS(b, a), b, b.models, a, st);
     else hipLaunchKernelGGL((k_resprop<Model, NX, NY, false, false>), g, dim3(BLOCK), 0, s, LLPF_HOT_ARGS(b, a), b, b.models, a, st);
     return hipGetLastError();

@@ -108,6 +108,11 @@ hipError_t launch_post_predict(const BankDev& b, hipStream_t s) {
     return hipGetLastError();
 }
 
+hipError_t launch_requant(const BankDev& b, hipStream_t s) {
+    hipLaunchKernelGGL(k_requant, dim3((unsigned)((b.Ns / 2 + BLOCK - 1) / BLOCK), (unsigned)b.F, 1), dim3(BLOCK), 0, s, b);
+    return hipGetLastError();
+}
+
 hipError_t launch_tile_prefix(const BankDev& b, int parity, hipStream_t s) {
     if (b.P2 <= TQ_GROUP) return hipSuccess;          // a head reads the tile sums themselves
     if (!b.tpre || !b.gsum) return hipErrorInvalidValue;

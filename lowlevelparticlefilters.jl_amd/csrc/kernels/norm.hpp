@@ -24,7 +24,11 @@ DEV void norm_store_q(uint64_t* p, ulonglong2 qv) {
 #endif
 }
 template <int NX, bool XMEAN, bool NEED_E2>
-__global__ __launch_bounds__(BLOCK) void k_norm(LLPF_NORM_HOT_PARAMS, int64_t kstep, int K, int parity, int only_fallback, int bound, uint32_t step, BankDev b) {
+__global__ __launch_bounds__(BLOCK) void k_norm(LLPF_NORM_HOT_PARAMS, int64_t kstep, int K, int parity, int only_fallback, int bound_in, uint32_t step, BankDev b) {
+    // bound_in: bit 0 = bound form, bit 1 = store no quanta (the fused kernel behind this launch forms them itself from the weights, ResArgs::lazy_q:
+    // a step that does not resample never reads them, and a step that does reads 8 bytes per particle either way)
+    const int bound = bound_in & 1;
+    const bool store_q = (bound_in & 2) == 0;
     __shared__ uint64_t sm_u[BLOCK / 64][6];
     __shared__ double sm_x[BLOCK / 64][MAXD];
     const int f = blockIdx.y;
@@ -80,7 +84,7 @@ __global__ __launch_bounds__(BLOCK) void k_norm(LLPF_NORM_HOT_PARAMS, int64_t ks
         ulonglong2 qv;
         qv.x = llpf_q64_unit(e0, K);
         qv.y = llpf_q64_unit(e1, K);
-        norm_store_q(b.quanta + (size_t)f * b.Ns + i0, qv);
+        if (store_q) norm_store_q(b.quanta + (size_t)f * b.Ns + i0, qv);
         Q += qv.x;
         Q += qv.y;
         if (XMEAN) {
@@ -135,7 +139,7 @@ __global__ __launch_bounds__(BLOCK) void k_norm(LLPF_NORM_HOT_PARAMS, int64_t ks
                 ulonglong2 qv;
                 qv.x = llpf_q64_unit(e0, K);
                 qv.y = llpf_q64_unit(e1, K);
-                norm_store_q(b.quanta + (size_t)f * b.Ns + i0, qv);
+                if (store_q) norm_store_q(b.quanta + (size_t)f * b.Ns + i0, qv);
                 Q += qv.x;
                 Q += qv.y;
                 if (XMEAN) {
@@ -226,6 +230,24 @@ __global__ __launch_bounds__(BLOCK) void k_ess(BankDev b) {
 }
 
 // after a propagate-only predict!: reset_weights! if it resampled (reference src/utils.jl:73-79)
+// The quanta of the current weights, floor(exp(w - m) 2^K) with the offset and the fraction bits the last head published: what the k_norm of
+// the run's last timestep would have stored had it not been told to store none (bound_in bit 1).  Launched once at the end of such a run,
+// in front of k_post_predict; a filter whose last predict! resampled has uniform weights and nobody reads its quanta.
+__global__ __launch_bounds__(BLOCK) void k_requant(BankDev b) {
+    const int f = blockIdx.y;
+    const FilterScal* sc = b.scal + f;
+    if (sc->do_resample || sc->uniform) return;
+    const double m = sc->m;
+    const int K = sc->K;
+    const int64_t i0 = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) * 2;
+    if (i0 >= b.Ns) return;
+    const double2 wv = *reinterpret_cast<const double2*>(b.w + (size_t)f * b.Ns + i0);
+    ulonglong2 qv;
+    qv.x = llpf_q64_unit(llpf_exp_le0(wv.x - m), K);
+    qv.y = llpf_q64_unit(llpf_exp_le0(wv.y - m), K);
+    *reinterpret_cast<ulonglong2*>(b.quanta + (size_t)f * b.Ns + i0) = qv;
+}
+
 __global__ void k_post_predict(BankDev b) {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= b.F) return;

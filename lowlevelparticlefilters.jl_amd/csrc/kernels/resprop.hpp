@@ -53,7 +53,8 @@ struct PropCtx {
     const double* y;
     const double* __restrict__ xc;
     double* __restrict__ xn;
-    double* w;
+    double* w;             // weights in front of this launch (read: w_prev of a step that does not resample)
+    double* wn;            // weights this launch forms (BankDev::w_next)
     uint32_t k0, k1;
     uint32_t pstep;        // Philox step of this predict! (step_base + st.step)
     int ablate;
@@ -94,7 +95,7 @@ struct PropCtx {
                 if (st.has_y) wr = wr + model.rb_weight(xs, y, st.rb_corr + blockIdx.y, o == 0);
                 if (o >= (uint32_t)b.N) wr = -LLPF_INF;
                 bad = bad || (wr != wr);
-                Mem<LLPF_STCOH>::st_off(w, oo, wr);
+                Mem<LLPF_STCOH>::st_off(wn, oo, wr);
             }
 #pragma unroll
             for (int d = 0; d < NX; ++d) Mem<LLPF_STCOH>::st_off(xn + (size_t)d * Ns, oo, xs[d]);
@@ -131,7 +132,7 @@ struct PropCtx {
             }
             if (o >= (uint32_t)b.N) wv = -LLPF_INF;
             bad = bad || (wv != wv);
-            Mem<LLPF_STCOH>::st_off(w, oo, wv);
+            Mem<LLPF_STCOH>::st_off(wn, oo, wv);
         }
         return wv;
     }
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(((!Model:
     }
     LLPF_STAMP(1);
     PropCtx<Model, NX, NY, WEIGHT, false, !RBFAT> pc{b, model, md, st, y, b.xcur + (size_t)f * NX * Ns, b.xnext + (size_t)f * NX * Ns,
-                                      b.w + (size_t)f * Ns, key0, key1, sb + st.step, a.ablate, 0.0, b.quanta_next + (size_t)f * Ns,
+                                      b.w + (size_t)f * Ns, b.w_next + (size_t)f * Ns, key0, key1, sb + st.step, a.ablate, 0.0, b.quanta_next + (size_t)f * Ns,
                                       RBFAT ? nullptr : sh_rng_lg, RBFAT ? nullptr : sh_rng_sc};
     int32_t* anc = b.anc + (size_t)f * Ns;
     double bmax = -LLPF_INF;
@@ -284,6 +285,19 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(((!Model:
     uint64_t* tq_next = tileq_slot(b, st.parity, f);
     if (res) {
         int32_t c_start;
+        if constexpr (!ACC) {
+            // ResArgs::lazy_q (split schedule): the k_norm in front of this launch stored no quanta and `qsrc` is the filter's WEIGHTS — what the
+            // speculative request above brought are the tile's raw log-weights, and their quanta are formed here, by k_norm's own expression
+            // against the offset the head has just read back (the bound, or the maximum after a one-tile redo): identical integers.  A step
+            // that does not resample (97 of 100 at the reference's threshold) thus moves neither the 8 bytes k_norm stored nor the 8 read here.
+            if (a.lazy_q) {
+#pragma unroll
+                for (int k = 0; k < NORM_IPT / 2; ++k) {
+                    qv[k].x = llpf_q64_unit(llpf_exp_le0(llpf_u2d(qv[k].x) - h.a), a.K);
+                    qv[k].y = llpf_q64_unit(llpf_exp_le0(llpf_u2d(qv[k].y) - h.a), a.K);
+                }
+            }
+        }
         if (b.strategy == LLPF_RESAMPLE_SYSTEMATIC) res_counts<LLPF_RESAMPLE_SYSTEMATIC>(b, a, f, tile, h, qv, sh, c_start, c_end);
         else res_counts<LLPF_RESAMPLE_STRATIFIED>(b, a, f, tile, h, qv, sh, c_start, c_end);
         first = c_start;
@@ -434,7 +448,7 @@ _Pragma("unroll") \
                 __syncthreads();
 #pragma unroll 1
                 for (uint32_t o = (uint32_t)first + threadIdx.x; o < ulast; o += BLOCK) {
-                    const double wv = ld_off(pc.w, o << 3);
+                    const double wv = ld_off(pc.wn, o << 3);
                     double e;
                     const uint64_t q = wacc.add(wv, mx, st.K, st.need_e2 != 0, &e);
                     st_off(pc.qnext, o << 3, q);

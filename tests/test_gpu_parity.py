@@ -815,6 +815,47 @@ def test_schedules_are_bit_identical(schedule, monkeypatch):
     _compare_state(g, o)
 
 
+@pytest.mark.parametrize("thr", [0.1, 0.5, 1.0])
+def test_split_schedule_forms_its_quanta_in_the_fused_kernel(thr, monkeypatch):
+    """Split schedule in front of the fused kernel (banks and filters beyond 3 M particles; forced here on small ones): k_norm stores
+    no quanta, the fused kernel's scan forms its tile's quanta from the weights against the offset its head has just read
+    (ResArgs::lazy_q), and the run leaves the quanta of the current weights behind for the verbs that follow (k_requant).  Against
+    the device-order oracle, bit for bit: the run, the state after it, a second predict! straight after the run (the consumer of
+    the stored quanta: resample without a correct! in between), more single steps, and a second run; for one-tile filters (the
+    redo of a failed bound test inside k_norm), ragged sizes and several tiles, with an outlier that makes a bound test fail; and
+    the stored form (LLPF_LAZY_Q=0) gives the same bits."""
+    monkeypatch.setenv("LLPF_SCHEDULE", "split")
+    model = M.lg_test_model(0.1)
+    _, U, Y = M.simulate_lg(model, 40)
+    Y[11] += 9.0
+    for N in (700, 5000, 3 * 1024 + 5):
+        cfg = _cfg(model, N, thr=thr, seed=31 + N)
+        lls = {}
+        for lazy in ("1", "0"):
+            monkeypatch.setenv("LLPF_LAZY_Q", lazy)
+            g = _capi.FilterHandle(cfg)
+            o = ob.OracleFilter(cfg, ob.ORDER_DEVICE)
+            g.reset(); o.reset()
+            rg = g.run(U[:20], Y[:20], 1.0, ll_steps=True)
+            ro = o.run(U[:20], Y[:20], 1.0, ll_steps=True)
+            assert np.array_equal(rg["ll_steps"].view(np.uint64), ro["ll_steps"].view(np.uint64)), (N, lazy)
+            _compare_state(g, o)
+            assert g.ess() == o.ess()
+            g.predict(U[20], 21.0); o.predict(U[20], 21.0)          # predict! twice in a row: resamples from the quanta the run left
+            assert g.last_resampled() == o.last_resampled()
+            _compare_state(g, o)
+            for k in range(21, 26):
+                assert g.correct(U[k], Y[k], 1.0 + k) == o.correct(U[k], Y[k], 1.0 + k)
+                g.predict(U[k], 1.0 + k); o.predict(U[k], 1.0 + k)
+            _compare_state(g, o)
+            rg2 = g.run(U[26:40], Y[26:40], 27.0, ll_steps=True)
+            ro2 = o.run(U[26:40], Y[26:40], 27.0, ll_steps=True)
+            assert np.array_equal(rg2["ll_steps"].view(np.uint64), ro2["ll_steps"].view(np.uint64)), (N, lazy)
+            _compare_state(g, o)
+            lls[lazy] = np.concatenate([rg["ll_steps"], rg2["ll_steps"]])
+        assert np.array_equal(lls["1"].view(np.uint64), lls["0"].view(np.uint64))
+
+
 @pytest.mark.parametrize("schedule", ["merged", "split"])
 def test_launches_larger_than_the_resident_set(schedule, monkeypatch):
     """More workgroups than the chip holds at once (~1000-2000): blocks of a launch that start after other blocks of
