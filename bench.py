@@ -694,7 +694,7 @@ def main():
                     roof["traffic"] = pm["k_resprop"]["bytes"]
                     roof["traffic_source"] = pm["file"] + ": " + pm["source"] + "; " + pm["correction"]
                 big = pm.get("c2_big")
-                if one_launch and big and big["n_particles"] == N and args.workload == "lg" and thr == pm["resample_threshold"]:
+                if fused and not aux and big and big["n_particles"] == N and args.workload == "lg" and thr == pm["resample_threshold"]:      # (split schedule at this size: k_norm + k_resprop)
                     roof["traffic"] = big["k_resprop"]["bytes"]
                     roof["traffic_source"] = pm["file"] + ": " + big["source"] + "; " + pm["correction"]
                 if args.workload == "quadtank" and pm["c3"]["n_particles"] == N:
