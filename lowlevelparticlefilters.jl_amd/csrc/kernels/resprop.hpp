@@ -39,6 +39,9 @@ template <class T> DEV void st_off(T* base, uint32_t byte_off, T v) {
 #ifndef LLPF_RESPROP_ST_ID
 #define LLPF_RESPROP_ST_ID LLPF_RESPROP_ST
 #endif
+#ifndef LLPF_RESPROP_ID2
+#define LLPF_RESPROP_ID2 1     /* steps that do not resample, split-schedule form: two adjacent outputs per thread, 16-byte accesses (LLPF_OUTPUT_LOOP_ID2) */
+#endif
 #ifndef LLPF_RESPROP_LD_ID
 #define LLPF_RESPROP_LD_ID 0      /* 1: the sources of such a step are read nontemporal as well */
 #endif
@@ -81,7 +84,8 @@ struct PropCtx {
         fetch<NTL>(src, xp);
         return one_x<STP>(xp, o, wprev, bad, xs);
     }
-    // ... from the state xp of its source (fetch); STP: the store policy of this call (LLPF_RESPROP_ST / LLPF_RESPROP_ST_ID)
+    // ... from the state xp of its source (fetch); STP: the store policy of this call (LLPF_RESPROP_ST / LLPF_RESPROP_ST_ID), or -1: nothing is
+    // stored here — the caller stores xs and the returned weight itself (LLPF_OUTPUT_LOOP_ID2: two outputs per 16-byte store)
     template <int STP = LLPF_RESPROP_ST>
     DEV double one_x(const double* xp, uint32_t o, double wprev, bool& bad, double* xs) const {
         const int64_t Ns = b.Ns;
@@ -95,10 +99,12 @@ struct PropCtx {
                 if (st.has_y) wr = wr + model.rb_weight(xs, y, st.rb_corr + blockIdx.y, o == 0);
                 if (o >= (uint32_t)b.N) wr = -LLPF_INF;
                 bad = bad || (wr != wr);
-                Mem<LLPF_STCOH>::st_off(wn, oo, wr);
+                if constexpr (STP >= 0) Mem<LLPF_STCOH>::st_off(wn, oo, wr);
             }
+            if constexpr (STP >= 0) {
 #pragma unroll
-            for (int d = 0; d < NX; ++d) Mem<LLPF_STCOH>::st_off(xn + (size_t)d * Ns, oo, xs[d]);
+                for (int d = 0; d < NX; ++d) Mem<LLPF_STCOH>::st_off(xn + (size_t)d * Ns, oo, xs[d]);
+            }
             return wr;
         }
 #ifdef LLPF_DEVTOOLS   /* ablation switches for performance experiments (results invalid); not in production builds */
@@ -115,7 +121,7 @@ struct PropCtx {
 #pragma unroll
         for (int d = 0; d < NX; ++d) {
             xs[d] = fx[d] + nz[d];
-            Mem<LLPF_STCOH>::st_off(xn + (size_t)d * Ns, oo, xs[d]);
+            if constexpr (STP >= 0) Mem<LLPF_STCOH>::st_off(xn + (size_t)d * Ns, oo, xs[d]);
         }
         double wv = wprev;
         if (WEIGHT) {
@@ -132,7 +138,7 @@ struct PropCtx {
             }
             if (o >= (uint32_t)b.N) wv = -LLPF_INF;
             bad = bad || (wv != wv);
-            Mem<LLPF_STCOH>::st_off(wn, oo, wv);
+            if constexpr (STP >= 0) Mem<LLPF_STCOH>::st_off(wn, oo, wv);
         }
         return wv;
     }
@@ -412,13 +418,53 @@ _Pragma("unroll") \
             } \
         } \
     }
+    // A step that does not resample, split-schedule form: output o reads index o, so a thread takes TWO ADJACENT outputs and every plane
+    // is read and written 16 bytes per lane — three loads and three stores per pair instead of six and six.  With 8-byte accesses this
+    // loop was bound by neither issue nor bandwidth but by the number of memory instructions in flight: cut to a third of its vector
+    // instructions (the tile-loop experiment, EXPERIMENTS 6.12) it took the same time, 4.9 TB/s.  Per-output arithmetic and counters
+    // untouched (PropCtx::one_x with STP = -1 returns what it would have stored).  (The same pairing for the steps that DO resample — adjacent
+    // outputs, 16-byte stores of both states, weights and ancestors — is 7.6 % slower than two rounds a block apart: adjacent outputs gather
+    // from the same or neighbouring sources, and the wave's requests cover half as many lines; both pairs of a thread requested before the
+    // first is computed: no better, 169.2 / 170.0 us on the C4 share; profiles/r06_paired_outputs_ab.txt.)
+#define LLPF_OUTPUT_LOOP_ID2 \
+_Pragma("unroll 1") \
+    for (uint32_t o2 = (uint32_t)first + 2u * threadIdx.x; o2 < ulast; o2 += 2u * BLOCK) { \
+        typedef double __attribute__((ext_vector_type(2))) d2_t; \
+        d2_t xv[NX], wv2 = {b.log1N, b.log1N}; \
+_Pragma("unroll") \
+        for (int d = 0; d < NX; ++d) { \
+            const d2_t* src_ = reinterpret_cast<const d2_t*>(reinterpret_cast<const char*>(pc.xc + (size_t)d * Ns) + (o2 << 3)); \
+            xv[d] = LLPF_RESPROP_LD_ID ? __builtin_nontemporal_load(src_) : *src_; \
+        } \
+        if (WEIGHT) wv2 = *reinterpret_cast<const d2_t*>(reinterpret_cast<const char*>(pc.w) + (o2 << 3)); \
+        double xp0[NX], xp1[NX], xs0[NX], xs1[NX]; \
+_Pragma("unroll") \
+        for (int d = 0; d < NX; ++d) { xp0[d] = xv[d].x; xp1[d] = xv[d].y; } \
+        const double wp0 = WEIGHT ? (wv2.x - h.a) - l : b.log1N, wp1 = WEIGHT ? (wv2.y - h.a) - l : b.log1N; \
+        const double w0 = pc.template one_x<-1>(xp0, o2, wp0, bad, xs0); \
+        const double w1 = pc.template one_x<-1>(xp1, o2 + 1u, wp1, bad, xs1); \
+        bmax = llpf_fmax(bmax, w0); \
+        bmax = llpf_fmax(bmax, w1); \
+_Pragma("unroll") \
+        for (int d = 0; d < NX; ++d) { \
+            d2_t v_; v_.x = xs0[d]; v_.y = xs1[d]; \
+            d2_t* dst_ = reinterpret_cast<d2_t*>(reinterpret_cast<char*>(pc.xn + (size_t)d * Ns) + (o2 << 3)); \
+            if (LLPF_RESPROP_ST_ID == 2) __builtin_nontemporal_store(v_, dst_); else *dst_ = v_; \
+        } \
+        if (WEIGHT) { \
+            d2_t v_; v_.x = w0; v_.y = w1; \
+            d2_t* dst_ = reinterpret_cast<d2_t*>(reinterpret_cast<char*>(pc.wn) + (o2 << 3)); \
+            if (LLPF_RESPROP_ST_ID == 2) __builtin_nontemporal_store(v_, dst_); else *dst_ = v_; \
+        } \
+    }
     constexpr bool PREFETCH = LLPF_RESPROP_PF > 1 && !(WEIGHT && ACC) && !Model::RB && !AUX;
     if constexpr (WEIGHT && ACC && !Model::RB) { LLPF_OUTPUT_LOOP(res, false) }
-    else if constexpr (PREFETCH) { if (res) { LLPF_OUTPUT_LOOP_PF(true) } else { LLPF_OUTPUT_LOOP_PF(false) } }
+    else if constexpr (PREFETCH) { if (res) { LLPF_OUTPUT_LOOP_PF(true) } else if (LLPF_RESPROP_ID2) { LLPF_OUTPUT_LOOP_ID2 } else { LLPF_OUTPUT_LOOP_PF(false) } }
     else if (res) { LLPF_OUTPUT_LOOP(true, false) }
     else { LLPF_OUTPUT_LOOP(false, (LLPF_RESPROP_LD_ID != 0)) }
 #undef LLPF_OUTPUT_LOOP
 #undef LLPF_OUTPUT_LOOP_PF
+#undef LLPF_OUTPUT_LOOP_ID2
     if (WEIGHT && ACC) ts.flush(sh_tq, tq_next, tbase);
     __builtin_amdgcn_s_setprio(3);
     LLPF_STAMP(3);
