@@ -165,6 +165,9 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
     }
     double* const wbuf0 = b.d_w;
     double* const wbuf1 = lazy_run ? b.d_w_spare : b.d_w;
+    // The run ends in the buffer it began in (a handle's weights do not move between runs: one captured graph per shape, not two that
+    // alternate): T - 1 steps have a weighting phase; when that number is odd, step 0 keeps the stored form and weights in place.
+    const int64_t k_pp0 = (lazy_run && ((T - 1) & 1)) ? 1 : 0;
     static const char* abl_env = getenv("LLPF_ABLATE");
     static const char* dbg_env = getenv("LLPF_DEBUG_TIMING");
 
@@ -179,10 +182,10 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
         b.n_predict = np0 + (uint32_t)k;
         b.t_index = ti0 + k;
         // weights in front of step k: every step before it had a weighting phase that wrote the other buffer (the run's last step has none)
-        const int64_t wsw = std::min<int64_t>(k, T - 1 > 0 ? T - 1 : 0);
+        const int64_t wsw = std::max<int64_t>(0, std::min<int64_t>(k, T - 1 > 0 ? T - 1 : 0) - k_pp0);
         b.d_w = (wsw & 1) ? wbuf1 : wbuf0;
         if (lazy_run) b.d_w_spare = (wsw & 1) ? wbuf0 : wbuf1;
-        b.w_pingpong = lazy_run;
+        b.w_pingpong = lazy_run && k >= k_pp0;
     };
     auto head_slot = [&](int64_t k) { return (par0 + (int)(k % ACC_NSLOT)) % ACC_NSLOT; };
 
@@ -240,7 +243,7 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
         StepArgs st = step_args(k);
         const bool weight = (k + 1 < T);
         // (lazy_run, above; the exact redo of a failed bound test keeps the stored form — and the two weight buffers)
-        const bool lazy_q = fast && lazy_run;
+        const bool lazy_q = fast && lazy_run && k >= k_pp0;
         if (fast && !merged) {   // split schedule: the sums of the current weights in bound form, as a streaming launch
             ProfScope ps(b, LLPF_PROF_NORMALISE);
             HIPC(launch_norm(d, ra.parity, want_xm, ne2, rel_step(b), 0, lazy_q ? 3 : 1, k, b.stream));
