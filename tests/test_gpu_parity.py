@@ -856,6 +856,32 @@ def test_split_schedule_forms_its_quanta_in_the_fused_kernel(thr, monkeypatch):
         assert np.array_equal(lls["1"].view(np.uint64), lls["0"].view(np.uint64))
 
 
+def test_split_schedule_runs_repeat_themselves_beyond_the_resident_set():
+    """The split schedule without stored quanta reads, in a resampling step, weights that the same launch replaces (two weight buffers
+    keep the two apart).  Its first version had ONE buffer and raced — invisibly while every block of a launch was resident (all tests
+    up to 4e6 particles passed), with three different log-likelihoods in three runs at 1.6e7.  Here: the same run four times, on fresh
+    handles and on one handle, at 1.6e7 and 4.2e6 particles (15 625 and 4 102 tiles against ~1 500 resident blocks), every output
+    hashed (tools/dbg/lazy_repeat.py is the longer form)."""
+    import hashlib
+    model = M.lg_test_model(0.1)
+    for N, T, thr in ((16_000_000, 10, 0.5), (4_200_000, 24, 0.3)):
+        _, U, Y = M.simulate_lg(model, T)
+        cfg = _cfg(model, N, thr=thr, seed=4242)
+        one = _capi.FilterHandle(cfg)
+        digests = set()
+        for rep in range(4):
+            h = _capi.FilterHandle(cfg) if rep % 2 == 0 else one
+            h.seed(4242)
+            h.reset()
+            r = h.run(U, Y, 1.0, ll_steps=True)
+            m = hashlib.sha256()
+            for a in (r["ll_steps"], h.particles(), h.weights(), h.ancestors()):
+                m.update(np.ascontiguousarray(a).tobytes())
+            digests.add(m.hexdigest())
+        assert len(digests) == 1, (N, len(digests))
+        assert one.resample_count() >= 1
+
+
 @pytest.mark.parametrize("schedule", ["merged", "split"])
 def test_launches_larger_than_the_resident_set(schedule, monkeypatch):
     """More workgroups than the chip holds at once (~1000-2000): blocks of a launch that start after other blocks of
