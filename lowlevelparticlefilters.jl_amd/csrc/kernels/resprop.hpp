@@ -423,9 +423,10 @@ _Pragma("unroll") \
     // loop was bound by neither issue nor bandwidth but by the number of memory instructions in flight: cut to a third of its vector
     // instructions (the tile-loop experiment, EXPERIMENTS 6.12) it took the same time, 4.9 TB/s.  Per-output arithmetic and counters
     // untouched (PropCtx::one_x with STP = -1 returns what it would have stored).  (The same pairing for the steps that DO resample — adjacent
-    // outputs, 16-byte stores of both states, weights and ancestors — is 7.6 % slower than two rounds a block apart: adjacent outputs gather
-    // from the same or neighbouring sources, and the wave's requests cover half as many lines; both pairs of a thread requested before the
-    // first is computed: no better, 169.2 / 170.0 us on the C4 share; profiles/r06_paired_outputs_ab.txt.)
+    // outputs, 16-byte stores of both states, weights and ancestors — is 7.6 % slower than two rounds a block apart, and so is that loop with
+    // only its STORES paired (neighbouring lanes exchange halves through quad_perm, the gathers keep their spread): 9 % slower — 16-byte
+    // plain stores beside a gather cost more than twice as many 8-byte ones.  Both pairs of a thread requested before the first is computed:
+    // no better, 169.2 / 170.0 us on the C4 share.  profiles/r06_paired_outputs_ab.txt.)
 #define LLPF_OUTPUT_LOOP_ID2 \
 _Pragma("unroll 1") \
     for (uint32_t o2 = (uint32_t)first + 2u * threadIdx.x; o2 < ulast; o2 += 2u * BLOCK) { \
