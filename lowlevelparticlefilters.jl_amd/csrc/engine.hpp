@@ -251,6 +251,8 @@ struct ResArgs {
     int64_t row;           // row of ll_steps / xmean this finalize writes
     int32_t count_surv;    // k_resample: add the number of distinct ancestors to BankDev::surv (models that could take the source-side form)
     int32_t ablate;        // developer aid (LLPF_ABLATE): bit0 skip RNG, bit1 skip owner search, bit2 skip model math; results invalid
+    int32_t nt_id;         // k_resprop (split schedule): the steps that do not resample read and store nontemporal — set by the host for working sets well
+                           // beyond the Infinity Cache (host/run.hpp: below ~7 M particles plain accesses are up to 11 % faster, above nontemporal ones)
     int32_t lazy_q;        // k_resprop (split schedule): the k_norm in front of it stored no quanta — BankDev::quanta points at the WEIGHTS and the scan
                            // forms the tile's quanta itself, floor(exp(w - offset) 2^K): the same function of the same numbers (host/run.hpp)
     uint64_t* dbg;         // optional [P2][8] phase timestamps of one launch (s_memrealtime, 100 MHz), or nullptr

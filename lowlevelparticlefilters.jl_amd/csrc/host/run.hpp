@@ -155,6 +155,7 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
     // source, which is why a filter that resamples at every step keeps the stored form.  The scan then reads weights that other blocks
     // of the same launch are replacing with the next ones: such a run alternates between two weight buffers (BankDev::w / w_next; the
     // second is allocated here on first use and starts as a copy, so that its padding holds -Inf too).  LLPF_LAZY_Q=0: stored form.
+    const char* nt_env = getenv("LLPF_NT_ID");
     const char* lazy_s = getenv("LLPF_LAZY_Q");
     const bool lazy_run = !merged && !unfused && !no_bound && b.cfg.resample_threshold < 1.0 && !(lazy_s && atoi(lazy_s) == 0);
     if (lazy_run && !b.d_w_spare) {
@@ -249,6 +250,7 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
             HIPC(launch_norm(d, ra.parity, want_xm, ne2, rel_step(b), 0, lazy_q ? 3 : 1, k, b.stream));
         }
         ra.lazy_q = lazy_q ? 1 : 0;
+        ra.nt_id = nt_env ? (atoi(nt_env) != 0 ? 1 : 0) : (((int64_t)b.F * b.Ns >= ((int64_t)7 << 20)) ? 1 : 0);      // nontemporal accesses on the steps that do not resample: working sets well beyond the Infinity Cache (LLPF_NT_ID=0|1 pins it)
         if (!fast) {
             ProfScope ps(b, LLPF_PROF_NORMALISE);
             HIPC(launch_norm(d, ra.parity, want_xm, 1, rel_step(b), only_fb, 0, k, b.stream));
@@ -331,7 +333,7 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
     if (use_graph) {
         Bank::RunGraph key{};
         key.T = T; key.t_index0 = t_index0; key.par0 = par0; key.cur0 = cur0; key.qcur0 = qcur0;
-        key.flags = (merged ? 1 : 0) | (unfused ? 2 : 0) | (want_xm ? 4 : 0) | (ll_steps ? 8 : 0) | (xm_launch ? 16 : 0) | (multi ? 32 : 0) | (source_fx ? 64 : 0) | (xcov ? 128 : 0) | (xquant ? 256 : 0) | ((abl_env ? atoi(abl_env) : 0) << 9) | (lazy_run ? (1 << 30) : 0);      // (no_bound is a property of the model id, which a handle keeps)
+        key.flags = (merged ? 1 : 0) | (unfused ? 2 : 0) | (want_xm ? 4 : 0) | (ll_steps ? 8 : 0) | (xm_launch ? 16 : 0) | (multi ? 32 : 0) | (source_fx ? 64 : 0) | (xcov ? 128 : 0) | (xquant ? 256 : 0) | ((abl_env ? atoi(abl_env) : 0) << 9) | (lazy_run ? (1 << 30) : 0) | ((nt_env && atoi(nt_env) != 0) ? (1 << 29) : 0) | ((nt_env && atoi(nt_env) == 0) ? (1 << 28) : 0);      // (no_bound is a property of the model id, which a handle keeps)
         key.np_parity = (int)(np0 & 1u);
         key.dU = b.d_U; key.dY = b.d_Y; key.dll = ll_steps ? b.d_ll_steps : nullptr; key.dxm = xmean ? b.d_xmean : nullptr; key.dxc = xcov ? b.d_xcov : nullptr; key.drb = b.d_rbseq;
         key.dw = wbuf0; key.dws = wbuf1;

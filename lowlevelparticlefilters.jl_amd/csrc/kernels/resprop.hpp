@@ -422,12 +422,14 @@ _Pragma("unroll") \
     // is read and written 16 bytes per lane — three loads and three stores per pair instead of six and six.  With 8-byte accesses this
     // loop was bound by neither issue nor bandwidth but by the number of memory instructions in flight: cut to a third of its vector
     // instructions (the tile-loop experiment, EXPERIMENTS 6.12) it took the same time, 4.9 TB/s.  Per-output arithmetic and counters
-    // untouched (PropCtx::one_x with STP = -1 returns what it would have stored).  (The same pairing for the steps that DO resample — adjacent
+    // untouched (PropCtx::one_x with STP = -1 returns what it would have stored).  The nontemporal forms of both (LLPF_RESPROP_LD_ID, _ST_ID) are
+    // taken when the host says so (ResArgs::nt_id): from ~7 M particles on; a working set the size of the Infinity Cache prefers plain accesses
+    // (N = 3.3e6 / 4e6 at threshold 0.1: 47.0 / 55.1 us plain, 52.6 / 62.1 nontemporal; 8e6: 109.0 / 108.0; 1.6e7: 209.3 / 202.4).  (The same pairing for the steps that DO resample — adjacent
     // outputs, 16-byte stores of both states, weights and ancestors — is 7.6 % slower than two rounds a block apart, and so is that loop with
     // only its STORES paired (neighbouring lanes exchange halves through quad_perm, the gathers keep their spread): 9 % slower — 16-byte
     // plain stores beside a gather cost more than twice as many 8-byte ones.  Both pairs of a thread requested before the first is computed:
     // no better, 169.2 / 170.0 us on the C4 share.  profiles/r06_paired_outputs_ab.txt.)
-#define LLPF_OUTPUT_LOOP_ID2 \
+#define LLPF_OUTPUT_LOOP_ID2(LDNT, STNT) \
 _Pragma("unroll 1") \
     for (uint32_t o2 = (uint32_t)first + 2u * threadIdx.x; o2 < ulast; o2 += 2u * BLOCK) { \
         typedef double __attribute__((ext_vector_type(2))) d2_t; \
@@ -435,7 +437,7 @@ _Pragma("unroll 1") \
 _Pragma("unroll") \
         for (int d = 0; d < NX; ++d) { \
             const d2_t* src_ = reinterpret_cast<const d2_t*>(reinterpret_cast<const char*>(pc.xc + (size_t)d * Ns) + (o2 << 3)); \
-            xv[d] = LLPF_RESPROP_LD_ID ? __builtin_nontemporal_load(src_) : *src_; \
+            xv[d] = (LDNT) ? __builtin_nontemporal_load(src_) : *src_; \
         } \
         if (WEIGHT) wv2 = *reinterpret_cast<const d2_t*>(reinterpret_cast<const char*>(pc.w) + (o2 << 3)); \
         double xp0[NX], xp1[NX], xs0[NX], xs1[NX]; \
@@ -450,17 +452,17 @@ _Pragma("unroll") \
         for (int d = 0; d < NX; ++d) { \
             d2_t v_; v_.x = xs0[d]; v_.y = xs1[d]; \
             d2_t* dst_ = reinterpret_cast<d2_t*>(reinterpret_cast<char*>(pc.xn + (size_t)d * Ns) + (o2 << 3)); \
-            if (LLPF_RESPROP_ST_ID == 2) __builtin_nontemporal_store(v_, dst_); else *dst_ = v_; \
+            if (STNT) __builtin_nontemporal_store(v_, dst_); else *dst_ = v_; \
         } \
         if (WEIGHT) { \
             d2_t v_; v_.x = w0; v_.y = w1; \
             d2_t* dst_ = reinterpret_cast<d2_t*>(reinterpret_cast<char*>(pc.wn) + (o2 << 3)); \
-            if (LLPF_RESPROP_ST_ID == 2) __builtin_nontemporal_store(v_, dst_); else *dst_ = v_; \
+            if (STNT) __builtin_nontemporal_store(v_, dst_); else *dst_ = v_; \
         } \
     }
     constexpr bool PREFETCH = LLPF_RESPROP_PF > 1 && !(WEIGHT && ACC) && !Model::RB && !AUX;
     if constexpr (WEIGHT && ACC && !Model::RB) { LLPF_OUTPUT_LOOP(res, false) }
-    else if constexpr (PREFETCH) { if (res) { LLPF_OUTPUT_LOOP_PF(true) } else if (LLPF_RESPROP_ID2) { LLPF_OUTPUT_LOOP_ID2 } else { LLPF_OUTPUT_LOOP_PF(false) } }
+    else if constexpr (PREFETCH) { if (res) { LLPF_OUTPUT_LOOP_PF(true) } else if (LLPF_RESPROP_ID2) { if (a.nt_id) { LLPF_OUTPUT_LOOP_ID2(LLPF_RESPROP_LD_ID != 0, LLPF_RESPROP_ST_ID == 2) } else { LLPF_OUTPUT_LOOP_ID2(false, false) } } else { LLPF_OUTPUT_LOOP_PF(false) } }
     else if (res) { LLPF_OUTPUT_LOOP(true, false) }
     else { LLPF_OUTPUT_LOOP(false, (LLPF_RESPROP_LD_ID != 0)) }
 #undef LLPF_OUTPUT_LOOP

@@ -823,7 +823,7 @@ def test_split_schedule_forms_its_quanta_in_the_fused_kernel(thr, monkeypatch):
     the device-order oracle, bit for bit: the run, the state after it, a second predict! straight after the run (the consumer of
     the stored quanta: resample without a correct! in between), more single steps, and a second run; for one-tile filters (the
     redo of a failed bound test inside k_norm), ragged sizes and several tiles, with an outlier that makes a bound test fail; and
-    the stored form (LLPF_LAZY_Q=0) gives the same bits."""
+    the stored form (LLPF_LAZY_Q=0) gives the same bits, as do the nontemporal and the plain form of the 16-byte loop (LLPF_NT_ID)."""
     monkeypatch.setenv("LLPF_SCHEDULE", "split")
     model = M.lg_test_model(0.1)
     _, U, Y = M.simulate_lg(model, 40)
@@ -833,6 +833,7 @@ def test_split_schedule_forms_its_quanta_in_the_fused_kernel(thr, monkeypatch):
         lls = {}
         for lazy in ("1", "0"):
             monkeypatch.setenv("LLPF_LAZY_Q", lazy)
+            monkeypatch.setenv("LLPF_NT_ID", lazy)       # the nontemporal form of the steps that do not resample (default: from 7 M particles on) / the plain form
             g = _capi.FilterHandle(cfg)
             o = ob.OracleFilter(cfg, ob.ORDER_DEVICE)
             g.reset(); o.reset()
