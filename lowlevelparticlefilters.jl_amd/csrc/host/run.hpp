@@ -145,7 +145,11 @@ static int bank_run(Bank& b, const double* U, const double* Y, int64_t T, double
     // its registers for the propagate and runs at higher occupancy: best when many filters saturate the SIMDs).
     // Measured on MI355X: C2 single filter 29.4 vs 30.2 us, bank 128 x 1e5: 4.3e10 vs 5.0e10 particle-steps/s.
     const char* sch_env = getenv("LLPF_SCHEDULE");       // "merged" | "split" override
-    const bool merged = (hist || (sch_env ? (strcmp(sch_env, "merged") == 0) : ((int64_t)b.F * b.Ns <= ((int64_t)3 << 20))));
+    // (round 6: below threshold 1 the split schedule stores no quanta and moves 16 bytes per lane on the steps that do not resample — it
+    //  overtakes the merged one from ~1.3 M particles on: N = 1.5e6 / 2e6 / 3e6 at threshold 0.1 27.9 / 34.4 / 43.9 against 29.6 / 36.0 / 48.3 us;
+    //  at threshold 1.0 the two stay within 4 % of each other up to 3 M, profiles/r06_schedule_crossover_ab.txt)
+    const int64_t merged_max = (b.cfg.resample_threshold < 1.0) ? ((int64_t)5 << 18) : ((int64_t)3 << 20);
+    const bool merged = (hist || (sch_env ? (strcmp(sch_env, "merged") == 0) : ((int64_t)b.F * b.Ns <= merged_max)));
     // (a model without a bound: the weighting launches form no sums at all — a step without a measurement would otherwise leave real ones
     // in the slot, against the finite bound max(w), and the exact-form k_norm in front of the next head would add to them)
     const bool acc_in_weighting = merged && !no_bound;
